@@ -1,0 +1,169 @@
+/*
+ * oracle/ora.h -- TEST INFRASTRUCTURE ONLY (CPU oracle for the WAMINTGR hot path).
+ *
+ * PARITY UNPINNED: the reference (ecmwf-ifs/ecwam 1.5.13) holds no golden vector or
+ * known-answer test for IMPLSCH / PROPAGS2 (its only checks are whole-model swh norms that
+ * need ETOPO1 + GRIB forcing downloads), and the reference Fortran cannot be built in this
+ * image without stand-ins for fiat (PARKIND1, YOMHOOK), generated *.intfb.h and the
+ * fypp-generated YOWDRVTYPE.  This file set is therefore a plain-C restatement of the
+ * reference algorithm, routine by routine, each function citing the reference file:line
+ * it follows.  Nothing under ecwam_amd/ may include, link or call it.
+ *
+ * Built twice: -DORA_SINGLE (JWRB = float) and default (JWRB = double), mirroring the
+ * reference's sp/dp libraries (parkind_wave.F90:23-35).
+ *
+ * Array convention (C order, last index fastest):
+ *   spectra    FL[ij][k][m]        k = direction (0..NANG-1), m = frequency (0..NFRE-1)
+ *   per-freq   X[ij][m]
+ *   per-point  X[ij]
+ * The reference keeps IJ fastest (FL1(IJ,K,M)); no routine on the path couples grid
+ * points except through explicit neighbour tables, so the loop interchange is exact.
+ */
+#ifndef ORA_H
+#define ORA_H
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+#ifdef ORA_SINGLE
+typedef float real;
+#define SIN sinf
+#define COS cosf
+#define TANH tanhf
+#define SINH sinhf
+#define COSH coshf
+#define EXP expf
+#define LOG logf
+#define LOG10 log10f
+#define SQRT sqrtf
+#define ATAN2 atan2f
+#define ATAN atanf
+#define ACOS acosf
+#define POW powf
+#define FABS fabsf
+#define NINT(x) ((int)lroundf(x))
+#define FLOORI(x) ((int)floorf(x))
+#else
+typedef double real;
+#define SIN sin
+#define COS cos
+#define TANH tanh
+#define SINH sinh
+#define COSH cosh
+#define EXP exp
+#define LOG log
+#define LOG10 log10
+#define SQRT sqrt
+#define ATAN2 atan2
+#define ATAN atan
+#define ACOS acos
+#define POW pow
+#define FABS fabs
+#define NINT(x) ((int)lround(x))
+#define FLOORI(x) ((int)floor(x))
+#endif
+
+/* a Fortran literal 1.25_JWRB */
+#define C_(x) ((real)(x))
+#define RMAX(a, b) ((a) > (b) ? (a) : (b))
+#define RMIN(a, b) ((a) < (b) ? (a) : (b))
+#define SIGN(a, b) ((b) >= 0 ? FABS(a) : -FABS(a)) /* Fortran SIGN(A,B) */
+
+/* Fortran X**N with integer N: compilers expand it by binary powering (libgcc __powidf2 order) */
+static inline real powi(real x, int m) {
+  unsigned n = (unsigned)(m < 0 ? -m : m);
+  real y = (n % 2) ? x : (real)1;
+  while (n >>= 1) { x = x * x; if (n % 2) y *= x; }
+  return m < 0 ? (real)1 / y : y;
+}
+
+#define ORA_MAXANG 64
+#define ORA_MAXFRE 64
+#define ORA_MAXGC 128
+#define ORA_IAB 200      /* yowtabl.F90:25 */
+#define ORA_JTOT_TAUHF 19 /* yowcoup.F90:60 */
+
+/* run configuration = the namelist/flag subset the hot path reads */
+typedef struct {
+  int nang, nfre, nfre_red;
+  int ifre1;
+  double fr1;
+  int idelt;       /* source-term step [s]  (yowstat IDELT) */
+  int idelpro;     /* advection step [s]    (yowstat IDELPRO) */
+  double ximp;     /* implicitness (yowstat XIMP) */
+  int iphys;       /* 1 = Ardhuin */
+  int isnonlin;    /* 0 */
+  int irefra;      /* 0 */
+  int icode;       /* 3 = 10 m wind forcing */
+  int llgcbz0, llnormagam, llcapchnk;
+  int lbiwbk, licerun, lmaskice, lwamrsetci;
+  int lciwa1, lciwa2, lciwa3, lciscal;
+  int lwvflx_snl, lwflux, lwfluxout, lwnemocou, lwcou, lwcouast;
+  int lwnemocouwrs, lwnemocouibr, lwnemotauoc;
+  double wspmin;   /* set by ora_init from llgcbz0 unless > 0 */
+  double rnu, rnum; /* air viscosity (runwam.F90:232-233) */
+} ora_cfg;
+
+/* module-level state (YOWFRED, YOWPHYS, YOWINDN, YOWPCONS, YOWCOUP, YOWICE, YOWTABL, YOWUBUF selectors) */
+typedef struct {
+  ora_cfg c;
+  int NANG, NFRE, NFRE_RED, NFRE_ODD;
+  /* YOWPCONS (yowpcons.F90:19-66, iniwcst.F90:54-69) */
+  real G, GM1, PI, ZPI, ZPI4GM1, ZPI4GM2, RAD, DEG, R, CIRC;
+  real EPSMIN, ROWATER, ROWATERM1, ROAIR, SURFT, GAM_SURF, SQRTGOSURFT;
+  real EPSUS, EPSU10, ACD, BCD, ACDLIN, BCDLIN, CDMAX;
+  real TAUOCMIN, TAUOCMAX, PHIEPSMIN, PHIEPSMAX, WSEMEAN_MIN;
+  /* YOWFRED */
+  real FRATIO, WETAIL, FRTAIL, WP1TAIL, COEF4, FRIC, DELTH, FLOGSPRDM1;
+  real FR[ORA_MAXFRE], DFIM[ORA_MAXFRE], DFIMOFR[ORA_MAXFRE], DFIMFR[ORA_MAXFRE];
+  real DFIM_SIM[ORA_MAXFRE], RHOWG_DFIM[ORA_MAXFRE], ZPIFR[ORA_MAXFRE], FR5[ORA_MAXFRE];
+  real COFRM4[ORA_MAXFRE], FLMAX[ORA_MAXFRE];
+  real TH[ORA_MAXANG], COSTH[ORA_MAXANG], SINTH[ORA_MAXANG];
+  /* gravity-capillary tables (initgc.F90) */
+  int NWAV_GC;
+  real XLOGKRATIOM1_GC;
+  real XK_GC[ORA_MAXGC], XKM_GC[ORA_MAXGC], OMEGA_GC[ORA_MAXGC], OMXKM3_GC[ORA_MAXGC];
+  real VG_GC[ORA_MAXGC], C_GC[ORA_MAXGC], CM_GC[ORA_MAXGC], C2OSQRTVG_GC[ORA_MAXGC];
+  real XKMSQRTVGOC2_GC[ORA_MAXGC], OM3GMKM_GC[ORA_MAXGC], DELKCC_GC[ORA_MAXGC];
+  real DELKCC_GC_NS[ORA_MAXGC], DELKCC_OMXKM3_GC[ORA_MAXGC];
+  /* YOWPHYS (yowphys.F90, setwavphys.F90, init_x0tauhf.F90) */
+  real XKAPPA, XNLEV, RNU, RNUM, BETAMAX, BETAMAXOXKAPPA2, BMAXOKAP, BMAXOKAPDTH, GAMNCONST;
+  real ZALP, ALPHA, ALPHAMIN, ALPHAMAX, CHNKMIN_U, TAUWSHELTER, ALPHAPMAX;
+  real DELTA_THETA_RN, RN1_RN, DTHRN_A, DTHRN_U, TAILFACTOR, TAILFACTOR_PM;
+  real ANG_GC_A, ANG_GC_B, ANG_GC_C;
+  real SWELLF, SWELLF2, SWELLF3, SWELLF4, SWELLF5, SWELLF6, SWELLF7, SWELLF7M1;
+  real Z0RAT, Z0TUBMAX, ABMIN, ABMAX;
+  real SDSBR, SSDSC2, SSDSC3, SSDSC4, SSDSC5, SSDSC6, MICHE;
+  int ISDSDTH, ISB, IPSAT, NSDSNTH;
+  int INDICESSAT[ORA_MAXANG][2 * ORA_MAXANG + 1]; /* 0-based direction index */
+  real SATWEIGHTS[ORA_MAXANG][2 * ORA_MAXANG + 1];
+  real EGRCRV, AFCRV, BFCRV;
+  /* YOWCOUP */
+  real X0TAUHF, WTAUHF[ORA_JTOT_TAUHF];
+  /* YOWTABL */
+  real EPS1, SWELLFT[ORA_IAB + 1]; /* 1-based like the reference */
+  /* YOWICE / YOWSHAL / YOWWIND */
+  real FLMIN, CITHRSH, CIBLOCK, CITHRSH_TAIL, CDICWA, ZALPFACX, ZALPWRS;
+  real GAM_B_J, BATHYMAX, WSPMIN, WSPMIN_RESET_TAUW;
+  /* YOWINDN (nlweigt.F90, inisnonlin.F90); MC index 1..MLSTHG stored at [mc-1] */
+  int MFRSTLW, MLSTHG, KFRH;
+  int IKP[ORA_MAXFRE + 16], IKP1[ORA_MAXFRE + 16], IKM[ORA_MAXFRE + 16], IKM1[ORA_MAXFRE + 16];
+  real FKLAP[ORA_MAXFRE + 16], FKLAP1[ORA_MAXFRE + 16], FKLAM[ORA_MAXFRE + 16], FKLAM1[ORA_MAXFRE + 16];
+  real AF11[ORA_MAXFRE + 16];
+  int K1W[ORA_MAXANG][2], K2W[ORA_MAXANG][2], K11W[ORA_MAXANG][2], K21W[ORA_MAXANG][2]; /* 1-based values */
+  real ACL1, ACL2, CL11, CL21, DAL1, DAL2;
+  int INLCOEF[ORA_MAXFRE + 16][5];  /* 1-based frequency indices as in the reference */
+  real RNLCOEF[ORA_MAXFRE + 16][25];
+  /* CTU selectors (ctuwupdt.F90:97-161); values 1-based like the reference */
+  int KPM[ORA_MAXANG][3], JXO[ORA_MAXANG][2], JYO[ORA_MAXANG][2], KCR[ORA_MAXANG][4];
+} ora_state;
+
+extern ora_state S;
+
+void ora_default_cfg(ora_cfg *c);
+int ora_init(const ora_cfg *c);
+int ora_real_size(void);
+
+#endif

@@ -1,0 +1,174 @@
+"""ctypes wrapper of the CPU oracle (oracle/*.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(the product package ecwam_amd never does).  "Parity unpinned": see oracle/ora.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class OraCfg(C.Structure):
+    _fields_ = [
+        ("nang", C.c_int), ("nfre", C.c_int), ("nfre_red", C.c_int), ("ifre1", C.c_int), ("fr1", C.c_double),
+        ("idelt", C.c_int), ("idelpro", C.c_int), ("ximp", C.c_double),
+        ("iphys", C.c_int), ("isnonlin", C.c_int), ("irefra", C.c_int), ("icode", C.c_int),
+        ("llgcbz0", C.c_int), ("llnormagam", C.c_int), ("llcapchnk", C.c_int),
+        ("lbiwbk", C.c_int), ("licerun", C.c_int), ("lmaskice", C.c_int), ("lwamrsetci", C.c_int),
+        ("lciwa1", C.c_int), ("lciwa2", C.c_int), ("lciwa3", C.c_int), ("lciscal", C.c_int),
+        ("lwvflx_snl", C.c_int), ("lwflux", C.c_int), ("lwfluxout", C.c_int), ("lwnemocou", C.c_int),
+        ("lwcou", C.c_int), ("lwcouast", C.c_int),
+        ("lwnemocouwrs", C.c_int), ("lwnemocouibr", C.c_int), ("lwnemotauoc", C.c_int),
+        ("wspmin", C.c_double), ("rnu", C.c_double), ("rnum", C.c_double),
+    ]
+
+
+def build(force: bool = False) -> None:
+    need = force or not all(os.path.exists(os.path.join(_HERE, f)) for f in ("libora_sp.so", "libora_dp.so"))
+    if not need:
+        src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in os.listdir(_HERE) if f.endswith((".c", ".h")))
+        so_m = min(os.path.getmtime(os.path.join(_HERE, f)) for f in ("libora_sp.so", "libora_dp.so"))
+        need = src_m > so_m
+    if need:
+        subprocess.run(["make", "-C", _HERE, "-s", "-B"], check=True)
+
+
+class Oracle:
+    """One initialised oracle instance (module state lives inside the shared object, like the
+    Fortran modules it restates: one configuration per loaded library)."""
+
+    def __init__(self, cfg, precision: str = "dp"):
+        build()
+        self.precision = precision
+        self.dtype = np.float32 if precision == "sp" else np.float64
+        # a private copy per instance so that sp/dp and several configs can coexist in one process
+        path = os.path.join(_HERE, f"libora_{precision}.so")
+        self._fresh_copy(path)
+        assert self.lib.ora_real_size() == np.dtype(self.dtype).itemsize
+        oc = OraCfg()
+        self.lib.ora_default_cfg(C.byref(oc))
+        for name, _ in OraCfg._fields_:
+            if hasattr(cfg, name):
+                setattr(oc, name, type(getattr(oc, name))(getattr(cfg, name)))
+        rc = self.lib.ora_init(C.byref(oc))
+        if rc:
+            raise RuntimeError(f"ora_init failed rc={rc}")
+        self.cfg = cfg
+        self.NANG, self.NFRE = cfg.nang, cfg.nfre
+        self.NFRE_RED = cfg.nfre_red if cfg.nfre_red > 0 else cfg.nfre
+        self.lib.ora_get.restype = C.c_int
+
+    def _fresh_copy(self, path: str) -> None:
+        import shutil
+        import tempfile
+
+        tmp = tempfile.NamedTemporaryFile(prefix="libora_", suffix=".so", delete=False)
+        tmp.close()
+        shutil.copy(path, tmp.name)
+        self.lib = C.CDLL(tmp.name, mode=os.RTLD_LOCAL)
+        os.unlink(tmp.name)
+
+    # -- helpers
+    def _p(self, a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    def get(self, name: str) -> np.ndarray:
+        buf = np.zeros(8192, dtype=np.float64)
+        n = self.lib.ora_get(name.encode(), self._p(buf), C.c_int(buf.size))
+        if n < 0:
+            raise KeyError(name)
+        return buf[:n].copy()
+
+    def depthprpt(self, depth: np.ndarray) -> dict:
+        n = depth.size
+        d = np.ascontiguousarray(depth, dtype=self.dtype)
+        out = {k: np.zeros((n, self.NFRE), dtype=self.dtype) for k in ("WAVNUM", "CINV", "CGROUP", "XK2CG", "OMOSNH2KD", "STOKFAC")}
+        out["EMAXDPT"] = np.zeros(n, dtype=self.dtype)
+        self.lib.ora_depthprpt(C.c_int(n), self._p(d), self._p(out["WAVNUM"]), self._p(out["CINV"]), self._p(out["CGROUP"]),
+                               self._p(out["XK2CG"]), self._p(out["OMOSNH2KD"]), self._p(out["STOKFAC"]), self._p(out["EMAXDPT"]))
+        return out
+
+    def implsch(self, fl1, wavnum, cgroup, cinv, xk2cg, stokfac, env, ff, intf, want_dbg=False):
+        """All arrays are copied; returns dict(FL1, XLLWS, MIJ, FF, INTF[, DBG])."""
+        n = fl1.shape[0]
+        T = self.dtype
+        fl1 = np.array(fl1, dtype=T, order="C")
+        ff = np.array(ff, dtype=T, order="C")
+        intf = np.array(intf, dtype=T, order="C")
+        xllws = np.zeros_like(fl1)
+        mij = np.zeros(n, dtype=np.int32)
+        dbg = np.zeros((n, 8), dtype=T) if want_dbg else None
+        a = [np.ascontiguousarray(x, dtype=T) for x in (wavnum, cgroup, cinv, xk2cg, stokfac, env)]
+        rc = self.lib.ora_implsch(C.c_int(n), self._p(fl1), *(self._p(x) for x in a[:5]), self._p(a[5]), self._p(ff),
+                                  self._p(intf), self._p(mij), self._p(xllws), self._p(dbg) if want_dbg else None)
+        if rc:
+            raise RuntimeError(f"ora_implsch abort branch rc={rc}")
+        out = dict(FL1=fl1, XLLWS=xllws, MIJ=mij, FF=ff, INTF=intf)
+        if want_dbg:
+            out["DBG"] = dbg
+        return out
+
+    def newwind(self, ff, ffn):
+        ff = np.array(ff, dtype=self.dtype, order="C")
+        ffn = np.ascontiguousarray(ffn, dtype=self.dtype)
+        self.lib.ora_newwind(C.c_int(ff.shape[0]), self._p(ff), self._p(ffn))
+        return ff
+
+    def ctu_weights(self, grid, cgroup_ext, delpro, mstart=1, mend=None):
+        """CTUWINI + CTUW for all owned points of `grid` (a ecwam_amd.grid.Grid-like object).
+        cgroup_ext: [(npts+1)][NFRE] incl. land row.  Returns dict of reference-shaped weight arrays and
+        the (mutated) WLAT/WCOR."""
+        T = self.dtype
+        n, nland = grid.nsea, grid.nland
+        NANG, NR = self.NANG, self.NFRE_RED
+        mend = NR if mend is None else mend
+        kxlt = np.ascontiguousarray(grid.kxlt, dtype=np.int32)
+        klon = np.ascontiguousarray(grid.klon, dtype=np.int32)
+        klat = np.ascontiguousarray(grid.klat, dtype=np.int32)
+        kcor = np.ascontiguousarray(grid.kcor, dtype=np.int32)
+        wlat = np.array(grid.wlat, dtype=T, order="C")
+        wcor = np.array(grid.wcor, dtype=T, order="C")
+        cosph = np.ascontiguousarray(grid.cosph, dtype=T)
+        sinph = np.ascontiguousarray(grid.sinph, dtype=T)
+        zdello = np.ascontiguousarray(grid.zdello, dtype=T)
+        cosphm1 = np.ascontiguousarray(grid.cosphm1_ext, dtype=T)
+        cg = np.ascontiguousarray(cgroup_ext, dtype=T)
+        wlatm1 = np.zeros((n, 2), T)
+        wcorm1 = np.zeros((n, 4), T)
+        dp = np.zeros((n, 2), T)
+        self.lib.ora_ctuwini(C.c_int(n), C.c_int(nland), C.c_int(grid.ngy), self._p(kxlt), self._p(cosph), self._p(cosphm1),
+                             self._p(klat), self._p(kcor), self._p(wlat), self._p(wcor), self._p(wlatm1), self._p(wcorm1), self._p(dp))
+        sumwn = np.zeros((n, NANG, NR), T)
+        wlonn = np.zeros((n, NANG, NR, 2), T)
+        wlatn = np.zeros((n, NANG, NR, 2, 2), T)
+        wcorn = np.zeros((n, NANG, NR, 4, 2), T)
+        wkpmn = np.zeros((n, NANG, NR, 3), T)
+        fail = np.zeros(n, np.int32)
+        creal = C.c_float if T == np.float32 else C.c_double
+        self.lib.ora_ctuw.restype = C.c_int
+        nfail = self.lib.ora_ctuw(C.c_int(n), C.c_int(nland), creal(delpro), C.c_int(mstart), C.c_int(mend), self._p(kxlt),
+                                  self._p(zdello), creal(grid.xdella), self._p(cosph), self._p(sinph), self._p(klon), self._p(klat),
+                                  self._p(wlat), self._p(wcor), self._p(wlatm1), self._p(wcorm1), self._p(dp), self._p(cg),
+                                  self._p(cosphm1), self._p(sumwn), self._p(wlonn), self._p(wlatn), self._p(wcorn), self._p(wkpmn),
+                                  self._p(fail))
+        return dict(SUMWN=sumwn, WLONN=wlonn, WLATN=wlatn, WCORN=wcorn, WKPMN=wkpmn, WLAT=wlat, WCOR=wcor, NFAIL=nfail, FAIL=fail)
+
+    def propags2(self, grid, f1, w, nd3s=1, nd3e=None):
+        """f1: [(npts+1)][NANG][NFRE] (land row zero). Returns F3 with the same shape (rows >= nsea untouched = 0)."""
+        T = self.dtype
+        nd3e = self.NFRE_RED if nd3e is None else nd3e
+        f1 = np.ascontiguousarray(f1, dtype=T)
+        f3 = np.zeros_like(f1)
+        klon = np.ascontiguousarray(grid.klon, dtype=np.int32)
+        klat = np.ascontiguousarray(grid.klat, dtype=np.int32)
+        kcor = np.ascontiguousarray(grid.kcor, dtype=np.int32)
+        self.lib.ora_propags2(C.c_int(0), C.c_int(grid.nsea), self._p(f1), self._p(f3), self._p(klon), self._p(klat), self._p(kcor),
+                              self._p(w["SUMWN"]), self._p(w["WLONN"]), self._p(w["WLATN"]), self._p(w["WCORN"]), self._p(w["WKPMN"]),
+                              C.c_int(nd3s), C.c_int(nd3e))
+        return f3

@@ -1,0 +1,179 @@
+"""Host-side mirror of the reference's hot-path interfaces over the C ABI.
+
+`HipContext` owns one `ecwam_hip_ctx`; its methods carry the reference routine names
+(PROPAGS2, CTUW, IMPLSCH, NEWWIND) and take torch CUDA tensors purely as device-memory handles
+(`data_ptr()` + the current HIP stream).  Shapes, dtypes and index ranges are validated on the host
+before any launch, so that a wrong operand cannot reach a kernel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .tables import Tables
+
+NFF, NINTF, NWPR = 16, 16, 5
+
+
+class EcwamHipError(RuntimeError):
+    pass
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class HipContext:
+    def __init__(self, tables: Tables, device: int = 0):
+        self.lib = _lib.load()
+        self.t = tables
+        self.dtype = torch.float32 if tables.dtype == np.float32 else torch.float64
+        self.real_bytes = 4 if tables.dtype == np.float32 else 8
+        self.NANG, self.NFRE, self.NR = tables.cfg.nang, tables.cfg.nfre, tables.cfg.nfre_red
+        self.N = self.NANG * self.NFRE
+        self.device = torch.device("cuda", device)
+        params = _lib.make_params(tables)
+        tp, keep = _lib.make_tables(tables)
+        self._h = C.c_void_p()
+        rc = self.lib.ecwam_hip_create(C.byref(params), C.byref(tp), self.real_bytes, device, C.byref(self._h))
+        del keep
+        self._chk(rc)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.ecwam_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int) -> None:
+        if rc != 0:
+            raise EcwamHipError(self.lib.ecwam_hip_last_error().decode())
+
+    # -- validation helpers
+    def _real(self, t: torch.Tensor, shape, name: str) -> int:
+        if not (t.is_cuda and t.dtype == self.dtype and t.is_contiguous() and tuple(t.shape) == tuple(shape)):
+            raise ValueError(f"{name}: expected contiguous {self.dtype} cuda tensor of shape {tuple(shape)}, got "
+                             f"{t.dtype} {tuple(t.shape)} cuda={t.is_cuda} contiguous={t.is_contiguous()}")
+        return t.data_ptr()
+
+    @staticmethod
+    def _int(t: torch.Tensor, shape, name: str) -> int:
+        if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and tuple(t.shape) == tuple(shape)):
+            raise ValueError(f"{name}: expected contiguous int32 cuda tensor of shape {tuple(shape)}, got {t.dtype} {tuple(t.shape)}")
+        return t.data_ptr()
+
+    # -- PROPAGS2(F1,F3,NINF,NSUP,KIJS,KIJL,NANG,ND3SF1,ND3EF1,ND3S,ND3E)  (propags2.F90:10)
+    def propags2(self, f1, f3, klon, klat, kcor, w, kijs, kijl, nd3s=1, nd3e=None, copy_rest=True, check_indices=False):
+        nd3e = self.NR if nd3e is None else nd3e
+        nrow = f1.shape[0]
+        n = klon.shape[0]
+        p1 = self._real(f1, (nrow, self.NANG, self.NFRE), "F1")
+        p3 = self._real(f3, (nrow, self.NANG, self.NFRE), "F3")
+        if not (0 <= kijs <= kijl <= n):
+            raise ValueError("PROPAGS2: KIJS/KIJL outside the neighbour tables")
+        pk = self._int(klon, (n, 2), "KLON"), self._int(klat, (n, 2, 2), "KLAT"), self._int(kcor, (n, 4, 2), "KCOR")
+        pw = self._real(w, (n, 8, self.NANG * self.NR), "W")
+        if check_indices:
+            for a, nm in ((klon, "KLON"), (klat, "KLAT"), (kcor, "KCOR")):
+                lo, hi = int(a.min()), int(a.max())
+                if lo < 0 or hi >= nrow:
+                    raise ValueError(f"PROPAGS2: {nm} index out of range [{lo},{hi}] for {nrow} spectra")
+        self._chk(self.lib.ecwam_hip_propags2(self._h, p1, p3, *pk, pw, kijs, kijl, nd3s, nd3e, int(copy_rest), _stream_ptr()))
+
+    # -- CTUWINI + CTUW (ctuwupdt.F90:204-238)
+    def ctuw(self, grid_dev: dict, cgroup_ext, w, cflfail, delpro: float, mstart=1, mend=None):
+        mend = self.NR if mend is None else mend
+        g = grid_dev
+        n, nland, ngy = g["n"], g["nland"], g["ngy"]
+        nrow = cgroup_ext.shape[0]
+        if nland >= nrow:
+            raise ValueError("CTUW: CGROUP_EXT must include the land row")
+        args = [self._int(g["kxlt"], (n,), "KXLT"), self._real(g["zdello"], (ngy,), "ZDELLO"), float(g["xdella"]),
+                self._real(g["cosph"], (ngy,), "COSPH"), self._real(g["sinph"], (ngy,), "SINPH"),
+                self._int(g["klon"], (n, 2), "KLON"), self._int(g["klat"], (n, 2, 2), "KLAT"), self._int(g["kcor"], (n, 4, 2), "KCOR"),
+                self._real(g["wlat"], (n, 2), "WLAT"), self._real(g["wcor"], (n, 4), "WCOR"),
+                self._real(cgroup_ext, (nrow, self.NFRE), "CGROUP_EXT"), self._real(g["cosphm1_ext"], (nrow,), "COSPHM1_EXT"),
+                self._real(w, (n, 8, self.NANG * self.NR), "W"), self._int(cflfail, (n,), "CFLFAIL")]
+        self._chk(self.lib.ecwam_hip_ctuw(self._h, n, nland, ngy, float(delpro), mstart, mend, *args, _stream_ptr()))
+
+    # -- IMPLSCH (implsch.F90:10-23)
+    def implsch(self, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, dbg=None):
+        nrow = fl1.shape[0]
+        if not (0 <= kijs <= kijl <= min(nrow, wvprpt.shape[0], ff.shape[0], intf.shape[0], mij.shape[0], xllws.shape[0])):
+            raise ValueError("IMPLSCH: KIJS/KIJL outside the operands")
+        a = [self._real(fl1, (nrow, self.NANG, self.NFRE), "FL1"), self._real(wvprpt, (wvprpt.shape[0], NWPR, self.NFRE), "WVPRPT"),
+             self._real(ff, (ff.shape[0], NFF), "FF"), self._real(intf, (intf.shape[0], NINTF), "INTF"),
+             self._int(mij, (mij.shape[0],), "MIJ"), self._real(xllws, (xllws.shape[0], self.NANG, self.NFRE), "XLLWS")]
+        pd = None if dbg is None else self._real(dbg, (nrow, 32), "DBG")
+        self._chk(self.lib.ecwam_hip_implsch(self._h, kijs, kijl, *a, pd, _stream_ptr()))
+
+    # -- NEWWIND (newwind.F90:126-161)
+    def newwind(self, ff, ff_next):
+        n = ff.shape[0]
+        self._chk(self.lib.ecwam_hip_newwind(self._h, n, self._real(ff, (n, NFF), "FF"), self._real(ff_next, (n, NFF), "FF_NEXT"),
+                                             _stream_ptr()))
+
+    # -- layout conversion (propag_wam.F90:124-137, 373-400)
+    def chunks_to_points(self, chunked, points, nproma, nchnk, npts, n2, n3):
+        pc = self._real(chunked, (nchnk, n3, n2, nproma), "chunked")
+        pp = self._real(points, (points.shape[0], n2, n3), "points")
+        if points.shape[0] < npts:
+            raise ValueError("points buffer too small")
+        self._chk(self.lib.ecwam_hip_chunks_to_points(self._h, pc, pp, nproma, nchnk, npts, n2, n3, _stream_ptr()))
+
+    def points_to_chunks(self, points, chunked, nproma, nchnk, npts, n2, n3):
+        pc = self._real(chunked, (nchnk, n3, n2, nproma), "chunked")
+        pp = self._real(points, (points.shape[0], n2, n3), "points")
+        if points.shape[0] < npts:
+            raise ValueError("points buffer too small")
+        self._chk(self.lib.ecwam_hip_points_to_chunks(self._h, pp, pc, nproma, nchnk, npts, n2, n3, _stream_ptr()))
+
+    # -- halo pack / unpack (mpexchng.F90:124-138, 217-231)
+    def pack_rows(self, fl, idx, buf):
+        n = idx.shape[0]
+        if n == 0:
+            return
+        self._chk(self.lib.ecwam_hip_pack_rows(self._h, self._real(fl, (fl.shape[0], self.NANG, self.NFRE), "FL"),
+                                               self._int(idx, (n,), "IDX"), n, self._real(buf, (n, self.NANG, self.NFRE), "BUF"),
+                                               _stream_ptr()))
+
+    def unpack_rows(self, buf, fl, dst0):
+        n = buf.shape[0]
+        if n == 0:
+            return
+        if dst0 < 0 or dst0 + n > fl.shape[0]:
+            raise ValueError("unpack_rows: destination range outside FL")
+        self._chk(self.lib.ecwam_hip_unpack_rows(self._h, self._real(buf, (n, self.NANG, self.NFRE), "BUF"), n,
+                                                 self._real(fl, (fl.shape[0], self.NANG, self.NFRE), "FL"), dst0, _stream_ptr()))
+
+
+def grid_to_device(grid, dtype, device, lo: int = 0, hi: int | None = None, local=None) -> dict:
+    """Upload the grid tables of points [lo,hi) (or a decomp.LocalDomain) as the dict `HipContext.ctuw` expects."""
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    if local is not None:
+        klon, klat, kcor, kxlt = local.klon, local.klat, local.kcor, local.kxlt
+        wlat, wcor = grid.wlat[local.lo:local.hi], grid.wcor[local.lo:local.hi]
+        n, nland, cosphm1 = local.n, local.nland, local.cosphm1_ext
+    else:
+        hi = grid.nsea if hi is None else hi
+        assert lo == 0 and hi == grid.nsea
+        klon, klat, kcor, kxlt = grid.klon, grid.klat, grid.kcor, grid.kxlt
+        wlat, wcor, n, nland, cosphm1 = grid.wlat, grid.wcor, grid.nsea, grid.nland, grid.cosphm1_ext
+
+    def ti(a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+
+    def tr(a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=npdt)).to(device)
+
+    return dict(n=n, nland=nland, ngy=grid.ngy, xdella=grid.xdella, kxlt=ti(kxlt), zdello=tr(grid.zdello), cosph=tr(grid.cosph),
+                sinph=tr(grid.sinph), klon=ti(klon), klat=ti(klat), kcor=ti(kcor), wlat=tr(wlat), wcor=tr(wcor),
+                cosphm1_ext=tr(cosphm1))

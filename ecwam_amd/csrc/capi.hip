@@ -1,0 +1,245 @@
+// C ABI of libecwam_hip.so (include/ecwam_hip.h): context management and kernel launch entry points.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dev.h"
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) {
+  g_err = m;
+  return 1;
+}
+#define HIPCHK(x)                                                                        \
+  do {                                                                                   \
+    hipError_t e_ = (x);                                                                 \
+    if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+
+struct ecwam_hip_ctx {
+  int real_bytes;
+  int device;
+  int NANG, NFRE, NFRE_RED;
+  void* dtab;  // DevTab<T> in device memory
+  ecwam_hip_params p;
+};
+
+// launchers implemented in propag.hip / implsch.hip
+template <typename T> void launch_propags2(const void*, const void*, void*, const int*, const int*, const int*, const void*, int, int, int, int, int, int, hipStream_t);
+template <typename T> void launch_ctuw(const void*, int, int, int, double, int, int, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, void*, void*, const void*, const void*, void*, int*, int, hipStream_t);
+template <typename T> void launch_newwind(const void*, int, void*, const void*, hipStream_t);
+template <typename T> void launch_c2p(const void*, void*, int, int, int, int, int, hipStream_t);
+template <typename T> void launch_p2c(const void*, void*, int, int, int, int, int, hipStream_t);
+template <typename T> void launch_pack(const void*, const int*, int, int, void*, hipStream_t);
+template <typename T> int launch_implsch(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, int, int, int, hipStream_t);
+
+template <typename T>
+static void cpv(T* dst, const void* src, int n) {
+  if (src) for (int i = 0; i < n; i++) dst[i] = ((const T*)src)[i];
+}
+
+template <typename T>
+static int build_tab(const ecwam_hip_params* p, const ecwam_hip_tables* t, DevTab<T>* d) {
+  memset(d, 0, sizeof(*d));
+  const int NANG = p->nang, NFRE = p->nfre, ML = p->mlsthg;
+  d->NANG = NANG; d->NFRE = NFRE; d->NFRE_RED = p->nfre_red; d->NFRE_ODD = p->nfre_odd; d->IDELT = p->idelt;
+  d->LLGCBZ0 = p->llgcbz0; d->LLNORMAGAM = p->llnormagam; d->LLCAPCHNK = p->llcapchnk; d->LBIWBK = p->lbiwbk;
+  d->LICERUN = p->licerun; d->LMASKICE = p->lmaskice; d->LWAMRSETCI = p->lwamrsetci; d->LWVFLX_SNL = p->lwvflx_snl;
+  d->LWFLUX = p->lwflux; d->LCFLX = (p->lwflux || p->lwfluxout || p->lwnemocou); d->LWNEMOCOU = p->lwnemocou; d->LWCOU = p->lwcou;
+  d->LWCOUAST = p->lwcouast; d->LWNEMOCOUWRS = p->lwnemocouwrs;
+  d->NSDSNTH = p->nsdsnth; d->NTAP = 2 * p->nsdsnth + 1; d->MFRSTLW = p->mfrstlw; d->MLSTHG = ML; d->KFRH = p->kfrh; d->NWAV_GC = p->nwav_gc;
+#define S_(dst, src) d->dst = (T)p->src
+  S_(XIMP, ximp); S_(G, g); S_(GM1, gm1); S_(PI, pi); S_(ZPI, zpi); S_(ZPI4GM1, zpi4gm1); S_(ZPI4GM2, zpi4gm2); S_(EPSMIN, epsmin);
+  S_(ROWATER, rowater); S_(ROWATERM1, rowaterm1); S_(EPSUS, epsus); S_(EPSU10, epsu10); S_(ACD, acd); S_(BCD, bcd);
+  S_(ACDLIN, acdlin); S_(BCDLIN, bcdlin); S_(CDMAX, cdmax); S_(TAUOCMIN, tauocmin); S_(TAUOCMAX, tauocmax);
+  S_(PHIEPSMIN, phiepsmin); S_(PHIEPSMAX, phiepsmax); S_(WSEMEAN_MIN, wsemean_min); S_(CIRC, circ); S_(R, r_earth);
+  S_(FRATIO, fratio); S_(WETAIL, wetail); S_(FRTAIL, frtail); S_(WP1TAIL, wp1tail); S_(FRIC, fric); S_(DELTH, delth);
+  S_(FLOGSPRDM1, flogsprdm1); S_(XKAPPA, xkappa); S_(XNLEV, xnlev); S_(RNU, rnu); S_(RNUM, rnum);
+  S_(BETAMAXOXKAPPA2, betamaxoxkappa2); S_(BMAXOKAP, bmaxokap); S_(GAMNCONST, gamnconst); S_(ZALP, zalp); S_(ALPHA, alpha);
+  S_(ALPHAMIN, alphamin); S_(ALPHAMAX, alphamax); S_(CHNKMIN_U, chnkmin_u); S_(TAUWSHELTER, tauwshelter); S_(DTHRN_A, dthrn_a);
+  S_(DTHRN_U, dthrn_u); S_(TAILFACTOR, tailfactor); S_(TAILFACTOR_PM, tailfactor_pm); S_(ANG_GC_A, ang_gc_a);
+  S_(ANG_GC_B, ang_gc_b); S_(ANG_GC_C, ang_gc_c); S_(RN1_RN, rn1_rn); S_(SWELLF, swellf); S_(SWELLF2, swellf2);
+  S_(SWELLF3, swellf3); S_(SWELLF4, swellf4); S_(SWELLF5, swellf5); S_(SWELLF6, swellf6); S_(SWELLF7, swellf7);
+  S_(SWELLF7M1, swellf7m1); S_(Z0RAT, z0rat); S_(Z0TUBMAX, z0tubmax); S_(ABMIN, abmin); S_(ABMAX, abmax); S_(SDSBR, sdsbr);
+  S_(SSDSC2, ssdsc2); S_(SSDSC3, ssdsc3); S_(SSDSC4, ssdsc4); S_(SSDSC5, ssdsc5); S_(SSDSC6, ssdsc6); S_(MICHE, miche);
+  S_(EGRCRV, egrcrv); S_(AFCRV, afcrv); S_(BFCRV, bfcrv); S_(X0TAUHF, x0tauhf); S_(EPS1, eps1); S_(FLMIN, flmin);
+  S_(CITHRSH, cithrsh); S_(CIBLOCK, ciblock); S_(CITHRSH_TAIL, cithrsh_tail); S_(ZALPWRS, zalpwrs); S_(BATHYMAX, bathymax);
+  S_(WSPMIN, wspmin); S_(WSPMIN_RESET_TAUW, wspmin_reset_tauw); S_(DAL1, dal1); S_(DAL2, dal2);
+  S_(XLOGKRATIOM1_GC, xlogkratiom1_gc); S_(SQRTGOSURFT, sqrtgosurft);
+#undef S_
+  cpv(d->FR, t->fr, NFRE); cpv(d->DFIM, t->dfim, NFRE); cpv(d->DFIMOFR, t->dfimofr, NFRE); cpv(d->DFIMFR, t->dfimfr, NFRE);
+  cpv(d->DFIM_SIM, t->dfim_sim, NFRE); cpv(d->RHOWG_DFIM, t->rhowg_dfim, NFRE); cpv(d->ZPIFR, t->zpifr, NFRE);
+  cpv(d->FR5, t->fr5, NFRE); cpv(d->COFRM4, t->cofrm4, NFRE); cpv(d->FLMAX, t->flmax, NFRE);
+  cpv(d->TH, t->th, NANG); cpv(d->COSTH, t->costh, NANG); cpv(d->SINTH, t->sinth, NANG);
+  cpv(d->WTAUHF, t->wtauhf, JTOT);
+  cpv(d->SWELLFT + 1, t->swellft, ECWAM_HIP_IAB);
+  for (int i = 0; i < ML; i++) { d->IKP[i] = t->ikp[i]; d->IKP1[i] = t->ikp1[i]; d->IKM[i] = t->ikm[i]; d->IKM1[i] = t->ikm1[i]; }
+  cpv(d->AF11, t->af11, ML);
+  for (int k = 0; k < NANG; k++)
+    for (int kh = 0; kh < 2; kh++) {
+      d->K1W[kh][k] = t->k1w[k * 2 + kh] - 1; d->K2W[kh][k] = t->k2w[k * 2 + kh] - 1;
+      d->K11W[kh][k] = t->k11w[k * 2 + kh] - 1; d->K21W[kh][k] = t->k21w[k * 2 + kh] - 1;
+    }
+  for (int i = 0; i < ML; i++) {
+    for (int j = 0; j < 5; j++) d->INLCOEF[i][j] = t->inlcoef[i * 5 + j] - 1;
+    for (int j = 0; j < 25; j++) d->RNLCOEF[i][j] = ((const T*)t->rnlcoef)[i * 25 + j];
+  }
+  const int ntap = 2 * p->nsdsnth + 1;
+  for (int k = 0; k < NANG; k++)
+    for (int j = 0; j < ntap; j++) {
+      d->INDICESSAT[j][k] = t->indicessat[k * ntap + j] - 1;
+      d->SATWEIGHTS[j][k] = ((const T*)t->satweights)[k * ntap + j];
+    }
+  for (int k = 0; k < NANG; k++) {
+    for (int j = 0; j < 3; j++) d->KPM[k][j] = t->kpm[k * 3 + j] - 1;
+    for (int j = 0; j < 2; j++) { d->JXO[k][j] = t->jxo[k * 2 + j] - 1; d->JYO[k][j] = t->jyo[k * 2 + j] - 1; }
+    for (int j = 0; j < 4; j++) d->KCR[k][j] = t->kcr[k * 4 + j] - 1;
+  }
+  const int ng = p->nwav_gc;
+  cpv(d->XK_GC + 1, t->xk_gc, ng); cpv(d->XKM_GC + 1, t->xkm_gc, ng); cpv(d->OMEGA_GC + 1, t->omega_gc, ng);
+  cpv(d->OMXKM3_GC + 1, t->omxkm3_gc, ng); cpv(d->CM_GC + 1, t->cm_gc, ng); cpv(d->C2OSQRTVG_GC + 1, t->c2osqrtvg_gc, ng);
+  cpv(d->XKMSQRTVGOC2_GC + 1, t->xkmsqrtvgoc2_gc, ng); cpv(d->OM3GMKM_GC + 1, t->om3gmkm_gc, ng);
+  cpv(d->DELKCC_GC_NS + 1, t->delkcc_gc_ns, ng); cpv(d->DELKCC_OMXKM3_GC + 1, t->delkcc_omxkm3_gc, ng);
+  return 0;
+}
+
+extern "C" {
+
+const char* ecwam_hip_last_error(void) { return g_err.c_str(); }
+int ecwam_hip_abi_version(void) { return 1; }
+
+int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int real_bytes, int device, ecwam_hip_ctx** out) {
+  if (!p || !t || !out) return fail("ecwam_hip_create: null argument");
+  if (real_bytes != 4 && real_bytes != 8) return fail("ecwam_hip_create: real_bytes must be 4 or 8");
+  if (p->nang < 4 || p->nang > MAXA || p->nfre < 8 || p->nfre > MAXF || p->nfre_red < 1 || p->nfre_red > p->nfre)
+    return fail("ecwam_hip_create: NANG/NFRE/NFRE_RED out of the supported range");
+  if (p->mlsthg > MAXMC || 2 * p->nsdsnth + 1 > MAXTAP || p->nwav_gc + 1 > MAXGC) return fail("ecwam_hip_create: table size exceeds library limits");
+  if (p->iphys != 1 || p->isnonlin != 0 || p->irefra != 0 || p->icode != 3)
+    return fail("ecwam_hip_create: only IPHYS=1, ISNONLIN=0, IREFRA=0, ICODE=3 are on the hot path (SURVEY.md 8a)");
+  if (p->lciwa1 || p->lciwa2 || p->lciwa3 || p->lciscal) return fail("ecwam_hip_create: SDICE/LCISCAL not supported yet");
+  if (p->llgcbz0) return fail("ecwam_hip_create: LLGCBZ0=T (gravity-capillary roughness, taut_z0.F90:148-287) not supported yet");
+  if (p->lwnemocou || p->lwnemocouwrs) return fail("ecwam_hip_create: NEMO coupling outputs (WAVE2OCEAN) not supported yet");
+  HIPCHK(hipSetDevice(device));
+  ecwam_hip_ctx* c = new ecwam_hip_ctx();
+  c->real_bytes = real_bytes; c->device = device; c->NANG = p->nang; c->NFRE = p->nfre; c->NFRE_RED = p->nfre_red; c->p = *p;
+  if (real_bytes == 4) {
+    std::vector<DevTab<float>> h(1);
+    build_tab<float>(p, t, h.data());
+    HIPCHK(hipMalloc(&c->dtab, sizeof(DevTab<float>)));
+    HIPCHK(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<float>), hipMemcpyHostToDevice));
+  } else {
+    std::vector<DevTab<double>> h(1);
+    build_tab<double>(p, t, h.data());
+    HIPCHK(hipMalloc(&c->dtab, sizeof(DevTab<double>)));
+    HIPCHK(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<double>), hipMemcpyHostToDevice));
+  }
+  *out = c;
+  return 0;
+}
+
+int ecwam_hip_destroy(ecwam_hip_ctx* c) {
+  if (!c) return 0;
+  if (c->dtab) (void)hipFree(c->dtab);
+  delete c;
+  return 0;
+}
+
+#define DISPATCH(call_f, call_d) \
+  do {                           \
+    if (c->real_bytes == 4) {    \
+      call_f;                    \
+    } else {                     \
+      call_d;                    \
+    }                            \
+  } while (0)
+
+int ecwam_hip_propags2(ecwam_hip_ctx* c, const void* f1, void* f3, const int* klon, const int* klat, const int* kcor, const void* w,
+                       int kijs, int kijl, int nd3s, int nd3e, int copy_rest, void* stream) {
+  if (!c) return fail("null context");
+  if (kijl < kijs || nd3s < 1 || nd3e > c->NFRE_RED || nd3e < nd3s - 1) return fail("ecwam_hip_propags2: bad range");
+  if (kijl > kijs && (!f1 || !f3 || !klon || !klat || !kcor || !w)) return fail("ecwam_hip_propags2: null pointer");
+  if (f1 == f3) return fail("ecwam_hip_propags2: F1 and F3 must not alias");
+  hipStream_t s = (hipStream_t)stream;
+  const int N = c->NANG * c->NFRE;
+  DISPATCH(launch_propags2<float>(c->dtab, f1, f3, klon, klat, kcor, w, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, s),
+           launch_propags2<double>(c->dtab, f1, f3, klon, klat, kcor, w, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, s));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ecwam_hip_ctuw(ecwam_hip_ctx* c, int n, int nland, int ngy, double delpro, int mstart, int mend, const int* kxlt, const void* zdello,
+                   double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat, const int* kcor, void* wlat,
+                   void* wcor, const void* cgroup_ext, const void* cosphm1_ext, void* w, int* cflfail, void* stream) {
+  if (!c) return fail("null context");
+  if (n < 0 || mstart < 1 || mend > c->NFRE_RED || mend < mstart) return fail("ecwam_hip_ctuw: bad range");
+  if (n > 0 && (!kxlt || !zdello || !cosph || !sinph || !klon || !klat || !kcor || !wlat || !wcor || !cgroup_ext || !cosphm1_ext || !w || !cflfail))
+    return fail("ecwam_hip_ctuw: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH(launch_ctuw<float>(c->dtab, n, nland, ngy, delpro, mstart - 1, mend, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, w, cflfail, c->NANG, s),
+           launch_ctuw<double>(c->dtab, n, nland, ngy, delpro, mstart - 1, mend, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, w, cflfail, c->NANG, s));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws,
+                      void* dbg, void* stream) {
+  if (!c) return fail("null context");
+  if (kijl < kijs) return fail("ecwam_hip_implsch: bad range");
+  if (kijl > kijs && (!fl1 || !wvprpt || !ff || !intf || !mij || !xllws)) return fail("ecwam_hip_implsch: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  DISPATCH(rc = launch_implsch<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, dbg, c->NANG, c->NFRE, c->p.nsdsnth, s),
+           rc = launch_implsch<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, dbg, c->NANG, c->NFRE, c->p.nsdsnth, s));
+  if (rc) return fail("ecwam_hip_implsch: unsupported spectral size for the LDS tiling");
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ecwam_hip_newwind(ecwam_hip_ctx* c, int n, void* ff, const void* ff_next, void* stream) {
+  if (!c) return fail("null context");
+  if (n > 0 && (!ff || !ff_next)) return fail("ecwam_hip_newwind: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH(launch_newwind<float>(c->dtab, n, ff, ff_next, s), launch_newwind<double>(c->dtab, n, ff, ff_next, s));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ecwam_hip_chunks_to_points(ecwam_hip_ctx* c, const void* chunked, void* points, int nproma, int nchnk, int npts, int n2, int n3, void* stream) {
+  if (!c) return fail("null context");
+  if (nproma < 1 || nchnk < 0 || npts > nproma * nchnk || n2 < 1 || n3 < 1) return fail("ecwam_hip_chunks_to_points: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH(launch_c2p<float>(chunked, points, nproma, nchnk, npts, n2, n3, s), launch_c2p<double>(chunked, points, nproma, nchnk, npts, n2, n3, s));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ecwam_hip_points_to_chunks(ecwam_hip_ctx* c, const void* points, void* chunked, int nproma, int nchnk, int npts, int n2, int n3, void* stream) {
+  if (!c) return fail("null context");
+  if (nproma < 1 || nchnk < 0 || npts > nproma * nchnk || npts <= nproma * (nchnk - 1) || n2 < 1 || n3 < 1) return fail("ecwam_hip_points_to_chunks: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH(launch_p2c<float>(points, chunked, nproma, nchnk, npts, n2, n3, s), launch_p2c<double>(points, chunked, nproma, nchnk, npts, n2, n3, s));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ecwam_hip_pack_rows(ecwam_hip_ctx* c, const void* fl, const int* idx, int n, void* buf, void* stream) {
+  if (!c) return fail("null context");
+  if (n > 0 && (!fl || !idx || !buf)) return fail("ecwam_hip_pack_rows: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int rowlen = c->NANG * c->NFRE;
+  DISPATCH(launch_pack<float>(fl, idx, n, rowlen, buf, s), launch_pack<double>(fl, idx, n, rowlen, buf, s));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ecwam_hip_unpack_rows(ecwam_hip_ctx* c, const void* buf, int n, void* fl, int dst0, void* stream) {
+  if (!c) return fail("null context");
+  if (n > 0 && (!fl || !buf)) return fail("ecwam_hip_unpack_rows: null pointer");
+  if (n <= 0) return 0;
+  const size_t row = (size_t)c->NANG * c->NFRE * c->real_bytes;
+  HIPCHK(hipMemcpyAsync((char*)fl + (size_t)dst0 * row, buf, (size_t)n * row, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// Device-side tables and wavefront helpers shared by the ecwam_hip kernels (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/ecwam_hip.h"
+
+#define MAXA ECWAM_HIP_MAXANG
+#define MAXF ECWAM_HIP_MAXFRE
+#define MAXMC ECWAM_HIP_MAXMC
+#define MAXTAP ECWAM_HIP_MAXTAP
+#define MAXGC ECWAM_HIP_MAXGC
+#define JTOT ECWAM_HIP_JTOT_TAUHF
+
+// Module-level read-only state of the reference (YOWFRED, YOWPHYS, YOWINDN, YOWPCONS, YOWCOUP, YOWICE,
+// YOWTABL, YOWUBUF selectors) in the working precision T.  One instance lives in device memory per
+// context; kernels take a pointer to it and read it with wave-uniform (scalar) or per-lane loads.
+template <typename T>
+struct DevTab {
+  int NANG, NFRE, NFRE_RED, NFRE_ODD, IDELT;
+  int LLGCBZ0, LLNORMAGAM, LLCAPCHNK, LBIWBK, LICERUN, LMASKICE, LWAMRSETCI;
+  int LWVFLX_SNL, LWFLUX, LCFLX, LWNEMOCOU, LWCOU, LWCOUAST, LWNEMOCOUWRS;
+  int NSDSNTH, NTAP, MFRSTLW, MLSTHG, KFRH, NWAV_GC;
+  T XIMP, G, GM1, PI, ZPI, ZPI4GM1, ZPI4GM2, EPSMIN, ROWATER, ROWATERM1, EPSUS, EPSU10, ACD, BCD, ACDLIN, BCDLIN, CDMAX;
+  T TAUOCMIN, TAUOCMAX, PHIEPSMIN, PHIEPSMAX, WSEMEAN_MIN, CIRC, R;
+  T FRATIO, WETAIL, FRTAIL, WP1TAIL, FRIC, DELTH, FLOGSPRDM1;
+  T XKAPPA, XNLEV, RNU, RNUM, BETAMAXOXKAPPA2, BMAXOKAP, GAMNCONST, ZALP, ALPHA, ALPHAMIN, ALPHAMAX, CHNKMIN_U;
+  T TAUWSHELTER, DTHRN_A, DTHRN_U, TAILFACTOR, TAILFACTOR_PM, ANG_GC_A, ANG_GC_B, ANG_GC_C, RN1_RN;
+  T SWELLF, SWELLF2, SWELLF3, SWELLF4, SWELLF5, SWELLF6, SWELLF7, SWELLF7M1, Z0RAT, Z0TUBMAX, ABMIN, ABMAX;
+  T SDSBR, SSDSC2, SSDSC3, SSDSC4, SSDSC5, SSDSC6, MICHE;
+  T EGRCRV, AFCRV, BFCRV;
+  T X0TAUHF, EPS1, FLMIN, CITHRSH, CIBLOCK, CITHRSH_TAIL, ZALPWRS, BATHYMAX, WSPMIN, WSPMIN_RESET_TAUW;
+  T DAL1, DAL2, XLOGKRATIOM1_GC, SQRTGOSURFT;
+  // per-frequency
+  T FR[MAXF], DFIM[MAXF], DFIMOFR[MAXF], DFIMFR[MAXF], DFIM_SIM[MAXF], RHOWG_DFIM[MAXF], ZPIFR[MAXF], FR5[MAXF];
+  T COFRM4[MAXF], FLMAX[MAXF];
+  // per-direction
+  T TH[MAXA], COSTH[MAXA], SINTH[MAXA];
+  T WTAUHF[JTOT];
+  T SWELLFT[ECWAM_HIP_IAB + 1];  // 1-based like the reference
+  // DIA (index values 0-based here)
+  int IKP[MAXMC], IKP1[MAXMC], IKM[MAXMC], IKM1[MAXMC];  // 1-based frequency values as in the reference
+  T AF11[MAXMC];
+  int K1W[2][MAXA], K2W[2][MAXA], K11W[2][MAXA], K21W[2][MAXA];  // [kh][k], 0-based direction
+  int INLCOEF[MAXMC][5];                                         // 0-based frequency
+  T RNLCOEF[MAXMC][25];
+  // saturation filter: [k2][k] so that lanes (k) read consecutive words
+  int INDICESSAT[MAXTAP][MAXA];  // 0-based direction
+  T SATWEIGHTS[MAXTAP][MAXA];
+  // CTU selectors, 0-based
+  int KPM[MAXA][3], JXO[MAXA][2], JYO[MAXA][2], KCR[MAXA][4];
+  // gravity-capillary tables, 1-based like the reference
+  T XK_GC[MAXGC], XKM_GC[MAXGC], OMEGA_GC[MAXGC], OMXKM3_GC[MAXGC], CM_GC[MAXGC], C2OSQRTVG_GC[MAXGC];
+  T XKMSQRTVGOC2_GC[MAXGC], OM3GMKM_GC[MAXGC], DELKCC_GC_NS[MAXGC], DELKCC_OMXKM3_GC[MAXGC];
+};
+
+// ---- precision-generic math ---------------------------------------------------------------------
+__device__ __forceinline__ float m_sin(float x) { return sinf(x); }
+__device__ __forceinline__ double m_sin(double x) { return sin(x); }
+__device__ __forceinline__ float m_cos(float x) { return cosf(x); }
+__device__ __forceinline__ double m_cos(double x) { return cos(x); }
+__device__ __forceinline__ float m_exp(float x) { return expf(x); }
+__device__ __forceinline__ double m_exp(double x) { return exp(x); }
+__device__ __forceinline__ float m_log(float x) { return logf(x); }
+__device__ __forceinline__ double m_log(double x) { return log(x); }
+__device__ __forceinline__ float m_log10(float x) { return log10f(x); }
+__device__ __forceinline__ double m_log10(double x) { return log10(x); }
+__device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float m_tanh(float x) { return tanhf(x); }
+__device__ __forceinline__ double m_tanh(double x) { return tanh(x); }
+__device__ __forceinline__ float m_sinh(float x) { return sinhf(x); }
+__device__ __forceinline__ double m_sinh(double x) { return sinh(x); }
+__device__ __forceinline__ float m_atan2(float y, float x) { return atan2f(y, x); }
+__device__ __forceinline__ double m_atan2(double y, double x) { return atan2(y, x); }
+__device__ __forceinline__ float m_pow(float x, float y) { return powf(x, y); }
+__device__ __forceinline__ double m_pow(double x, double y) { return pow(x, y); }
+__device__ __forceinline__ float m_abs(float x) { return fabsf(x); }
+__device__ __forceinline__ double m_abs(double x) { return fabs(x); }
+__device__ __forceinline__ float m_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double m_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float m_min(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double m_min(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float m_sign(float a, float b) { return copysignf(a, b); }
+__device__ __forceinline__ double m_sign(double a, double b) { return copysign(a, b); }
+__device__ __forceinline__ int m_nint(float x) { return (int)lroundf(x); }
+__device__ __forceinline__ int m_nint(double x) { return (int)lround(x); }
+template <typename T>
+__device__ __forceinline__ T m_pow4(T x) {
+  T x2 = x * x;
+  return x2 * x2;
+}
+
+// ---- wavefront helpers (wave64) -------------------------------------------------------------------
+// value held by lane `l` (l wave-uniform) -> every lane, through SGPRs (v_readlane_b32)
+__device__ __forceinline__ float lane_get(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ int lane_get(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double lane_get(double v, int l) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// all-lanes reductions; inactive lanes must contribute the identity
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) v = m_max(v, __shfl_xor(v, o, 64));
+  return v;
+}

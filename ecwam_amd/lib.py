@@ -1,0 +1,115 @@
+"""ctypes binding of libecwam_hip.so (include/ecwam_hip.h).  There is no CPU fallback: if the HIP
+library is missing this module raises, and nothing in the product path imports the oracle."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .tables import JTOT_TAUHF, Tables
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(HERE, "lib", "libecwam_hip.so")
+
+_INT_FIELDS_1 = ["nang", "nfre", "nfre_red", "nfre_odd", "idelt"]
+_PARAM_LAYOUT = (
+    [(n, C.c_int) for n in _INT_FIELDS_1]
+    + [("ximp", C.c_double)]
+    + [(n, C.c_int) for n in ["iphys", "isnonlin", "irefra", "icode", "llgcbz0", "llnormagam", "llcapchnk", "lbiwbk", "licerun",
+                               "lmaskice", "lwamrsetci", "lciwa1", "lciwa2", "lciwa3", "lciscal", "lwvflx_snl", "lwflux",
+                               "lwfluxout", "lwnemocou", "lwcou", "lwcouast", "lwnemocouwrs", "lwnemotauoc"]]
+    + [(n, C.c_double) for n in ["g", "gm1", "pi", "zpi", "zpi4gm1", "zpi4gm2", "epsmin", "rowater", "rowaterm1", "epsus",
+                                  "epsu10", "acd", "bcd", "acdlin", "bcdlin", "cdmax", "tauocmin", "tauocmax", "phiepsmin",
+                                  "phiepsmax", "wsemean_min", "circ", "r_earth", "fratio", "wetail", "frtail", "wp1tail", "fric",
+                                  "delth", "flogsprdm1", "xkappa", "xnlev", "rnu", "rnum", "betamaxoxkappa2", "bmaxokap",
+                                  "gamnconst", "zalp", "alpha", "alphamin", "alphamax", "chnkmin_u", "tauwshelter", "dthrn_a",
+                                  "dthrn_u", "tailfactor", "tailfactor_pm", "ang_gc_a", "ang_gc_b", "ang_gc_c", "rn1_rn", "swellf",
+                                  "swellf2", "swellf3", "swellf4", "swellf5", "swellf6", "swellf7", "swellf7m1", "z0rat",
+                                  "z0tubmax", "abmin", "abmax", "sdsbr", "ssdsc2", "ssdsc3", "ssdsc4", "ssdsc5", "ssdsc6", "miche"]]
+    + [("nsdsnth", C.c_int), ("ipsat", C.c_int)]
+    + [(n, C.c_double) for n in ["egrcrv", "afcrv", "bfcrv", "x0tauhf", "eps1", "flmin", "cithrsh", "ciblock", "cithrsh_tail",
+                                  "zalpwrs", "bathymax", "wspmin", "wspmin_reset_tauw"]]
+    + [("mfrstlw", C.c_int), ("mlsthg", C.c_int), ("kfrh", C.c_int), ("dal1", C.c_double), ("dal2", C.c_double),
+       ("nwav_gc", C.c_int), ("xlogkratiom1_gc", C.c_double), ("sqrtgosurft", C.c_double)]
+)
+
+
+class Params(C.Structure):
+    _fields_ = _PARAM_LAYOUT
+
+
+_TABLE_NAMES = ["fr", "dfim", "dfimofr", "dfimfr", "dfim_sim", "rhowg_dfim", "zpifr", "fr5", "cofrm4", "flmax", "th", "costh",
+                "sinth", "wtauhf", "swellft", "ikp", "ikp1", "ikm", "ikm1", "af11", "k1w", "k2w", "k11w", "k21w", "inlcoef",
+                "rnlcoef", "indicessat", "satweights", "kpm", "jxo", "jyo", "kcr", "xk_gc", "xkm_gc", "omega_gc", "omxkm3_gc",
+                "cm_gc", "c2osqrtvg_gc", "xkmsqrtvgoc2_gc", "om3gmkm_gc", "delkcc_gc_ns", "delkcc_omxkm3_gc"]
+_INT_TABLES = {"ikp", "ikp1", "ikm", "ikm1", "k1w", "k2w", "k11w", "k21w", "inlcoef", "indicessat", "kpm", "jxo", "jyo", "kcr"}
+
+
+class TablePtrs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _TABLE_NAMES]
+
+
+EXPORTS = ["ecwam_hip_last_error", "ecwam_hip_abi_version", "ecwam_hip_create", "ecwam_hip_destroy", "ecwam_hip_propags2",
+           "ecwam_hip_ctuw", "ecwam_hip_implsch", "ecwam_hip_newwind", "ecwam_hip_chunks_to_points",
+           "ecwam_hip_points_to_chunks", "ecwam_hip_pack_rows", "ecwam_hip_unpack_rows"]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBPATH):
+        raise RuntimeError(f"{LIBPATH} not found: the HIP extension is not built (run `python -m ecwam_amd.build` or "
+                           "__graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(LIBPATH)
+    lib.ecwam_hip_last_error.restype = C.c_char_p
+    for name in EXPORTS[1:]:
+        getattr(lib, name).restype = C.c_int
+    vp, ci, cd = C.c_void_p, C.c_int, C.c_double
+    lib.ecwam_hip_create.argtypes = [C.POINTER(Params), C.POINTER(TablePtrs), ci, ci, C.POINTER(vp)]
+    lib.ecwam_hip_destroy.argtypes = [vp]
+    lib.ecwam_hip_propags2.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    lib.ecwam_hip_ctuw.argtypes = [vp, ci, ci, ci, cd, ci, ci, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ecwam_hip_implsch.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ecwam_hip_newwind.argtypes = [vp, ci, vp, vp, vp]
+    lib.ecwam_hip_chunks_to_points.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    lib.ecwam_hip_points_to_chunks.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    lib.ecwam_hip_pack_rows.argtypes = [vp, vp, vp, ci, vp, vp]
+    lib.ecwam_hip_unpack_rows.argtypes = [vp, vp, ci, vp, ci, vp]
+    _lib = lib
+    return lib
+
+
+def make_params(t: Tables) -> Params:
+    c = t.cfg
+    p = Params()
+    for name, typ in _PARAM_LAYOUT:
+        if hasattr(c, name) and name not in ("wspmin", "rnu", "rnum"):
+            v = getattr(c, name)
+        elif name == "r_earth":
+            v = t.R
+        else:
+            v = getattr(t, name.upper())
+        setattr(p, name, int(v) if typ is C.c_int else float(v))
+    return p
+
+
+def make_tables(t: Tables):
+    """Returns (TablePtrs, keepalive list).  Index tables are passed 1-based as the reference holds them."""
+    T = t.dtype
+    keep = []
+    tp = TablePtrs()
+    one_based = {"indicessat": 1, "kpm": 1}  # ours are stored 0-based in Tables
+    for name in _TABLE_NAMES:
+        a = getattr(t, name.upper())
+        if name in _INT_TABLES:
+            a = np.ascontiguousarray(np.asarray(a) + one_based.get(name, 0), dtype=np.int32)
+        else:
+            a = np.ascontiguousarray(a, dtype=T)
+        keep.append(a)
+        setattr(tp, name, a.ctypes.data_as(C.c_void_p))
+    assert t.WTAUHF.size == JTOT_TAUHF
+    return tp, keep

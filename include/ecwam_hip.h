@@ -1,0 +1,168 @@
+/*
+ * ecwam_hip.h -- C ABI of libecwam_hip.so: the MI355X-native WAMINTGR hot path
+ * (PROPAG_WAM/PROPAGS2 advection + NEWWIND + IMPLSCH source-term integration) of ecWAM.
+ *
+ * This is the drop-in boundary.  Every entry point names the reference
+ * interface it replaces (paths relative to ecwam/src/ecwam).  All functions return 0 on success
+ * and a non-zero status otherwise (the reference aborts through WAM_ABORT/ABORT1, yowabort.F90;
+ * the Fortran wrapper fortran/wamintgr_hip.F90 turns a non-zero status into WAM_ABORT).
+ * ecwam_hip_last_error() gives the message.  No torch / C++ types cross this boundary.
+ *
+ * Precision: `real_bytes` = 4 (JWRB single build) or 8 (double build), parkind_wave.F90:23-35.
+ * Every `void*` array below holds reals of that size unless the name says int.
+ *
+ * DEVICE LAYOUT (private to the library; converted from the reference's chunked layout by
+ * ecwam_hip_chunks_to_points / _points_to_chunks):
+ *   spectra   FL[ij][K][M]           ij = local sea point (0-based), K = direction, M = frequency,
+ *                                    M fastest; slot ij = nland (= "NSUP+1", propag_wam.F90:146)
+ *                                    holds the zero land spectrum, halo points sit between the
+ *                                    owned range and nland (mpdecomp.F90:89-100 convention)
+ *   WVPRPT    [ij][5][NFRE]          WAVNUM, CGROUP, CINV, XK2CG, STOKFAC (FREQUENCY type, yowdrvtype_config.yml)
+ *   FF        [ij][16]               AIRD WDWAVE CICOVER WSWAVE WSTAR USTRA VSTRA UFRIC TAUW TAUWDIR Z0M Z0B
+ *                                    CHRNCK CITHICK (FORCING_FIELDS) + EMAXDPT DEPTH (ENVIRONMENT)
+ *   INTF      [ij][16]               WSEMEAN WSFMEAN USTOKES VSTOKES STRNMS TAUXD TAUYD TAUOCXD TAUOCYD TAUOC
+ *                                    TAUICX TAUICY PHIOCD PHIEPS PHIAW (INTGT_PARAM_FIELDS) + 1 pad
+ *   weights   W[ij][8][NANG*NFRE_RED] the 8 CTU weights PROPAGS2 reads when IREFRA=0 (propags2.F90:107-116):
+ *                                    SUMWN, WLONN(JXO(K,1)), WLATN(JYO(K,1),1), WLATN(JYO(K,1),2),
+ *                                    WCORN(1,1), WCORN(1,2), WKPMN(-1), WKPMN(+1)
+ */
+#ifndef ECWAM_HIP_H
+#define ECWAM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ECWAM_HIP_MAXANG 48
+#define ECWAM_HIP_MAXFRE 48
+#define ECWAM_HIP_MAXMC 56     /* MLSTHG = NFRE - ISM <= 48 + 8 */
+#define ECWAM_HIP_MAXTAP 47    /* 2*NSDSNTH+1, NSDSNTH <= NANG/2-1 */
+#define ECWAM_HIP_MAXGC 96     /* NWAV_GC (initgc.F90:67) = 82 */
+#define ECWAM_HIP_IAB 200      /* yowtabl.F90:25 */
+#define ECWAM_HIP_JTOT_TAUHF 19 /* yowcoup.F90:60 */
+#define ECWAM_HIP_NFF 16
+#define ECWAM_HIP_NINTF 16
+#define ECWAM_HIP_NWPR 5
+
+/* Scalars and flags the kernels read from the reference's modules (replaces `!$loki update_device`
+ * of the module globals, wamintgr_loki_gpu.F90:95-97).  Reals are passed as double and rounded
+ * to the working precision inside the library. */
+typedef struct ecwam_hip_params {
+  /* YOWPARAM / YOWSTAT / YOWWNDG */
+  int nang, nfre, nfre_red, nfre_odd;
+  int idelt;                /* IDELT: source time step [s] */
+  double ximp;              /* XIMP */
+  int iphys, isnonlin, irefra, icode;
+  /* YOWCOUP / YOWSTAT / YOWICE flags (0/1) */
+  int llgcbz0, llnormagam, llcapchnk, lbiwbk, licerun, lmaskice, lwamrsetci;
+  int lciwa1, lciwa2, lciwa3, lciscal;
+  int lwvflx_snl, lwflux, lwfluxout, lwnemocou, lwcou, lwcouast, lwnemocouwrs, lwnemotauoc;
+  /* YOWPCONS */
+  double g, gm1, pi, zpi, zpi4gm1, zpi4gm2, epsmin, rowater, rowaterm1, epsus, epsu10, acd, bcd, acdlin, bcdlin, cdmax;
+  double tauocmin, tauocmax, phiepsmin, phiepsmax, wsemean_min, circ, r_earth;
+  /* YOWFRED scalars */
+  double fratio, wetail, frtail, wp1tail, fric, delth, flogsprdm1;
+  /* YOWPHYS */
+  double xkappa, xnlev, rnu, rnum, betamaxoxkappa2, bmaxokap, gamnconst, zalp, alpha, alphamin, alphamax, chnkmin_u;
+  double tauwshelter, dthrn_a, dthrn_u, tailfactor, tailfactor_pm, ang_gc_a, ang_gc_b, ang_gc_c, rn1_rn;
+  double swellf, swellf2, swellf3, swellf4, swellf5, swellf6, swellf7, swellf7m1, z0rat, z0tubmax, abmin, abmax;
+  double sdsbr, ssdsc2, ssdsc3, ssdsc4, ssdsc5, ssdsc6, miche;
+  int nsdsnth, ipsat;
+  double egrcrv, afcrv, bfcrv;
+  /* YOWCOUP / YOWTABL / YOWICE / YOWSHAL / YOWWIND */
+  double x0tauhf, eps1, flmin, cithrsh, ciblock, cithrsh_tail, zalpwrs, bathymax, wspmin, wspmin_reset_tauw;
+  /* YOWINDN scalars */
+  int mfrstlw, mlsthg, kfrh;
+  double dal1, dal2;
+  /* gravity-capillary model (YOWFRED *_GC) */
+  int nwav_gc;
+  double xlogkratiom1_gc, sqrtgosurft;
+} ecwam_hip_params;
+
+/* Host pointers to the reference's module tables, reals in the working precision, ints 32-bit.
+ * Index values are passed exactly as the reference holds them (1-based where the reference is
+ * 1-based); INDICESSAT is 1-based on this interface as in yowphys.F90:154. */
+typedef struct ecwam_hip_tables {
+  const void *fr, *dfim, *dfimofr, *dfimfr, *dfim_sim, *rhowg_dfim, *zpifr, *fr5, *cofrm4, *flmax; /* [NFRE]  yowfred.F90 */
+  const void *th, *costh, *sinth;                                                                     /* [NANG] */
+  const void *wtauhf;                                                                                 /* [19]   yowcoup.F90:61 */
+  const void *swellft;                                                                                /* [200]  yowtabl.F90:56 */
+  const int *ikp, *ikp1, *ikm, *ikm1;                                                                 /* [MLSTHG] values for MC=1.. (yowindn) */
+  const void *af11;                                                                                   /* [MLSTHG] AF11(1:MLSTHG) */
+  const int *k1w, *k2w, *k11w, *k21w;                                                                 /* [NANG][2] C order of K1W(K,KH) */
+  const int *inlcoef;                                                                                 /* [MLSTHG][5]  INLCOEF(:,MC) */
+  const void *rnlcoef;                                                                                /* [MLSTHG][25] RNLCOEF(:,MC) */
+  const int *indicessat;                                                                              /* [NANG][2*NSDSNTH+1] */
+  const void *satweights;                                                                             /* [NANG][2*NSDSNTH+1] */
+  const int *kpm, *jxo, *jyo, *kcr;                                                                   /* [NANG][3],[2],[2],[4] (yowubuf) */
+  const void *xk_gc, *xkm_gc, *omega_gc, *omxkm3_gc, *cm_gc, *c2osqrtvg_gc, *xkmsqrtvgoc2_gc, *om3gmkm_gc, *delkcc_gc_ns,
+      *delkcc_omxkm3_gc;                                                                              /* [NWAV_GC] */
+} ecwam_hip_tables;
+
+typedef struct ecwam_hip_ctx ecwam_hip_ctx;
+
+const char *ecwam_hip_last_error(void);
+int ecwam_hip_abi_version(void);
+
+/* Context: one per (device, configuration).  Replaces the device residency of the module globals. */
+int ecwam_hip_create(const ecwam_hip_params *p, const ecwam_hip_tables *t, int real_bytes, int device, ecwam_hip_ctx **out);
+int ecwam_hip_destroy(ecwam_hip_ctx *ctx);
+
+/*
+ * PROPAGS2 (propags2.F90:10, IREFRA=0 branch :99-121) on device pointers.
+ *   f1, f3      FL[npts+1][NANG][NFRE]; only rows [kijs,kijl) of f3 are written; frequencies
+ *               [nd3s-1, nd3e) are advected (1-based inclusive as in the reference);
+ *               if copy_rest != 0 the remaining frequencies of those rows are copied f1 -> f3
+ *               (the reference leaves them in FL1, propag_wam.F90:379-386)
+ *   klon[ij][2] klat[ij][2][2] kcor[ij][4][2]  0-based local indices, land = nland (yowubuf KLON/KLAT/KCOR)
+ *   w           W[ij][8][NANG*NFRE_RED]
+ */
+int ecwam_hip_propags2(ecwam_hip_ctx *ctx, const void *f1, void *f3, const int *klon, const int *klat, const int *kcor,
+                       const void *w, int kijs, int kijl, int nd3s, int nd3e, int copy_rest, void *stream);
+
+/*
+ * CTUWINI + CTUW (ctuwini.F90:58-164, ctuw.F90:146-275 + :407-484 + :536-608) for IREFRA=0, ICASE=1,
+ * LSUBGRID=F: builds W for rows [0,n) and frequencies [mstart,mend] (1-based) with time step delpro.
+ *   kxlt[ij] 0-based latitude row; zdello/cosph/sinph [ngy] (yowmap ZDELLO, yowgrid COSPH/SINPH)
+ *   wlat[ij][2], wcor[ij][4] are MODIFIED near land exactly as ctuwini.F90:66-97 does
+ *   cgroup_ext [npts+1][NFRE] group velocity incl. halo and land rows (proenvhalo.F90 BUFFER_EXT)
+ *   cosphm1_ext[npts+1]
+ *   cflfail  int[n] set to 1 where a CFL/weight-range check of ctuw.F90:288-357,541-685 fails
+ */
+int ecwam_hip_ctuw(ecwam_hip_ctx *ctx, int n, int nland, int ngy, double delpro, int mstart, int mend, const int *kxlt,
+                   const void *zdello, double xdella, const void *cosph, const void *sinph, const int *klon, const int *klat,
+                   const int *kcor, void *wlat, void *wcor, const void *cgroup_ext, const void *cosphm1_ext, void *w,
+                   int *cflfail, void *stream);
+
+/*
+ * IMPLSCH (implsch.F90:10-23) for local points [kijs,kijl) on device pointers (layouts above).
+ *   fl1 inout, wvprpt in, ff inout, intf inout, mij out (1-based), xllws out
+ *   dbg: optional real[npts][32] intermediate dump (tests only), may be NULL
+ */
+int ecwam_hip_implsch(ecwam_hip_ctx *ctx, int kijs, int kijl, void *fl1, const void *wvprpt, void *ff, void *intf, int *mij,
+                      void *xllws, void *dbg, void *stream);
+
+/* NEWWIND forcing hand-over (newwind.F90:126-161, ICODE_WND=3): FF <- FF_NEXT members + TAUW cap */
+int ecwam_hip_newwind(ecwam_hip_ctx *ctx, int n, void *ff, const void *ff_next, void *stream);
+
+/*
+ * Layout conversion between the reference's chunked host-shaped arrays and the device layout
+ * (replaces the chunk<->block copies of propag_wam.F90:124-137,373-400).
+ *   chunked spectra: FL1(NPROMA,NANG,NFRE,NCHNK) Fortran order; point ij = ichnk*nproma + iprm (mchunk.F90:62-68)
+ *   pad lanes (iprm >= KIJL4CHNK) replicate lane 1 on the way back (propag_wam.F90:388-398)
+ */
+int ecwam_hip_chunks_to_points(ecwam_hip_ctx *ctx, const void *chunked, void *points, int nproma, int nchnk, int npts,
+                               int n2, int n3, void *stream);
+int ecwam_hip_points_to_chunks(ecwam_hip_ctx *ctx, const void *points, void *chunked, int nproma, int nchnk, int npts,
+                               int n2, int n3, void *stream);
+
+/* Halo pack/unpack for the advection exchange (mpexchng.F90:124-138, 217-231):
+ *   pack:   buf[i][:] = fl[idx[i]][:]   for i < n   (row = NANG*NFRE reals)
+ *   unpack: fl[dst0+i][:] = buf[i][:]  */
+int ecwam_hip_pack_rows(ecwam_hip_ctx *ctx, const void *fl, const int *idx, int n, void *buf, void *stream);
+int ecwam_hip_unpack_rows(ecwam_hip_ctx *ctx, const void *buf, int n, void *fl, int dst0, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

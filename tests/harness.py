@@ -1,0 +1,111 @@
+"""Shared test harness: builds identical inputs for the oracle (oracle/, CPU) and the HIP path
+(ecwam_amd via the C ABI) and compares their outputs.  Test infrastructure only."""
+from __future__ import annotations
+
+import numpy as np
+
+from ecwam_amd import synthetic as syn
+from ecwam_amd.tables import Config, Tables
+
+FF_OUT = [7, 8, 9, 10, 11, 12]          # UFRIC TAUW TAUWDIR Z0M Z0B CHRNCK
+INTF_OUT = [2, 3, 5, 6, 7, 8, 9, 12, 13, 14]  # USTOKES VSTOKES TAUXD TAUYD TAUOCXD TAUOCYD TAUOC PHIOCD PHIEPS PHIAW
+
+
+def np_dtype(prec: str):
+    return np.float32 if prec == "sp" else np.float64
+
+
+def make_point_case(n: int, cfg: Config, prec: str, seed: int = 12345, spectra: str = "jonswap") -> dict:
+    """Inputs of IMPLSCH for n independent points."""
+    dt = np_dtype(prec)
+    t = Tables(cfg, dt)
+    p = syn.point_params(n, seed=seed)
+    props = syn.depth_props(p["DEPTH"], t, dt)
+    fl = syn.jonswap_spectra(t.FR, t.TH, p["FP"], p["THETAQ"], dt)
+    if spectra == "mixed":  # add a swell system and noise to exercise more branches
+        rng = np.random.default_rng(seed + 1)
+        fl2 = syn.jonswap_spectra(t.FR, t.TH, rng.uniform(0.05, 0.12, n), rng.uniform(0, 2 * np.pi, n), dt, alfa=0.004)
+        fl = (fl + fl2 * rng.uniform(0, 1, (n, 1, 1))).astype(dt)
+    ff = syn.forcing(p, slice(0, n), t, dt)
+    intf = np.zeros((n, syn.NINTF), dt)
+    env = np.stack([props["EMAXDPT"], p["DEPTH"].astype(dt)], 1)
+    return dict(cfg=cfg, prec=prec, tables=t, n=n, FL1=fl, props=props, FF=ff, INTF=intf, ENV=env, params=p)
+
+
+def oracle_implsch(case: dict, oracle, want_dbg=False) -> dict:
+    pr = case["props"]
+    return oracle.implsch(case["FL1"], pr["WAVNUM"], pr["CGROUP"], pr["CINV"], pr["XK2CG"], pr["STOKFAC"], case["ENV"], case["FF"],
+                          case["INTF"], want_dbg=want_dbg)
+
+
+def pack_device_inputs(case: dict):
+    """numpy arrays in the device layouts of include/ecwam_hip.h."""
+    dt = np_dtype(case["prec"])
+    n = case["n"]
+    pr = case["props"]
+    wv = np.stack([pr["WAVNUM"], pr["CGROUP"], pr["CINV"], pr["XK2CG"], pr["STOKFAC"]], 1).astype(dt)
+    ff = np.zeros((n, 16), dt)
+    ff[:, :14] = case["FF"]
+    ff[:, 14:16] = case["ENV"]
+    intf = np.zeros((n, 16), dt)
+    intf[:, :15] = case["INTF"]
+    return wv, ff, intf
+
+
+def gpu_implsch(case: dict, ctx, want_dbg=False) -> dict:
+    import torch
+
+    dev = ctx.device
+    wv, ff, intf = pack_device_inputs(case)
+    n = case["n"]
+    fl1 = torch.from_numpy(case["FL1"].copy()).to(dev)
+    twv, tff, tintf = (torch.from_numpy(a).to(dev) for a in (wv, ff, intf))
+    mij = torch.zeros(n, dtype=torch.int32, device=dev)
+    xllws = torch.zeros_like(fl1)
+    dbg = torch.zeros((n, 32), dtype=fl1.dtype, device=dev) if want_dbg else None
+    ctx.implsch(0, n, fl1, twv, tff, tintf, mij, xllws, dbg)
+    torch.cuda.synchronize()
+    out = dict(FL1=fl1.cpu().numpy(), XLLWS=xllws.cpu().numpy(), MIJ=mij.cpu().numpy(), FF=tff.cpu().numpy()[:, :14],
+               INTF=tintf.cpu().numpy()[:, :15])
+    if want_dbg:
+        out["DBG"] = dbg.cpu().numpy()
+    return out
+
+
+def rel_err(a, b, floor):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b) / np.maximum(np.abs(b), floor)
+
+
+def compare_implsch(ref: dict, got: dict, tables) -> dict:
+    """Error statistics of an IMPLSCH result against the oracle."""
+    st = {}
+    n = ref["FL1"].shape[0]
+    mij_same = ref["MIJ"] == got["MIJ"]
+    xl_same_pt = (ref["XLLWS"] == got["XLLWS"]).all(axis=(1, 2))
+    st["n"] = n
+    st["mij_flips"] = int((~mij_same).sum())
+    st["xllws_bins_diff"] = int((ref["XLLWS"] != got["XLLWS"]).sum())
+    st["xllws_pts_diff"] = int((~xl_same_pt).sum())
+    clean = mij_same & xl_same_pt
+    # spectral bins: error relative to the point's spectral peak (bins far below the peak carry no energy)
+    peak = np.max(np.abs(ref["FL1"].astype(np.float64)), axis=(1, 2), keepdims=True)
+    e = np.abs(got["FL1"].astype(np.float64) - ref["FL1"].astype(np.float64)) / np.maximum(peak, 1e-300)
+    st["fl1_max_rel_peak_clean"] = float(e[clean].max()) if clean.any() else 0.0
+    st["fl1_max_rel_peak_all"] = float(e.max())
+    ebin = rel_err(got["FL1"], ref["FL1"], 1e-300)
+    st["fl1_max_rel_bin_clean"] = float(ebin[clean].max()) if clean.any() else 0.0
+    st["fl1_frac_bins_gt_1e-5"] = float((ebin > 1e-5).mean())
+    dfim = np.asarray(tables.DFIM, dtype=np.float64)
+    hs_r = 4 * np.sqrt((ref["FL1"].astype(np.float64).sum(1) * dfim).sum(1))
+    hs_g = 4 * np.sqrt((got["FL1"].astype(np.float64).sum(1) * dfim).sum(1))
+    st["swh_max_rel"] = float(np.max(np.abs(hs_g - hs_r) / np.maximum(hs_r, 1e-12)))
+    for nm, idx, key in (("ff", FF_OUT, "FF"), ("intf", INTF_OUT, "INTF")):
+        r, g = ref[key][:, idx].astype(np.float64), got[key][:, idx].astype(np.float64)
+        scale = np.maximum(np.abs(r), np.abs(r).max(0, keepdims=True) * 1e-6 + 1e-300)
+        err = np.abs(g - r) / scale
+        st[f"{nm}_max_rel_clean"] = float(err[clean].max()) if clean.any() else 0.0
+        st[f"{nm}_max_rel_all"] = float(err.max())
+        st[f"{nm}_worst_col"] = int(idx[int(np.argmax(err.max(0)))])
+    return st

@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- grid-point spectral steps/sec of the WAMINTGR hot path on MI355X.
+
+One "step" = one WAMINTGR cycle on synthetic forcing: advection (halo exchange + PROPAGS2) + NEWWIND +
+IMPLSCH over every owned sea point, state resident in HBM.  Workload at N=1: octahedral
+O320 all-ocean grid (421 080 sea points), 36 directions x 36 frequencies, single precision -- the
+configuration BASELINE.json's metric is quoted on.  For N>1 (one process per GPU, launched by
+torch.distributed.run) the per-GPU work is held fixed (weak scaling): grid O<round(320*sqrt(N))>, sharded
+into contiguous sea-point ranges with a point-to-point halo exchange over RCCL.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from ecwam_amd import grid as G  # noqa: E402
+from ecwam_amd.tables import Config  # noqa: E402
+from ecwam_amd.wamintgr import Wamintgr  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def cpu_baseline(nang: int, nfre: int, prec: str, target_s: float = 15.0) -> dict:
+    """Oracle (plain-C restatement, OpenMP over points) timed on this host on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ecwam_amd import synthetic as syn
+    from ecwam_amd.tables import Tables
+    from oracle.oracle import Oracle
+
+    cfg = Config(nang=nang, nfre=nfre, nfre_red=nfre, idelt=450, idelpro=450)
+    dt = np.float32 if prec == "sp" else np.float64
+    t = Tables(cfg, dt)
+    o = Oracle(cfg, prec)
+    g = G.build_grid(48)
+    n = g.nsea
+    p = syn.point_params(n)
+    pr = syn.depth_props(p["DEPTH"], t, dt)
+    fl = np.zeros((n + 1, nang, nfre), dt)
+    fl[:n] = syn.jonswap_spectra(t.FR, t.TH, p["FP"], p["THETAQ"], dt)
+    ff = syn.forcing(p, slice(0, n), t, dt)
+    intf = np.zeros((n, syn.NINTF), dt)
+    env = np.stack([pr["EMAXDPT"], p["DEPTH"].astype(dt)], 1)
+    cg_ext = np.zeros((n + 1, nfre), dt)
+    cg_ext[:n] = pr["CGROUP"]
+    cg_ext[n] = syn.depth_props(np.array([998.999]), t, dt)["CGROUP"][0]
+    w = o.ctu_weights(g, cg_ext, float(cfg.idelpro))
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        f3 = o.propags2(g, fl, w)
+        r = o.implsch(f3[:n], pr["WAVNUM"], pr["CGROUP"], pr["CINV"], pr["XK2CG"], pr["STOKFAC"], env, ff, intf)
+        fl[:n], ff = r["FL1"], r["FF"]
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > target_s or steps >= 50:
+            break
+    return {"value": n * steps / el, "unit": "grid-point spectral steps/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"O48 all-ocean grid ({n} sea points), {nang}x{nfre} spectrum, {prec}, {steps} full steps "
+                      f"(PROPAGS2 + IMPLSCH), oracle/ C restatement with OpenMP over points"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--grid", type=int, default=0, help="octahedral resolution (default 320*sqrt(gpus))")
+    ap.add_argument("--prec", default="sp", choices=["sp", "dp"])
+    ap.add_argument("--nang", type=int, default=36)
+    ap.add_argument("--nfre", type=int, default=36)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ng = a.grid or int(round(320 * math.sqrt(world)))
+    # time step: 450 s at O320 (the 900 s of the reference's 24-direction O320 yml violates the CTU stability criterion
+    # with 36 directions near the poles of the all-ocean grid, ctuw.F90:637); scaled with the grid spacing beyond
+    dt = 450 if ng <= 320 else max(15, int(450 * 320 / ng) // 15 * 15)
+    cfg = Config(nang=a.nang, nfre=a.nfre, nfre_red=a.nfre, idelt=dt, idelpro=dt)
+    grid = G.build_grid(ng)
+    m = Wamintgr(cfg, grid, a.prec, device=local_rank, rank=rank, nranks=world)
+    m.init_synthetic()
+    nfail = m.build_weights()
+    if nfail:
+        raise SystemExit(f"CFL violated at {nfail} points")
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        m.step()
+    sync()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        e = ev[s]
+        m.halo(m.fl1) if world > 1 else None
+        e[0].record()
+        g = m.gd
+        m.ctx.propags2(m.fl1, m.fl3, g["klon"], g["klat"], g["kcor"], m.w, 0, m.n, 1, cfg.nfre_red, copy_rest=True)
+        e[1].record()
+        m.fl1, m.fl3 = m.fl3, m.fl1
+        m.newwind()
+        e[2].record()
+        m.implsch()
+        e[3].record()
+    sync()
+    el = time.perf_counter() - t0
+    t_prop = sum(e[0].elapsed_time(e[1]) for e in ev) / a.steps
+    t_impl = sum(e[2].elapsed_time(e[3]) for e in ev) / a.steps
+    if dist is not None:
+        tt = torch.tensor([el, t_prop, t_impl], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el, t_prop, t_impl = (float(x) for x in tt.cpu())
+    swh = m.swh()
+    finite = bool(torch.isfinite(swh).all().item())
+
+    if rank == 0:
+        w = 4 if a.prec == "sp" else 8
+        N, NR = a.nang * a.nfre, a.nang * cfg.nfre_red
+        b_impl = w * (3 * N + 5 * a.nfre + 55)          # F r+w, XLLWS w, 5 per-frequency props, ~55 scalars
+        b_prop = w * 10 * NR + 56                        # 8 weights + F1 + F3, 14 int32 neighbour ids
+        kern = {
+            "propags2": {"ms": t_prop, "alg_bytes": b_prop * m.n, "gbs": b_prop * m.n / t_prop / 1e6},
+            "implsch": {"ms": t_impl, "alg_bytes": b_impl * m.n, "gbs": b_impl * m.n / t_impl / 1e6},
+        }
+        dom = max(kern, key=lambda k: kern[k]["ms"])
+        out = {
+            "metric": "grid-point spectral steps/sec (whole node) at O320, 36dir x 36freq",
+            "value": grid.nsea * a.steps / el, "unit": "grid-point spectral steps/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if a.prec == "sp" else "f64", "data": "synthetic",
+            "config": {"workload": f"O{ng} all-ocean octahedral grid, {grid.nsea} sea points, {a.nang} dir x {a.nfre} freq "
+                                   f"(NFRE_RED={cfg.nfre_red}), full WAMINTGR step = PROPAGS2 advection + NEWWIND + IMPLSCH, "
+                                   f"IDELT=IDELPRO={dt} s, flag set A (IPHYS=1, ISNONLIN=0, LLGCBZ0=F, LLNORMAGAM=F)",
+                       "points_per_gpu": m.n, "halo_points": m.dom.nh, "parallelism": f"sea-point block x{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": None},
+            "kernels": kern,
+            "finite": finite,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.nang, a.nfre, a.prec)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

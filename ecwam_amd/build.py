@@ -12,6 +12,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libecwam_hip.so")
 SOURCES = ["capi.hip", "propag.hip", "implsch.hip"]
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+# IMPLSCH is VALU-issue bound: single-precision divide/sqrt by the hardware reciprocal / square root plus one
+# refinement (<= 2.5 ulp) instead of the correctly rounded sequences; double precision is unaffected.
+EXTRA = {"implsch.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 
 
@@ -32,7 +35,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC, *FLAGS, *EXTRA.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

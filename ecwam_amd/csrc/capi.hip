@@ -1,5 +1,6 @@
 // C ABI of libecwam_hip.so (include/ecwam_hip.h): context management and kernel launch entry points.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -48,6 +49,7 @@ static int build_tab(const ecwam_hip_params* p, const ecwam_hip_tables* t, DevTa
   d->LICERUN = p->licerun; d->LMASKICE = p->lmaskice; d->LWAMRSETCI = p->lwamrsetci; d->LWVFLX_SNL = p->lwvflx_snl;
   d->LWFLUX = p->lwflux; d->LCFLX = (p->lwflux || p->lwfluxout || p->lwnemocou); d->LWNEMOCOU = p->lwnemocou; d->LWCOU = p->lwcou;
   d->LWCOUAST = p->lwcouast; d->LWNEMOCOUWRS = p->lwnemocouwrs;
+  { const char* e_ = getenv("ECWAM_HIP_DEBUG_SKIP"); d->DBG_SKIP = e_ ? atoi(e_) : 0; }
   d->NSDSNTH = p->nsdsnth; d->NTAP = 2 * p->nsdsnth + 1; d->MFRSTLW = p->mfrstlw; d->MLSTHG = ML; d->KFRH = p->kfrh; d->NWAV_GC = p->nwav_gc;
 #define S_(dst, src) d->dst = (T)p->src
   S_(XIMP, ximp); S_(G, g); S_(GM1, gm1); S_(PI, pi); S_(ZPI, zpi); S_(ZPI4GM1, zpi4gm1); S_(ZPI4GM2, zpi4gm2); S_(EPSMIN, epsmin);
@@ -81,6 +83,27 @@ static int build_tab(const ecwam_hip_params* p, const ecwam_hip_tables* t, DevTa
       d->K1W[kh][k] = t->k1w[k * 2 + kh] - 1; d->K2W[kh][k] = t->k2w[k * 2 + kh] - 1;
       d->K11W[kh][k] = t->k11w[k * 2 + kh] - 1; d->K21W[kh][k] = t->k21w[k * 2 + kh] - 1;
     }
+  // structure check for the pull-form DIA kernel: K1W/K2W rotations, K11W/K21W = K1W/K2W +-1, row offsets -4,-3,+2,+3
+  d->DIA_PULL = 1;
+  for (int kh = 0; kh < 2 && d->DIA_PULL; kh++) {
+    const int s1 = ((d->K1W[kh][0] - 0) % NANG + NANG) % NANG, s2 = ((d->K2W[kh][0] - 0) % NANG + NANG) % NANG;
+    const int e1 = ((d->K11W[kh][0] - d->K1W[kh][0]) % NANG + NANG) % NANG, e2 = ((d->K21W[kh][0] - d->K2W[kh][0]) % NANG + NANG) % NANG;
+    if (!((e1 == 1 || e1 == NANG - 1) && (e2 == 1 || e2 == NANG - 1))) { d->DIA_PULL = 0; break; }
+    d->D11[kh] = (e1 == 1) ? 1 : -1;
+    d->D21[kh] = (e2 == 1) ? 1 : -1;
+    for (int k = 0; k < NANG; k++) {
+      if (d->K1W[kh][k] != (k + s1) % NANG || d->K2W[kh][k] != (k + s2) % NANG || d->K11W[kh][k] != (k + s1 + e1) % NANG ||
+          d->K21W[kh][k] != (k + s2 + e2) % NANG) { d->DIA_PULL = 0; break; }
+      d->IK1[kh][(k + s1) % NANG] = k;
+      d->IK2[kh][(k + s2) % NANG] = k;
+    }
+  }
+  for (int i = 0; i < ML && d->DIA_PULL; i++) {
+    const int MC = i + 1;
+    if (t->ikp[i] != MC + 2 || t->ikp1[i] != MC + 3) d->DIA_PULL = 0;
+    if (t->ikm[i] != MC - 4 || t->ikm1[i] != MC - 3) d->DIA_PULL = 0;
+  }
+  if (ML != NFRE + 4 || p->kfrh != 8 || p->mfrstlw != -3) d->DIA_PULL = 0;
   for (int i = 0; i < ML; i++) {
     for (int j = 0; j < 5; j++) d->INLCOEF[i][j] = t->inlcoef[i * 5 + j] - 1;
     for (int j = 0; j < 25; j++) d->RNLCOEF[i][j] = ((const T*)t->rnlcoef)[i * 25 + j];

@@ -20,6 +20,7 @@ struct DevTab {
   int LLGCBZ0, LLNORMAGAM, LLCAPCHNK, LBIWBK, LICERUN, LMASKICE, LWAMRSETCI;
   int LWVFLX_SNL, LWFLUX, LCFLX, LWNEMOCOU, LWCOU, LWCOUAST, LWNEMOCOUWRS;
   int NSDSNTH, NTAP, MFRSTLW, MLSTHG, KFRH, NWAV_GC;
+  int DBG_SKIP;  // timing diagnostics only (env ECWAM_HIP_DEBUG_SKIP): bit mask of IMPLSCH phases to skip
   T XIMP, G, GM1, PI, ZPI, ZPI4GM1, ZPI4GM2, EPSMIN, ROWATER, ROWATERM1, EPSUS, EPSU10, ACD, BCD, ACDLIN, BCDLIN, CDMAX;
   T TAUOCMIN, TAUOCMAX, PHIEPSMIN, PHIEPSMAX, WSEMEAN_MIN, CIRC, R;
   T FRATIO, WETAIL, FRTAIL, WP1TAIL, FRIC, DELTH, FLOGSPRDM1;
@@ -41,6 +42,9 @@ struct DevTab {
   int IKP[MAXMC], IKP1[MAXMC], IKM[MAXMC], IKM1[MAXMC];  // 1-based frequency values as in the reference
   T AF11[MAXMC];
   int K1W[2][MAXA], K2W[2][MAXA], K11W[2][MAXA], K21W[2][MAXA];  // [kh][k], 0-based direction
+  // pull form of the DIA (implsch.hip snonlin_pull): inverse rotations IK*[kh][c] = the lane whose K*W target is c,
+  // D11/D21[kh] = K11W-K1W / K21W-K2W (+1 or -1 mod NANG); DIA_PULL = 1 when the tables have the rotation structure
+  int IK1[2][MAXA], IK2[2][MAXA], D11[2], D21[2], DIA_PULL;
   int INLCOEF[MAXMC][5];                                         // 0-based frequency
   T RNLCOEF[MAXMC][25];
   // saturation filter: [k2][k] so that lanes (k) read consecutive words
@@ -102,16 +106,62 @@ __device__ __forceinline__ double lane_get(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
-// all-lanes reductions; inactive lanes must contribute the identity
+// ---- DPP cross-lane moves (no LDS traffic): dst lane reads the lane selected by CTRL -----------------
+// CTRL: 0xB1 quad_perm[1,0,3,2], 0x4E quad_perm[2,3,0,1], 0x141 row_half_mirror, 0x140 row_mirror,
+//       0x142 row_bcast:15, 0x143 row_bcast:31, 0x138 wave_shr:1 (lane c <- c-1), 0x130 wave_shl:1 (lane c <- c+1)
+template <int CTRL, int ROWMASK = 0xF>
+__device__ __forceinline__ float dpp_mov(float v, float old = 0.f) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROWMASK, 0xF, false));
+}
+template <int CTRL, int ROWMASK = 0xF>
+__device__ __forceinline__ double dpp_mov(double v, double old = 0.0) {
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROWMASK, 0xF, false);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROWMASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Wave-uniform reductions: 4 DPP butterfly steps inside each row of 16 lanes, two row broadcasts, and a
+// v_readlane of lane 63 (result in SGPRs).  Inactive lanes must contribute the identity (0 / -inf..0).
 template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-  return v;
+__device__ __forceinline__ T usum(T v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  v += dpp_mov<0x142, 0xA>(v);
+  v += dpp_mov<0x143, 0xC>(v);
+  return lane_get(v, 63);
 }
 template <typename T>
-__device__ __forceinline__ T wave_max(T v) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) v = m_max(v, __shfl_xor(v, o, 64));
-  return v;
+__device__ __forceinline__ T umax(T v) {  // for values >= 0 (identity 0)
+  v = m_max(v, dpp_mov<0xB1>(v, v));
+  v = m_max(v, dpp_mov<0x4E>(v, v));
+  v = m_max(v, dpp_mov<0x141>(v, v));
+  v = m_max(v, dpp_mov<0x140>(v, v));
+  v = m_max(v, dpp_mov<0x142, 0xA>(v, v));
+  v = m_max(v, dpp_mov<0x143, 0xC>(v, v));
+  return lane_get(v, 63);
+}
+
+// rotation by one lane inside the first n lanes: rot_up: lane c <- c-1 (lane 0 <- n-1); rot_dn: lane c <- c+1 (n-1 <- 0)
+template <typename T>
+__device__ __forceinline__ T rot_up(T v, int lane, int n) {
+  const T w = lane_get(v, n - 1);
+  const T s = dpp_mov<0x138>(v);
+  return lane == 0 ? w : s;
+}
+template <typename T>
+__device__ __forceinline__ T rot_dn(T v, int lane, int n) {
+  const T w = lane_get(v, 0);
+  const T s = dpp_mov<0x130>(v);
+  return lane == n - 1 ? w : s;
+}
+// arbitrary pull: every lane reads lane src (ds_bpermute: LDS crossbar, no LDS memory)
+__device__ __forceinline__ float lane_pull(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ double lane_pull(double v, int src) {
+  int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
+  int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
+  return __hiloint2double(hi, lo);
 }

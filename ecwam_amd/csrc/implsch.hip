@@ -26,11 +26,6 @@ struct Lane {
   bool actm;   // lane < NFRE
 };
 
-template <typename T>
-__device__ __forceinline__ T usum(T v) { return lane_get(wave_sum(v), 0); }
-template <typename T>
-__device__ __forceinline__ T umax(T v) { return lane_get(wave_max(v), 0); }
-
 // TEMP2(M) = SUM_K F(K,M) in the reference's order (K sequential), lane m gets M=m+1
 template <typename T>
 __device__ __forceinline__ T colsum(const T* sF, const Lane<T>& L) {
@@ -252,8 +247,15 @@ __device__ void sinput_ard(const DevTab<T>& tb, const T* sF, T* sFLD, T* sSPOS, 
     ROGOROAIR = tb.G / RAORW;
   }
   GAMNORMA[0] = T(1); GAMNORMA[1] = T(1);
-  const T thk = tb.TH[L.k], sinthk = tb.SINTH[L.k], costhk = tb.COSTH[L.k];
+  const T sinthk = tb.SINTH[L.k], costhk = tb.COSTH[L.k];
   xmask = 0ull;
+  // per-frequency scalars that need a transcendental: evaluated once, lane m for M=m+1, broadcast in the loop
+  T rZCN = T(0), rCOEF5 = T(0);
+  if (L.actm) {
+    rZCN = m_log(rWAVNUM * Z0M);
+    if (LLSNEG) rCOEF5 = -tb.SWELLF5 * T(2) * m_sqrt(T(2) * NU_AIR * tb.ZPIFR[L.lane]);
+  }
+  T COSU[2], SINU[2];  // cos/sin of the sheltered stress direction USDIRP = ATAN2(TAUPX,TAUPY)
 
   for (int m = 0; m < L.NFRE; m++) {
     const T SIG = tb.ZPIFR[m];
@@ -263,16 +265,21 @@ __device__ void sinput_ard(const DevTab<T>& tb, const T* sF, T* sFLD, T* sSPOS, 
     T COEF = T(0), COEF5 = T(0);
     if (LLSNEG) {
       COEF = -tb.SWELLF * T(16) * SIG2 / tb.G;
-      COEF5 = -tb.SWELLF5 * T(2) * m_sqrt(T(2) * NU_AIR * SIG);
+      COEF5 = lane_get(rCOEF5, m);
     }
     T CONSTF = T(0);
     if (LTAUWSHELTER) {
 #pragma unroll
       for (int ig = 0; ig < NGST; ig++) {
+        // sinput_ard.F90:360-364.  COS(TH(K)-USDIRP) is formed below from cos/sin(USDIRP) = TAUPY/|TAUP|, TAUPX/|TAUP|
+        // (no ATAN2/COS per lane) and USTP = |TAUP|**0.5 as two square roots: algebraically identical evaluation.
         T TAUPX = TAUX[ig] - ABS_TAUWSHELTER * XSTRESS[ig];
         T TAUPY = TAUY[ig] - ABS_TAUWSHELTER * YSTRESS[ig];
-        USDIRP[ig] = m_atan2(TAUPX, TAUPY);
-        USTP[ig] = m_pow(TAUPX * TAUPX + TAUPY * TAUPY, T(0.25));
+        const T h = m_sqrt(TAUPX * TAUPX + TAUPY * TAUPY);
+        const bool zero = !(h > T(0));
+        COSU[ig] = zero ? T(1) : TAUPY / h;
+        SINU[ig] = zero ? T(0) : TAUPX / h;
+        USTP[ig] = m_sqrt(h);
         USTPM1[ig] = T(1) / m_max(USTP[ig], tb.EPSUS);
       }
       CONSTF = ROGOROAIR * cinv_m * tb.DFIM[m];
@@ -282,7 +289,7 @@ __device__ void sinput_ard(const DevTab<T>& tb, const T* sF, T* sFLD, T* sSPOS, 
       UCN[ig] = USTP[ig] * cinv_m;
       UCNZALPD[ig] = tb.XKAPPA / (UCN[ig] + tb.ZALP);
     }
-    const T ZCN = m_log(wavnum_m * Z0M);
+    const T ZCN = lane_get(rZCN, m);
     const T CNSN = CONST * RAORW;
     T XNGAMCONST = T(0);
     if (LLNORMAGAM) XNGAMCONST = CSTRNFAC * lane_get(rXK2CG, m);
@@ -296,7 +303,7 @@ __device__ void sinput_ard(const DevTab<T>& tb, const T* sF, T* sFLD, T* sSPOS, 
     bool xl = false;
 #pragma unroll
     for (int ig = 0; ig < NGST; ig++) {
-      T coslp = LTAUWSHELTER ? m_cos(thk - USDIRP[ig]) : coswdif;
+      T coslp = LTAUWSHELTER ? (costhk * COSU[ig] + sinthk * SINU[ig]) : coswdif;
       T gam0 = T(0);
       if (coslp > T(0.01)) {
         T X = coslp * UCN[ig];
@@ -374,13 +381,21 @@ __device__ void tau_phi_hf(const DevTab<T>& tb, const T* sF, const Lane<T>& L, i
   const T ZSUP = T(0);
   T TAUL = UST * UST;
   T DELZ = m_max((ZSUP - ZINF) / T(JTOT - 1), T(0));
+  // the 19 integration nodes do not depend on the sheltered friction velocity: evaluate Y, CM1 and
+  // XLOGGZ0+2*LOG(CM1) lane-parallel (lane J), leaving one EXP, one divide and one SQRT per sequential step
+  T rY = T(1), rCM1 = T(1), rLC = T(0);
+  if (L.lane < JTOT) {
+    rY = m_exp(ZINF + T(L.lane) * DELZ);
+    rCM1 = (rY * SQRTGZ0) * tb.GM1;
+    rLC = XLOGGZ0 + T(2) * m_log(rCM1);
+  }
   TAUHF = T(0);
   if (LTAUWSHELTER) {
     for (int J = 0; J < JTOT; J++) {
-      T Y = m_exp(ZINF + T(J) * DELZ);
-      T CM1 = (Y * SQRTGZ0) * tb.GM1;
+      const T Y = lane_get(rY, J);
+      const T CM1 = lane_get(rCM1, J);
       T ZARG = tb.XKAPPA / (UST * CM1 + tb.ZALP);
-      T ZLOG = m_min(XLOGGZ0 + T(2) * m_log(CM1) + ZARG, T(0));
+      T ZLOG = m_min(lane_get(rLC, J) + ZARG, T(0));
       T ZBETA = m_pow4(ZLOG) * m_exp(ZLOG);
       T ZNZ = ZBETA * UST * Y;
       T GAMNORMA = (T(1) + CONST1 * ZNZ) / (T(1) + CONST2 * ZNZ);
@@ -391,10 +406,10 @@ __device__ void tau_phi_hf(const DevTab<T>& tb, const T* sF, const Lane<T>& L, i
     }
   } else {
     for (int J = 0; J < JTOT; J++) {
-      T Y = m_exp(ZINF + T(J) * DELZ);
-      T CM1 = (Y * SQRTGZ0) * tb.GM1;
+      const T Y = lane_get(rY, J);
+      const T CM1 = lane_get(rCM1, J);
       T ZARG = tb.XKAPPA / (UST * CM1 + tb.ZALP);
-      T ZLOG = m_min(XLOGGZ0 + T(2) * m_log(CM1) + ZARG, T(0));
+      T ZLOG = m_min(lane_get(rLC, J) + ZARG, T(0));
       T ZBETA = m_pow4(ZLOG) * m_exp(ZLOG);
       T FNC2 = ZBETA * tb.WTAUHF[J];
       T ZNZ = ZBETA * UST * Y;
@@ -410,10 +425,10 @@ __device__ void tau_phi_hf(const DevTab<T>& tb, const T* sF, const Lane<T>& L, i
     const T CONSTPHI = AIRD * tb.ZPI4GM1 * fr5;
     if (LTAUWSHELTER) {
       for (int J = 0; J < JTOT; J++) {
-        T Y = m_exp(ZINF + T(J) * DELZ);
-        T CM1 = (Y * SQRTGZ0) * tb.GM1;
+        const T Y = lane_get(rY, J);
+        const T CM1 = lane_get(rCM1, J);
         T ZARG = tb.XKAPPA / (USTPH * CM1 + tb.ZALP);
-        T ZLOG = m_min(XLOGGZ0 + T(2) * m_log(CM1) + ZARG, T(0));
+        T ZLOG = m_min(lane_get(rLC, J) + ZARG, T(0));
         T ZBETA = m_pow4(ZLOG) * m_exp(ZLOG);
         T ZNZ = ZBETA * UST * Y;
         T GAMNORMA = (T(1) + CONST1 * ZNZ) / (T(1) + CONST2 * ZNZ);
@@ -425,10 +440,10 @@ __device__ void tau_phi_hf(const DevTab<T>& tb, const T* sF, const Lane<T>& L, i
       PHIHF = F1DCOS2 * CONSTPHI * SQRTZ0OG * PHIHF;
     } else {
       for (int J = 0; J < JTOT; J++) {
-        T Y = m_exp(ZINF + T(J) * DELZ);
-        T CM1 = (Y * SQRTGZ0) * tb.GM1;
+        const T Y = lane_get(rY, J);
+        const T CM1 = lane_get(rCM1, J);
         T ZARG = tb.XKAPPA / (USTPH * CM1 + tb.ZALP);
-        T ZLOG = m_min(XLOGGZ0 + T(2) * m_log(CM1) + ZARG, T(0));
+        T ZLOG = m_min(lane_get(rLC, J) + ZARG, T(0));
         T ZBETA = m_pow4(ZLOG) * m_exp(ZLOG);
         T ZNZ = ZBETA * UST * Y;
         T GAMNORMA = (T(1) + CONST1 * ZNZ) / (T(1) + CONST2 * ZNZ);
@@ -575,12 +590,104 @@ __device__ void snonlin(const DevTab<T>& tb, const T* sF, T* sFLD, T* sSL, const
 #undef ADDF
 }
 
+// snonlin.F90:126-494 in "pull" form (used when the DIA tables have their regular structure, DevTab::DIA_PULL):
+//   * K1W/K2W are rotations of the direction index and K11W/K21W their +-1 neighbours, so the 4-point gathers
+//     SAP/SAM become one lane rotation of a locally combined value, and the scatters into (K1,MP), (K11,MP), ... become
+//     pulls of AD/DELAP/DELAM through the inverse rotation (ds_bpermute: crossbar only) plus a one-lane DPP rotate;
+//   * the target rows of interaction MC are MC-4, MC-3, MC, MC+2, MC+3, so SL/FLD increments are accumulated in an
+//     8-row register ring (compile-time slots via unrolling MC by 8) and each row is added to the LDS tile once,
+//     when it leaves the window.  Rows outside 1..NFRE are dropped, which is what the reference's edge branches do.
+// LDS instructions per MC: 5 own-column reads of F + 12 bpermutes + 2 RMW, against 9+36 per (MC,KH) in scatter form.
+template <typename T>
+__device__ void snonlin_pull(const DevTab<T>& tb, const T* sF, T* sFLD, T* sSL, const Lane<T>& L, T DEPTH, T AKMEAN) {
+  T ENHFR = m_max(T(0.75) * DEPTH * AKMEAN, T(0.5));
+  ENHFR = T(1) + (T(5.5) / ENHFR) * (T(1) - T(.833) * ENHFR) * m_exp(-T(1.25) * ENHFR);
+  const int NAP = L.NAP, NFRE = L.NFRE, NANG = L.NANG, k = L.k, lane = L.lane;
+  const int MFR1STFR = -tb.MFRSTLW + 1;
+  const int MFRLSTFR = NFRE - tb.KFRH + MFR1STFR;
+  int k1[2], k2[2], ik1[2], ik2[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; kh++) { k1[kh] = tb.K1W[kh][k]; k2[kh] = tb.K2W[kh][k]; ik1[kh] = tb.IK1[kh][k]; ik2[kh] = tb.IK2[kh][k]; }
+  const bool up11[2] = {tb.D11[0] > 0, tb.D11[1] > 0}, up21[2] = {tb.D21[0] > 0, tb.D21[1] > 0};
+  T aS[8], aF[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { aS[i] = T(0); aF[i] = T(0); }
+  for (int MCb = 0; MCb < tb.MLSTHG; MCb += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int MC = MCb + 1 + j;
+      if (MC <= tb.MLSTHG) {
+        constexpr int dummy = 0;
+        const int c0 = (1 + j) & 7, cm = (1 + j + 4) & 7, cm1 = (1 + j + 5) & 7, cp = (1 + j + 2) & 7, cp1 = (1 + j + 3) & 7;  // rows MC, MC-4, MC-3, MC+2, MC+3
+        const int IC = tb.INLCOEF[MC - 1][0], IP = tb.INLCOEF[MC - 1][1], IP1 = tb.INLCOEF[MC - 1][2];
+        const int IM = tb.INLCOEF[MC - 1][3], IM1 = tb.INLCOEF[MC - 1][4];
+        const T* R = tb.RNLCOEF[MC - 1];
+        const T FTAIL = R[0], GW1 = R[1], GW2 = R[2], GW3 = R[3], GW4 = R[4];
+        const T FKLAMPA = R[5], FKLAMPB = R[6], FKLAMP2 = R[7], FKLAMP1 = R[8];
+        const T FKLAPA2 = R[9], FKLAPB2 = R[10], FKLAP12 = R[11], FKLAP22 = R[12];
+        const T GW5 = R[13], GW6 = R[14], GW7 = R[15], GW8 = R[16];
+        const T FKLAMMA = R[17], FKLAMMB = R[18], FKLAMM2 = R[19], FKLAMM1 = R[20];
+        const T FKLAMA2 = R[21], FKLAMB2 = R[22], FKLAM12 = R[23], FKLAM22 = R[24];
+        const T FTEMP = tb.AF11[MC - 1] * ENHFR;
+        const bool mid = (MC > MFR1STFR && MC < MFRLSTFR);
+        const T fIP = sF[IP * NAP + k], fIP1 = sF[IP1 * NAP + k], fIM = sF[IM * NAP + k], fIM1 = sF[IM1 * NAP + k];
+        T FIJ = sF[IC * NAP + k];
+        if (!mid) FIJ = FIJ * FTAIL;
+        const T up = GW1 * fIP + GW3 * fIP1, vp = GW2 * fIP + GW4 * fIP1;
+        const T um = GW5 * fIM + GW7 * fIM1, vm = GW6 * fIM + GW8 * fIM1;
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++) {
+          // SAP(k) = up[k1] + vp[k11], k11 = k1 + d11:  y[j] = up[j] + vp[j+d11]; SAP = y[k1]
+          const T yp = up + (up11[kh] ? rot_dn(vp, lane, NANG) : rot_up(vp, lane, NANG));
+          const T ym = um + (up21[kh] ? rot_dn(vm, lane, NANG) : rot_up(vm, lane, NANG));
+          const T SAP = lane_pull(yp, k1[kh]);
+          const T SAM = lane_pull(ym, k2[kh]);
+          T FAD1 = FIJ * (SAP + SAM);
+          const T FAD2 = FAD1 - T(2) * SAP * SAM;
+          FAD1 = FAD1 + FAD2;
+          const T FCEN = FTEMP * FIJ;
+          const T AD = FAD2 * FCEN;
+          const T DELAD = FAD1 * FTEMP;
+          const T DELAP = (FIJ - T(2) * SAM) * tb.DAL1 * FCEN;
+          const T DELAM = (FIJ - T(2) * SAP) * tb.DAL2 * FCEN;
+          // increments arriving at column c: from the lane whose K2 (K1) is c, and from the one whose K21 (K11) is c
+          const T A2 = lane_pull(AD, ik2[kh]), D2 = lane_pull(DELAM, ik2[kh]);
+          const T A1 = lane_pull(AD, ik1[kh]), P1 = lane_pull(DELAP, ik1[kh]);
+          const T A2s = up21[kh] ? rot_up(A2, lane, NANG) : rot_dn(A2, lane, NANG);
+          const T D2s = up21[kh] ? rot_up(D2, lane, NANG) : rot_dn(D2, lane, NANG);
+          const T A1s = up11[kh] ? rot_up(A1, lane, NANG) : rot_dn(A1, lane, NANG);
+          const T P1s = up11[kh] ? rot_up(P1, lane, NANG) : rot_dn(P1, lane, NANG);
+          aS[c0] -= T(2) * AD;
+          aF[c0] -= T(2) * DELAD;
+          aS[cm] += A2 * FKLAMM1 + A2s * FKLAMM2;
+          aF[cm] += D2 * FKLAM12 + D2s * FKLAM22;
+          aS[cm1] += A2 * FKLAMMA + A2s * FKLAMMB;
+          aF[cm1] += D2 * FKLAMA2 + D2s * FKLAMB2;
+          aS[cp] += A1 * FKLAMP1 + A1s * FKLAMP2;
+          aF[cp] += P1 * FKLAP12 + P1s * FKLAP22;
+          aS[cp1] += A1 * FKLAMPA + A1s * FKLAMPB;
+          aF[cp1] += P1 * FKLAPA2 + P1s * FKLAPB2;
+        }
+        (void)dummy;
+        const int r = MC - 4;  // this row receives nothing from later interactions
+        if (r >= 1 && r <= NFRE && L.act) {
+          sSL[(r - 1) * NAP + k] += aS[cm];
+          sFLD[(r - 1) * NAP + k] += aF[cm];
+        }
+        aS[cm] = T(0);
+        aF[cm] = T(0);
+      }
+    }
+  }
+}
+
 template <typename T, int WPB>
 __global__ void __launch_bounds__(64 * WPB) k_implsch(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__ fl1,
                                                       const T* __restrict__ wvprpt, T* __restrict__ ffa, T* __restrict__ intfa,
                                                       int* __restrict__ mij_out, T* __restrict__ xllws, T* __restrict__ dbg) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const DevTab<T>& tb = *tp;
+  const int SKIP = tb.DBG_SKIP;  // 0 in production; timing diagnostics only
   const int wave = threadIdx.x >> 6;
   const int ij = kijs + blockIdx.x * WPB + wave;
   if (ij >= kijl) return;  // wave-uniform; no block-level barrier is used anywhere below
@@ -599,11 +706,10 @@ __global__ void __launch_bounds__(64 * WPB) k_implsch(const DevTab<T>* __restric
   // ---- load the spectrum FL1[ij][K][M] (coalesced) into the [M][NAP] tile
   {
     const T* g = fl1 + (size_t)ij * N;
-    int kk = L.lane / NFRE, mm = L.lane - kk * NFRE;
+    const float rnf = 1.0f / (float)NFRE;  // e/NFRE by a float multiply: (e+0.5)/NFRE is never within 1e-2 of an integer
     for (int e = L.lane; e < N; e += 64) {
+      const int kk = (int)(((float)e + 0.5f) * rnf), mm = e - kk * NFRE;
       sF[mm * NAP + kk] = g[e];
-      mm += 64;
-      while (mm >= NFRE) { mm -= NFRE; kk++; }
     }
   }
   // per-frequency point properties: lane m holds M=m+1
@@ -660,8 +766,9 @@ __global__ void __launch_bounds__(64 * WPB) k_implsch(const DevTab<T>* __restric
       if (L.act) sF[(NFRE - 1) * NAP + L.k] = m_max(sF[(NFRE - 1) * NAP + L.k], FLM);
       WSYNC();
     }
-    taut_z0_a(tb, IUSFG, WSWAVE, WDWAVE, TAUW, TAUWDIR, UFRIC, Z0M, Z0B, CHRNCK);
-    if (ICALL == 1)
+    if (!(SKIP & 16)) taut_z0_a(tb, IUSFG, WSWAVE, WDWAVE, TAUW, TAUWDIR, UFRIC, Z0M, Z0B, CHRNCK);
+    if (SKIP & 1) {
+    } else if (ICALL == 1)
       sinput_ard<T, 1, false>(tb, sF, sFLD, sSL, L, rWAVNUM, rCINV, rXK2CG, WDWAVE, WSWAVE, UFRIC, Z0M, coswdif, sinwdif2, RAORW,
                               WSTAR, RNFAC, xmask);
     else
@@ -688,7 +795,7 @@ __global__ void __launch_bounds__(64 * WPB) k_implsch(const DevTab<T>* __restric
       }
     }
     // STRESSO (stresso.F90:125-229)
-    {
+    if (!(SKIP & 2)) {
       const bool LLPHIWA = (ICALL == 2);
       T ax = T(0), at = T(0), ap = T(0);
       for (int m = 0; m < NFRE; m++) {
@@ -733,13 +840,16 @@ __global__ void __launch_bounds__(64 * WPB) k_implsch(const DevTab<T>* __restric
   }
 
   // ---- SDISSIP (also rebuilds SL = FLD*F from the wind input)
-  if (tb.NTAP == 17) sdissip_ard<T, 17>(tb, sF, sFLD, sSL, L, rWAVNUM, rXK2CG, UFRIC, coswdif, RAORW);
+  if (SKIP & 4) {
+  } else if (tb.NTAP == 17) sdissip_ard<T, 17>(tb, sF, sFLD, sSL, L, rWAVNUM, rXK2CG, UFRIC, coswdif, RAORW);
   else if (tb.NTAP == 11) sdissip_ard<T, 11>(tb, sF, sFLD, sSL, L, rWAVNUM, rXK2CG, UFRIC, coswdif, RAORW);
   else if (tb.NTAP == 7) sdissip_ard<T, 7>(tb, sF, sFLD, sSL, L, rWAVNUM, rXK2CG, UFRIC, coswdif, RAORW);
   else sdissip_ard<T, 0>(tb, sF, sFLD, sSL, L, rWAVNUM, rXK2CG, UFRIC, coswdif, RAORW);
   WSYNC();
   // ---- SNONLIN
-  snonlin(tb, sF, sFLD, sSL, L, DEPTH, AKMEAN);
+  if (SKIP & 8) {
+  } else if (tb.DIA_PULL) snonlin_pull(tb, sF, sFLD, sSL, L, DEPTH, AKMEAN);
+  else snonlin(tb, sF, sFLD, sSL, L, DEPTH, AKMEAN);
   WSYNC();
 
   // ---- SSOURCE, SDIWBK, SBOTTOM, new spectrum, WNFLUXES integrals: one pass (implsch.F90:294-395)
@@ -766,7 +876,7 @@ __global__ void __launch_bounds__(64 * WPB) k_implsch(const DevTab<T>* __restric
   }
   const T USFM = UFRIC * m_max(FMEANWS, FMEAN);
   T a_t = T(0), a_x = T(0);
-  for (int m = 0; m < NFRE; m++) {
+  for (int m = (SKIP & 32) ? NFRE : 0; m < NFRE; m++) {
     T fld = sFLD[m * NAP + L.k], sl = sSL[m * NAP + L.k];
     const T f = sF[m * NAP + L.k];
     T ss = T(0);
@@ -876,12 +986,11 @@ __global__ void __launch_bounds__(64 * WPB) k_implsch(const DevTab<T>* __restric
   {
     T* g = fl1 + (size_t)ij * N;
     T* gx = xllws + (size_t)ij * N;
-    int kk = L.lane / NFRE, mm = L.lane - kk * NFRE;
+    const float rnf = 1.0f / (float)NFRE;
     for (int e = L.lane; e < N; e += 64) {
+      const int kk = (int)(((float)e + 0.5f) * rnf), mm = e - kk * NFRE;
       g[e] = sF[mm * NAP + kk];
       gx[e] = sSL[mm * NAP + kk];
-      mm += 64;
-      while (mm >= NFRE) { mm -= NFRE; kk++; }
     }
   }
   if (L.lane == 0) {
@@ -912,10 +1021,13 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
   if (n <= 0) return 0;
   const int NAP = NANG | 1;
   const size_t per_wave = (size_t)(3 * NFRE * NAP + 64) * sizeof(T);
-  // waves per block: as many as keep >= 2 blocks per CU within 160 KiB of LDS
-  int wpb = 4;
-  while (wpb > 1 && per_wave * wpb > 80 * 1024) wpb >>= 1;
-  if (per_wave * wpb > 160 * 1024) return 1;
+  // waves per block (4, 2 or 1): the choice that fits the most waves into the 160 KiB of LDS of a CU
+  int wpb = 1, best = 0;
+  for (int cand = 4; cand >= 1; cand >>= 1) {
+    const int waves = (int)((160 * 1024) / (per_wave * cand)) * cand;
+    if (waves > best) { best = waves; wpb = cand; }
+  }
+  if (best == 0) return 1;
   const size_t shmem = per_wave * wpb;
   const int blocks = (n + wpb - 1) / wpb;
 #define LAUNCH(W)                                                                                                            \

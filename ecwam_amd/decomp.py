@@ -1,0 +1,97 @@
+"""Sea-point block decomposition for the multi-GPU path (one process per GPU).
+
+Mirrors the reference's 1-D latitude-band decomposition (mpdecomp.F90:58-100, LL1D): the
+south->north sea-point list is cut into contiguous ranges of (almost) equal point counts; each
+rank renumbers its neighbour tables into local indices [0,n) owned, [n,n+nh) halo (sorted by global
+index, hence grouped by owner), nland = n+nh for land ("NSUP+1").  The advection halo exchange
+(mpexchng.F90:141-206) then is: pack the owned points each neighbouring rank needs, exchange
+point-to-point, receive straight into the contiguous halo segment of that rank.
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+
+def split_points(nsea: int, nranks: int) -> np.ndarray:
+    """bounds[r]..bounds[r+1] = range of rank r (mpdecomp.F90: equal counts, remainder to the first ranks)."""
+    base, rem = divmod(nsea, nranks)
+    counts = np.full(nranks, base, dtype=np.int64)
+    counts[:rem] += 1
+    return np.concatenate([[0], np.cumsum(counts)])
+
+
+def _halo_global(grid, lo: int, hi: int) -> np.ndarray:
+    nb = np.concatenate([grid.klon[lo:hi].ravel(), grid.klat[lo:hi].ravel(), grid.kcor[lo:hi].ravel()]).astype(np.int64)
+    nb = nb[(nb != grid.nland) & ((nb < lo) | (nb >= hi))]
+    return np.unique(nb)
+
+
+@dataclasses.dataclass
+class LocalDomain:
+    rank: int
+    nranks: int
+    lo: int
+    hi: int
+    n: int                      # owned points
+    nh: int                     # halo points
+    halo_global: np.ndarray     # [nh] global indices, sorted
+    klon: np.ndarray            # local numbering
+    klat: np.ndarray
+    kcor: np.ndarray
+    kxlt: np.ndarray            # [n]
+    cosphm1_ext: np.ndarray     # [n+nh+1]
+    send: dict                  # peer -> local owned indices to send (int32, ordered by global index)
+    recv: dict                  # peer -> (dst0 local row, count)
+
+    @property
+    def nland(self) -> int:
+        return self.n + self.nh
+
+    @property
+    def nrows(self) -> int:
+        return self.n + self.nh + 1
+
+    def ext_global(self) -> np.ndarray:
+        """global index of every local row except land"""
+        return np.concatenate([np.arange(self.lo, self.hi), self.halo_global])
+
+
+def local_domain(grid, rank: int, nranks: int) -> LocalDomain:
+    bounds = split_points(grid.nsea, nranks)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    n = hi - lo
+    halo = _halo_global(grid, lo, hi)
+    nh = halo.size
+    nland = n + nh
+
+    def renum(a):
+        a = a[lo:hi].astype(np.int64)
+        out = np.full(a.shape, nland, dtype=np.int64)
+        own = (a >= lo) & (a < hi)
+        out[own] = a[own] - lo
+        ish = ~own & (a != grid.nland)
+        out[ish] = n + np.searchsorted(halo, a[ish])
+        return out.astype(np.int32)
+
+    cos_ext = np.zeros(nland + 1)
+    full = grid.cosphm1_ext
+    cos_ext[:n] = full[lo:hi]
+    cos_ext[n:nland] = full[halo]
+    owner = np.searchsorted(bounds, halo, side="right") - 1
+    recv, send = {}, {}
+    for p in np.unique(owner):
+        idx = np.flatnonzero(owner == p)
+        assert np.all(np.diff(idx) == 1)
+        recv[int(p)] = (n + int(idx[0]), int(idx.size))
+    for p in range(nranks):
+        if p == rank:
+            continue
+        ph = _halo_global(grid, int(bounds[p]), int(bounds[p + 1]))
+        mine = ph[(ph >= lo) & (ph < hi)]
+        if mine.size:
+            send[p] = (mine - lo).astype(np.int32)
+    return LocalDomain(rank=rank, nranks=nranks, lo=lo, hi=hi, n=n, nh=nh, halo_global=halo, klon=renum(grid.klon),
+                       klat=renum(grid.klat), kcor=renum(grid.kcor), kxlt=grid.kxlt[lo:hi].astype(np.int32),
+                       cosphm1_ext=cos_ext, send=send, recv=recv)

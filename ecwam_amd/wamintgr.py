@@ -1,0 +1,159 @@
+"""WAMINTGR on the device: the reference's per-step call sequence (wamintgr.F90:94-146)
+
+    IF (CDATE == CDTPRA) CALL PROPAG_WAM      -> halo exchange (MPEXCHNG) + PROPAGS2 (+ fast-wave sub-steps)
+    CALL NEWWIND                              -> forcing hand-over when a new wind field is due
+    IF (CDATE >= CDTIMPNEXT) CALL IMPLSCH     -> source-term integration of every owned point
+
+with the state resident in HBM between steps (the GPU variant's behaviour, wamintgr_loki_gpu.F90:99-201).
+One instance = one rank = one GPU; ranks own contiguous sea-point ranges (decomp.py) and exchange
+halo spectra point-to-point through torch.distributed (backend "nccl" = RCCL over xGMI).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import api, decomp, synthetic as syn
+from .tables import Config, Tables
+
+
+class HaloExchange:
+    """MPEXCHNG (mpexchng.F90:141-206): pack -> isend/irecv per neighbouring rank -> halo rows."""
+
+    def __init__(self, dom: decomp.LocalDomain, device, ctx=None):
+        self.dom = dom
+        self.ctx = ctx
+        self.send_idx = {p: torch.from_numpy(np.ascontiguousarray(ix)).to(device) for p, ix in dom.send.items()}
+        self.bufs = {}
+
+    def __call__(self, fl: torch.Tensor) -> None:
+        if self.dom.nranks == 1:
+            return
+        import torch.distributed as dist
+
+        ops = []
+        for p, ix in sorted(self.send_idx.items()):
+            buf = self.bufs.get(p)
+            if buf is None or buf.dtype != fl.dtype:
+                buf = self.bufs[p] = torch.empty((ix.numel(),) + tuple(fl.shape[1:]), dtype=fl.dtype, device=fl.device)
+            if fl.is_cuda and self.ctx is not None:
+                self.ctx.pack_rows(fl, ix, buf)
+            else:
+                torch.index_select(fl, 0, ix.long(), out=buf)
+            ops.append(dist.P2POp(dist.isend, buf, p))
+        for p, (dst0, cnt) in sorted(self.dom.recv.items()):
+            ops.append(dist.P2POp(dist.irecv, fl[dst0:dst0 + cnt], p))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+
+
+class Wamintgr:
+    """Device-resident WAMINTGR for one rank."""
+
+    def __init__(self, cfg: Config, grid, prec: str = "sp", device: int = 0, rank: int = 0, nranks: int = 1,
+                 ifrelfmax: int = 0, delpro_lf: float | None = None):
+        self.cfg, self.grid, self.prec = cfg, grid, prec
+        self.npdt = np.float32 if prec == "sp" else np.float64
+        self.t = Tables(cfg, self.npdt)
+        self.ctx = api.HipContext(self.t, device)
+        self.dev, self.dtype = self.ctx.device, self.ctx.dtype
+        self.dom = decomp.local_domain(grid, rank, nranks)
+        self.n, self.nrows = self.dom.n, self.dom.nrows
+        self.gd = api.grid_to_device(grid, self.dtype, self.dev, local=self.dom)
+        self.halo = HaloExchange(self.dom, self.dev, self.ctx)
+        NANG, NFRE, NR = cfg.nang, cfg.nfre, cfg.nfre_red
+        z = dict(dtype=self.dtype, device=self.dev)
+        self.fl1 = torch.zeros((self.nrows, NANG, NFRE), **z)
+        self.fl3 = torch.zeros((self.nrows, NANG, NFRE), **z)
+        self.w = torch.zeros((self.n, 8, NANG * NR), **z)
+        self.wvprpt = torch.zeros((self.n, api.NWPR, NFRE), **z)
+        self.ff = torch.zeros((self.n, api.NFF), **z)
+        self.ff_next = None
+        self.intf = torch.zeros((self.n, api.NINTF), **z)
+        self.mij = torch.zeros(self.n, dtype=torch.int32, device=self.dev)
+        self.xllws = torch.zeros((self.n, NANG, NFRE), **z)
+        self.cflfail = torch.zeros(self.n, dtype=torch.int32, device=self.dev)
+        self.ifrelfmax = ifrelfmax
+        self.delpro_lf = delpro_lf
+        self.weights_ready = False
+
+    # ---- synthetic initial state; identical for every decomposition
+    def init_synthetic(self, seed: int = 12345, chunk: int = 65536) -> None:
+        g, d, t = self.grid, self.dom, self.t
+        p = syn.point_params(g.nsea, seed=seed)
+        self.params = p
+        ext = d.ext_global()
+        props_ext_cg = np.zeros((self.nrows, self.cfg.nfre), self.npdt)
+        for s in range(0, ext.size, chunk):
+            sl = ext[s:s + chunk]
+            pr = syn.depth_props(p["DEPTH"][sl], t, self.npdt)
+            props_ext_cg[s:s + sl.size] = pr["CGROUP"]
+            own = sl[(sl >= d.lo) & (sl < d.hi)]
+            if own.size:
+                a, b = s, s + own.size  # owned rows come first in ext
+                wv = np.stack([pr[k][: own.size] for k in ("WAVNUM", "CGROUP", "CINV", "XK2CG", "STOKFAC")], 1)
+                self.wvprpt[a:b] = torch.from_numpy(wv).to(self.dev)
+                ff = np.zeros((own.size, api.NFF), self.npdt)
+                ff[:, :14] = syn.forcing(p, own, t, self.npdt)
+                ff[:, 14] = pr["EMAXDPT"][: own.size]
+                ff[:, 15] = p["DEPTH"][own]
+                self.ff[a:b] = torch.from_numpy(ff).to(self.dev)
+                fl = syn.jonswap_spectra(t.FR, t.TH, p["FP"][own], p["THETAQ"][own], self.npdt)
+                self.fl1[a:b] = torch.from_numpy(fl).to(self.dev)
+        props_ext_cg[self.dom.nland] = syn.depth_props(np.array([float(t.BATHYMAX)]), t, self.npdt)["CGROUP"][0]  # WVPRPT_LAND
+        self.cgroup_ext = torch.from_numpy(props_ext_cg).to(self.dev)
+        self.fl1[self.dom.nland].zero_()
+        self.fl3[self.dom.nland].zero_()
+
+    # ---- CTUWUPDT (ctuwupdt.F90:220-256): weights for the (sub-)step structure
+    def build_weights(self) -> int:
+        c = self.cfg
+        self.cflfail.zero_()
+        if self.ifrelfmax <= 0:
+            self.ctx.ctuw(self.gd, self.cgroup_ext, self.w, self.cflfail, float(c.idelpro), 1, c.nfre_red)
+        else:
+            self.ctx.ctuw(self.gd, self.cgroup_ext, self.w, self.cflfail, float(self.delpro_lf), 1, self.ifrelfmax)
+            if self.ifrelfmax < c.nfre_red:
+                self.ctx.ctuw(self.gd, self.cgroup_ext, self.w, self.cflfail, float(c.idelpro), self.ifrelfmax + 1, c.nfre_red)
+        self.weights_ready = True
+        return int(self.cflfail.sum().item())
+
+    # ---- PROPAG_WAM (propag_wam.F90:166-313), IPROPAGS = 2
+    def propag(self) -> None:
+        if not self.weights_ready:
+            nfail = self.build_weights()
+            if nfail:
+                raise api.EcwamHipError(f"CFL criterion violated at {nfail} points (ctuwdrv.F90:128-146)")
+        c, g = self.cfg, self.gd
+        self.halo(self.fl1)
+        self.ctx.propags2(self.fl1, self.fl3, g["klon"], g["klat"], g["kcor"], self.w, 0, self.n, 1, c.nfre_red, copy_rest=True)
+        if 0 < self.ifrelfmax < c.nfre_red:
+            nstep_lf = int(round(float(c.idelpro) / float(self.delpro_lf)))
+            for _ in range(2, nstep_lf + 1):
+                # FL1_EXT(:,:,1:IFRELFMAX) <- FL3_EXT ; exchange ; PROPAGS2 on the fast waves only
+                self.fl1[: self.n, :, : self.ifrelfmax] = self.fl3[: self.n, :, : self.ifrelfmax]
+                self.halo(self.fl1)
+                self.ctx.propags2(self.fl1, self.fl3, g["klon"], g["klat"], g["kcor"], self.w, 0, self.n, 1, self.ifrelfmax,
+                                  copy_rest=False)
+        self.fl1, self.fl3 = self.fl3, self.fl1
+
+    def newwind(self) -> None:
+        if self.ff_next is not None:
+            self.ctx.newwind(self.ff, self.ff_next)
+
+    def implsch(self) -> None:
+        self.ctx.implsch(0, self.n, self.fl1, self.wvprpt, self.ff, self.intf, self.mij, self.xllws)
+
+    def step(self, advect: bool = True, source: bool = True) -> None:
+        if advect:
+            self.propag()
+        self.newwind()
+        if source:
+            self.implsch()
+
+    # ---- diagnostics used by tests/bench (swh = 4 sqrt(EM), outbs.F90 / semean.F90)
+    def swh(self) -> torch.Tensor:
+        dfim = torch.from_numpy(np.asarray(self.t.DFIM, dtype=np.float64)).to(self.dev)
+        e = (self.fl1[: self.n].double().sum(1) * dfim).sum(1)
+        return 4.0 * torch.sqrt(e)

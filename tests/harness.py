@@ -101,11 +101,27 @@ def compare_implsch(ref: dict, got: dict, tables) -> dict:
     hs_r = 4 * np.sqrt((ref["FL1"].astype(np.float64).sum(1) * dfim).sum(1))
     hs_g = 4 * np.sqrt((got["FL1"].astype(np.float64).sum(1) * dfim).sum(1))
     st["swh_max_rel"] = float(np.max(np.abs(hs_g - hs_r) / np.maximum(hs_r, 1e-12)))
-    for nm, idx, key in (("ff", FF_OUT, "FF"), ("intf", INTF_OUT, "INTF")):
-        r, g = ref[key][:, idx].astype(np.float64), got[key][:, idx].astype(np.float64)
-        scale = np.maximum(np.abs(r), np.abs(r).max(0, keepdims=True) * 1e-6 + 1e-300)
-        err = np.abs(g - r) / scale
-        st[f"{nm}_max_rel_clean"] = float(err[clean].max()) if clean.any() else 0.0
-        st[f"{nm}_max_rel_all"] = float(err.max())
-        st[f"{nm}_worst_col"] = int(idx[int(np.argmax(err.max(0)))])
+    r, g = ref["FF"][:, FF_OUT].astype(np.float64), got["FF"][:, FF_OUT].astype(np.float64)
+    scale = np.maximum(np.abs(r), np.abs(r).max(0, keepdims=True) * 1e-6 + 1e-300)
+    scale[:, 2] = np.pi  # TAUWDIR is an angle
+    err = np.abs(g - r) / scale
+    st["ff_max_rel_clean"] = float(err[clean].max()) if clean.any() else 0.0
+    st["ff_max_rel_all"] = float(err.max())
+    st["ff_worst_col"] = int(FF_OUT[int(np.argmax(err.max(0)))])
+    # flux outputs: errors relative to the physical scale of each group (they are differences of nearly cancelling
+    # integrals): Stokes drift and stresses as vectors, energy fluxes against |PHIEPS|+|PHIAW| (x XN for PHIOCD)
+    ri, gi = ref["INTF"].astype(np.float64), got["INTF"].astype(np.float64)
+    d = np.abs(gi - ri)
+    tiny = 1e-300
+    e_stk = np.maximum(d[:, 2], d[:, 3]) / np.maximum(np.hypot(ri[:, 2], ri[:, 3]), 1e-6)
+    tau = np.maximum(np.hypot(ri[:, 5], ri[:, 6]), tiny)
+    e_tau = d[:, 5:9].max(1) / tau
+    e_tauoc = d[:, 9] / np.maximum(np.abs(ri[:, 9]), tiny)
+    phis = np.abs(ri[:, 13]) + np.abs(ri[:, 14])
+    xn = np.abs(ri[:, 12] / np.where(ri[:, 13] == 0, 1.0, ri[:, 13]))
+    e_phi = np.maximum(np.maximum(d[:, 13], d[:, 14]) / np.maximum(phis, tiny), d[:, 12] / np.maximum(xn * phis, tiny))
+    e_all = np.stack([e_stk, e_tau, e_tauoc, e_phi], 1)
+    st["intf_max_rel_clean"] = float(e_all[clean].max()) if clean.any() else 0.0
+    st["intf_max_rel_all"] = float(e_all.max())
+    st["intf_worst_group"] = ["stokes", "stress", "tauoc", "phi"][int(np.argmax(e_all.max(0)))]
     return st

@@ -1,0 +1,166 @@
+"""CPU tests: the C ABI library loads and exports every declared symbol, host-side grid / decomposition logic,
+the N>1 halo-exchange path over gloo (world_size 2), and oracle invariants."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import harness as H
+from ecwam_amd import decomp, grid as G
+from ecwam_amd.tables import Config, Tables
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from ecwam_amd import build, lib
+
+    build.build()
+    h = lib.load()
+    hdr = open(os.path.join(ROOT, "include", "ecwam_hip.h")).read()
+    declared = set(re.findall(r"\b(ecwam_hip_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
+    for name in declared:
+        assert getattr(h, name) is not None
+    assert h.ecwam_hip_abi_version() == 1
+    # the parameter struct seen from Python has the size the C compiler gives it
+    src = '#include "ecwam_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu", sizeof(ecwam_hip_params), sizeof(ecwam_hip_tables));return 0;}'
+    exe = os.path.join(ROOT, "ecwam_amd", "lib", "_abi_sizes")
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
+    a, b = (int(x) for x in subprocess.run([exe], capture_output=True, check=True).stdout.split())
+    import ctypes
+    assert a == ctypes.sizeof(lib.Params) and b == ctypes.sizeof(lib.TablePtrs)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "ecwam_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".F90")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("test oracle", "").lower() or f in ("lib.py",), (dirpath, f)
+
+
+def test_grid_counts_and_neighbours():
+    for n in (16, 24, 48):
+        g = G.build_grid(n)
+        assert g.nsea == G.nsea_aqua(n)
+    g = G.build_grid(24, mask="continents")
+    nl = g.nland
+    assert g.klon.min() >= 0 and g.klon.max() <= nl and g.klat.max() <= nl and g.kcor.max() <= nl
+    sea = g.klon[:, 1] < nl                         # east neighbour of a point has that point as west neighbour
+    assert np.array_equal(g.klon[g.klon[sea, 1], 0], np.flatnonzero(sea))
+    for ic, dk in ((0, -1), (1, 1)):                # latitude neighbours live in the adjacent row
+        ok = g.klat[:, ic, 0] < nl
+        assert np.all(g.kxlt[g.klat[ok, ic, 0]] == g.kxlt[ok] + dk)
+        ok = g.kcor[:, 0 if dk > 0 else 1, 0] < nl
+        assert np.all(g.kxlt[g.kcor[ok, 0 if dk > 0 else 1, 0]] == g.kxlt[ok] + dk)
+    assert 0.0 < g.wlat.min() and g.wlat.max() <= 1.0 and 0.0 <= g.wcor.min() and g.wcor.max() <= 1.0
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 3, 8])
+def test_decomposition_consistency(nranks):
+    g = G.build_grid(24, mask="continents")
+    doms = [decomp.local_domain(g, r, nranks) for r in range(nranks)]
+    assert sum(d.n for d in doms) == g.nsea and max(d.n for d in doms) - min(d.n for d in doms) <= 1
+    for d in doms:
+        ext = np.concatenate([d.ext_global(), [g.nland]])
+        for loc, glo in ((d.klon, g.klon), (d.klat, g.klat), (d.kcor, g.kcor)):
+            assert np.array_equal(ext[loc], glo[d.lo:d.hi])
+        for p, (dst0, cnt) in d.recv.items():       # what I expect from p is exactly what p plans to send me
+            want = d.halo_global[dst0 - d.n: dst0 - d.n + cnt]
+            assert np.array_equal(doms[p].send[d.rank] + doms[p].lo, want)
+        assert set(d.recv) == {p for p in range(nranks) if d.rank in doms[p].send}
+
+
+def test_oracle_decomposed_advection_equals_global():
+    """Advecting each rank's local domain (with halo rows filled from the neighbours) reproduces the global result
+    bit for bit: the stencil is a pure gather (decomposition independence)."""
+    from oracle.oracle import Oracle
+
+    cfg = Config(nang=12, nfre=36, nfre_red=25)
+    g = G.build_grid(16, mask="continents")
+    o = Oracle(cfg, "dp")
+    rng = np.random.default_rng(0)
+    cg = np.zeros((g.nsea + 1, 36))
+    cg[:] = rng.uniform(3, 12, (g.nsea + 1, 36))
+    f1 = np.zeros((g.nsea + 1, 12, 36))
+    f1[: g.nsea] = rng.uniform(0, 1, (g.nsea, 12, 36))
+    w = o.ctu_weights(g, cg, 900.0)
+    f3 = o.propags2(g, f1, w)
+
+    class LG:  # a Grid-like view of one local domain
+        pass
+
+    for r in range(3):
+        d = decomp.local_domain(g, r, 3)
+        ext = np.concatenate([d.ext_global(), [g.nland]])
+        lg = LG()
+        lg.nsea, lg.nland, lg.ngy, lg.xdella = d.n, d.nland, g.ngy, g.xdella
+        lg.kxlt, lg.klon, lg.klat, lg.kcor = d.kxlt, d.klon, d.klat, d.kcor
+        lg.wlat, lg.wcor = g.wlat[d.lo:d.hi], g.wcor[d.lo:d.hi]
+        lg.cosph, lg.sinph, lg.zdello, lg.cosphm1_ext = g.cosph, g.sinph, g.zdello, d.cosphm1_ext
+        wl = o.ctu_weights(lg, cg[ext], 900.0)
+        f3l = o.propags2(lg, f1[ext], wl)
+        assert np.array_equal(f3l[: d.n], f3[d.lo:d.hi])
+
+
+def test_oracle_physics_invariants():
+    """Properties the domain offers: limiter bounds, noise floor, ice mask, f^-5 tail continuity (implsch.F90:384-391,
+    imphftail.F90:73-87, setice.F90:67-86)."""
+    from oracle.oracle import Oracle
+
+    cfg = Config(nang=24, nfre=36, nfre_red=29)
+    case = H.make_point_case(400, cfg, "dp", spectra="mixed", seed=11)
+    t = case["tables"]
+    r = H.oracle_implsch(case, Oracle(cfg, "dp"))
+    fl, mij = r["FL1"], r["MIJ"]
+    assert np.isfinite(fl).all() and fl.min() >= 0
+    assert np.all(fl <= np.asarray(t.FLMAX)[None, None, :] * (1 + 1e-12) + 1e-30)
+    ice = case["FF"][:, 2] > float(t.CITHRSH)
+    assert ice.any() and np.all(fl[ice].max(axis=(1, 2)) < 1e-4)
+    assert np.all((mij >= 1) & (mij <= 36))
+    free = ~ice
+    for ij in np.flatnonzero(free)[:50]:            # above MIJ the spectrum follows F(MIJ) * k-dependent factor (or the floor)
+        m = mij[ij]
+        if m < 36:
+            pr = case["props"]
+            fac = (pr["XK2CG"][ij, m - 1] * pr["WAVNUM"][ij, m - 1]) / (pr["XK2CG"][ij, m:] * pr["WAVNUM"][ij, m:])
+            tail = fl[ij, :, m - 1][:, None] * fac[None, :]
+            assert np.all((np.abs(fl[ij, :, m:] - tail) <= 1e-12 * tail + 1e-30) | (fl[ij, :, m:] >= tail))
+
+
+GLOO_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from ecwam_amd import decomp, grid as G
+from ecwam_amd.wamintgr import HaloExchange
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+g = G.build_grid(16, mask="continents")
+d = decomp.local_domain(g, rank, world)
+rng = np.random.default_rng(42)
+glob = rng.uniform(0, 1, (g.nsea, 4, 6))          # same on every rank
+fl = torch.zeros((d.nrows, 4, 6), dtype=torch.float64)
+fl[: d.n] = torch.from_numpy(glob[d.lo:d.hi])
+HaloExchange(d, torch.device("cpu"))(fl)
+exp = glob[d.halo_global]
+ok = np.array_equal(fl[d.n:d.n + d.nh].numpy(), exp) and float(fl[d.nland].abs().sum()) == 0.0 and d.nh > 0
+t = torch.tensor([1 if ok else 0]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+dist.destroy_process_group()
+sys.exit(0 if int(t) == 1 else 3)
+'''
+
+
+def test_halo_exchange_gloo_world2(tmp_path):
+    """N>1 path on CPU: two processes, gloo backend, the same HaloExchange object the GPU path uses."""
+    script = tmp_path / "w.py"
+    script.write_text(GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29537", str(script), ROOT]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

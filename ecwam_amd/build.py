@@ -52,5 +52,44 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+FLANG = shutil.which("amdflang") or "/opt/rocm/lib/llvm/bin/flang"
+FSRC = os.path.join(HERE, "fortran")
+FFILES = ["ecwam_hip_mod.F90", "wamintgr_hip.F90", "smoke_wamintgr_hip.F90"]
+
+
+def fortran_exe(prec: str) -> str:
+    return os.path.join(LIBDIR, f"smoke_wamintgr_hip_{prec}")
+
+
+def build_fortran(force: bool = False) -> list:
+    """Fortran host layer (iso_c_binding module + WAMINTGR_HIP + harness program), sp and dp, linked against
+    libecwam_hip.so with amdflang."""
+    build(force=False)
+    out = []
+    for prec in ("sp", "dp"):
+        exe = fortran_exe(prec)
+        out.append(exe)
+        srcs = [os.path.join(FSRC, f) for f in FFILES]
+        if not force and os.path.exists(exe) and all(os.path.getmtime(s) < os.path.getmtime(exe) for s in srcs + [LIB]):
+            continue
+        moddir = os.path.join(LIBDIR, f"fmod_{prec}")
+        os.makedirs(moddir, exist_ok=True)
+        defs = ["-DECWAM_HIP_SINGLE"] if prec == "sp" else []
+        objs = []
+        for s in srcs:
+            o = os.path.join(moddir, os.path.basename(s).replace(".F90", ".o"))
+            r = subprocess.run([FLANG, "-cpp", "-O2", "-fPIC", *defs, "-module-dir", moddir, "-I", moddir, "-c", s, "-o", o],
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"flang failed for {s}:\n{r.stdout}")
+            objs.append(o)
+        r = subprocess.run([FLANG, "-o", exe, *objs, "-L", LIBDIR, "-lecwam_hip", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,$ORIGIN"],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"fortran link failed:\n{r.stdout}")
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_fortran(force="--force" in sys.argv))

@@ -184,7 +184,7 @@ int ecwam_hip_propags2(ecwam_hip_ctx* c, const void* f1, void* f3, const int* kl
   if (kijl > kijs && (!f1 || !f3 || !klon || !klat || !kcor || !w)) return fail("ecwam_hip_propags2: null pointer");
   if (f1 == f3) return fail("ecwam_hip_propags2: F1 and F3 must not alias");
   hipStream_t s = (hipStream_t)stream;
-  const int N = c->NANG * c->NFRE;
+  const int N = (c->NANG << 16) | (c->NFRE << 8) | c->NFRE_RED;
   DISPATCH(launch_propags2<float>(c->dtab, f1, f3, klon, klat, kcor, w, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, s),
            launch_propags2<double>(c->dtab, f1, f3, klon, klat, kcor, w, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, s));
   HIPCHK(hipGetLastError());
@@ -262,6 +262,38 @@ int ecwam_hip_unpack_rows(ecwam_hip_ctx* c, const void* buf, int n, void* fl, in
   if (n <= 0) return 0;
   const size_t row = (size_t)c->NANG * c->NFRE * c->real_bytes;
   HIPCHK(hipMemcpyAsync((char*)fl + (size_t)dst0 * row, buf, (size_t)n * row, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+int ecwam_hip_malloc(ecwam_hip_ctx* c, unsigned long long bytes, void** dptr) {
+  if (!c || !dptr) return fail("ecwam_hip_malloc: null argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMalloc(dptr, bytes ? bytes : 1));
+  return 0;
+}
+int ecwam_hip_free(ecwam_hip_ctx* c, void* dptr) {
+  if (!c) return fail("null context");
+  if (dptr) HIPCHK(hipFree(dptr));
+  return 0;
+}
+int ecwam_hip_memcpy_h2d(ecwam_hip_ctx* c, void* dst, const void* src, unsigned long long bytes, void* stream) {
+  if (!c || (bytes && (!dst || !src))) return fail("ecwam_hip_memcpy_h2d: null argument");
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return 0;
+}
+int ecwam_hip_memcpy_d2h(ecwam_hip_ctx* c, void* dst, const void* src, unsigned long long bytes, void* stream) {
+  if (!c || (bytes && (!dst || !src))) return fail("ecwam_hip_memcpy_d2h: null argument");
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return 0;
+}
+int ecwam_hip_memset(ecwam_hip_ctx* c, void* dst, int value, unsigned long long bytes, void* stream) {
+  if (!c || (bytes && !dst)) return fail("ecwam_hip_memset: null argument");
+  HIPCHK(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+  return 0;
+}
+int ecwam_hip_sync(ecwam_hip_ctx* c, void* stream) {
+  if (!c) return fail("null context");
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }
 

@@ -46,6 +46,63 @@ __global__ void __launch_bounds__(256) k_propags2(const DevTab<T>* __restrict__ 
   }
 }
 
+// Vectorised form (16 B per lane: 4 floats / 2 doubles along M) used when NFRE, NFRE_RED and the frequency range are
+// multiples of the vector width: 4x fewer load/store instructions, 1 KiB per wave-instruction on every stream.
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { typedef float4 type; enum { W = 4 }; };
+template <> struct VecOf<double> { typedef double2 type; enum { W = 2 }; };
+__device__ __forceinline__ float4 vmul_add(float4 acc, float4 w, float4 f) {
+  acc.x = acc.x + w.x * f.x; acc.y = acc.y + w.y * f.y; acc.z = acc.z + w.z * f.z; acc.w = acc.w + w.w * f.w;
+  return acc;
+}
+__device__ __forceinline__ double2 vmul_add(double2 acc, double2 w, double2 f) {
+  acc.x = acc.x + w.x * f.x; acc.y = acc.y + w.y * f.y;
+  return acc;
+}
+__device__ __forceinline__ float4 vfirst(float4 w, float4 f) { return make_float4((1.f - w.x) * f.x, (1.f - w.y) * f.y, (1.f - w.z) * f.z, (1.f - w.w) * f.w); }
+__device__ __forceinline__ double2 vfirst(double2 w, double2 f) { return make_double2((1.0 - w.x) * f.x, (1.0 - w.y) * f.y); }
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_propags2_vec(const DevTab<T>* __restrict__ tab, const T* __restrict__ f1, T* __restrict__ f3,
+                                                      const int* __restrict__ klon, const int* __restrict__ klat,
+                                                      const int* __restrict__ kcor, const T* __restrict__ w, int kijs, int kijl,
+                                                      int m0, int m1, int copy_rest) {
+  typedef typename VecOf<T>::type V;
+  constexpr int W = VecOf<T>::W;
+  const int NANG = tab->NANG, NFRE = tab->NFRE, NR = tab->NFRE_RED;
+  const int N = NANG * NFRE, NV = N / W, FV = NFRE / W;
+  const long long total = (long long)(kijl - kijs) * NV;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const int ij = kijs + (int)(g / NV);
+    const int ev = (int)(g - (long long)(ij - kijs) * NV);
+    const int k = ev / FV, m = (ev - k * FV) * W;
+    const size_t own = (size_t)ij * N;
+    const int e = k * NFRE + m;
+    if (m < m0 || m >= m1) {
+      if (copy_rest) *reinterpret_cast<V*>(f3 + own + e) = *reinterpret_cast<const V*>(f1 + own + e);
+      continue;
+    }
+    const int jx = tab->JXO[k][0], jy = tab->JYO[k][0], kc = tab->KCR[k][0];
+    const int km = tab->KPM[k][0], kp = tab->KPM[k][2];
+    const int ilon = klon[ij * 2 + jx];
+    const int ilat1 = klat[(ij * 2 + jy) * 2 + 0], ilat2 = klat[(ij * 2 + jy) * 2 + 1];
+    const int icor1 = kcor[(ij * 4 + kc) * 2 + 0], icor2 = kcor[(ij * 4 + kc) * 2 + 1];
+    const size_t ws = (size_t)NANG * NR;
+    const T* wp = w + (size_t)ij * 8 * ws + (size_t)k * NR + m;
+#define LDV(p) (*reinterpret_cast<const V*>(p))
+    V r = vfirst(LDV(wp), LDV(f1 + own + e));
+    r = vmul_add(r, LDV(wp + ws), LDV(f1 + (size_t)ilon * N + e));
+    r = vmul_add(r, LDV(wp + 2 * ws), LDV(f1 + (size_t)ilat1 * N + e));
+    r = vmul_add(r, LDV(wp + 3 * ws), LDV(f1 + (size_t)ilat2 * N + e));
+    r = vmul_add(r, LDV(wp + 4 * ws), LDV(f1 + (size_t)icor1 * N + e));
+    r = vmul_add(r, LDV(wp + 5 * ws), LDV(f1 + (size_t)icor2 * N + e));
+    r = vmul_add(r, LDV(wp + 6 * ws), LDV(f1 + own + km * NFRE + m));
+    r = vmul_add(r, LDV(wp + 7 * ws), LDV(f1 + own + kp * NFRE + m));
+#undef LDV
+    *reinterpret_cast<V*>(f3 + own + e) = r;
+  }
+}
+
 // ctuwini.F90:58-99: snap WLAT/WCOR near land.  One thread per point.
 template <typename T>
 __global__ void k_ctuwini(int n, int nland, const int* __restrict__ klat, const int* __restrict__ kcor, T* __restrict__ wlat,
@@ -222,9 +279,17 @@ static inline int grid_for(long long total, int block = 256) {
 
 template <typename T>
 void launch_propags2(const void* tab, const void* f1, void* f3, const int* klon, const int* klat, const int* kcor, const void* w,
-                     int kijs, int kijl, int m0, int m1, int copy_rest, int N, hipStream_t s) {
+                     int kijs, int kijl, int m0, int m1, int copy_rest, int dims, hipStream_t s) {
+  const int NANG = dims >> 16, NFRE = (dims >> 8) & 0xFF, NR = dims & 0xFF, N = NANG * NFRE;  // packed by capi.hip
   long long total = (long long)(kijl - kijs) * N;
   if (total <= 0) return;
+  constexpr int W = VecOf<T>::W;
+  const bool aligned = ((uintptr_t)f1 % 16 == 0) && ((uintptr_t)f3 % 16 == 0) && ((uintptr_t)w % 16 == 0);
+  if (aligned && NFRE % W == 0 && NR % W == 0 && m0 % W == 0 && m1 % W == 0) {
+    hipLaunchKernelGGL(k_propags2_vec<T>, dim3(grid_for(total / W)), dim3(256), 0, s, (const DevTab<T>*)tab, (const T*)f1, (T*)f3,
+                       klon, klat, kcor, (const T*)w, kijs, kijl, m0, m1, copy_rest);
+    return;
+  }
   hipLaunchKernelGGL(k_propags2<T>, dim3(grid_for(total)), dim3(256), 0, s, (const DevTab<T>*)tab, (const T*)f1, (T*)f3, klon,
                      klat, kcor, (const T*)w, kijs, kijl, m0, m1, copy_rest);
 }

@@ -52,7 +52,8 @@ class TablePtrs(C.Structure):
 
 EXPORTS = ["ecwam_hip_last_error", "ecwam_hip_abi_version", "ecwam_hip_create", "ecwam_hip_destroy", "ecwam_hip_propags2",
            "ecwam_hip_ctuw", "ecwam_hip_implsch", "ecwam_hip_newwind", "ecwam_hip_chunks_to_points",
-           "ecwam_hip_points_to_chunks", "ecwam_hip_pack_rows", "ecwam_hip_unpack_rows"]
+           "ecwam_hip_points_to_chunks", "ecwam_hip_pack_rows", "ecwam_hip_unpack_rows", "ecwam_hip_malloc", "ecwam_hip_free",
+           "ecwam_hip_memcpy_h2d", "ecwam_hip_memcpy_d2h", "ecwam_hip_memset", "ecwam_hip_sync"]
 
 _lib = None
 

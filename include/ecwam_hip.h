@@ -162,6 +162,15 @@ int ecwam_hip_points_to_chunks(ecwam_hip_ctx *ctx, const void *points, void *chu
 int ecwam_hip_pack_rows(ecwam_hip_ctx *ctx, const void *fl, const int *idx, int n, void *buf, void *stream);
 int ecwam_hip_unpack_rows(ecwam_hip_ctx *ctx, const void *buf, int n, void *fl, int dst0, void *stream);
 
+/* Device-memory helpers for hosts without their own HIP binding (the Fortran layer): the counterpart of FIELD_API's
+ * device allocation / GET_DEVICE_DATA / SYNC_HOST copies (drvtype_mod.fypp:116-480).  `stream` may be NULL. */
+int ecwam_hip_malloc(ecwam_hip_ctx *ctx, unsigned long long bytes, void **dptr);
+int ecwam_hip_free(ecwam_hip_ctx *ctx, void *dptr);
+int ecwam_hip_memcpy_h2d(ecwam_hip_ctx *ctx, void *dst_dev, const void *src_host, unsigned long long bytes, void *stream);
+int ecwam_hip_memcpy_d2h(ecwam_hip_ctx *ctx, void *dst_host, const void *src_dev, unsigned long long bytes, void *stream);
+int ecwam_hip_memset(ecwam_hip_ctx *ctx, void *dst_dev, int value, unsigned long long bytes, void *stream);
+int ecwam_hip_sync(ecwam_hip_ctx *ctx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,107 @@
+"""GPU test of the drop-in boundary seen from the reference's host language: a Fortran program fills YOWDRVTYPE-shaped
+host types (chunked NPROMA x NCHNK arrays), calls ECWAM_HIP_SETUP and WAMINTGR_HIP (iso_c_binding -> C ABI -> HIP kernels)
+with the WAMODEL date sequence, and must reproduce the Python/ctypes host driving the same C ABI bit for bit."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import harness as H
+from ecwam_amd.tables import Config
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _write_case(path, m, cfg, grid, nproma, nstep):
+    from ecwam_amd import lib as L, synthetic as syn
+
+    t = m.t
+    dt = m.npdt
+    n = grid.nsea
+    nchnk = (n + nproma - 1) // nproma
+    params = L.make_params(t)
+    tp, keep = L.make_tables(t)
+    with open(path, "wb") as f:
+        hdr = np.array([cfg.nang, cfg.nfre, cfg.nfre_red, nproma, nchnk, n, grid.ngy, cfg.idelt, cfg.idelpro,
+                        np.dtype(dt).itemsize, nstep, ctypes.sizeof(params)], dtype=np.int32)
+        f.write(hdr.tobytes())
+        f.write(bytes(params))
+        for a in keep:
+            f.write(np.int32(a.size).tobytes())
+            f.write(np.ascontiguousarray(a).tobytes())
+
+        def F(a, dtype):  # Fortran-order bytes
+            return np.asfortranarray(np.asarray(a, dtype=dtype)).tobytes(order="F")
+
+        f.write(F(grid.klon + 1, np.int32) + F(grid.klat + 1, np.int32) + F(grid.kcor + 1, np.int32) + F(grid.kxlt + 1, np.int32))
+        f.write(F(grid.wlat, dt) + F(grid.wcor, dt) + F(grid.zdello, dt) + dt(grid.xdella).tobytes() + F(grid.cosph, dt) + F(grid.sinph, dt))
+        f.write(F(m.cgroup_ext.cpu().numpy(), dt) + F(grid.cosphm1_ext, dt))
+
+        def chunk(a):  # [n][...] point-major -> (NPROMA, ..., NCHNK) with pad lanes replicating lane 1
+            pad = nchnk * nproma - n
+            a = np.concatenate([a, np.repeat(a[(nchnk - 1) * nproma:(nchnk - 1) * nproma + 1], pad, axis=0)], 0) if pad else a
+            a = a.reshape((nchnk, nproma) + a.shape[1:])
+            return np.moveaxis(a, (0, 1), (-1, 0))  # (NPROMA, ..., NCHNK)
+
+        fl = m.fl1.cpu().numpy()[:n]
+        f.write(F(chunk(fl), dt))
+        wv = m.wvprpt.cpu().numpy()
+        for i in range(5):
+            f.write(F(chunk(wv[:, i]), dt))
+        ff = m.ff.cpu().numpy()
+        for i in range(16):
+            f.write(F(chunk(ff[:, i]), dt))
+    return nchnk
+
+
+@pytest.mark.parametrize("prec", ["sp", "dp"])
+def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ecwam_amd import build, grid as G
+    from ecwam_amd.wamintgr import Wamintgr
+
+    exe = build.fortran_exe(prec)
+    if not os.path.exists(exe):
+        build.build_fortran()
+    cfg = Config(nang=12, nfre=36, nfre_red=25, idelt=900, idelpro=900)
+    g = G.build_grid(16, mask="continents")
+    m = Wamintgr(cfg, g, prec)
+    m.init_synthetic(seed=21)
+    nproma, nstep = 24, 2
+    case, out = str(tmp_path / "case.bin"), str(tmp_path / "out.bin")
+    nchnk = _write_case(case, m, cfg, g, nproma, nstep)
+    r = subprocess.run([exe, case, out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    for _ in range(nstep):
+        m.step()
+    torch.cuda.synchronize()
+    dt = m.npdt
+    n = g.nsea
+    raw = np.fromfile(out, dtype=np.uint8)
+    nsp = nproma * cfg.nang * cfg.nfre * nchnk
+    isz = np.dtype(dt).itemsize
+    off = 0
+    fl_f = np.frombuffer(raw, dtype=dt, count=nsp, offset=off).reshape((nproma, cfg.nang, cfg.nfre, nchnk), order="F"); off += nsp * isz
+    xl_f = np.frombuffer(raw, dtype=dt, count=nsp, offset=off).reshape((nproma, cfg.nang, cfg.nfre, nchnk), order="F"); off += nsp * isz
+    mij_f = np.frombuffer(raw, dtype=np.int32, count=nproma * nchnk, offset=off).reshape((nproma, nchnk), order="F"); off += 4 * nproma * nchnk
+    ff_f = np.frombuffer(raw, dtype=dt, count=14 * nproma * nchnk, offset=off).reshape((nproma, nchnk, 14), order="F"); off += 14 * nproma * nchnk * isz
+    in_f = np.frombuffer(raw, dtype=dt, count=15 * nproma * nchnk, offset=off).reshape((nproma, nchnk, 15), order="F")
+    ij = np.arange(n)
+    fl_pts = fl_f[ij % nproma, :, :, ij // nproma]
+    xl_pts = xl_f[ij % nproma, :, :, ij // nproma]
+    assert np.array_equal(fl_pts, m.fl1.cpu().numpy()[:n])
+    assert np.array_equal(xl_pts, m.xllws.cpu().numpy())
+    assert np.array_equal(mij_f[ij % nproma, ij // nproma], m.mij.cpu().numpy())
+    assert np.array_equal(ff_f[ij % nproma, ij // nproma, :], m.ff.cpu().numpy()[:, :14])
+    # INTGT_PARAM_FIELDS members written in the order of synthetic.INTF_NAMES
+    assert np.array_equal(in_f[ij % nproma, ij // nproma, :][:, [2, 3, 5, 6, 7, 8, 9, 12, 13, 14]],
+                          m.intf.cpu().numpy()[:, [2, 3, 5, 6, 7, 8, 9, 12, 13, 14]])
+    # pad lanes of the ragged last chunk replicate its lane 1 (propag_wam.F90:388-398)
+    kl = n - (nchnk - 1) * nproma
+    if kl < nproma:
+        assert np.array_equal(fl_f[kl:, :, :, -1], np.repeat(fl_f[:1, :, :, -1], nproma - kl, axis=0))
+    m.ctx.close()

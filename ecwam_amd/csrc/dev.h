@@ -88,6 +88,19 @@ __device__ __forceinline__ float m_sign(float a, float b) { return copysignf(a, 
 __device__ __forceinline__ double m_sign(double a, double b) { return copysign(a, b); }
 __device__ __forceinline__ int m_nint(float x) { return (int)lroundf(x); }
 __device__ __forceinline__ int m_nint(double x) { return (int)lround(x); }
+// ---- IMPLSCH hot-loop math: single precision goes straight to the hardware transcendental unit (v_rcp/v_sqrt/v_exp/
+// v_log, <= 1 ulp each, no range fix-up code: the arguments on these paths are bounded, see the call sites);
+// double precision keeps the library routines.  f_exp(x) = 2^(x*log2e): relative error <= |x|*1.2e-7.
+__device__ __forceinline__ float f_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ double f_div(double a, double b) { return a / b; }
+__device__ __forceinline__ float f_rcp(float b) { return __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ double f_rcp(double b) { return 1.0 / b; }
+__device__ __forceinline__ float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double f_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float f_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ double f_exp(double x) { return exp(x); }
+__device__ __forceinline__ float f_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
+__device__ __forceinline__ double f_log(double x) { return log(x); }
 template <typename T>
 __device__ __forceinline__ T m_pow4(T x) {
   T x2 = x * x;

@@ -24,6 +24,8 @@ struct Lane {
   int lane, k, NANG, NFRE, NAP;
   bool act;    // lane < NANG
   bool actm;   // lane < NFRE
+  // module tables per frequency, lane m holds M=m+1 (broadcast with v_readlane: no scalar loads inside the M loops)
+  T rDFIM, rDFIMOFR, rZPIFR, rCOFRM4, rFLMAX;
 };
 
 // TEMP2(M) = SUM_K F(K,M) in the reference's order (K sequential), lane m gets M=m+1
@@ -77,8 +79,8 @@ __device__ void femeanws(const DevTab<T>& tb, const T* sF, const Lane<T>& L, uns
   T ae = T(0), af = T(0), last = T(0);
   for (int m = 0; m < L.NFRE; m++) {
     T x = ((xmask >> m) & 1ull) ? sF[m * L.NAP + L.k] : T(0);
-    ae += tb.DFIM[m] * x;
-    af += tb.DFIMOFR[m] * x;
+    ae += lane_get(L.rDFIM, m) * x;
+    af += lane_get(L.rDFIMOFR, m) * x;
     last = x;
   }
   if (!L.act) { ae = T(0); af = T(0); last = T(0); }
@@ -124,19 +126,20 @@ __device__ void taut_z0_a(const DevTab<T>& tb, int IUSFG, T UTOP, T UDIR, T TAUW
   T USTM1 = T(1) / m_max(USTAR, tb.EPSUS);
   T Z0CH = T(0);
   for (int it = 0; it < 18; it++) {
-    T X = m_max(TAUWACT / TAUOLD, XMIN);
-    Z0CH = ALPHAOG * TAUOLD / m_sqrt(T(1) - X);
+    T X = m_max(f_div(TAUWACT, TAUOLD), XMIN);
+    const T omx = f_rcp(T(1) - X);
+    Z0CH = ALPHAOG * TAUOLD * f_sqrt(omx);
     T Z0VIS = tb.RNUM * USTM1;
     T Z0TOT = Z0CH + Z0VIS;
-    T XOLOGZ0 = T(1) / (XLOGXL - m_log(Z0TOT));
+    T XOLOGZ0 = f_rcp(XLOGXL - f_log(Z0TOT));
     T Fv = USTAR - XKUTOP * XOLOGZ0;
-    T ZZ = USTM1 * (Z0CH * (T(2) - TWOXMP1 * X) / (T(1) - X) - Z0VIS) / Z0TOT;
+    T ZZ = f_div(USTM1 * (Z0CH * (T(2) - TWOXMP1 * X) * omx - Z0VIS), Z0TOT);
     T DELF = T(1) - XKUTOP * XOLOGZ0 * XOLOGZ0 * ZZ;
-    if (DELF != T(0)) USTAR = USTAR - Fv / DELF;
+    if (DELF != T(0)) USTAR = USTAR - f_div(Fv, DELF);
     T TAUNEW = m_max(USTAR * USTAR, TAUWEFF);
-    USTAR = m_sqrt(TAUNEW);
+    USTAR = f_sqrt(TAUNEW);
     if (TAUNEW == TAUOLD) break;
-    USTM1 = T(1) / m_max(USTAR, tb.EPSUS);
+    USTM1 = f_rcp(m_max(USTAR, tb.EPSUS));
     TAUOLD = TAUNEW;
   }
   Z0 = Z0CH;
@@ -258,7 +261,7 @@ __device__ void sinput_ard(const DevTab<T>& tb, const T* sF, T* sFLD, T* sSPOS, 
   T COSU[2], SINU[2];  // cos/sin of the sheltered stress direction USDIRP = ATAN2(TAUPX,TAUPY)
 
   for (int m = 0; m < L.NFRE; m++) {
-    const T SIG = tb.ZPIFR[m];
+    const T SIG = lane_get(L.rZPIFR, m);
     const T SIG2 = SIG * SIG;
     const T CONST = SIG * CONST1;
     const T cinv_m = lane_get(rCINV, m), wavnum_m = lane_get(rWAVNUM, m);
@@ -275,19 +278,20 @@ __device__ void sinput_ard(const DevTab<T>& tb, const T* sF, T* sFLD, T* sSPOS, 
         // (no ATAN2/COS per lane) and USTP = |TAUP|**0.5 as two square roots: algebraically identical evaluation.
         T TAUPX = TAUX[ig] - ABS_TAUWSHELTER * XSTRESS[ig];
         T TAUPY = TAUY[ig] - ABS_TAUWSHELTER * YSTRESS[ig];
-        const T h = m_sqrt(TAUPX * TAUPX + TAUPY * TAUPY);
+        const T h = f_sqrt(TAUPX * TAUPX + TAUPY * TAUPY);
         const bool zero = !(h > T(0));
-        COSU[ig] = zero ? T(1) : TAUPY / h;
-        SINU[ig] = zero ? T(0) : TAUPX / h;
-        USTP[ig] = m_sqrt(h);
-        USTPM1[ig] = T(1) / m_max(USTP[ig], tb.EPSUS);
+        const T rh = f_rcp(h);
+        COSU[ig] = zero ? T(1) : TAUPY * rh;
+        SINU[ig] = zero ? T(0) : TAUPX * rh;
+        USTP[ig] = f_sqrt(h);
+        USTPM1[ig] = f_rcp(m_max(USTP[ig], tb.EPSUS));
       }
-      CONSTF = ROGOROAIR * cinv_m * tb.DFIM[m];
+      CONSTF = ROGOROAIR * cinv_m * lane_get(L.rDFIM, m);
     }
 #pragma unroll
     for (int ig = 0; ig < NGST; ig++) {
       UCN[ig] = USTP[ig] * cinv_m;
-      UCNZALPD[ig] = tb.XKAPPA / (UCN[ig] + tb.ZALP);
+      UCNZALPD[ig] = tb.XKAPPA * f_rcp(UCN[ig] + tb.ZALP);
     }
     const T ZCN = lane_get(rZCN, m);
     const T CNSN = CONST * RAORW;
@@ -307,10 +311,10 @@ __device__ void sinput_ard(const DevTab<T>& tb, const T* sF, T* sFLD, T* sSPOS, 
       T gam0 = T(0);
       if (coslp > T(0.01)) {
         T X = coslp * UCN[ig];
-        T ZLOG = ZCN + UCNZALPD[ig] / coslp;
+        T ZLOG = ZCN + UCNZALPD[ig] * f_rcp(coslp);
         if (ZLOG < T(0)) {
           T ZLOG2X = ZLOG * ZLOG * X;
-          gam0 = m_exp(ZLOG) * ZLOG2X * ZLOG2X * CNSN;
+          gam0 = f_exp(ZLOG) * ZLOG2X * ZLOG2X * CNSN;
           xl = true;
         }
       }
@@ -383,9 +387,11 @@ __device__ void tau_phi_hf(const DevTab<T>& tb, const T* sF, const Lane<T>& L, i
   T DELZ = m_max((ZSUP - ZINF) / T(JTOT - 1), T(0));
   // the 19 integration nodes do not depend on the sheltered friction velocity: evaluate Y, CM1 and
   // XLOGGZ0+2*LOG(CM1) lane-parallel (lane J), leaving one EXP, one divide and one SQRT per sequential step
-  T rY = T(1), rCM1 = T(1), rLC = T(0);
+  T rY = T(1), rCM1 = T(1), rLC = T(0), rYI = T(1);
+  const bool NORMA = tb.LLNORMAGAM != 0;
   if (L.lane < JTOT) {
     rY = m_exp(ZINF + T(L.lane) * DELZ);
+    rYI = T(1) / rY;
     rCM1 = (rY * SQRTGZ0) * tb.GM1;
     rLC = XLOGGZ0 + T(2) * m_log(rCM1);
   }
@@ -394,26 +400,26 @@ __device__ void tau_phi_hf(const DevTab<T>& tb, const T* sF, const Lane<T>& L, i
     for (int J = 0; J < JTOT; J++) {
       const T Y = lane_get(rY, J);
       const T CM1 = lane_get(rCM1, J);
-      T ZARG = tb.XKAPPA / (UST * CM1 + tb.ZALP);
+      T ZARG = tb.XKAPPA * f_rcp(UST * CM1 + tb.ZALP);
       T ZLOG = m_min(lane_get(rLC, J) + ZARG, T(0));
-      T ZBETA = m_pow4(ZLOG) * m_exp(ZLOG);
+      T ZBETA = m_pow4(ZLOG) * f_exp(ZLOG);
       T ZNZ = ZBETA * UST * Y;
-      T GAMNORMA = (T(1) + CONST1 * ZNZ) / (T(1) + CONST2 * ZNZ);
+      const T GAMNORMA = NORMA ? f_div(T(1) + CONST1 * ZNZ, T(1) + CONST2 * ZNZ) : T(1);
       T FNC2 = F1DCOS3 * CONSTTAU * ZBETA * TAUL * tb.WTAUHF[J] * DELZ * GAMNORMA;
       TAUL = m_max(TAUL - tb.TAUWSHELTER * FNC2, T(0));
-      UST = m_sqrt(TAUL);
+      UST = f_sqrt(TAUL);
       TAUHF = TAUHF + FNC2;
     }
   } else {
     for (int J = 0; J < JTOT; J++) {
       const T Y = lane_get(rY, J);
       const T CM1 = lane_get(rCM1, J);
-      T ZARG = tb.XKAPPA / (UST * CM1 + tb.ZALP);
+      T ZARG = tb.XKAPPA * f_rcp(UST * CM1 + tb.ZALP);
       T ZLOG = m_min(lane_get(rLC, J) + ZARG, T(0));
-      T ZBETA = m_pow4(ZLOG) * m_exp(ZLOG);
+      T ZBETA = m_pow4(ZLOG) * f_exp(ZLOG);
       T FNC2 = ZBETA * tb.WTAUHF[J];
       T ZNZ = ZBETA * UST * Y;
-      T GAMNORMA = (T(1) + CONST1 * ZNZ) / (T(1) + CONST2 * ZNZ);
+      const T GAMNORMA = NORMA ? f_div(T(1) + CONST1 * ZNZ, T(1) + CONST2 * ZNZ) : T(1);
       TAUHF = TAUHF + FNC2 * GAMNORMA;
     }
     TAUHF = F1DCOS3 * CONSTTAU * TAUL * TAUHF * DELZ;
@@ -427,28 +433,28 @@ __device__ void tau_phi_hf(const DevTab<T>& tb, const T* sF, const Lane<T>& L, i
       for (int J = 0; J < JTOT; J++) {
         const T Y = lane_get(rY, J);
         const T CM1 = lane_get(rCM1, J);
-        T ZARG = tb.XKAPPA / (USTPH * CM1 + tb.ZALP);
+        T ZARG = tb.XKAPPA * f_rcp(USTPH * CM1 + tb.ZALP);
         T ZLOG = m_min(lane_get(rLC, J) + ZARG, T(0));
-        T ZBETA = m_pow4(ZLOG) * m_exp(ZLOG);
+        T ZBETA = m_pow4(ZLOG) * f_exp(ZLOG);
         T ZNZ = ZBETA * UST * Y;
-        T GAMNORMA = (T(1) + CONST1 * ZNZ) / (T(1) + CONST2 * ZNZ);
+        const T GAMNORMA = NORMA ? f_div(T(1) + CONST1 * ZNZ, T(1) + CONST2 * ZNZ) : T(1);
         T FNC2 = ZBETA * TAUL * tb.WTAUHF[J] * DELZ * GAMNORMA;
         TAUL = m_max(TAUL - tb.TAUWSHELTER * F1DCOS3 * CONSTTAU * FNC2, T(0));
-        USTPH = m_sqrt(TAUL);
-        PHIHF = PHIHF + FNC2 / Y;
+        USTPH = f_sqrt(TAUL);
+        PHIHF = PHIHF + FNC2 * lane_get(rYI, J);
       }
       PHIHF = F1DCOS2 * CONSTPHI * SQRTZ0OG * PHIHF;
     } else {
       for (int J = 0; J < JTOT; J++) {
         const T Y = lane_get(rY, J);
         const T CM1 = lane_get(rCM1, J);
-        T ZARG = tb.XKAPPA / (USTPH * CM1 + tb.ZALP);
+        T ZARG = tb.XKAPPA * f_rcp(USTPH * CM1 + tb.ZALP);
         T ZLOG = m_min(lane_get(rLC, J) + ZARG, T(0));
-        T ZBETA = m_pow4(ZLOG) * m_exp(ZLOG);
+        T ZBETA = m_pow4(ZLOG) * f_exp(ZLOG);
         T ZNZ = ZBETA * UST * Y;
-        T GAMNORMA = (T(1) + CONST1 * ZNZ) / (T(1) + CONST2 * ZNZ);
+        const T GAMNORMA = NORMA ? f_div(T(1) + CONST1 * ZNZ, T(1) + CONST2 * ZNZ) : T(1);
         T FNC2 = ZBETA * tb.WTAUHF[J] * GAMNORMA;
-        PHIHF = PHIHF + FNC2 / Y;
+        PHIHF = PHIHF + FNC2 * lane_get(rYI, J);
       }
       PHIHF = F1DCOS2 * CONSTPHI * SQRTZ0OG * TAUL * PHIHF * DELZ;
     }
@@ -484,7 +490,7 @@ __device__ void sdissip_ard(const DevTab<T>& tb, const T* sF, T* sFLD, T* sSL, c
     }
     b = b * lane_get(rFACSAT, m);
     const T bth0 = umax(L.act ? b : T(0));
-    const T SSDSC2_SIG = tb.SSDSC2 * tb.ZPIFR[m];
+    const T SSDSC2_SIG = tb.SSDSC2 * lane_get(L.rZPIFR, m);
     const T ZCOEF = SSDSC2_SIG * tb.SSDSC6;
     const T ZCOEFM1 = SSDSC2_SIG * SSDSC6M1;
     const T a0 = m_max(T(0), bth0 * TMP03 - tb.SSDSC4);
@@ -696,6 +702,10 @@ __global__ void __launch_bounds__(64 * WPB) k_implsch(const DevTab<T>* __restric
   L.NANG = tb.NANG; L.NFRE = tb.NFRE; L.NAP = tb.NANG | 1;
   L.act = L.lane < L.NANG; L.actm = L.lane < L.NFRE;
   L.k = L.act ? L.lane : 0;
+  {
+    const int mi = L.actm ? L.lane : 0;
+    L.rDFIM = tb.DFIM[mi]; L.rDFIMOFR = tb.DFIMOFR[mi]; L.rZPIFR = tb.ZPIFR[mi]; L.rCOFRM4 = tb.COFRM4[mi]; L.rFLMAX = tb.FLMAX[mi];
+  }
   const int NANG = L.NANG, NFRE = L.NFRE, NAP = L.NAP, N = NANG * NFRE;
   const int tile = NFRE * NAP;
   T* sF = reinterpret_cast<T*>(smem_raw) + (size_t)wave * (3 * tile + 64);
@@ -880,16 +890,16 @@ __global__ void __launch_bounds__(64 * WPB) k_implsch(const DevTab<T>* __restric
     T fld = sFLD[m * NAP + L.k], sl = sSL[m * NAP + L.k];
     const T f = sF[m * NAP + L.k];
     T ss = T(0);
-    if (tb.LCFLX && tb.LWVFLX_SNL) ss = sl / m_max(T(1) - DELT5 * fld, T(1));
+    if (tb.LCFLX && tb.LWVFLX_SNL) ss = f_div(sl, m_max(T(1) - DELT5 * fld, T(1)));
     if (shallow_brk && m < tb.NFRE_RED) { sl = sl - SDS * f; fld = fld - SDS; }
     const T sbo = lane_get(rSBO, m);
     if (m < tb.NFRE_RED) { sl = sl + sbo * f; fld = fld + sbo; }
     const T GTEMP1 = m_max(T(1) - DELT5 * fld, T(1));
-    const T GTEMP2 = DELT * sl / GTEMP1;
-    const T FLHAB = m_min(m_abs(GTEMP2), USFM * (tb.COFRM4[m] * DELT));
+    const T GTEMP2 = f_div(DELT * sl, GTEMP1);
+    const T FLHAB = m_min(m_abs(GTEMP2), USFM * (lane_get(L.rCOFRM4, m) * DELT));
     T fn = f + m_sign(FLHAB, GTEMP2);
     fn = m_max(fn, FLM);
-    const T flmax = tb.FLMAX[m];
+    const T flmax = lane_get(L.rFLMAX, m);
     ss = ss + DELTM * m_min(flmax - fn, T(0));
     fn = m_min(fn, flmax);
     if (L.act) sF[m * NAP + L.k] = fn;

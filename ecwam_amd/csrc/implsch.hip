@@ -304,26 +304,32 @@ __device__ void sinput_ard(const DevTab<T>& tb, const T* sF, T* sFLD, T* sSPOS, 
     }
     const T f = sF[m * L.NAP + L.k];
     T g0[2], ds[2];
-    bool xl = false;
+    bool xl = false, grow[2];
 #pragma unroll
     for (int ig = 0; ig < NGST; ig++) {
       T coslp = LTAUWSHELTER ? (costhk * COSU[ig] + sinthk * SINU[ig]) : coswdif;
-      T gam0 = T(0);
+      T gam0 = T(0), ZLOG = T(0);
+      bool neg = false;
       if (coslp > T(0.01)) {
-        T X = coslp * UCN[ig];
-        T ZLOG = ZCN + UCNZALPD[ig] * f_rcp(coslp);
-        if (ZLOG < T(0)) {
-          T ZLOG2X = ZLOG * ZLOG * X;
+        ZLOG = ZCN + UCNZALPD[ig] * f_rcp(coslp);
+        neg = ZLOG < T(0);
+      }
+      // rows in which no direction grows (waves outrunning the wind): wave-uniform skip of the growth rate, its
+      // normalisation and the stress reductions -- they would all add exact zeros
+      grow[ig] = __builtin_amdgcn_ballot_w64(neg) != 0ull;
+      if (grow[ig]) {
+        if (neg) {
+          T ZLOG2X = ZLOG * ZLOG * (coslp * UCN[ig]);
           gam0 = f_exp(ZLOG) * ZLOG2X * ZLOG2X * CNSN;
           xl = true;
         }
-      }
-      if (LLNORMAGAM) {
-        T a = L.act ? gam0 * f : T(0);
-        T SUMF = usum(a);
-        T SUMFSIN2 = usum(a * sinwdif2);
-        T ZNZ = XNGAMCONST * USTPM1[ig];
-        GAMNORMA[ig] = (T(1) + ZNZ * SUMFSIN2) / (T(1) + ZNZ * SUMF);
+        if (LLNORMAGAM) {
+          T a = L.act ? gam0 * f : T(0);
+          T SUMF = usum(a);
+          T SUMFSIN2 = usum(a * sinwdif2);
+          T ZNZ = XNGAMCONST * USTPM1[ig];
+          GAMNORMA[ig] = (T(1) + ZNZ * SUMFSIN2) / (T(1) + ZNZ * SUMF);
+        }
       }
       T dstab = T(0);
       if (LLSNEG) {
@@ -339,7 +345,7 @@ __device__ void sinput_ard(const DevTab<T>& tb, const T* sF, T* sFLD, T* sSPOS, 
       T SLP = g0[ig] * GAMNORMA[ig];
       T FLP = SLP + ds[ig];
       SLP = SLP * f;
-      if (LTAUWSHELTER) {
+      if (LTAUWSHELTER && grow[ig]) {
         T sx = L.act ? SLP * (CONSTF * sinthk) : T(0);
         T sy = L.act ? SLP * (CONSTF * costhk) : T(0);
         XSTRESS[ig] = XSTRESS[ig] + usum(sx);
@@ -611,10 +617,17 @@ __device__ void snonlin_pull(const DevTab<T>& tb, const T* sF, T* sFLD, T* sSL, 
   const int NAP = L.NAP, NFRE = L.NFRE, NANG = L.NANG, k = L.k, lane = L.lane;
   const int MFR1STFR = -tb.MFRSTLW + 1;
   const int MFRLSTFR = NFRE - tb.KFRH + MFR1STFR;
-  int k1[2], k2[2], ik1[2], ik2[2];
+  // every +-1 rotation is folded into a second pull index (ds_bpermute runs on the LDS crossbar, the VALU is the bound here)
+  int k1[2], k2[2], k11[2], k21[2], ik1[2], ik2[2], ik1s[2], ik2s[2];
 #pragma unroll
-  for (int kh = 0; kh < 2; kh++) { k1[kh] = tb.K1W[kh][k]; k2[kh] = tb.K2W[kh][k]; ik1[kh] = tb.IK1[kh][k]; ik2[kh] = tb.IK2[kh][k]; }
-  const bool up11[2] = {tb.D11[0] > 0, tb.D11[1] > 0}, up21[2] = {tb.D21[0] > 0, tb.D21[1] > 0};
+  for (int kh = 0; kh < 2; kh++) {
+    k1[kh] = tb.K1W[kh][k]; k2[kh] = tb.K2W[kh][k]; k11[kh] = tb.K11W[kh][k]; k21[kh] = tb.K21W[kh][k];
+    ik1[kh] = tb.IK1[kh][k]; ik2[kh] = tb.IK2[kh][k];
+    // increments sent to K11 (K21) arrive one lane further along D11 (D21): column c takes them from the sender of c-D
+    const int c1 = k - tb.D11[kh], c2 = k - tb.D21[kh];
+    ik1s[kh] = tb.IK1[kh][c1 < 0 ? c1 + NANG : (c1 >= NANG ? c1 - NANG : c1)];
+    ik2s[kh] = tb.IK2[kh][c2 < 0 ? c2 + NANG : (c2 >= NANG ? c2 - NANG : c2)];
+  }
   T aS[8], aF[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) { aS[i] = T(0); aF[i] = T(0); }
@@ -643,11 +656,8 @@ __device__ void snonlin_pull(const DevTab<T>& tb, const T* sF, T* sFLD, T* sSL, 
         const T um = GW5 * fIM + GW7 * fIM1, vm = GW6 * fIM + GW8 * fIM1;
 #pragma unroll
         for (int kh = 0; kh < 2; kh++) {
-          // SAP(k) = up[k1] + vp[k11], k11 = k1 + d11:  y[j] = up[j] + vp[j+d11]; SAP = y[k1]
-          const T yp = up + (up11[kh] ? rot_dn(vp, lane, NANG) : rot_up(vp, lane, NANG));
-          const T ym = um + (up21[kh] ? rot_dn(vm, lane, NANG) : rot_up(vm, lane, NANG));
-          const T SAP = lane_pull(yp, k1[kh]);
-          const T SAM = lane_pull(ym, k2[kh]);
+          const T SAP = lane_pull(up, k1[kh]) + lane_pull(vp, k11[kh]);
+          const T SAM = lane_pull(um, k2[kh]) + lane_pull(vm, k21[kh]);
           T FAD1 = FIJ * (SAP + SAM);
           const T FAD2 = FAD1 - T(2) * SAP * SAM;
           FAD1 = FAD1 + FAD2;
@@ -659,10 +669,8 @@ __device__ void snonlin_pull(const DevTab<T>& tb, const T* sF, T* sFLD, T* sSL, 
           // increments arriving at column c: from the lane whose K2 (K1) is c, and from the one whose K21 (K11) is c
           const T A2 = lane_pull(AD, ik2[kh]), D2 = lane_pull(DELAM, ik2[kh]);
           const T A1 = lane_pull(AD, ik1[kh]), P1 = lane_pull(DELAP, ik1[kh]);
-          const T A2s = up21[kh] ? rot_up(A2, lane, NANG) : rot_dn(A2, lane, NANG);
-          const T D2s = up21[kh] ? rot_up(D2, lane, NANG) : rot_dn(D2, lane, NANG);
-          const T A1s = up11[kh] ? rot_up(A1, lane, NANG) : rot_dn(A1, lane, NANG);
-          const T P1s = up11[kh] ? rot_up(P1, lane, NANG) : rot_dn(P1, lane, NANG);
+          const T A2s = lane_pull(AD, ik2s[kh]), D2s = lane_pull(DELAM, ik2s[kh]);
+          const T A1s = lane_pull(AD, ik1s[kh]), P1s = lane_pull(DELAP, ik1s[kh]);
           aS[c0] -= T(2) * AD;
           aF[c0] -= T(2) * DELAD;
           aS[cm] += A2 * FKLAMM1 + A2s * FKLAMM2;

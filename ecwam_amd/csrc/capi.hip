@@ -23,6 +23,7 @@ struct ecwam_hip_ctx {
   int device;
   int NANG, NFRE, NFRE_RED;
   void* dtab;  // DevTab<T> in device memory
+  int implsch_variant;  // 2: two-tile fused-sweep kernel (needs the DIA rotation structure), 1: three-tile kernel
   ecwam_hip_params p;
 };
 
@@ -149,11 +150,13 @@ int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int r
   if (real_bytes == 4) {
     std::vector<DevTab<float>> h(1);
     build_tab<float>(p, t, h.data());
+    c->implsch_variant = h[0].DIA_PULL ? 2 : 1;
     HIPCHK(hipMalloc(&c->dtab, sizeof(DevTab<float>)));
     HIPCHK(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<float>), hipMemcpyHostToDevice));
   } else {
     std::vector<DevTab<double>> h(1);
     build_tab<double>(p, t, h.data());
+    c->implsch_variant = h[0].DIA_PULL ? 2 : 1;
     HIPCHK(hipMalloc(&c->dtab, sizeof(DevTab<double>)));
     HIPCHK(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<double>), hipMemcpyHostToDevice));
   }
@@ -211,9 +214,10 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   if (kijl < kijs) return fail("ecwam_hip_implsch: bad range");
   if (kijl > kijs && (!fl1 || !wvprpt || !ff || !intf || !mij || !xllws)) return fail("ecwam_hip_implsch: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  int rc;
-  DISPATCH(rc = launch_implsch<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, dbg, c->NANG, c->NFRE, c->p.nsdsnth, s),
-           rc = launch_implsch<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, dbg, c->NANG, c->NFRE, c->p.nsdsnth, s));
+  int rc, variant = c->implsch_variant;
+  { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_VARIANT"); if (e_ && atoi(e_) == 1) variant = 1; }  // diagnostics: force the 3-tile kernel
+  DISPATCH(rc = launch_implsch<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, dbg, c->NANG, c->NFRE, variant, s),
+           rc = launch_implsch<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, dbg, c->NANG, c->NFRE, variant, s));
   if (rc) return fail("ecwam_hip_implsch: unsupported spectral size for the LDS tiling");
   HIPCHK(hipGetLastError());
   return 0;

@@ -1032,31 +1032,49 @@ __global__ void __launch_bounds__(64 * WPB) k_implsch(const DevTab<T>* __restric
   }
 }
 
+#include "implsch_v2.h"
+
 template <typename T>
 int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws,
-                   void* dbg, int NANG, int NFRE, int nsdsnth, hipStream_t s) {
+                   void* dbg, int NANG, int NFRE, int variant, hipStream_t s) {
   const int n = kijl - kijs;
   if (n <= 0) return 0;
   const int NAP = NANG | 1;
-  const size_t per_wave = (size_t)(3 * NFRE * NAP + 64) * sizeof(T);
-  // waves per block (4, 2 or 1): the choice that fits the most waves into the 160 KiB of LDS of a CU
+  const int ntile = (variant == 2) ? 2 : 3;
+  const size_t per_wave = (size_t)(ntile * NFRE * NAP + 64) * sizeof(T) + (variant == 2 ? NSC * sizeof(T) : 0);
+  // waves (= points) per block: the choice that fits the most waves into the 160 KiB of LDS of a CU; ties go to the larger
+  // block, which amortises the lane-per-point scalar stages of variant 2 over more points
+  static const int cands3[] = {4, 2, 1}, cands2[] = {7, 4, 2, 1};
+  const int* cands = (variant == 2) ? cands2 : cands3;
+  const int ncand = (variant == 2) ? 4 : 3;
   int wpb = 1, best = 0;
-  for (int cand = 4; cand >= 1; cand >>= 1) {
-    const int waves = (int)((160 * 1024) / (per_wave * cand)) * cand;
+  for (int i = 0; i < ncand; i++) {
+    const int cand = cands[i];
+    int nb = (int)((160 * 1024) / (per_wave * cand));
+    if (nb * cand > 32) nb = 32 / cand;  // 8 waves per SIMD at most
+    const int waves = nb * cand;
     if (waves > best) { best = waves; wpb = cand; }
   }
   if (best == 0) return 1;
+  { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_WPB"); if (e_ && variant == 2) { const int w = atoi(e_); if (w == 7 || w == 4 || w == 2 || w == 1) wpb = w; } }
   const size_t shmem = per_wave * wpb;
   const int blocks = (n + wpb - 1) / wpb;
-#define LAUNCH(W)                                                                                                            \
+#define LAUNCH(K, W)                                                                                                         \
   do {                                                                                                                       \
-    if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_implsch<T, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-    hipLaunchKernelGGL((k_implsch<T, W>), dim3(blocks), dim3(64 * W), shmem, s, (const DevTab<T>*)tab, kijs, kijl, (T*)fl1,  \
+    if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)K<T, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+    hipLaunchKernelGGL((K<T, W>), dim3(blocks), dim3(64 * W), shmem, s, (const DevTab<T>*)tab, kijs, kijl, (T*)fl1,          \
                        (const T*)wvprpt, (T*)ff, (T*)intf, mij, (T*)xllws, (T*)dbg);                                         \
   } while (0)
-  if (wpb == 4) LAUNCH(4);
-  else if (wpb == 2) LAUNCH(2);
-  else LAUNCH(1);
+  if (variant == 2) {
+    if (wpb == 7) LAUNCH(k_implsch2, 7);
+    else if (wpb == 4) LAUNCH(k_implsch2, 4);
+    else if (wpb == 2) LAUNCH(k_implsch2, 2);
+    else LAUNCH(k_implsch2, 1);
+  } else {
+    if (wpb == 4) LAUNCH(k_implsch, 4);
+    else if (wpb == 2) LAUNCH(k_implsch, 2);
+    else LAUNCH(k_implsch, 1);
+  }
 #undef LAUNCH
   return 0;
 }

@@ -1,0 +1,817 @@
+// =====================================================================================================================
+// Variant 2 of the fused IMPLSCH kernel (used whenever the DIA tables have the rotation structure, DevTab::DIA_PULL).
+//
+//  * Two LDS tiles per point instead of three: F and FLD(wind input).  SINPUT keeps its per-frequency directional
+//    integrals (the only thing STRESSO needs from SPOS) in lane-m registers, and SDISSIP, the DIA increments and the
+//    implicit update of a frequency row are applied in ONE sweep: interaction MC is the last one that reads or feeds row
+//    MC-4, so that row is dissipated, limited and overwritten in place as soon as MC is done.
+//  * The point-scalar chains (TAUT_Z0 Newton iteration, TAU_PHI_HF quadratures, WSIGSTAR, the swell-damping set-up,
+//    SDIWBK) are wave-uniform work: executed per wave they occupy 64 lanes for one result.  The WPB waves (= WPB points)
+//    of a block post their inputs to LDS and one wave evaluates them lane-per-point between two block barriers.
+// =====================================================================================================================
+enum {
+  C_WSWAVE = 0, C_WDWAVE, C_TAUW, C_TAUWDIR, C_UFRIC, C_Z0M, C_Z0B, C_CHRNCK, C_AIRD, C_WSTAR, C_RNFAC, C_RAORW,
+  C_XS, C_YS, C_PHIWA, C_MIJ, C_F1DCOS3, C_F1DCOS2, C_F1DSIN2, C_F1D, C_UORBT, C_AORB, C_SIGN, C_TEMP2, C_PTURB, C_AIRDPVISC,
+  C_EMEAN, C_F1MEAN, C_EMAXDPT, C_DEPTH, C_SDS, C_SPARE, NSC
+};
+
+// tau_phi_hf.F90:125-301 for one point per lane: the directional integrals of F(:,MIJ) come in as arguments
+template <typename T>
+__device__ void tau_phi_hf_pt(const DevTab<T>& tb, int MIJ, bool LTAUWSHELTER, T Z0M, T AIRD, T RNFAC, T F1DCOS3, T F1DCOS2,
+                              T F1DSIN2, T F1D, T& UST, T& TAUHF, T& PHIHF, bool LLPHIHF) {
+  const T X0G = tb.X0TAUHF * tb.G;
+  T USTPH = UST;
+  const T XLOGGZ0 = m_log(tb.G * Z0M);
+  const T OMEGACC = m_max(tb.ZPIFR[MIJ - 1], X0G / UST);
+  const T SQRTZ0OG = m_sqrt(Z0M * tb.GM1);
+  const T SQRTGZ0 = T(1) / SQRTZ0OG;
+  const T ZINF = m_log(OMEGACC * SQRTZ0OG);
+  const T fr5 = tb.FR5[MIJ - 1];
+  const T CONSTTAU = tb.ZPI4GM2 * fr5;
+  T CONST1 = T(0), CONST2 = T(0);
+  const bool NORMA = tb.LLNORMAGAM != 0;
+  if (NORMA) {
+    const T CONFG = tb.GAMNCONST * fr5 * RNFAC * SQRTGZ0;
+    CONST1 = CONFG * F1DSIN2;
+    CONST2 = CONFG * F1D;
+  }
+  T TAUL = UST * UST;
+  const T DELZ = m_max((T(0) - ZINF) / T(JTOT - 1), T(0));
+  TAUHF = T(0);
+  T acc = T(0);
+  for (int J = 0; J < JTOT; J++) {
+    const T Y = m_exp(ZINF + T(J) * DELZ);
+    const T CM1 = (Y * SQRTGZ0) * tb.GM1;
+    const T LC = XLOGGZ0 + T(2) * m_log(CM1);
+    const T ZARG = tb.XKAPPA * f_rcp(UST * CM1 + tb.ZALP);
+    const T ZLOG = m_min(LC + ZARG, T(0));
+    const T ZBETA = m_pow4(ZLOG) * f_exp(ZLOG);
+    const T ZNZ = ZBETA * UST * Y;
+    const T GAMNORMA = NORMA ? f_div(T(1) + CONST1 * ZNZ, T(1) + CONST2 * ZNZ) : T(1);
+    if (LTAUWSHELTER) {
+      const T FNC2 = F1DCOS3 * CONSTTAU * ZBETA * TAUL * tb.WTAUHF[J] * DELZ * GAMNORMA;
+      TAUL = m_max(TAUL - tb.TAUWSHELTER * FNC2, T(0));
+      UST = f_sqrt(TAUL);
+      TAUHF = TAUHF + FNC2;
+    } else {
+      acc = acc + (ZBETA * tb.WTAUHF[J]) * GAMNORMA;
+    }
+  }
+  if (!LTAUWSHELTER) TAUHF = F1DCOS3 * CONSTTAU * TAUL * acc * DELZ;
+  PHIHF = T(0);
+  if (LLPHIHF) {
+    TAUL = USTPH * USTPH;
+    const T CONSTPHI = AIRD * tb.ZPI4GM1 * fr5;
+    for (int J = 0; J < JTOT; J++) {
+      const T Y = m_exp(ZINF + T(J) * DELZ);
+      const T CM1 = (Y * SQRTGZ0) * tb.GM1;
+      const T LC = XLOGGZ0 + T(2) * m_log(CM1);
+      const T ZARG = tb.XKAPPA * f_rcp(USTPH * CM1 + tb.ZALP);
+      const T ZLOG = m_min(LC + ZARG, T(0));
+      const T ZBETA = m_pow4(ZLOG) * f_exp(ZLOG);
+      const T ZNZ = ZBETA * UST * Y;
+      const T GAMNORMA = NORMA ? f_div(T(1) + CONST1 * ZNZ, T(1) + CONST2 * ZNZ) : T(1);
+      if (LTAUWSHELTER) {
+        const T FNC2 = ZBETA * TAUL * tb.WTAUHF[J] * DELZ * GAMNORMA;
+        TAUL = m_max(TAUL - tb.TAUWSHELTER * F1DCOS3 * CONSTTAU * FNC2, T(0));
+        USTPH = f_sqrt(TAUL);
+        PHIHF = PHIHF + FNC2 * (T(1) / Y);
+      } else {
+        PHIHF = PHIHF + ((ZBETA * tb.WTAUHF[J]) * GAMNORMA) * (T(1) / Y);
+      }
+    }
+    if (LTAUWSHELTER) PHIHF = F1DCOS2 * CONSTPHI * SQRTZ0OG * PHIHF;
+    else PHIHF = F1DCOS2 * CONSTPHI * SQRTZ0OG * TAUL * PHIHF * DELZ;
+  }
+}
+
+// the scalar half of STRESSO (stresso.F90:180-229) for one point per lane; c[C_XS], c[C_YS], c[C_PHIWA] hold the spectral
+// integrals of the resolved range, the results replace c[C_TAUW], c[C_TAUWDIR] and c[C_PHIWA]
+template <typename T>
+__device__ void stresso_pt(const DevTab<T>& tb, T* c, bool LLPHIWA) {
+  const T AIRD = c[C_AIRD], WDWAVE = c[C_WDWAVE], UFRIC = c[C_UFRIC], Z0M = c[C_Z0M];
+  const int MIJ = (int)c[C_MIJ];
+  T XSTRESS = c[C_XS] / m_max(AIRD, T(1));
+  T YSTRESS = c[C_YS] / m_max(AIRD, T(1));
+  bool LTAUWSHELTER;
+  T USDIRP, UST;
+  if (tb.TAUWSHELTER == T(0)) { LTAUWSHELTER = false; USDIRP = WDWAVE; UST = UFRIC; }
+  else {
+    LTAUWSHELTER = true;
+    const T TAUPX = UFRIC * UFRIC * m_sin(WDWAVE) - tb.TAUWSHELTER * XSTRESS;
+    const T TAUPY = UFRIC * UFRIC * m_cos(WDWAVE) - tb.TAUWSHELTER * YSTRESS;
+    USDIRP = m_atan2(TAUPX, TAUPY);
+    UST = m_pow(TAUPX * TAUPX + TAUPY * TAUPY, T(0.25));
+  }
+  T TAUHF, PHIHF;
+  tau_phi_hf_pt(tb, MIJ, LTAUWSHELTER, Z0M, AIRD, c[C_RNFAC], c[C_F1DCOS3], c[C_F1DCOS2], c[C_F1DSIN2], c[C_F1D], UST, TAUHF, PHIHF,
+                LLPHIWA);
+  XSTRESS = XSTRESS + TAUHF * m_sin(USDIRP);
+  YSTRESS = YSTRESS + TAUHF * m_cos(USDIRP);
+  T TAUW = m_max(m_sqrt(XSTRESS * XSTRESS + YSTRESS * YSTRESS), T(0));
+  const T TAUWDIR = m_atan2(XSTRESS, YSTRESS);
+  if (!tb.LLGCBZ0) TAUW = m_min(TAUW, UFRIC * UFRIC * (T(1) / (T(1) + tb.EPS1)));
+  c[C_TAUW] = TAUW;
+  c[C_TAUWDIR] = TAUWDIR;
+  if (LLPHIWA) c[C_PHIWA] = c[C_PHIWA] + PHIHF;
+}
+
+// scalar set-up of the swell damping (sinput_ard.F90:213-262) from the orbital integrals c[C_UORBT], c[C_AORB]
+template <typename T>
+__device__ void swell_setup_pt(const DevTab<T>& tb, T* c) {
+  const T UFRIC = c[C_UFRIC], Z0M = c[C_Z0M];
+  const T NU_AIR = tb.RNU;
+  const T FACM1_NU_AIR = T(4) / NU_AIR;
+  const T DELABM1 = T(ECWAM_HIP_IAB) / (tb.ABMAX - tb.ABMIN);
+  const T UORBT = T(2) * m_sqrt(c[C_UORBT]);
+  const T AORB = T(2) * m_sqrt(c[C_AORB]);
+  const T RE = FACM1_NU_AIR * UORBT * AORB;
+  const T Z0VIS = tb.RNUM / m_max(UFRIC, T(0.0001));
+  const T Z0TUB = tb.Z0RAT * m_min(tb.Z0TUBMAX, Z0M);
+  const T Z0NOZ = m_max(Z0VIS, Z0TUB);
+  const T ZORB = AORB / Z0NOZ;
+  const T XI = (m_log10(m_max(ZORB, T(3))) - tb.ABMIN) * DELABM1;
+  int IND = (int)XI;
+  if (IND > ECWAM_HIP_IAB - 1) IND = ECWAM_HIP_IAB - 1;
+  const T DELI1 = m_min(T(1), XI - (T)IND);
+  const T DELI2 = T(1) - DELI1;
+  const T FWW = tb.SWELLFT[IND] * DELI2 + tb.SWELLFT[IND + 1] * DELI1;
+  c[C_TEMP2] = FWW * UORBT;
+  T RE_C;
+  if (tb.SWELLF6 == T(1)) RE_C = tb.SWELLF4;
+  else RE_C = tb.SWELLF4 * m_pow(T(2) / AORB, T(1) - tb.SWELLF6);
+  T PVISC, PTURB;
+  if (tb.SWELLF7 > T(0)) {
+    const T SMOOTH = T(0.5) * m_tanh((RE - RE_C) * tb.SWELLF7M1);
+    PTURB = T(0.5) + SMOOTH;
+    PVISC = T(0.5) - SMOOTH;
+  } else if (RE <= RE_C) { PTURB = T(0); PVISC = T(0.5); }
+  else { PTURB = T(0.5); PVISC = T(0); }
+  c[C_PTURB] = PTURB;
+  c[C_AIRDPVISC] = PVISC * c[C_RAORW];
+}
+
+// sdiwbk.F90:88-103, one point per lane
+template <typename T>
+__device__ T sdiwbk_pt(const DevTab<T>& tb, T EMAXDPT, T EMEAN, T F1MEAN, T DEPTH) {
+  if (!(tb.LBIWBK && DEPTH < T(50.0))) return T(0);
+  const T ALPH = T(2) * EMAXDPT / EMEAN;
+  const T ARG = m_min(ALPH, T(50));
+  T Q_OLD = m_exp(-ARG), Q = T(0);
+  for (int ic = 0; ic < 15; ic++) {
+    const T EXPQ = m_exp(-ARG * (T(1) - Q_OLD));
+    Q = Q_OLD - (EXPQ - Q_OLD) / (ARG * EXPQ - T(1));
+    const T REL_ERR = m_abs(Q - Q_OLD) / Q_OLD;
+    if (REL_ERR < T(0.00001)) break;
+    Q_OLD = Q;
+  }
+  Q = m_min(Q, T(1));
+  return T(2) * ALPH * Q * F1MEAN;
+}
+
+// one value into lane m of a lane-m register
+template <typename T>
+__device__ __forceinline__ void lane_put(T& r, int lane, int m, T v) { r = (lane == m) ? v : r; }
+
+// sinput_ard.F90:153-520 for variant 2.  STORE: write FLD (second SINFLX call); first call needs XLLWS and the stresses only.
+// Out: xmask (XLLWS), lane-m registers rX/rY/rS = SUM_K SPOS*SINTH, SUM_K SPOS*COSTH, SUM_K SPOS, and the per-direction
+// accumulator apl = SUM_M RHOWG_DFIM(M)*(FLD*F-SPOS) of the negative wind input (stresso.F90:160-168).
+template <typename T, int NGST, bool LLSNEG>
+__device__ void sinput_ard2(const DevTab<T>& tb, const T* sF, T* sFLD, const Lane<T>& L, T rWAVNUM, T rCINV, T rXK2CG, T WDWAVE,
+                            T UFRIC, T Z0M, T coswdif, T sinwdif2, T RAORW, T RNFAC, T SIG_N, T TEMP2, T PTURB, T AIRD_PVISC,
+                            unsigned long long& xmask, T& rX, T& rY, T& rS, T& apl) {
+  const T AVG_GST = T(1) / T(NGST);
+  const T CONST1 = tb.BETAMAXOXKAPPA2;
+  const T CONSTN = tb.DELTH / (tb.XKAPPA * tb.ZPI);
+  const T ABS_TAUWSHELTER = m_abs(tb.TAUWSHELTER);
+  const bool LTAUWSHELTER = (ABS_TAUWSHELTER != T(0));
+  const bool LLNORMAGAM = tb.LLNORMAGAM != 0;
+  T CSTRNFAC = T(0);
+  if (LLNORMAGAM) CSTRNFAC = CONSTN * RNFAC / RAORW;
+  const T NU_AIR = tb.RNU;
+  const T FU = m_abs(tb.SWELLF3), FUD = tb.SWELLF2;
+
+  T USTP[2], USTPM1[2], XSTRESS[2], YSTRESS[2], TAUX[2], TAUY[2], UCN[2], UCNZALPD[2], GAMNORMA[2];
+  if (NGST == 1) USTP[0] = UFRIC;
+  else { USTP[0] = UFRIC * (T(1) + SIG_N); USTP[1] = UFRIC * (T(1) - SIG_N); }
+#pragma unroll
+  for (int ig = 0; ig < NGST; ig++) USTPM1[ig] = T(1) / m_max(USTP[ig], tb.EPSUS);
+  T ROGOROAIR = T(0);
+  if (LTAUWSHELTER) {
+#pragma unroll
+    for (int ig = 0; ig < NGST; ig++) {
+      XSTRESS[ig] = T(0); YSTRESS[ig] = T(0);
+      const T USG2 = USTP[ig] * USTP[ig];
+      TAUX[ig] = USG2 * m_sin(WDWAVE);
+      TAUY[ig] = USG2 * m_cos(WDWAVE);
+    }
+    ROGOROAIR = tb.G / RAORW;
+  }
+  GAMNORMA[0] = T(1); GAMNORMA[1] = T(1);
+  const T sinthk = tb.SINTH[L.k], costhk = tb.COSTH[L.k];
+  xmask = 0ull;
+  rX = T(0); rY = T(0); rS = T(0); apl = T(0);
+  T rZCN = T(0), rCOEF5 = T(0);
+  if (L.actm) {
+    rZCN = m_log(rWAVNUM * Z0M);
+    if (LLSNEG) rCOEF5 = -tb.SWELLF5 * T(2) * m_sqrt(T(2) * NU_AIR * tb.ZPIFR[L.lane]);
+  }
+  T COSU[2], SINU[2];
+
+  for (int m = 0; m < L.NFRE; m++) {
+    const T SIG = lane_get(L.rZPIFR, m);
+    const T SIG2 = SIG * SIG;
+    const T CONST = SIG * CONST1;
+    const T cinv_m = lane_get(rCINV, m), wavnum_m = lane_get(rWAVNUM, m);
+    T COEF = T(0), COEF5 = T(0);
+    if (LLSNEG) {
+      COEF = -tb.SWELLF * T(16) * SIG2 / tb.G;
+      COEF5 = lane_get(rCOEF5, m);
+    }
+    T CONSTF = T(0);
+    if (LTAUWSHELTER) {
+#pragma unroll
+      for (int ig = 0; ig < NGST; ig++) {
+        const T TAUPX = TAUX[ig] - ABS_TAUWSHELTER * XSTRESS[ig];
+        const T TAUPY = TAUY[ig] - ABS_TAUWSHELTER * YSTRESS[ig];
+        const T h = f_sqrt(TAUPX * TAUPX + TAUPY * TAUPY);
+        const bool zero = !(h > T(0));
+        const T rh = f_rcp(h);
+        COSU[ig] = zero ? T(1) : TAUPY * rh;
+        SINU[ig] = zero ? T(0) : TAUPX * rh;
+        USTP[ig] = f_sqrt(h);
+        USTPM1[ig] = f_rcp(m_max(USTP[ig], tb.EPSUS));
+      }
+      CONSTF = ROGOROAIR * cinv_m * lane_get(L.rDFIM, m);
+    }
+#pragma unroll
+    for (int ig = 0; ig < NGST; ig++) {
+      UCN[ig] = USTP[ig] * cinv_m;
+      UCNZALPD[ig] = tb.XKAPPA * f_rcp(UCN[ig] + tb.ZALP);
+    }
+    const T ZCN = lane_get(rZCN, m);
+    const T CNSN = CONST * RAORW;
+    T XNGAMCONST = T(0);
+    if (LLNORMAGAM) XNGAMCONST = CSTRNFAC * lane_get(rXK2CG, m);
+    T DSTAB1 = T(0), TEMP1 = T(0);
+    if (LLSNEG) {
+      DSTAB1 = COEF5 * AIRD_PVISC * wavnum_m;
+      TEMP1 = COEF * RAORW;
+    }
+    const T f = sF[m * L.NAP + L.k];
+    T g0[2], ds[2];
+    bool xl = false, grow[2];
+#pragma unroll
+    for (int ig = 0; ig < NGST; ig++) {
+      const T coslp = LTAUWSHELTER ? (costhk * COSU[ig] + sinthk * SINU[ig]) : coswdif;
+      T gam0 = T(0), ZLOG = T(0);
+      bool neg = false;
+      if (coslp > T(0.01)) {
+        ZLOG = ZCN + UCNZALPD[ig] * f_rcp(coslp);
+        neg = ZLOG < T(0);
+      }
+      grow[ig] = __builtin_amdgcn_ballot_w64(neg) != 0ull;
+      if (grow[ig]) {
+        if (neg) {
+          const T ZLOG2X = ZLOG * ZLOG * (coslp * UCN[ig]);
+          gam0 = f_exp(ZLOG) * ZLOG2X * ZLOG2X * CNSN;
+          xl = true;
+        }
+        if (LLNORMAGAM) {
+          const T a = L.act ? gam0 * f : T(0);
+          const T SUMF = usum(a);
+          const T SUMFSIN2 = usum(a * sinwdif2);
+          const T ZNZ = XNGAMCONST * USTPM1[ig];
+          GAMNORMA[ig] = (T(1) + ZNZ * SUMFSIN2) / (T(1) + ZNZ * SUMF);
+        }
+      }
+      T dstab = T(0);
+      if (LLSNEG) {
+        const T DSTAB2 = TEMP1 * (TEMP2 + (FU + FUD * coslp) * USTP[ig]);
+        dstab = DSTAB1 + PTURB * DSTAB2;
+      }
+      g0[ig] = gam0;
+      ds[ig] = dstab;
+    }
+    T SLP_AVG = T(0), FLP_AVG = T(0), xrow = T(0), yrow = T(0);
+#pragma unroll
+    for (int ig = 0; ig < NGST; ig++) {
+      T SLP = g0[ig] * GAMNORMA[ig];
+      const T FLP = SLP + ds[ig];
+      SLP = SLP * f;
+      if (grow[ig]) {
+        const T sa = L.act ? SLP : T(0);
+        const T xs = usum(sa * sinthk), ys = usum(sa * costhk);
+        if (LTAUWSHELTER) {
+          XSTRESS[ig] = XSTRESS[ig] + CONSTF * xs;
+          YSTRESS[ig] = YSTRESS[ig] + CONSTF * ys;
+        }
+        xrow = xrow + xs;
+        yrow = yrow + ys;
+      }
+      if (ig == 0) { SLP_AVG = SLP; FLP_AVG = FLP; }
+      else { SLP_AVG = SLP_AVG + SLP; FLP_AVG = FLP_AVG + FLP; }
+    }
+    const T spos = AVG_GST * SLP_AVG, fld = AVG_GST * FLP_AVG;
+    if (grow[0] || (NGST > 1 && grow[1])) {
+      lane_put(rX, L.lane, m, AVG_GST * xrow);
+      lane_put(rY, L.lane, m, AVG_GST * yrow);
+      if (LLSNEG) lane_put(rS, L.lane, m, usum(L.act ? spos : T(0)));
+    }
+    if (LLSNEG) {
+      apl = apl + (fld * f - spos) * tb.RHOWG_DFIM[m];
+      if (L.act) sFLD[m * L.NAP + L.k] = fld;
+    }
+    if (xl) xmask |= (1ull << m);
+  }
+}
+
+// One sweep over the DIA interactions MC = 1..NFRE+4 (snonlin.F90:126-494, ISNONLIN = 0, pull form of snonlin_pull above);
+// after interaction MC row R = MC-4 is final: SDISSIP_ARD (sdissip_ard.F90:117-314), SDIWBK, SBOTTOM, the implicit update
+// with its limiter and the WNFLUXES integrands (implsch.F90:294-395) are applied to it and F(:,R) is overwritten in place.
+template <typename T, int NTAPC>
+__device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const Lane<T>& L, T rWAVNUM, T rCINV, T rXK2CG, T rRH, T UFRIC,
+                             T coswdif, T RAORW, T DEPTH, T AKMEAN, T SDS, bool shallow_brk, T USFM, T FLM, T& a_t, T& a_x) {
+  const int SKIP = tb.DBG_SKIP;
+  T ENHFR = m_max(T(0.75) * DEPTH * AKMEAN, T(0.5));
+  ENHFR = T(1) + (T(5.5) / ENHFR) * (T(1) - T(.833) * ENHFR) * m_exp(-T(1.25) * ENHFR);
+  const int NAP = L.NAP, NFRE = L.NFRE, NANG = L.NANG, k = L.k;
+  const int MFR1STFR = -tb.MFRSTLW + 1;
+  const int MFRLSTFR = NFRE - tb.KFRH + MFR1STFR;
+  int k1[2], k2[2], k11[2], k21[2], ik1[2], ik2[2], ik1s[2], ik2s[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; kh++) {
+    k1[kh] = tb.K1W[kh][k]; k2[kh] = tb.K2W[kh][k]; k11[kh] = tb.K11W[kh][k]; k21[kh] = tb.K21W[kh][k];
+    ik1[kh] = tb.IK1[kh][k]; ik2[kh] = tb.IK2[kh][k];
+    const int c1 = k - tb.D11[kh], c2 = k - tb.D21[kh];
+    ik1s[kh] = tb.IK1[kh][c1 < 0 ? c1 + NANG : (c1 >= NANG ? c1 - NANG : c1)];
+    ik2s[kh] = tb.IK2[kh][c2 < 0 ? c2 + NANG : (c2 >= NANG ? c2 - NANG : c2)];
+  }
+  // dissipation constants
+  const T TPIINV = T(1) / tb.ZPI;
+  const T TMP03 = T(1) / (tb.SDSBR * tb.MICHE);
+  const T SSDSC6M1 = T(1) - tb.SSDSC6;
+  const int ntap = NTAPC > 0 ? NTAPC : tb.NTAP;
+  T wgt[NTAPC > 0 ? NTAPC : 1];
+  int idx[NTAPC > 0 ? NTAPC : 1];
+  if (NTAPC > 0) {
+#pragma unroll
+    for (int j = 0; j < NTAPC; j++) { wgt[j] = tb.SATWEIGHTS[j][k]; idx[j] = tb.INDICESSAT[j][k]; }
+  }
+  const T rFACSAT = rWAVNUM * TPIINV * rXK2CG;  // lane m
+  T FACTURB = T(0);
+  const bool turb = (tb.SSDSC5 != T(0));
+  if (turb) FACTURB = (T(2) * tb.SSDSC5 / tb.G) * RAORW * UFRIC * UFRIC;
+  // update constants
+  const T DELT = T(tb.IDELT);
+  const T DELTM = T(1) / DELT;
+  const T DELT5 = tb.XIMP * DELT;
+  T rSBO = T(0);  // sbottom.F90:79-89, lane m
+  if (L.actm && L.lane < tb.NFRE_RED && DEPTH < tb.BATHYMAX) {
+    const T ARG = m_min(T(2) * DEPTH * rWAVNUM, T(50));
+    rSBO = (-T(2) * T(0.038) * tb.GM1) * rWAVNUM / m_sinh(ARG);
+  }
+  const bool flux_snl = tb.LCFLX && tb.LWVFLX_SNL;
+  a_t = T(0); a_x = T(0);
+
+  T aS[8], aF[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { aS[i] = T(0); aF[i] = T(0); }
+  for (int MCb = 0; MCb < tb.MLSTHG; MCb += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int MC = MCb + 1 + j;
+      if (MC <= tb.MLSTHG) {
+        const int c0 = (1 + j) & 7, cm = (1 + j + 4) & 7, cm1 = (1 + j + 5) & 7, cp = (1 + j + 2) & 7, cp1 = (1 + j + 3) & 7;  // rows MC, MC-4, MC-3, MC+2, MC+3
+        if (!(SKIP & 8)) {
+          const int IC = tb.INLCOEF[MC - 1][0], IP = tb.INLCOEF[MC - 1][1], IP1 = tb.INLCOEF[MC - 1][2];
+          const int IM = tb.INLCOEF[MC - 1][3], IM1 = tb.INLCOEF[MC - 1][4];
+          const T* R = tb.RNLCOEF[MC - 1];
+          const T FTAIL = R[0], GW1 = R[1], GW2 = R[2], GW3 = R[3], GW4 = R[4];
+          const T FKLAMPA = R[5], FKLAMPB = R[6], FKLAMP2 = R[7], FKLAMP1 = R[8];
+          const T FKLAPA2 = R[9], FKLAPB2 = R[10], FKLAP12 = R[11], FKLAP22 = R[12];
+          const T GW5 = R[13], GW6 = R[14], GW7 = R[15], GW8 = R[16];
+          const T FKLAMMA = R[17], FKLAMMB = R[18], FKLAMM2 = R[19], FKLAMM1 = R[20];
+          const T FKLAMA2 = R[21], FKLAMB2 = R[22], FKLAM12 = R[23], FKLAM22 = R[24];
+          const T FTEMP = tb.AF11[MC - 1] * ENHFR;
+          const bool mid = (MC > MFR1STFR && MC < MFRLSTFR);
+          const T fIP = sF[IP * NAP + k], fIP1 = sF[IP1 * NAP + k], fIM = sF[IM * NAP + k], fIM1 = sF[IM1 * NAP + k];
+          T FIJ = sF[IC * NAP + k];
+          if (!mid) FIJ = FIJ * FTAIL;
+          const T up = GW1 * fIP + GW3 * fIP1, vp = GW2 * fIP + GW4 * fIP1;
+          const T um = GW5 * fIM + GW7 * fIM1, vm = GW6 * fIM + GW8 * fIM1;
+#pragma unroll
+          for (int kh = 0; kh < 2; kh++) {
+            const T SAP = lane_pull(up, k1[kh]) + lane_pull(vp, k11[kh]);
+            const T SAM = lane_pull(um, k2[kh]) + lane_pull(vm, k21[kh]);
+            T FAD1 = FIJ * (SAP + SAM);
+            const T FAD2 = FAD1 - T(2) * SAP * SAM;
+            FAD1 = FAD1 + FAD2;
+            const T FCEN = FTEMP * FIJ;
+            const T AD = FAD2 * FCEN;
+            const T DELAD = FAD1 * FTEMP;
+            const T DELAP = (FIJ - T(2) * SAM) * tb.DAL1 * FCEN;
+            const T DELAM = (FIJ - T(2) * SAP) * tb.DAL2 * FCEN;
+            const T A2 = lane_pull(AD, ik2[kh]), D2 = lane_pull(DELAM, ik2[kh]);
+            const T A1 = lane_pull(AD, ik1[kh]), P1 = lane_pull(DELAP, ik1[kh]);
+            const T A2s = lane_pull(AD, ik2s[kh]), D2s = lane_pull(DELAM, ik2s[kh]);
+            const T A1s = lane_pull(AD, ik1s[kh]), P1s = lane_pull(DELAP, ik1s[kh]);
+            aS[c0] -= T(2) * AD;
+            aF[c0] -= T(2) * DELAD;
+            aS[cm] += A2 * FKLAMM1 + A2s * FKLAMM2;
+            aF[cm] += D2 * FKLAM12 + D2s * FKLAM22;
+            aS[cm1] += A2 * FKLAMMA + A2s * FKLAMMB;
+            aF[cm1] += D2 * FKLAMA2 + D2s * FKLAMB2;
+            aS[cp] += A1 * FKLAMP1 + A1s * FKLAMP2;
+            aF[cp] += P1 * FKLAP12 + P1s * FKLAP22;
+            aS[cp1] += A1 * FKLAMPA + A1s * FKLAMPB;
+            aF[cp1] += P1 * FKLAPA2 + P1s * FKLAPB2;
+          }
+        }
+        const int m = MC - 5;  // 0-based row MC-4: final now
+        if (m >= 0 && m < NFRE) {
+          T* row = sF + m * NAP;
+          // --- SDISSIP_ARD
+          T D = T(0);
+          if (!(SKIP & 4)) {
+            T b = T(0);
+            if (NTAPC > 0) {
+#pragma unroll
+              for (int jj = 0; jj < NTAPC; jj++) b = b + wgt[jj] * row[idx[jj]];
+            } else {
+              for (int jj = 0; jj < ntap; jj++) b = b + tb.SATWEIGHTS[jj][k] * row[tb.INDICESSAT[jj][k]];
+            }
+            b = b * lane_get(rFACSAT, m);
+            const T bth0 = umax(L.act ? b : T(0));
+            const T SSDSC2_SIG = tb.SSDSC2 * lane_get(L.rZPIFR, m);
+            const T ZCOEF = SSDSC2_SIG * tb.SSDSC6;
+            const T ZCOEFM1 = SSDSC2_SIG * SSDSC6M1;
+            const T a0 = m_max(T(0), bth0 * TMP03 - tb.SSDSC4);
+            const T a1 = m_max(T(0), b * TMP03 - tb.SSDSC4);
+            D = ZCOEF * (a0 * a0) + ZCOEFM1 * (a1 * a1);
+            if (turb) D = D - (tb.ZPIFR[m] * lane_get(rWAVNUM, m) * FACTURB) * coswdif;
+          }
+          const T f = row[k];
+          const T fldw = sFLD[m * NAP + k];
+          T sl = (fldw * f + D * f) + aS[cm];
+          T fld = (fldw + D) + aF[cm];
+          // --- SSOURCE, SDIWBK, SBOTTOM, new spectrum
+          T ss = T(0);
+          if (flux_snl) ss = f_div(sl, m_max(T(1) - DELT5 * fld, T(1)));
+          if (shallow_brk && m < tb.NFRE_RED) { sl = sl - SDS * f; fld = fld - SDS; }
+          const T sbo = lane_get(rSBO, m);
+          if (m < tb.NFRE_RED) { sl = sl + sbo * f; fld = fld + sbo; }
+          const T GTEMP1 = m_max(T(1) - DELT5 * fld, T(1));
+          const T GTEMP2 = f_div(DELT * sl, GTEMP1);
+          const T FLHAB = m_min(m_abs(GTEMP2), USFM * (lane_get(L.rCOFRM4, m) * DELT));
+          T fn = f + m_sign(FLHAB, GTEMP2);
+          fn = m_max(fn, FLM);
+          const T flmax = lane_get(L.rFLMAX, m);
+          ss = ss + DELTM * m_min(flmax - fn, T(0));
+          fn = m_min(fn, flmax);
+          if (L.act && !(SKIP & 32)) row[k] = fn;
+          const T rh = lane_get(rRH, m);
+          a_t += rh * ss;
+          a_x += (lane_get(rCINV, m) * rh) * ss;
+        }
+        aS[cm] = T(0);
+        aF[cm] = T(0);
+      }
+    }
+  }
+}
+
+template <typename T, int WPB>
+__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 3 : 2))) k_implsch2(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__ fl1,
+                                                       const T* __restrict__ wvprpt, T* __restrict__ ffa, T* __restrict__ intfa,
+                                                       int* __restrict__ mij_out, T* __restrict__ xllws, T* __restrict__ dbg) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const DevTab<T>& tb = *tp;
+  const int SKIP = tb.DBG_SKIP;
+  const int wave = threadIdx.x >> 6;
+  int ij = kijs + blockIdx.x * WPB + wave;
+  const bool valid = ij < kijl;  // waves past the end redo the last point (they must reach the block barriers) and store nothing
+  if (!valid) ij = kijl - 1;
+  Lane<T> L;
+  L.lane = threadIdx.x & 63;
+  L.NANG = tb.NANG; L.NFRE = tb.NFRE; L.NAP = tb.NANG | 1;
+  L.act = L.lane < L.NANG; L.actm = L.lane < L.NFRE;
+  L.k = L.act ? L.lane : 0;
+  {
+    const int mi = L.actm ? L.lane : 0;
+    L.rDFIM = tb.DFIM[mi]; L.rDFIMOFR = tb.DFIMOFR[mi]; L.rZPIFR = tb.ZPIFR[mi]; L.rCOFRM4 = tb.COFRM4[mi]; L.rFLMAX = tb.FLMAX[mi];
+  }
+  const int NANG = L.NANG, NFRE = L.NFRE, NAP = L.NAP, N = NANG * NFRE;
+  const int tile = NFRE * NAP;
+  T* sF = reinterpret_cast<T*>(smem_raw) + (size_t)wave * (2 * tile + 64);
+  T* sFLD = sF + tile;
+  T* sScr = sFLD + tile;
+  T* sSC = reinterpret_cast<T*>(smem_raw) + (size_t)WPB * (2 * tile + 64);  // [WPB][NSC] point scalars of the block
+  T* c = sSC + wave * NSC;
+
+  // ---- load the spectrum FL1[ij][K][M] (coalesced) into the [M][NAP] tile
+  {
+    const T* g = fl1 + (size_t)ij * N;
+    const float rnf = 1.0f / (float)NFRE;
+    for (int e = L.lane; e < N; e += 64) {
+      const int kk = (int)(((float)e + 0.5f) * rnf), mm = e - kk * NFRE;
+      sF[mm * NAP + kk] = g[e];
+    }
+  }
+  T rWAVNUM = T(1), rCINV = T(0), rXK2CG = T(0), rSTOKFAC = T(0);
+  {
+    const T* wp = wvprpt + (size_t)ij * ECWAM_HIP_NWPR * NFRE;
+    if (L.actm) { rWAVNUM = wp[L.lane]; rCINV = wp[2 * NFRE + L.lane]; rXK2CG = wp[3 * NFRE + L.lane]; rSTOKFAC = wp[4 * NFRE + L.lane]; }
+  }
+  const T ffv = (L.lane < ECWAM_HIP_NFF) ? ffa[(size_t)ij * ECWAM_HIP_NFF + L.lane] : T(0);
+  const T AIRD = lane_get(ffv, 0), WDWAVE = lane_get(ffv, 1), CICOVER = lane_get(ffv, 2), WSWAVE = lane_get(ffv, 3);
+  const T WSTAR = lane_get(ffv, 4), USTRA = lane_get(ffv, 5), VSTRA = lane_get(ffv, 6);
+  const T EMAXDPT = lane_get(ffv, 14), DEPTH = lane_get(ffv, 15);
+  const T RAORW = m_max(AIRD, T(1)) * tb.ROWATERM1;
+  // ---- stage 1 inputs: first TAUT_Z0 (depends on the forcing only)
+  if (L.lane < 13) {
+    // FF slots 7..12 = UFRIC, TAUW, TAUWDIR, Z0M, Z0B, CHRNCK
+    const int slot = (L.lane == 7) ? C_UFRIC : (L.lane == 8) ? C_TAUW : (L.lane == 9) ? C_TAUWDIR : (L.lane == 10) ? C_Z0M
+                     : (L.lane == 11) ? C_Z0B : (L.lane == 12) ? C_CHRNCK : (L.lane == 0) ? C_AIRD : (L.lane == 1) ? C_WDWAVE
+                     : (L.lane == 3) ? C_WSWAVE : (L.lane == 4) ? C_WSTAR : C_SPARE;
+    c[slot] = ffv;
+  }
+  if (L.lane == 0) { c[C_RAORW] = RAORW; c[C_EMAXDPT] = EMAXDPT; c[C_DEPTH] = DEPTH; }
+  __syncthreads();
+  if (wave == 0 && L.lane < WPB) {
+    T* q = sSC + L.lane * NSC;
+    T UFRIC = q[C_UFRIC], Z0M = q[C_Z0M], Z0B = q[C_Z0B], CHRNCK = q[C_CHRNCK];
+    if (!(SKIP & 16)) taut_z0_a(tb, 0, q[C_WSWAVE], q[C_WDWAVE], q[C_TAUW], q[C_TAUWDIR], UFRIC, Z0M, Z0B, CHRNCK);
+    q[C_UFRIC] = UFRIC; q[C_Z0M] = Z0M; q[C_Z0B] = Z0B; q[C_CHRNCK] = CHRNCK;
+    T RNFAC = T(1);
+    if (tb.LLNORMAGAM && tb.LLCAPCHNK) RNFAC = T(1) + tb.DTHRN_A * (T(1) + m_tanh(q[C_WSWAVE] - tb.DTHRN_U));
+    q[C_RNFAC] = RNFAC;
+  }
+
+  // ---- implsch.F90:183-203 (overlaps stage 1)
+  const T thk = tb.TH[L.k];
+  const T coswdif = m_cos(thk - WDWAVE);
+  T sinwdif2 = m_sin(thk - WDWAVE);
+  sinwdif2 = sinwdif2 * sinwdif2;
+  WSYNC();
+  // ---- SDEPTHLIM (sdepthlim.F90:64-78, semean.F90:82-120)
+  if (tb.LBIWBK) {
+    const T t2 = colsum(sF, L);
+    T EM = tb.EPSMIN + usum(L.actm ? tb.DFIM[L.lane] * t2 : T(0));
+    EM = EM + (tb.WETAIL * tb.FR[NFRE - 1] * tb.DELTH) * lane_get(t2, NFRE - 1);
+    const T s = m_min(EMAXDPT / EM, T(1));
+    WSYNC();
+    if (L.act)
+      for (int m = 0; m < NFRE; m++) sF[m * NAP + L.k] = m_max(sF[m * NAP + L.k] * s, tb.EPSMIN);
+    WSYNC();
+  }
+  // ---- FKMEAN
+  T EMEAN, FMEAN, F1MEAN, AKMEAN, XKMEAN;
+  fkmean(tb, sF, L, rWAVNUM, EMEAN, FMEAN, F1MEAN, AKMEAN, XKMEAN);
+  const T cpos = m_max(T(0), coswdif);
+  const T FLM = (T(1) - T(0.9) * m_min(CICOVER, T(0.99))) * tb.FLMIN * (cpos * cpos);
+  if (L.act) sF[(NFRE - 1) * NAP + L.k] = m_max(sF[(NFRE - 1) * NAP + L.k], FLM);  // sinflx.F90:124-128
+  WSYNC();
+  // orbital velocity / displacement integrals of the swell damping (sinput_ard.F90:213-222)
+  T UORBT_S, AORB_S;
+  {
+    const T temp = colsum(sF, L);
+    T w1 = T(0), w2 = T(0);
+    if (L.actm) {
+      const T sig = tb.ZPIFR[L.lane];
+      w2 = tb.DFIM[L.lane];
+      w1 = w2 * (sig * sig);
+    }
+    UORBT_S = tb.EPSMIN + usum(w1 * temp);
+    AORB_S = tb.EPSMIN + usum(w2 * temp);
+  }
+  __syncthreads();  // stage 1 results
+  T UFRIC = c[C_UFRIC], Z0M = c[C_Z0M];
+  const T RNFAC = c[C_RNFAC];
+
+  // quantities of F(:,MIJ) TAU_PHI_HF integrates (tau_phi_hf.F90:170-196)
+  auto hf_integrals = [&](int MIJ) {
+    const T fm = L.act ? sF[(MIJ - 1) * NAP + L.k] : T(0);
+    const T fc2 = fm * cpos * cpos;
+    const T F1DCOS3 = tb.DELTH * usum(fc2 * cpos);
+    const T F1DCOS2 = tb.DELTH * usum(fc2);
+    T F1DSIN2 = T(0), F1D = T(0);
+    if (tb.LLNORMAGAM) {
+      F1DSIN2 = tb.DELTH * usum(fm * sinwdif2);
+      F1D = tb.DELTH * usum(fm);
+    }
+    if (L.lane == 0) { c[C_F1DCOS3] = F1DCOS3; c[C_F1DCOS2] = F1DCOS2; c[C_F1DSIN2] = F1DSIN2; c[C_F1D] = F1D; c[C_MIJ] = T(MIJ); }
+  };
+  // FRCUTINDEX (frcutindex.F90:84-108)
+  auto frcutindex = [&](T FMEANWS, T UFRICv, T& rRH) -> int {
+    const T FPMH = tb.TAILFACTOR / tb.FR[0];
+    const T FPPM = tb.TAILFACTOR_PM * tb.G / (tb.FRIC * tb.ZPIFR[0]);
+    int MIJ;
+    if (CICOVER <= tb.CITHRSH_TAIL) {
+      const T FM2 = m_max(FMEANWS, FMEAN) * FPMH;
+      const T FPM = FPPM / m_max(UFRICv, tb.EPSMIN);
+      const T FPM4 = m_max(FM2, FPM);
+      MIJ = m_nint(m_log10(FPM4) * tb.FLOGSPRDM1) + 1;
+      MIJ = MIJ < 1 ? 1 : (MIJ > NFRE ? NFRE : MIJ);
+    } else MIJ = NFRE;
+    MIJ = __builtin_amdgcn_readfirstlane(MIJ);
+    rRH = T(0);
+    if (L.actm && L.lane + 1 <= MIJ) {
+      rRH = tb.RHOWG_DFIM[L.lane];
+      if (L.lane + 1 == MIJ && MIJ != NFRE) rRH = T(0.5) * rRH;
+    }
+    return MIJ;
+  };
+
+  // ---- first SINFLX call (sinflx.F90:105-183): XLLWS, MIJ and the wave stress only
+  T FMEANWS = T(0), EMW;
+  int MIJ = NFRE;
+  T rRH = T(0), rX, rY, rS, apl;
+  unsigned long long xmask = 0ull;
+  if (!(SKIP & 1))
+    sinput_ard2<T, 1, false>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, WDWAVE, UFRIC, Z0M, coswdif, sinwdif2, RAORW, RNFAC, T(0), T(0),
+                             T(0), T(0), xmask, rX, rY, rS, apl);
+  else { rX = rY = rS = apl = T(0); }
+  femeanws(tb, sF, L, xmask, FMEANWS, EMW);
+  MIJ = frcutindex(FMEANWS, UFRIC, rRH);
+  {
+    const T wx = rRH * rCINV;
+    const T XS = usum(wx * rX), YS = usum(wx * rY);
+    hf_integrals(MIJ);
+    if (L.lane == 0) {
+      c[C_XS] = XS; c[C_YS] = YS; c[C_UORBT] = UORBT_S; c[C_AORB] = AORB_S;
+      c[C_EMEAN] = EMEAN; c[C_F1MEAN] = F1MEAN;
+    }
+  }
+  // ---- stage 2: STRESSO scalars, second TAUT_Z0, WSIGSTAR, swell set-up, SDIWBK
+  __syncthreads();
+  if (wave == (1 % WPB) && L.lane < WPB) {
+    T* q = sSC + L.lane * NSC;
+    if (!(SKIP & 2)) stresso_pt(tb, q, false);
+    T UF = q[C_UFRIC], Z0 = q[C_Z0M], Z0Bv = q[C_Z0B], CH = q[C_CHRNCK];
+    if (!(SKIP & 16)) taut_z0_a(tb, 1, q[C_WSWAVE], q[C_WDWAVE], q[C_TAUW], q[C_TAUWDIR], UF, Z0, Z0Bv, CH);
+    q[C_UFRIC] = UF; q[C_Z0M] = Z0; q[C_Z0B] = Z0Bv; q[C_CHRNCK] = CH;
+    q[C_SIGN] = wsigstar(tb, q[C_WSWAVE], UF, Z0, q[C_WSTAR]);
+    swell_setup_pt(tb, q);
+    q[C_SDS] = sdiwbk_pt(tb, q[C_EMAXDPT], q[C_EMEAN], q[C_F1MEAN], q[C_DEPTH]);
+  }
+  __syncthreads();
+  UFRIC = c[C_UFRIC]; Z0M = c[C_Z0M];
+  const T SDS = c[C_SDS];
+
+  // ---- second SINFLX call: FLD, XLLWS, MIJ, wave stress and the PHIWA integrals
+  if (!(SKIP & 1))
+    sinput_ard2<T, 2, true>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, WDWAVE, UFRIC, Z0M, coswdif, sinwdif2, RAORW, RNFAC, c[C_SIGN],
+                            c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], xmask, rX, rY, rS, apl);
+  else {
+    rX = rY = rS = apl = T(0);
+    if (L.act)
+      for (int m = 0; m < NFRE; m++) sFLD[m * NAP + L.k] = T(0);
+  }
+  femeanws(tb, sF, L, xmask, FMEANWS, EMW);
+  MIJ = frcutindex(FMEANWS, UFRIC, rRH);
+  __syncthreads();  // every wave has consumed the stage 2 results: the scalar slots can be reused
+  {
+    const T wx = rRH * rCINV;
+    const T XS = usum(wx * rX), YS = usum(wx * rY);
+    const T PH = usum(L.act ? apl : T(0)) + usum(rRH * rS);
+    hf_integrals(MIJ);
+    if (L.lane == 0) { c[C_XS] = XS; c[C_YS] = YS; c[C_PHIWA] = PH; }
+  }
+  // ---- stage 3: STRESSO scalars of the second call; its results are first needed by WNFLUXES, after the sweep
+  __syncthreads();
+  if (wave == (2 % WPB) && L.lane < WPB && !(SKIP & 2)) stresso_pt(tb, sSC + L.lane * NSC, true);
+
+  // ---- SDISSIP + SNONLIN + update sweep
+  const bool shallow_brk = tb.LBIWBK && (DEPTH < T(50.0));
+  const T USFM = UFRIC * m_max(FMEANWS, FMEAN);
+  T a_t, a_x;
+  WSYNC();
+  if (tb.NTAP == 17) source_sweep<T, 17>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, rRH, UFRIC, coswdif, RAORW, DEPTH, AKMEAN, SDS, shallow_brk, USFM, FLM, a_t, a_x);
+  else if (tb.NTAP == 11) source_sweep<T, 11>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, rRH, UFRIC, coswdif, RAORW, DEPTH, AKMEAN, SDS, shallow_brk, USFM, FLM, a_t, a_x);
+  else if (tb.NTAP == 7) source_sweep<T, 7>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, rRH, UFRIC, coswdif, RAORW, DEPTH, AKMEAN, SDS, shallow_brk, USFM, FLM, a_t, a_x);
+  else source_sweep<T, 0>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, rRH, UFRIC, coswdif, RAORW, DEPTH, AKMEAN, SDS, shallow_brk, USFM, FLM, a_t, a_x);
+  WSYNC();
+  __syncthreads();  // stage 3 results
+  const T TAUW = c[C_TAUW], TAUWDIR = c[C_TAUWDIR], PHIWA = c[C_PHIWA];
+  const T Z0B = c[C_Z0B], CHRNCK = c[C_CHRNCK];
+  if (dbg && L.lane == 0 && valid) {
+    T* d = dbg + (size_t)ij * 32;
+    d[0] = EMEAN; d[1] = FMEAN; d[2] = F1MEAN; d[3] = AKMEAN; d[4] = XKMEAN; d[5] = FMEANWS; d[6] = PHIWA;
+  }
+
+  // ---- WNFLUXES (wnfluxes.F90:147-330), LWNEMOCOUWRS = F
+  T TAUXD = T(0), TAUYD = T(0), TAUOCXD = T(0), TAUOCYD = T(0), TAUOC = T(0), PHIOCD = T(0), PHIEPS = T(0), PHIAW = T(0);
+  if (tb.LCFLX) {
+    if (!L.act) { a_t = T(0); a_x = T(0); }
+    const T PHILF = usum(a_t);
+    const T XSTRESS = usum(a_x * tb.SINTH[L.k]);
+    const T YSTRESS = usum(a_x * tb.COSTH[L.k]);
+    const T EPSUS3 = tb.EPSUS * m_sqrt(tb.EPSUS);
+    const T ZCITHRS = tb.CIBLOCK;
+    const T CITHRSH_INV = T(1) / m_max(tb.CITHRSH, T(0.01));
+    const T ZMAXEXP = T(10);
+    T OOVAL = T(1), USTAR = UFRIC;
+    if (tb.LICERUN && tb.LWAMRSETCI && CICOVER > ZCITHRS) {
+      OOVAL = m_exp(-m_min(m_pow4(CICOVER * CITHRSH_INV), ZMAXEXP));
+      const T U10P = m_max(WSWAVE, tb.EPSU10);
+      const T CD_BULK = m_min((T(1.03E-3) + T(0.04E-3) * m_pow(U10P, T(1.48))) * m_pow(U10P, T(-0.21)), T(0.003));
+      const T CD_WAVE = (UFRIC / U10P) * (UFRIC / U10P);
+      const T CD_ICE = OOVAL * CD_WAVE + (T(1) - OOVAL) * CD_BULK;
+      USTAR = m_max(m_sqrt(CD_ICE) * U10P, tb.EPSUS);
+    }
+    const T TAU = AIRD * m_max(USTAR * USTAR, tb.EPSUS);
+    TAUXD = TAU * m_sin(WDWAVE);
+    TAUYD = TAU * m_cos(WDWAVE);
+    TAUOCXD = TAUXD - OOVAL * XSTRESS;
+    TAUOCYD = TAUYD - OOVAL * YSTRESS;
+    const T TAUO = m_sqrt(TAUOCXD * TAUOCXD + TAUOCYD * TAUOCYD);
+    TAUOC = m_min(m_max(TAUO / TAU, tb.TAUOCMIN), tb.TAUOCMAX);
+    if (tb.LWCOUAST && (USTRA != T(0) || VSTRA != T(0))) {
+      TAUXD = USTRA; TAUOCXD = USTRA * TAUOC; TAUYD = VSTRA; TAUOCYD = VSTRA * TAUOC;
+    }
+    const T XN = AIRD * m_max(USTAR * USTAR * USTAR, EPSUS3);
+    PHIOCD = OOVAL * (PHILF - PHIWA) + (T(1) - OOVAL) * T(-3.75) * XN;
+    PHIEPS = m_min(m_max(PHIOCD / XN, tb.PHIEPSMIN), tb.PHIEPSMAX);
+    PHIOCD = PHIEPS * XN;
+    PHIAW = OOVAL * PHIWA / XN + (T(1) - OOVAL) * T(3.75);
+  }
+
+  // ---- second FKMEAN / FEMEANWS, IMPHFTAIL, SETICE, STOKESDRIFT (implsch.F90:422-462)
+  fkmean(tb, sF, L, rWAVNUM, EMEAN, FMEAN, F1MEAN, AKMEAN, XKMEAN);
+  T EMEANWS;
+  femeanws(tb, sF, L, xmask, FMEANWS, EMEANWS);
+  {
+    T rT = T(1) / rXK2CG / rWAVNUM;
+    const T TEMP1 = lane_get(rT, MIJ - 1);
+    rT = rT / TEMP1;
+    const T tf = sF[(MIJ - 1) * NAP + L.k];
+    for (int m = MIJ; m < NFRE; m++) {
+      const T tm = lane_get(rT, m);
+      if (L.act) sF[m * NAP + L.k] = m_max(tm * tf, FLM);
+    }
+  }
+  if (tb.LICERUN && tb.LMASKICE) {  // setice.F90:67-86
+    T CIREDUC, ICEFREE;
+    if (CICOVER > tb.CITHRSH) { CIREDUC = m_max(tb.EPSMIN, T(1) - CICOVER); ICEFREE = T(0); }
+    else { CIREDUC = T(0); ICEFREE = T(1); }
+    const T add = (CIREDUC * tb.FLMIN) * (cpos * cpos);
+    if (L.act)
+      for (int m = 0; m < NFRE; m++) sF[m * NAP + L.k] = sF[m * NAP + L.k] * ICEFREE + add;
+  }
+  T USTOKES, VSTOKES;
+  {  // stokesdrift.F90:89-142
+    const int MO = tb.NFRE_ODD;
+    const T fo = tb.FR[MO - 1];
+    const T CONST = T(2) * tb.DELTH * (tb.ZPI * tb.ZPI * tb.ZPI) / tb.G * m_pow4(fo);
+    T a = T(0);
+    for (int m = 0; m < MO; m++) a += (lane_get(rSTOKFAC, m) * tb.DFIM_SIM[m]) * sF[m * NAP + L.k];
+    a += CONST * sF[(MO - 1) * NAP + L.k];
+    if (!L.act) a = T(0);
+    USTOKES = usum(a * tb.SINTH[L.k]);
+    VSTOKES = usum(a * tb.COSTH[L.k]);
+    if (tb.LICERUN && tb.LWAMRSETCI && CICOVER > tb.CITHRSH) {
+      USTOKES = T(0.016) * WSWAVE * m_sin(WDWAVE) * (T(1) - CICOVER);
+      VSTOKES = T(0.016) * WSWAVE * m_cos(WDWAVE) * (T(1) - CICOVER);
+    }
+    USTOKES = m_min(m_max(USTOKES, T(-1.5)), T(1.5));
+    VSTOKES = m_min(m_max(VSTOKES, T(-1.5)), T(1.5));
+  }
+  // XLLWS as reals into the FLD tile for the coalesced store
+  if (L.act)
+    for (int m = 0; m < NFRE; m++) sFLD[m * NAP + L.k] = ((xmask >> m) & 1ull) ? T(1) : T(0);
+  WSYNC();
+
+  // ---- store FL1, XLLWS (coalesced) and the per-point scalars
+  if (valid) {
+    T* g = fl1 + (size_t)ij * N;
+    T* gx = xllws + (size_t)ij * N;
+    const float rnf = 1.0f / (float)NFRE;
+    for (int e = L.lane; e < N; e += 64) {
+      const int kk = (int)(((float)e + 0.5f) * rnf), mm = e - kk * NFRE;
+      g[e] = sF[mm * NAP + kk];
+      gx[e] = sFLD[mm * NAP + kk];
+    }
+  }
+  if (L.lane == 0) {
+    sScr[7] = UFRIC; sScr[8] = TAUW; sScr[9] = TAUWDIR; sScr[10] = Z0M; sScr[11] = Z0B; sScr[12] = CHRNCK;
+    sScr[16 + 2] = USTOKES; sScr[16 + 3] = VSTOKES;
+    sScr[16 + 5] = TAUXD; sScr[16 + 6] = TAUYD; sScr[16 + 7] = TAUOCXD; sScr[16 + 8] = TAUOCYD; sScr[16 + 9] = TAUOC;
+    sScr[16 + 10] = T(0); sScr[16 + 11] = T(0); sScr[16 + 12] = PHIOCD; sScr[16 + 13] = PHIEPS; sScr[16 + 14] = PHIAW;
+    if (valid) mij_out[ij] = MIJ;
+  }
+  WSYNC();
+  if (valid) {
+    if (L.lane >= 7 && L.lane <= 12) ffa[(size_t)ij * ECWAM_HIP_NFF + L.lane] = sScr[L.lane];
+    if (L.lane < ECWAM_HIP_NINTF) {
+      const int i = L.lane;
+      const bool fluxes = tb.LCFLX && (i >= 5 && i <= 14);
+      if (i == 2 || i == 3 || fluxes) intfa[(size_t)ij * ECWAM_HIP_NINTF + i] = sScr[16 + i];
+      if (tb.LWFLUX && (i == 0 || i == 1)) {
+        const T v = (i == 0) ? ((EMEANWS < tb.WSEMEAN_MIN) ? tb.WSEMEAN_MIN : EMEANWS)
+                             : ((EMEANWS < tb.WSEMEAN_MIN) ? T(2) * tb.FR[NFRE - 1] : FMEANWS);
+        intfa[(size_t)ij * ECWAM_HIP_NINTF + i] = v;
+      }
+    }
+  }
+}

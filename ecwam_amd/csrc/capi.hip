@@ -128,10 +128,53 @@ static int build_tab(const ecwam_hip_params* p, const ecwam_hip_tables* t, DevTa
   return 0;
 }
 
+// ---- lane-primitive self test (one wave): every cross-lane helper of dev.h against serial sums over LDS ----------------
+template <typename T>
+__global__ void k_selftest(int* nbad) {
+  __shared__ T v[4][64];
+  const int lane = threadIdx.x;
+  T q[4];
+  for (int j = 0; j < 4; j++) {
+    q[j] = (lane < 36) ? T((lane * (7 + 2 * j) + 3 * j) % 23 + j) : T(0);  // small integers: every summation order is exact
+    v[j][lane] = q[j];
+  }
+  __syncthreads();
+  T ref[4], mx[4];
+  for (int j = 0; j < 4; j++) {
+    ref[j] = T(0); mx[j] = T(0);
+    for (int l = 0; l < 64; l++) { ref[j] += v[j][l]; mx[j] = m_max(mx[j], v[j][l]); }
+  }
+  int bad = 0;
+  T a, b, c, d;
+  bad += (usum(q[0]) != ref[0]) + (umax(q[1]) != mx[1]);
+  usum2(q[0], q[1], a, b); bad += (a != ref[0]) + (b != ref[1]);
+  usum4(q[0], q[1], q[2], q[3], a, b, c, d); bad += (a != ref[0]) + (b != ref[1]) + (c != ref[2]) + (d != ref[3]);
+  umax2(q[2], q[3], a, b); bad += (a != mx[2]) + (b != mx[3]);
+  bad += (lane_get(q[0], 5) != v[0][5]);
+  bad += (lane_pull(q[1], (lane + 9) & 63) != v[1][(lane + 9) & 63]);
+  bad += (rot_up(q[2], lane, 36) != ((lane < 36) ? v[2][(lane + 35) % 36] : (lane == 36 ? v[2][35] : T(0))));
+  if (bad) atomicAdd(nbad, bad);
+}
+
 extern "C" {
 
 const char* ecwam_hip_last_error(void) { return g_err.c_str(); }
 int ecwam_hip_abi_version(void) { return 1; }
+
+int ecwam_hip_selftest(int device) {
+  HIPCHK(hipSetDevice(device));
+  int* d = nullptr;
+  int h[2] = {0, 0};
+  HIPCHK(hipMalloc(&d, 2 * sizeof(int)));
+  HIPCHK(hipMemset(d, 0, 2 * sizeof(int)));
+  hipLaunchKernelGGL(k_selftest<float>, dim3(1), dim3(64), 0, 0, d);
+  hipLaunchKernelGGL(k_selftest<double>, dim3(1), dim3(64), 0, 0, d + 1);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(h, d, 2 * sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  if (h[0] || h[1]) return fail("ecwam_hip_selftest: a wavefront primitive returned a wrong value");
+  return 0;
+}
 
 int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int real_bytes, int device, ecwam_hip_ctx** out) {
   if (!p || !t || !out) return fail("ecwam_hip_create: null argument");

@@ -97,6 +97,8 @@ __device__ __forceinline__ float f_rcp(float b) { return __builtin_amdgcn_rcpf(b
 __device__ __forceinline__ double f_rcp(double b) { return 1.0 / b; }
 __device__ __forceinline__ float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ double f_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float f_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ double f_rsq(double x) { return 1.0 / sqrt(x); }
 __device__ __forceinline__ float f_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 __device__ __forceinline__ double f_exp(double x) { return exp(x); }
 __device__ __forceinline__ float f_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
@@ -154,6 +156,69 @@ __device__ __forceinline__ T umax(T v) {  // for values >= 0 (identity 0)
   v = m_max(v, dpp_mov<0x142, 0xA>(v, v));
   v = m_max(v, dpp_mov<0x143, 0xC>(v, v));
   return lane_get(v, 63);
+}
+
+// ---- multi-value reductions (gfx950 v_permlane32_swap / v_permlane16_swap): fold the wave so that each 16-lane row (or
+// 32-lane half) carries a different quantity, then ONE DPP butterfly reduces all of them.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// a <- [a.lanes0-31 | b.lanes0-31], b <- [a.lanes32-63 | b.lanes32-63]
+__device__ __forceinline__ void swap32(float& a, float& b) {
+  u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r.x); b = __uint_as_float(r.y);
+}
+// rows of 16 lanes: a <- [a.r0, b.r0, a.r2, b.r2], b <- [a.r1, b.r1, a.r3, b.r3]
+__device__ __forceinline__ void swap16(float& a, float& b) {
+  u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r.x); b = __uint_as_float(r.y);
+}
+__device__ __forceinline__ void swap32(double& a, double& b) {
+  u32x2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  u32x2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi.x, (int)lo.x); b = __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ void swap16(double& a, double& b) {
+  u32x2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  u32x2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi.x, (int)lo.x); b = __hiloint2double((int)hi.y, (int)lo.y);
+}
+// two wave sums at once (9 VALU instead of 14).  Inactive lanes must hold 0.
+template <typename T>
+__device__ __forceinline__ void usum2(T a, T b, T& sa, T& sb) {
+  swap32(a, b);
+  T v = a + b;  // lanes 0-31: a_k + a_{k+32}, lanes 32-63: b
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  v += dpp_mov<0x142, 0xA>(v);
+  sa = lane_get(v, 31); sb = lane_get(v, 63);
+}
+// four wave sums at once (14 VALU instead of 28)
+template <typename T>
+__device__ __forceinline__ void usum4(T a, T b, T c, T d, T& sa, T& sb, T& sc, T& sd) {
+  swap16(a, b);
+  T ab = a + b;  // rows: [a0+a1, b0+b1, a2+a3, b2+b3]
+  swap16(c, d);
+  T cd = c + d;
+  swap32(ab, cd);
+  T v = ab + cd;  // rows: [A, B, C, D] partial sums
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  sa = lane_get(v, 0); sb = lane_get(v, 16); sc = lane_get(v, 32); sd = lane_get(v, 48);
+}
+// two wave maxima at once, values >= 0 (identity 0)
+template <typename T>
+__device__ __forceinline__ void umax2(T a, T b, T& ma, T& mb) {
+  swap32(a, b);
+  T v = m_max(a, b);
+  v = m_max(v, dpp_mov<0xB1>(v, v));
+  v = m_max(v, dpp_mov<0x4E>(v, v));
+  v = m_max(v, dpp_mov<0x141>(v, v));
+  v = m_max(v, dpp_mov<0x140>(v, v));
+  v = m_max(v, dpp_mov<0x142, 0xA>(v, v));
+  ma = lane_get(v, 31); mb = lane_get(v, 63);
 }
 
 // rotation by one lane inside the first n lanes: rot_up: lane c <- c-1 (lane 0 <- n-1); rot_dn: lane c <- c+1 (n-1 <- 0)

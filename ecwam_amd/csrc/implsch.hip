@@ -1044,19 +1044,21 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
   const size_t per_wave = (size_t)(ntile * NFRE * NAP + 64) * sizeof(T) + (variant == 2 ? NSC * sizeof(T) : 0);
   // waves (= points) per block: the choice that fits the most waves into the 160 KiB of LDS of a CU; ties go to the larger
   // block, which amortises the lane-per-point scalar stages of variant 2 over more points
-  static const int cands3[] = {4, 2, 1}, cands2[] = {7, 4, 2, 1};
+  static const int cands3[] = {4, 2, 1}, cands2[] = {4, 2, 1};
   const int* cands = (variant == 2) ? cands2 : cands3;
-  const int ncand = (variant == 2) ? 4 : 3;
+  const int ncand = 3;
+  // register-limited residency: variant 2 is compiled for 3 (sp) / 2 (dp) waves per SIMD, variant 1 uses 151 / 256 VGPRs
+  const int capw = 4 * ((sizeof(T) == 4) ? 3 : 2);
   int wpb = 1, best = 0;
   for (int i = 0; i < ncand; i++) {
     const int cand = cands[i];
     int nb = (int)((160 * 1024) / (per_wave * cand));
-    if (nb * cand > 32) nb = 32 / cand;  // 8 waves per SIMD at most
+    if (nb * cand > capw) nb = capw / cand;
     const int waves = nb * cand;
     if (waves > best) { best = waves; wpb = cand; }
   }
   if (best == 0) return 1;
-  { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_WPB"); if (e_ && variant == 2) { const int w = atoi(e_); if (w == 7 || w == 4 || w == 2 || w == 1) wpb = w; } }
+  { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_WPB"); if (e_ && variant == 2) { const int w = atoi(e_); if (w == 4 || w == 2 || w == 1) wpb = w; } }
   const size_t shmem = per_wave * wpb;
   const int blocks = (n + wpb - 1) / wpb;
 #define LAUNCH(K, W)                                                                                                         \
@@ -1066,8 +1068,7 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
                        (const T*)wvprpt, (T*)ff, (T*)intf, mij, (T*)xllws, (T*)dbg);                                         \
   } while (0)
   if (variant == 2) {
-    if (wpb == 7) LAUNCH(k_implsch2, 7);
-    else if (wpb == 4) LAUNCH(k_implsch2, 4);
+    if (wpb == 4) LAUNCH(k_implsch2, 4);
     else if (wpb == 2) LAUNCH(k_implsch2, 2);
     else LAUNCH(k_implsch2, 1);
   } else {

@@ -234,13 +234,15 @@ __device__ void sinput_ard2(const DevTab<T>& tb, const T* sF, T* sFLD, const Lan
       for (int ig = 0; ig < NGST; ig++) {
         const T TAUPX = TAUX[ig] - ABS_TAUWSHELTER * XSTRESS[ig];
         const T TAUPY = TAUY[ig] - ABS_TAUWSHELTER * YSTRESS[ig];
-        const T h = f_sqrt(TAUPX * TAUPX + TAUPY * TAUPY);
-        const bool zero = !(h > T(0));
-        const T rh = f_rcp(h);
+        const T h2 = TAUPX * TAUPX + TAUPY * TAUPY;
+        const bool zero = !(h2 > T(0));
+        T h, rh;
+        if (sizeof(T) == 4) { rh = f_rsq(h2); h = zero ? T(0) : h2 * rh; }  // one v_rsq instead of v_sqrt + v_rcp
+        else { h = f_sqrt(h2); rh = f_rcp(h); }
         COSU[ig] = zero ? T(1) : TAUPY * rh;
         SINU[ig] = zero ? T(0) : TAUPX * rh;
         USTP[ig] = f_sqrt(h);
-        USTPM1[ig] = f_rcp(m_max(USTP[ig], tb.EPSUS));
+        if (LLNORMAGAM) USTPM1[ig] = f_rcp(m_max(USTP[ig], tb.EPSUS));
       }
       CONSTF = ROGOROAIR * cinv_m * lane_get(L.rDFIM, m);
     }
@@ -326,10 +328,83 @@ __device__ void sinput_ard2(const DevTab<T>& tb, const T* sF, T* sFLD, const Lan
   }
 }
 
-// One sweep over the DIA interactions MC = 1..NFRE+4 (snonlin.F90:126-494, ISNONLIN = 0, pull form of snonlin_pull above);
-// after interaction MC row R = MC-4 is final: SDISSIP_ARD (sdissip_ard.F90:117-314), SDIWBK, SBOTTOM, the implicit update
-// with its limiter and the WNFLUXES integrands (implsch.F90:294-395) are applied to it and F(:,R) is overwritten in place.
+// sdissip_ard.F90:117-314 (SSDSC3 = 0) for variant 2: FLD += D, two frequency rows per iteration so that the saturation
+// filter runs on packed-fp32 FMAs (v_pk_fma_f32) and the two directional maxima share one reduction.
 template <typename T, int NTAPC>
+__device__ void sdissip_rows2(const DevTab<T>& tb, const T* sF, T* sFLD, const Lane<T>& L, T rWAVNUM, T rXK2CG, T UFRIC, T coswdif,
+                              T RAORW) {
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  const int NAP = L.NAP, NFRE = L.NFRE, k = L.k;
+  const int ntap = NTAPC > 0 ? NTAPC : tb.NTAP;
+  const T TPIINV = T(1) / tb.ZPI;
+  const T TMP03 = T(1) / (tb.SDSBR * tb.MICHE);
+  const T SSDSC6M1 = T(1) - tb.SSDSC6;
+  T wgt[NTAPC > 0 ? NTAPC : 1];
+  int idx[NTAPC > 0 ? NTAPC : 1];
+  if (NTAPC > 0) {
+#pragma unroll
+    for (int j = 0; j < NTAPC; j++) { wgt[j] = tb.SATWEIGHTS[j][k]; idx[j] = tb.INDICESSAT[j][k]; }
+  }
+  const T rFACSAT = rWAVNUM * TPIINV * rXK2CG;  // lane m
+  T FACTURB = T(0);
+  const bool turb = (tb.SSDSC5 != T(0));
+  if (turb) FACTURB = (T(2) * tb.SSDSC5 / tb.G) * RAORW * UFRIC * UFRIC;
+  const T c2 = tb.SSDSC2 * tb.SSDSC6, c2m1 = tb.SSDSC2 * SSDSC6M1;
+  int m = 0;
+  for (; m + 1 < NFRE; m += 2) {
+    const T* r0 = sF + m * NAP;
+    const T* r1 = r0 + NAP;
+    V2 b = {T(0), T(0)};
+    if (NTAPC > 0) {
+      // neighbours through the LDS crossbar (ds_bpermute, per-tap address registers are row-invariant): no address arithmetic
+      const T f0 = r0[k], f1 = r1[k];
+#pragma unroll
+      for (int j = 0; j < NTAPC; j++) { const V2 v = {lane_pull(f0, idx[j]), lane_pull(f1, idx[j])}; b = b + wgt[j] * v; }
+    } else {
+      for (int j = 0; j < ntap; j++) {
+        const int id = tb.INDICESSAT[j][k];
+        const V2 v = {r0[id], r1[id]};
+        b = b + tb.SATWEIGHTS[j][k] * v;
+      }
+    }
+    const V2 fs = {lane_get(rFACSAT, m), lane_get(rFACSAT, m + 1)};
+    b = b * fs;
+    T bm0, bm1;
+    umax2(L.act ? b.x : T(0), L.act ? b.y : T(0), bm0, bm1);
+    const V2 sig = {lane_get(L.rZPIFR, m), lane_get(L.rZPIFR, m + 1)};
+    const T a00 = m_max(T(0), bm0 * TMP03 - tb.SSDSC4), a01 = m_max(T(0), bm1 * TMP03 - tb.SSDSC4);
+    const V2 t1 = b * TMP03 - tb.SSDSC4;
+    const V2 a0 = {a00, a01};
+    const V2 a1 = {m_max(T(0), t1.x), m_max(T(0), t1.y)};
+    V2 D = (c2 * sig) * (a0 * a0) + (c2m1 * sig) * (a1 * a1);
+    if (turb) {
+      const V2 wn = {lane_get(rWAVNUM, m), lane_get(rWAVNUM, m + 1)};
+      D = D - (sig * wn * FACTURB) * coswdif;
+    }
+    if (L.act) {
+      sFLD[m * NAP + k] += D.x;
+      sFLD[(m + 1) * NAP + k] += D.y;
+    }
+  }
+  for (; m < NFRE; m++) {  // odd NFRE: last row on its own
+    const T* row = sF + m * NAP;
+    T b = T(0);
+    for (int j = 0; j < ntap; j++) b = b + tb.SATWEIGHTS[j][k] * row[tb.INDICESSAT[j][k]];
+    b = b * lane_get(rFACSAT, m);
+    const T bth0 = umax(L.act ? b : T(0));
+    const T SSDSC2_SIG = tb.SSDSC2 * lane_get(L.rZPIFR, m);
+    const T a0 = m_max(T(0), bth0 * TMP03 - tb.SSDSC4);
+    const T a1 = m_max(T(0), b * TMP03 - tb.SSDSC4);
+    T D = (SSDSC2_SIG * tb.SSDSC6) * (a0 * a0) + (SSDSC2_SIG * SSDSC6M1) * (a1 * a1);
+    if (turb) D = D - (tb.ZPIFR[m] * lane_get(rWAVNUM, m) * FACTURB) * coswdif;
+    if (L.act) sFLD[m * NAP + k] += D;
+  }
+}
+
+// One sweep over the DIA interactions MC = 1..NFRE+4 (snonlin.F90:126-494, ISNONLIN = 0, pull form of snonlin_pull above);
+// after interaction MC row R = MC-4 is final: SDIWBK, SBOTTOM, the implicit update
+// with its limiter and the WNFLUXES integrands (implsch.F90:294-395) are applied to it and F(:,R) is overwritten in place.
+template <typename T>
 __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const Lane<T>& L, T rWAVNUM, T rCINV, T rXK2CG, T rRH, T UFRIC,
                              T coswdif, T RAORW, T DEPTH, T AKMEAN, T SDS, bool shallow_brk, T USFM, T FLM, T& a_t, T& a_x) {
   const int SKIP = tb.DBG_SKIP;
@@ -347,21 +422,6 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
     ik1s[kh] = tb.IK1[kh][c1 < 0 ? c1 + NANG : (c1 >= NANG ? c1 - NANG : c1)];
     ik2s[kh] = tb.IK2[kh][c2 < 0 ? c2 + NANG : (c2 >= NANG ? c2 - NANG : c2)];
   }
-  // dissipation constants
-  const T TPIINV = T(1) / tb.ZPI;
-  const T TMP03 = T(1) / (tb.SDSBR * tb.MICHE);
-  const T SSDSC6M1 = T(1) - tb.SSDSC6;
-  const int ntap = NTAPC > 0 ? NTAPC : tb.NTAP;
-  T wgt[NTAPC > 0 ? NTAPC : 1];
-  int idx[NTAPC > 0 ? NTAPC : 1];
-  if (NTAPC > 0) {
-#pragma unroll
-    for (int j = 0; j < NTAPC; j++) { wgt[j] = tb.SATWEIGHTS[j][k]; idx[j] = tb.INDICESSAT[j][k]; }
-  }
-  const T rFACSAT = rWAVNUM * TPIINV * rXK2CG;  // lane m
-  T FACTURB = T(0);
-  const bool turb = (tb.SSDSC5 != T(0));
-  if (turb) FACTURB = (T(2) * tb.SSDSC5 / tb.G) * RAORW * UFRIC * UFRIC;
   // update constants
   const T DELT = T(tb.IDELT);
   const T DELTM = T(1) / DELT;
@@ -431,30 +491,10 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
         const int m = MC - 5;  // 0-based row MC-4: final now
         if (m >= 0 && m < NFRE) {
           T* row = sF + m * NAP;
-          // --- SDISSIP_ARD
-          T D = T(0);
-          if (!(SKIP & 4)) {
-            T b = T(0);
-            if (NTAPC > 0) {
-#pragma unroll
-              for (int jj = 0; jj < NTAPC; jj++) b = b + wgt[jj] * row[idx[jj]];
-            } else {
-              for (int jj = 0; jj < ntap; jj++) b = b + tb.SATWEIGHTS[jj][k] * row[tb.INDICESSAT[jj][k]];
-            }
-            b = b * lane_get(rFACSAT, m);
-            const T bth0 = umax(L.act ? b : T(0));
-            const T SSDSC2_SIG = tb.SSDSC2 * lane_get(L.rZPIFR, m);
-            const T ZCOEF = SSDSC2_SIG * tb.SSDSC6;
-            const T ZCOEFM1 = SSDSC2_SIG * SSDSC6M1;
-            const T a0 = m_max(T(0), bth0 * TMP03 - tb.SSDSC4);
-            const T a1 = m_max(T(0), b * TMP03 - tb.SSDSC4);
-            D = ZCOEF * (a0 * a0) + ZCOEFM1 * (a1 * a1);
-            if (turb) D = D - (tb.ZPIFR[m] * lane_get(rWAVNUM, m) * FACTURB) * coswdif;
-          }
           const T f = row[k];
-          const T fldw = sFLD[m * NAP + k];
-          T sl = (fldw * f + D * f) + aS[cm];
-          T fld = (fldw + D) + aF[cm];
+          const T fldw = sFLD[m * NAP + k];  // wind input + dissipation
+          T sl = fldw * f + aS[cm];
+          T fld = fldw + aF[cm];
           // --- SSOURCE, SDIWBK, SBOTTOM, new spectrum
           T ss = T(0);
           if (flux_snl) ss = f_div(sl, m_max(T(1) - DELT5 * fld, T(1)));
@@ -687,10 +727,12 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   const T USFM = UFRIC * m_max(FMEANWS, FMEAN);
   T a_t, a_x;
   WSYNC();
-  if (tb.NTAP == 17) source_sweep<T, 17>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, rRH, UFRIC, coswdif, RAORW, DEPTH, AKMEAN, SDS, shallow_brk, USFM, FLM, a_t, a_x);
-  else if (tb.NTAP == 11) source_sweep<T, 11>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, rRH, UFRIC, coswdif, RAORW, DEPTH, AKMEAN, SDS, shallow_brk, USFM, FLM, a_t, a_x);
-  else if (tb.NTAP == 7) source_sweep<T, 7>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, rRH, UFRIC, coswdif, RAORW, DEPTH, AKMEAN, SDS, shallow_brk, USFM, FLM, a_t, a_x);
-  else source_sweep<T, 0>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, rRH, UFRIC, coswdif, RAORW, DEPTH, AKMEAN, SDS, shallow_brk, USFM, FLM, a_t, a_x);
+  if (SKIP & 4) {
+  } else if (tb.NTAP == 17) sdissip_rows2<T, 17>(tb, sF, sFLD, L, rWAVNUM, rXK2CG, UFRIC, coswdif, RAORW);
+  else if (tb.NTAP == 11) sdissip_rows2<T, 11>(tb, sF, sFLD, L, rWAVNUM, rXK2CG, UFRIC, coswdif, RAORW);
+  else if (tb.NTAP == 7) sdissip_rows2<T, 7>(tb, sF, sFLD, L, rWAVNUM, rXK2CG, UFRIC, coswdif, RAORW);
+  else sdissip_rows2<T, 0>(tb, sF, sFLD, L, rWAVNUM, rXK2CG, UFRIC, coswdif, RAORW);
+  source_sweep<T>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, rRH, UFRIC, coswdif, RAORW, DEPTH, AKMEAN, SDS, shallow_brk, USFM, FLM, a_t, a_x);
   WSYNC();
   __syncthreads();  // stage 3 results
   const T TAUW = c[C_TAUW], TAUWDIR = c[C_TAUWDIR], PHIWA = c[C_PHIWA];

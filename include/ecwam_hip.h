@@ -103,6 +103,9 @@ typedef struct ecwam_hip_ctx ecwam_hip_ctx;
 
 const char *ecwam_hip_last_error(void);
 int ecwam_hip_abi_version(void);
+/* diagnostics: runs the wavefront reduction / permutation primitives of the kernels on `device` against serial sums;
+   0 = all agree.  No counterpart in the reference (the OpenACC build relies on the compiler's reductions). */
+int ecwam_hip_selftest(int device);
 
 /* Context: one per (device, configuration).  Replaces the device residency of the module globals. */
 int ecwam_hip_create(const ecwam_hip_params *p, const ecwam_hip_tables *t, int real_bytes, int device, ecwam_hip_ctx **out);

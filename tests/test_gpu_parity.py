@@ -35,6 +35,16 @@ def _oracle(cfg, prec):
     return Oracle(cfg, prec)
 
 
+def test_wavefront_primitives(api):
+    """usum/usum2/usum4/umax/umax2 (DPP + v_permlane*_swap), v_readlane, ds_bpermute and the lane rotations against
+    serial sums, in both precisions, on the device itself."""
+    from ecwam_amd import lib as L
+
+    h = L.load()
+    rc = h.ecwam_hip_selftest(0)
+    assert rc == 0, h.ecwam_hip_last_error()
+
+
 @pytest.mark.parametrize("nang,nred", [(36, 36), (24, 29), (12, 25)])
 @pytest.mark.parametrize("prec", ["dp", "sp"])
 @pytest.mark.parametrize("llnormagam", [False, True])

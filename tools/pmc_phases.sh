@@ -1,7 +1,7 @@
 #!/bin/bash
 # diagnostics: VALU/SALU/LDS instruction counts of IMPLSCH with phases ablated (ECWAM_HIP_DEBUG_SKIP)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for mask in 0 1 2 4 8 16 32 127; do
+for mask in ${MASKS:-0 1 2 4 8 16 32 127}; do
   export ECWAM_HIP_DEBUG_SKIP=$mask
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SMEM --kernel-trace --output-format csv -d gpurun_out/ph_$mask -- python3 tools/prof_implsch.py sp 32768 > /dev/null 2>&1
   python3 - <<PY

@@ -1059,7 +1059,8 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
   }
   if (best == 0) return 1;
   { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_WPB"); if (e_ && variant == 2) { const int w = atoi(e_); if (w == 4 || w == 2 || w == 1) wpb = w; } }
-  const size_t shmem = per_wave * wpb;
+  size_t shmem = per_wave * wpb;
+  { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_PADLDS"); if (e_) shmem += (size_t)atoi(e_); }  // diagnostics: lower the residency
   const int blocks = (n + wpb - 1) / wpb;
 #define LAUNCH(K, W)                                                                                                         \
   do {                                                                                                                       \

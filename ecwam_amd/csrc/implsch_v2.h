@@ -217,6 +217,8 @@ __device__ void sinput_ard2(const DevTab<T>& tb, const T* sF, T* sFLD, const Lan
     if (LLSNEG) rCOEF5 = -tb.SWELLF5 * T(2) * m_sqrt(T(2) * NU_AIR * tb.ZPIFR[L.lane]);
   }
   T COSU[2], SINU[2];
+  T spq[4] = {T(0), T(0), T(0), T(0)};
+  bool growq = false;
 
   for (int m = 0; m < L.NFRE; m++) {
     const T SIG = lane_get(L.rZPIFR, m);
@@ -295,40 +297,63 @@ __device__ void sinput_ard2(const DevTab<T>& tb, const T* sF, T* sFLD, const Lan
       g0[ig] = gam0;
       ds[ig] = dstab;
     }
-    T SLP_AVG = T(0), FLP_AVG = T(0), xrow = T(0), yrow = T(0);
+    T SLP_AVG = T(0), FLP_AVG = T(0), sa[2];
 #pragma unroll
     for (int ig = 0; ig < NGST; ig++) {
       T SLP = g0[ig] * GAMNORMA[ig];
       const T FLP = SLP + ds[ig];
       SLP = SLP * f;
-      if (grow[ig]) {
-        const T sa = L.act ? SLP : T(0);
-        const T xs = usum(sa * sinthk), ys = usum(sa * costhk);
-        if (LTAUWSHELTER) {
-          XSTRESS[ig] = XSTRESS[ig] + CONSTF * xs;
-          YSTRESS[ig] = YSTRESS[ig] + CONSTF * ys;
-        }
-        xrow = xrow + xs;
-        yrow = yrow + ys;
-      }
+      sa[ig] = L.act ? SLP : T(0);
       if (ig == 0) { SLP_AVG = SLP; FLP_AVG = FLP; }
       else { SLP_AVG = SLP_AVG + SLP; FLP_AVG = FLP_AVG + FLP; }
     }
     const T spos = AVG_GST * SLP_AVG, fld = AVG_GST * FLP_AVG;
-    if (grow[0] || (NGST > 1 && grow[1])) {
+    const bool anygrow = grow[0] || (NGST > 1 && grow[1]);
+    if (anygrow) {
+      // all directional stress integrals of the row in one folded reduction (a gust state that does not grow adds zeros)
+      T xs[2], ys[2];
+      if (NGST == 1) usum2(sa[0] * sinthk, sa[0] * costhk, xs[0], ys[0]);
+      else usum4(sa[0] * sinthk, sa[0] * costhk, sa[1] * sinthk, sa[1] * costhk, xs[0], ys[0], xs[1], ys[1]);
+      T xrow = T(0), yrow = T(0);
+#pragma unroll
+      for (int ig = 0; ig < NGST; ig++) {
+        if (LTAUWSHELTER) {
+          XSTRESS[ig] = XSTRESS[ig] + CONSTF * xs[ig];
+          YSTRESS[ig] = YSTRESS[ig] + CONSTF * ys[ig];
+        }
+        xrow = xrow + xs[ig];
+        yrow = yrow + ys[ig];
+      }
       lane_put(rX, L.lane, m, AVG_GST * xrow);
       lane_put(rY, L.lane, m, AVG_GST * yrow);
-      if (LLSNEG) lane_put(rS, L.lane, m, usum(L.act ? spos : T(0)));
+    }
+    if (LLSNEG) {
+      // SUM_K SPOS of four rows at a time (not part of the sheltering recurrence)
+      const int q = m & 3;
+      spq[0] = spq[1]; spq[1] = spq[2]; spq[2] = spq[3];
+      spq[3] = (anygrow && L.act) ? spos : T(0);
+      growq = growq || anygrow;
+      if (q == 3 || m == L.NFRE - 1) {
+        if (growq) {
+          T s0, s1, s2, s3;
+          usum4(spq[0], spq[1], spq[2], spq[3], s0, s1, s2, s3);  // rows m-3 .. m (a short last group ignores the stale heads)
+          if (q >= 3) lane_put(rS, L.lane, m - 3, s0);
+          if (q >= 2) lane_put(rS, L.lane, m - 2, s1);
+          if (q >= 1) lane_put(rS, L.lane, m - 1, s2);
+          lane_put(rS, L.lane, m, s3);
+        }
+        growq = false;
+      }
     }
     if (LLSNEG) {
       apl = apl + (fld * f - spos) * tb.RHOWG_DFIM[m];
-      if (L.act) sFLD[m * L.NAP + L.k] = fld;
+      if (L.act) sFLD[m * L.NAP + L.k] += fld;  // on top of the dissipation coefficient already there
     }
     if (xl) xmask |= (1ull << m);
   }
 }
 
-// sdissip_ard.F90:117-314 (SSDSC3 = 0) for variant 2: FLD += D, two frequency rows per iteration so that the saturation
+// sdissip_ard.F90:117-314 (SSDSC3 = 0) for variant 2: FLD = D (SINPUT adds the wind input afterwards), two frequency rows per iteration so that the saturation
 // filter runs on packed-fp32 FMAs (v_pk_fma_f32) and the two directional maxima share one reduction.
 template <typename T, int NTAPC>
 __device__ void sdissip_rows2(const DevTab<T>& tb, const T* sF, T* sFLD, const Lane<T>& L, T rWAVNUM, T rXK2CG, T UFRIC, T coswdif,
@@ -382,8 +407,8 @@ __device__ void sdissip_rows2(const DevTab<T>& tb, const T* sF, T* sFLD, const L
       D = D - (sig * wn * FACTURB) * coswdif;
     }
     if (L.act) {
-      sFLD[m * NAP + k] += D.x;
-      sFLD[(m + 1) * NAP + k] += D.y;
+      sFLD[m * NAP + k] = D.x;
+      sFLD[(m + 1) * NAP + k] = D.y;
     }
   }
   for (; m < NFRE; m++) {  // odd NFRE: last row on its own
@@ -397,7 +422,7 @@ __device__ void sdissip_rows2(const DevTab<T>& tb, const T* sF, T* sFLD, const L
     const T a1 = m_max(T(0), b * TMP03 - tb.SSDSC4);
     T D = (SSDSC2_SIG * tb.SSDSC6) * (a0 * a0) + (SSDSC2_SIG * SSDSC6M1) * (a1 * a1);
     if (turb) D = D - (tb.ZPIFR[m] * lane_get(rWAVNUM, m) * FACTURB) * coswdif;
-    if (L.act) sFLD[m * NAP + k] += D;
+    if (L.act) sFLD[m * NAP + k] = D;
   }
 }
 
@@ -695,9 +720,22 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
     swell_setup_pt(tb, q);
     q[C_SDS] = sdiwbk_pt(tb, q[C_EMAXDPT], q[C_EMEAN], q[C_F1MEAN], q[C_DEPTH]);
   }
+  // SDISSIP needs F only (and the new UFRIC when SSDSC5 /= 0): it runs while the scalar stage is being evaluated
+  auto dissipation = [&](T UF) {
+    if (SKIP & 4) {
+      if (L.act)
+        for (int m = 0; m < NFRE; m++) sFLD[m * NAP + L.k] = T(0);
+    } else if (tb.NTAP == 17) sdissip_rows2<T, 17>(tb, sF, sFLD, L, rWAVNUM, rXK2CG, UF, coswdif, RAORW);
+    else if (tb.NTAP == 11) sdissip_rows2<T, 11>(tb, sF, sFLD, L, rWAVNUM, rXK2CG, UF, coswdif, RAORW);
+    else if (tb.NTAP == 7) sdissip_rows2<T, 7>(tb, sF, sFLD, L, rWAVNUM, rXK2CG, UF, coswdif, RAORW);
+    else sdissip_rows2<T, 0>(tb, sF, sFLD, L, rWAVNUM, rXK2CG, UF, coswdif, RAORW);
+  };
+  const bool diss_early = (tb.SSDSC5 == T(0));
+  if (diss_early) dissipation(UFRIC);
   __syncthreads();
   UFRIC = c[C_UFRIC]; Z0M = c[C_Z0M];
   const T SDS = c[C_SDS];
+  if (!diss_early) dissipation(UFRIC);
 
   // ---- second SINFLX call: FLD, XLLWS, MIJ, wave stress and the PHIWA integrals
   if (!(SKIP & 1))
@@ -705,12 +743,9 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
                             c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], xmask, rX, rY, rS, apl);
   else {
     rX = rY = rS = apl = T(0);
-    if (L.act)
-      for (int m = 0; m < NFRE; m++) sFLD[m * NAP + L.k] = T(0);
   }
   femeanws(tb, sF, L, xmask, FMEANWS, EMW);
   MIJ = frcutindex(FMEANWS, UFRIC, rRH);
-  __syncthreads();  // every wave has consumed the stage 2 results: the scalar slots can be reused
   {
     const T wx = rRH * rCINV;
     const T XS = usum(wx * rX), YS = usum(wx * rY);
@@ -727,11 +762,6 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   const T USFM = UFRIC * m_max(FMEANWS, FMEAN);
   T a_t, a_x;
   WSYNC();
-  if (SKIP & 4) {
-  } else if (tb.NTAP == 17) sdissip_rows2<T, 17>(tb, sF, sFLD, L, rWAVNUM, rXK2CG, UFRIC, coswdif, RAORW);
-  else if (tb.NTAP == 11) sdissip_rows2<T, 11>(tb, sF, sFLD, L, rWAVNUM, rXK2CG, UFRIC, coswdif, RAORW);
-  else if (tb.NTAP == 7) sdissip_rows2<T, 7>(tb, sF, sFLD, L, rWAVNUM, rXK2CG, UFRIC, coswdif, RAORW);
-  else sdissip_rows2<T, 0>(tb, sF, sFLD, L, rWAVNUM, rXK2CG, UFRIC, coswdif, RAORW);
   source_sweep<T>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, rRH, UFRIC, coswdif, RAORW, DEPTH, AKMEAN, SDS, shallow_brk, USFM, FLM, a_t, a_x);
   WSYNC();
   __syncthreads();  // stage 3 results

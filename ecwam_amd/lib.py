@@ -10,7 +10,8 @@ import numpy as np
 from .tables import JTOT_TAUHF, Tables
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIBPATH = os.path.join(HERE, "lib", "libecwam_hip.so")
+# ECWAM_HIP_LIB: A/B timing of two builds of the same extension (tools/); never a fallback: the file must exist
+LIBPATH = os.environ.get("ECWAM_HIP_LIB") or os.path.join(HERE, "lib", "libecwam_hip.so")
 
 _INT_FIELDS_1 = ["nang", "nfre", "nfre_red", "nfre_odd", "idelt"]
 _PARAM_LAYOUT = (

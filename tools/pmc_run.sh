@@ -1,0 +1,15 @@
+#!/bin/bash
+# diagnostics: arbitrary PMC sets on the IMPLSCH profiling driver.  usage: PMC="A B C" [N=32768] [PREC=sp] bash tools/pmc_run.sh
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+N=${N:-32768}; PREC=${PREC:-sp}; TAG=${TAG:-x}
+rm -rf gpurun_out/pmc_$TAG
+rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d gpurun_out/pmc_$TAG -- python3 tools/prof_implsch.py $PREC $N > /dev/null 2>&1
+python3 - <<PY
+import csv,glob,collections
+f=glob.glob('gpurun_out/pmc_$TAG/*/*counter_collection.csv')[0]
+agg=collections.defaultdict(float)
+for r in csv.DictReader(open(f)):
+    if 'implsch' in r['Kernel_Name']:
+        agg[r['Counter_Name']]+=float(r['Counter_Value'])
+print({k:round(v/3/$N,1) for k,v in agg.items()})
+PY

@@ -1048,7 +1048,7 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
   const int* cands = (variant == 2) ? cands2 : cands3;
   const int ncand = 3;
   // register-limited residency: variant 2 is compiled for 3 (sp) / 2 (dp) waves per SIMD, variant 1 uses 151 / 256 VGPRs
-  const int capw = 4 * ((sizeof(T) == 4) ? 3 : 2);
+  const int capw = 4 * ((sizeof(T) == 4) ? (variant == 2 ? 4 : 3) : 2);
   int wpb = 1, best = 0;
   for (int i = 0; i < ncand; i++) {
     const int cand = cands[i];

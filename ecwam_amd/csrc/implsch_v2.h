@@ -547,7 +547,7 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
 }
 
 template <typename T, int WPB>
-__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 3 : 2))) k_implsch2(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__ fl1,
+__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 4 : 2))) k_implsch2(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__ fl1,
                                                        const T* __restrict__ wvprpt, T* __restrict__ ffa, T* __restrict__ intfa,
                                                        int* __restrict__ mij_out, T* __restrict__ xllws, T* __restrict__ dbg) {
   extern __shared__ __align__(16) unsigned char smem_raw[];

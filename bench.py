@@ -80,6 +80,9 @@ def main() -> None:
     ap.add_argument("--nang", type=int, default=36)
     ap.add_argument("--nfre", type=int, default=36)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--weights", default="otf", choices=["otf", "stored"],
+                    help="CTU weights rebuilt inside PROPAGS2 (default) or streamed from the stored W array")
+    ap.add_argument("--strip", type=int, default=0, help="longitude-strip width of the advection work order (0: natural order)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,7 +103,7 @@ def main() -> None:
     dt = 450 if ng <= 320 else max(15, int(450 * 320 / ng) // 15 * 15)
     cfg = Config(nang=a.nang, nfre=a.nfre, nfre_red=a.nfre, idelt=dt, idelpro=dt)
     grid = G.build_grid(ng)
-    m = Wamintgr(cfg, grid, a.prec, device=local_rank, rank=rank, nranks=world)
+    m = Wamintgr(cfg, grid, a.prec, device=local_rank, rank=rank, nranks=world, weights=a.weights, strip_width=a.strip)
     m.init_synthetic()
     nfail = m.build_weights()
     if nfail:
@@ -119,12 +122,9 @@ def main() -> None:
     t0 = time.perf_counter()
     for s in range(a.steps):
         e = ev[s]
-        m.halo(m.fl1) if world > 1 else None
         e[0].record()
-        g = m.gd
-        m.ctx.propags2(m.fl1, m.fl3, g["klon"], g["klat"], g["kcor"], m.w, 0, m.n, 1, cfg.nfre_red, copy_rest=True)
+        m.propag()            # halo exchange (N > 1) + PROPAGS2
         e[1].record()
-        m.fl1, m.fl3 = m.fl3, m.fl1
         m.newwind()
         e[2].record()
         m.implsch()
@@ -144,7 +144,10 @@ def main() -> None:
         w = 4 if a.prec == "sp" else 8
         N, NR = a.nang * a.nfre, a.nang * cfg.nfre_red
         b_impl = w * (3 * N + 5 * a.nfre + 55)          # F r+w, XLLWS w, 5 per-frequency props, ~55 scalars
-        b_prop = w * 10 * NR + 56                        # 8 weights + F1 + F3, 14 int32 neighbour ids
+        if a.weights == "stored":
+            b_prop = w * 10 * NR + 56                    # 8 weights + F1 + F3, 14 int32 neighbour ids
+        else:
+            b_prop = w * (2 * NR + a.nfre + 13) + 60     # F1 + F3 + own CGROUP row + point geometry, 15 int32 ids
         kern = {
             "propags2": {"ms": t_prop, "alg_bytes": b_prop * m.n, "gbs": b_prop * m.n / t_prop / 1e6},
             "implsch": {"ms": t_impl, "alg_bytes": b_impl * m.n, "gbs": b_impl * m.n / t_impl / 1e6},

@@ -101,8 +101,28 @@ class HipContext:
                 self._int(g["klon"], (n, 2), "KLON"), self._int(g["klat"], (n, 2, 2), "KLAT"), self._int(g["kcor"], (n, 4, 2), "KCOR"),
                 self._real(g["wlat"], (n, 2), "WLAT"), self._real(g["wcor"], (n, 4), "WCOR"),
                 self._real(cgroup_ext, (nrow, self.NFRE), "CGROUP_EXT"), self._real(g["cosphm1_ext"], (nrow,), "COSPHM1_EXT"),
-                self._real(w, (n, 8, self.NANG * self.NR), "W"), self._int(cflfail, (n,), "CFLFAIL")]
+                None if w is None else self._real(w, (n, 8, self.NANG * self.NR), "W"), self._int(cflfail, (n,), "CFLFAIL")]
         self._chk(self.lib.ecwam_hip_ctuw(self._h, n, nland, ngy, float(delpro), mstart, mend, *args, _stream_ptr()))
+
+    # -- PROPAGS2 with on-the-fly CTU weights (no W array): same result as ctuw() + propags2()
+    def propags2_otf(self, f1, f3, grid_dev: dict, cgroup_ext, delpro: float, kijs, kijl, nd3s=1, nd3e=None, copy_rest=True,
+                     order=None):
+        nd3e = self.NR if nd3e is None else nd3e
+        g = grid_dev
+        n, nland, ngy = g["n"], g["nland"], g["ngy"]
+        nrow = f1.shape[0]
+        if not (0 <= kijs <= kijl <= n) or nland >= nrow or cgroup_ext.shape[0] != nrow:
+            raise ValueError("PROPAGS2: KIJS/KIJL outside the neighbour tables, or F1 / CGROUP_EXT without the land row")
+        po = None if order is None else self._int(order, (order.shape[0],), "ORDER")
+        if order is not None and order.shape[0] < kijl:
+            raise ValueError("PROPAGS2: ORDER shorter than KIJL")
+        args = [self._real(f1, (nrow, self.NANG, self.NFRE), "F1"), self._real(f3, (nrow, self.NANG, self.NFRE), "F3"), n, ngy,
+                float(delpro), self._int(g["kxlt"], (n,), "KXLT"), self._real(g["zdello"], (ngy,), "ZDELLO"), float(g["xdella"]),
+                self._real(g["cosph"], (ngy,), "COSPH"), self._real(g["sinph"], (ngy,), "SINPH"),
+                self._int(g["klon"], (n, 2), "KLON"), self._int(g["klat"], (n, 2, 2), "KLAT"), self._int(g["kcor"], (n, 4, 2), "KCOR"),
+                self._real(g["wlat"], (n, 2), "WLAT"), self._real(g["wcor"], (n, 4), "WCOR"),
+                self._real(cgroup_ext, (nrow, self.NFRE), "CGROUP_EXT"), self._real(g["cosphm1_ext"], (nrow,), "COSPHM1_EXT"), po]
+        self._chk(self.lib.ecwam_hip_propags2_otf(self._h, *args, kijs, kijl, nd3s, nd3e, int(copy_rest), _stream_ptr()))
 
     # -- IMPLSCH (implsch.F90:10-23)
     def implsch(self, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, dbg=None):

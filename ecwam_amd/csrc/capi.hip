@@ -30,6 +30,7 @@ struct ecwam_hip_ctx {
 // launchers implemented in propag.hip / implsch.hip
 template <typename T> void launch_propags2(const void*, const void*, void*, const int*, const int*, const int*, const void*, int, int, int, int, int, int, hipStream_t);
 template <typename T> void launch_ctuw(const void*, int, int, int, double, int, int, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, void*, void*, const void*, const void*, void*, int*, int, hipStream_t);
+template <typename T> void launch_propags2_otf(const void*, const void*, void*, int, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const int*, int, int, int, int, int, int, hipStream_t);
 template <typename T> void launch_newwind(const void*, int, void*, const void*, hipStream_t);
 template <typename T> void launch_c2p(const void*, void*, int, int, int, int, int, hipStream_t);
 template <typename T> void launch_p2c(const void*, void*, int, int, int, int, int, hipStream_t);
@@ -242,11 +243,29 @@ int ecwam_hip_ctuw(ecwam_hip_ctx* c, int n, int nland, int ngy, double delpro, i
                    void* wcor, const void* cgroup_ext, const void* cosphm1_ext, void* w, int* cflfail, void* stream) {
   if (!c) return fail("null context");
   if (n < 0 || mstart < 1 || mend > c->NFRE_RED || mend < mstart) return fail("ecwam_hip_ctuw: bad range");
-  if (n > 0 && (!kxlt || !zdello || !cosph || !sinph || !klon || !klat || !kcor || !wlat || !wcor || !cgroup_ext || !cosphm1_ext || !w || !cflfail))
+  if (n > 0 && (!kxlt || !zdello || !cosph || !sinph || !klon || !klat || !kcor || !wlat || !wcor || !cgroup_ext || !cosphm1_ext || !cflfail))
     return fail("ecwam_hip_ctuw: null pointer");
   hipStream_t s = (hipStream_t)stream;
   DISPATCH(launch_ctuw<float>(c->dtab, n, nland, ngy, delpro, mstart - 1, mend, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, w, cflfail, c->NANG, s),
            launch_ctuw<double>(c->dtab, n, nland, ngy, delpro, mstart - 1, mend, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, w, cflfail, c->NANG, s));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ecwam_hip_propags2_otf(ecwam_hip_ctx* c, const void* f1, void* f3, int n, int ngy, double delpro, const int* kxlt, const void* zdello,
+                           double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat, const int* kcor,
+                           const void* wlat, const void* wcor, const void* cgroup_ext, const void* cosphm1_ext, const int* order,
+                           int kijs, int kijl, int nd3s, int nd3e, int copy_rest, void* stream) {
+  if (!c) return fail("null context");
+  if (kijl < kijs || kijs < 0 || kijl > n || nd3s < 1 || nd3e > c->NFRE_RED || nd3e < nd3s - 1)
+    return fail("ecwam_hip_propags2_otf: bad range");
+  if (kijl > kijs && (!f1 || !f3 || !kxlt || !zdello || !cosph || !sinph || !klon || !klat || !kcor || !wlat || !wcor || !cgroup_ext || !cosphm1_ext))
+    return fail("ecwam_hip_propags2_otf: null pointer");
+  if (f1 == f3) return fail("ecwam_hip_propags2_otf: F1 and F3 must not alias");
+  hipStream_t s = (hipStream_t)stream;
+  const int N = (c->NANG << 16) | (c->NFRE << 8) | c->NFRE_RED;
+  DISPATCH(launch_propags2_otf<float>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, s),
+           launch_propags2_otf<double>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, s));
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -8,6 +8,23 @@
 // is re-used by its ~8 neighbours within one or two latitude rows).
 #include "dev.h"
 
+// propags2.F90:107-116 for one element, in the reference's association order; contraction off so that every kernel that
+// applies the stencil (stored weights, vectorised, on-the-fly weights) rounds identically
+template <typename T>
+__device__ __forceinline__ T ctu_stencil(T w0, T w1, T w2, T w3, T w4, T w5, T w6, T w7, T f0, T f1, T f2, T f3, T f4, T f5, T f6,
+                                         T f7) {
+#pragma clang fp contract(off)
+  T r = (T(1) - w0) * f0;
+  r = r + w1 * f1;
+  r = r + w2 * f2;
+  r = r + w3 * f3;
+  r = r + w4 * f4;
+  r = r + w5 * f5;
+  r = r + w6 * f6;
+  r = r + w7 * f7;
+  return r;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_propags2(const DevTab<T>* __restrict__ tab, const T* __restrict__ f1, T* __restrict__ f3,
                                                   const int* __restrict__ klon, const int* __restrict__ klat,
@@ -33,15 +50,10 @@ __global__ void __launch_bounds__(256) k_propags2(const DevTab<T>* __restrict__ 
     const size_t wb = (size_t)ij * 8 * NANG * NR + (size_t)k * NR + m;
     const size_t ws = (size_t)NANG * NR;
     const int km_e = k * NFRE + m;
-    // same association order as propags2.F90:107-116
-    T r = (T(1) - w[wb]) * f1[own + km_e];
-    r = r + w[wb + ws] * f1[(size_t)ilon * N + km_e];
-    r = r + w[wb + 2 * ws] * f1[(size_t)ilat1 * N + km_e];
-    r = r + w[wb + 3 * ws] * f1[(size_t)ilat2 * N + km_e];
-    r = r + w[wb + 4 * ws] * f1[(size_t)icor1 * N + km_e];
-    r = r + w[wb + 5 * ws] * f1[(size_t)icor2 * N + km_e];
-    r = r + w[wb + 6 * ws] * f1[own + km * NFRE + m];
-    r = r + w[wb + 7 * ws] * f1[own + kp * NFRE + m];
+    const T r = ctu_stencil(w[wb], w[wb + ws], w[wb + 2 * ws], w[wb + 3 * ws], w[wb + 4 * ws], w[wb + 5 * ws], w[wb + 6 * ws],
+                            w[wb + 7 * ws], f1[own + km_e], f1[(size_t)ilon * N + km_e], f1[(size_t)ilat1 * N + km_e],
+                            f1[(size_t)ilat2 * N + km_e], f1[(size_t)icor1 * N + km_e], f1[(size_t)icor2 * N + km_e],
+                            f1[own + km * NFRE + m], f1[own + kp * NFRE + m]);
     f3[own + e] = r;
   }
 }
@@ -90,14 +102,18 @@ __global__ void __launch_bounds__(256) k_propags2_vec(const DevTab<T>* __restric
     const size_t ws = (size_t)NANG * NR;
     const T* wp = w + (size_t)ij * 8 * ws + (size_t)k * NR + m;
 #define LDV(p) (*reinterpret_cast<const V*>(p))
-    V r = vfirst(LDV(wp), LDV(f1 + own + e));
-    r = vmul_add(r, LDV(wp + ws), LDV(f1 + (size_t)ilon * N + e));
-    r = vmul_add(r, LDV(wp + 2 * ws), LDV(f1 + (size_t)ilat1 * N + e));
-    r = vmul_add(r, LDV(wp + 3 * ws), LDV(f1 + (size_t)ilat2 * N + e));
-    r = vmul_add(r, LDV(wp + 4 * ws), LDV(f1 + (size_t)icor1 * N + e));
-    r = vmul_add(r, LDV(wp + 5 * ws), LDV(f1 + (size_t)icor2 * N + e));
-    r = vmul_add(r, LDV(wp + 6 * ws), LDV(f1 + own + km * NFRE + m));
-    r = vmul_add(r, LDV(wp + 7 * ws), LDV(f1 + own + kp * NFRE + m));
+    const V w0 = LDV(wp), w1 = LDV(wp + ws), w2 = LDV(wp + 2 * ws), w3 = LDV(wp + 3 * ws), w4 = LDV(wp + 4 * ws),
+            w5 = LDV(wp + 5 * ws), w6 = LDV(wp + 6 * ws), w7 = LDV(wp + 7 * ws);
+    const V g0 = LDV(f1 + own + e), g1 = LDV(f1 + (size_t)ilon * N + e), g2 = LDV(f1 + (size_t)ilat1 * N + e),
+            g3 = LDV(f1 + (size_t)ilat2 * N + e), g4 = LDV(f1 + (size_t)icor1 * N + e), g5 = LDV(f1 + (size_t)icor2 * N + e),
+            g6 = LDV(f1 + own + km * NFRE + m), g7 = LDV(f1 + own + kp * NFRE + m);
+    V r;
+    const T* pw[8] = {(const T*)&w0, (const T*)&w1, (const T*)&w2, (const T*)&w3, (const T*)&w4, (const T*)&w5, (const T*)&w6, (const T*)&w7};
+    const T* pf[8] = {(const T*)&g0, (const T*)&g1, (const T*)&g2, (const T*)&g3, (const T*)&g4, (const T*)&g5, (const T*)&g6, (const T*)&g7};
+#pragma unroll
+    for (int c = 0; c < W; c++)
+      ((T*)&r)[c] = ctu_stencil(pw[0][c], pw[1][c], pw[2][c], pw[3][c], pw[4][c], pw[5][c], pw[6][c], pw[7][c], pf[0][c], pf[1][c],
+                                pf[2][c], pf[3][c], pf[4][c], pf[5][c], pf[6][c], pf[7][c]);
 #undef LDV
     *reinterpret_cast<V*>(f3 + own + e) = r;
   }
@@ -134,7 +150,104 @@ __global__ void k_ctuwini(int n, int nland, const int* __restrict__ klat, const 
 }
 
 // ctuw.F90:146-275 (space weights), :407-484 (great-circle refraction WKPMN), :536-608 (range checks, SUMWN)
-// restricted to what PROPAGS2 reads for IREFRA=0 (ISSU=ISSV=1 => DXDW=DYDW=0).  One thread per (ij,K,M).
+// restricted to what PROPAGS2 reads for IREFRA=0 (ISSU=ISSV=1 => DXDW=DYDW=0).
+//
+// The arithmetic lives in two helpers shared by k_ctuw (weights stored once, the reference's scheme) and k_propags2_otf
+// (weights rebuilt inside the stencil): floating-point contraction is switched off in them so that both kernels produce
+// the same bits whatever the surrounding code looks like.
+template <typename T>
+struct CtuBase {  // direction-independent part for one (point, frequency)
+  T h[2];   // 0.5*(CG(IJ)+CG(KLON(IC)))
+  T hy[2];  // 0.5*(CG(IJ)+DP(IC)*CGYP(IC))
+  T cg0;
+};
+template <typename T>
+__device__ __forceinline__ CtuBase<T> ctu_base(T cg0, const T cgl[2], const T cgy0[2], const T cgy1[2], const T wl[2], const T dp[2]) {
+#pragma clang fp contract(off)
+  CtuBase<T> b;
+  b.cg0 = cg0;
+  for (int ic = 0; ic < 2; ic++) {
+    b.h[ic] = T(0.5) * (cg0 + cgl[ic]);
+    const T cgyp = wl[ic] * cgy0[ic] + (T(1) - wl[ic]) * cgy1[ic];
+    b.hy[ic] = T(0.5) * (cg0 + dp[ic] * cgyp);
+  }
+  return b;
+}
+// w8 = SUMWN, WLONN(JXO(K,1)), WLATN(JYO(K,1),1:2), WCORN(1,1:2), WKPMN(-1), WKPMN(+1); returns the CFL / range failure flag
+template <typename T>
+__device__ __forceinline__ bool ctu_w8(const CtuBase<T>& b, T sink, T cosk, T cpm1, T zd, T xdella, T ga, T delpro, T cmtodeg,
+                                       int jx0, int jx1, int jy0, int jy1, T wl_jy0, T wc_kc, T tsp, T tsm, T* w8) {
+#pragma clang fp contract(off)
+  T adxp[2], adyp[2];
+  bool fail = false;
+  for (int ic = 0; ic < 2; ic++) {
+    const T cgx = b.h[ic] * sink * cpm1;
+    const T cgy = b.hy[ic] * cosk;
+    adxp[ic] = m_abs(-delpro * cgx * cmtodeg);
+    adyp[ic] = m_abs(-delpro * cgy * cmtodeg);
+    if (adxp[ic] > zd || adyp[ic] > xdella) fail = true;
+  }
+  const T dxx = zd - adxp[jx1];
+  const T dyy = xdella - adyp[jy1];
+  const T wgt_lat = dxx * adyp[jy0] * ga;  // WEIGHT(JYO(K,1))
+  const T wlatn1 = wl_jy0 * wgt_lat;
+  const T wlatn2 = (T(1) - wl_jy0) * wgt_lat;
+  const T wlonn = dyy * adxp[jx0] * ga;
+  const T wgt_cor = adxp[jx0] * adyp[jy0] * ga;  // WEIGHT(1)
+  const T wcorn1 = wc_kc * wgt_cor;
+  const T wcorn2 = (T(1) - wc_kc) * wgt_cor;
+  T sumwn = (zd * adyp[jy1] + xdella * adxp[jx1] - adxp[jx1] * adyp[jy1]) * ga;
+  const T dthp = tsp * b.cg0;  // TANPH*SP*CG
+  const T dthm = tsm * b.cg0;
+  const T wk0 = (dthp + m_abs(dthp)) + (m_abs(dthm) - dthm);
+  const T wkp = -dthp + m_abs(dthp);
+  const T wkm = dthm + m_abs(dthm);
+  sumwn = sumwn + wk0;
+  const T one = T(1), zero = T(0);
+  if (wlatn1 > one || wlatn1 < zero || wlatn2 > one || wlatn2 < zero || wlonn > one || wlonn < zero || wcorn1 > one ||
+      wcorn1 < zero || wcorn2 > one || wcorn2 < zero || wk0 > one || wk0 < zero || wkp > one || wkp < zero || wkm > one ||
+      wkm < zero || sumwn > one || sumwn < zero)
+    fail = true;
+  w8[0] = sumwn; w8[1] = wlonn; w8[2] = wlatn1; w8[3] = wlatn2; w8[4] = wcorn1; w8[5] = wcorn2; w8[6] = wkm; w8[7] = wkp;
+  return fail;
+}
+// per-point scalars of the weights (ctuw.F90:146-170, 407-420)
+template <typename T>
+struct CtuPoint {
+  T zd, cpm1, ga, tanph, dp[2], wl[2], wc[4];
+};
+template <typename T>
+__device__ __forceinline__ CtuPoint<T> ctu_point(int ij, int ngy, const int* __restrict__ kxlt, const T* __restrict__ zdello, T xdella,
+                                                 const T* __restrict__ cosph, const T* __restrict__ sinph, const T* __restrict__ wlat,
+                                                 const T* __restrict__ wcor, const T* __restrict__ cosphm1) {
+#pragma clang fp contract(off)
+  CtuPoint<T> p;
+  const int ky = kxlt[ij];
+  p.zd = zdello[ky];
+  p.cpm1 = cosphm1[ij];
+  p.ga = T(1) / (p.zd * xdella);
+  p.tanph = sinph[ky] / cosph[ky];
+  for (int ic = 0; ic < 2; ic++) {
+    int kk = ky + 1 + 2 * (ic + 1) - 3;  // 1-based row of the neighbour latitude, ctuwini.F90:159-162
+    kk = kk < 1 ? 1 : (kk > ngy ? ngy : kk);
+    p.dp[ic] = cosph[kk - 1] * p.cpm1;
+    p.wl[ic] = wlat[ij * 2 + ic];
+  }
+  for (int ic = 0; ic < 4; ic++) p.wc[ic] = wcor[ij * 4 + ic];
+  return p;
+}
+// TANPH*SP and TANPH*SM factors of direction k (ctuw.F90:407-420): DELTH0*(SINTH(K)+SINTH(K+-1))/R
+template <typename T>
+__device__ __forceinline__ void ctu_dirfac(const DevTab<T>* tab, int k, T delth0, T tanph, T& tsp, T& tsm) {
+#pragma clang fp contract(off)
+  const int kp1 = tab->KPM[k][2], km1 = tab->KPM[k][0];
+  const T sp = delth0 * (tab->SINTH[k] + tab->SINTH[kp1]) / tab->R;
+  const T sm = delth0 * (tab->SINTH[k] + tab->SINTH[km1]) / tab->R;
+  tsp = tanph * sp;
+  tsm = tanph * sm;
+}
+
+// One thread per (ij,K,M): stores the eight weights (w != nullptr) and raises the CFL flag of the point.
 template <typename T>
 __global__ void __launch_bounds__(256) k_ctuw(const DevTab<T>* __restrict__ tab, int n, int ngy, T delpro, int m0, int m1,
                                               const int* __restrict__ kxlt, const T* __restrict__ zdello, T xdella,
@@ -152,66 +265,159 @@ __global__ void __launch_bounds__(256) k_ctuw(const DevTab<T>* __restrict__ tab,
     const int ij = (int)(g / (NANG * nm));
     const int r = (int)(g - (long long)ij * NANG * nm);
     const int k = r / nm, m = m0 + (r - k * nm);
-    const int ky = kxlt[ij];
-    const T zd = zdello[ky];
-    const T cg0 = cg[(size_t)ij * NFRE + m];
-    const T cpm1 = cosphm1[ij];
-    T adxp[2], adyp[2];
-    bool fail = false;
+    const CtuPoint<T> p = ctu_point(ij, ngy, kxlt, zdello, xdella, cosph, sinph, wlat, wcor, cosphm1);
+    T cgl[2], cgy0[2], cgy1[2];
     for (int ic = 0; ic < 2; ic++) {
-      const T cgl = cg[(size_t)klon[ij * 2 + ic] * NFRE + m];
-      const T cgx = T(0.5) * (cg0 + cgl) * tab->SINTH[k] * cpm1;
-      const T wl = wlat[ij * 2 + ic];
-      const T cgyp = wl * cg[(size_t)klat[(ij * 2 + ic) * 2 + 0] * NFRE + m] +
-                     (T(1) - wl) * cg[(size_t)klat[(ij * 2 + ic) * 2 + 1] * NFRE + m];
-      int kk = ky + 1 + 2 * (ic + 1) - 3;  // 1-based row of the neighbour latitude, ctuwini.F90:159-162
-      kk = kk < 1 ? 1 : (kk > ngy ? ngy : kk);
-      const T dp = cosph[kk - 1] * cpm1;
-      const T cgy = T(0.5) * (cg0 + dp * cgyp) * tab->COSTH[k];
-      adxp[ic] = m_abs(-delpro * cgx * CMTODEG);
-      adyp[ic] = m_abs(-delpro * cgy * CMTODEG);
-      if (adxp[ic] > zd || adyp[ic] > xdella) fail = true;
+      cgl[ic] = cg[(size_t)klon[ij * 2 + ic] * NFRE + m];
+      cgy0[ic] = cg[(size_t)klat[(ij * 2 + ic) * 2 + 0] * NFRE + m];
+      cgy1[ic] = cg[(size_t)klat[(ij * 2 + ic) * 2 + 1] * NFRE + m];
     }
-    const int jx0 = tab->JXO[k][0], jx1 = tab->JXO[k][1], jy0 = tab->JYO[k][0], jy1 = tab->JYO[k][1];
-    const T dxx = zd - adxp[jx1] - T(0);
-    const T dyy = xdella - adyp[jy1] - T(0);
-    const T ga = T(1) / (zd * xdella);
-    const T wgt_lat = dxx * adyp[jy0] * ga;   // WEIGHT(JYO(K,1))
-    const T wlatn1 = wlat[ij * 2 + jy0] * wgt_lat;
-    const T wlatn2 = (T(1) - wlat[ij * 2 + jy0]) * wgt_lat;
-    const T wlonn = dyy * adxp[jx0] * ga;
-    const T wgt_cor = adxp[jx0] * adyp[jy0] * ga;  // WEIGHT(1)
-    const int kc = tab->KCR[k][0];
-    const T wcorn1 = wcor[ij * 4 + kc] * wgt_cor;
-    const T wcorn2 = (T(1) - wcor[ij * 4 + kc]) * wgt_cor;
-    T sumwn = (zd * (T(0) + adyp[jy1]) + xdella * (adxp[jx1] + T(0)) - (T(0) + adxp[jx1]) * (T(0) + adyp[jy1])) * ga;
-    // direction weights
-    const int kp1 = tab->KPM[k][2], km1 = tab->KPM[k][0];
-    const T sp = DELTH0 * (tab->SINTH[k] + tab->SINTH[kp1]) / tab->R;
-    const T sm = DELTH0 * (tab->SINTH[k] + tab->SINTH[km1]) / tab->R;
-    const T tanph = sinph[ky] / cosph[ky];
-    const T dthp = tanph * sp * cg0 + T(0);
-    const T dthm = tanph * sm * cg0 + T(0);
-    const T wk0 = (dthp + m_abs(dthp)) + (m_abs(dthm) - dthm);
-    const T wkp = -dthp + m_abs(dthp);
-    const T wkm = dthm + m_abs(dthm);
-    sumwn = sumwn + wk0;
-    const T one = T(1), zero = T(0);
-    if (wlatn1 > one || wlatn1 < zero || wlatn2 > one || wlatn2 < zero || wlonn > one || wlonn < zero || wcorn1 > one ||
-        wcorn1 < zero || wcorn2 > one || wcorn2 < zero || wk0 > one || wk0 < zero || wkp > one || wkp < zero || wkm > one ||
-        wkm < zero || sumwn > one || sumwn < zero)
-      fail = true;
+    const CtuBase<T> b = ctu_base(cg[(size_t)ij * NFRE + m], cgl, cgy0, cgy1, p.wl, p.dp);
+    T tsp, tsm, w8[8];
+    ctu_dirfac(tab, k, DELTH0, p.tanph, tsp, tsm);
+    const int jx0 = tab->JXO[k][0], jx1 = tab->JXO[k][1], jy0 = tab->JYO[k][0], jy1 = tab->JYO[k][1], kc = tab->KCR[k][0];
+    const bool fail = ctu_w8(b, tab->SINTH[k], tab->COSTH[k], p.cpm1, p.zd, xdella, p.ga, delpro, CMTODEG, jx0, jx1, jy0, jy1,
+                             p.wl[jy0], p.wc[kc], tsp, tsm, w8);
     if (fail) cflfail[ij] = 1;
-    const size_t ws = (size_t)NANG * NR;
-    const size_t wb = (size_t)ij * 8 * ws + (size_t)k * NR + m;
-    w[wb] = sumwn;
-    w[wb + ws] = wlonn;
-    w[wb + 2 * ws] = wlatn1;
-    w[wb + 3 * ws] = wlatn2;
-    w[wb + 4 * ws] = wcorn1;
-    w[wb + 5 * ws] = wcorn2;
-    w[wb + 6 * ws] = wkm;
-    w[wb + 7 * ws] = wkp;
+    if (w) {
+      const size_t ws = (size_t)NANG * NR;
+      const size_t wb = (size_t)ij * 8 * ws + (size_t)k * NR + m;
+      for (int i = 0; i < 8; i++) w[wb + i * ws] = w8[i];
+    }
+  }
+}
+
+// PROPAGS2 with the weights rebuilt on the fly: the eight weight streams (8/10 of the HBM traffic of k_propags2*) are
+// replaced by ~45 flops per element on data that is already on chip.  A block walks tiles of OTF_TP points: (1) the
+// point scalars, (2) the direction-independent halves of the weights per (point, frequency) -- seven CGROUP runs per
+// point, shared by all NANG directions -- go to LDS, (3) every thread combines them with its direction's factors and
+// applies the stencil to VW consecutive frequencies (16-byte loads/stores along M).
+#define OTF_TP 16
+template <typename T, int VW> struct VecIO {  // VW consecutive elements as one 16-byte access (VW == 1: scalar)
+  static __device__ __forceinline__ void ld(const T* p, T* o) {
+    typedef T V __attribute__((ext_vector_type(VW)));
+    const V v = *reinterpret_cast<const V*>(p);
+#pragma unroll
+    for (int c = 0; c < VW; c++) o[c] = v[c];
+  }
+  static __device__ __forceinline__ void st(T* p, const T* o) {
+    typedef T V __attribute__((ext_vector_type(VW)));
+    V v;
+#pragma unroll
+    for (int c = 0; c < VW; c++) v[c] = o[c];
+    *reinterpret_cast<V*>(p) = v;
+  }
+};
+template <typename T> struct VecIO<T, 1> {
+  static __device__ __forceinline__ void ld(const T* p, T* o) { o[0] = p[0]; }
+  static __device__ __forceinline__ void st(T* p, const T* o) { p[0] = o[0]; }
+};
+template <typename T, int VW>
+__global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restrict__ tab, const T* __restrict__ f1, T* __restrict__ f3,
+                                                      int n_geom, int ngy, T delpro, const int* __restrict__ kxlt,
+                                                      const T* __restrict__ zdello, T xdella, const T* __restrict__ cosph,
+                                                      const T* __restrict__ sinph, const int* __restrict__ klon,
+                                                      const int* __restrict__ klat, const int* __restrict__ kcor,
+                                                      const T* __restrict__ wlat, const T* __restrict__ wcor,
+                                                      const T* __restrict__ cg, const T* __restrict__ cosphm1,
+                                                      const int* __restrict__ order, int kijs, int kijl, int m0, int m1,
+                                                      int copy_rest, int ntiles) {
+  extern __shared__ __align__(16) unsigned char otf_smem[];
+  const int NANG = tab->NANG, NFRE = tab->NFRE;
+  const int N = NANG * NFRE, NV = N / VW, FV = NFRE / VW;
+  const T CMTODEG = T(360.0) / tab->CIRC;
+  const T DELTH0 = T(0.25) * delpro / tab->DELTH;
+  // LDS: point scalars, neighbour indices, CtuBase per (point, frequency) as 5 planes, direction factors
+  CtuPoint<T>* sP = reinterpret_cast<CtuPoint<T>*>(otf_smem);
+  int* sI = reinterpret_cast<int*>(sP + OTF_TP);                    // [TP][16]: ij, ilon[2], ilat[2][2], icor[4][2]
+  T* sB = reinterpret_cast<T*>(sI + OTF_TP * 16);                   // [TP][5][NFRE]
+  T* sK = sB + (size_t)OTF_TP * 5 * NFRE;                           // [NANG][2]: (SINTH+SINTH(K+1))*DELTH0/R, same for K-1
+  for (int k = threadIdx.x; k < NANG; k += blockDim.x) {
+    T a, b;
+    ctu_dirfac(tab, k, DELTH0, T(1), a, b);  // TANPH applied per point below: TANPH*SP is formed as in k_ctuw
+    sK[2 * k] = a; sK[2 * k + 1] = b;
+  }
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int p0 = kijs + tile * OTF_TP;
+    const int np = min(OTF_TP, kijl - p0);
+    __syncthreads();  // previous tile fully consumed
+    if (threadIdx.x < np) {
+      const int t = threadIdx.x;
+      const int ij = order ? order[p0 + t] : p0 + t;
+      sP[t] = ctu_point(ij, ngy, kxlt, zdello, xdella, cosph, sinph, wlat, wcor, cosphm1);
+      int* q = sI + t * 16;
+      q[0] = ij;
+      q[1] = klon[ij * 2 + 0]; q[2] = klon[ij * 2 + 1];
+      for (int i = 0; i < 4; i++) q[3 + i] = klat[ij * 4 + i];
+      for (int i = 0; i < 8; i++) q[7 + i] = kcor[ij * 8 + i];
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < np * NFRE; it += blockDim.x) {
+      const int t = it / NFRE, m = it - t * NFRE;
+      const int* q = sI + t * 16;
+      if (m >= m0 && m < m1) {
+        T cgl[2], cgy0[2], cgy1[2];
+        for (int ic = 0; ic < 2; ic++) {
+          cgl[ic] = cg[(size_t)q[1 + ic] * NFRE + m];
+          cgy0[ic] = cg[(size_t)q[3 + 2 * ic] * NFRE + m];
+          cgy1[ic] = cg[(size_t)q[4 + 2 * ic] * NFRE + m];
+        }
+        const CtuBase<T> b = ctu_base(cg[(size_t)q[0] * NFRE + m], cgl, cgy0, cgy1, sP[t].wl, sP[t].dp);
+        T* o = sB + (size_t)t * 5 * NFRE + m;
+        o[0] = b.h[0]; o[NFRE] = b.h[1]; o[2 * NFRE] = b.hy[0]; o[3 * NFRE] = b.hy[1]; o[4 * NFRE] = b.cg0;
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < np * NV; e += blockDim.x) {
+      const int t = e / NV, ev = e - t * NV;
+      const int k = ev / FV, m = (ev - k * FV) * VW;
+      const int* q = sI + t * 16;
+      const size_t own = (size_t)q[0] * N;
+      const int el = k * NFRE + m;
+      typedef VecIO<T, VW> IO;
+      if (m < m0 || m >= m1) {
+        if (copy_rest) {
+          T v[VW];
+          IO::ld(f1 + own + el, v);
+          IO::st(f3 + own + el, v);
+        }
+        continue;
+      }
+      const CtuPoint<T>& p = sP[t];
+      const int jx0 = tab->JXO[k][0], jx1 = tab->JXO[k][1], jy0 = tab->JYO[k][0], jy1 = tab->JYO[k][1], kc = tab->KCR[k][0];
+      const int km = tab->KPM[k][0], kp = tab->KPM[k][2];
+      const T sink = tab->SINTH[k], cosk = tab->COSTH[k];
+      T tsp, tsm;
+      {
+#pragma clang fp contract(off)
+        tsp = p.tanph * sK[2 * k];
+        tsm = p.tanph * sK[2 * k + 1];
+      }
+      T fo[VW], flon[VW], fla1[VW], fla2[VW], fco1[VW], fco2[VW], fkm[VW], fkp[VW];
+      IO::ld(f1 + own + el, fo);
+      IO::ld(f1 + (size_t)q[1 + jx0] * N + el, flon);
+      IO::ld(f1 + (size_t)q[3 + 2 * jy0] * N + el, fla1);
+      IO::ld(f1 + (size_t)q[4 + 2 * jy0] * N + el, fla2);
+      IO::ld(f1 + (size_t)q[7 + 2 * kc] * N + el, fco1);
+      IO::ld(f1 + (size_t)q[8 + 2 * kc] * N + el, fco2);
+      IO::ld(f1 + own + km * NFRE + m, fkm);
+      IO::ld(f1 + own + kp * NFRE + m, fkp);
+      const T* bb = sB + (size_t)t * 5 * NFRE + m;
+      T bh0[VW], bh1[VW], by0[VW], by1[VW], bc0[VW];
+      IO::ld(bb, bh0); IO::ld(bb + NFRE, bh1); IO::ld(bb + 2 * NFRE, by0); IO::ld(bb + 3 * NFRE, by1); IO::ld(bb + 4 * NFRE, bc0);
+      T r[VW];
+#pragma unroll
+      for (int c = 0; c < VW; c++) {
+        CtuBase<T> b;
+        b.h[0] = bh0[c]; b.h[1] = bh1[c]; b.hy[0] = by0[c]; b.hy[1] = by1[c]; b.cg0 = bc0[c];
+        T w8[8];
+        (void)ctu_w8(b, sink, cosk, p.cpm1, p.zd, xdella, p.ga, delpro, CMTODEG, jx0, jx1, jy0, jy1, p.wl[jy0], p.wc[kc], tsp, tsm, w8);
+        const T a = ctu_stencil(w8[0], w8[1], w8[2], w8[3], w8[4], w8[5], w8[6], w8[7], fo[c], flon[c], fla1[c], fla2[c], fco1[c],
+                                fco2[c], fkm[c], fkp[c]);
+        r[c] = a;
+      }
+      IO::st(f3 + own + el, r);
+    }
   }
 }
 
@@ -305,6 +511,29 @@ void launch_ctuw(const void* tab, int n, int nland, int ngy, double delpro, int 
                      (const T*)cg, (const T*)cosphm1, (T*)w, cflfail);
 }
 template <typename T>
+void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, int ngy, double delpro, const int* kxlt,
+                         const void* zdello, double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat,
+                         const int* kcor, const void* wlat, const void* wcor, const void* cg, const void* cosphm1, const int* order,
+                         int kijs, int kijl, int m0, int m1, int copy_rest, int dims, hipStream_t s) {
+  const int NANG = dims >> 16, NFRE = (dims >> 8) & 0xFF;
+  const int n = kijl - kijs;
+  if (n <= 0) return;
+  const int ntiles = (n + OTF_TP - 1) / OTF_TP;
+  const size_t shmem = OTF_TP * (sizeof(CtuPoint<T>) + 16 * sizeof(int)) + ((size_t)OTF_TP * 5 * NFRE + 2 * NANG) * sizeof(T) + 16;
+  const int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
+  constexpr int W = VecOf<T>::W;
+  const bool aligned = ((uintptr_t)f1 % 16 == 0) && ((uintptr_t)f3 % 16 == 0);
+#define OTF_ARGS                                                                                                              \
+  (const DevTab<T>*)tab, (const T*)f1, (T*)f3, n_geom, ngy, (T)delpro, kxlt, (const T*)zdello, (T)xdella, (const T*)cosph,     \
+      (const T*)sinph, klon, klat, kcor, (const T*)wlat, (const T*)wcor, (const T*)cg, (const T*)cosphm1, order, kijs, kijl, m0, \
+      m1, copy_rest, ntiles
+  if (aligned && NFRE % W == 0 && m0 % W == 0 && m1 % W == 0)
+    hipLaunchKernelGGL((k_propags2_otf<T, W>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
+  else
+    hipLaunchKernelGGL((k_propags2_otf<T, 1>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
+#undef OTF_ARGS
+}
+template <typename T>
 void launch_newwind(const void* tab, int n, void* ff, const void* ffn, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_newwind<T>, dim3((n + 255) / 256), dim3(256), 0, s, (const DevTab<T>*)tab, n, (T*)ff, (const T*)ffn);
@@ -335,6 +564,9 @@ void launch_pack(const void* fl, const int* idx, int n, int rowlen, void* buf, h
                                const void*, const int*, const int*, const int*, void*, void*, const void*, const void*, void*,   \
                                int*, int, hipStream_t);                                                                           \
   template void launch_newwind<T>(const void*, int, void*, const void*, hipStream_t);                                             \
+  template void launch_propags2_otf<T>(const void*, const void*, void*, int, int, double, const int*, const void*, double,        \
+                                       const void*, const void*, const int*, const int*, const int*, const void*, const void*,   \
+                                       const void*, const void*, const int*, int, int, int, int, int, int, hipStream_t);         \
   template void launch_c2p<T>(const void*, void*, int, int, int, int, int, hipStream_t);                                          \
   template void launch_p2c<T>(const void*, void*, int, int, int, int, int, hipStream_t);                                          \
   template void launch_pack<T>(const void*, const int*, int, int, void*, hipStream_t);

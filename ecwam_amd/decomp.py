@@ -95,3 +95,21 @@ def local_domain(grid, rank: int, nranks: int) -> LocalDomain:
     return LocalDomain(rank=rank, nranks=nranks, lo=lo, hi=hi, n=n, nh=nh, halo_global=halo, klon=renum(grid.klon),
                        klat=renum(grid.klat), kcor=renum(grid.kcor), kxlt=grid.kxlt[lo:hi].astype(np.int32),
                        cosphm1_ext=cos_ext, send=send, recv=recv)
+
+
+def strip_order(grid, dom, width: int = 256) -> np.ndarray:
+    """Processing order of the owned points for the advection kernel: longitude strips of about `width` points on the
+    longest owned latitude row, each strip walked row by row.  A point's latitude neighbours (KLAT/KCOR, the nearest
+    longitudes of the adjacent rows) then lie ~`width` points away in the processing sequence instead of a whole row
+    (~4*N points on an O-N grid), so that they are still in the XCD's L2 when they are needed.  Pure work ordering:
+    the storage order of the spectra is the reference's (block order of mpdecomp.F90)."""
+    ix = np.asarray(grid.ixlg[dom.lo:dom.hi], dtype=np.int64)        # 0-based longitude index in the row
+    ky = np.asarray(grid.kxlt[dom.lo:dom.hi], dtype=np.int64)        # latitude row
+    nlon = np.asarray(grid.nlonrgg, dtype=np.int64)[ky]
+    lon = (ix + 0.5) / nlon                                          # longitude as a fraction of the circle
+    rows = np.unique(ky)
+    nmax = int(max(np.asarray(grid.nlonrgg)[rows].max(), 1))
+    nstrip = max(1, int(round(nmax / float(width))))
+    strip = np.minimum((lon * nstrip).astype(np.int64), nstrip - 1)
+    key = (strip * (int(ky.max()) + 1) + ky) * (nmax + 1) + ix
+    return np.argsort(key, kind="stable").astype(np.int32)

@@ -52,7 +52,9 @@ class Wamintgr:
     """Device-resident WAMINTGR for one rank."""
 
     def __init__(self, cfg: Config, grid, prec: str = "sp", device: int = 0, rank: int = 0, nranks: int = 1,
-                 ifrelfmax: int = 0, delpro_lf: float | None = None):
+                 ifrelfmax: int = 0, delpro_lf: float | None = None, weights: str = "otf", strip_width: int = 0):
+        # weights: "otf" rebuilds the CTU weights inside PROPAGS2 (no W array, default); "stored" keeps the reference's
+        # scheme (CTUW once into W[ij][8][NANG*NFRE_RED], PROPAGS2 streams them).  Bit-identical results.
         self.cfg, self.grid, self.prec = cfg, grid, prec
         self.npdt = np.float32 if prec == "sp" else np.float64
         self.t = Tables(cfg, self.npdt)
@@ -66,7 +68,15 @@ class Wamintgr:
         z = dict(dtype=self.dtype, device=self.dev)
         self.fl1 = torch.zeros((self.nrows, NANG, NFRE), **z)
         self.fl3 = torch.zeros((self.nrows, NANG, NFRE), **z)
-        self.w = torch.zeros((self.n, 8, NANG * NR), **z)
+        if weights not in ("otf", "stored"):
+            raise ValueError("weights must be 'otf' or 'stored'")
+        self.weights = weights
+        self.w = torch.zeros((self.n, 8, NANG * NR), **z) if weights == "stored" else None
+        # optional processing order of the advection (longitude strips); measured neutral on MI355X (the 256 MB Infinity Cache
+        # already serves the latitude neighbours), kept as an option
+        self.order = None
+        if strip_width > 0 and self.n > 4 * strip_width:
+            self.order = torch.from_numpy(decomp.strip_order(grid, self.dom, strip_width)).to(self.dev)
         self.wvprpt = torch.zeros((self.n, api.NWPR, NFRE), **z)
         self.ff = torch.zeros((self.n, api.NFF), **z)
         self.ff_next = None
@@ -110,6 +120,7 @@ class Wamintgr:
     def build_weights(self) -> int:
         c = self.cfg
         self.cflfail.zero_()
+        # weights == "otf": w is None, CTUW only snaps WLAT/WCOR near land and runs the CFL / range checks
         if self.ifrelfmax <= 0:
             self.ctx.ctuw(self.gd, self.cgroup_ext, self.w, self.cflfail, float(c.idelpro), 1, c.nfre_red)
         else:
@@ -126,16 +137,29 @@ class Wamintgr:
             if nfail:
                 raise api.EcwamHipError(f"CFL criterion violated at {nfail} points (ctuwdrv.F90:128-146)")
         c, g = self.cfg, self.gd
+        lf = 0 < self.ifrelfmax < c.nfre_red
+
+        def advect(m1, m2, delpro, copy_rest):
+            if self.weights == "stored":
+                self.ctx.propags2(self.fl1, self.fl3, g["klon"], g["klat"], g["kcor"], self.w, 0, self.n, m1, m2, copy_rest=copy_rest)
+            else:
+                self.ctx.propags2_otf(self.fl1, self.fl3, g, self.cgroup_ext, delpro, 0, self.n, m1, m2, copy_rest=copy_rest,
+                                      order=self.order)
+
         self.halo(self.fl1)
-        self.ctx.propags2(self.fl1, self.fl3, g["klon"], g["klat"], g["kcor"], self.w, 0, self.n, 1, c.nfre_red, copy_rest=True)
-        if 0 < self.ifrelfmax < c.nfre_red:
+        if self.weights == "stored" or self.ifrelfmax <= 0:
+            advect(1, c.nfre_red, float(c.idelpro), True)      # stored W already carries the per-range time steps
+        else:
+            advect(1, self.ifrelfmax, float(self.delpro_lf), True)
+            if lf:
+                advect(self.ifrelfmax + 1, c.nfre_red, float(c.idelpro), False)
+        if lf:
             nstep_lf = int(round(float(c.idelpro) / float(self.delpro_lf)))
             for _ in range(2, nstep_lf + 1):
                 # FL1_EXT(:,:,1:IFRELFMAX) <- FL3_EXT ; exchange ; PROPAGS2 on the fast waves only
                 self.fl1[: self.n, :, : self.ifrelfmax] = self.fl3[: self.n, :, : self.ifrelfmax]
                 self.halo(self.fl1)
-                self.ctx.propags2(self.fl1, self.fl3, g["klon"], g["klat"], g["kcor"], self.w, 0, self.n, 1, self.ifrelfmax,
-                                  copy_rest=False)
+                advect(1, self.ifrelfmax, float(self.delpro_lf), False)
         self.fl1, self.fl3 = self.fl3, self.fl1
 
     def newwind(self) -> None:

@@ -131,11 +131,28 @@ int ecwam_hip_propags2(ecwam_hip_ctx *ctx, const void *f1, void *f3, const int *
  *   cgroup_ext [npts+1][NFRE] group velocity incl. halo and land rows (proenvhalo.F90 BUFFER_EXT)
  *   cosphm1_ext[npts+1]
  *   cflfail  int[n] set to 1 where a CFL/weight-range check of ctuw.F90:288-357,541-685 fails
+ *   w        may be NULL: checks and WLAT/WCOR snapping only (see ecwam_hip_propags2_otf)
  */
 int ecwam_hip_ctuw(ecwam_hip_ctx *ctx, int n, int nland, int ngy, double delpro, int mstart, int mend, const int *kxlt,
                    const void *zdello, double xdella, const void *cosph, const void *sinph, const int *klon, const int *klat,
                    const int *kcor, void *wlat, void *wcor, const void *cgroup_ext, const void *cosphm1_ext, void *w,
                    int *cflfail, void *stream);
+
+/*
+ * PROPAGS2 with the CTU weights rebuilt inside the stencil ("on the fly") instead of read from W: the device-side
+ * replacement of PROPAGS2 + the WLATN/WLONN/WCORN/WKPMN/SUMWN module arrays of yowubuf.F90:175-193 when the weights are
+ * static (IREFRA=0: ctuwupdt.F90:204-238 builds them once).  Same arguments as ecwam_hip_ctuw (the geometry, with
+ * wlat/wcor as LEFT BY ecwam_hip_ctuw, i.e. after the CTUWINI land snapping) plus those of ecwam_hip_propags2; the
+ * result is bit-identical to ecwam_hip_ctuw followed by ecwam_hip_propags2 with the same delpro.  ecwam_hip_ctuw with
+ * w == NULL performs the CTUWINI snapping and the CFL / weight-range checks without storing the weights.
+ *   order  optional int[>=kijl]: rows are processed in the order order[kijs..kijl) (a permutation of [kijs,kijl) chosen by
+ *          the host for cache locality, e.g. longitude strips); NULL = natural order.  Results do not depend on it.
+ */
+int ecwam_hip_propags2_otf(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n, int ngy, double delpro, const int *kxlt,
+                           const void *zdello, double xdella, const void *cosph, const void *sinph, const int *klon,
+                           const int *klat, const int *kcor, const void *wlat, const void *wcor, const void *cgroup_ext,
+                           const void *cosphm1_ext, const int *order, int kijs, int kijl, int nd3s, int nd3e, int copy_rest,
+                           void *stream);
 
 /*
  * IMPLSCH (implsch.F90:10-23) for local points [kijs,kijl) on device pointers (layouts above).

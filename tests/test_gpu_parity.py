@@ -164,6 +164,22 @@ def test_ctuw_and_propags2_parity(api, prec, mask):
     f3b = tf3b.cpu().numpy()
     assert np.all(f3b[:3] == -7.0) and np.all(f3b[g.nsea - 2:] == -7.0) and np.all(f3b[3:g.nsea - 2, :, 5:] == -7.0)
     assert np.array_equal(f3b[3:g.nsea - 2, :, :5], f3[3:g.nsea - 2, :, :5])
+    # on-the-fly weights (no W array): bit-identical to the stored-weight path, in any processing order, and the
+    # check-only form of CTUW raises the same CFL flags
+    cg = torch.from_numpy(cg_ext).to(dev)
+    tf3c = torch.full_like(tf1, -7.0)
+    ctx.propags2_otf(tf1, tf3c, gd, cg, float(cfg.idelpro), 0, g.nsea)
+    order = torch.from_numpy(np.random.default_rng(3).permutation(g.nsea).astype(np.int32)).to(dev)
+    tf3d = torch.full_like(tf1, -7.0)
+    ctx.propags2_otf(tf1, tf3d, gd, cg, float(cfg.idelpro), 0, g.nsea, order=order)
+    tf3e = torch.full_like(tf1, -7.0)
+    ctx.propags2_otf(tf1, tf3e, gd, cg, float(cfg.idelpro), 3, g.nsea - 2, 1, 5, copy_rest=False)
+    fail2 = torch.ones(g.nsea, dtype=torch.int32, device=dev) * 0
+    ctx.ctuw(gd, cg, None, fail2, float(cfg.idelpro))
+    torch.cuda.synchronize()
+    assert np.array_equal(tf3c.cpu().numpy(), f3) and np.array_equal(tf3d.cpu().numpy(), f3)
+    assert np.array_equal(tf3e.cpu().numpy(), f3b)
+    assert int(fail2.sum()) == 0
     ctx.close()
 
 

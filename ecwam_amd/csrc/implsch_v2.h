@@ -176,16 +176,16 @@ __device__ __forceinline__ void lane_put(T& r, int lane, int m, T v) { r = (lane
 // sinput_ard.F90:153-520 for variant 2.  STORE: write FLD (second SINFLX call); first call needs XLLWS and the stresses only.
 // Out: xmask (XLLWS), lane-m registers rX/rY/rS = SUM_K SPOS*SINTH, SUM_K SPOS*COSTH, SUM_K SPOS, and the per-direction
 // accumulator apl = SUM_M RHOWG_DFIM(M)*(FLD*F-SPOS) of the negative wind input (stresso.F90:160-168).
-template <typename T, int NGST, bool LLSNEG>
+template <typename T, int NGST, bool LLSNEG, bool NORMA>
 __device__ void sinput_ard2(const DevTab<T>& tb, const T* sF, T* sFLD, const Lane<T>& L, T rWAVNUM, T rCINV, T rXK2CG, T WDWAVE,
                             T UFRIC, T Z0M, T coswdif, T sinwdif2, T RAORW, T RNFAC, T SIG_N, T TEMP2, T PTURB, T AIRD_PVISC,
-                            unsigned long long& xmask, T& rX, T& rY, T& rS, T& apl) {
+                            unsigned long long& xmask, T& rX, T& rY, T& rS, T& apl, T& wsae, T& wsaf, T& wslast) {
   const T AVG_GST = T(1) / T(NGST);
   const T CONST1 = tb.BETAMAXOXKAPPA2;
   const T CONSTN = tb.DELTH / (tb.XKAPPA * tb.ZPI);
   const T ABS_TAUWSHELTER = m_abs(tb.TAUWSHELTER);
   const bool LTAUWSHELTER = (ABS_TAUWSHELTER != T(0));
-  const bool LLNORMAGAM = tb.LLNORMAGAM != 0;
+  const bool LLNORMAGAM = NORMA;  // compile-time: the LLNORMAGAM = F build carries no normalisation code or registers
   T CSTRNFAC = T(0);
   if (LLNORMAGAM) CSTRNFAC = CONSTN * RNFAC / RAORW;
   const T NU_AIR = tb.RNU;
@@ -211,6 +211,7 @@ __device__ void sinput_ard2(const DevTab<T>& tb, const T* sF, T* sFLD, const Lan
   const T sinthk = tb.SINTH[L.k], costhk = tb.COSTH[L.k];
   xmask = 0ull;
   rX = T(0); rY = T(0); rS = T(0); apl = T(0);
+  wsae = T(0); wsaf = T(0); wslast = T(0);  // FEMEANWS integrands of the windsea part (femeanws.F90:84-123), finished by the caller
   T rZCN = T(0), rCOEF5 = T(0);
   if (L.actm) {
     rZCN = m_log(rWAVNUM * Z0M);
@@ -300,7 +301,7 @@ __device__ void sinput_ard2(const DevTab<T>& tb, const T* sF, T* sFLD, const Lan
     T SLP_AVG = T(0), FLP_AVG = T(0), sa[2];
 #pragma unroll
     for (int ig = 0; ig < NGST; ig++) {
-      T SLP = g0[ig] * GAMNORMA[ig];
+      T SLP = NORMA ? g0[ig] * GAMNORMA[ig] : g0[ig];
       const T FLP = SLP + ds[ig];
       SLP = SLP * f;
       sa[ig] = L.act ? SLP : T(0);
@@ -350,7 +351,29 @@ __device__ void sinput_ard2(const DevTab<T>& tb, const T* sF, T* sFLD, const Lan
       if (L.act) sFLD[m * L.NAP + L.k] += fld;  // on top of the dissipation coefficient already there
     }
     if (xl) xmask |= (1ull << m);
+    {
+      const T x = xl ? f : T(0);
+      wsae += lane_get(L.rDFIM, m) * x;
+      wsaf += lane_get(L.rDFIMOFR, m) * x;
+      wslast = x;
+    }
   }
+}
+
+// femeanws.F90:103-123 from the per-direction integrands gathered in SINPUT
+template <typename T>
+__device__ __forceinline__ void femeanws_finish(const DevTab<T>& tb, const Lane<T>& L, T ae, T af, T last, T& FM, T& EMW) {
+  if (!L.act) { ae = T(0); af = T(0); last = T(0); }
+  T t2, d0, se, sf;
+  usum4(last, T(0), ae, af, t2, d0, se, sf);
+  const T DELT25 = tb.WETAIL * tb.FR[L.NFRE - 1] * tb.DELTH;
+  const T DELT2 = tb.FRTAIL * tb.DELTH;
+  T em = tb.EPSMIN + se;
+  T fm = tb.EPSMIN + sf;
+  em = em + DELT25 * t2;
+  fm = fm + DELT2 * t2;
+  FM = em / fm;
+  EMW = em;
 }
 
 // sdissip_ard.F90:117-314 (SSDSC3 = 0) for variant 2: FLD = D (SINPUT adds the wind input afterwards), two frequency rows per iteration so that the saturation
@@ -546,7 +569,7 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
   }
 }
 
-template <typename T, int WPB>
+template <typename T, int WPB, bool NORMA>
 __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 4 : 2))) k_implsch2(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__ fl1,
                                                        const T* __restrict__ wvprpt, T* __restrict__ ffa, T* __restrict__ intfa,
                                                        int* __restrict__ mij_out, T* __restrict__ xllws, T* __restrict__ dbg) {
@@ -691,13 +714,13 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   // ---- first SINFLX call (sinflx.F90:105-183): XLLWS, MIJ and the wave stress only
   T FMEANWS = T(0), EMW;
   int MIJ = NFRE;
-  T rRH = T(0), rX, rY, rS, apl;
+  T rRH = T(0), rX, rY, rS, apl, wsae, wsaf, wslast;
   unsigned long long xmask = 0ull;
   if (!(SKIP & 1))
-    sinput_ard2<T, 1, false>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, WDWAVE, UFRIC, Z0M, coswdif, sinwdif2, RAORW, RNFAC, T(0), T(0),
-                             T(0), T(0), xmask, rX, rY, rS, apl);
-  else { rX = rY = rS = apl = T(0); }
-  femeanws(tb, sF, L, xmask, FMEANWS, EMW);
+    sinput_ard2<T, 1, false, NORMA>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, WDWAVE, UFRIC, Z0M, coswdif, sinwdif2, RAORW, RNFAC, T(0),
+                                    T(0), T(0), T(0), xmask, rX, rY, rS, apl, wsae, wsaf, wslast);
+  else { rX = rY = rS = apl = wsae = wsaf = wslast = T(0); }
+  femeanws_finish(tb, L, wsae, wsaf, wslast, FMEANWS, EMW);
   MIJ = frcutindex(FMEANWS, UFRIC, rRH);
   {
     const T wx = rRH * rCINV;
@@ -739,12 +762,12 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
 
   // ---- second SINFLX call: FLD, XLLWS, MIJ, wave stress and the PHIWA integrals
   if (!(SKIP & 1))
-    sinput_ard2<T, 2, true>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, WDWAVE, UFRIC, Z0M, coswdif, sinwdif2, RAORW, RNFAC, c[C_SIGN],
-                            c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], xmask, rX, rY, rS, apl);
+    sinput_ard2<T, 2, true, NORMA>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, WDWAVE, UFRIC, Z0M, coswdif, sinwdif2, RAORW, RNFAC,
+                                   c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], xmask, rX, rY, rS, apl, wsae, wsaf, wslast);
   else {
-    rX = rY = rS = apl = T(0);
+    rX = rY = rS = apl = wsae = wsaf = wslast = T(0);
   }
-  femeanws(tb, sF, L, xmask, FMEANWS, EMW);
+  femeanws_finish(tb, L, wsae, wsaf, wslast, FMEANWS, EMW);
   MIJ = frcutindex(FMEANWS, UFRIC, rRH);
   {
     const T wx = rRH * rCINV;

@@ -1044,7 +1044,7 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
   const bool variant2 = (variant == 2);
   const int ntile = (variant == 2) ? 2 : 3;
   const int NAP = variant2 ? NANG : (NANG | 1);
-  const int nscr = variant2 ? 32 : 64;
+  const int nscr = variant2 ? 0 : 64;
   const size_t per_wave = (size_t)(ntile * NFRE * NAP + nscr) * sizeof(T) + (variant == 2 ? NSC * sizeof(T) : 0);
   // waves (= points) per block: the choice that fits the most waves into the 160 KiB of LDS of a CU; ties go to the larger
   // block, which amortises the lane-per-point scalar stages of variant 2 over more points

@@ -12,37 +12,73 @@
 enum {
   C_WSWAVE = 0, C_WDWAVE, C_TAUW, C_TAUWDIR, C_UFRIC, C_Z0M, C_Z0B, C_CHRNCK, C_AIRD, C_WSTAR, C_RNFAC, C_RAORW,
   C_XS, C_YS, C_PHIWA, C_MIJ, C_F1DCOS3, C_F1DCOS2, C_F1DSIN2, C_F1D, C_UORBT, C_AORB, C_SIGN, C_TEMP2, C_PTURB, C_AIRDPVISC,
-  C_EMEAN, C_F1MEAN, C_EMAXDPT, C_DEPTH, C_SDS, C_SPARE, NSC
+  C_EMEAN, C_F1MEAN, C_EMAXDPT, C_DEPTH, C_SDS, C_SPARE,
+  C_XSN, C_YSN, C_UST, C_SINU, C_COSU, C_XLOGGZ0, C_SQRTGZ0, C_ZINF, NSC  // NSC = 40
 };
 
-// tau_phi_hf.F90:125-301 for one point per lane: the directional integrals of F(:,MIJ) come in as arguments
+// STRESSO's scalar half (stresso.F90:180-229) with TAU_PHI_HF (tau_phi_hf.F90:125-301), one point per lane, in three steps
+// so that the 19 quadrature nodes of every point of the block are evaluated side by side (lane = point*JTOT + node) and
+// only the sheltering recurrence itself is serial:
+//   head : c[C_XS], c[C_YS] (resolved-range stress integrals) -> sheltered friction velocity and direction, node geometry
+//   nodes: Y(J), CM1(J), XLOGGZ0 + 2 LOG(CM1(J)) in registers of lane point*JTOT + J
+//   tail : the TAUHF / PHIHF recurrences, TAUW, TAUWDIR, PHIWA
 template <typename T>
-__device__ void tau_phi_hf_pt(const DevTab<T>& tb, int MIJ, bool LTAUWSHELTER, T Z0M, T AIRD, T RNFAC, T F1DCOS3, T F1DCOS2,
-                              T F1DSIN2, T F1D, T& UST, T& TAUHF, T& PHIHF, bool LLPHIHF) {
+__device__ void stresso_head_pt(const DevTab<T>& tb, T* c) {
+  const T AIRD = c[C_AIRD], WDWAVE = c[C_WDWAVE], UFRIC = c[C_UFRIC], Z0M = c[C_Z0M];
+  const int MIJ = (int)c[C_MIJ];
+  const T XSTRESS = c[C_XS] / m_max(AIRD, T(1));
+  const T YSTRESS = c[C_YS] / m_max(AIRD, T(1));
+  T USDIRP, UST;
+  if (tb.TAUWSHELTER == T(0)) { USDIRP = WDWAVE; UST = UFRIC; }
+  else {
+    const T TAUPX = UFRIC * UFRIC * m_sin(WDWAVE) - tb.TAUWSHELTER * XSTRESS;
+    const T TAUPY = UFRIC * UFRIC * m_cos(WDWAVE) - tb.TAUWSHELTER * YSTRESS;
+    USDIRP = m_atan2(TAUPX, TAUPY);
+    UST = m_pow(TAUPX * TAUPX + TAUPY * TAUPY, T(0.25));
+  }
+  c[C_XSN] = XSTRESS; c[C_YSN] = YSTRESS; c[C_UST] = UST;
+  c[C_SINU] = m_sin(USDIRP); c[C_COSU] = m_cos(USDIRP);
   const T X0G = tb.X0TAUHF * tb.G;
-  T USTPH = UST;
-  const T XLOGGZ0 = m_log(tb.G * Z0M);
   const T OMEGACC = m_max(tb.ZPIFR[MIJ - 1], X0G / UST);
   const T SQRTZ0OG = m_sqrt(Z0M * tb.GM1);
-  const T SQRTGZ0 = T(1) / SQRTZ0OG;
-  const T ZINF = m_log(OMEGACC * SQRTZ0OG);
+  c[C_XLOGGZ0] = m_log(tb.G * Z0M);
+  c[C_SQRTGZ0] = T(1) / SQRTZ0OG;
+  c[C_ZINF] = m_log(OMEGACC * SQRTZ0OG);
+}
+template <typename T>
+__device__ __forceinline__ void stresso_node(const DevTab<T>& tb, const T* c, int J, T& nY, T& nCM1, T& nLC) {
+  const T ZINF = c[C_ZINF];
+  const T DELZ = m_max((T(0) - ZINF) / T(JTOT - 1), T(0));
+  const T Y = m_exp(ZINF + T(J) * DELZ);
+  const T CM1 = (Y * c[C_SQRTGZ0]) * tb.GM1;
+  nY = Y; nCM1 = CM1; nLC = c[C_XLOGGZ0] + T(2) * m_log(CM1);
+}
+template <typename T>
+// nY/nCM1/nLC: node values held by lane nbase+J (pulled through the LDS crossbar; every lane of the wave runs this)
+__device__ void stresso_tail_pt(const DevTab<T>& tb, T* c, T nY, T nCM1, T nLC, int nbase, bool store, bool LLPHIWA) {
+  const T AIRD = c[C_AIRD], UFRIC = c[C_UFRIC], Z0M = c[C_Z0M], RNFAC = c[C_RNFAC];
+  const T F1DCOS3 = c[C_F1DCOS3], F1DCOS2 = c[C_F1DCOS2];
+  const int MIJ = (int)c[C_MIJ];
+  const bool LTAUWSHELTER = (tb.TAUWSHELTER != T(0));
+  T UST = c[C_UST];
+  T USTPH = UST;
+  const T SQRTGZ0 = c[C_SQRTGZ0];
+  const T SQRTZ0OG = m_sqrt(Z0M * tb.GM1);
+  const T ZINF = c[C_ZINF];
   const T fr5 = tb.FR5[MIJ - 1];
   const T CONSTTAU = tb.ZPI4GM2 * fr5;
   T CONST1 = T(0), CONST2 = T(0);
   const bool NORMA = tb.LLNORMAGAM != 0;
   if (NORMA) {
     const T CONFG = tb.GAMNCONST * fr5 * RNFAC * SQRTGZ0;
-    CONST1 = CONFG * F1DSIN2;
-    CONST2 = CONFG * F1D;
+    CONST1 = CONFG * c[C_F1DSIN2];
+    CONST2 = CONFG * c[C_F1D];
   }
   T TAUL = UST * UST;
   const T DELZ = m_max((T(0) - ZINF) / T(JTOT - 1), T(0));
-  TAUHF = T(0);
-  T acc = T(0);
+  T TAUHF = T(0), acc = T(0);
   for (int J = 0; J < JTOT; J++) {
-    const T Y = m_exp(ZINF + T(J) * DELZ);
-    const T CM1 = (Y * SQRTGZ0) * tb.GM1;
-    const T LC = XLOGGZ0 + T(2) * m_log(CM1);
+    const T Y = lane_pull(nY, nbase + J), CM1 = lane_pull(nCM1, nbase + J), LC = lane_pull(nLC, nbase + J);
     const T ZARG = tb.XKAPPA * f_rcp(UST * CM1 + tb.ZALP);
     const T ZLOG = m_min(LC + ZARG, T(0));
     const T ZBETA = m_pow4(ZLOG) * f_exp(ZLOG);
@@ -58,14 +94,12 @@ __device__ void tau_phi_hf_pt(const DevTab<T>& tb, int MIJ, bool LTAUWSHELTER, T
     }
   }
   if (!LTAUWSHELTER) TAUHF = F1DCOS3 * CONSTTAU * TAUL * acc * DELZ;
-  PHIHF = T(0);
-  if (LLPHIHF) {
+  T PHIHF = T(0);
+  if (LLPHIWA) {
     TAUL = USTPH * USTPH;
     const T CONSTPHI = AIRD * tb.ZPI4GM1 * fr5;
     for (int J = 0; J < JTOT; J++) {
-      const T Y = m_exp(ZINF + T(J) * DELZ);
-      const T CM1 = (Y * SQRTGZ0) * tb.GM1;
-      const T LC = XLOGGZ0 + T(2) * m_log(CM1);
+      const T Y = lane_pull(nY, nbase + J), CM1 = lane_pull(nCM1, nbase + J), LC = lane_pull(nLC, nbase + J);
       const T ZARG = tb.XKAPPA * f_rcp(USTPH * CM1 + tb.ZALP);
       const T ZLOG = m_min(LC + ZARG, T(0));
       const T ZBETA = m_pow4(ZLOG) * f_exp(ZLOG);
@@ -83,37 +117,30 @@ __device__ void tau_phi_hf_pt(const DevTab<T>& tb, int MIJ, bool LTAUWSHELTER, T
     if (LTAUWSHELTER) PHIHF = F1DCOS2 * CONSTPHI * SQRTZ0OG * PHIHF;
     else PHIHF = F1DCOS2 * CONSTPHI * SQRTZ0OG * TAUL * PHIHF * DELZ;
   }
-}
-
-// the scalar half of STRESSO (stresso.F90:180-229) for one point per lane; c[C_XS], c[C_YS], c[C_PHIWA] hold the spectral
-// integrals of the resolved range, the results replace c[C_TAUW], c[C_TAUWDIR] and c[C_PHIWA]
-template <typename T>
-__device__ void stresso_pt(const DevTab<T>& tb, T* c, bool LLPHIWA) {
-  const T AIRD = c[C_AIRD], WDWAVE = c[C_WDWAVE], UFRIC = c[C_UFRIC], Z0M = c[C_Z0M];
-  const int MIJ = (int)c[C_MIJ];
-  T XSTRESS = c[C_XS] / m_max(AIRD, T(1));
-  T YSTRESS = c[C_YS] / m_max(AIRD, T(1));
-  bool LTAUWSHELTER;
-  T USDIRP, UST;
-  if (tb.TAUWSHELTER == T(0)) { LTAUWSHELTER = false; USDIRP = WDWAVE; UST = UFRIC; }
-  else {
-    LTAUWSHELTER = true;
-    const T TAUPX = UFRIC * UFRIC * m_sin(WDWAVE) - tb.TAUWSHELTER * XSTRESS;
-    const T TAUPY = UFRIC * UFRIC * m_cos(WDWAVE) - tb.TAUWSHELTER * YSTRESS;
-    USDIRP = m_atan2(TAUPX, TAUPY);
-    UST = m_pow(TAUPX * TAUPX + TAUPY * TAUPY, T(0.25));
-  }
-  T TAUHF, PHIHF;
-  tau_phi_hf_pt(tb, MIJ, LTAUWSHELTER, Z0M, AIRD, c[C_RNFAC], c[C_F1DCOS3], c[C_F1DCOS2], c[C_F1DSIN2], c[C_F1D], UST, TAUHF, PHIHF,
-                LLPHIWA);
-  XSTRESS = XSTRESS + TAUHF * m_sin(USDIRP);
-  YSTRESS = YSTRESS + TAUHF * m_cos(USDIRP);
+  const T XSTRESS = c[C_XSN] + TAUHF * c[C_SINU];
+  const T YSTRESS = c[C_YSN] + TAUHF * c[C_COSU];
   T TAUW = m_max(m_sqrt(XSTRESS * XSTRESS + YSTRESS * YSTRESS), T(0));
   const T TAUWDIR = m_atan2(XSTRESS, YSTRESS);
   if (!tb.LLGCBZ0) TAUW = m_min(TAUW, UFRIC * UFRIC * (T(1) / (T(1) + tb.EPS1)));
-  c[C_TAUW] = TAUW;
-  c[C_TAUWDIR] = TAUWDIR;
-  if (LLPHIWA) c[C_PHIWA] = c[C_PHIWA] + PHIHF;
+  if (store) {
+    c[C_TAUW] = TAUW;
+    c[C_TAUWDIR] = TAUWDIR;
+    if (LLPHIWA) c[C_PHIWA] = c[C_PHIWA] + PHIHF;
+  }
+}
+// the three steps on the stage's wave: lanes < WPB own a point, lanes < WPB*JTOT a node
+template <typename T, int WPB>
+__device__ __forceinline__ void stresso_stage(const DevTab<T>& tb, T* sSC, int lane, bool LLPHIWA) {
+  static_assert(WPB * JTOT <= 64, "one lane per (point, node)");
+  if (lane < WPB) stresso_head_pt(tb, sSC + lane * NSC);
+  WSYNC();
+  T nY = T(1), nCM1 = T(1), nLC = T(0);
+  if (lane < WPB * JTOT) {
+    const int pt = lane / JTOT;
+    stresso_node(tb, sSC + pt * NSC, lane - pt * JTOT, nY, nCM1, nLC);
+  }
+  const int pt = lane < WPB ? lane : WPB - 1;  // spare lanes shadow the last point (the pulls need the whole wave)
+  stresso_tail_pt(tb, sSC + pt * NSC, nY, nCM1, nLC, pt * JTOT, lane < WPB, LLPHIWA);
 }
 
 // scalar set-up of the swell damping (sinput_ard.F90:213-262) from the orbital integrals c[C_UORBT], c[C_AORB]
@@ -593,11 +620,11 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   }
   const int NANG = L.NANG, NFRE = L.NFRE, NAP = L.NAP, N = NANG * NFRE;
   const int tile = NFRE * NAP;
-  T* sF = reinterpret_cast<T*>(smem_raw) + (size_t)wave * (2 * tile + 32);
+  T* sF = reinterpret_cast<T*>(smem_raw) + (size_t)wave * (2 * tile);
   T* sFLD = sF + tile;
-  T* sScr = sFLD + tile;
-  T* sSC = reinterpret_cast<T*>(smem_raw) + (size_t)WPB * (2 * tile + 32);  // [WPB][NSC] point scalars of the block
+  T* sSC = reinterpret_cast<T*>(smem_raw) + (size_t)WPB * (2 * tile);  // [WPB][NSC] point scalars of the block
   T* c = sSC + wave * NSC;
+  T* sScr = c;               // output staging at the very end, when the point scalars have all been consumed (NSC >= 32)
 
   // ---- load the spectrum FL1[ij][K][M] (coalesced) into the [M][NAP] tile
   {
@@ -735,9 +762,9 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   }
   // ---- stage 2: STRESSO scalars, second TAUT_Z0, WSIGSTAR, swell set-up, SDIWBK
   __syncthreads();
+  if (wave == (1 % WPB) && !(SKIP & 2)) stresso_stage<T, WPB>(tb, sSC, L.lane, false);
   if (wave == (1 % WPB) && L.lane < WPB) {
     T* q = sSC + L.lane * NSC;
-    if (!(SKIP & 2)) stresso_pt(tb, q, false);
     T UF = q[C_UFRIC], Z0 = q[C_Z0M], Z0Bv = q[C_Z0B], CH = q[C_CHRNCK];
     if (!(SKIP & 16)) taut_z0_a(tb, 1, q[C_WSWAVE], q[C_WDWAVE], q[C_TAUW], q[C_TAUWDIR], UF, Z0, Z0Bv, CH);
     q[C_UFRIC] = UF; q[C_Z0M] = Z0; q[C_Z0B] = Z0Bv; q[C_CHRNCK] = CH;
@@ -780,7 +807,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   }
   // ---- stage 3: STRESSO scalars of the second call; its results are first needed by WNFLUXES, after the sweep
   __syncthreads();
-  if (wave == (2 % WPB) && L.lane < WPB && !(SKIP & 2)) stresso_pt(tb, sSC + L.lane * NSC, true);
+  if (wave == (2 % WPB) && !(SKIP & 2)) stresso_stage<T, WPB>(tb, sSC, L.lane, true);
 
   // ---- SDISSIP + SNONLIN + update sweep
   const bool shallow_brk = tb.LBIWBK && (DEPTH < T(50.0));

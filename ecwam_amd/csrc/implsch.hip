@@ -103,11 +103,17 @@ __device__ __forceinline__ T chnkmin(const DevTab<T>& tb, T U10) {
 
 // taut_z0.F90:288-340 (LLGCBZ0 = F branch).  All lanes compute the same scalars.
 template <typename T>
+__device__ void taut_z0_c(const DevTab<T>& tb, int IUSFG, T UTOP, T COSDIFF, T TAUW, T& USTAR, T& Z0, T& Z0B, T& CHRNCK);
+template <typename T>
 __device__ void taut_z0_a(const DevTab<T>& tb, int IUSFG, T UTOP, T UDIR, T TAUW, T TAUWDIR, T& USTAR, T& Z0, T& Z0B, T& CHRNCK) {
+  taut_z0_c(tb, IUSFG, UTOP, m_cos(UDIR - TAUWDIR), TAUW, USTAR, Z0, Z0B, CHRNCK);
+}
+// same with COS(UDIR-TAUWDIR) supplied by the caller
+template <typename T>
+__device__ void taut_z0_c(const DevTab<T>& tb, int IUSFG, T UTOP, T COSDIFF, T TAUW, T& USTAR, T& Z0, T& Z0B, T& CHRNCK) {
   const T TWOXMP1 = T(3.0);
   const T XLOGXL = m_log(tb.XNLEV);
   const T US2TOTAUW = T(1) + tb.EPS1;
-  const T COSDIFF = m_cos(UDIR - TAUWDIR);
   const T TAUWACT = m_max(TAUW * COSDIFF, tb.EPSMIN);
   const T TAUWEFF = TAUWACT * US2TOTAUW;
   T XMIN, ALPHAOG;

@@ -13,7 +13,7 @@ enum {
   C_WSWAVE = 0, C_WDWAVE, C_TAUW, C_TAUWDIR, C_UFRIC, C_Z0M, C_Z0B, C_CHRNCK, C_AIRD, C_WSTAR, C_RNFAC, C_RAORW,
   C_XS, C_YS, C_PHIWA, C_MIJ, C_F1DCOS3, C_F1DCOS2, C_F1DSIN2, C_F1D, C_UORBT, C_AORB, C_SIGN, C_TEMP2, C_PTURB, C_AIRDPVISC,
   C_EMEAN, C_F1MEAN, C_EMAXDPT, C_DEPTH, C_SDS, C_SPARE,
-  C_XSN, C_YSN, C_UST, C_SINU, C_COSU, C_XLOGGZ0, C_SQRTGZ0, C_ZINF, NSC  // NSC = 40
+  C_XSN, C_YSN, C_UST, C_SINU, C_COSU, C_XLOGGZ0, C_SQRTGZ0, C_ZINF, C_SINWD, C_COSWD, C_TWSIN, C_TWCOS, NSC  // NSC = 44
 };
 
 // STRESSO's scalar half (stresso.F90:180-229) with TAU_PHI_HF (tau_phi_hf.F90:125-301), one point per lane, in three steps
@@ -24,20 +24,25 @@ enum {
 //   tail : the TAUHF / PHIHF recurrences, TAUW, TAUWDIR, PHIWA
 template <typename T>
 __device__ void stresso_head_pt(const DevTab<T>& tb, T* c) {
-  const T AIRD = c[C_AIRD], WDWAVE = c[C_WDWAVE], UFRIC = c[C_UFRIC], Z0M = c[C_Z0M];
+  const T AIRD = c[C_AIRD], UFRIC = c[C_UFRIC], Z0M = c[C_Z0M];
   const int MIJ = (int)c[C_MIJ];
   const T XSTRESS = c[C_XS] / m_max(AIRD, T(1));
   const T YSTRESS = c[C_YS] / m_max(AIRD, T(1));
-  T USDIRP, UST;
-  if (tb.TAUWSHELTER == T(0)) { USDIRP = WDWAVE; UST = UFRIC; }
+  // USDIRP = ATAN2(TAUPX,TAUPY) is only ever used as SIN/COS(USDIRP) = TAUPX/|TAUP|, TAUPY/|TAUP|; UST = |TAUP|**0.5
+  const T sinwd = c[C_SINWD], coswd = c[C_COSWD];
+  T UST, SINU, COSU;
+  if (tb.TAUWSHELTER == T(0)) { UST = UFRIC; SINU = sinwd; COSU = coswd; }
   else {
-    const T TAUPX = UFRIC * UFRIC * m_sin(WDWAVE) - tb.TAUWSHELTER * XSTRESS;
-    const T TAUPY = UFRIC * UFRIC * m_cos(WDWAVE) - tb.TAUWSHELTER * YSTRESS;
-    USDIRP = m_atan2(TAUPX, TAUPY);
-    UST = m_pow(TAUPX * TAUPX + TAUPY * TAUPY, T(0.25));
+    const T TAUPX = UFRIC * UFRIC * sinwd - tb.TAUWSHELTER * XSTRESS;
+    const T TAUPY = UFRIC * UFRIC * coswd - tb.TAUWSHELTER * YSTRESS;
+    const T h = m_sqrt(TAUPX * TAUPX + TAUPY * TAUPY);
+    const bool zero = !(h > T(0));
+    SINU = zero ? T(0) : TAUPX / h;
+    COSU = zero ? T(1) : TAUPY / h;
+    UST = m_sqrt(h);
   }
   c[C_XSN] = XSTRESS; c[C_YSN] = YSTRESS; c[C_UST] = UST;
-  c[C_SINU] = m_sin(USDIRP); c[C_COSU] = m_cos(USDIRP);
+  c[C_SINU] = SINU; c[C_COSU] = COSU;
   const T X0G = tb.X0TAUHF * tb.G;
   const T OMEGACC = m_max(tb.ZPIFR[MIJ - 1], X0G / UST);
   const T SQRTZ0OG = m_sqrt(Z0M * tb.GM1);
@@ -119,13 +124,19 @@ __device__ void stresso_tail_pt(const DevTab<T>& tb, T* c, T nY, T nCM1, T nLC, 
   }
   const T XSTRESS = c[C_XSN] + TAUHF * c[C_SINU];
   const T YSTRESS = c[C_YSN] + TAUHF * c[C_COSU];
-  T TAUW = m_max(m_sqrt(XSTRESS * XSTRESS + YSTRESS * YSTRESS), T(0));
-  const T TAUWDIR = m_atan2(XSTRESS, YSTRESS);
+  const T r = m_sqrt(XSTRESS * XSTRESS + YSTRESS * YSTRESS);
+  T TAUW = m_max(r, T(0));
   if (!tb.LLGCBZ0) TAUW = m_min(TAUW, UFRIC * UFRIC * (T(1) / (T(1) + tb.EPS1)));
   if (store) {
     c[C_TAUW] = TAUW;
-    c[C_TAUWDIR] = TAUWDIR;
-    if (LLPHIWA) c[C_PHIWA] = c[C_PHIWA] + PHIHF;
+    // TAUWDIR = ATAN2(XSTRESS,YSTRESS): the next TAUT_Z0 needs COS(WDWAVE-TAUWDIR) only, the angle itself is an output
+    const bool zero = !(r > T(0));
+    c[C_TWSIN] = zero ? T(0) : XSTRESS / r;
+    c[C_TWCOS] = zero ? T(1) : YSTRESS / r;
+    if (LLPHIWA) {
+      c[C_TAUWDIR] = m_atan2(XSTRESS, YSTRESS);
+      c[C_PHIWA] = c[C_PHIWA] + PHIHF;
+    }
   }
 }
 // the three steps on the stage's wave: lanes < WPB own a point, lanes < WPB*JTOT a node
@@ -205,7 +216,7 @@ __device__ __forceinline__ void lane_put(T& r, int lane, int m, T v) { r = (lane
 // accumulator apl = SUM_M RHOWG_DFIM(M)*(FLD*F-SPOS) of the negative wind input (stresso.F90:160-168).
 template <typename T, int NGST, bool LLSNEG, bool NORMA>
 __device__ void sinput_ard2(const DevTab<T>& tb, const T* sF, T* sFLD, const Lane<T>& L, T rWAVNUM, T rCINV, T rXK2CG, T WDWAVE,
-                            T UFRIC, T Z0M, T coswdif, T sinwdif2, T RAORW, T RNFAC, T SIG_N, T TEMP2, T PTURB, T AIRD_PVISC,
+                            T UFRIC, T Z0M, T coswdif, T sinwdif2, T RAORW, T RNFAC, T SIG_N, T TEMP2, T PTURB, T AIRD_PVISC, T sinwd, T coswd,
                             unsigned long long& xmask, T& rX, T& rY, T& rS, T& apl, T& wsae, T& wsaf, T& wslast) {
   const T AVG_GST = T(1) / T(NGST);
   const T CONST1 = tb.BETAMAXOXKAPPA2;
@@ -229,8 +240,8 @@ __device__ void sinput_ard2(const DevTab<T>& tb, const T* sF, T* sFLD, const Lan
     for (int ig = 0; ig < NGST; ig++) {
       XSTRESS[ig] = T(0); YSTRESS[ig] = T(0);
       const T USG2 = USTP[ig] * USTP[ig];
-      TAUX[ig] = USG2 * m_sin(WDWAVE);
-      TAUY[ig] = USG2 * m_cos(WDWAVE);
+      TAUX[ig] = USG2 * sinwd;
+      TAUY[ig] = USG2 * coswd;
     }
     ROGOROAIR = tb.G / RAORW;
   }
@@ -658,6 +669,8 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   if (wave == 0 && L.lane < WPB) {
     T* q = sSC + L.lane * NSC;
     T UFRIC = q[C_UFRIC], Z0M = q[C_Z0M], Z0B = q[C_Z0B], CHRNCK = q[C_CHRNCK];
+    q[C_SINWD] = m_sin(q[C_WDWAVE]); q[C_COSWD] = m_cos(q[C_WDWAVE]);  // once per point, for every later use
+    if (SKIP & 2) { q[C_TWSIN] = m_sin(q[C_TAUWDIR]); q[C_TWCOS] = m_cos(q[C_TAUWDIR]); }  // ablation runs only
     if (!(SKIP & 16)) taut_z0_a(tb, 0, q[C_WSWAVE], q[C_WDWAVE], q[C_TAUW], q[C_TAUWDIR], UFRIC, Z0M, Z0B, CHRNCK);
     q[C_UFRIC] = UFRIC; q[C_Z0M] = Z0M; q[C_Z0B] = Z0B; q[C_CHRNCK] = CHRNCK;
     T RNFAC = T(1);
@@ -704,7 +717,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   }
   __syncthreads();  // stage 1 results
   T UFRIC = c[C_UFRIC], Z0M = c[C_Z0M];
-  const T RNFAC = c[C_RNFAC];
+  const T RNFAC = c[C_RNFAC], sinwd = c[C_SINWD], coswd = c[C_COSWD];
 
   // quantities of F(:,MIJ) TAU_PHI_HF integrates (tau_phi_hf.F90:170-196)
   auto hf_integrals = [&](int MIJ) {
@@ -747,7 +760,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   unsigned long long xmask = 0ull;
   if (!(SKIP & 1))
     sinput_ard2<T, 1, false, NORMA>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, WDWAVE, UFRIC, Z0M, coswdif, sinwdif2, RAORW, RNFAC, T(0),
-                                    T(0), T(0), T(0), xmask, rX, rY, rS, apl, wsae, wsaf, wslast);
+                                    T(0), T(0), T(0), sinwd, coswd, xmask, rX, rY, rS, apl, wsae, wsaf, wslast);
   else { rX = rY = rS = apl = wsae = wsaf = wslast = T(0); }
   femeanws_finish(tb, L, wsae, wsaf, wslast, FMEANWS, EMW);
   MIJ = frcutindex(FMEANWS, UFRIC, rRH);
@@ -766,11 +779,13 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   if (wave == (1 % WPB) && L.lane < WPB) {
     T* q = sSC + L.lane * NSC;
     T UF = q[C_UFRIC], Z0 = q[C_Z0M], Z0Bv = q[C_Z0B], CH = q[C_CHRNCK];
-    if (!(SKIP & 16)) taut_z0_a(tb, 1, q[C_WSWAVE], q[C_WDWAVE], q[C_TAUW], q[C_TAUWDIR], UF, Z0, Z0Bv, CH);
+    if (!(SKIP & 16)) taut_z0_c(tb, 1, q[C_WSWAVE], q[C_COSWD] * q[C_TWCOS] + q[C_SINWD] * q[C_TWSIN], q[C_TAUW], UF, Z0, Z0Bv, CH);
     q[C_UFRIC] = UF; q[C_Z0M] = Z0; q[C_Z0B] = Z0Bv; q[C_CHRNCK] = CH;
-    q[C_SIGN] = wsigstar(tb, q[C_WSWAVE], UF, Z0, q[C_WSTAR]);
-    swell_setup_pt(tb, q);
-    q[C_SDS] = sdiwbk_pt(tb, q[C_EMAXDPT], q[C_EMEAN], q[C_F1MEAN], q[C_DEPTH]);
+    if (!(SKIP & 64)) {
+      q[C_SIGN] = wsigstar(tb, q[C_WSWAVE], UF, Z0, q[C_WSTAR]);
+      swell_setup_pt(tb, q);
+      q[C_SDS] = sdiwbk_pt(tb, q[C_EMAXDPT], q[C_EMEAN], q[C_F1MEAN], q[C_DEPTH]);
+    } else { q[C_SIGN] = T(0.1); q[C_TEMP2] = T(0); q[C_PTURB] = T(0.5); q[C_AIRDPVISC] = T(0); q[C_SDS] = T(0); }
   }
   // SDISSIP needs F only (and the new UFRIC when SSDSC5 /= 0): it runs while the scalar stage is being evaluated
   auto dissipation = [&](T UF) {
@@ -792,7 +807,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   // ---- second SINFLX call: FLD, XLLWS, MIJ, wave stress and the PHIWA integrals
   if (!(SKIP & 1))
     sinput_ard2<T, 2, true, NORMA>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, WDWAVE, UFRIC, Z0M, coswdif, sinwdif2, RAORW, RNFAC,
-                                   c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], xmask, rX, rY, rS, apl, wsae, wsaf, wslast);
+                                   c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], sinwd, coswd, xmask, rX, rY, rS, apl, wsae, wsaf, wslast);
   else {
     rX = rY = rS = apl = wsae = wsaf = wslast = T(0);
   }
@@ -845,8 +860,8 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
       USTAR = m_max(m_sqrt(CD_ICE) * U10P, tb.EPSUS);
     }
     const T TAU = AIRD * m_max(USTAR * USTAR, tb.EPSUS);
-    TAUXD = TAU * m_sin(WDWAVE);
-    TAUYD = TAU * m_cos(WDWAVE);
+    TAUXD = TAU * sinwd;
+    TAUYD = TAU * coswd;
     TAUOCXD = TAUXD - OOVAL * XSTRESS;
     TAUOCYD = TAUYD - OOVAL * YSTRESS;
     const T TAUO = m_sqrt(TAUOCXD * TAUOCXD + TAUOCYD * TAUOCYD);
@@ -895,8 +910,8 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
     USTOKES = usum(a * tb.SINTH[L.k]);
     VSTOKES = usum(a * tb.COSTH[L.k]);
     if (tb.LICERUN && tb.LWAMRSETCI && CICOVER > tb.CITHRSH) {
-      USTOKES = T(0.016) * WSWAVE * m_sin(WDWAVE) * (T(1) - CICOVER);
-      VSTOKES = T(0.016) * WSWAVE * m_cos(WDWAVE) * (T(1) - CICOVER);
+      USTOKES = T(0.016) * WSWAVE * sinwd * (T(1) - CICOVER);
+      VSTOKES = T(0.016) * WSWAVE * coswd * (T(1) - CICOVER);
     }
     USTOKES = m_min(m_max(USTOKES, T(-1.5)), T(1.5));
     VSTOKES = m_min(m_max(VSTOKES, T(-1.5)), T(1.5));

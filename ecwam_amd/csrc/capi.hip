@@ -264,6 +264,8 @@ int ecwam_hip_propags2_otf(ecwam_hip_ctx* c, const void* f1, void* f3, int n, in
   if (f1 == f3) return fail("ecwam_hip_propags2_otf: F1 and F3 must not alias");
   hipStream_t s = (hipStream_t)stream;
   const int N = (c->NANG << 16) | (c->NFRE << 8) | c->NFRE_RED;
+  copy_rest = copy_rest ? 1 : 0;
+  { const char* e_ = getenv("ECWAM_HIP_OTF_WALK"); if (e_ && atoi(e_) == 0) copy_rest |= 2; }  // diagnostics: plain grid-stride tile walk
   DISPATCH(launch_propags2_otf<float>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, s),
            launch_propags2_otf<double>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, s));
   HIPCHK(hipGetLastError());

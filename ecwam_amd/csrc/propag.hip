@@ -337,7 +337,15 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
     ctu_dirfac(tab, k, DELTH0, T(1), a, b);  // TANPH applied per point below: TANPH*SP is formed as in k_ctuw
     sK[2 * k] = a; sK[2 * k + 1] = b;
   }
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // XCD-aware tile walk: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own 4 MiB L2.  XCD x
+  // walks the contiguous tile range [x*tpx, (x+1)*tpx) so that a spectrum fetched as somebody's neighbour is still in that
+  // L2 when its own tile (or the next neighbour) comes up; gridDim.x is a multiple of 8 (launch_propags2_otf).
+  const bool xwalk = copy_rest < 2;  // copy_rest & 2: plain grid-stride walk (diagnostics)
+  const int tpx = xwalk ? (ntiles + 7) / 8 : ntiles;
+  const int xcd = xwalk ? (blockIdx.x & 7) : 0;
+  const int tend = min((xcd + 1) * tpx, ntiles);
+  const int tstep = xwalk ? (gridDim.x >> 3) : gridDim.x;
+  for (int tile = xcd * tpx + (xwalk ? (blockIdx.x >> 3) : blockIdx.x); tile < tend; tile += tstep) {
     const int p0 = kijs + tile * OTF_TP;
     const int np = min(OTF_TP, kijl - p0);
     __syncthreads();  // previous tile fully consumed
@@ -376,7 +384,7 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
       const int el = k * NFRE + m;
       typedef VecIO<T, VW> IO;
       if (m < m0 || m >= m1) {
-        if (copy_rest) {
+        if (copy_rest & 1) {
           T v[VW];
           IO::ld(f1 + own + el, v);
           IO::st(f3 + own + el, v);
@@ -520,7 +528,8 @@ void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, 
   if (n <= 0) return;
   const int ntiles = (n + OTF_TP - 1) / OTF_TP;
   const size_t shmem = OTF_TP * (sizeof(CtuPoint<T>) + 16 * sizeof(int)) + ((size_t)OTF_TP * 5 * NFRE + 2 * NANG) * sizeof(T) + 16;
-  const int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
+  int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
+  grid = (grid + 7) & ~7;  // whole rounds of the 8 XCDs
   constexpr int W = VecOf<T>::W;
   const bool aligned = ((uintptr_t)f1 % 16 == 0) && ((uintptr_t)f3 % 16 == 0);
 #define OTF_ARGS                                                                                                              \

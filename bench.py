@@ -153,6 +153,16 @@ def main() -> None:
             "implsch": {"ms": t_impl, "alg_bytes": b_impl * m.n, "gbs": b_impl * m.n / t_impl / 1e6},
         }
         dom = max(kern, key=lambda k: kern[k]["ms"])
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh; FETCH_SIZE / WRITE_SIZE in
+        # KiB, FETCH doubled for the 16 B/lane streams of PROPAGS2 as MI355X_MICROARCH.md prescribes for gfx950).  Only
+        # valid for the workload they were taken on: the default O320 / 36x36 / sp / on-the-fly-weights run on one GPU.
+        traffic = None
+        tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic_pmc.json")
+        if world == 1 and ng == 320 and a.prec == "sp" and a.nang == 36 and a.nfre == 36 and a.weights == "otf" and os.path.exists(tf):
+            with open(tf) as fh:
+                pm = json.load(fh).get(dom, {})
+            if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+                traffic = 1024.0 * ((2.0 if dom == "propags2" else 1.0) * pm["FETCH_SIZE"] + pm["WRITE_SIZE"])
         out = {
             "metric": "grid-point spectral steps/sec (whole node) at O320, 36dir x 36freq",
             "value": grid.nsea * a.steps / el, "unit": "grid-point spectral steps/s", "n_gpus": world, "steps": a.steps,
@@ -163,7 +173,7 @@ def main() -> None:
                                    f"IDELT=IDELPRO={dt} s, flag set A (IPHYS=1, ISNONLIN=0, LLGCBZ0=F, LLNORMAGAM=F)",
                        "points_per_gpu": m.n, "halo_points": m.dom.nh, "parallelism": f"sea-point block x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": None},
+                         "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic},
             "kernels": kern,
             "finite": finite,
         }

@@ -1,15 +1,16 @@
 #!/bin/bash
-# HBM traffic of the bench kernels (MI355X_MICROARCH.md, "HBM traffic with rocprofv3"): separate --pmc passes on
-# `bench.py --steps 3 --warmup 1`, per-launch averages, gfx950 FETCH_SIZE correction applied in the summary.
+# HBM traffic of the bench kernels (MI355X_MICROARCH.md "HBM traffic"): FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes
+# (3 + 2 TCC counters do not fit one pass), per-launch averages in bytes; FETCH_SIZE doubled for the 16 B/lane streams (gfx950).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/traf_*
-timeout 300 rocprofv3 --kernel-include-regex 'implsch|propags2' --pmc FETCH_SIZE WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/traf_a -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-timeout 300 rocprofv3 --kernel-include-regex 'implsch|propags2' --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d gpurun_out/traf_b -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
+  d=gpurun_out/traf_$(echo $c | cut -c1-5)
+  timeout 150 rocprofv3 --kernel-include-regex "implsch|propags2" --pmc $c --kernel-trace --output-format csv -d $d -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || echo "pass $c failed"
+done
 python3 - <<'PY'
 import csv,glob,collections,json
 out=collections.defaultdict(dict)
-for d in ("a","b"):
-    f=glob.glob(f"gpurun_out/traf_{d}/*/*counter_collection.csv")[0]
+for f in glob.glob("gpurun_out/traf_*/*/*counter_collection.csv"):
     agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
         n=r["Kernel_Name"]

@@ -25,7 +25,7 @@ struct DevTab {
   T TAUOCMIN, TAUOCMAX, PHIEPSMIN, PHIEPSMAX, WSEMEAN_MIN, CIRC, R;
   T FRATIO, WETAIL, FRTAIL, WP1TAIL, FRIC, DELTH, FLOGSPRDM1;
   T XKAPPA, XNLEV, RNU, RNUM, BETAMAXOXKAPPA2, BMAXOKAP, GAMNCONST, ZALP, ALPHA, ALPHAMIN, ALPHAMAX, CHNKMIN_U;
-  T TAUWSHELTER, DTHRN_A, DTHRN_U, TAILFACTOR, TAILFACTOR_PM, ANG_GC_A, ANG_GC_B, ANG_GC_C, RN1_RN;
+  T TAUWSHELTER, DTHRN_A, DTHRN_U, TAILFACTOR, TAILFACTOR_PM, ANG_GC_A, ANG_GC_B, ANG_GC_C, RN1_RN, ALPHAPMAX;
   T SWELLF, SWELLF2, SWELLF3, SWELLF4, SWELLF5, SWELLF6, SWELLF7, SWELLF7M1, Z0RAT, Z0TUBMAX, ABMIN, ABMAX;
   T SDSBR, SSDSC2, SSDSC3, SSDSC4, SSDSC5, SSDSC6, MICHE;
   T EGRCRV, AFCRV, BFCRV;

@@ -13,8 +13,184 @@ enum {
   C_WSWAVE = 0, C_WDWAVE, C_TAUW, C_TAUWDIR, C_UFRIC, C_Z0M, C_Z0B, C_CHRNCK, C_AIRD, C_WSTAR, C_RNFAC, C_RAORW,
   C_XS, C_YS, C_PHIWA, C_MIJ, C_F1DCOS3, C_F1DCOS2, C_F1DSIN2, C_F1D, C_UORBT, C_AORB, C_SIGN, C_TEMP2, C_PTURB, C_AIRDPVISC,
   C_EMEAN, C_F1MEAN, C_EMAXDPT, C_DEPTH, C_SDS, C_SPARE,
-  C_XSN, C_YSN, C_UST, C_SINU, C_COSU, C_XLOGGZ0, C_SQRTGZ0, C_ZINF, C_SINWD, C_COSWD, C_TWSIN, C_TWCOS, NSC  // NSC = 44
+  C_XSN, C_YSN, C_UST, C_SINU, C_COSU, C_XLOGGZ0, C_SQRTGZ0, C_ZINF, C_SINWD, C_COSWD, C_TWSIN, C_TWCOS, C_ZSUP, C_HALP, NSC  // NSC = 46
 };
+
+// ---- LLGCBZ0 = T (gravity-capillary roughness model, flag set B) -------------------------------------------------------
+// ns_gc.F90:47-49
+template <typename T>
+__device__ __forceinline__ int ns_gc_d(const DevTab<T>& tb, T USTAR) {
+  const T XKS = tb.SQRTGOSURFT / (T(1.48) + T(2.05) * USTAR);
+  const int n = (int)(m_log(m_max(XKS * tb.XKM_GC[1], T(1))) * tb.XLOGKRATIOM1_GC) + 1;
+  return n < tb.NWAV_GC - 1 ? n : tb.NWAV_GC - 1;
+}
+// stress_gc.F90:80-130: the sum over the gravity-capillary wavenumbers NS..NWAV_GC runs across the lanes of the wave
+// (wave-uniform arguments and result)
+template <typename T>
+__device__ T stress_gc_w(const DevTab<T>& tb, int lane, T ANG_GC, T USTAR, T Z0, T Z0MIN, T HALP, T RNFAC) {
+  const T XLAMA = T(0.25), XLAMB = T(4.0);
+  const int NS = __builtin_amdgcn_readfirstlane(ns_gc_d(tb, USTAR));
+  const T t = USTAR * (Z0MIN / Z0);
+  const T TAUWCG_MIN = t * t;
+  const T XLAMBDA = T(1) + XLAMA * m_tanh(XLAMB * m_pow4(USTAR));
+  const T LOGXL = m_log(XLAMBDA);
+  const T hc = HALP * tb.C2OSQRTVG_GC[NS];
+  const T ZABHRC = ANG_GC * tb.BETAMAXOXKAPPA2 * hc;
+  const T CONST = tb.LLNORMAGAM ? RNFAC * tb.BMAXOKAP * hc / m_max(USTAR, tb.EPSUS) : T(0);
+  T acc = T(0);
+  for (int I = NS + lane; I <= tb.NWAV_GC; I += 64) {
+    const T X = USTAR * tb.CM_GC[I];
+    const T XLOG = m_log(tb.XK_GC[I] * Z0) + tb.XKAPPA / (X + tb.ZALP);
+    const T ZLOG = m_min(XLOG - LOGXL, T(0));
+    const T ZLOG2X = ZLOG * ZLOG * X;
+    const T GAM_W = ZLOG2X * ZLOG2X * m_exp(XLOG) * tb.OM3GMKM_GC[I];
+    const T ZN = CONST * tb.XKMSQRTVGOC2_GC[I] * GAM_W;
+    const T GAMNORMA = (T(1) + tb.RN1_RN * ZN) / (T(1) + ZN);
+    const T wt = (I == NS) ? tb.DELKCC_GC_NS[NS] * tb.OMXKM3_GC[NS] : tb.DELKCC_OMXKM3_GC[I];
+    acc = acc + (GAM_W * wt) * GAMNORMA;
+  }
+  const T TAUWCG = usum(acc);
+  return m_max(ZABHRC * TAUWCG, TAUWCG_MIN);
+}
+// cdm.func.h
+template <typename T>
+__device__ __forceinline__ T cdm_d(T U) {
+  return m_max(m_min(T(0.0006) + T(0.00008) * U, T(0.001) + T(0.0018) * m_exp(-T(0.05) * (U - T(33.)))), T(0.001));
+}
+// taut_z0.F90:148-287 (LLGCBZ0 = T): damped fixed point on the total stress with STRESS_GC, then the Newton refinement.
+// Wave-uniform; only STRESS_GC uses the lanes.
+template <typename T>
+__device__ void taut_z0_b_w(const DevTab<T>& tb, int lane, int IUSFG, T HALP, T UTOP, T COSDIFF, T TAUW, T RNFAC, T& USTAR, T& Z0,
+                            T& Z0B, T& CHRNCK) {
+  const int NITER = 18;
+  const T PMAX = T(0.99), Z0MIN = T(0.000001);
+  const T US2TOTAUW = T(1) + tb.EPS1;
+  const T RNUKAPPAM1 = (T(0.04) * tb.RNU) / tb.XKAPPA;
+  const T PCE_GC = T(0.001) * IUSFG + (1 - IUSFG) * T(0.005);
+  const T TAUWACT = m_max(TAUW * COSDIFF, tb.EPSMIN);
+  const bool LLCOSDIFF = (COSDIFF > T(0.9));
+  T ALPHAOG = T(0);
+  if (tb.LLCAPCHNK) ALPHAOG = chnkmin(tb, UTOP) * tb.GM1;
+  const T USMAX = m_max(-T(0.21339) + T(0.093698) * UTOP - T(0.0020944) * UTOP * UTOP + T(5.5091E-5) * UTOP * UTOP * UTOP, T(0.03));
+  const T TAUWEFF = m_min(TAUWACT * US2TOTAUW, USMAX * USMAX);
+  T X, CDFG;
+  if (IUSFG == 0) {
+    const T ALPHAGM1 = tb.ALPHA * tb.GM1;
+    if (UTOP < T(1)) CDFG = T(0.002);
+    else if (LLCOSDIFF) {
+      const T um = m_max(USTAR, tb.EPSUS);
+      X = m_min(TAUWACT / (um * um), PMAX);
+      T ZCHAR = m_min(ALPHAGM1 * USTAR * USTAR / m_sqrt(T(1) - X), T(0.05) * m_exp(-T(0.05) * (UTOP - T(35.))));
+      ZCHAR = m_min(ZCHAR, tb.ALPHAMAX);
+      CDFG = tb.ACDLIN + tb.BCDLIN * m_sqrt(ZCHAR) * UTOP;
+    } else CDFG = cdm_d(UTOP);
+    USTAR = UTOP * m_sqrt(CDFG);
+  }
+  const T W1 = T(0.85) - T(0.05) * (m_tanh(T(10) * (UTOP - T(5))) + T(1));
+  const T XKUTOP = tb.XKAPPA * UTOP;
+  T USTOLD = USTAR;
+  T TAUOLD = USTOLD * USTOLD;
+  T TAUUNR = T(0);
+  int ITER;
+  for (ITER = 1; ITER <= NITER; ITER++) {
+    Z0 = m_max(tb.XNLEV / (m_exp(m_min(XKUTOP / USTOLD, T(50))) - T(1)), Z0MIN);
+    const T TAUV = RNUKAPPAM1 * USTOLD / Z0;
+    const T ANG_GC = tb.ANG_GC_A + tb.ANG_GC_B * m_tanh(tb.ANG_GC_C * TAUOLD);
+    TAUUNR = stress_gc_w(tb, lane, ANG_GC, USTAR, Z0, Z0MIN, HALP, RNFAC);
+    const T TAUNEW = TAUWEFF + TAUV + TAUUNR;
+    const T USTNEW = m_sqrt(TAUNEW);
+    USTAR = W1 * USTOLD + (T(1) - W1) * USTNEW;
+    const T DEL = USTAR - USTOLD;
+    if (m_abs(DEL) < PCE_GC * USTAR) break;
+    TAUOLD = USTAR * USTAR;
+    USTOLD = USTAR;
+  }
+  X = TAUWEFF / TAUOLD;
+  if (ITER > NITER && X >= PMAX) {
+    CDFG = cdm_d(UTOP);
+    USTAR = UTOP * m_sqrt(CDFG);
+    const T Z0MINRST = USTAR * USTAR * tb.ALPHA * tb.GM1;
+    Z0 = m_max(tb.XNLEV / (m_exp(XKUTOP / USTAR) - T(1)), Z0MINRST);
+    Z0B = Z0MINRST;
+  } else {
+    Z0 = m_max(tb.XNLEV / (m_exp(XKUTOP / USTAR) - T(1)), Z0MIN);
+    Z0B = Z0 * m_sqrt(TAUUNR / TAUOLD);
+  }
+  if (X < PMAX) {
+    const T USNRF = USTAR, Z0NRF = Z0, Z0BNRF = Z0B;
+    USTOLD = USTAR;
+    TAUOLD = m_max(USTOLD * USTOLD, TAUWEFF);
+    const T ALPOG = m_max(m_min(Z0B / TAUOLD, tb.ALPHAMAX), ALPHAOG);
+    for (ITER = 1; ITER <= NITER; ITER++) {
+      X = m_min(TAUWEFF / TAUOLD, PMAX);
+      const T USTM1 = T(1) / m_max(USTOLD, tb.EPSUS);
+      const T Z0VIS = tb.RNUM * USTM1;
+      const T HZ0VISO1MX = T(0.5) * Z0VIS / (T(1) - X);
+      Z0B = ALPOG * TAUOLD;
+      Z0 = HZ0VISO1MX + m_sqrt(HZ0VISO1MX * HZ0VISO1MX + Z0B * Z0B / (T(1) - X));
+      const T XOLOGZ0 = T(1) / m_log(tb.XNLEV / Z0 + T(1));
+      const T Fv = USTOLD - XKUTOP * XOLOGZ0;
+      const T ZZ = T(2) * USTM1 * (T(3) * Z0B * Z0B + T(0.5) * Z0VIS * Z0 - Z0 * Z0) / (T(2) * Z0 * Z0 * (T(1) - X) - Z0VIS * Z0);
+      const T DELF = T(1) - XKUTOP * XOLOGZ0 * XOLOGZ0 * ZZ;
+      if (DELF != T(0)) USTAR = USTOLD - Fv / DELF;
+      const T TAUNEW = m_max(USTAR * USTAR, TAUWEFF);
+      USTAR = m_sqrt(TAUNEW);
+      const T DEL = TAUNEW - TAUOLD;
+      if (m_abs(DEL) < PCE_GC * TAUOLD) break;
+      TAUOLD = TAUNEW;
+      USTOLD = USTAR;
+    }
+    if (ITER > NITER) {
+      USTAR = USNRF; Z0 = Z0NRF; Z0B = Z0BNRF;
+      const T USTM1 = T(1) / m_max(USTAR, tb.EPSUS);
+      const T Z0VIS = tb.RNUM * USTM1;
+      CHRNCK = m_max(tb.G * (Z0 - Z0VIS) * USTM1 * USTM1, tb.ALPHAMIN);
+    } else {
+      const T um = m_max(USTAR, tb.EPSUS);
+      CHRNCK = m_max(tb.G * (Z0B / m_sqrt(T(1) - X)) / (um * um), tb.ALPHAMIN);
+    }
+  } else {
+    const T USTM1 = T(1) / m_max(USTAR, tb.EPSUS);
+    const T Z0VIS = tb.RNUM * USTM1;
+    CHRNCK = m_max(tb.G * (Z0 - Z0VIS) * USTM1 * USTM1, tb.ALPHAMIN);
+  }
+}
+// halphap.F90:68-112 with meansqs_lf.F90:80-100 and femean.F90:84-121: Phillips parameter of the wind-sea half plane.
+// Column sums (lane = M, K sequential as in the reference) of F*WD and MAX(F*WD,EPSMIN).
+template <typename T>
+__device__ T halphap_w(const DevTab<T>& tb, const T* sF, const Lane<T>& L, T rWAVNUM, T coswdif) {
+  const int NFRE = L.NFRE;
+  const unsigned long long wd = __builtin_amdgcn_ballot_w64(L.act && !__builtin_signbit(coswdif));  // WD = 0.5+0.5*SIGN(1,COSWDIF)
+  T t1 = T(0), t2 = T(0);
+  if (L.actm) {
+    const T* p = sF + L.lane * L.NAP;
+    for (int kk = 0; kk < L.NANG; kk++) {
+      const T v = ((wd >> kk) & 1ull) ? p[kk] : T(0);
+      t1 = t1 + v;
+      t2 = (kk == 0) ? m_max(v, tb.EPSMIN) : t2 + m_max(v, tb.EPSMIN);
+    }
+  }
+  T XMSS, EM, FM, d0;
+  {
+    T w1 = T(0), w2 = T(0), w3 = T(0);
+    if (L.actm) { w2 = tb.DFIM[L.lane]; w1 = w2 * rWAVNUM * rWAVNUM; w3 = tb.DFIMOFR[L.lane]; }
+    usum4(w1 * t1, w2 * t2, w3 * t2, T(0), XMSS, EM, FM, d0);
+  }
+  const T tl = lane_get(t2, NFRE - 1);
+  EM = EM + tb.WETAIL * tb.FR[NFRE - 1] * tb.DELTH * tl;
+  FM = FM + tb.FRTAIL * tb.DELTH * tl;
+  FM = EM / FM;
+  FM = m_max(FM, tb.FR[0]);
+  const T fl = (L.act && ((wd >> L.lane) & 1ull)) ? sF[(NFRE - 1) * L.NAP + L.k] * tb.DELTH : T(0);
+  const T F1D = usum(fl);
+  const T ATAIL = tb.ZPI4GM2 * tb.FR5[NFRE - 1] * F1D;
+  T ALPHAP;
+  if (EM > T(0) && FM < tb.FR[NFRE - 3]) {
+    ALPHAP = XMSS / (m_log(tb.FR[NFRE - 1]) - m_log(FM));
+    if (ALPHAP > tb.ALPHAPMAX) ALPHAP = ATAIL;
+  } else ALPHAP = ATAIL;
+  return T(0.5) * m_min(ALPHAP, tb.ALPHAPMAX);
+}
 
 // STRESSO's scalar half (stresso.F90:180-229) with TAU_PHI_HF (tau_phi_hf.F90:125-301), one point per lane, in three steps
 // so that the 19 quadrature nodes of every point of the block are evaluated side by side (lane = point*JTOT + node) and
@@ -49,18 +225,23 @@ __device__ void stresso_head_pt(const DevTab<T>& tb, T* c) {
   c[C_XLOGGZ0] = m_log(tb.G * Z0M);
   c[C_SQRTGZ0] = T(1) / SQRTZ0OG;
   c[C_ZINF] = m_log(OMEGACC * SQRTZ0OG);
+  // upper limit of the TAUHF quadrature: 0, or the gravity-capillary transition OMEGA_GC(NS_GC(UFRIC)) (tau_phi_hf.F90:127,
+  // omegagc.F90:51-55) when LLGCBZ0
+  T ZSUP = T(0);
+  if (tb.LLGCBZ0) ZSUP = m_min(m_log(tb.OMEGA_GC[ns_gc_d(tb, UFRIC)] * SQRTZ0OG), T(0));
+  c[C_ZSUP] = ZSUP;
 }
 template <typename T>
-__device__ __forceinline__ void stresso_node(const DevTab<T>& tb, const T* c, int J, T& nY, T& nCM1, T& nLC) {
+__device__ __forceinline__ void stresso_node(const DevTab<T>& tb, const T* c, int J, T ZSUP, T& nY, T& nCM1, T& nLC) {
   const T ZINF = c[C_ZINF];
-  const T DELZ = m_max((T(0) - ZINF) / T(JTOT - 1), T(0));
+  const T DELZ = m_max((ZSUP - ZINF) / T(JTOT - 1), T(0));
   const T Y = m_exp(ZINF + T(J) * DELZ);
   const T CM1 = (Y * c[C_SQRTGZ0]) * tb.GM1;
   nY = Y; nCM1 = CM1; nLC = c[C_XLOGGZ0] + T(2) * m_log(CM1);
 }
 template <typename T>
 // nY/nCM1/nLC: node values held by lane nbase+J (pulled through the LDS crossbar; every lane of the wave runs this)
-__device__ void stresso_tail_pt(const DevTab<T>& tb, T* c, T nY, T nCM1, T nLC, int nbase, bool store, bool LLPHIWA) {
+__device__ void stresso_tail_pt(const DevTab<T>& tb, T* c, T nY, T nCM1, T nLC, T pY, T pCM1, T pLC, int nbase, bool store, bool LLPHIWA) {
   const T AIRD = c[C_AIRD], UFRIC = c[C_UFRIC], Z0M = c[C_Z0M], RNFAC = c[C_RNFAC];
   const T F1DCOS3 = c[C_F1DCOS3], F1DCOS2 = c[C_F1DCOS2];
   const int MIJ = (int)c[C_MIJ];
@@ -80,7 +261,7 @@ __device__ void stresso_tail_pt(const DevTab<T>& tb, T* c, T nY, T nCM1, T nLC, 
     CONST2 = CONFG * c[C_F1D];
   }
   T TAUL = UST * UST;
-  const T DELZ = m_max((T(0) - ZINF) / T(JTOT - 1), T(0));
+  T DELZ = m_max((c[C_ZSUP] - ZINF) / T(JTOT - 1), T(0));
   T TAUHF = T(0), acc = T(0);
   for (int J = 0; J < JTOT; J++) {
     const T Y = lane_pull(nY, nbase + J), CM1 = lane_pull(nCM1, nbase + J), LC = lane_pull(nLC, nbase + J);
@@ -102,9 +283,10 @@ __device__ void stresso_tail_pt(const DevTab<T>& tb, T* c, T nY, T nCM1, T nLC, 
   T PHIHF = T(0);
   if (LLPHIWA) {
     TAUL = USTPH * USTPH;
+    DELZ = m_max((T(0) - ZINF) / T(JTOT - 1), T(0));  // ZSUP = ZSUPMAX = 0 for the energy flux (tau_phi_hf.F90:246-248)
     const T CONSTPHI = AIRD * tb.ZPI4GM1 * fr5;
     for (int J = 0; J < JTOT; J++) {
-      const T Y = lane_pull(nY, nbase + J), CM1 = lane_pull(nCM1, nbase + J), LC = lane_pull(nLC, nbase + J);
+      const T Y = lane_pull(pY, nbase + J), CM1 = lane_pull(pCM1, nbase + J), LC = lane_pull(pLC, nbase + J);
       const T ZARG = tb.XKAPPA * f_rcp(USTPH * CM1 + tb.ZALP);
       const T ZLOG = m_min(LC + ZARG, T(0));
       const T ZBETA = m_pow4(ZLOG) * f_exp(ZLOG);
@@ -145,13 +327,18 @@ __device__ __forceinline__ void stresso_stage(const DevTab<T>& tb, T* sSC, int l
   static_assert(WPB * JTOT <= 64, "one lane per (point, node)");
   if (lane < WPB) stresso_head_pt(tb, sSC + lane * NSC);
   WSYNC();
-  T nY = T(1), nCM1 = T(1), nLC = T(0);
+  T nY = T(1), nCM1 = T(1), nLC = T(0), pY, pCM1, pLC;
   if (lane < WPB * JTOT) {
     const int pt = lane / JTOT;
-    stresso_node(tb, sSC + pt * NSC, lane - pt * JTOT, nY, nCM1, nLC);
+    stresso_node(tb, sSC + pt * NSC, lane - pt * JTOT, sSC[pt * NSC + C_ZSUP], nY, nCM1, nLC);
+  }
+  pY = nY; pCM1 = nCM1; pLC = nLC;
+  if (tb.LLGCBZ0 && LLPHIWA && lane < WPB * JTOT) {  // the energy-flux quadrature keeps ZSUP = 0: its own node set
+    const int pt = lane / JTOT;
+    stresso_node(tb, sSC + pt * NSC, lane - pt * JTOT, T(0), pY, pCM1, pLC);
   }
   const int pt = lane < WPB ? lane : WPB - 1;  // spare lanes shadow the last point (the pulls need the whole wave)
-  stresso_tail_pt(tb, sSC + pt * NSC, nY, nCM1, nLC, pt * JTOT, lane < WPB, LLPHIWA);
+  stresso_tail_pt(tb, sSC + pt * NSC, nY, nCM1, nLC, pY, pCM1, pLC, pt * JTOT, lane < WPB, LLPHIWA);
 }
 
 // scalar set-up of the swell damping (sinput_ard.F90:213-262) from the orbital integrals c[C_UORBT], c[C_AORB]
@@ -671,7 +858,8 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
     T UFRIC = q[C_UFRIC], Z0M = q[C_Z0M], Z0B = q[C_Z0B], CHRNCK = q[C_CHRNCK];
     q[C_SINWD] = m_sin(q[C_WDWAVE]); q[C_COSWD] = m_cos(q[C_WDWAVE]);  // once per point, for every later use
     if (SKIP & 2) { q[C_TWSIN] = m_sin(q[C_TAUWDIR]); q[C_TWCOS] = m_cos(q[C_TAUWDIR]); }  // ablation runs only
-    if (!(SKIP & 16)) taut_z0_a(tb, 0, q[C_WSWAVE], q[C_WDWAVE], q[C_TAUW], q[C_TAUWDIR], UFRIC, Z0M, Z0B, CHRNCK);
+    if (tb.LLGCBZ0) q[C_TWCOS] = m_cos(q[C_WDWAVE] - q[C_TAUWDIR]);  // COSDIFF of the first TAUT_Z0, which runs per wave below
+    else if (!(SKIP & 16)) taut_z0_a(tb, 0, q[C_WSWAVE], q[C_WDWAVE], q[C_TAUW], q[C_TAUWDIR], UFRIC, Z0M, Z0B, CHRNCK);
     q[C_UFRIC] = UFRIC; q[C_Z0M] = Z0M; q[C_Z0B] = Z0B; q[C_CHRNCK] = CHRNCK;
     T RNFAC = T(1);
     if (tb.LLNORMAGAM && tb.LLCAPCHNK) RNFAC = T(1) + tb.DTHRN_A * (T(1) + m_tanh(q[C_WSWAVE] - tb.DTHRN_U));
@@ -718,6 +906,17 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   __syncthreads();  // stage 1 results
   T UFRIC = c[C_UFRIC], Z0M = c[C_Z0M];
   const T RNFAC = c[C_RNFAC], sinwd = c[C_SINWD], coswd = c[C_COSWD];
+  // LLGCBZ0: HALPHAP (sinflx.F90:130) and the gravity-capillary TAUT_Z0 per wave, STRESS_GC's wavenumber sum across the lanes
+  const bool gcb = tb.LLGCBZ0 != 0;
+  T HALP = T(0);
+  if (gcb) {
+    HALP = halphap_w(tb, sF, L, rWAVNUM, coswdif);
+    T Z0Bv = c[C_Z0B], CH = c[C_CHRNCK];
+    const T cosd = c[C_TWCOS], tauw0 = c[C_TAUW];
+    if (!(SKIP & 16)) taut_z0_b_w(tb, L.lane, 0, HALP, WSWAVE, cosd, tauw0, RNFAC, UFRIC, Z0M, Z0Bv, CH);
+    WSYNC();
+    if (L.lane == 0) { c[C_UFRIC] = UFRIC; c[C_Z0M] = Z0M; c[C_Z0B] = Z0Bv; c[C_CHRNCK] = CH; c[C_HALP] = HALP; }
+  }
 
   // quantities of F(:,MIJ) TAU_PHI_HF integrates (tau_phi_hf.F90:170-196)
   auto hf_integrals = [&](int MIJ) {
@@ -779,11 +978,15 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   if (wave == (1 % WPB) && L.lane < WPB) {
     T* q = sSC + L.lane * NSC;
     T UF = q[C_UFRIC], Z0 = q[C_Z0M], Z0Bv = q[C_Z0B], CH = q[C_CHRNCK];
-    if (!(SKIP & 16)) taut_z0_c(tb, 1, q[C_WSWAVE], q[C_COSWD] * q[C_TWCOS] + q[C_SINWD] * q[C_TWSIN], q[C_TAUW], UF, Z0, Z0Bv, CH);
-    q[C_UFRIC] = UF; q[C_Z0M] = Z0; q[C_Z0B] = Z0Bv; q[C_CHRNCK] = CH;
+    if (!tb.LLGCBZ0) {
+      if (!(SKIP & 16)) taut_z0_c(tb, 1, q[C_WSWAVE], q[C_COSWD] * q[C_TWCOS] + q[C_SINWD] * q[C_TWSIN], q[C_TAUW], UF, Z0, Z0Bv, CH);
+      q[C_UFRIC] = UF; q[C_Z0M] = Z0; q[C_Z0B] = Z0Bv; q[C_CHRNCK] = CH;
+    }
     if (!(SKIP & 64)) {
-      q[C_SIGN] = wsigstar(tb, q[C_WSWAVE], UF, Z0, q[C_WSTAR]);
-      swell_setup_pt(tb, q);
+      if (!tb.LLGCBZ0) {
+        q[C_SIGN] = wsigstar(tb, q[C_WSWAVE], UF, Z0, q[C_WSTAR]);
+        swell_setup_pt(tb, q);
+      }
       q[C_SDS] = sdiwbk_pt(tb, q[C_EMAXDPT], q[C_EMEAN], q[C_F1MEAN], q[C_DEPTH]);
     } else { q[C_SIGN] = T(0.1); q[C_TEMP2] = T(0); q[C_PTURB] = T(0.5); q[C_AIRDPVISC] = T(0); q[C_SDS] = T(0); }
   }
@@ -802,6 +1005,17 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   __syncthreads();
   UFRIC = c[C_UFRIC]; Z0M = c[C_Z0M];
   const T SDS = c[C_SDS];
+  if (gcb) {
+    T Z0Bv = c[C_Z0B], CH = c[C_CHRNCK];
+    const T cosd = coswd * c[C_TWCOS] + sinwd * c[C_TWSIN], tauw1 = c[C_TAUW];
+    if (!(SKIP & 16)) taut_z0_b_w(tb, L.lane, 1, HALP, WSWAVE, cosd, tauw1, RNFAC, UFRIC, Z0M, Z0Bv, CH);
+    const T sgn = wsigstar(tb, WSWAVE, UFRIC, Z0M, WSTAR);
+    WSYNC();
+    if (L.lane == 0) { c[C_UFRIC] = UFRIC; c[C_Z0M] = Z0M; c[C_Z0B] = Z0Bv; c[C_CHRNCK] = CH; c[C_SIGN] = sgn; }
+    WSYNC();
+    swell_setup_pt(tb, c);  // every lane writes the same three values
+    WSYNC();
+  }
   if (!diss_early) dissipation(UFRIC);
 
   // ---- second SINFLX call: FLD, XLLWS, MIJ, wave stress and the PHIWA integrals

@@ -24,7 +24,7 @@ _PARAM_LAYOUT = (
                                   "epsu10", "acd", "bcd", "acdlin", "bcdlin", "cdmax", "tauocmin", "tauocmax", "phiepsmin",
                                   "phiepsmax", "wsemean_min", "circ", "r_earth", "fratio", "wetail", "frtail", "wp1tail", "fric",
                                   "delth", "flogsprdm1", "xkappa", "xnlev", "rnu", "rnum", "betamaxoxkappa2", "bmaxokap",
-                                  "gamnconst", "zalp", "alpha", "alphamin", "alphamax", "chnkmin_u", "tauwshelter", "dthrn_a",
+                                  "gamnconst", "zalp", "alpha", "alphamin", "alphamax", "chnkmin_u", "alphapmax", "tauwshelter", "dthrn_a",
                                   "dthrn_u", "tailfactor", "tailfactor_pm", "ang_gc_a", "ang_gc_b", "ang_gc_c", "rn1_rn", "swellf",
                                   "swellf2", "swellf3", "swellf4", "swellf5", "swellf6", "swellf7", "swellf7m1", "z0rat",
                                   "z0tubmax", "abmin", "abmax", "sdsbr", "ssdsc2", "ssdsc3", "ssdsc4", "ssdsc5", "ssdsc6", "miche"]]

@@ -63,7 +63,7 @@ typedef struct ecwam_hip_params {
   /* YOWFRED scalars */
   double fratio, wetail, frtail, wp1tail, fric, delth, flogsprdm1;
   /* YOWPHYS */
-  double xkappa, xnlev, rnu, rnum, betamaxoxkappa2, bmaxokap, gamnconst, zalp, alpha, alphamin, alphamax, chnkmin_u;
+  double xkappa, xnlev, rnu, rnum, betamaxoxkappa2, bmaxokap, gamnconst, zalp, alpha, alphamin, alphamax, chnkmin_u, alphapmax;
   double tauwshelter, dthrn_a, dthrn_u, tailfactor, tailfactor_pm, ang_gc_a, ang_gc_b, ang_gc_c, rn1_rn;
   double swellf, swellf2, swellf3, swellf4, swellf5, swellf6, swellf7, swellf7m1, z0rat, z0tubmax, abmin, abmax;
   double sdsbr, ssdsc2, ssdsc3, ssdsc4, ssdsc5, ssdsc6, miche;

@@ -68,6 +68,30 @@ def test_implsch_parity(api, nang, nred, prec, llnormagam):
     ctx.close()
 
 
+@pytest.mark.parametrize("nang,nred", [(36, 36), (24, 29)])
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+def test_implsch_parity_flag_set_b(api, nang, nred, prec):
+    """Flag set B of SURVEY.md 8(d) (cy49r1): LLGCBZ0=T (HALPHAP, gravity-capillary TAUT_Z0 with STRESS_GC, OMEGAGC limit of
+    the TAUHF quadrature) + LLNORMAGAM=T."""
+    cfg = Config(nang=nang, nfre=36, nfre_red=nred, llgcbz0=True, llnormagam=True)
+    case = H.make_point_case(1536, cfg, prec, spectra="mixed")
+    ref = H.oracle_implsch(case, _oracle(cfg, prec))
+    ctx = api.HipContext(case["tables"])
+    got = H.gpu_implsch(case, ctx)
+    st = H.compare_implsch(ref, got, case["tables"])
+    ctx.close()
+    n = 1536
+    assert np.isfinite(got["FL1"]).all() and np.isfinite(got["FF"]).all() and np.isfinite(got["INTF"]).all()
+    if prec == "dp":
+        assert st["mij_flips"] == 0 and st["xllws_bins_diff"] == 0, st
+        assert st["fl1_max_rel_peak_all"] < 1e-10 and st["swh_max_rel"] < 1e-12, st
+        assert st["ff_max_rel_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
+    else:
+        assert st["mij_flips"] <= n * 0.005 and st["xllws_pts_diff"] <= n * 0.005, st
+        assert st["fl1_max_rel_peak_clean"] < 1e-4 and st["swh_max_rel"] < 1e-5, st
+        assert st["ff_max_rel_clean"] < 1e-4 and st["intf_max_rel_clean"] < 5e-3, st
+
+
 @pytest.mark.parametrize("prec", ["dp", "sp"])
 def test_implsch_edge_cases(api, prec):
     """empty range, single point, ice-covered and very shallow points, tiny and huge spectra"""

@@ -437,25 +437,27 @@ __device__ void sinput_ard2(const DevTab<T>& tb, const T* sF, T* sFLD, const Lan
   xmask = 0ull;
   rX = T(0); rY = T(0); rS = T(0); apl = T(0);
   wsae = T(0); wsaf = T(0); wslast = T(0);  // FEMEANWS integrands of the windsea part (femeanws.F90:84-123), finished by the caller
-  T rZCN = T(0), rCOEF5 = T(0);
+  // per-frequency factors of the row loop, evaluated once with lane m holding M=m+1 (same operations as the reference
+  // does per M: sinput_ard.F90:340-354, 379-388) and broadcast with v_readlane inside the loop
+  T rZCN = T(0), rCNSN = T(0), rCONSTF = T(0), rTEMP1 = T(0), rDSTAB1 = T(0), rXNG = T(0);
   if (L.actm) {
+    const T SIG = L.rZPIFR;
     rZCN = m_log(rWAVNUM * Z0M);
-    if (LLSNEG) rCOEF5 = -tb.SWELLF5 * T(2) * m_sqrt(T(2) * NU_AIR * tb.ZPIFR[L.lane]);
+    rCNSN = (SIG * CONST1) * RAORW;
+    if (LTAUWSHELTER) rCONSTF = ROGOROAIR * rCINV * L.rDFIM;
+    if (LLNORMAGAM) rXNG = CSTRNFAC * rXK2CG;
+    if (LLSNEG) {
+      const T COEF5 = -tb.SWELLF5 * T(2) * m_sqrt(T(2) * NU_AIR * SIG);
+      rDSTAB1 = COEF5 * AIRD_PVISC * rWAVNUM;
+      rTEMP1 = (-tb.SWELLF * T(16) * (SIG * SIG) / tb.G) * RAORW;
+    }
   }
   T COSU[2], SINU[2];
   T spq[4] = {T(0), T(0), T(0), T(0)};
   bool growq = false;
 
   for (int m = 0; m < L.NFRE; m++) {
-    const T SIG = lane_get(L.rZPIFR, m);
-    const T SIG2 = SIG * SIG;
-    const T CONST = SIG * CONST1;
-    const T cinv_m = lane_get(rCINV, m), wavnum_m = lane_get(rWAVNUM, m);
-    T COEF = T(0), COEF5 = T(0);
-    if (LLSNEG) {
-      COEF = -tb.SWELLF * T(16) * SIG2 / tb.G;
-      COEF5 = lane_get(rCOEF5, m);
-    }
+    const T cinv_m = lane_get(rCINV, m);
     T CONSTF = T(0);
     if (LTAUWSHELTER) {
 #pragma unroll
@@ -472,7 +474,7 @@ __device__ void sinput_ard2(const DevTab<T>& tb, const T* sF, T* sFLD, const Lan
         USTP[ig] = f_sqrt(h);
         if (LLNORMAGAM) USTPM1[ig] = f_rcp(m_max(USTP[ig], tb.EPSUS));
       }
-      CONSTF = ROGOROAIR * cinv_m * lane_get(L.rDFIM, m);
+      CONSTF = lane_get(rCONSTF, m);
     }
 #pragma unroll
     for (int ig = 0; ig < NGST; ig++) {
@@ -480,13 +482,13 @@ __device__ void sinput_ard2(const DevTab<T>& tb, const T* sF, T* sFLD, const Lan
       UCNZALPD[ig] = tb.XKAPPA * f_rcp(UCN[ig] + tb.ZALP);
     }
     const T ZCN = lane_get(rZCN, m);
-    const T CNSN = CONST * RAORW;
+    const T CNSN = lane_get(rCNSN, m);
     T XNGAMCONST = T(0);
-    if (LLNORMAGAM) XNGAMCONST = CSTRNFAC * lane_get(rXK2CG, m);
+    if (LLNORMAGAM) XNGAMCONST = lane_get(rXNG, m);
     T DSTAB1 = T(0), TEMP1 = T(0);
     if (LLSNEG) {
-      DSTAB1 = COEF5 * AIRD_PVISC * wavnum_m;
-      TEMP1 = COEF * RAORW;
+      DSTAB1 = lane_get(rDSTAB1, m);
+      TEMP1 = lane_get(rTEMP1, m);
     }
     const T f = sF[m * L.NAP + L.k];
     T g0[2], ds[2];
@@ -706,6 +708,7 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
   }
   const bool flux_snl = tb.LCFLX && tb.LWVFLX_SNL;
   a_t = T(0); a_x = T(0);
+  const T rLIM = USFM * (L.rCOFRM4 * DELT), rCR = rCINV * rRH;  // lane m: limiter bound and CINV*RHOWGDFTH of row M=m+1
 
   T aS[8], aF[8];
 #pragma unroll
@@ -776,7 +779,7 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
           if (m < tb.NFRE_RED) { sl = sl + sbo * f; fld = fld + sbo; }
           const T GTEMP1 = m_max(T(1) - DELT5 * fld, T(1));
           const T GTEMP2 = f_div(DELT * sl, GTEMP1);
-          const T FLHAB = m_min(m_abs(GTEMP2), USFM * (lane_get(L.rCOFRM4, m) * DELT));
+          const T FLHAB = m_min(m_abs(GTEMP2), lane_get(rLIM, m));
           T fn = f + m_sign(FLHAB, GTEMP2);
           fn = m_max(fn, FLM);
           const T flmax = lane_get(L.rFLMAX, m);
@@ -785,7 +788,7 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
           if (L.act && !(SKIP & 32)) row[k] = fn;
           const T rh = lane_get(rRH, m);
           a_t += rh * ss;
-          a_x += (lane_get(rCINV, m) * rh) * ss;
+          a_x += lane_get(rCR, m) * ss;
         }
         aS[cm] = T(0);
         aF[cm] = T(0);

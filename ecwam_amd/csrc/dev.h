@@ -19,6 +19,7 @@ struct DevTab {
   int NANG, NFRE, NFRE_RED, NFRE_ODD, IDELT;
   int LLGCBZ0, LLNORMAGAM, LLCAPCHNK, LBIWBK, LICERUN, LMASKICE, LWAMRSETCI;
   int LWVFLX_SNL, LWFLUX, LCFLX, LWNEMOCOU, LWCOU, LWCOUAST, LWNEMOCOUWRS;
+  int LCISCAL, LCIWA2, LCIWA3;  // sea-ice attenuation (implsch.F90:312-339, sdice2.F90, sdice3.F90)
   int NSDSNTH, NTAP, MFRSTLW, MLSTHG, KFRH, NWAV_GC;
   int DBG_SKIP;  // timing diagnostics only (env ECWAM_HIP_DEBUG_SKIP): bit mask of IMPLSCH phases to skip
   T XIMP, G, GM1, PI, ZPI, ZPI4GM1, ZPI4GM2, EPSMIN, ROWATER, ROWATERM1, EPSUS, EPSU10, ACD, BCD, ACDLIN, BCDLIN, CDMAX;
@@ -31,6 +32,7 @@ struct DevTab {
   T EGRCRV, AFCRV, BFCRV;
   T X0TAUHF, EPS1, FLMIN, CITHRSH, CIBLOCK, CITHRSH_TAIL, ZALPWRS, BATHYMAX, WSPMIN, WSPMIN_RESET_TAUW;
   T DAL1, DAL2, XLOGKRATIOM1_GC, SQRTGOSURFT;
+  T CDICWA, ZALPFACB, ZALPFACX;
   // per-frequency
   T FR[MAXF], DFIM[MAXF], DFIMOFR[MAXF], DFIMFR[MAXF], DFIM_SIM[MAXF], RHOWG_DFIM[MAXF], ZPIFR[MAXF], FR5[MAXF];
   T COFRM4[MAXF], FLMAX[MAXF];

@@ -681,7 +681,8 @@ __device__ void sdissip_rows2(const DevTab<T>& tb, const T* sF, T* sFLD, const L
 // with its limiter and the WNFLUXES integrands (implsch.F90:294-395) are applied to it and F(:,R) is overwritten in place.
 template <typename T>
 __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const Lane<T>& L, T rWAVNUM, T rCINV, T rXK2CG, T rRH, T UFRIC,
-                             T coswdif, T RAORW, T DEPTH, T AKMEAN, T SDS, bool shallow_brk, T USFM, T FLM, T& a_t, T& a_x) {
+                             T coswdif, T RAORW, T DEPTH, T AKMEAN, T SDS, bool shallow_brk, T USFM, T FLM, T CICOVER, T CITHICK,
+                             T rCGROUP, T& a_t, T& a_x) {
   const int SKIP = tb.DBG_SKIP;
   T ENHFR = m_max(T(0.75) * DEPTH * AKMEAN, T(0.5));
   ENHFR = T(1) + (T(5.5) / ENHFR) * (T(1) - T(.833) * ENHFR) * m_exp(-T(1.25) * ENHFR);
@@ -708,6 +709,16 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
   }
   const bool flux_snl = tb.LCFLX && tb.LWVFLX_SNL;
   a_t = T(0); a_x = T(0);
+  // sea-ice attenuation between SDIWBK and SBOTTOM (implsch.F90:312-339; LWNEMOCOUIBR = F: ALPFAC = ZALPFACX)
+  const bool ice_scal = tb.LICERUN && tb.LCISCAL, ice2 = tb.LICERUN && tb.LCIWA2, ice3 = tb.LICERUN && tb.LCIWA3;
+  const T BETA = T(1) - CICOVER;
+  T rICE3 = T(0), rICE2 = T(0);  // lane m: -CICV*ALP(M)*CGROUP(M) of SDICE3; CDICWA*WAVNUM(M)**2 of SDICE2
+  if (ice3 && L.actm) {
+    const T CDICE = T(0.1274) * m_pow(tb.ZPI / m_sqrt(tb.G), T(4.5));
+    const T ALP = (T(2) * CDICE * m_pow(CITHICK, T(1.25)) * m_pow(tb.FR[L.lane], T(4.5))) * tb.ZALPFACX;
+    rICE3 = -CICOVER * ALP * rCGROUP;
+  }
+  if (ice2 && L.actm) rICE2 = tb.CDICWA * (rWAVNUM * rWAVNUM);
   const T rLIM = USFM * (L.rCOFRM4 * DELT), rCR = rCINV * rRH;  // lane m: limiter bound and CINV*RHOWGDFTH of row M=m+1
 
   T aS[8], aF[8];
@@ -775,6 +786,19 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
           T ss = T(0);
           if (flux_snl) ss = f_div(sl, m_max(T(1) - DELT5 * fld, T(1)));
           if (shallow_brk && m < tb.NFRE_RED) { sl = sl - SDS * f; fld = fld - SDS; }
+          if (ice_scal) { sl = BETA * sl; fld = BETA * fld; }
+          if (ice2) {  // sdice2.F90:97-121
+            const T EWH = T(4) * m_sqrt(m_max(tb.EPSMIN, f * lane_get(L.rDFIM, m)));
+            const T ALP = lane_get(rICE2, m) * EWH * tb.ZALPFACB;
+            const T FLDICE = -ALP * lane_get(rCGROUP, m);
+            sl = sl + CICOVER * (f * FLDICE);
+            fld = fld + CICOVER * FLDICE;
+          }
+          if (ice3) {  // sdice3.F90:139-160
+            const T TEMP = lane_get(rICE3, m);
+            sl = sl + f * TEMP;
+            fld = fld + TEMP;
+          }
           const T sbo = lane_get(rSBO, m);
           if (m < tb.NFRE_RED) { sl = sl + sbo * f; fld = fld + sbo; }
           const T GTEMP1 = m_max(T(1) - DELT5 * fld, T(1));
@@ -836,15 +860,16 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
       sF[mm * NAP + kk] = g[e];
     }
   }
-  T rWAVNUM = T(1), rCINV = T(0), rXK2CG = T(0), rSTOKFAC = T(0);
+  T rWAVNUM = T(1), rCINV = T(0), rXK2CG = T(0), rSTOKFAC = T(0), rCGROUP = T(0);
   {
     const T* wp = wvprpt + (size_t)ij * ECWAM_HIP_NWPR * NFRE;
     if (L.actm) { rWAVNUM = wp[L.lane]; rCINV = wp[2 * NFRE + L.lane]; rXK2CG = wp[3 * NFRE + L.lane]; rSTOKFAC = wp[4 * NFRE + L.lane]; }
+    if (L.actm && (tb.LCIWA2 || tb.LCIWA3)) rCGROUP = wp[NFRE + L.lane];
   }
   const T ffv = (L.lane < ECWAM_HIP_NFF) ? ffa[(size_t)ij * ECWAM_HIP_NFF + L.lane] : T(0);
   const T AIRD = lane_get(ffv, 0), WDWAVE = lane_get(ffv, 1), CICOVER = lane_get(ffv, 2), WSWAVE = lane_get(ffv, 3);
   const T WSTAR = lane_get(ffv, 4), USTRA = lane_get(ffv, 5), VSTRA = lane_get(ffv, 6);
-  const T EMAXDPT = lane_get(ffv, 14), DEPTH = lane_get(ffv, 15);
+  const T EMAXDPT = lane_get(ffv, 14), DEPTH = lane_get(ffv, 15), CITHICK = lane_get(ffv, 13);
   const T RAORW = m_max(AIRD, T(1)) * tb.ROWATERM1;
   // ---- stage 1 inputs: first TAUT_Z0 (depends on the forcing only)
   if (L.lane < 13) {
@@ -1046,7 +1071,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   const T USFM = UFRIC * m_max(FMEANWS, FMEAN);
   T a_t, a_x;
   WSYNC();
-  source_sweep<T>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, rRH, UFRIC, coswdif, RAORW, DEPTH, AKMEAN, SDS, shallow_brk, USFM, FLM, a_t, a_x);
+  source_sweep<T>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, rRH, UFRIC, coswdif, RAORW, DEPTH, AKMEAN, SDS, shallow_brk, USFM, FLM, CICOVER, CITHICK, rCGROUP, a_t, a_x);
   WSYNC();
   __syncthreads();  // stage 3 results
   const T TAUW = c[C_TAUW], TAUWDIR = c[C_TAUWDIR], PHIWA = c[C_PHIWA];
@@ -1064,9 +1089,11 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
     const T XSTRESS = usum(a_x * tb.SINTH[L.k]);
     const T YSTRESS = usum(a_x * tb.COSTH[L.k]);
     const T EPSUS3 = tb.EPSUS * m_sqrt(tb.EPSUS);
-    const T ZCITHRS = tb.CIBLOCK;
-    const T CITHRSH_INV = T(1) / m_max(tb.CITHRSH, T(0.01));
-    const T ZMAXEXP = T(10);
+    // wnfluxes.F90: with an explicit ice attenuation term the blending with the ice-covered fluxes starts at CICOVER = 0
+    const bool sdice_on = tb.LCIWA2 || tb.LCIWA3;
+    const T ZCITHRS = sdice_on ? T(0) : tb.CIBLOCK;
+    const T CITHRSH_INV = sdice_on ? T(50) : T(1) / m_max(tb.CITHRSH, T(0.01));
+    const T ZMAXEXP = sdice_on ? T(20) : T(10);
     T OOVAL = T(1), USTAR = UFRIC;
     if (tb.LICERUN && tb.LWAMRSETCI && CICOVER > ZCITHRS) {
       OOVAL = m_exp(-m_min(m_pow4(CICOVER * CITHRSH_INV), ZMAXEXP));

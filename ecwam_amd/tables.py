@@ -80,8 +80,8 @@ class Config:
             raise NotImplementedError("IREFRA != 0 (refraction weights) is a 'next' row (SURVEY.md 8f)")
         if self.icode != 3:
             raise NotImplementedError("only ICODE=3 (10 m wind forcing) is supported")
-        if self.lciwa1 or self.lciwa2 or self.lciwa3 or self.lciscal or self.lwnemocouibr:
-            raise NotImplementedError("sea-ice attenuation SDICE1-3/LCISCAL is a 'next' row (SURVEY.md 8f)")
+        if self.lciwa1 or self.lwnemocouibr:
+            raise NotImplementedError("SDICE1 (scattering table CIDEAC) and the ice break-up coupling are 'next' rows (SURVEY.md 8f)")
         if self.nfre_red <= 0:
             self.nfre_red = self.nfre
         if not (8 <= self.nfre <= 48 and 4 <= self.nang <= 48 and self.nfre_red <= self.nfre):
@@ -232,8 +232,9 @@ class Tables:
         if c.lmaskice:
             self.CITHRSH, self.CIBLOCK, self.CITHRSH_TAIL, self.CDICWA = T(0.3), T(0.0), T(0.3), T(0.0)
         else:
-            self.CITHRSH, self.CIBLOCK, self.CITHRSH_TAIL, self.CDICWA = T(1.0), T(1.0), T(0.1), T(0.0)
-        self.ZALPWRS = T(1.0)
+            self.CITHRSH, self.CIBLOCK, self.CITHRSH_TAIL = T(1.0), T(1.0), T(0.1)
+            self.CDICWA = T(0.01) if c.lciwa2 else T(0.0)          # ice-water drag coefficient, userin.F90:971-977
+        self.ZALPWRS, self.ZALPFACB, self.ZALPFACX = T(1.0), T(1.0), T(1.0)   # mpuserin.F90:780-782
         self.GAM_B_J, self.BATHYMAX, self.WSPMIN_RESET_TAUW = T(0.8), T(998.999), T(4.0)
         self._swellft()
         self._nlweigt()

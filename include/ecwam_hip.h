@@ -71,6 +71,7 @@ typedef struct ecwam_hip_params {
   double egrcrv, afcrv, bfcrv;
   /* YOWCOUP / YOWTABL / YOWICE / YOWSHAL / YOWWIND */
   double x0tauhf, eps1, flmin, cithrsh, ciblock, cithrsh_tail, zalpwrs, bathymax, wspmin, wspmin_reset_tauw;
+  double cdicwa, zalpfacb, zalpfacx; /* YOWICE: SDICE2 drag coefficient, attenuation scale factors (sdice2.F90, implsch.F90:195) */
   /* YOWINDN scalars */
   int mfrstlw, mlsthg, kfrh;
   double dal1, dal2;

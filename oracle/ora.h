@@ -145,7 +145,7 @@ typedef struct {
   /* YOWTABL */
   real EPS1, SWELLFT[ORA_IAB + 1]; /* 1-based like the reference */
   /* YOWICE / YOWSHAL / YOWWIND */
-  real FLMIN, CITHRSH, CIBLOCK, CITHRSH_TAIL, CDICWA, ZALPFACX, ZALPWRS;
+  real FLMIN, CITHRSH, CIBLOCK, CITHRSH_TAIL, CDICWA, ZALPFACX, ZALPFACB, ZALPWRS;
   real GAM_B_J, BATHYMAX, WSPMIN, WSPMIN_RESET_TAUW;
   /* YOWINDN (nlweigt.F90, inisnonlin.F90); MC index 1..MLSTHG stored at [mc-1] */
   int MFRSTLW, MLSTHG, KFRH;

@@ -917,6 +917,34 @@ static void sdiwbk(const real *FL1, real *FLD, real *SL, real DEPTH, real EMAXDP
   }
 }
 
+/* sdice2.F90:97-121: attenuation by ice-water drag (SLICE only feeds WNFLUXES under LWNEMOCOUWRS and is not kept) */
+static void sdice2(const real *FL1, real *FLD, real *SL, const real *WAVNUM, const real *CGROUP, real CICV) {
+  const int NANG = S.NANG, NFRE = S.NFRE;
+  for (int M = 0; M < NFRE; M++)
+    for (int K = 0; K < NANG; K++) {
+      real EWH = C_(4.0) * SQRT(RMAX(S.EPSMIN, F(K, M) * S.DFIM[M]));
+      real XK2 = WAVNUM[M] * WAVNUM[M];
+      real ALP = S.CDICWA * XK2 * EWH * S.ZALPFACB;
+      real FLDICE = -ALP * CGROUP[M];
+      real SLICE = F(K, M) * FLDICE;
+      X3(SL, K, M) = X3(SL, K, M) + CICV * SLICE;
+      X3(FLD, K, M) = X3(FLD, K, M) + CICV * FLDICE;
+    }
+}
+/* sdice3.F90:103-160, IMODEL = 2 (Yu, Rogers & Wang 2022): viscous attenuation ~ CITH**1.25 FR**4.5 */
+static void sdice3(const real *FL1, real *FLD, real *SL, const real *CGROUP, real CICV, real CITH, real ALPFAC) {
+  const int NANG = S.NANG, NFRE = S.NFRE;
+  real CDICE = C_(0.1274) * POW(S.ZPI / SQRT(S.G), C_(4.5));
+  for (int M = 0; M < NFRE; M++) {
+    real ALP = (C_(2.0) * CDICE * POW(CITH, C_(1.25)) * POW(S.FR[M], C_(4.5))) * ALPFAC;
+    for (int K = 0; K < NANG; K++) {
+      real TEMP = -CICV * ALP * CGROUP[M];
+      X3(SL, K, M) = X3(SL, K, M) + F(K, M) * TEMP;
+      X3(FLD, K, M) = X3(FLD, K, M) + TEMP;
+    }
+  }
+}
+
 /* sbottom.F90:79-97 */
 static void sbottom(const real *FL1, real *FLD, real *SL, const real *WAVNUM, real DEPTH) {
   const int NANG = S.NANG, NFRE = S.NFRE;
@@ -1092,7 +1120,7 @@ static int implsch_point(real *FL1, real *XLLWS, point_t *p, real *dbg) {
   real F1MEAN, AKMEAN, XKMEAN, PHIWA;
   real FLM[NA], COSWDIF[NA], SINWDIF2[NA], TEMP[NF], RHOWGDFTH[NF], DELFL[NF];
   int LCFLX;
-  if (S.c.lciwa1 || S.c.lciwa2 || S.c.lciwa3 || S.c.lciscal || S.c.lwnemocouibr) return 2; /* SDICE*: not restated yet */
+  if (S.c.lciwa1 || S.c.lwnemocouibr) return 2; /* SDICE1 (CIDEAC scattering table) and the ice break-up coupling: not restated */
 
   DELT = (real)S.c.idelt;
   DELTM = C_(1.0) / DELT;
@@ -1125,6 +1153,15 @@ static int implsch_point(real *FL1, real *XLLWS, point_t *p, real *dbg) {
       SSOURCE[i] = SL[i] / GTEMP1;
     }
   sdiwbk(FL1, FLD, SL, p->DEPTH, p->EMAXDPT, EMEAN, F1MEAN);
+  if (S.c.licerun) { /* implsch.F90:312-339 */
+    if (S.c.lciscal) {
+      real BETA = C_(1.0) - p->CICOVER;
+      for (int i = 0; i < NANG * NFRE; i++) { SL[i] = BETA * SL[i]; FLD[i] = BETA * FLD[i]; }
+    }
+    /* LWNEMOCOUIBR = F: ALPFAC keeps ZALPFACX (implsch.F90:195) */
+    if (S.c.lciwa2) sdice2(FL1, FLD, SL, p->WAVNUM, p->CGROUP, p->CICOVER);
+    if (S.c.lciwa3) sdice3(FL1, FLD, SL, p->CGROUP, p->CICOVER, p->CITHICK, S.ZALPFACX);
+  }
   sbottom(FL1, FLD, SL, p->WAVNUM, p->DEPTH);
 
   /* :352-395 (LLUNSTR = F) */

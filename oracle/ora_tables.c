@@ -574,8 +574,8 @@ int ora_init(const ora_cfg *c) {
   S.WSPMIN = (c->wspmin > 0) ? (real)c->wspmin : (c->llgcbz0 ? C_(0.3) : C_(1.0));
   S.FLMIN = C_(0.00001);
   if (c->lmaskice) { S.CITHRSH = C_(0.3); S.CIBLOCK = C_(0.0); S.CITHRSH_TAIL = S.CITHRSH; S.CDICWA = C_(0.0); }
-  else { S.CITHRSH = C_(1.0); S.CIBLOCK = C_(1.0); S.CITHRSH_TAIL = C_(0.1); S.CDICWA = C_(0.0); }
-  S.ZALPFACX = C_(1.0); S.ZALPWRS = C_(1.0);
+  else { S.CITHRSH = C_(1.0); S.CIBLOCK = C_(1.0); S.CITHRSH_TAIL = C_(0.1); S.CDICWA = c->lciwa2 ? C_(0.01) : C_(0.0); } /* userin.F90:971-977 */
+  S.ZALPFACX = C_(1.0); S.ZALPFACB = C_(1.0); S.ZALPWRS = C_(1.0);                                          /* mpuserin.F90:780-782 */
   S.GAM_B_J = C_(0.8); S.BATHYMAX = C_(998.999); S.WSPMIN_RESET_TAUW = C_(4.0);
 
   /* ctuwupdt.F90:97-161 */

@@ -93,6 +93,41 @@ def test_implsch_parity_flag_set_b(api, nang, nred, prec):
 
 
 @pytest.mark.parametrize("prec", ["dp", "sp"])
+@pytest.mark.parametrize("flags", [dict(lciwa3=True, lciscal=True), dict(lciwa2=True, lciwa3=True, lciscal=True, lmaskice=False)])
+def test_implsch_parity_sea_ice_attenuation(api, prec, flags):
+    """SDICE2 / SDICE3 / LCISCAL (implsch.F90:312-339; the cy50r1 test configuration selects LCIWA3 + LCISCAL) on points with
+    partial ice cover and 0..3 m ice thickness; with LMASKICE=F the ice-water drag CDICWA=0.01 of SDICE2 is active too."""
+    cfg = Config(nang=24, nfre=36, nfre_red=29, **flags)
+    n = 1024
+    case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=21)
+    rng = np.random.default_rng(5)
+    dt = H.np_dtype(prec)
+    case["FF"][:, 2] = np.where(rng.uniform(size=n) < 0.6, rng.uniform(0.0, 1.0, n), 0.0).astype(dt)   # CICOVER
+    case["FF"][:, 13] = rng.uniform(0.0, 3.0, n).astype(dt)                                           # CITHICK
+    ref = H.oracle_implsch(case, _oracle(cfg, prec))
+    ctx = api.HipContext(case["tables"])
+    got = H.gpu_implsch(case, ctx)
+    st = H.compare_implsch(ref, got, case["tables"])
+    ctx.close()
+    assert np.isfinite(got["FL1"]).all() and np.isfinite(got["INTF"]).all()
+    if prec == "dp":
+        assert st["mij_flips"] == 0 and st["xllws_bins_diff"] == 0, st
+        assert st["fl1_max_rel_peak_all"] < 1e-10 and st["swh_max_rel"] < 1e-12, st
+        assert st["ff_max_rel_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
+    else:
+        assert st["mij_flips"] <= n * 0.005 and st["xllws_pts_diff"] <= n * 0.005, st
+        assert st["fl1_max_rel_peak_clean"] < 1e-4 and st["swh_max_rel"] < 1e-5, st
+        assert st["ff_max_rel_clean"] < 1e-4 and st["intf_max_rel_clean"] < 5e-3, st
+    # the attenuation must actually have acted: the same case without the flags gives a different answer
+    cfg0 = Config(nang=24, nfre=36, nfre_red=29, lmaskice=flags.get("lmaskice", True))
+    case0 = dict(case); case0["cfg"] = cfg0
+    from ecwam_amd.tables import Tables as _T
+    case0["tables"] = _T(cfg0, dt)
+    ref0 = H.oracle_implsch(case0, _oracle(cfg0, prec))
+    assert np.max(np.abs(ref0["FL1"] - ref["FL1"])) > 0
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
 def test_implsch_edge_cases(api, prec):
     """empty range, single point, ice-covered and very shallow points, tiny and huge spectra"""
     cfg = Config(nang=24, nfre=36, nfre_red=29)

@@ -125,7 +125,7 @@ class HipContext:
         self._chk(self.lib.ecwam_hip_propags2_otf(self._h, *args, kijs, kijl, nd3s, nd3e, int(copy_rest), _stream_ptr()))
 
     # -- IMPLSCH (implsch.F90:10-23)
-    def implsch(self, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, dbg=None):
+    def implsch(self, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, dbg=None, wam2nemo=None):
         nrow = fl1.shape[0]
         if not (0 <= kijs <= kijl <= min(nrow, wvprpt.shape[0], ff.shape[0], intf.shape[0], mij.shape[0], xllws.shape[0])):
             raise ValueError("IMPLSCH: KIJS/KIJL outside the operands")
@@ -133,7 +133,13 @@ class HipContext:
              self._real(ff, (ff.shape[0], NFF), "FF"), self._real(intf, (intf.shape[0], NINTF), "INTF"),
              self._int(mij, (mij.shape[0],), "MIJ"), self._real(xllws, (xllws.shape[0], self.NANG, self.NFRE), "XLLWS")]
         pd = None if dbg is None else self._real(dbg, (nrow, 32), "DBG")
-        self._chk(self.lib.ecwam_hip_implsch(self._h, kijs, kijl, *a, pd, _stream_ptr()))
+        pw = None
+        if wam2nemo is not None:
+            if not (wam2nemo.is_cuda and wam2nemo.dtype == torch.float64 and wam2nemo.is_contiguous()
+                    and tuple(wam2nemo.shape) == (nrow if wam2nemo.shape[0] == nrow else wam2nemo.shape[0], 13) and wam2nemo.shape[0] >= kijl):
+                raise ValueError("WAM2NEMO: expected contiguous float64 cuda tensor [npts][13]")
+            pw = wam2nemo.data_ptr()
+        self._chk(self.lib.ecwam_hip_implsch(self._h, kijs, kijl, *a, pw, pd, _stream_ptr()))
 
     # -- NEWWIND (newwind.F90:126-161)
     def newwind(self, ff, ff_next):

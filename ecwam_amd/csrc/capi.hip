@@ -35,7 +35,7 @@ template <typename T> void launch_newwind(const void*, int, void*, const void*, 
 template <typename T> void launch_c2p(const void*, void*, int, int, int, int, int, hipStream_t);
 template <typename T> void launch_p2c(const void*, void*, int, int, int, int, int, hipStream_t);
 template <typename T> void launch_pack(const void*, const int*, int, int, void*, hipStream_t);
-template <typename T> int launch_implsch(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, int, int, int, hipStream_t);
+template <typename T> int launch_implsch(const void*, int, int, void*, const void*, void*, void*, int*, void*, double*, void*, int, int, int, hipStream_t);
 
 template <typename T>
 static void cpv(T* dst, const void* src, int n) {
@@ -51,6 +51,7 @@ static int build_tab(const ecwam_hip_params* p, const ecwam_hip_tables* t, DevTa
   d->LICERUN = p->licerun; d->LMASKICE = p->lmaskice; d->LWAMRSETCI = p->lwamrsetci; d->LWVFLX_SNL = p->lwvflx_snl;
   d->LWFLUX = p->lwflux; d->LCFLX = (p->lwflux || p->lwfluxout || p->lwnemocou); d->LWNEMOCOU = p->lwnemocou; d->LWCOU = p->lwcou;
   d->LWCOUAST = p->lwcouast; d->LWNEMOCOUWRS = p->lwnemocouwrs;
+  d->LWNEMOTAUOC = p->lwnemotauoc; d->LWNEMOCOUSEND = p->lwnemocousend; d->LWNEMOCOUSTK = p->lwnemocoustk;
   d->LCISCAL = p->lciscal; d->LCIWA2 = p->lciwa2; d->LCIWA3 = p->lciwa3;
   { const char* e_ = getenv("ECWAM_HIP_DEBUG_SKIP"); d->DBG_SKIP = e_ ? atoi(e_) : 0; }
   d->NSDSNTH = p->nsdsnth; d->NTAP = 2 * p->nsdsnth + 1; d->MFRSTLW = p->mfrstlw; d->MLSTHG = ML; d->KFRH = p->kfrh; d->NWAV_GC = p->nwav_gc;
@@ -187,7 +188,7 @@ int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int r
   if (p->iphys != 1 || p->isnonlin != 0 || p->irefra != 0 || p->icode != 3)
     return fail("ecwam_hip_create: only IPHYS=1, ISNONLIN=0, IREFRA=0, ICODE=3 are on the hot path (SURVEY.md 8a)");
   if (p->lciwa1) return fail("ecwam_hip_create: SDICE1 (scattering attenuation table CIDEAC, sdice1.F90) not supported yet");
-  if (p->lwnemocou || p->lwnemocouwrs) return fail("ecwam_hip_create: NEMO coupling outputs (WAVE2OCEAN) not supported yet");
+  if (p->lwnemocouwrs || p->lwnemocoustrn) return fail("ecwam_hip_create: LWNEMOCOUWRS (ice radiative stress from SLICE) / LWNEMOCOUSTRN (CIMSSTRN) not supported yet");
   HIPCHK(hipSetDevice(device));
   ecwam_hip_ctx* c = new ecwam_hip_ctx();
   c->real_bytes = real_bytes; c->device = device; c->NANG = p->nang; c->NFRE = p->nfre; c->NFRE_RED = p->nfre_red; c->p = *p;
@@ -195,14 +196,14 @@ int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int r
     std::vector<DevTab<float>> h(1);
     build_tab<float>(p, t, h.data());
     c->implsch_variant = h[0].DIA_PULL ? 2 : 1;
-    if ((p->llgcbz0 || p->lciwa2 || p->lciwa3 || p->lciscal) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
+    if ((p->llgcbz0 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
     HIPCHK(hipMalloc(&c->dtab, sizeof(DevTab<float>)));
     HIPCHK(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<float>), hipMemcpyHostToDevice));
   } else {
     std::vector<DevTab<double>> h(1);
     build_tab<double>(p, t, h.data());
     c->implsch_variant = h[0].DIA_PULL ? 2 : 1;
-    if ((p->llgcbz0 || p->lciwa2 || p->lciwa3 || p->lciscal) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
+    if ((p->llgcbz0 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
     HIPCHK(hipMalloc(&c->dtab, sizeof(DevTab<double>)));
     HIPCHK(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<double>), hipMemcpyHostToDevice));
   }
@@ -275,16 +276,18 @@ int ecwam_hip_propags2_otf(ecwam_hip_ctx* c, const void* f1, void* f3, int n, in
 }
 
 int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws,
-                      void* dbg, void* stream) {
+                      double* wam2nemo, void* dbg, void* stream) {
   if (!c) return fail("null context");
   if (kijl < kijs) return fail("ecwam_hip_implsch: bad range");
   if (kijl > kijs && (!fl1 || !wvprpt || !ff || !intf || !mij || !xllws)) return fail("ecwam_hip_implsch: null pointer");
+  if (kijl > kijs && c->p.lwnemocou && !wam2nemo) return fail("ecwam_hip_implsch: LWNEMOCOU needs the WAVE2OCEAN buffer");
+  if (!c->p.lwnemocou) wam2nemo = nullptr;
   hipStream_t s = (hipStream_t)stream;
   int rc, variant = c->implsch_variant;
   { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_VARIANT"); if (e_ && atoi(e_) == 1) variant = 1; }  // diagnostics: force the 3-tile kernel
   if (c->p.llnormagam) variant |= 16;
-  DISPATCH(rc = launch_implsch<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, dbg, c->NANG, c->NFRE, variant, s),
-           rc = launch_implsch<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, dbg, c->NANG, c->NFRE, variant, s));
+  DISPATCH(rc = launch_implsch<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s),
+           rc = launch_implsch<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s));
   if (rc) return fail("ecwam_hip_implsch: unsupported spectral size for the LDS tiling");
   HIPCHK(hipGetLastError());
   return 0;

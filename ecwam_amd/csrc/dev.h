@@ -19,6 +19,7 @@ struct DevTab {
   int NANG, NFRE, NFRE_RED, NFRE_ODD, IDELT;
   int LLGCBZ0, LLNORMAGAM, LLCAPCHNK, LBIWBK, LICERUN, LMASKICE, LWAMRSETCI;
   int LWVFLX_SNL, LWFLUX, LCFLX, LWNEMOCOU, LWCOU, LWCOUAST, LWNEMOCOUWRS;
+  int LWNEMOTAUOC, LWNEMOCOUSEND, LWNEMOCOUSTK;
   int LCISCAL, LCIWA2, LCIWA3;  // sea-ice attenuation (implsch.F90:312-339, sdice2.F90, sdice3.F90)
   int NSDSNTH, NTAP, MFRSTLW, MLSTHG, KFRH, NWAV_GC;
   int DBG_SKIP;  // timing diagnostics only (env ECWAM_HIP_DEBUG_SKIP): bit mask of IMPLSCH phases to skip

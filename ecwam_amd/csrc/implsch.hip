@@ -704,7 +704,8 @@ __device__ void snonlin_pull(const DevTab<T>& tb, const T* sF, T* sFLD, T* sSL, 
 template <typename T, int WPB>
 __global__ void __launch_bounds__(64 * WPB) k_implsch(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__ fl1,
                                                       const T* __restrict__ wvprpt, T* __restrict__ ffa, T* __restrict__ intfa,
-                                                      int* __restrict__ mij_out, T* __restrict__ xllws, T* __restrict__ dbg) {
+                                                      int* __restrict__ mij_out, T* __restrict__ xllws, double* __restrict__ /*w2n: variant 2 only*/,
+                                                      T* __restrict__ dbg) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const DevTab<T>& tb = *tp;
   const int SKIP = tb.DBG_SKIP;  // 0 in production; timing diagnostics only
@@ -1042,7 +1043,7 @@ __global__ void __launch_bounds__(64 * WPB) k_implsch(const DevTab<T>* __restric
 
 template <typename T>
 int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws,
-                   void* dbg, int NANG, int NFRE, int variant, hipStream_t s) {
+                   double* w2n, void* dbg, int NANG, int NFRE, int variant, hipStream_t s) {
   const int n = kijl - kijs;
   if (n <= 0) return 0;
   const bool norma = (variant & 16) != 0;  // LLNORMAGAM, packed by capi.hip
@@ -1076,7 +1077,7 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
   do {                                                                                                                       \
     if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)KFN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
     hipLaunchKernelGGL(KFN, dim3(blocks), dim3(64 * wpb), shmem, s, (const DevTab<T>*)tab, kijs, kijl, (T*)fl1,              \
-                       (const T*)wvprpt, (T*)ff, (T*)intf, mij, (T*)xllws, (T*)dbg);                                         \
+                       (const T*)wvprpt, (T*)ff, (T*)intf, mij, (T*)xllws, w2n, (T*)dbg);                                         \
   } while (0)
 #define LAUNCH(K, W) LAUNCHK((K<T, W>))
   if (variant2) {
@@ -1098,5 +1099,5 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
 #undef LAUNCHK
   return 0;
 }
-template int launch_implsch<float>(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, int, int, int, hipStream_t);
-template int launch_implsch<double>(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, int, int, int, hipStream_t);
+template int launch_implsch<float>(const void*, int, int, void*, const void*, void*, void*, int*, void*, double*, void*, int, int, int, hipStream_t);
+template int launch_implsch<double>(const void*, int, int, void*, const void*, void*, void*, int*, void*, double*, void*, int, int, int, hipStream_t);

@@ -824,7 +824,8 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
 template <typename T, int WPB, bool NORMA>
 __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 4 : 2))) k_implsch2(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__ fl1,
                                                        const T* __restrict__ wvprpt, T* __restrict__ ffa, T* __restrict__ intfa,
-                                                       int* __restrict__ mij_out, T* __restrict__ xllws, T* __restrict__ dbg) {
+                                                       int* __restrict__ mij_out, T* __restrict__ xllws, double* __restrict__ w2n,
+                                                       T* __restrict__ dbg) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const DevTab<T>& tb = *tp;
   const int SKIP = tb.DBG_SKIP;
@@ -1095,6 +1096,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
     const T CITHRSH_INV = sdice_on ? T(50) : T(1) / m_max(tb.CITHRSH, T(0.01));
     const T ZMAXEXP = sdice_on ? T(20) : T(10);
     T OOVAL = T(1), USTAR = UFRIC;
+    T EM_OC = EMEAN, F1_OC = F1MEAN;  // EMEAN/F1MEAN of the spectrum before the update (first FKMEAN), as passed in implsch.F90:396-414
     if (tb.LICERUN && tb.LWAMRSETCI && CICOVER > ZCITHRS) {
       OOVAL = m_exp(-m_min(m_pow4(CICOVER * CITHRSH_INV), ZMAXEXP));
       const T U10P = m_max(WSWAVE, tb.EPSU10);
@@ -1102,6 +1104,15 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
       const T CD_WAVE = (UFRIC / U10P) * (UFRIC / U10P);
       const T CD_ICE = OOVAL * CD_WAVE + (T(1) - OOVAL) * CD_BULK;
       USTAR = m_max(m_sqrt(CD_ICE) * U10P, tb.EPSUS);
+      if (tb.LWNEMOCOU) {  // fully developed sea under ice for the NEMO wave height / period (wnfluxes.F90:236-246)
+        const T EFD_FAC = T(4) * tb.EGRCRV / (tb.G * tb.G);
+        const T FFD_FAC = m_pow(tb.EGRCRV / tb.AFCRV, T(1) / tb.BFCRV) * tb.G;
+        const T EFD = m_min(EFD_FAC * m_pow4(USTAR), T(6.25));
+        EM_OC = m_max(OOVAL * EMEAN + (T(1) - OOVAL) * EFD, T(0.0625));
+        const T FFD = FFD_FAC / USTAR;
+        F1_OC = OOVAL * F1MEAN + (T(1) - OOVAL) * FFD;
+        F1_OC = m_min(m_max(F1_OC, tb.FR[1]), tb.FR[NFRE - 1]);
+      }
     }
     const T TAU = AIRD * m_max(USTAR * USTAR, tb.EPSUS);
     TAUXD = TAU * sinwd;
@@ -1118,6 +1129,16 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
     PHIEPS = m_min(m_max(PHIOCD / XN, tb.PHIEPSMIN), tb.PHIEPSMAX);
     PHIOCD = PHIEPS * XN;
     PHIAW = OOVAL * PHIWA / XN + (T(1) - OOVAL) * T(3.75);
+    if (tb.LWNEMOCOU && w2n && valid && L.lane == 0) {  // wnfluxes.F90:304-328 (LNUPD = T; TAUICX/Y = 0 without LWNEMOCOUWRS)
+      double* q = w2n + (size_t)ij * 13;
+      q[3] = (double)PHIEPS; q[4] = (double)TAUOC;
+      q[5] = (EM_OC != T(0)) ? 4.0 * (double)m_sqrt(EM_OC) : 0.0;
+      q[6] = (F1_OC != T(0)) ? 1.0 / (double)F1_OC : 0.0;
+      if (tb.LWNEMOTAUOC) { q[7] += (double)TAUOCXD; q[8] += (double)TAUOCYD; }
+      else { q[7] += (double)TAUXD; q[8] += (double)TAUYD; }
+      q[11] += (double)WSWAVE; q[12] += (double)PHIOCD;
+      q[9] += 0.0; q[10] += 0.0;
+    }
   }
 
   // ---- second FKMEAN / FEMEANWS, IMPHFTAIL, SETICE, STOKESDRIFT (implsch.F90:422-462)
@@ -1159,6 +1180,12 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
     }
     USTOKES = m_min(m_max(USTOKES, T(-1.5)), T(1.5));
     VSTOKES = m_min(m_max(VSTOKES, T(-1.5)), T(1.5));
+    // stokestrn.F90:75-88 (LWNEMOCOUSTRN = F)
+    if (tb.LWNEMOCOU && w2n && valid && L.lane == 0 && ((tb.LWNEMOCOUSEND && tb.LWCOU) || !tb.LWCOU)) {
+      double* q = w2n + (size_t)ij * 13;
+      q[0] = tb.LWNEMOCOUSTK ? (double)USTOKES : 0.0;
+      q[1] = tb.LWNEMOCOUSTK ? (double)VSTOKES : 0.0;
+    }
   }
   // XLLWS as reals into the FLD tile for the coalesced store
   if (L.act)

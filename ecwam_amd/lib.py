@@ -19,7 +19,8 @@ _PARAM_LAYOUT = (
     + [("ximp", C.c_double)]
     + [(n, C.c_int) for n in ["iphys", "isnonlin", "irefra", "icode", "llgcbz0", "llnormagam", "llcapchnk", "lbiwbk", "licerun",
                                "lmaskice", "lwamrsetci", "lciwa1", "lciwa2", "lciwa3", "lciscal", "lwvflx_snl", "lwflux",
-                               "lwfluxout", "lwnemocou", "lwcou", "lwcouast", "lwnemocouwrs", "lwnemotauoc"]]
+                               "lwfluxout", "lwnemocou", "lwcou", "lwcouast", "lwnemocouwrs", "lwnemotauoc", "lwnemocousend",
+                               "lwnemocoustk", "lwnemocoustrn"]]
     + [(n, C.c_double) for n in ["g", "gm1", "pi", "zpi", "zpi4gm1", "zpi4gm2", "epsmin", "rowater", "rowaterm1", "epsus",
                                   "epsu10", "acd", "bcd", "acdlin", "bcdlin", "cdmax", "tauocmin", "tauocmax", "phiepsmin",
                                   "phiepsmax", "wsemean_min", "circ", "r_earth", "fratio", "wetail", "frtail", "wp1tail", "fric",
@@ -77,7 +78,7 @@ def load() -> C.CDLL:
     lib.ecwam_hip_propags2.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
     lib.ecwam_hip_ctuw.argtypes = [vp, ci, ci, ci, cd, ci, ci, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ecwam_hip_propags2_otf.argtypes = [vp, vp, vp, ci, ci, cd, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
-    lib.ecwam_hip_implsch.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ecwam_hip_implsch.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ecwam_hip_newwind.argtypes = [vp, ci, vp, vp, vp]
     lib.ecwam_hip_chunks_to_points.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp]
     lib.ecwam_hip_points_to_chunks.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp]

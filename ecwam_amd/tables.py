@@ -67,6 +67,9 @@ class Config:
     lwnemocouwrs: bool = False
     lwnemocouibr: bool = False
     lwnemotauoc: bool = False
+    lwnemocousend: bool = True     # mpuserin.F90:721-723
+    lwnemocoustk: bool = True
+    lwnemocoustrn: bool = False
     wspmin: float = -1.0
     rnu: float = 1.5e-5            # runwam.F90:232
     rnum: float = 0.11 * 1.5e-5    # runwam.F90:233
@@ -80,6 +83,8 @@ class Config:
             raise NotImplementedError("IREFRA != 0 (refraction weights) is a 'next' row (SURVEY.md 8f)")
         if self.icode != 3:
             raise NotImplementedError("only ICODE=3 (10 m wind forcing) is supported")
+        if self.lwnemocouwrs or self.lwnemocoustrn:
+            raise NotImplementedError("wave radiative stress on ice (SLICE) and CIMSSTRN are 'next' rows (SURVEY.md 8f)")
         if self.lciwa1 or self.lwnemocouibr:
             raise NotImplementedError("SDICE1 (scattering table CIDEAC) and the ice break-up coupling are 'next' rows (SURVEY.md 8f)")
         if self.nfre_red <= 0:

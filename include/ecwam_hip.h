@@ -57,6 +57,7 @@ typedef struct ecwam_hip_params {
   int llgcbz0, llnormagam, llcapchnk, lbiwbk, licerun, lmaskice, lwamrsetci;
   int lciwa1, lciwa2, lciwa3, lciscal;
   int lwvflx_snl, lwflux, lwfluxout, lwnemocou, lwcou, lwcouast, lwnemocouwrs, lwnemotauoc;
+  int lwnemocousend, lwnemocoustk, lwnemocoustrn; /* YOWCOUP: which WAVE2OCEAN members STOKESTRN fills (stokestrn.F90:75-88) */
   /* YOWPCONS */
   double g, gm1, pi, zpi, zpi4gm1, zpi4gm2, epsmin, rowater, rowaterm1, epsus, epsu10, acd, bcd, acdlin, bcdlin, cdmax;
   double tauocmin, tauocmax, phiepsmin, phiepsmax, wsemean_min, circ, r_earth;
@@ -158,10 +159,14 @@ int ecwam_hip_propags2_otf(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n, 
 /*
  * IMPLSCH (implsch.F90:10-23) for local points [kijs,kijl) on device pointers (layouts above).
  *   fl1 inout, wvprpt in, ff inout, intf inout, mij out (1-based), xllws out
+ *   wam2nemo: double[npts][13] inout, the WAVE2OCEAN members (always JWRO = double, yowdrvtype_config.yml:44-55) in the order
+ *             NEMOUSTOKES NEMOVSTOKES NEMOSTRN NPHIEPS NTAUOC NSWH NMWP NEMOTAUX NEMOTAUY NEMOTAUICX NEMOTAUICY NEMOWSWAVE
+ *             NEMOPHIF; updated as wnfluxes.F90:304-328 (LNUPD = T) and stokestrn.F90:75-88 do; required when LWNEMOCOU,
+ *             ignored (may be NULL) otherwise
  *   dbg: optional real[npts][32] intermediate dump (tests only), may be NULL
  */
 int ecwam_hip_implsch(ecwam_hip_ctx *ctx, int kijs, int kijl, void *fl1, const void *wvprpt, void *ff, void *intf, int *mij,
-                      void *xllws, void *dbg, void *stream);
+                      void *xllws, double *wam2nemo, void *dbg, void *stream);
 
 /* NEWWIND forcing hand-over (newwind.F90:126-161, ICODE_WND=3): FF <- FF_NEXT members + TAUW cap */
 int ecwam_hip_newwind(ecwam_hip_ctx *ctx, int n, void *ff, const void *ff_next, void *stream);

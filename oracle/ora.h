@@ -101,7 +101,7 @@ typedef struct {
   int lbiwbk, licerun, lmaskice, lwamrsetci;
   int lciwa1, lciwa2, lciwa3, lciscal;
   int lwvflx_snl, lwflux, lwfluxout, lwnemocou, lwcou, lwcouast;
-  int lwnemocouwrs, lwnemocouibr, lwnemotauoc;
+  int lwnemocouwrs, lwnemocouibr, lwnemotauoc, lwnemocousend, lwnemocoustk;
   double wspmin;   /* set by ora_init from llgcbz0 unless > 0 */
   double rnu, rnum; /* air viscosity (runwam.F90:232-233) */
 } ora_cfg;

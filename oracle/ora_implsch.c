@@ -1045,7 +1045,7 @@ static void wnfluxes(point_t *p, const real *RHOWGDFTH, const real *SSURF, real 
   p->PHIAW = OOVAL * PHIWA / XN + (C_(1.0) - OOVAL) * PHIAW_ICE;
   if (S.c.lwnemocou && LNUPD) {
     p->NPHIEPS = p->PHIEPS; p->NTAUOC = p->TAUOC;
-    p->NSWH = (EM_OC != C_(0.0)) ? 4.0 * sqrt((double)EM_OC) : 0.0;
+    p->NSWH = (EM_OC != C_(0.0)) ? 4.0 * (double)SQRT(EM_OC) : 0.0; /* 4.0_JWRO*SQRT(EM_OC): the root in JWRB */
     p->NMWP = (F1_OC != C_(0.0)) ? 1.0 / (double)F1_OC : 0.0;
     if (S.c.lwnemotauoc) { p->NEMOTAUX += p->TAUOCXD; p->NEMOTAUY += p->TAUOCYD; }
     else { p->NEMOTAUX += p->TAUXD; p->NEMOTAUY += p->TAUYD; }
@@ -1191,7 +1191,10 @@ static int implsch_point(real *FL1, real *XLLWS, point_t *p, real *dbg) {
   if (S.c.licerun && S.c.lmaskice) setice(FL1, p->CICOVER, COSWDIF);
   stokesdrift(FL1, p->STOKFAC, p->WSWAVE, p->WDWAVE, p->CICOVER, &p->USTOKES, &p->VSTOKES);
   /* stokestrn.F90:77-89: NEMO copies only when LWNEMOCOU */
-  if (S.c.lwnemocou && !S.c.lwcou) { p->NEMOUSTOKES = p->USTOKES; p->NEMOVSTOKES = p->VSTOKES; }
+  if (S.c.lwnemocou && ((S.c.lwnemocousend && S.c.lwcou) || !S.c.lwcou)) {
+    if (S.c.lwnemocoustk) { p->NEMOUSTOKES = p->USTOKES; p->NEMOVSTOKES = p->VSTOKES; }
+    else { p->NEMOUSTOKES = 0.0; p->NEMOVSTOKES = 0.0; }
+  }
   return 0;
 }
 
@@ -1202,8 +1205,16 @@ static int implsch_point(real *FL1, real *XLLWS, point_t *p, real *dbg) {
  * ENV (in)             [n][2] : EMAXDPT DEPTH ; IENV [n][2]: IOBND IODP
  * MIJ out [n] (1-based); DBG optional [n][8]
  */
+/* W2N (inout, may be NULL) [n][13] double: NEMOUSTOKES NEMOVSTOKES NEMOSTRN NPHIEPS NTAUOC NSWH NMWP NEMOTAUX NEMOTAUY NEMOTAUICX
+ *                                          NEMOTAUICY NEMOWSWAVE NEMOPHIF (WAVE2OCEAN, yowdrvtype_config.yml) */
+int ora_implsch_w2n(int n, real *FL1, const real *WAVNUM, const real *CGROUP, const real *CINV, const real *XK2CG,
+                    const real *STOKFAC, const real *ENV, real *FF, real *INTF, int *MIJ, real *XLLWS, real *DBG, double *W2N);
 int ora_implsch(int n, real *FL1, const real *WAVNUM, const real *CGROUP, const real *CINV, const real *XK2CG,
                 const real *STOKFAC, const real *ENV, real *FF, real *INTF, int *MIJ, real *XLLWS, real *DBG) {
+  return ora_implsch_w2n(n, FL1, WAVNUM, CGROUP, CINV, XK2CG, STOKFAC, ENV, FF, INTF, MIJ, XLLWS, DBG, NULL);
+}
+int ora_implsch_w2n(int n, real *FL1, const real *WAVNUM, const real *CGROUP, const real *CINV, const real *XK2CG,
+                    const real *STOKFAC, const real *ENV, real *FF, real *INTF, int *MIJ, real *XLLWS, real *DBG, double *W2N) {
   const int NANG = S.NANG, NFRE = S.NFRE;
   int rc = 0;
 #pragma omp parallel for schedule(dynamic, 16) reduction(| : rc)
@@ -1219,7 +1230,17 @@ int ora_implsch(int n, real *FL1, const real *WAVNUM, const real *CGROUP, const 
     p.WSEMEAN = it[0]; p.WSFMEAN = it[1]; p.USTOKES = it[2]; p.VSTOKES = it[3]; p.STRNMS = it[4]; p.TAUXD = it[5];
     p.TAUYD = it[6]; p.TAUOCXD = it[7]; p.TAUOCYD = it[8]; p.TAUOC = it[9]; p.TAUICX = it[10]; p.TAUICY = it[11];
     p.PHIOCD = it[12]; p.PHIEPS = it[13]; p.PHIAW = it[14];
+    if (W2N) {
+      const double *w = W2N + (size_t)ij * 13;
+      p.NEMOUSTOKES = w[0]; p.NEMOVSTOKES = w[1]; p.NEMOSTRN = w[2]; p.NPHIEPS = w[3]; p.NTAUOC = w[4]; p.NSWH = w[5]; p.NMWP = w[6];
+      p.NEMOTAUX = w[7]; p.NEMOTAUY = w[8]; p.NEMOTAUICX = w[9]; p.NEMOTAUICY = w[10]; p.NEMOWSWAVE = w[11]; p.NEMOPHIF = w[12];
+    }
     rc |= implsch_point(FL1 + (size_t)ij * NANG * NFRE, XLLWS + (size_t)ij * NANG * NFRE, &p, DBG ? DBG + (size_t)ij * 8 : NULL);
+    if (W2N) {
+      double *w = W2N + (size_t)ij * 13;
+      w[0] = p.NEMOUSTOKES; w[1] = p.NEMOVSTOKES; w[2] = p.NEMOSTRN; w[3] = p.NPHIEPS; w[4] = p.NTAUOC; w[5] = p.NSWH; w[6] = p.NMWP;
+      w[7] = p.NEMOTAUX; w[8] = p.NEMOTAUY; w[9] = p.NEMOTAUICX; w[10] = p.NEMOTAUICY; w[11] = p.NEMOWSWAVE; w[12] = p.NEMOPHIF;
+    }
     ff[0] = p.AIRD; ff[1] = p.WDWAVE; ff[2] = p.CICOVER; ff[3] = p.WSWAVE; ff[4] = p.WSTAR; ff[5] = p.USTRA; ff[6] = p.VSTRA;
     ff[7] = p.UFRIC; ff[8] = p.TAUW; ff[9] = p.TAUWDIR; ff[10] = p.Z0M; ff[11] = p.Z0B; ff[12] = p.CHRNCK; ff[13] = p.CITHICK;
     it[0] = p.WSEMEAN; it[1] = p.WSFMEAN; it[2] = p.USTOKES; it[3] = p.VSTOKES; it[4] = p.STRNMS; it[5] = p.TAUXD;

@@ -22,7 +22,7 @@ void ora_default_cfg(ora_cfg *c) {
   c->lbiwbk = 1; c->licerun = 1; c->lmaskice = 1; c->lwamrsetci = 1;
   c->lciwa1 = 0; c->lciwa2 = 0; c->lciwa3 = 0; c->lciscal = 0;
   c->lwvflx_snl = 1; c->lwflux = 0; c->lwfluxout = 1; c->lwnemocou = 0; c->lwcou = 0; c->lwcouast = 1;
-  c->lwnemocouwrs = 0; c->lwnemocouibr = 0; c->lwnemotauoc = 0;
+  c->lwnemocouwrs = 0; c->lwnemocouibr = 0; c->lwnemotauoc = 0; c->lwnemocousend = 1; c->lwnemocoustk = 1;
   c->wspmin = -1.0;
   c->rnu = 1.5E-5; c->rnum = 0.11 * 1.5E-5;
 }

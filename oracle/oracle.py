@@ -24,7 +24,8 @@ class OraCfg(C.Structure):
         ("lciwa1", C.c_int), ("lciwa2", C.c_int), ("lciwa3", C.c_int), ("lciscal", C.c_int),
         ("lwvflx_snl", C.c_int), ("lwflux", C.c_int), ("lwfluxout", C.c_int), ("lwnemocou", C.c_int),
         ("lwcou", C.c_int), ("lwcouast", C.c_int),
-        ("lwnemocouwrs", C.c_int), ("lwnemocouibr", C.c_int), ("lwnemotauoc", C.c_int),
+        ("lwnemocouwrs", C.c_int), ("lwnemocouibr", C.c_int), ("lwnemotauoc", C.c_int), ("lwnemocousend", C.c_int),
+        ("lwnemocoustk", C.c_int),
         ("wspmin", C.c_double), ("rnu", C.c_double), ("rnum", C.c_double),
     ]
 
@@ -94,7 +95,7 @@ class Oracle:
                                self._p(out["XK2CG"]), self._p(out["OMOSNH2KD"]), self._p(out["STOKFAC"]), self._p(out["EMAXDPT"]))
         return out
 
-    def implsch(self, fl1, wavnum, cgroup, cinv, xk2cg, stokfac, env, ff, intf, want_dbg=False):
+    def implsch(self, fl1, wavnum, cgroup, cinv, xk2cg, stokfac, env, ff, intf, want_dbg=False, w2n=None):
         """All arrays are copied; returns dict(FL1, XLLWS, MIJ, FF, INTF[, DBG])."""
         n = fl1.shape[0]
         T = self.dtype
@@ -105,11 +106,17 @@ class Oracle:
         mij = np.zeros(n, dtype=np.int32)
         dbg = np.zeros((n, 8), dtype=T) if want_dbg else None
         a = [np.ascontiguousarray(x, dtype=T) for x in (wavnum, cgroup, cinv, xk2cg, stokfac, env)]
-        rc = self.lib.ora_implsch(C.c_int(n), self._p(fl1), *(self._p(x) for x in a[:5]), self._p(a[5]), self._p(ff),
-                                  self._p(intf), self._p(mij), self._p(xllws), self._p(dbg) if want_dbg else None)
+        if w2n is not None:
+            w2n = np.array(w2n, dtype=np.float64, order="C")
+            assert w2n.shape == (n, 13)
+        rc = self.lib.ora_implsch_w2n(C.c_int(n), self._p(fl1), *(self._p(x) for x in a[:5]), self._p(a[5]), self._p(ff),
+                                      self._p(intf), self._p(mij), self._p(xllws), self._p(dbg) if want_dbg else None,
+                                      None if w2n is None else w2n.ctypes.data_as(C.c_void_p))
         if rc:
             raise RuntimeError(f"ora_implsch abort branch rc={rc}")
         out = dict(FL1=fl1, XLLWS=xllws, MIJ=mij, FF=ff, INTF=intf)
+        if w2n is not None:
+            out["W2N"] = w2n
         if want_dbg:
             out["DBG"] = dbg
         return out

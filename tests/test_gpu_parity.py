@@ -128,6 +128,45 @@ def test_implsch_parity_sea_ice_attenuation(api, prec, flags):
 
 
 @pytest.mark.parametrize("prec", ["dp", "sp"])
+@pytest.mark.parametrize("tauoc", [True, False])
+def test_implsch_wam2nemo_outputs(api, prec, tauoc):
+    """LWNEMOCOU: the 13 WAVE2OCEAN members (always double) -- instantaneous NPHIEPS/NTAUOC/NSWH/NMWP/NEMO*STOKES and the
+    accumulating NEMOTAUX/Y, NEMOWSWAVE, NEMOPHIF (wnfluxes.F90:304-328, stokestrn.F90:75-88) -- over two consecutive calls."""
+    cfg = Config(nang=24, nfre=36, nfre_red=29, lwnemocou=True, lwnemotauoc=tauoc)
+    n = 768
+    case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=31)
+    rng = np.random.default_rng(8)
+    case["FF"][:, 2] = np.where(rng.uniform(size=n) < 0.3, rng.uniform(0.0, 1.0, n), 0.0).astype(H.np_dtype(prec))
+    w0 = rng.uniform(-1.0, 1.0, (n, 13))
+    o = _oracle(cfg, prec)
+    pr = case["props"]
+    r1 = o.implsch(case["FL1"], pr["WAVNUM"], pr["CGROUP"], pr["CINV"], pr["XK2CG"], pr["STOKFAC"], case["ENV"], case["FF"],
+                   case["INTF"], w2n=w0)
+    r2 = o.implsch(r1["FL1"], pr["WAVNUM"], pr["CGROUP"], pr["CINV"], pr["XK2CG"], pr["STOKFAC"], case["ENV"], r1["FF"],
+                   r1["INTF"], w2n=r1["W2N"])
+    ctx = api.HipContext(case["tables"])
+    dev = ctx.device
+    wv, ff, intf = H.pack_device_inputs(case)
+    fl1 = torch.from_numpy(case["FL1"].copy()).to(dev)
+    twv, tff, tintf = (torch.from_numpy(a).to(dev) for a in (wv, ff, intf))
+    mij = torch.zeros(n, dtype=torch.int32, device=dev)
+    xllws = torch.zeros_like(fl1)
+    w = torch.from_numpy(w0.copy()).to(dev)
+    with pytest.raises(api.EcwamHipError):
+        ctx.implsch(0, n, fl1, twv, tff, tintf, mij, xllws)          # LWNEMOCOU without the buffer is an error
+    for _ in range(2):
+        ctx.implsch(0, n, fl1, twv, tff, tintf, mij, xllws, wam2nemo=w)
+    torch.cuda.synchronize()
+    got, want = w.cpu().numpy(), r2["W2N"]
+    ctx.close()
+    assert np.array_equal(got[:, [2, 9, 10]], want[:, [2, 9, 10]])    # NEMOSTRN, NEMOTAUICX/Y: carried through untouched
+    tol = 1e-10 if prec == "dp" else 2e-4
+    scale = np.maximum(np.abs(want).max(axis=0, keepdims=True), 1e-12)
+    assert np.max(np.abs(got - want) / scale) < tol, np.max(np.abs(got - want) / scale, axis=0)
+    assert np.max(np.abs(want[:, 7] - w0[:, 7])) > 0 and np.max(np.abs(want[:, 5] - w0[:, 5])) > 0
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
 def test_implsch_edge_cases(api, prec):
     """empty range, single point, ice-covered and very shallow points, tiny and huge spectra"""
     cfg = Config(nang=24, nfre=36, nfre_red=29)

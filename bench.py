@@ -139,6 +139,7 @@ def main() -> None:
         el, t_prop, t_impl = (float(x) for x in tt.cpu())
     swh = m.swh()
     finite = bool(torch.isfinite(swh).all().item())
+    swh_avg, swh_min, swh_max, _ = m.swh_norm()      # OUTWNORM of the significant wave height, computed on the device
 
     if rank == 0:
         w = 4 if a.prec == "sp" else 8
@@ -176,6 +177,7 @@ def main() -> None:
                          "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic},
             "kernels": kern,
             "finite": finite,
+            "swh_norm_rank0": {"avg": swh_avg, "min": swh_min, "max": swh_max},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.nang, a.nfre, a.prec)

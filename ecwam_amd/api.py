@@ -141,6 +141,24 @@ class HipContext:
             pw = wam2nemo.data_ptr()
         self._chk(self.lib.ecwam_hip_implsch(self._h, kijs, kijl, *a, pw, pd, _stream_ptr()))
 
+    # -- OUTBS subset (outblock.F90 parameters 1-3) and OUTWNORM statistics, on the device
+    def outbs(self, kijs, kijl, fl1, out, zmiss: float = -999.0):
+        nrow = fl1.shape[0]
+        if not (0 <= kijs <= kijl <= min(nrow, out.shape[0])):
+            raise ValueError("OUTBS: KIJS/KIJL outside the operands")
+        self._chk(self.lib.ecwam_hip_outbs(self._h, kijs, kijl, self._real(fl1, (nrow, self.NANG, self.NFRE), "FL1"), float(zmiss),
+                                           self._real(out, (out.shape[0], 4), "OUT"), _stream_ptr()))
+
+    def outwnorm(self, field, column: int, n: int, zmiss: float = -999.0):
+        """(average, minimum, maximum, count) of field[:n, column] over the values != zmiss."""
+        if not (field.is_cuda and field.dtype == self.dtype and field.is_contiguous() and field.dim() == 2 and n <= field.shape[0]):
+            raise ValueError("OUTWNORM: expected a contiguous 2-D cuda tensor in the working precision")
+        import ctypes as C
+        res = (C.c_double * 4)()
+        ptr = field.data_ptr() + column * field.element_size()
+        self._chk(self.lib.ecwam_hip_outwnorm(self._h, ptr, field.shape[1], n, float(zmiss), res, _stream_ptr()))
+        return tuple(res)
+
     # -- NEWWIND (newwind.F90:126-161)
     def newwind(self, ff, ff_next):
         n = ff.shape[0]

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libecwam_hip.so")
-SOURCES = ["capi.hip", "propag.hip", "implsch.hip"]
+SOURCES = ["capi.hip", "propag.hip", "implsch.hip", "outbs.hip"]
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # IMPLSCH is VALU-issue bound: single-precision divide/sqrt by the hardware reciprocal / square root plus one
 # refinement (<= 2.5 ulp) instead of the correctly rounded sequences; double precision is unaffected.

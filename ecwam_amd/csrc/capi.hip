@@ -31,6 +31,8 @@ struct ecwam_hip_ctx {
 template <typename T> void launch_propags2(const void*, const void*, void*, const int*, const int*, const int*, const void*, int, int, int, int, int, int, hipStream_t);
 template <typename T> void launch_ctuw(const void*, int, int, int, double, int, int, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, void*, void*, const void*, const void*, void*, int*, int, hipStream_t);
 template <typename T> void launch_propags2_otf(const void*, const void*, void*, int, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const int*, int, int, int, int, int, int, hipStream_t);
+template <typename T> int launch_outbs(const void*, int, int, const void*, double, void*, int, int, hipStream_t);
+template <typename T> void launch_norm(const void*, int, int, double, double*, int, hipStream_t);
 template <typename T> void launch_newwind(const void*, int, void*, const void*, hipStream_t);
 template <typename T> void launch_c2p(const void*, void*, int, int, int, int, int, hipStream_t);
 template <typename T> void launch_p2c(const void*, void*, int, int, int, int, int, hipStream_t);
@@ -290,6 +292,35 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
            rc = launch_implsch<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s));
   if (rc) return fail("ecwam_hip_implsch: unsupported spectral size for the LDS tiling");
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ecwam_hip_outbs(ecwam_hip_ctx* c, int kijs, int kijl, const void* fl1, double zmiss, void* out, void* stream) {
+  if (!c) return fail("null context");
+  if (kijl < kijs || kijs < 0) return fail("ecwam_hip_outbs: bad range");
+  if (kijl > kijs && (!fl1 || !out)) return fail("ecwam_hip_outbs: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  DISPATCH(rc = launch_outbs<float>(c->dtab, kijs, kijl, fl1, zmiss, out, c->NANG, c->NFRE, s),
+           rc = launch_outbs<double>(c->dtab, kijs, kijl, fl1, zmiss, out, c->NANG, c->NFRE, s));
+  if (rc) return fail("ecwam_hip_outbs: unsupported spectral size");
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ecwam_hip_outwnorm(ecwam_hip_ctx* c, const void* field, int stride, int n, double zmiss, double* result, void* stream) {
+  if (!c) return fail("null context");
+  if (n < 0 || stride < 1 || !result || (n > 0 && !field)) return fail("ecwam_hip_outwnorm: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = 256;
+  double* scratch = nullptr;
+  HIPCHK(hipMalloc(&scratch, (size_t)(4 + 4 * nb) * sizeof(double)));
+  DISPATCH(launch_norm<float>(field, stride, n, zmiss, scratch, nb, s), launch_norm<double>(field, stride, n, zmiss, scratch, nb, s));
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(result, scratch, 4 * sizeof(double), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(scratch);
+  HIPCHK(e);
   return 0;
 }
 

@@ -176,6 +176,15 @@ class Wamintgr:
         if source:
             self.implsch()
 
+    # ---- OUTBS subset on the device: [n][4] = swh, mean direction, mean period, EM; norms = OUTWNORM (avg, min, max, count)
+    def outbs(self) -> torch.Tensor:
+        out = torch.zeros((self.n, 4), dtype=self.dtype, device=self.dev)
+        self.ctx.outbs(0, self.n, self.fl1, out)
+        return out
+
+    def swh_norm(self):
+        return self.ctx.outwnorm(self.outbs(), 0, self.n)
+
     # ---- diagnostics used by tests/bench (swh = 4 sqrt(EM), outbs.F90 / semean.F90)
     def swh(self) -> torch.Tensor:
         dfim = torch.from_numpy(np.asarray(self.t.DFIM, dtype=np.float64)).to(self.dev)

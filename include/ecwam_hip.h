@@ -168,6 +168,16 @@ int ecwam_hip_propags2_otf(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n, 
 int ecwam_hip_implsch(ecwam_hip_ctx *ctx, int kijs, int kijl, void *fl1, const void *wvprpt, void *ff, void *intf, int *mij,
                       void *xllws, double *wam2nemo, void *dbg, void *stream);
 
+/*
+ * Integrated output parameters without a spectrum copy-back (the device-side part of OUTBS: outblock.F90:204,223-243,
+ * LSECONDORDER=F) for rows [kijs,kijl):  out[npts][4] = significant wave height 4*SQRT(EM) (FEMEAN), mean direction in
+ * degrees / meteorological convention (STHQ), mean period 1/FM or zmiss, EM.
+ * ecwam_hip_outwnorm: the OUTWNORM statistics of one such field: result[4] (HOST doubles) = average, minimum, maximum over the
+ * n values field[i*stride] that differ from zmiss, and their count (outwnorm.F90).  Synchronises the stream.
+ */
+int ecwam_hip_outbs(ecwam_hip_ctx *ctx, int kijs, int kijl, const void *fl1, double zmiss, void *out, void *stream);
+int ecwam_hip_outwnorm(ecwam_hip_ctx *ctx, const void *field, int stride, int n, double zmiss, double *result, void *stream);
+
 /* NEWWIND forcing hand-over (newwind.F90:126-161, ICODE_WND=3): FF <- FF_NEXT members + TAUW cap */
 int ecwam_hip_newwind(ecwam_hip_ctx *ctx, int n, void *ff, const void *ff_next, void *stream);
 

@@ -42,6 +42,7 @@ typedef float real;
 #define ATAN atanf
 #define ACOS acosf
 #define POW powf
+#define FMOD fmodf
 #define FABS fabsf
 #define NINT(x) ((int)lroundf(x))
 #define FLOORI(x) ((int)floorf(x))
@@ -55,6 +56,7 @@ typedef double real;
 #define EXP exp
 #define LOG log
 #define LOG10 log10
+#define FMOD fmod
 #define SQRT sqrt
 #define ATAN2 atan2
 #define ATAN atan

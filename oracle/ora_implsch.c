@@ -1312,3 +1312,38 @@ void ora_newwind(int n, real *FF, const real *FFN) {
     f[1] = g[1]; f[0] = g[0]; f[4] = g[4]; f[2] = g[2]; f[13] = g[13]; f[5] = g[5]; f[6] = g[6];
   }
 }
+
+/* outblock.F90:204,223-243 for the parameters 1-3 (LSECONDORDER = F: FL2ND = FL1): FEMEAN (femean.F90:84-121), STHQ
+ * (sthq.F90:75-120).  OUT [n][4] = SWH, MWD (degrees, meteorological convention), MWP (or ZMISS), EM. */
+void ora_outbs(int n, const real *FL1a, real ZMISS, real *OUT) {
+  const int NANG = S.NANG, NFRE = S.NFRE;
+#pragma omp parallel for schedule(static)
+  for (int ij = 0; ij < n; ij++) {
+    const real *FL1 = FL1a + (size_t)ij * NANG * NFRE;
+    real EM = C_(0.0), FM = C_(0.0), TEMP2 = C_(0.0), SI = C_(0.0), CI = C_(0.0), THQ;
+    for (int M = 0; M < NFRE; M++) {
+      TEMP2 = RMAX(F(0, M), S.EPSMIN);
+      for (int K = 1; K < NANG; K++) TEMP2 = TEMP2 + RMAX(F(K, M), S.EPSMIN);
+      EM = EM + TEMP2 * S.DFIM[M];
+      FM = FM + S.DFIMOFR[M] * TEMP2;
+    }
+    EM = EM + S.WETAIL * S.FR[NFRE - 1] * S.DELTH * TEMP2;
+    FM = FM + S.FRTAIL * S.DELTH * TEMP2;
+    FM = EM / FM;
+    FM = RMAX(FM, S.FR[0]);
+    for (int K = 0; K < NANG; K++) {
+      real TEMP = C_(0.0);
+      for (int M = 0; M < NFRE; M++) TEMP = TEMP + F(K, M) * S.DFIM[M];
+      SI = SI + S.SINTH[K] * TEMP;
+      CI = CI + S.COSTH[K] * TEMP;
+    }
+    if (CI == C_(0.0)) CI = S.EPSMIN;
+    THQ = ATAN2(SI, CI);
+    if (THQ < C_(0.0)) THQ = THQ + S.ZPI;
+    real *o = OUT + (size_t)ij * 4;
+    o[0] = C_(4.0) * SQRT(RMAX(EM, C_(0.0)));
+    o[1] = FMOD(S.DEG * THQ + C_(180.0), C_(360.0));
+    o[2] = (FM > C_(0.0)) ? C_(1.0) / FM : ZMISS;
+    o[3] = EM;
+  }
+}

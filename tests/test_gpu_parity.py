@@ -455,3 +455,37 @@ def test_decomposed_step_is_bit_identical_on_device(api, prec, weights):
     assert np.array_equal(torch.cat([m.mij for m in parts]).cpu().numpy(), ref.mij.cpu().numpy())
     for m in parts + [ref]:
         m.ctx.close()
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+def test_outbs_parameters_and_norms(api, prec):
+    """Device-side OUTBS subset: swh / mean direction / mean period per point against the oracle's
+    FEMEAN + STHQ restatement, and the OUTWNORM statistics against numpy, with missing values."""
+    cfg = Config(nang=36, nfre=36, nfre_red=36)
+    n = 3001
+    case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=17)
+    case["FL1"][5] = 0.0                                   # empty spectrum: EPSMIN floor everywhere
+    ref = _oracle(cfg, prec).outbs(case["FL1"])
+    ctx = api.HipContext(case["tables"])
+    dev = ctx.device
+    fl1 = torch.from_numpy(case["FL1"]).to(dev)
+    out = torch.full((n, 4), -1.0, dtype=fl1.dtype, device=dev)
+    ctx.outbs(7, n - 3, fl1, out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.all(got[:7] == -1.0) and np.all(got[n - 3:] == -1.0)
+    g, r = got[7:n - 3].astype(float), ref[7:n - 3].astype(float)
+    tol = 1e-12 if prec == "dp" else 2e-6
+    assert np.max(np.abs(g[:, 0] - r[:, 0]) / np.maximum(r[:, 0], 1e-3)) < tol            # swh
+    assert np.max(np.abs(g[:, 2] - r[:, 2]) / r[:, 2]) < tol                                # mean period
+    dd = np.abs(g[:, 1] - r[:, 1]); dd = np.minimum(dd, 360.0 - dd)                         # direction, cyclic
+    assert np.max(dd) < (1e-9 if prec == "dp" else 2e-2)
+    # norms, with missing values
+    out[11:40, 2] = -999.0
+    avg, mn, mx, cnt = ctx.outwnorm(out, 2, n)
+    col = out[:, 2].cpu().numpy().astype(float)
+    ok = col != -999.0
+    assert cnt == ok.sum() and mn == col[ok].min() and mx == col[ok].max()
+    assert abs(avg - col[ok].mean()) < 1e-12 * max(1.0, abs(avg))
+    assert ctx.outwnorm(out, 0, 0)[3] == 0
+    ctx.close()

@@ -132,6 +132,60 @@ def test_oracle_physics_invariants():
             assert np.all((np.abs(fl[ij, :, m:] - tail) <= 1e-12 * tail + 1e-30) | (fl[ij, :, m:] >= tail))
 
 
+def test_oracle_optional_branches_invariants():
+    """The optional branches the device also implements, checked on the oracle alone (CPU): flag set B runs and differs
+    from A; sea-ice attenuation only removes energy and only under ice; the NEMO accumulators add up linearly; the OUTBS
+    subset is consistent with SEMEAN-type integrals; strip work order is a permutation with better neighbour locality."""
+    from oracle.oracle import Oracle
+
+    base = dict(nang=24, nfre=36, nfre_red=29)
+    n = 300
+    cfg_a = Config(**base)
+    case = H.make_point_case(n, cfg_a, "dp", spectra="mixed", seed=5)
+    rng = np.random.default_rng(2)
+    case["FF"][:, 2] = np.where(rng.uniform(size=n) < 0.5, rng.uniform(0.05, 0.29, n), 0.0)   # partial ice below the mask threshold
+    case["FF"][:, 13] = rng.uniform(0.5, 3.0, n)
+    ra = H.oracle_implsch(case, Oracle(cfg_a, "dp"))
+    # flag set B
+    cfg_b = Config(llgcbz0=True, llnormagam=True, **base)
+    cb = dict(case); cb["cfg"] = cfg_b; cb["tables"] = Tables(cfg_b, np.float64)
+    rb = H.oracle_implsch(cb, Oracle(cfg_b, "dp"))
+    assert np.isfinite(rb["FL1"]).all() and np.isfinite(rb["FF"]).all()
+    assert np.max(np.abs(rb["FF"][:, 7] - ra["FF"][:, 7]) / ra["FF"][:, 7]) > 1e-3          # UFRIC from the other roughness model
+    # sea-ice attenuation
+    dfim = np.asarray(case["tables"].DFIM, dtype=float)
+    ice = case["FF"][:, 2] > 0
+    ea = (ra["FL1"].sum(1) * dfim).sum(1)
+    for flags, monotone in ((dict(lciwa3=True), True), (dict(lciwa3=True, lciscal=True), False)):
+        cfg_i = Config(**flags, **base)
+        ci = dict(case); ci["cfg"] = cfg_i; ci["tables"] = Tables(cfg_i, np.float64)
+        ri = H.oracle_implsch(ci, Oracle(cfg_i, "dp"))
+        ei = (ri["FL1"].sum(1) * dfim).sum(1)
+        assert np.array_equal(ri["FL1"][~ice], ra["FL1"][~ice])                               # no ice: untouched
+        assert np.any(np.abs(ei[ice] - ea[ice]) > 1e-6 * ea[ice])
+        if monotone:   # a pure attenuation term only removes energy (LCISCAL also scales the dissipation down)
+            assert np.all(ei[ice] <= ea[ice] * (1 + 1e-12)) and np.any(ei[ice] < ea[ice] * 0.999)
+    # NEMO accumulators
+    cfg_n = Config(lwnemocou=True, **base)
+    o = Oracle(cfg_n, "dp")
+    pr = case["props"]
+    args = (pr["WAVNUM"], pr["CGROUP"], pr["CINV"], pr["XK2CG"], pr["STOKFAC"], case["ENV"])
+    w0 = np.zeros((n, 13))
+    r1 = o.implsch(case["FL1"], *args, case["FF"], case["INTF"], w2n=w0)
+    r1b = o.implsch(case["FL1"], *args, case["FF"], case["INTF"], w2n=r1["W2N"])
+    assert np.allclose(r1b["W2N"][:, [7, 8, 11, 12]], 2 * r1["W2N"][:, [7, 8, 11, 12]], rtol=1e-13, atol=0)
+    assert np.array_equal(r1b["W2N"][:, 3:7], r1["W2N"][:, 3:7]) and np.all(r1["W2N"][:, 5] > 0)
+    assert np.allclose(r1["W2N"][:, 0], r1["INTF"][:, 2]) and np.allclose(r1["W2N"][:, 1], r1["INTF"][:, 3])
+    # OUTBS subset
+    ob = Oracle(cfg_a, "dp").outbs(case["FL1"])
+    assert np.allclose(ob[:, 0], 4 * np.sqrt(ob[:, 3])) and np.all((ob[:, 1] >= 0) & (ob[:, 1] < 360)) and np.all(ob[:, 2] > 0)
+    # strip order
+    g = G.build_grid(24, mask="continents")
+    d = decomp.local_domain(g, 0, 1)
+    order = decomp.strip_order(g, d, 32)
+    assert sorted(order.tolist()) == list(range(d.n))
+
+
 GLOO_WORKER = r'''
 import os, sys
 import numpy as np, torch, torch.distributed as dist

@@ -60,6 +60,23 @@ def test_grid_counts_and_neighbours():
     assert 0.0 < g.wlat.min() and g.wlat.max() <= 1.0 and 0.0 <= g.wcor.min() and g.wcor.max() <= 1.0
 
 
+@pytest.mark.parametrize("name", ["O48", "O320", "O640"])
+def test_grid_matches_reference_grid_description(name):
+    """Golden vectors produced by the reference's own grid script (tools/make_golden_grid.py ran
+    share/ecwam/scripts/ecwam_grids.py here): resolution, first latitude, east-most longitude, ny and every row length of
+    the octahedral grids of the BASELINE configurations against ecwam_amd.grid."""
+    f = os.path.join(ROOT, "tests", "golden", f"grid_description_{name}.txt")
+    v = open(f).read().split()
+    n, north, south, west, east, iper, irgg, ny = int(v[0]), float(v[1]), float(v[2]), float(v[3]), float(v[4]), int(v[5]), int(v[6]), int(v[7])
+    rows = np.array([int(x) for x in v[8:8 + ny]])
+    g = G.build_grid(n)
+    assert g.ngy == ny == 2 * n and iper == 1 and irgg == 1 and west == 0.0
+    assert np.array_equal(np.asarray(g.nlonrgg), rows)
+    assert abs(float(g.amosop) - south) < 1e-12 and abs(float(g.xdella) - (north - south) / (ny - 1)) < 1e-12
+    assert abs(360.0 - 360.0 / rows.max() - east) < 1e-9
+    assert g.nsea == G.nsea_aqua(n)
+
+
 @pytest.mark.parametrize("nranks", [1, 2, 3, 8])
 def test_decomposition_consistency(nranks):
     g = G.build_grid(24, mask="continents")

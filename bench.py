@@ -164,6 +164,18 @@ def main() -> None:
                 pm = json.load(fh).get(dom, {})
             if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
                 traffic = 1024.0 * ((2.0 if dom == "propags2" else 1.0) * pm["FETCH_SIZE"] + pm["WRITE_SIZE"])
+        # IMPLSCH is bound by the vector-ALU issue rate, not by HBM or MFMA (SURVEY.md 8d asks for this figure next to the HBM
+        # fraction): busy fraction of the SIMD time from the committed PMC pass, wave instructions per point and the issue-rate
+        # ceiling they imply (256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz)
+        valu = None
+        pf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_implsch_pmc.json")
+        if os.path.exists(pf) and a.prec == "sp":
+            with open(pf) as fh:
+                pm = json.load(fh)
+            ceil_pts = 256 * 4 * 2.4e9 / 4.0 / (pm["SQ_ACTIVE_INST_VALU_quadcycles"])
+            valu = {"kernel": "implsch", "valu_busy_fraction_pmc": pm["valu_busy_fraction"],
+                    "valu_insts_per_point": pm["SQ_INSTS_VALU"], "issue_ceiling_points_per_s": ceil_pts,
+                    "achieved_points_per_s": m.n / (t_impl * 1e-3), "frac_of_issue_ceiling": m.n / (t_impl * 1e-3) / ceil_pts}
         out = {
             "metric": "grid-point spectral steps/sec (whole node) at O320, 36dir x 36freq",
             "value": grid.nsea * a.steps / el, "unit": "grid-point spectral steps/s", "n_gpus": world, "steps": a.steps,
@@ -176,6 +188,7 @@ def main() -> None:
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic},
             "kernels": kern,
+            "valu": valu,
             "finite": finite,
             "swh_norm_rank0": {"avg": swh_avg, "min": swh_min, "max": swh_max},
         }

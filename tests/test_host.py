@@ -35,6 +35,31 @@ def test_c_abi_exports_every_declared_symbol():
     assert a == ctypes.sizeof(lib.Params) and b == ctypes.sizeof(lib.TablePtrs)
 
 
+def test_create_refuses_unsupported_configurations_without_a_gpu():
+    """Error convention of the boundary: int status + ecwam_hip_last_error(); the configuration checks of
+    ecwam_hip_create run before any HIP call, so they are testable here."""
+    import ctypes as C
+    from ecwam_amd import lib
+
+    h = lib.load()
+    t = Tables(Config(nang=12, nfre=36, nfre_red=25), np.float32)
+    tp, keep = lib.make_tables(t)
+    cases = [(dict(lciwa1=1), "SDICE1"), (dict(iphys=0), "IPHYS"), (dict(irefra=2), "IREFRA"), (dict(lwnemocouwrs=1), "LWNEMOCOUWRS"),
+             (dict(nang=3), "NANG"), (dict(nfre_red=40), "NFRE_RED")]
+    for changes, word in cases:
+        p = lib.make_params(t)
+        for k, v in changes.items():
+            setattr(p, k, v)
+        ctx = C.c_void_p()
+        rc = h.ecwam_hip_create(C.byref(p), C.byref(tp), 4, 0, C.byref(ctx))
+        assert rc != 0 and not ctx.value
+        msg = h.ecwam_hip_last_error().decode()
+        assert word in msg, (word, msg)
+    p = lib.make_params(t)
+    assert h.ecwam_hip_create(C.byref(p), C.byref(tp), 2, 0, C.byref(C.c_void_p())) != 0      # real_bytes must be 4 or 8
+    assert h.ecwam_hip_create(None, C.byref(tp), 4, 0, C.byref(C.c_void_p())) != 0
+
+
 def test_product_never_imports_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "ecwam_amd")):
         for f in files:

@@ -587,6 +587,122 @@ __device__ void sinput_ard2(const DevTab<T>& tb, const T* sF, T* sFLD, const Lan
   }
 }
 
+// The second SINFLX call (NGST = 2, LLSNEG = T) for LLNORMAGAM = F with sheltering: the two gust states are the two
+// halves of packed-fp32 operands (v_pk_mul/add/fma_f32 on T = float), branch-free per lane, so that one instruction
+// advances both.  Same operations per component as sinput_ard2 above; outputs identical.
+template <typename T>
+__device__ void sinput_ard2_pk(const DevTab<T>& tb, const T* sF, T* sFLD, const Lane<T>& L, T rWAVNUM, T rCINV, T UFRIC, T Z0M,
+                               T RAORW, T SIG_N, T TEMP2, T PTURB, T AIRD_PVISC, T sinwd, T coswd, unsigned long long& xmask,
+                               T& rX, T& rY, T& rS, T& apl, T& wsae, T& wsaf, T& wslast) {
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  const T AVG_GST = T(0.5);
+  const T CONST1 = tb.BETAMAXOXKAPPA2;
+  const T ABS_TAUWSHELTER = m_abs(tb.TAUWSHELTER);
+  const T NU_AIR = tb.RNU;
+  const T FU = m_abs(tb.SWELLF3), FUD = tb.SWELLF2;
+  V2 USTP = {UFRIC * (T(1) + SIG_N), UFRIC * (T(1) - SIG_N)};
+  V2 XS = {T(0), T(0)}, YS = {T(0), T(0)};
+  const V2 USG2 = USTP * USTP;
+  const V2 TAUX = USG2 * sinwd, TAUY = USG2 * coswd;
+  const T ROGOROAIR = tb.G / RAORW;
+  const T sinthk = tb.SINTH[L.k], costhk = tb.COSTH[L.k];
+  const T actf = L.act ? T(1) : T(0);
+  xmask = 0ull;
+  rX = T(0); rY = T(0); rS = T(0); apl = T(0);
+  wsae = T(0); wsaf = T(0); wslast = T(0);
+  T rZCN = T(0), rCNSN = T(0), rCONSTF = T(0), rTEMP1 = T(0), rDSTAB1 = T(0);
+  if (L.actm) {
+    const T SIG = L.rZPIFR;
+    rZCN = m_log(rWAVNUM * Z0M);
+    rCNSN = (SIG * CONST1) * RAORW;
+    rCONSTF = ROGOROAIR * rCINV * L.rDFIM;
+    const T COEF5 = -tb.SWELLF5 * T(2) * m_sqrt(T(2) * NU_AIR * SIG);
+    rDSTAB1 = COEF5 * AIRD_PVISC * rWAVNUM;
+    rTEMP1 = (-tb.SWELLF * T(16) * (SIG * SIG) / tb.G) * RAORW;
+  }
+  T spq[4] = {T(0), T(0), T(0), T(0)};
+  bool growq = false;
+  for (int m = 0; m < L.NFRE; m++) {
+    const T cinv_m = lane_get(rCINV, m);
+    // sheltered friction velocity and stress direction of both gust states (sinput_ard.F90:356-372)
+    const V2 TAUPX = TAUX - ABS_TAUWSHELTER * XS, TAUPY = TAUY - ABS_TAUWSHELTER * YS;
+    const V2 h2 = TAUPX * TAUPX + TAUPY * TAUPY;
+    V2 h, rh;
+    if (sizeof(T) == 4) { rh.x = f_rsq(h2.x); rh.y = f_rsq(h2.y); h = h2 * rh; }
+    else { h.x = f_sqrt(h2.x); h.y = f_sqrt(h2.y); rh.x = f_rcp(h.x); rh.y = f_rcp(h.y); }
+    V2 COSU = TAUPY * rh, SINU = TAUPX * rh;
+    if (!(h2.x > T(0)) || !(h2.y > T(0))) {  // vanishing stress (wave-uniform, practically never): the reference's limits
+      if (!(h2.x > T(0))) { h.x = T(0); COSU.x = T(1); SINU.x = T(0); }
+      if (!(h2.y > T(0))) { h.y = T(0); COSU.y = T(1); SINU.y = T(0); }
+    }
+    USTP.x = f_sqrt(h.x); USTP.y = f_sqrt(h.y);
+    const T CONSTF = lane_get(rCONSTF, m);
+    const V2 UCN = USTP * cinv_m;
+    const V2 den = UCN + tb.ZALP;
+    const V2 UCNZALPD = {tb.XKAPPA * f_rcp(den.x), tb.XKAPPA * f_rcp(den.y)};
+    const T ZCN = lane_get(rZCN, m), CNSN = lane_get(rCNSN, m), DSTAB1 = lane_get(rDSTAB1, m), TEMP1 = lane_get(rTEMP1, m);
+    const T f = sF[m * L.NAP + L.k];
+    const V2 coslp = costhk * COSU + sinthk * SINU;
+    const bool pos0 = coslp.x > T(0.01), pos1 = coslp.y > T(0.01);
+    const V2 rc = {f_rcp(coslp.x), f_rcp(coslp.y)};
+    const V2 ZLOG = ZCN + UCNZALPD * rc;
+    const bool neg0 = pos0 && ZLOG.x < T(0), neg1 = pos1 && ZLOG.y < T(0);
+    const bool anygrow = __builtin_amdgcn_ballot_w64(neg0 || neg1) != 0ull;
+    V2 gam0 = {T(0), T(0)};
+    if (anygrow) {
+      const V2 ZLOG2X = ZLOG * ZLOG * (coslp * UCN);
+      const V2 e = {f_exp(ZLOG.x), f_exp(ZLOG.y)};
+      const V2 g = e * ZLOG2X * ZLOG2X * CNSN;
+      gam0.x = neg0 ? g.x : T(0);
+      gam0.y = neg1 ? g.y : T(0);
+    }
+    const V2 DSTAB2 = TEMP1 * (TEMP2 + (FU + FUD * coslp) * USTP);
+    const V2 dstab = DSTAB1 + PTURB * DSTAB2;
+    const V2 FLP = gam0 + dstab;
+    const V2 SLP = gam0 * f;
+    const T SLP_AVG = SLP.x + SLP.y, FLP_AVG = FLP.x + FLP.y;
+    const T spos = AVG_GST * SLP_AVG, fld = AVG_GST * FLP_AVG;
+    if (anygrow) {
+      const V2 sa = SLP * actf;
+      const V2 sx = sa * sinthk, sy = sa * costhk;
+      T xs0, ys0, xs1, ys1;
+      usum4(sx.x, sy.x, sx.y, sy.y, xs0, ys0, xs1, ys1);
+      const V2 xs = {xs0, xs1}, ys = {ys0, ys1};
+      XS = XS + CONSTF * xs;
+      YS = YS + CONSTF * ys;
+      lane_put(rX, L.lane, m, AVG_GST * (xs.x + xs.y));
+      lane_put(rY, L.lane, m, AVG_GST * (ys.x + ys.y));
+    }
+    {
+      const int q = m & 3;
+      spq[0] = spq[1]; spq[1] = spq[2]; spq[2] = spq[3];
+      spq[3] = (anygrow && L.act) ? spos : T(0);
+      growq = growq || anygrow;
+      if (q == 3 || m == L.NFRE - 1) {
+        if (growq) {
+          T s0, s1, s2, s3;
+          usum4(spq[0], spq[1], spq[2], spq[3], s0, s1, s2, s3);
+          if (q >= 3) lane_put(rS, L.lane, m - 3, s0);
+          if (q >= 2) lane_put(rS, L.lane, m - 2, s1);
+          if (q >= 1) lane_put(rS, L.lane, m - 1, s2);
+          lane_put(rS, L.lane, m, s3);
+        }
+        growq = false;
+      }
+    }
+    apl = apl + (fld * f - spos) * tb.RHOWG_DFIM[m];
+    if (L.act) sFLD[m * L.NAP + L.k] += fld;
+    const bool xl = neg0 || neg1;
+    if (xl) xmask |= (1ull << m);
+    {
+      const T x = xl ? f : T(0);
+      wsae += lane_get(L.rDFIM, m) * x;
+      wsaf += lane_get(L.rDFIMOFR, m) * x;
+      wslast = x;
+    }
+  }
+}
+
 // femeanws.F90:103-123 from the per-direction integrands gathered in SINPUT
 template <typename T>
 __device__ __forceinline__ void femeanws_finish(const DevTab<T>& tb, const Lane<T>& L, T ae, T af, T last, T& FM, T& EMW) {
@@ -1049,8 +1165,14 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
 
   // ---- second SINFLX call: FLD, XLLWS, MIJ, wave stress and the PHIWA integrals
   if (!(SKIP & 1))
-    sinput_ard2<T, 2, true, NORMA>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, WDWAVE, UFRIC, Z0M, coswdif, sinwdif2, RAORW, RNFAC,
-                                   c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], sinwd, coswd, xmask, rX, rY, rS, apl, wsae, wsaf, wslast);
+  {
+    if (!NORMA && tb.TAUWSHELTER != T(0))
+      sinput_ard2_pk<T>(tb, sF, sFLD, L, rWAVNUM, rCINV, UFRIC, Z0M, RAORW, c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], sinwd,
+                        coswd, xmask, rX, rY, rS, apl, wsae, wsaf, wslast);
+    else
+      sinput_ard2<T, 2, true, NORMA>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, WDWAVE, UFRIC, Z0M, coswdif, sinwdif2, RAORW, RNFAC,
+                                     c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], sinwd, coswd, xmask, rX, rY, rS, apl, wsae, wsaf, wslast);
+  }
   else {
     rX = rY = rS = apl = wsae = wsaf = wslast = T(0);
   }

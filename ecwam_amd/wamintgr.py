@@ -176,6 +176,16 @@ class Wamintgr:
         if source:
             self.implsch()
 
+    # ---- restart spectra in the reference's file layout (writefl.F90:110-118, one record per rank)
+    def write_restart(self, path: str) -> None:
+        from . import restart
+        restart.write_fl(path, self.fl1[: self.n].cpu().numpy())
+
+    def read_restart(self, path: str) -> None:
+        from . import restart
+        a = restart.read_fl(path, self.n, self.cfg.nang, self.cfg.nfre, self.npdt)
+        self.fl1[: self.n] = torch.from_numpy(a).to(self.dev)
+
     # ---- OUTBS subset on the device: [n][4] = swh, mean direction, mean period, EM; norms = OUTWNORM (avg, min, max, count)
     def outbs(self) -> torch.Tensor:
         out = torch.zeros((self.n, 4), dtype=self.dtype, device=self.dev)

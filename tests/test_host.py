@@ -60,6 +60,36 @@ def test_create_refuses_unsupported_configurations_without_a_gpu():
     assert h.ecwam_hip_create(None, C.byref(tp), 4, 0, C.byref(C.c_void_p())) != 0
 
 
+def test_restart_spectra_file_layout(tmp_path, monkeypatch):
+    """writefl.F90:110-118 layout: one unformatted sequential record, FL(IJ,K,M) with IJ fastest; framed so that a Fortran
+    reader (checked with scipy.io.FortranFile, which implements the same 4-byte markers) sees it; sub-record splitting of
+    huge records exercised with a lowered limit."""
+    from scipy.io import FortranFile
+    from ecwam_amd import restart
+
+    rng = np.random.default_rng(0)
+    n, K, M = 37, 12, 25
+    fl = rng.uniform(0, 1, (n, K, M)).astype(np.float32)
+    f = str(tmp_path / "BLS_test")
+    restart.write_fl(f, fl)
+    restart.write_fl(f, 2 * fl, append=True)
+    with FortranFile(f, "r") as ff:
+        rec = ff.read_reals(dtype=np.float32)
+    assert rec.size == n * K * M
+    assert np.array_equal(rec.reshape(M, K, n)[3, 5, :], fl[:, 5, 3])          # IJ runs fastest in the record
+    assert np.array_equal(restart.read_fl(f, n, K, M, np.float32), fl)
+    assert np.array_equal(restart.read_fl(f, n, K, M, np.float32, record=1), 2 * fl)
+    with pytest.raises(ValueError):
+        restart.read_fl(f, n + 1, K, M, np.float32)
+    monkeypatch.setattr(restart, "_MAX_SUB", 1000)                                # force gfortran-style sub-records
+    g = str(tmp_path / "BLS_big")
+    fd = fl.astype(np.float64)
+    restart.write_fl(g, fd)
+    assert np.array_equal(restart.read_fl(g, n, K, M, np.float64), fd)
+    raw = open(g, "rb").read()
+    assert int(np.frombuffer(raw[:4], "<i4")[0]) == -1000 and int(np.frombuffer(raw[-4:], "<i4")[0]) < 0
+
+
 def test_product_never_imports_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "ecwam_amd")):
         for f in files:

@@ -527,3 +527,39 @@ def test_long_run_single_precision_tracks_oracle(api):
     uf = m.ff.cpu().numpy()[:, 7].astype(float)
     assert np.max(np.abs(uf - ff[:, 7]) / np.maximum(ff[:, 7], 1e-3)) < 5e-2
     m.ctx.close()
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+def test_implsch_three_tile_fallback_kernel(api, prec, monkeypatch):
+    """The three-tile kernel (variant 1) that serves DIA tables without the rotation structure stays correct: forced through
+    the diagnostics switch on a configuration that normally takes variant 2."""
+    monkeypatch.setenv("ECWAM_HIP_IMPLSCH_VARIANT", "1")
+    cfg = Config(nang=24, nfre=36, nfre_red=29)
+    n = 515
+    case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=41)
+    ref = H.oracle_implsch(case, _oracle(cfg, prec))
+    ctx = api.HipContext(case["tables"])
+    got = H.gpu_implsch(case, ctx)
+    st = H.compare_implsch(ref, got, case["tables"])
+    ctx.close()
+    if prec == "dp":
+        assert st["mij_flips"] == 0 and st["fl1_max_rel_peak_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
+    else:
+        assert st["mij_flips"] <= 3 and st["fl1_max_rel_peak_clean"] < 1e-4 and st["swh_max_rel"] < 1e-5, st
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+def test_implsch_parity_48_directions(api, prec):
+    """Largest supported direction count (48 lanes of the wavefront carry data): reductions and folds over rows 0-2."""
+    cfg = Config(nang=48, nfre=36, nfre_red=36)
+    n = 300
+    case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=43)
+    ref = H.oracle_implsch(case, _oracle(cfg, prec))
+    ctx = api.HipContext(case["tables"])
+    got = H.gpu_implsch(case, ctx)
+    st = H.compare_implsch(ref, got, case["tables"])
+    ctx.close()
+    if prec == "dp":
+        assert st["mij_flips"] == 0 and st["fl1_max_rel_peak_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
+    else:
+        assert st["mij_flips"] <= 2 and st["fl1_max_rel_peak_clean"] < 1e-4 and st["swh_max_rel"] < 1e-5, st

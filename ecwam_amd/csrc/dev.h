@@ -95,9 +95,21 @@ __device__ __forceinline__ int m_nint(double x) { return (int)lround(x); }
 // v_log, <= 1 ulp each, no range fix-up code: the arguments on these paths are bounded, see the call sites);
 // double precision keeps the library routines.  f_exp(x) = 2^(x*log2e): relative error <= |x|*1.2e-7.
 __device__ __forceinline__ float f_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
-__device__ __forceinline__ double f_div(double a, double b) { return a / b; }
+// double precision: hardware seed (v_rcp_f64 / v_rsq_f64, ~2^-26) + two Newton steps in FMA form: < 2 ulp, no IEEE
+// special-case sequence (div_scale/div_fmas/div_fixup).  Arguments on these paths are finite, non-zero and normal.
+__device__ __forceinline__ double f_rcp(double b);
+__device__ __forceinline__ double f_div(double a, double b) {
+  const double r = f_rcp(b);
+  const double q = a * r;
+  return fma(fma(-b, q, a), r, q);
+}
 __device__ __forceinline__ float f_rcp(float b) { return __builtin_amdgcn_rcpf(b); }
-__device__ __forceinline__ double f_rcp(double b) { return 1.0 / b; }
+__device__ __forceinline__ double f_rcp(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  return r;
+}
 __device__ __forceinline__ float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ double f_sqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ float f_rsq(float x) { return __builtin_amdgcn_rsqf(x); }

@@ -67,6 +67,10 @@ def load() -> C.CDLL:
     if not os.path.exists(LIBPATH):
         raise RuntimeError(f"{LIBPATH} not found: the HIP extension is not built (run `python -m ecwam_amd.build` or "
                            "__graft_entry__.build()); there is no CPU fallback")
+    # PyTorch-ROCm bundles its own HIP runtime (same SONAME as the system one the extension was linked against).  Whichever is
+    # mapped first serves the whole process, and two different copies cannot both own the devices: load torch's first so
+    # that device buffers, streams and our kernels live in ONE runtime, whatever order the caller imports things in.
+    import torch  # noqa: F401
     lib = C.CDLL(LIBPATH)
     lib.ecwam_hip_last_error.restype = C.c_char_p
     for name in EXPORTS[1:]:

@@ -135,9 +135,9 @@ class HipContext:
         pd = None if dbg is None else self._real(dbg, (nrow, 32), "DBG")
         pw = None
         if wam2nemo is not None:
-            if not (wam2nemo.is_cuda and wam2nemo.dtype == torch.float64 and wam2nemo.is_contiguous()
-                    and tuple(wam2nemo.shape) == (nrow if wam2nemo.shape[0] == nrow else wam2nemo.shape[0], 13) and wam2nemo.shape[0] >= kijl):
-                raise ValueError("WAM2NEMO: expected contiguous float64 cuda tensor [npts][13]")
+            if not (wam2nemo.is_cuda and wam2nemo.dtype == torch.float64 and wam2nemo.is_contiguous() and wam2nemo.dim() == 2
+                    and wam2nemo.shape[1] == 13 and wam2nemo.shape[0] >= kijl):
+                raise ValueError("WAM2NEMO: expected contiguous float64 cuda tensor [npts >= KIJL][13]")
             pw = wam2nemo.data_ptr()
         self._chk(self.lib.ecwam_hip_implsch(self._h, kijs, kijl, *a, pw, pd, _stream_ptr()))
 

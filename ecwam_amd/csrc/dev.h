@@ -22,7 +22,9 @@ struct DevTab {
   int LWNEMOTAUOC, LWNEMOCOUSEND, LWNEMOCOUSTK;
   int LCISCAL, LCIWA2, LCIWA3;  // sea-ice attenuation (implsch.F90:312-339, sdice2.F90, sdice3.F90)
   int NSDSNTH, NTAP, MFRSTLW, MLSTHG, KFRH, NWAV_GC;
-  int DBG_SKIP;  // timing diagnostics only (env ECWAM_HIP_DEBUG_SKIP): bit mask of IMPLSCH phases to skip
+  // timing diagnostics only (env ECWAM_HIP_DEBUG_SKIP): bit mask of IMPLSCH phases to skip -- 1 SINPUT, 2 STRESSO scalars,
+  // 4 SDISSIP, 8 DIA, 16 TAUT_Z0, 32 spectrum store of the update, 64 WSIGSTAR/swell set-up/SDIWBK.  0 in production.
+  int DBG_SKIP;
   T XIMP, G, GM1, PI, ZPI, ZPI4GM1, ZPI4GM2, EPSMIN, ROWATER, ROWATERM1, EPSUS, EPSU10, ACD, BCD, ACDLIN, BCDLIN, CDMAX;
   T TAUOCMIN, TAUOCMAX, PHIEPSMIN, PHIEPSMAX, WSEMEAN_MIN, CIRC, R;
   T FRATIO, WETAIL, FRTAIL, WP1TAIL, FRIC, DELTH, FLOGSPRDM1;

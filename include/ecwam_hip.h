@@ -22,7 +22,10 @@
  *                                    CHRNCK CITHICK (FORCING_FIELDS) + EMAXDPT DEPTH (ENVIRONMENT)
  *   INTF      [ij][16]               WSEMEAN WSFMEAN USTOKES VSTOKES STRNMS TAUXD TAUYD TAUOCXD TAUOCYD TAUOC
  *                                    TAUICX TAUICY PHIOCD PHIEPS PHIAW (INTGT_PARAM_FIELDS) + 1 pad
- *   weights   W[ij][8][NANG*NFRE_RED] the 8 CTU weights PROPAGS2 reads when IREFRA=0 (propags2.F90:107-116):
+ *   WAM2NEMO  double[ij][13]         NEMOUSTOKES NEMOVSTOKES NEMOSTRN NPHIEPS NTAUOC NSWH NMWP NEMOTAUX NEMOTAUY NEMOTAUICX
+ *                                    NEMOTAUICY NEMOWSWAVE NEMOPHIF (WAVE2OCEAN, always double = JWRO); only with LWNEMOCOU
+ *   weights   W[ij][8][NANG*NFRE_RED] OPTIONAL (ecwam_hip_propags2_otf needs none): the 8 CTU weights PROPAGS2 reads when
+ *                                    IREFRA=0 (propags2.F90:107-116):
  *                                    SUMWN, WLONN(JXO(K,1)), WLATN(JYO(K,1),1), WLATN(JYO(K,1),2),
  *                                    WCORN(1,1), WCORN(1,2), WKPMN(-1), WKPMN(+1)
  */

@@ -1047,6 +1047,7 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
   const int n = kijl - kijs;
   if (n <= 0) return 0;
   const bool norma = (variant & 16) != 0;  // LLNORMAGAM, packed by capi.hip
+  const bool rare = (variant & 32) != 0;   // any of LLGCBZ0 / LCIWA2 / LCIWA3 / LCISCAL / LWNEMOCOU: the build that carries those branches
   variant &= 15;
   const bool variant2 = (variant == 2);
   const int ntile = (variant == 2) ? 2 : 3;
@@ -1055,7 +1056,7 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
   const size_t per_wave = (size_t)(ntile * NFRE * NAP + nscr) * sizeof(T) + (variant == 2 ? NSC * sizeof(T) : 0);
   // waves (= points) per block: the choice that fits the most waves into the 160 KiB of LDS of a CU; ties go to the larger
   // block, which amortises the lane-per-point scalar stages of variant 2 over more points
-  static const int cands3[] = {4, 2, 1}, cands2[] = {3, 2, 1};
+  static const int cands3[] = {4, 2, 1}, cands2[] = {3, 1, 1};
   const int* cands = (variant == 2) ? cands2 : cands3;
   const int ncand = 3;
   // register-limited residency: variant 2 is compiled for 3 (sp) / 2 (dp) waves per SIMD, variant 1 uses 151 / 256 VGPRs
@@ -1069,7 +1070,7 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
     if (waves > best) { best = waves; wpb = cand; }
   }
   if (best == 0) return 1;
-  { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_WPB"); if (e_ && variant == 2) { const int w = atoi(e_); if (w == 3 || w == 2 || w == 1) wpb = w; } }
+  { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_WPB"); if (e_ && variant == 2) { const int w = atoi(e_); if (w == 3 || w == 1) wpb = w; } }
   size_t shmem = per_wave * wpb;
   { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_PADLDS"); if (e_) shmem += (size_t)atoi(e_); }  // diagnostics: lower the residency
   const int blocks = (n + wpb - 1) / wpb;
@@ -1083,11 +1084,12 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
   if (variant2) {
 #define LAUNCH2(W)                                                                                                           \
   do {                                                                                                                       \
-    if (norma) LAUNCHK((k_implsch2<T, W, true>));                                                                            \
-    else LAUNCHK((k_implsch2<T, W, false>));                                                                                 \
+    if (norma && rare) LAUNCHK((k_implsch2<T, W, true, true>));                                                              \
+    else if (norma) LAUNCHK((k_implsch2<T, W, true, false>));                                                                \
+    else if (rare) LAUNCHK((k_implsch2<T, W, false, true>));                                                                 \
+    else LAUNCHK((k_implsch2<T, W, false, false>));                                                                          \
   } while (0)
     if (wpb == 3) LAUNCH2(3);
-    else if (wpb == 2) LAUNCH2(2);
     else LAUNCH2(1);
 #undef LAUNCH2
   } else {

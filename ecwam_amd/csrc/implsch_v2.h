@@ -198,7 +198,7 @@ __device__ T halphap_w(const DevTab<T>& tb, const T* sF, const Lane<T>& L, T rWA
 //   head : c[C_XS], c[C_YS] (resolved-range stress integrals) -> sheltered friction velocity and direction, node geometry
 //   nodes: Y(J), CM1(J), XLOGGZ0 + 2 LOG(CM1(J)) in registers of lane point*JTOT + J
 //   tail : the TAUHF / PHIHF recurrences, TAUW, TAUWDIR, PHIWA
-template <typename T>
+template <typename T, bool RARE>
 __device__ void stresso_head_pt(const DevTab<T>& tb, T* c) {
   const T AIRD = c[C_AIRD], UFRIC = c[C_UFRIC], Z0M = c[C_Z0M];
   const int MIJ = (int)c[C_MIJ];
@@ -228,7 +228,7 @@ __device__ void stresso_head_pt(const DevTab<T>& tb, T* c) {
   // upper limit of the TAUHF quadrature: 0, or the gravity-capillary transition OMEGA_GC(NS_GC(UFRIC)) (tau_phi_hf.F90:127,
   // omegagc.F90:51-55) when LLGCBZ0
   T ZSUP = T(0);
-  if (tb.LLGCBZ0) ZSUP = m_min(m_log(tb.OMEGA_GC[ns_gc_d(tb, UFRIC)] * SQRTZ0OG), T(0));
+  if ((RARE && tb.LLGCBZ0)) ZSUP = m_min(m_log(tb.OMEGA_GC[ns_gc_d(tb, UFRIC)] * SQRTZ0OG), T(0));
   c[C_ZSUP] = ZSUP;
 }
 template <typename T>
@@ -239,7 +239,7 @@ __device__ __forceinline__ void stresso_node(const DevTab<T>& tb, const T* c, in
   const T CM1 = (Y * c[C_SQRTGZ0]) * tb.GM1;
   nY = Y; nCM1 = CM1; nLC = c[C_XLOGGZ0] + T(2) * m_log(CM1);
 }
-template <typename T>
+template <typename T, bool RARE>
 // nY/nCM1/nLC: node values held by lane nbase+J (pulled through the LDS crossbar; every lane of the wave runs this)
 __device__ void stresso_tail_pt(const DevTab<T>& tb, T* c, T nY, T nCM1, T nLC, T pY, T pCM1, T pLC, int nbase, bool store, bool LLPHIWA) {
   const T AIRD = c[C_AIRD], UFRIC = c[C_UFRIC], Z0M = c[C_Z0M], RNFAC = c[C_RNFAC];
@@ -308,7 +308,7 @@ __device__ void stresso_tail_pt(const DevTab<T>& tb, T* c, T nY, T nCM1, T nLC, 
   const T YSTRESS = c[C_YSN] + TAUHF * c[C_COSU];
   const T r = m_sqrt(XSTRESS * XSTRESS + YSTRESS * YSTRESS);
   T TAUW = m_max(r, T(0));
-  if (!tb.LLGCBZ0) TAUW = m_min(TAUW, UFRIC * UFRIC * (T(1) / (T(1) + tb.EPS1)));
+  if (!(RARE && tb.LLGCBZ0)) TAUW = m_min(TAUW, UFRIC * UFRIC * (T(1) / (T(1) + tb.EPS1)));
   if (store) {
     c[C_TAUW] = TAUW;
     // TAUWDIR = ATAN2(XSTRESS,YSTRESS): the next TAUT_Z0 needs COS(WDWAVE-TAUWDIR) only, the angle itself is an output
@@ -322,10 +322,10 @@ __device__ void stresso_tail_pt(const DevTab<T>& tb, T* c, T nY, T nCM1, T nLC, 
   }
 }
 // the three steps on the stage's wave: lanes < WPB own a point, lanes < WPB*JTOT a node
-template <typename T, int WPB>
+template <typename T, int WPB, bool RARE>
 __device__ __forceinline__ void stresso_stage(const DevTab<T>& tb, T* sSC, int lane, bool LLPHIWA) {
   static_assert(WPB * JTOT <= 64, "one lane per (point, node)");
-  if (lane < WPB) stresso_head_pt(tb, sSC + lane * NSC);
+  if (lane < WPB) stresso_head_pt<T, RARE>(tb, sSC + lane * NSC);
   WSYNC();
   T nY = T(1), nCM1 = T(1), nLC = T(0), pY, pCM1, pLC;
   if (lane < WPB * JTOT) {
@@ -333,12 +333,12 @@ __device__ __forceinline__ void stresso_stage(const DevTab<T>& tb, T* sSC, int l
     stresso_node(tb, sSC + pt * NSC, lane - pt * JTOT, sSC[pt * NSC + C_ZSUP], nY, nCM1, nLC);
   }
   pY = nY; pCM1 = nCM1; pLC = nLC;
-  if (tb.LLGCBZ0 && LLPHIWA && lane < WPB * JTOT) {  // the energy-flux quadrature keeps ZSUP = 0: its own node set
+  if ((RARE && tb.LLGCBZ0) && LLPHIWA && lane < WPB * JTOT) {  // the energy-flux quadrature keeps ZSUP = 0: its own node set
     const int pt = lane / JTOT;
     stresso_node(tb, sSC + pt * NSC, lane - pt * JTOT, T(0), pY, pCM1, pLC);
   }
   const int pt = lane < WPB ? lane : WPB - 1;  // spare lanes shadow the last point (the pulls need the whole wave)
-  stresso_tail_pt(tb, sSC + pt * NSC, nY, nCM1, nLC, pY, pCM1, pLC, pt * JTOT, lane < WPB, LLPHIWA);
+  stresso_tail_pt<T, RARE>(tb, sSC + pt * NSC, nY, nCM1, nLC, pY, pCM1, pLC, pt * JTOT, lane < WPB, LLPHIWA);
 }
 
 // scalar set-up of the swell damping (sinput_ard.F90:213-262) from the orbital integrals c[C_UORBT], c[C_AORB]
@@ -795,7 +795,7 @@ __device__ void sdissip_rows2(const DevTab<T>& tb, const T* sF, T* sFLD, const L
 // One sweep over the DIA interactions MC = 1..NFRE+4 (snonlin.F90:126-494, ISNONLIN = 0, pull form of snonlin_pull above);
 // after interaction MC row R = MC-4 is final: SDIWBK, SBOTTOM, the implicit update
 // with its limiter and the WNFLUXES integrands (implsch.F90:294-395) are applied to it and F(:,R) is overwritten in place.
-template <typename T>
+template <typename T, bool RARE>
 __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const Lane<T>& L, T rWAVNUM, T rCINV, T rXK2CG, T rRH, T UFRIC,
                              T coswdif, T RAORW, T DEPTH, T AKMEAN, T SDS, bool shallow_brk, T USFM, T FLM, T CICOVER, T CITHICK,
                              T rCGROUP, T& a_t, T& a_x) {
@@ -826,7 +826,7 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
   const bool flux_snl = tb.LCFLX && tb.LWVFLX_SNL;
   a_t = T(0); a_x = T(0);
   // sea-ice attenuation between SDIWBK and SBOTTOM (implsch.F90:312-339; LWNEMOCOUIBR = F: ALPFAC = ZALPFACX)
-  const bool ice_scal = tb.LICERUN && tb.LCISCAL, ice2 = tb.LICERUN && tb.LCIWA2, ice3 = tb.LICERUN && tb.LCIWA3;
+  const bool ice_scal = tb.LICERUN && (RARE && tb.LCISCAL), ice2 = tb.LICERUN && (RARE && tb.LCIWA2), ice3 = tb.LICERUN && (RARE && tb.LCIWA3);
   const T BETA = T(1) - CICOVER;
   T rICE3 = T(0), rICE2 = T(0);  // lane m: -CICV*ALP(M)*CGROUP(M) of SDICE3; CDICWA*WAVNUM(M)**2 of SDICE2
   if (ice3 && L.actm) {
@@ -937,7 +937,7 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
   }
 }
 
-template <typename T, int WPB, bool NORMA>
+template <typename T, int WPB, bool NORMA, bool RARE>
 __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 4 : 2))) k_implsch2(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__ fl1,
                                                        const T* __restrict__ wvprpt, T* __restrict__ ffa, T* __restrict__ intfa,
                                                        int* __restrict__ mij_out, T* __restrict__ xllws, double* __restrict__ w2n,
@@ -981,7 +981,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   {
     const T* wp = wvprpt + (size_t)ij * ECWAM_HIP_NWPR * NFRE;
     if (L.actm) { rWAVNUM = wp[L.lane]; rCINV = wp[2 * NFRE + L.lane]; rXK2CG = wp[3 * NFRE + L.lane]; rSTOKFAC = wp[4 * NFRE + L.lane]; }
-    if (L.actm && (tb.LCIWA2 || tb.LCIWA3)) rCGROUP = wp[NFRE + L.lane];
+    if (L.actm && ((RARE && tb.LCIWA2) || (RARE && tb.LCIWA3))) rCGROUP = wp[NFRE + L.lane];
   }
   const T ffv = (L.lane < ECWAM_HIP_NFF) ? ffa[(size_t)ij * ECWAM_HIP_NFF + L.lane] : T(0);
   const T AIRD = lane_get(ffv, 0), WDWAVE = lane_get(ffv, 1), CICOVER = lane_get(ffv, 2), WSWAVE = lane_get(ffv, 3);
@@ -1003,7 +1003,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
     T UFRIC = q[C_UFRIC], Z0M = q[C_Z0M], Z0B = q[C_Z0B], CHRNCK = q[C_CHRNCK];
     q[C_SINWD] = m_sin(q[C_WDWAVE]); q[C_COSWD] = m_cos(q[C_WDWAVE]);  // once per point, for every later use
     if (SKIP & 2) { q[C_TWSIN] = m_sin(q[C_TAUWDIR]); q[C_TWCOS] = m_cos(q[C_TAUWDIR]); }  // ablation runs only
-    if (tb.LLGCBZ0) q[C_TWCOS] = m_cos(q[C_WDWAVE] - q[C_TAUWDIR]);  // COSDIFF of the first TAUT_Z0, which runs per wave below
+    if ((RARE && tb.LLGCBZ0)) q[C_TWCOS] = m_cos(q[C_WDWAVE] - q[C_TAUWDIR]);  // COSDIFF of the first TAUT_Z0, which runs per wave below
     else if (!(SKIP & 16)) taut_z0_a(tb, 0, q[C_WSWAVE], q[C_WDWAVE], q[C_TAUW], q[C_TAUWDIR], UFRIC, Z0M, Z0B, CHRNCK);
     q[C_UFRIC] = UFRIC; q[C_Z0M] = Z0M; q[C_Z0B] = Z0B; q[C_CHRNCK] = CHRNCK;
     T RNFAC = T(1);
@@ -1052,7 +1052,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   T UFRIC = c[C_UFRIC], Z0M = c[C_Z0M];
   const T RNFAC = c[C_RNFAC], sinwd = c[C_SINWD], coswd = c[C_COSWD];
   // LLGCBZ0: HALPHAP (sinflx.F90:130) and the gravity-capillary TAUT_Z0 per wave, STRESS_GC's wavenumber sum across the lanes
-  const bool gcb = tb.LLGCBZ0 != 0;
+  const bool gcb = (RARE && tb.LLGCBZ0) != 0;
   T HALP = T(0);
   if (gcb) {
     HALP = halphap_w(tb, sF, L, rWAVNUM, coswdif);
@@ -1119,16 +1119,16 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   }
   // ---- stage 2: STRESSO scalars, second TAUT_Z0, WSIGSTAR, swell set-up, SDIWBK
   __syncthreads();
-  if (wave == (1 % WPB) && !(SKIP & 2)) stresso_stage<T, WPB>(tb, sSC, L.lane, false);
+  if (wave == (1 % WPB) && !(SKIP & 2)) stresso_stage<T, WPB, RARE>(tb, sSC, L.lane, false);
   if (wave == (1 % WPB) && L.lane < WPB) {
     T* q = sSC + L.lane * NSC;
     T UF = q[C_UFRIC], Z0 = q[C_Z0M], Z0Bv = q[C_Z0B], CH = q[C_CHRNCK];
-    if (!tb.LLGCBZ0) {
+    if (!(RARE && tb.LLGCBZ0)) {
       if (!(SKIP & 16)) taut_z0_c(tb, 1, q[C_WSWAVE], q[C_COSWD] * q[C_TWCOS] + q[C_SINWD] * q[C_TWSIN], q[C_TAUW], UF, Z0, Z0Bv, CH);
       q[C_UFRIC] = UF; q[C_Z0M] = Z0; q[C_Z0B] = Z0Bv; q[C_CHRNCK] = CH;
     }
     if (!(SKIP & 64)) {
-      if (!tb.LLGCBZ0) {
+      if (!(RARE && tb.LLGCBZ0)) {
         q[C_SIGN] = wsigstar(tb, q[C_WSWAVE], UF, Z0, q[C_WSTAR]);
         swell_setup_pt(tb, q);
       }
@@ -1187,14 +1187,14 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   }
   // ---- stage 3: STRESSO scalars of the second call; its results are first needed by WNFLUXES, after the sweep
   __syncthreads();
-  if (wave == (2 % WPB) && !(SKIP & 2)) stresso_stage<T, WPB>(tb, sSC, L.lane, true);
+  if (wave == (2 % WPB) && !(SKIP & 2)) stresso_stage<T, WPB, RARE>(tb, sSC, L.lane, true);
 
   // ---- SDISSIP + SNONLIN + update sweep
   const bool shallow_brk = tb.LBIWBK && (DEPTH < T(50.0));
   const T USFM = UFRIC * m_max(FMEANWS, FMEAN);
   T a_t, a_x;
   WSYNC();
-  source_sweep<T>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, rRH, UFRIC, coswdif, RAORW, DEPTH, AKMEAN, SDS, shallow_brk, USFM, FLM, CICOVER, CITHICK, rCGROUP, a_t, a_x);
+  source_sweep<T, RARE>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, rRH, UFRIC, coswdif, RAORW, DEPTH, AKMEAN, SDS, shallow_brk, USFM, FLM, CICOVER, CITHICK, rCGROUP, a_t, a_x);
   WSYNC();
   __syncthreads();  // stage 3 results
   const T TAUW = c[C_TAUW], TAUWDIR = c[C_TAUWDIR], PHIWA = c[C_PHIWA];
@@ -1213,7 +1213,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
     const T YSTRESS = usum(a_x * tb.COSTH[L.k]);
     const T EPSUS3 = tb.EPSUS * m_sqrt(tb.EPSUS);
     // wnfluxes.F90: with an explicit ice attenuation term the blending with the ice-covered fluxes starts at CICOVER = 0
-    const bool sdice_on = tb.LCIWA2 || tb.LCIWA3;
+    const bool sdice_on = (RARE && tb.LCIWA2) || (RARE && tb.LCIWA3);
     const T ZCITHRS = sdice_on ? T(0) : tb.CIBLOCK;
     const T CITHRSH_INV = sdice_on ? T(50) : T(1) / m_max(tb.CITHRSH, T(0.01));
     const T ZMAXEXP = sdice_on ? T(20) : T(10);
@@ -1226,7 +1226,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
       const T CD_WAVE = (UFRIC / U10P) * (UFRIC / U10P);
       const T CD_ICE = OOVAL * CD_WAVE + (T(1) - OOVAL) * CD_BULK;
       USTAR = m_max(m_sqrt(CD_ICE) * U10P, tb.EPSUS);
-      if (tb.LWNEMOCOU) {  // fully developed sea under ice for the NEMO wave height / period (wnfluxes.F90:236-246)
+      if ((RARE && tb.LWNEMOCOU)) {  // fully developed sea under ice for the NEMO wave height / period (wnfluxes.F90:236-246)
         const T EFD_FAC = T(4) * tb.EGRCRV / (tb.G * tb.G);
         const T FFD_FAC = m_pow(tb.EGRCRV / tb.AFCRV, T(1) / tb.BFCRV) * tb.G;
         const T EFD = m_min(EFD_FAC * m_pow4(USTAR), T(6.25));
@@ -1251,7 +1251,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
     PHIEPS = m_min(m_max(PHIOCD / XN, tb.PHIEPSMIN), tb.PHIEPSMAX);
     PHIOCD = PHIEPS * XN;
     PHIAW = OOVAL * PHIWA / XN + (T(1) - OOVAL) * T(3.75);
-    if (tb.LWNEMOCOU && w2n && valid && L.lane == 0) {  // wnfluxes.F90:304-328 (LNUPD = T; TAUICX/Y = 0 without LWNEMOCOUWRS)
+    if ((RARE && tb.LWNEMOCOU) && w2n && valid && L.lane == 0) {  // wnfluxes.F90:304-328 (LNUPD = T; TAUICX/Y = 0 without LWNEMOCOUWRS)
       double* q = w2n + (size_t)ij * 13;
       q[3] = (double)PHIEPS; q[4] = (double)TAUOC;
       q[5] = (EM_OC != T(0)) ? 4.0 * (double)m_sqrt(EM_OC) : 0.0;
@@ -1303,7 +1303,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
     USTOKES = m_min(m_max(USTOKES, T(-1.5)), T(1.5));
     VSTOKES = m_min(m_max(VSTOKES, T(-1.5)), T(1.5));
     // stokestrn.F90:75-88 (LWNEMOCOUSTRN = F)
-    if (tb.LWNEMOCOU && w2n && valid && L.lane == 0 && ((tb.LWNEMOCOUSEND && tb.LWCOU) || !tb.LWCOU)) {
+    if ((RARE && tb.LWNEMOCOU) && w2n && valid && L.lane == 0 && ((tb.LWNEMOCOUSEND && tb.LWCOU) || !tb.LWCOU)) {
       double* q = w2n + (size_t)ij * 13;
       q[0] = tb.LWNEMOCOUSTK ? (double)USTOKES : 0.0;
       q[1] = tb.LWNEMOCOUSTK ? (double)VSTOKES : 0.0;

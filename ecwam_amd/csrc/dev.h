@@ -20,6 +20,7 @@ struct DevTab {
   int LLGCBZ0, LLNORMAGAM, LLCAPCHNK, LBIWBK, LICERUN, LMASKICE, LWAMRSETCI;
   int LWVFLX_SNL, LWFLUX, LCFLX, LWNEMOCOU, LWCOU, LWCOUAST, LWNEMOCOUWRS;
   int LWNEMOTAUOC, LWNEMOCOUSEND, LWNEMOCOUSTK;
+  int ISNONLIN;  // 0: DIA depth scaling from AKMEAN, 1: TRANSF per interaction frequency (snonlin.F90:126-150)
   int LCISCAL, LCIWA2, LCIWA3;  // sea-ice attenuation (implsch.F90:312-339, sdice2.F90, sdice3.F90)
   int NSDSNTH, NTAP, MFRSTLW, MLSTHG, KFRH, NWAV_GC;
   // timing diagnostics only (env ECWAM_HIP_DEBUG_SKIP): bit mask of IMPLSCH phases to skip -- 1 SINPUT, 2 STRESSO scalars,

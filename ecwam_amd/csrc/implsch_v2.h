@@ -792,6 +792,31 @@ __device__ void sdissip_rows2(const DevTab<T>& tb, const T* sF, T* sFLD, const L
   }
 }
 
+// transf.F90:44-71
+template <typename T>
+__device__ T transf_d(const DevTab<T>& tb, T XK, T D) {
+  const T EPS = T(0.0001), DKMAX = T(40.0);
+  if (D < tb.BATHYMAX && D > T(0)) {
+    const T X = XK * D;
+    if (X > DKMAX) return T(1);
+    const T T_0 = m_tanh(X);
+    const T OM = m_sqrt(tb.G * XK * T_0);
+    const T C_0 = OM / XK;
+    T V_G;
+    if (X < EPS) V_G = C_0;
+    else V_G = T(0.5) * C_0 * (T(1) + T(2) * X / m_sinh(T(2) * X));
+    const T a = T_0 - X * (T(1) - T_0 * T_0);
+    const T DV_G = a * a + T(4) * (X * X) * (T_0 * T_0) * (T(1) - T_0 * T_0);
+    const T t4 = m_pow4(T_0);
+    const T XNL_1 = (T(9) * t4 - T(10) * (T_0 * T_0) + T(9)) / (T(8) * (T_0 * T_0 * T_0));
+    const T b = T(2) * V_G - T(0.5) * C_0;
+    const T XNL_2 = (b * b / (tb.G * D - V_G * V_G) + T(1)) / X;
+    const T XNL = XNL_1 - XNL_2;
+    return (XNL * XNL) / (DV_G * (t4 * t4));
+  }
+  return T(1);
+}
+
 // One sweep over the DIA interactions MC = 1..NFRE+4 (snonlin.F90:126-494, ISNONLIN = 0, pull form of snonlin_pull above);
 // after interaction MC row R = MC-4 is final: SDIWBK, SBOTTOM, the implicit update
 // with its limiter and the WNFLUXES integrands (implsch.F90:294-395) are applied to it and F(:,R) is overwritten in place.
@@ -803,6 +828,20 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
   T ENHFR = m_max(T(0.75) * DEPTH * AKMEAN, T(0.5));
   ENHFR = T(1) + (T(5.5) / ENHFR) * (T(1) - T(.833) * ENHFR) * m_exp(-T(1.25) * ENHFR);
   const int NAP = L.NAP, NFRE = L.NFRE, NANG = L.NANG, k = L.k;
+  // ISNONLIN = 1 (snonlin.F90:138-150): enhancement per interaction frequency, lane mc holds MC = mc+1 (MLSTHG <= 56 lanes)
+  const bool enh_mc = RARE && tb.ISNONLIN == 1;
+  T rENH = ENHFR;
+  if (enh_mc && L.lane < tb.MLSTHG) {
+    T XK;
+    if (L.lane < NFRE) XK = rWAVNUM;
+    else {
+      T fr = T(1);
+      for (int i = 0; i < L.lane + 1 - NFRE; i++) fr = fr * tb.FRATIO;
+      const T w = tb.ZPIFR[NFRE - 1] * fr;
+      XK = tb.GM1 * (w * w);
+    }
+    rENH = m_max(m_min(T(10), transf_d(tb, XK, DEPTH)), T(0.1));
+  }
   const int MFR1STFR = -tb.MFRSTLW + 1;
   const int MFRLSTFR = NFRE - tb.KFRH + MFR1STFR;
   int k1[2], k2[2], k11[2], k21[2], ik1[2], ik2[2], ik1s[2], ik2s[2];
@@ -856,7 +895,7 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
           const T GW5 = R[13], GW6 = R[14], GW7 = R[15], GW8 = R[16];
           const T FKLAMMA = R[17], FKLAMMB = R[18], FKLAMM2 = R[19], FKLAMM1 = R[20];
           const T FKLAMA2 = R[21], FKLAMB2 = R[22], FKLAM12 = R[23], FKLAM22 = R[24];
-          const T FTEMP = tb.AF11[MC - 1] * ENHFR;
+          const T FTEMP = tb.AF11[MC - 1] * (enh_mc ? lane_get(rENH, MC - 1) : ENHFR);
           const bool mid = (MC > MFR1STFR && MC < MFRLSTFR);
           const T fIP = sF[IP * NAP + k], fIP1 = sF[IP1 * NAP + k], fIM = sF[IM * NAP + k], fIM1 = sF[IM1 * NAP + k];
           T FIJ = sF[IC * NAP + k];

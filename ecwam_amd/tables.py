@@ -77,8 +77,8 @@ class Config:
     def validate(self) -> None:
         if self.iphys != 1:
             raise NotImplementedError("only IPHYS=1 (Ardhuin) is on the hot path (SURVEY.md section 2 row 12)")
-        if self.isnonlin != 0:
-            raise NotImplementedError("only ISNONLIN=0 is on the hot path")
+        if self.isnonlin not in (0, 1):
+            raise NotImplementedError("ISNONLIN=2 (TRANSF_SNL / PEAK_ANG) is a 'next' row (SURVEY.md 8f rank 4)")
         if self.irefra != 0:
             raise NotImplementedError("IREFRA != 0 (refraction weights) is a 'next' row (SURVEY.md 8f)")
         if self.icode != 3:

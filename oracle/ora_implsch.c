@@ -807,8 +807,29 @@ static void sdissip_ard(const real *FL1, real *FLD, real *SL, const real *WAVNUM
     }
 }
 
-/* snonlin.F90:126-494 (ISNONLIN = 0 depth scaling) */
-static void snonlin(const real *FL1, real *FLD, real *SL, real DEPTH, real AKMEAN) {
+/* transf.F90:44-71: narrow-band shallow-water enhancement of the nonlinear transfer */
+static real transf(real XK, real D) {
+  const real EPS = C_(0.0001), DKMAX = C_(40.0);
+  if (D < S.BATHYMAX && D > C_(0.0)) {
+    real X = XK * D;
+    if (X > DKMAX) return C_(1.0);
+    real T_0 = TANH(X);
+    real OM = SQRT(S.G * XK * T_0);
+    real C_0 = OM / XK;
+    real V_G;
+    if (X < EPS) V_G = C_0;
+    else V_G = C_(0.5) * C_0 * (C_(1.0) + C_(2.0) * X / SINH(C_(2.0) * X));
+    real DV_G = powi(T_0 - X * (C_(1.0) - T_0 * T_0), 2) + C_(4.0) * (X * X) * (T_0 * T_0) * (C_(1.0) - T_0 * T_0);
+    real XNL_1 = (C_(9.0) * powi(T_0, 4) - C_(10.0) * (T_0 * T_0) + C_(9.0)) / (C_(8.0) * powi(T_0, 3));
+    real XNL_2 = (powi(C_(2.0) * V_G - C_(0.5) * C_0, 2) / (S.G * D - V_G * V_G) + C_(1.0)) / X;
+    real XNL = XNL_1 - XNL_2;
+    return (XNL * XNL) / (DV_G * powi(T_0, 8));
+  }
+  return C_(1.0);
+}
+
+/* snonlin.F90:126-494 (ISNONLIN = 0: depth scaling from AKMEAN; ISNONLIN = 1: TRANSF per interaction frequency) */
+static void snonlin(const real *FL1, real *FLD, real *SL, real DEPTH, real AKMEAN, const real *WAVNUM) {
   const int NANG = S.NANG, NFRE = S.NFRE;
   real ENHFR = RMAX(C_(0.75) * DEPTH * AKMEAN, C_(0.5));
   ENHFR = C_(1.0) + (C_(5.5) / ENHFR) * (C_(1.0) - C_(.833) * ENHFR) * EXP(-C_(1.25) * ENHFR);
@@ -825,7 +846,12 @@ static void snonlin(const real *FL1, real *FLD, real *SL, real DEPTH, real AKMEA
     real GW5 = R[13], GW6 = R[14], GW7 = R[15], GW8 = R[16];
     real FKLAMMA = R[17], FKLAMMB = R[18], FKLAMM2 = R[19], FKLAMM1 = R[20];
     real FKLAMA2 = R[21], FKLAMB2 = R[22], FKLAM12 = R[23], FKLAM22 = R[24];
-    real FTEMP = S.AF11[MC - 1] * ENHFR;
+    real ENH = ENHFR;
+    if (S.c.isnonlin == 1) { /* snonlin.F90:138-150 */
+      real XK = (MC <= NFRE) ? WAVNUM[MC - 1] : S.GM1 * powi(S.ZPIFR[NFRE - 1] * powi(S.FRATIO, MC - NFRE), 2);
+      ENH = RMAX(RMIN(C_(10.0), transf(XK, DEPTH)), C_(0.1));
+    }
+    real FTEMP = S.AF11[MC - 1] * ENH;
     int branch = (MC > MFR1STFR && MC < MFRLSTFR) ? 0 : (MC >= MFRLSTFR ? 1 : 2);
     for (int KH = 0; KH < 2; KH++) {
       for (int K = 0; K < NANG; K++) {
@@ -1120,6 +1146,7 @@ static int implsch_point(real *FL1, real *XLLWS, point_t *p, real *dbg) {
   real F1MEAN, AKMEAN, XKMEAN, PHIWA;
   real FLM[NA], COSWDIF[NA], SINWDIF2[NA], TEMP[NF], RHOWGDFTH[NF], DELFL[NF];
   int LCFLX;
+  if (S.c.isnonlin != 0 && S.c.isnonlin != 1) return 2; /* ISNONLIN = 2 (TRANSF_SNL, PEAK_ANG): not restated */
   if (S.c.lciwa1 || S.c.lwnemocouibr) return 2; /* SDICE1 (CIDEAC scattering table) and the ice break-up coupling: not restated */
 
   DELT = (real)S.c.idelt;
@@ -1146,7 +1173,7 @@ static int implsch_point(real *FL1, real *XLLWS, point_t *p, real *dbg) {
   sdissip_ard(FL1, FLD, SL, p->WAVNUM, p->XK2CG, p->UFRIC, COSWDIF, RAORW);
   if (LCFLX && !S.c.lwvflx_snl)
     for (int i = 0; i < NANG * NFRE; i++) SSOURCE[i] = SL[i];
-  snonlin(FL1, FLD, SL, p->DEPTH, AKMEAN);
+  snonlin(FL1, FLD, SL, p->DEPTH, AKMEAN, p->WAVNUM);
   if (LCFLX && S.c.lwvflx_snl)
     for (int i = 0; i < NANG * NFRE; i++) {
       GTEMP1 = RMAX((C_(1.0) - DELT5 * FLD[i]), C_(1.0));

@@ -128,6 +128,36 @@ def test_implsch_parity_sea_ice_attenuation(api, prec, flags):
 
 
 @pytest.mark.parametrize("prec", ["dp", "sp"])
+def test_implsch_parity_isnonlin_1(api, prec):
+    """ISNONLIN = 1: the DIA scaled per interaction frequency by TRANSF(k, depth) (snonlin.F90:138-150, transf.F90) on a
+    case with many intermediate-depth points."""
+    cfg = Config(nang=24, nfre=36, nfre_red=29, isnonlin=1)
+    n = 900
+    case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=51)
+    dt = H.np_dtype(prec)
+    rng = np.random.default_rng(6)
+    from ecwam_amd import synthetic as syn
+    case["ENV"][:, 1] = (10.0 ** rng.uniform(0.6, 2.5, n)).astype(dt)            # 4 m .. 316 m
+    pr = syn.depth_props(case["ENV"][:, 1], case["tables"], dt)
+    case["props"] = pr
+    case["ENV"][:, 0] = pr["EMAXDPT"]
+    o = _oracle(cfg, prec)
+    ref = H.oracle_implsch(case, o)
+    ctx = api.HipContext(case["tables"])
+    got = H.gpu_implsch(case, ctx)
+    st = H.compare_implsch(ref, got, case["tables"])
+    ctx.close()
+    if prec == "dp":
+        assert st["mij_flips"] == 0 and st["fl1_max_rel_peak_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
+    else:
+        assert st["mij_flips"] <= n * 0.005 and st["fl1_max_rel_peak_clean"] < 1e-4 and st["swh_max_rel"] < 1e-5, st
+    cfg0 = Config(nang=24, nfre=36, nfre_red=29)
+    c0 = dict(case); c0["cfg"] = cfg0; c0["tables"] = Tables(cfg0, dt)
+    r0 = H.oracle_implsch(c0, _oracle(cfg0, prec))
+    assert np.max(np.abs(r0["FL1"] - ref["FL1"])) > 0                             # the option acts
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
 @pytest.mark.parametrize("tauoc", [True, False])
 def test_implsch_wam2nemo_outputs(api, prec, tauoc):
     """LWNEMOCOU: the 13 WAVE2OCEAN members (always double) -- instantaneous NPHIEPS/NTAUOC/NSWH/NMWP/NEMO*STOKES and the

@@ -54,7 +54,7 @@ static int build_tab(const ecwam_hip_params* p, const ecwam_hip_tables* t, DevTa
   d->LWFLUX = p->lwflux; d->LCFLX = (p->lwflux || p->lwfluxout || p->lwnemocou); d->LWNEMOCOU = p->lwnemocou; d->LWCOU = p->lwcou;
   d->LWCOUAST = p->lwcouast; d->LWNEMOCOUWRS = p->lwnemocouwrs;
   d->LWNEMOTAUOC = p->lwnemotauoc; d->LWNEMOCOUSEND = p->lwnemocousend; d->LWNEMOCOUSTK = p->lwnemocoustk;
-  d->ISNONLIN = p->isnonlin;
+  d->ISNONLIN = p->isnonlin; d->IPHYS = p->iphys; d->IDAMPING = p->idamping;
   d->LCISCAL = p->lciscal; d->LCIWA2 = p->lciwa2; d->LCIWA3 = p->lciwa3;
   { const char* e_ = getenv("ECWAM_HIP_DEBUG_SKIP"); d->DBG_SKIP = e_ ? atoi(e_) : 0; }
   d->NSDSNTH = p->nsdsnth; d->NTAP = 2 * p->nsdsnth + 1; d->MFRSTLW = p->mfrstlw; d->MLSTHG = ML; d->KFRH = p->kfrh; d->NWAV_GC = p->nwav_gc;
@@ -68,7 +68,7 @@ static int build_tab(const ecwam_hip_params* p, const ecwam_hip_tables* t, DevTa
   S_(BETAMAXOXKAPPA2, betamaxoxkappa2); S_(BMAXOKAP, bmaxokap); S_(GAMNCONST, gamnconst); S_(ZALP, zalp); S_(ALPHA, alpha);
   S_(ALPHAMIN, alphamin); S_(ALPHAMAX, alphamax); S_(CHNKMIN_U, chnkmin_u); S_(TAUWSHELTER, tauwshelter); S_(DTHRN_A, dthrn_a);
   S_(DTHRN_U, dthrn_u); S_(TAILFACTOR, tailfactor); S_(TAILFACTOR_PM, tailfactor_pm); S_(ANG_GC_A, ang_gc_a);
-  S_(ANG_GC_B, ang_gc_b); S_(ANG_GC_C, ang_gc_c); S_(RN1_RN, rn1_rn); S_(ALPHAPMAX, alphapmax); S_(CDICWA, cdicwa); S_(ZALPFACB, zalpfacb); S_(ZALPFACX, zalpfacx); S_(SWELLF, swellf); S_(SWELLF2, swellf2);
+  S_(ANG_GC_B, ang_gc_b); S_(ANG_GC_C, ang_gc_c); S_(RN1_RN, rn1_rn); S_(ALPHAPMAX, alphapmax); S_(CDIS, cdis); S_(DELTA_SDIS, delta_sdis); S_(CDISVIS, cdisvis); S_(CDICWA, cdicwa); S_(ZALPFACB, zalpfacb); S_(ZALPFACX, zalpfacx); S_(SWELLF, swellf); S_(SWELLF2, swellf2);
   S_(SWELLF3, swellf3); S_(SWELLF4, swellf4); S_(SWELLF5, swellf5); S_(SWELLF6, swellf6); S_(SWELLF7, swellf7);
   S_(SWELLF7M1, swellf7m1); S_(Z0RAT, z0rat); S_(Z0TUBMAX, z0tubmax); S_(ABMIN, abmin); S_(ABMAX, abmax); S_(SDSBR, sdsbr);
   S_(SSDSC2, ssdsc2); S_(SSDSC3, ssdsc3); S_(SSDSC4, ssdsc4); S_(SSDSC5, ssdsc5); S_(SSDSC6, ssdsc6); S_(MICHE, miche);
@@ -188,8 +188,8 @@ int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int r
   if (p->nang < 4 || p->nang > MAXA || p->nfre < 8 || p->nfre > MAXF || p->nfre_red < 1 || p->nfre_red > p->nfre)
     return fail("ecwam_hip_create: NANG/NFRE/NFRE_RED out of the supported range");
   if (p->mlsthg > MAXMC || 2 * p->nsdsnth + 1 > MAXTAP || p->nwav_gc + 1 > MAXGC) return fail("ecwam_hip_create: table size exceeds library limits");
-  if (p->iphys != 1 || (p->isnonlin != 0 && p->isnonlin != 1) || p->irefra != 0 || p->icode != 3)
-    return fail("ecwam_hip_create: only IPHYS=1, ISNONLIN=0/1, IREFRA=0, ICODE=3 are on the hot path (SURVEY.md 8a)");
+  if ((p->iphys != 0 && p->iphys != 1) || (p->isnonlin != 0 && p->isnonlin != 1) || p->irefra != 0 || p->icode != 3)
+    return fail("ecwam_hip_create: only IPHYS=0/1, ISNONLIN=0/1, IREFRA=0, ICODE=3 are on the hot path (SURVEY.md 8a)");
   if (p->lciwa1) return fail("ecwam_hip_create: SDICE1 (scattering attenuation table CIDEAC, sdice1.F90) not supported yet");
   if (p->lwnemocouwrs || p->lwnemocoustrn) return fail("ecwam_hip_create: LWNEMOCOUWRS (ice radiative stress from SLICE) / LWNEMOCOUSTRN (CIMSSTRN) not supported yet");
   HIPCHK(hipSetDevice(device));
@@ -199,14 +199,14 @@ int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int r
     std::vector<DevTab<float>> h(1);
     build_tab<float>(p, t, h.data());
     c->implsch_variant = h[0].DIA_PULL ? 2 : 1;
-    if ((p->llgcbz0 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou || p->isnonlin) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
+    if ((p->llgcbz0 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou || p->isnonlin || p->iphys == 0) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
     HIPCHK(hipMalloc(&c->dtab, sizeof(DevTab<float>)));
     HIPCHK(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<float>), hipMemcpyHostToDevice));
   } else {
     std::vector<DevTab<double>> h(1);
     build_tab<double>(p, t, h.data());
     c->implsch_variant = h[0].DIA_PULL ? 2 : 1;
-    if ((p->llgcbz0 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou || p->isnonlin) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
+    if ((p->llgcbz0 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou || p->isnonlin || p->iphys == 0) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
     HIPCHK(hipMalloc(&c->dtab, sizeof(DevTab<double>)));
     HIPCHK(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<double>), hipMemcpyHostToDevice));
   }
@@ -289,7 +289,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   int rc, variant = c->implsch_variant;
   { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_VARIANT"); if (e_ && atoi(e_) == 1) variant = 1; }  // diagnostics: force the 3-tile kernel
   if (c->p.llnormagam) variant |= 16;
-  if (c->p.llgcbz0 || c->p.lciwa2 || c->p.lciwa3 || c->p.lciscal || c->p.lwnemocou || c->p.isnonlin) variant |= 32;
+  if (c->p.llgcbz0 || c->p.lciwa2 || c->p.lciwa3 || c->p.lciscal || c->p.lwnemocou || c->p.isnonlin || c->p.iphys == 0) variant |= 32;
   DISPATCH(rc = launch_implsch<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s),
            rc = launch_implsch<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s));
   if (rc) return fail("ecwam_hip_implsch: unsupported spectral size for the LDS tiling");

@@ -20,6 +20,7 @@ struct DevTab {
   int LLGCBZ0, LLNORMAGAM, LLCAPCHNK, LBIWBK, LICERUN, LMASKICE, LWAMRSETCI;
   int LWVFLX_SNL, LWFLUX, LCFLX, LWNEMOCOU, LWCOU, LWCOUAST, LWNEMOCOUWRS;
   int LWNEMOTAUOC, LWNEMOCOUSEND, LWNEMOCOUSTK;
+  int IPHYS, IDAMPING;  // 0: SINPUT_JAN + SDISSIP_JAN, 1: SINPUT_ARD + SDISSIP_ARD (sinput.F90:102, sdissip.F90:76)
   int ISNONLIN;  // 0: DIA depth scaling from AKMEAN, 1: TRANSF per interaction frequency (snonlin.F90:126-150)
   int LCISCAL, LCIWA2, LCIWA3;  // sea-ice attenuation (implsch.F90:312-339, sdice2.F90, sdice3.F90)
   int NSDSNTH, NTAP, MFRSTLW, MLSTHG, KFRH, NWAV_GC;
@@ -37,6 +38,7 @@ struct DevTab {
   T X0TAUHF, EPS1, FLMIN, CITHRSH, CIBLOCK, CITHRSH_TAIL, ZALPWRS, BATHYMAX, WSPMIN, WSPMIN_RESET_TAUW;
   T DAL1, DAL2, XLOGKRATIOM1_GC, SQRTGOSURFT;
   T CDICWA, ZALPFACB, ZALPFACX;
+  T CDIS, DELTA_SDIS, CDISVIS;
   // per-frequency
   T FR[MAXF], DFIM[MAXF], DFIMOFR[MAXF], DFIMFR[MAXF], DFIM_SIM[MAXF], RHOWG_DFIM[MAXF], ZPIFR[MAXF], FR5[MAXF];
   T COFRM4[MAXF], FLMAX[MAXF];

@@ -703,6 +703,118 @@ __device__ void sinput_ard2_pk(const DevTab<T>& tb, const T* sF, T* sFLD, const 
   }
 }
 
+// sinput_jan.F90:171-396 (IPHYS = 0): Janssen's wind input.  No sheltering: the frequency rows are independent, all
+// per-frequency factors of both gust states are evaluated with lane m = M-1 and broadcast row by row.  Same outputs as
+// sinput_ard2 (XLLWS mask, per-frequency stress integrals, FEMEANWS integrands, FLD added onto the dissipation).
+template <typename T, int NGST, bool LLSNEG, bool NORMA>
+__device__ void sinput_jan2(const DevTab<T>& tb, const T* sF, T* sFLD, const Lane<T>& L, T rWAVNUM, T rCINV, T rXK2CG, T WSWAVE,
+                            T UFRIC, T Z0M, T coswdif, T sinwdif2, T RAORW, T RNFAC, T SIG_N, unsigned long long& xmask, T& rX,
+                            T& rY, T& rS, T& apl, T& wsae, T& wsaf, T& wslast) {
+  const T CONST1 = tb.BETAMAXOXKAPPA2;
+  const T CONST3 = T(tb.IDAMPING) * (T(2) * tb.XKAPPA / CONST1);
+  const T XKAPPAD = T(1) / tb.XKAPPA;
+  const T CONSTN = tb.DELTH / (tb.XKAPPA * tb.ZPI);
+  const T CSTRNFAC = NORMA ? CONSTN * RNFAC / RAORW : T(0);
+  T WSIN[2], US[2], USTPM1[2];
+  if (NGST == 1) { WSIN[0] = T(1); US[0] = UFRIC; }
+  else { WSIN[0] = T(0.5); WSIN[1] = T(0.5); US[0] = UFRIC * (T(1) - SIG_N); US[1] = UFRIC * (T(1) + SIG_N); }
+#pragma unroll
+  for (int ig = 0; ig < NGST; ig++) USTPM1[ig] = T(1) / m_max(US[ig], tb.EPSUS);
+  const T sinthk = tb.SINTH[L.k], costhk = tb.COSTH[L.k];
+  const bool LZ = coswdif > T(0.01);
+  const T xkoc = tb.XKAPPA / coswdif;
+  xmask = 0ull;
+  rX = T(0); rY = T(0); rS = T(0); apl = T(0);
+  wsae = T(0); wsaf = T(0); wslast = T(0);
+  // lane m: CNSN, ZCN and per gust state UCN, 1/UCN, CONST3*UCN**2, XVD of frequency M = m+1
+  T rCNSN = T(0), rZCN = T(0), rUCN[2], rUCND[2], rC3[2], rXVD[2], rXNG = T(0);
+#pragma unroll
+  for (int ig = 0; ig < 2; ig++) { rUCN[ig] = T(1); rUCND[ig] = T(1); rC3[ig] = T(0); rXVD[ig] = T(0); }
+  if (L.actm) {
+    const T SIG = L.rZPIFR;
+    const T ZTANHKD = SIG * SIG / (tb.G * rWAVNUM);
+    rCNSN = (SIG * CONST1) * ZTANHKD * RAORW;
+    rZCN = m_log(rWAVNUM * Z0M);
+    if (NORMA) rXNG = CSTRNFAC * rXK2CG;
+#pragma unroll
+    for (int ig = 0; ig < NGST; ig++) {
+      rUCN[ig] = US[ig] * rCINV + tb.ZALP;
+      rC3[ig] = CONST3 * (rUCN[ig] * rUCN[ig]);
+      rUCND[ig] = T(1) / rUCN[ig];
+      rXVD[ig] = T(1) / (-US[ig] * XKAPPAD * rZCN * rCINV);
+    }
+  }
+  for (int m = 0; m < L.NFRE; m++) {
+    const T CNSN = lane_get(rCNSN, m), ZCN = lane_get(rZCN, m);
+    const T f = sF[m * L.NAP + L.k];
+    T g0[2], GN[2] = {T(1), T(1)};
+    bool xl = false;
+#pragma unroll
+    for (int ig = 0; ig < NGST; ig++) {
+      T gam0 = T(0);
+      if (LZ) {
+        const T ZLOG = ZCN + xkoc * lane_get(rUCND[ig], m);
+        if (ZLOG < T(0)) {
+          const T X = coswdif * lane_get(rUCN[ig], m);
+          const T ZLOG2X = ZLOG * ZLOG * X;
+          gam0 = ZLOG2X * ZLOG2X * f_exp(ZLOG) * CNSN;
+          xl = true;
+        }
+      }
+      g0[ig] = gam0;
+      if (NORMA) {
+        const T a = L.act ? gam0 * f : T(0);
+        T SUMF, SUMFSIN2;
+        usum2(a, a * sinwdif2, SUMF, SUMFSIN2);
+        const T ZNZ = lane_get(rXNG, m) * USTPM1[ig];
+        GN[ig] = (T(1) + ZNZ * SUMFSIN2) / (T(1) + ZNZ * SUMF);
+      }
+    }
+    T UFAC1 = WSIN[0] * g0[0] * GN[0], UFAC2 = T(0);
+    if (NGST == 2) UFAC1 = UFAC1 + WSIN[1] * g0[1] * GN[1];
+    if (LLSNEG) {
+      UFAC2 = WSIN[0] * (lane_get(rC3[0], m) * (coswdif - lane_get(rXVD[0], m)));
+      if (NGST == 2) UFAC2 = UFAC2 + WSIN[1] * (lane_get(rC3[1], m) * (coswdif - lane_get(rXVD[1], m)));
+    }
+    const T fld = UFAC1 + UFAC2 * CNSN;
+    const T spos = UFAC1 * f;
+    const bool anygrow = __builtin_amdgcn_ballot_w64(xl) != 0ull;
+    if (anygrow) {
+      const T sa = L.act ? spos : T(0);
+      T xs, ys, ss, d0;
+      usum4(sa * sinthk, sa * costhk, sa, T(0), xs, ys, ss, d0);
+      lane_put(rX, L.lane, m, xs);
+      lane_put(rY, L.lane, m, ys);
+      if (LLSNEG) lane_put(rS, L.lane, m, ss);
+    }
+    if (LLSNEG) {
+      apl = apl + (fld * f - spos) * tb.RHOWG_DFIM[m];
+      if (L.act) sFLD[m * L.NAP + L.k] += fld;
+    }
+    if (xl) xmask |= (1ull << m);
+    {
+      const T x = xl ? f : T(0);
+      wsae += lane_get(L.rDFIM, m) * x;
+      wsaf += lane_get(L.rDFIMOFR, m) * x;
+      wslast = x;
+    }
+  }
+}
+
+// sdissip_jan.F90:92-128 (IPHYS = 0): FLD = TEMP1(M), the same for every direction
+template <typename T>
+__device__ void sdissip_jan_rows(const DevTab<T>& tb, T* sFLD, const Lane<T>& L, T rWAVNUM, T EMEAN, T F1MEAN, T XKMEAN) {
+  const T DELTA_SDISM1 = T(1) - tb.DELTA_SDIS;
+  const T SDS = (tb.CDIS * tb.ZPI) * F1MEAN * (EMEAN * EMEAN) * m_pow4(XKMEAN);
+  T rT1 = T(0);
+  if (L.actm) {
+    const T X = rWAVNUM / XKMEAN;
+    rT1 = SDS * X * (DELTA_SDISM1 + tb.DELTA_SDIS * X) + (tb.RNU * tb.CDISVIS) * (rWAVNUM * rWAVNUM);
+  }
+  if (L.act)
+    for (int m = 0; m < L.NFRE; m++) sFLD[m * L.NAP + L.k] = lane_get(rT1, m);
+}
+
 // femeanws.F90:103-123 from the per-direction integrands gathered in SINPUT
 template <typename T>
 __device__ __forceinline__ void femeanws_finish(const DevTab<T>& tb, const Lane<T>& L, T ae, T af, T last, T& FM, T& EMW) {
@@ -1141,7 +1253,11 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   int MIJ = NFRE;
   T rRH = T(0), rX, rY, rS, apl, wsae, wsaf, wslast;
   unsigned long long xmask = 0ull;
-  if (!(SKIP & 1))
+  const bool jan = RARE && tb.IPHYS == 0;
+  if (jan && !(SKIP & 1))
+    sinput_jan2<T, 1, false, NORMA>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, WSWAVE, UFRIC, Z0M, coswdif, sinwdif2, RAORW, RNFAC, T(0), xmask,
+                                    rX, rY, rS, apl, wsae, wsaf, wslast);
+  else if (!(SKIP & 1))
     sinput_ard2<T, 1, false, NORMA>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, WDWAVE, UFRIC, Z0M, coswdif, sinwdif2, RAORW, RNFAC, T(0),
                                     T(0), T(0), T(0), sinwd, coswd, xmask, rX, rY, rS, apl, wsae, wsaf, wslast);
   else { rX = rY = rS = apl = wsae = wsaf = wslast = T(0); }
@@ -1179,7 +1295,8 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
     if (SKIP & 4) {
       if (L.act)
         for (int m = 0; m < NFRE; m++) sFLD[m * NAP + L.k] = T(0);
-    } else if (tb.NTAP == 17) sdissip_rows2<T, 17>(tb, sF, sFLD, L, rWAVNUM, rXK2CG, UF, coswdif, RAORW);
+    } else if (jan) sdissip_jan_rows<T>(tb, sFLD, L, rWAVNUM, EMEAN, F1MEAN, XKMEAN);
+    else if (tb.NTAP == 17) sdissip_rows2<T, 17>(tb, sF, sFLD, L, rWAVNUM, rXK2CG, UF, coswdif, RAORW);
     else if (tb.NTAP == 11) sdissip_rows2<T, 11>(tb, sF, sFLD, L, rWAVNUM, rXK2CG, UF, coswdif, RAORW);
     else if (tb.NTAP == 7) sdissip_rows2<T, 7>(tb, sF, sFLD, L, rWAVNUM, rXK2CG, UF, coswdif, RAORW);
     else sdissip_rows2<T, 0>(tb, sF, sFLD, L, rWAVNUM, rXK2CG, UF, coswdif, RAORW);
@@ -1205,7 +1322,10 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   // ---- second SINFLX call: FLD, XLLWS, MIJ, wave stress and the PHIWA integrals
   if (!(SKIP & 1))
   {
-    if (!NORMA && tb.TAUWSHELTER != T(0))
+    if (jan)
+      sinput_jan2<T, 2, true, NORMA>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, WSWAVE, UFRIC, Z0M, coswdif, sinwdif2, RAORW, RNFAC, c[C_SIGN],
+                                     xmask, rX, rY, rS, apl, wsae, wsaf, wslast);
+    else if (!NORMA && tb.TAUWSHELTER != T(0))
       sinput_ard2_pk<T>(tb, sF, sFLD, L, rWAVNUM, rCINV, UFRIC, Z0M, RAORW, c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], sinwd,
                         coswd, xmask, rX, rY, rS, apl, wsae, wsaf, wslast);
     else

@@ -31,7 +31,9 @@ _PARAM_LAYOUT = (
                                   "z0tubmax", "abmin", "abmax", "sdsbr", "ssdsc2", "ssdsc3", "ssdsc4", "ssdsc5", "ssdsc6", "miche"]]
     + [("nsdsnth", C.c_int), ("ipsat", C.c_int)]
     + [(n, C.c_double) for n in ["egrcrv", "afcrv", "bfcrv", "x0tauhf", "eps1", "flmin", "cithrsh", "ciblock", "cithrsh_tail",
-                                  "zalpwrs", "bathymax", "wspmin", "wspmin_reset_tauw", "cdicwa", "zalpfacb", "zalpfacx"]]
+                                  "zalpwrs", "bathymax", "wspmin", "wspmin_reset_tauw", "cdis", "delta_sdis", "cdisvis"]]
+    + [("idamping", C.c_int)]
+    + [(n, C.c_double) for n in ["cdicwa", "zalpfacb", "zalpfacx"]]
     + [("mfrstlw", C.c_int), ("mlsthg", C.c_int), ("kfrh", C.c_int), ("dal1", C.c_double), ("dal2", C.c_double),
        ("nwav_gc", C.c_int), ("xlogkratiom1_gc", C.c_double), ("sqrtgosurft", C.c_double)]
 )

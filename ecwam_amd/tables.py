@@ -75,8 +75,8 @@ class Config:
     rnum: float = 0.11 * 1.5e-5    # runwam.F90:233
 
     def validate(self) -> None:
-        if self.iphys != 1:
-            raise NotImplementedError("only IPHYS=1 (Ardhuin) is on the hot path (SURVEY.md section 2 row 12)")
+        if self.iphys not in (0, 1):
+            raise NotImplementedError("IPHYS must be 0 (Janssen) or 1 (Ardhuin)")
         if self.isnonlin not in (0, 1):
             raise NotImplementedError("ISNONLIN=2 (TRANSF_SNL / PEAK_ANG) is a 'next' row (SURVEY.md 8f rank 4)")
         if self.irefra != 0:
@@ -209,6 +209,19 @@ class Tables:
                 self.BETAMAX, self.TAUWSHELTER, self.ALPHAMIN, self.CHNKMIN_U = T(1.40), T(0.25), T(0.0001), T(33.0)
         self.SWELLF7M1 = T(1.0) / self.SWELLF7
         self.EGRCRV, self.AFCRV, self.BFCRV = T(1065.0), T(2.453e-4), T(-3.1236)
+        self.IDAMPING = 1                                                      # mpuserin.F90:609
+        self.CDIS, self.DELTA_SDIS, self.CDISVIS = T(0.0), T(0.0), T(0.0)
+        if c.iphys == 0:   # Janssen wind input + WAM cycle 4 dissipation, setwavphys.F90:46-112
+            self.ZALP, self.TAILFACTOR, self.ALPHAMIN, self.ALPHAPMAX, self.TAUWSHELTER = T(0.008), T(2.5), T(0.0001), T(0.03), T(0.0)
+            self.DELTA_THETA_RN, self.DTHRN_A, self.DTHRN_U, self.RN1_RN, self.TAILFACTOR_PM = T(0.75), T(0.80), T(33.0), T(0.25), T(0.0)
+            if c.llgcbz0:
+                self.ALPHA, self.CHNKMIN_U = T(0.0055), T(28.0)
+                self.BETAMAX = T(1.32) if c.llnormagam else T(1.25)
+                self.CDIS, self.DELTA_SDIS, self.CDISVIS = T(-1.3), T(0.6), T(-4.0)
+            else:
+                self.ALPHA, self.CHNKMIN_U, self.BETAMAX = T(0.0065), T(33.0), T(1.20)
+                self.CDIS, self.DELTA_SDIS, self.CDISVIS = T(-1.33), T(0.5), T(0.0)
+            self.EGRCRV, self.AFCRV, self.BFCRV = T(1108.0), T(4.0e-4), T(-3.0)
         self.FLMAX = (self.ALPHAPMAX / self.PI) / (self.ZPI4GM2 * self.FR5)
         # ---- init_x0tauhf
         self.BETAMAXOXKAPPA2 = self.BETAMAX / (self.XKAPPA * self.XKAPPA)

@@ -75,6 +75,7 @@ typedef struct ecwam_hip_params {
   double egrcrv, afcrv, bfcrv;
   /* YOWCOUP / YOWTABL / YOWICE / YOWSHAL / YOWWIND */
   double x0tauhf, eps1, flmin, cithrsh, ciblock, cithrsh_tail, zalpwrs, bathymax, wspmin, wspmin_reset_tauw;
+  double cdis, delta_sdis, cdisvis; int idamping; /* YOWPHYS / YOWSTAT: IPHYS=0 dissipation and swell damping switch */
   double cdicwa, zalpfacb, zalpfacx; /* YOWICE: SDICE2 drag coefficient, attenuation scale factors (sdice2.F90, implsch.F90:195) */
   /* YOWINDN scalars */
   int mfrstlw, mlsthg, kfrh;

@@ -148,6 +148,8 @@ typedef struct {
   real EPS1, SWELLFT[ORA_IAB + 1]; /* 1-based like the reference */
   /* YOWICE / YOWSHAL / YOWWIND */
   real FLMIN, CITHRSH, CIBLOCK, CITHRSH_TAIL, CDICWA, ZALPFACX, ZALPFACB, ZALPWRS;
+  real CDIS, DELTA_SDIS, CDISVIS; /* IPHYS = 0 dissipation (sdissip_jan.F90) */
+  int IDAMPING;
   real GAM_B_J, BATHYMAX, WSPMIN, WSPMIN_RESET_TAUW;
   /* YOWINDN (nlweigt.F90, inisnonlin.F90); MC index 1..MLSTHG stored at [mc-1] */
   int MFRSTLW, MLSTHG, KFRH;

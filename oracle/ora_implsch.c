@@ -492,6 +492,102 @@ static void sinput_ard(int NGST, int LLSNEG, const real *FL1, const real *WAVNUM
   }
 }
 
+/* sinput_jan.F90:171-396 (IPHYS = 0): Janssen (1991) wind input, optional gustiness (NGST = 2), growth renormalisation
+ * (LLNORMAGAM) and the swell damping of IDAMPING = 1 */
+static void sinput_jan(int NGST, int LLSNEG, const real *FL1, const real *WAVNUM, const real *CINV, const real *XK2CG,
+                       real WSWAVE, real UFRIC, real Z0M, const real *COSWDIF, const real *SINWDIF2, real RAORW, real WSTAR,
+                       real RNFAC, real *FLD, real *SL, real *SPOS, real *XLLWS) {
+  const int NANG = S.NANG, NFRE = S.NFRE;
+  real CONST1 = S.BETAMAXOXKAPPA2;
+  real CONST3 = C_(2.0) * S.XKAPPA / CONST1;
+  real XKAPPAD = C_(1.E0) / S.XKAPPA;
+  CONST3 = S.IDAMPING * CONST3;
+  real CONSTN = S.DELTH / (S.XKAPPA * S.ZPI);
+  real SIG_N = C_(0.0), CSTRNFAC = C_(0.0), WSIN[2], SIGDEV[2], US[2], Z0[2], USTPM1[2];
+  real UCN[2], CONST3_UCN2[2], UCND[2], ZCN[2], XVD[2], GAMNORMA[2];
+  static __thread real GAM0[2][NA];
+  int LZ[NA];
+  if (NGST > 1) SIG_N = wsigstar(WSWAVE, UFRIC, Z0M, WSTAR);
+  for (int K = 0; K < NANG; K++) LZ[K] = (COSWDIF[K] > C_(0.01));
+  if (S.c.llnormagam) CSTRNFAC = CONSTN * RNFAC / RAORW;
+  if (NGST == 1) { WSIN[0] = C_(1.0); SIGDEV[0] = C_(1.0); }
+  else { WSIN[0] = C_(0.5); WSIN[1] = C_(0.5); SIGDEV[0] = C_(1.0) - SIG_N; SIGDEV[1] = C_(1.0) + SIG_N; }
+  if (NGST == 1) { US[0] = UFRIC; Z0[0] = Z0M; }
+  else for (int IG = 0; IG < NGST; IG++) { US[IG] = UFRIC * SIGDEV[IG]; Z0[IG] = Z0M; }
+  for (int IG = 0; IG < NGST; IG++) USTPM1[IG] = C_(1.0) / RMAX(US[IG], S.EPSUS);
+  for (int M = 0; M < NFRE; M++) {
+    real CONST = S.ZPIFR[M] * CONST1;
+    real ZTANHKD = S.ZPIFR[M] * S.ZPIFR[M] / (S.G * WAVNUM[M]);
+    real CNSN = CONST * ZTANHKD * RAORW;
+    for (int IG = 0; IG < NGST; IG++) {
+      UCN[IG] = US[IG] * CINV[M] + S.ZALP;
+      CONST3_UCN2[IG] = CONST3 * (UCN[IG] * UCN[IG]);
+      UCND[IG] = C_(1.0) / UCN[IG];
+      ZCN[IG] = LOG(WAVNUM[M] * Z0[IG]);
+      XVD[IG] = C_(1.0) / (-US[IG] * XKAPPAD * ZCN[IG] * CINV[M]);
+    }
+    for (int K = 0; K < NANG; K++) {
+      X3(XLLWS, K, M) = C_(0.0);
+      for (int IG = 0; IG < NGST; IG++) {
+        if (LZ[K]) {
+          real ZLOG = ZCN[IG] + S.XKAPPA / COSWDIF[K] * UCND[IG];
+          if (ZLOG < C_(0.0)) {
+            real X = COSWDIF[K] * UCN[IG];
+            real ZLOG2X = ZLOG * ZLOG * X;
+            GAM0[IG][K] = ZLOG2X * ZLOG2X * EXP(ZLOG) * CNSN;
+            X3(XLLWS, K, M) = C_(1.0);
+          } else GAM0[IG][K] = C_(0.0);
+        } else GAM0[IG][K] = C_(0.0);
+      }
+    }
+    if (S.c.llnormagam) {
+      real XNGAMCONST = CSTRNFAC * XK2CG[M];
+      for (int IG = 0; IG < NGST; IG++) {
+        real SUMF = C_(0.0), SUMFSIN2 = C_(0.0);
+        for (int K = 0; K < NANG; K++) {
+          SUMF = SUMF + GAM0[IG][K] * F(K, M);
+          SUMFSIN2 = SUMFSIN2 + GAM0[IG][K] * F(K, M) * SINWDIF2[K];
+        }
+        real ZNZ = XNGAMCONST * USTPM1[IG];
+        GAMNORMA[IG] = (C_(1.0) + ZNZ * SUMFSIN2) / (C_(1.0) + ZNZ * SUMF);
+      }
+    } else { GAMNORMA[0] = C_(1.0); GAMNORMA[1] = C_(1.0); }
+    for (int K = 0; K < NANG; K++) {
+      real UFAC1 = WSIN[0] * GAM0[0][K] * GAMNORMA[0], UFAC2 = C_(0.0);
+      if (NGST == 2) UFAC1 = UFAC1 + WSIN[1] * GAM0[1][K] * GAMNORMA[1];
+      if (LLSNEG) {
+        real ZBETA = CONST3_UCN2[0] * (COSWDIF[K] - XVD[0]);
+        UFAC2 = WSIN[0] * ZBETA;
+        if (NGST == 2) {
+          ZBETA = CONST3_UCN2[1] * (COSWDIF[K] - XVD[1]);
+          UFAC2 = UFAC2 + WSIN[1] * ZBETA;
+        }
+      }
+      X3(FLD, K, M) = UFAC1 + UFAC2 * CNSN;
+      X3(SPOS, K, M) = UFAC1 * F(K, M);
+      X3(SL, K, M) = X3(FLD, K, M) * F(K, M);
+    }
+  }
+}
+
+/* sdissip_jan.F90:92-128 (IPHYS = 0): WAM cycle 4 whitecapping */
+static void sdissip_jan(const real *FL1, real *FLD, real *SL, const real *WAVNUM, real EMEAN, real F1MEAN, real XKMEAN) {
+  const int NANG = S.NANG, NFRE = S.NFRE;
+  real DELTA_SDISM1 = C_(1.0) - S.DELTA_SDIS;
+  real CONSS = S.CDIS * S.ZPI;
+  real SDS = CONSS * F1MEAN * (EMEAN * EMEAN) * powi(XKMEAN, 4);
+  for (int M = 0; M < NFRE; M++) {
+    real X = WAVNUM[M] / XKMEAN;
+    real XK2 = WAVNUM[M] * WAVNUM[M];
+    real CVIS = S.RNU * S.CDISVIS;
+    real TEMP1 = SDS * X * (DELTA_SDISM1 + S.DELTA_SDIS * X) + CVIS * XK2;
+    for (int K = 0; K < NANG; K++) {
+      X3(FLD, K, M) = X3(FLD, K, M) + TEMP1;
+      X3(SL, K, M) = X3(SL, K, M) + TEMP1 * F(K, M);
+    }
+  }
+}
+
 /* frcutindex.F90:84-108 */
 static int frcutindex(real FM, real FMWS, real UFRIC, real CICOVER, real *RHOWGDFTH) {
   const int NFRE = S.NFRE;
@@ -750,8 +846,12 @@ static int sinflx(int ICALL, int NCALL, int LUPDTUS, real *FL1, point_t *p, real
   }
   if (ICALL < NCALL) { NGST = 1; LLPHIWA = 0; LLSNEG = 0; }
   else { NGST = 2; LLPHIWA = 1; LLSNEG = 1; }
-  sinput_ard(NGST, LLSNEG, FL1, p->WAVNUM, p->CINV, p->XK2CG, p->WDWAVE, p->WSWAVE, p->UFRIC, p->Z0M, COSWDIF, SINWDIF2,
-             RAORW, p->WSTAR, RNFAC, FLD, SL, SPOS, XLLWS);
+  if (S.c.iphys == 0) /* sinput.F90:102-113 */
+    sinput_jan(NGST, LLSNEG, FL1, p->WAVNUM, p->CINV, p->XK2CG, p->WSWAVE, p->UFRIC, p->Z0M, COSWDIF, SINWDIF2, RAORW, p->WSTAR,
+               RNFAC, FLD, SL, SPOS, XLLWS);
+  else
+    sinput_ard(NGST, LLSNEG, FL1, p->WAVNUM, p->CINV, p->XK2CG, p->WDWAVE, p->WSWAVE, p->UFRIC, p->Z0M, COSWDIF, SINWDIF2,
+               RAORW, p->WSTAR, RNFAC, FLD, SL, SPOS, XLLWS);
   femeanws(FL1, XLLWS, FMEANWS, NULL);
   p->MIJ = frcutindex(FMEAN, *FMEANWS, p->UFRIC, p->CICOVER, RHOWGDFTH);
   stresso(p->MIJ, RHOWGDFTH, FL1, SL, SPOS, p->CINV, p->WDWAVE, p->UFRIC, p->Z0M, p->AIRD, RNFAC, COSWDIF, SINWDIF2,
@@ -1170,7 +1270,8 @@ static int implsch_point(real *FL1, real *XLLWS, point_t *p, real *dbg) {
                XLLWS)) return 1;
   }
   if (dbg) { dbg[0] = EMEAN; dbg[1] = FMEAN; dbg[2] = F1MEAN; dbg[3] = AKMEAN; dbg[4] = XKMEAN; dbg[5] = FMEANWS; dbg[6] = PHIWA; }
-  sdissip_ard(FL1, FLD, SL, p->WAVNUM, p->XK2CG, p->UFRIC, COSWDIF, RAORW);
+  if (S.c.iphys == 0) sdissip_jan(FL1, FLD, SL, p->WAVNUM, EMEAN, F1MEAN, XKMEAN); /* sdissip.F90:76-83 */
+  else sdissip_ard(FL1, FLD, SL, p->WAVNUM, p->XK2CG, p->UFRIC, COSWDIF, RAORW);
   if (LCFLX && !S.c.lwvflx_snl)
     for (int i = 0; i < NANG * NFRE; i++) SSOURCE[i] = SL[i];
   snonlin(FL1, FLD, SL, p->DEPTH, AKMEAN, p->WAVNUM);

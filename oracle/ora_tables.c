@@ -491,8 +491,10 @@ int ora_init(const ora_cfg *c) {
   S.SSDSC2 = C_(-2.2E-5); S.SSDSC4 = C_(1.0); S.SSDSC6 = C_(0.3); S.MICHE = C_(1.0); S.SSDSC3 = C_(0.0);
   S.RNU = (real)c->rnu; S.RNUM = (real)c->rnum;
 
-  /* setwavphys.F90:115-202 (IPHYS == 1) */
-  if (c->iphys != 1) return 2;
+  S.IDAMPING = 1; /* mpuserin.F90:609 */
+  S.CDIS = C_(0.0); S.DELTA_SDIS = C_(0.0); S.CDISVIS = C_(0.0);
+  if (c->iphys != 0 && c->iphys != 1) return 2;
+  /* setwavphys.F90:115-202 (IPHYS == 1), :46-112 (IPHYS == 0, applied below) */
   S.ZALP = C_(0.008); S.TAILFACTOR = C_(2.5); S.TAILFACTOR_PM = C_(3.0);
   if (NANG <= 24) { S.ANG_GC_A = C_(0.40); S.ANG_GC_B = C_(0.60); S.ANG_GC_C = C_(3.0); }
   else { S.ANG_GC_A = C_(0.35); S.ANG_GC_B = C_(0.65); S.ANG_GC_C = C_(3.0); }
@@ -513,6 +515,19 @@ int ora_init(const ora_cfg *c) {
     else { S.BETAMAX = C_(1.40); S.TAUWSHELTER = C_(0.25); S.ALPHAMIN = C_(0.0001); S.CHNKMIN_U = C_(33.); }
   }
   S.EGRCRV = C_(1065.0); S.AFCRV = C_(2.453E-4); S.BFCRV = C_(-3.1236);
+  if (c->iphys == 0) { /* Janssen wind input + WAM cycle 4 dissipation, setwavphys.F90:46-112 */
+    S.ZALP = C_(0.008); S.TAILFACTOR = C_(2.5); S.ALPHAMIN = C_(0.0001); S.ALPHAPMAX = C_(0.03); S.TAUWSHELTER = C_(0.0);
+    S.DELTA_THETA_RN = C_(0.75); S.DTHRN_A = C_(0.80); S.DTHRN_U = C_(33.0); S.RN1_RN = C_(0.25); S.TAILFACTOR_PM = C_(0.0);
+    if (c->llgcbz0) {
+      S.ALPHA = C_(0.0055); S.CHNKMIN_U = C_(28.);
+      S.BETAMAX = c->llnormagam ? C_(1.32) : C_(1.25);
+      S.CDIS = C_(-1.3); S.DELTA_SDIS = C_(0.6); S.CDISVIS = C_(-4.0);
+    } else {
+      S.ALPHA = C_(0.0065); S.CHNKMIN_U = C_(33.); S.BETAMAX = C_(1.20);
+      S.CDIS = C_(-1.33); S.DELTA_SDIS = C_(0.5); S.CDISVIS = C_(0.0);
+    }
+    S.EGRCRV = C_(1108.0); S.AFCRV = C_(4.0E-4); S.BFCRV = C_(-3.0);
+  }
 
   /* initmdl.F90:436-508 */
   for (int M = 1; M <= NFRE; M++) {

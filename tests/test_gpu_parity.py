@@ -128,6 +128,29 @@ def test_implsch_parity_sea_ice_attenuation(api, prec, flags):
 
 
 @pytest.mark.parametrize("prec", ["dp", "sp"])
+@pytest.mark.parametrize("llnormagam", [False, True])
+def test_implsch_parity_iphys_0(api, prec, llnormagam):
+    """IPHYS = 0 (the reference's etopo1_oper_an_fc_O48_iphys_0 configuration): Janssen wind input with gustiness and swell
+    damping (sinput_jan.F90) and the WAM cycle 4 dissipation (sdissip_jan.F90), constants of setwavphys.F90:46-112."""
+    cfg = Config(nang=12, nfre=36, nfre_red=25, iphys=0, llnormagam=llnormagam)
+    n = 1100
+    case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=61)
+    ref = H.oracle_implsch(case, _oracle(cfg, prec))
+    ctx = api.HipContext(case["tables"])
+    got = H.gpu_implsch(case, ctx)
+    st = H.compare_implsch(ref, got, case["tables"])
+    ctx.close()
+    assert np.isfinite(got["FL1"]).all() and np.isfinite(got["FF"]).all() and np.isfinite(got["INTF"]).all()
+    if prec == "dp":
+        assert st["mij_flips"] == 0 and st["xllws_bins_diff"] == 0, st
+        assert st["fl1_max_rel_peak_all"] < 1e-10 and st["ff_max_rel_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
+    else:
+        assert st["mij_flips"] <= n * 0.005 and st["xllws_pts_diff"] <= n * 0.005, st
+        assert st["fl1_max_rel_peak_clean"] < 1e-4 and st["swh_max_rel"] < 1e-5, st
+        assert st["ff_max_rel_clean"] < 1e-4 and st["intf_max_rel_clean"] < 5e-3, st
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
 def test_implsch_parity_isnonlin_1(api, prec):
     """ISNONLIN = 1: the DIA scaled per interaction frequency by TRANSF(k, depth) (snonlin.F90:138-150, transf.F90) on a
     case with many intermediate-depth points."""

@@ -44,7 +44,7 @@ def test_create_refuses_unsupported_configurations_without_a_gpu():
     h = lib.load()
     t = Tables(Config(nang=12, nfre=36, nfre_red=25), np.float32)
     tp, keep = lib.make_tables(t)
-    cases = [(dict(lciwa1=1), "SDICE1"), (dict(iphys=0), "IPHYS"), (dict(irefra=2), "IREFRA"), (dict(lwnemocouwrs=1), "LWNEMOCOUWRS"),
+    cases = [(dict(lciwa1=1), "SDICE1"), (dict(iphys=2), "IPHYS"), (dict(irefra=2), "IREFRA"), (dict(lwnemocouwrs=1), "LWNEMOCOUWRS"),
              (dict(nang=3), "NANG"), (dict(nfre_red=40), "NFRE_RED")]
     for changes, word in cases:
         p = lib.make_params(t)

@@ -32,9 +32,34 @@ from ecwam_amd.wamintgr import Wamintgr  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
+def usable_cores() -> int:
+    """Cores this process may actually run on: scheduler affinity, capped by the cgroup CPU quota (a GPU box hands one GPU's
+    share of a large host to the job; os.cpu_count() reports the whole host)."""
+    n = len(os.sched_getaffinity(0))
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(f) as fh:
+                tok = fh.read().split()
+            if f.endswith("cpu.max"):
+                if tok[0] != "max":
+                    n = min(n, max(1, int(float(tok[0]) / float(tok[1]) + 0.5)))
+            else:
+                q = int(tok[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                    per = int(fh.read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(nang: int, nfre: int, prec: str, target_s: float = 15.0) -> dict:
     """Oracle (plain-C restatement, OpenMP over points) timed on this host on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    cores = int(os.environ.get("ECWAM_BENCH_CPU_THREADS", "0")) or usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)     # read by libgomp when the oracle library is loaded below
     from ecwam_amd import synthetic as syn
     from ecwam_amd.tables import Tables
     from oracle.oracle import Oracle
@@ -65,9 +90,10 @@ def cpu_baseline(nang: int, nfre: int, prec: str, target_s: float = 15.0) -> dic
         el = time.perf_counter() - t0
         if el > target_s or steps >= 50:
             break
-    return {"value": n * steps / el, "unit": "grid-point spectral steps/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": n * steps / el, "unit": "grid-point spectral steps/s", "cores": cores, "kind": "port",
             "sample": f"O48 all-ocean grid ({n} sea points), {nang}x{nfre} spectrum, {prec}, {steps} full steps "
-                      f"(PROPAGS2 + IMPLSCH), oracle/ C restatement with OpenMP over points"}
+                      f"(PROPAGS2 + IMPLSCH), oracle/ C restatement with OpenMP over points, {cores} threads "
+                      f"(host reports {os.cpu_count()} logical CPUs)"}
 
 
 def main() -> None:

@@ -124,6 +124,56 @@ class HipContext:
                 self._real(cgroup_ext, (nrow, self.NFRE), "CGROUP_EXT"), self._real(g["cosphm1_ext"], (nrow,), "COSPHM1_EXT"), po]
         self._chk(self.lib.ecwam_hip_propags2_otf(self._h, *args, kijs, kijl, nd3s, nd3e, int(copy_rest), _stream_ptr()))
 
+    # -- refraction (IREFRA = 1, 2, 3): GRADI + PROPDOT per point, CTUWDRV checks, PROPAGS2 with all weights on the fly
+    def _geom(self, g, n, ngy):
+        return [self._int(g["kxlt"], (n,), "KXLT"), self._real(g["zdello"], (ngy,), "ZDELLO"), float(g["xdella"]),
+                self._real(g["cosph"], (ngy,), "COSPH"), self._real(g["sinph"], (ngy,), "SINPH"),
+                self._int(g["klon"], (n, 2), "KLON"), self._int(g["klat"], (n, 2, 2), "KLAT"), self._int(g["kcor"], (n, 4, 2), "KCOR"),
+                self._real(g["wlat"], (n, 2), "WLAT"), self._real(g["wcor"], (n, 4), "WCOR")]
+
+    def propdot(self, grid_dev: dict, depth_ext, u_ext, v_ext, refr):
+        g = grid_dev
+        n, nland, ngy = g["n"], g["nland"], g["ngy"]
+        nrow = depth_ext.shape[0]
+        if nland >= nrow:
+            raise ValueError("PROPDOT: the *_EXT arrays must include the land row")
+        self._chk(self.lib.ecwam_hip_propdot(
+            self._h, n, nland, self._int(g["kxlt"], (n,), "KXLT"), self._real(g["zdello"], (ngy,), "ZDELLO"), float(g["xdella"]),
+            self._real(g["cosph"], (ngy,), "COSPH"), self._int(g["klon"], (n, 2), "KLON"), self._int(g["klat"], (n, 2, 2), "KLAT"),
+            self._real(g["wlat"], (n, 2), "WLAT"), self._real(g["cosphm1_ext"], (nrow,), "COSPHM1_EXT"),
+            self._real(depth_ext, (nrow,), "DEPTH_EXT"), self._real(u_ext, (nrow,), "U_EXT"), self._real(v_ext, (nrow,), "V_EXT"),
+            self._real(refr, (n, 2 * self.NANG + 5), "REFR"), _stream_ptr()))
+
+    def ctuw_refra(self, grid_dev: dict, cgroup_ext, omosnh2kd_ext, wavnum_ext, refr, cflfail, delpro: float, mstart=1, mend=None,
+                   llcflcuroff=True, frange=0):
+        mend = self.NR if mend is None else mend
+        g = grid_dev
+        n, nland, ngy = g["n"], g["nland"], g["ngy"]
+        nrow = cgroup_ext.shape[0]
+        if nland >= nrow:
+            raise ValueError("CTUW: CGROUP_EXT must include the land row")
+        ext = [self._real(a, (nrow, self.NFRE), nm) for a, nm in ((cgroup_ext, "CGROUP_EXT"), (omosnh2kd_ext, "OMOSNH2KD_EXT"),
+                                                                 (wavnum_ext, "WAVNUM_EXT"))]
+        self._chk(self.lib.ecwam_hip_ctuw_refra(self._h, n, nland, ngy, float(delpro), mstart, mend, *self._geom(g, n, ngy), *ext,
+                                                self._real(g["cosphm1_ext"], (nrow,), "COSPHM1_EXT"),
+                                                self._real(refr, (n, 2 * self.NANG + 5), "REFR"), int(llcflcuroff), int(frange),
+                                                self._int(cflfail, (n,), "CFLFAIL"), _stream_ptr()))
+
+    def propags2_refra(self, f1, f3, grid_dev: dict, cgroup_ext, omosnh2kd_ext, wavnum_ext, refr, delpro: float, kijs, kijl, nd3s=1,
+                       nd3e=None, copy_rest=True, frange=0):
+        nd3e = self.NR if nd3e is None else nd3e
+        g = grid_dev
+        n, nland, ngy = g["n"], g["nland"], g["ngy"]
+        nrow = f1.shape[0]
+        if not (0 <= kijs <= kijl <= n) or nland >= nrow or cgroup_ext.shape[0] != nrow:
+            raise ValueError("PROPAGS2: KIJS/KIJL outside the neighbour tables, or F1 / CGROUP_EXT without the land row")
+        ext = [self._real(a, (nrow, self.NFRE), nm) for a, nm in ((cgroup_ext, "CGROUP_EXT"), (omosnh2kd_ext, "OMOSNH2KD_EXT"),
+                                                                 (wavnum_ext, "WAVNUM_EXT"))]
+        self._chk(self.lib.ecwam_hip_propags2_refra(
+            self._h, self._real(f1, (nrow, self.NANG, self.NFRE), "F1"), self._real(f3, (nrow, self.NANG, self.NFRE), "F3"), n, ngy,
+            float(delpro), *self._geom(g, n, ngy), *ext, self._real(g["cosphm1_ext"], (nrow,), "COSPHM1_EXT"),
+            self._real(refr, (n, 2 * self.NANG + 5), "REFR"), int(frange), kijs, kijl, nd3s, nd3e, int(copy_rest), _stream_ptr()))
+
     # -- IMPLSCH (implsch.F90:10-23)
     def implsch(self, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, dbg=None, wam2nemo=None):
         nrow = fl1.shape[0]

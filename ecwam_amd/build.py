@@ -18,23 +18,28 @@ EXTRA = {"implsch.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+INCLUDE = os.path.join(HERE, "..", "include", "ecwam_hip.h")
+DEPS = {"capi.hip": ["dev.h"], "propag.hip": ["dev.h"], "implsch.hip": ["dev.h", "implsch_v2.h"], "outbs.hip": ["dev.h"]}
+
+
+def _obj_stale(src: str, obj: str) -> bool:
+    if not os.path.exists(obj):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "ecwam_hip.h")]
+    t = os.path.getmtime(obj)
+    deps = [os.path.join(CSRC, src), INCLUDE, os.path.abspath(__file__)] + [os.path.join(CSRC, d) for d in DEPS.get(src, [])]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
-        return LIB
+    """Compile the objects whose source (or a header it includes) changed, then link."""
     os.makedirs(LIBDIR, exist_ok=True)
     objs = []
     procs = []
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(obj)
+        if not force and not _obj_stale(src, obj):
+            continue
         cmd = [HIPCC, *FLAGS, *EXTRA.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -45,6 +50,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed for {src}:\n{out}")
         if verbose and out.strip():
             print(out)
+    if not procs and os.path.exists(LIB) and all(os.path.getmtime(o) <= os.path.getmtime(LIB) for o in objs):
+        return LIB
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:

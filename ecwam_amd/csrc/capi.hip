@@ -30,6 +30,10 @@ struct ecwam_hip_ctx {
 // launchers implemented in propag.hip / implsch.hip
 template <typename T> void launch_propags2(const void*, const void*, void*, const int*, const int*, const int*, const void*, int, int, int, int, int, int, hipStream_t);
 template <typename T> void launch_ctuw(const void*, int, int, int, double, int, int, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, void*, void*, const void*, const void*, void*, int*, int, hipStream_t);
+template <typename T> void launch_ctuwini_only(int, int, const int*, const int*, void*, void*, hipStream_t);
+template <typename T> void launch_propdot(const void*, int, int, int, const int*, const void*, double, const void*, const int*, const int*, const void*, const void*, const void*, const void*, const void*, void*, hipStream_t);
+template <typename T> void launch_curmask(int, int, int, const int*, void*, hipStream_t);
+template <typename T> void launch_propags2_gen(const void*, int, const void*, void*, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const void*, const void*, const void*, int*, int, int, int, int, int, int, int, hipStream_t);
 template <typename T> void launch_propags2_otf(const void*, const void*, void*, int, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const int*, int, int, int, int, int, int, hipStream_t);
 template <typename T> int launch_outbs(const void*, int, int, const void*, double, void*, int, int, hipStream_t);
 template <typename T> void launch_norm(const void*, int, int, double, double*, int, hipStream_t);
@@ -188,8 +192,8 @@ int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int r
   if (p->nang < 4 || p->nang > MAXA || p->nfre < 8 || p->nfre > MAXF || p->nfre_red < 1 || p->nfre_red > p->nfre)
     return fail("ecwam_hip_create: NANG/NFRE/NFRE_RED out of the supported range");
   if (p->mlsthg > MAXMC || 2 * p->nsdsnth + 1 > MAXTAP || p->nwav_gc + 1 > MAXGC) return fail("ecwam_hip_create: table size exceeds library limits");
-  if ((p->iphys != 0 && p->iphys != 1) || (p->isnonlin != 0 && p->isnonlin != 1) || p->irefra != 0 || p->icode != 3)
-    return fail("ecwam_hip_create: only IPHYS=0/1, ISNONLIN=0/1, IREFRA=0, ICODE=3 are on the hot path (SURVEY.md 8a)");
+  if ((p->iphys != 0 && p->iphys != 1) || (p->isnonlin != 0 && p->isnonlin != 1) || p->irefra < 0 || p->irefra > 3 || p->icode != 3)
+    return fail("ecwam_hip_create: only IPHYS=0/1, ISNONLIN=0/1, IREFRA=0..3, ICODE=3 are on the hot path (SURVEY.md 8a)");
   if (p->lciwa1) return fail("ecwam_hip_create: SDICE1 (scattering attenuation table CIDEAC, sdice1.F90) not supported yet");
   if (p->lwnemocouwrs || p->lwnemocoustrn) return fail("ecwam_hip_create: LWNEMOCOUWRS (ice radiative stress from SLICE) / LWNEMOCOUSTRN (CIMSSTRN) not supported yet");
   HIPCHK(hipSetDevice(device));
@@ -276,6 +280,102 @@ int ecwam_hip_propags2_otf(ecwam_hip_ctx* c, const void* f1, void* f3, int n, in
            launch_propags2_otf<double>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, s));
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+int ecwam_hip_propdot(ecwam_hip_ctx* c, int n, int nland, const int* kxlt, const void* zdello, double xdella, const void* cosph,
+                      const int* klon, const int* klat, const void* wlat, const void* cosphm1_ext, const void* depth_ext,
+                      const void* u_ext, const void* v_ext, void* refr, void* stream) {
+  if (!c) return fail("null context");
+  if (n < 0) return fail("ecwam_hip_propdot: bad range");
+  if (n > 0 && (!kxlt || !zdello || !cosph || !klon || !klat || !wlat || !cosphm1_ext || !depth_ext || !u_ext || !v_ext || !refr))
+    return fail("ecwam_hip_propdot: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH(launch_propdot<float>(c->dtab, n, nland, c->p.irefra, kxlt, zdello, xdella, cosph, klon, klat, wlat, cosphm1_ext, depth_ext, u_ext, v_ext, refr, s),
+           launch_propdot<double>(c->dtab, n, nland, c->p.irefra, kxlt, zdello, xdella, cosph, klon, klat, wlat, cosphm1_ext, depth_ext, u_ext, v_ext, refr, s));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// shared argument checks + launch of the general-IREFRA kernel (f1 == NULL: checks only)
+static int propags2_gen_launch(ecwam_hip_ctx* c, const char* who, const void* f1, void* f3, int ngy, double delpro,
+                               const int* kxlt, const void* zdello, double xdella, const void* cosph, const void* sinph,
+                               const int* klon, const int* klat, const int* kcor, const void* wlat, const void* wcor,
+                               const void* cgroup_ext, const void* omosnh2kd_ext, const void* wavnum_ext, const void* cosphm1_ext,
+                               const void* refr, int* cflfail, int slot, int kijs, int kijl, int m0, int m1, int copy_rest,
+                               hipStream_t s) {
+  if (kijl > kijs && (!kxlt || !zdello || !cosph || !sinph || !klon || !klat || !kcor || !wlat || !wcor || !cgroup_ext || !omosnh2kd_ext ||
+                      !wavnum_ext || !cosphm1_ext || !refr))
+    return fail((std::string(who) + ": null pointer").c_str());
+  const int N = (c->NANG << 16) | (c->NFRE << 8) | c->NFRE_RED;
+  DISPATCH(launch_propags2_gen<float>(c->dtab, c->p.irefra, f1, f3, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, omosnh2kd_ext, wavnum_ext, cosphm1_ext, refr, cflfail, slot, kijs, kijl, m0, m1, copy_rest, N, s),
+           launch_propags2_gen<double>(c->dtab, c->p.irefra, f1, f3, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, omosnh2kd_ext, wavnum_ext, cosphm1_ext, refr, cflfail, slot, kijs, kijl, m0, m1, copy_rest, N, s));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ecwam_hip_ctuw_refra(ecwam_hip_ctx* c, int n, int nland, int ngy, double delpro, int mstart, int mend, const int* kxlt,
+                         const void* zdello, double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat,
+                         const int* kcor, void* wlat, void* wcor, const void* cgroup_ext, const void* omosnh2kd_ext,
+                         const void* wavnum_ext, const void* cosphm1_ext, void* refr, int llcflcuroff, int range, int* cflfail,
+                         void* stream) {
+  if (!c) return fail("null context");
+  if (n < 0 || mstart < 1 || mend > c->NFRE_RED || mend < mstart || range < 0 || range > 1) return fail("ecwam_hip_ctuw_refra: bad range");
+  if (n > 0 && (!wlat || !wcor || !cflfail || !klat || !kcor || !refr)) return fail("ecwam_hip_ctuw_refra: null pointer");
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  // CTUWINI (ctuwupdt.F90:204-214; idempotent), then CTUWDRV for this frequency range (ctuwdrv.F90:93-118)
+  DISPATCH(launch_ctuwini_only<float>(n, nland, klat, kcor, wlat, wcor, s), launch_ctuwini_only<double>(n, nland, klat, kcor, wlat, wcor, s));
+  const bool cur = c->p.irefra == 2 || c->p.irefra == 3;
+  std::vector<int> prev;  // flags of the first range survive the second range's own CTUWDRV
+  if (range == 1) {
+    prev.resize((size_t)n);
+    HIPCHK(hipMemcpyAsync(prev.data(), cflfail, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  HIPCHK(hipMemsetAsync(cflfail, 0, sizeof(int) * (size_t)n, s));
+  DISPATCH(launch_curmask<float>(n, c->NANG, range, nullptr, refr, s), launch_curmask<double>(n, c->NANG, range, nullptr, refr, s));  // CURMASK = 1
+  int rc = propags2_gen_launch(c, "ecwam_hip_ctuw_refra", nullptr, nullptr, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor,
+                               wlat, wcor, cgroup_ext, omosnh2kd_ext, wavnum_ext, cosphm1_ext, refr, cflfail, range, 0, n, mstart - 1, mend, 0, s);
+  if (rc) return rc;
+  if (cur && llcflcuroff) {
+    // second CTUW call: current refraction / frequency shift switched off where the first one failed, flags reset
+    std::vector<int> h((size_t)n);
+    HIPCHK(hipMemcpyAsync(h.data(), cflfail, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    bool any = false;
+    for (int i = 0; i < n && !any; i++) any = h[i] != 0;
+    if (any) {
+      DISPATCH(launch_curmask<float>(n, c->NANG, range, cflfail, refr, s), launch_curmask<double>(n, c->NANG, range, cflfail, refr, s));
+      HIPCHK(hipMemsetAsync(cflfail, 0, sizeof(int) * (size_t)n, s));
+      rc = propags2_gen_launch(c, "ecwam_hip_ctuw_refra", nullptr, nullptr, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat,
+                               kcor, wlat, wcor, cgroup_ext, omosnh2kd_ext, wavnum_ext, cosphm1_ext, refr, cflfail, range, 0, n, mstart - 1, mend, 0, s);
+      if (rc) return rc;
+    }
+  }
+  if (range == 1) {
+    std::vector<int> h((size_t)n);
+    HIPCHK(hipMemcpyAsync(h.data(), cflfail, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int i = 0; i < n; i++) h[i] |= prev[i];
+    HIPCHK(hipMemcpyAsync(cflfail, h.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  return 0;
+}
+
+int ecwam_hip_propags2_refra(ecwam_hip_ctx* c, const void* f1, void* f3, int n, int ngy, double delpro, const int* kxlt,
+                             const void* zdello, double xdella, const void* cosph, const void* sinph, const int* klon,
+                             const int* klat, const int* kcor, const void* wlat, const void* wcor, const void* cgroup_ext,
+                             const void* omosnh2kd_ext, const void* wavnum_ext, const void* cosphm1_ext, const void* refr, int range,
+                             int kijs, int kijl, int nd3s, int nd3e, int copy_rest, void* stream) {
+  if (!c) return fail("null context");
+  if (kijl < kijs || kijs < 0 || kijl > n || nd3s < 1 || nd3e > c->NFRE_RED || nd3e < nd3s - 1 || range < 0 || range > 1)
+    return fail("ecwam_hip_propags2_refra: bad range");
+  if (kijl > kijs && (!f1 || !f3)) return fail("ecwam_hip_propags2_refra: null pointer");
+  if (f1 == f3) return fail("ecwam_hip_propags2_refra: F1 and F3 must not alias");
+  return propags2_gen_launch(c, "ecwam_hip_propags2_refra", f1, f3, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat,
+                             wcor, cgroup_ext, omosnh2kd_ext, wavnum_ext, cosphm1_ext, refr, nullptr, range, kijs, kijl, nd3s - 1, nd3e,
+                             copy_rest ? 1 : 0, (hipStream_t)stream);
 }
 
 int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws,

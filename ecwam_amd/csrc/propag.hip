@@ -429,6 +429,355 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
   }
 }
 
+// =====================================================================================================================
+// IREFRA = 1 (depth refraction), 2 (current refraction), 3 (depth + current refraction)
+//
+// The reference keeps THDD/THDC(IJ,K), SDOT(IJ,K,M) and 21 weight arrays per (IJ,K,M) (ctuwupdt.F90:163-177).  Here the
+// per-point part of PROPDOT is stored -- REFR[ij][2*NANG+5] = THD(K) (THDD for IREFRA=1, THDC otherwise), S0(K) (the
+// current-gradient factor of SDOT, propdot.F90:172-173), U, V, OMDD, CURMASK of the first / second frequency range
+// (CTUWDRV is called per range, ctuwupdt.F90:220-256) -- and everything per (K,M) is rebuilt inside
+// the stencil, as for IREFRA=0.
+// =====================================================================================================================
+#define REFR_U(NANG) (2 * (NANG))
+#define REFR_V(NANG) (2 * (NANG) + 1)
+#define REFR_OMDD(NANG) (2 * (NANG) + 2)
+#define REFR_MASK(NANG) (2 * (NANG) + 3)
+#define REFR_W(NANG) (2 * (NANG) + 5)
+
+// gradi.F90:113-232 + propdot.F90:108-196, one thread per point
+template <typename T>
+__global__ void k_propdot(const DevTab<T>* __restrict__ tab, int n, int nland, int IREFRA, const int* __restrict__ kxlt,
+                          const T* __restrict__ zdello, T xdella, const T* __restrict__ cosph, const int* __restrict__ klon,
+                          const int* __restrict__ klat, const T* __restrict__ wlat, const T* __restrict__ cosphm1,
+                          const T* __restrict__ depth, const T* __restrict__ ue, const T* __restrict__ ve, T* __restrict__ refr) {
+#pragma clang fp contract(off)
+  const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ij >= n) return;
+  const int NANG = tab->NANG;
+  const T CGM = T(0.00001);  // CURRENT_GRADIENT_MAX, yowcurr.F90:19
+  const T DELPHI = xdella * tab->CIRC / T(360.0);
+  const T ONEO2DELPHI = T(0.5) / DELPHI;
+  const int KX = kxlt[ij];
+  const T DELLAM = zdello[KX] * tab->CIRC / T(360.0);
+  T DDPHI = T(0), DDLAM = T(0), DUPHI = T(0), DULAM = T(0), DVPHI = T(0), DVLAM = T(0);
+  const T wl0 = wlat[ij * 2 + 0], wl1 = wlat[ij * 2 + 1];
+  if (IREFRA == 1 || IREFRA == 3) {
+    const int IPP = klat[(ij * 2 + 1) * 2 + 0], IPM = klat[(ij * 2 + 0) * 2 + 0];
+    const int IPP2 = klat[(ij * 2 + 1) * 2 + 1], IPM2 = klat[(ij * 2 + 0) * 2 + 1];
+    if (IPP != nland && IPM != nland && IPP2 != nland && IPM2 != nland) {
+      const T DPTP = wl1 * depth[IPP] + (T(1) - wl1) * depth[IPP2];
+      const T DPTM = wl0 * depth[IPM] + (T(1) - wl0) * depth[IPM2];
+      DDPHI = (DPTP - DPTM) * ONEO2DELPHI;
+    } else if (IPP != nland && IPM != nland) DDPHI = (depth[IPP] - depth[IPM]) * ONEO2DELPHI;
+    else if (IPP2 != nland && IPM2 != nland) DDPHI = (depth[IPP2] - depth[IPM2]) * ONEO2DELPHI;
+    const int ILP = klon[ij * 2 + 1], ILM = klon[ij * 2 + 0];
+    if (ILP != nland && ILM != nland) DDLAM = (depth[ILP] - depth[ILM]) / (T(2) * DELLAM);
+  }
+  if (IREFRA == 2 || IREFRA == 3) {
+    int IPP = klat[(ij * 2 + 1) * 2 + 0], IPM = klat[(ij * 2 + 0) * 2 + 0];
+    int IPP2 = klat[(ij * 2 + 1) * 2 + 1], IPM2 = klat[(ij * 2 + 0) * 2 + 1];
+    // an exact zero means "current not defined there": no gradient is extrapolated (gradi.F90:170-180)
+    if (ue[IPP] == T(0) && ve[IPP] == T(0)) IPP = nland;
+    if (ue[IPM] == T(0) && ve[IPM] == T(0)) IPM = nland;
+    if (ue[IPP2] == T(0) && ve[IPP2] == T(0)) IPP2 = nland;
+    if (ue[IPM2] == T(0) && ve[IPM2] == T(0)) IPM2 = nland;
+    if (IPP != nland && IPM != nland && IPP2 != nland && IPM2 != nland) {
+      const T UP = wl1 * ue[IPP] + (T(1) - wl1) * ue[IPP2], VP = wl1 * ve[IPP] + (T(1) - wl1) * ve[IPP2];
+      const T UM = wl0 * ue[IPM] + (T(1) - wl0) * ue[IPM2], VM = wl0 * ve[IPM] + (T(1) - wl0) * ve[IPM2];
+      DUPHI = (UP - UM) * ONEO2DELPHI;
+      DVPHI = (VP - VM) * ONEO2DELPHI;
+    } else if (IPP != nland && IPM != nland) {
+      DUPHI = (ue[IPP] - ue[IPM]) * ONEO2DELPHI;
+      DVPHI = (ve[IPP] - ve[IPM]) * ONEO2DELPHI;
+    }
+    int ILP = klon[ij * 2 + 1], ILM = klon[ij * 2 + 0];
+    if (ue[ILP] == T(0) && ve[ILP] == T(0)) ILP = nland;
+    if (ue[ILM] == T(0) && ve[ILM] == T(0)) ILM = nland;
+    if (ILP != nland && ILM != nland) {
+      DULAM = (ue[ILP] - ue[ILM]) / (T(2) * DELLAM);
+      DVLAM = (ve[ILP] - ve[ILM]) / (T(2) * DELLAM);
+    }
+    const T CGMAX = CGM * cosph[KX];
+    DUPHI = m_sign(m_min(m_abs(DUPHI), CGMAX), DUPHI);
+    DVPHI = m_sign(m_min(m_abs(DVPHI), CGMAX), DVPHI);
+    DULAM = m_sign(m_min(m_abs(DULAM), CGMAX), DULAM);
+    DVLAM = m_sign(m_min(m_abs(DVLAM), CGMAX), DVLAM);
+  }
+  const T DCO = cosphm1[ij];
+  T* o = refr + (size_t)ij * REFR_W(NANG);
+  o[REFR_U(NANG)] = ue[ij];
+  o[REFR_V(NANG)] = ve[ij];
+  o[REFR_OMDD(NANG)] = (IREFRA == 3) ? ve[ij] * DDPHI + ue[ij] * DDLAM * DCO : T(0);
+  o[REFR_MASK(NANG)] = T(1);
+  o[REFR_MASK(NANG) + 1] = T(1);
+  for (int k = 0; k < NANG; k++) {
+    const T SD = tab->SINTH[k], CD = tab->COSTH[k];
+    T thd = T(0), s0 = T(0);
+    if (IREFRA == 1) thd = SD * DDPHI - CD * DDLAM * DCO;  // THDD enters CTUW for IREFRA = 1 only (ctuw.F90:434)
+    if (IREFRA == 2 || IREFRA == 3) {
+      const T SS = SD * SD, SC = SD * CD, CC = CD * CD;
+      s0 = -SC * DUPHI - CC * DVPHI - (SS * DULAM + SC * DVLAM) * DCO;
+      thd = SS * DUPHI + SC * DVPHI - (SC * DULAM + CC * DVLAM) * DCO;
+    }
+    o[k] = thd;
+    o[NANG + k] = s0;
+  }
+}
+
+// All weights of one (point, K, M) for any IREFRA (ctuw.F90:146-275, 403-527, 536-687); returns the CFL / range flag.
+// jx0,jx1,jy0,jy1,kc[] are the 0-based JXO/JYO/KCR entries of direction K.  dthp/dthm: the complete theta-dot sums of the
+// direction refraction, fdp/fdm: those of the frequency shift (formed by the caller), cur: IREFRA = 2 or 3.
+template <typename T>
+struct CtuGenW {
+  T sumwn, wlon[2], wlat[2][2], wcor[4][2], wk[3], wm[3];
+};
+template <typename T>
+__device__ __forceinline__ bool same_sign(T a, T b) { return __builtin_signbit(a) == __builtin_signbit(b); }
+template <typename T>
+__device__ __forceinline__ bool ctu_wgen(const CtuBase<T>& b, T sink, T cosk, const CtuPoint<T>& p, T xdella, T delpro, T cmtodeg,
+                                         int jx0, int jx1, int jy0, int jy1, const int* kc, bool cur, T u, T v, T dthp, T dthm,
+                                         T fdp, T fdm, T fratio, CtuGenW<T>& w) {
+#pragma clang fp contract(off)
+  T adxp[2], adyp[2], dxup[2], dxdw[2], dyup[2], dydw[2];
+  bool fail = false;
+  for (int ic = 0; ic < 2; ic++) {
+    const T cgx = b.h[ic] * sink * p.cpm1;
+    const T cgy = b.hy[ic] * cosk;
+    T urel = cgx, vrel = cgy;
+    bool su = true, sv = true;
+    if (cur) {
+      const T uu = u * p.cpm1;
+      urel = cgx + uu;
+      su = same_sign(urel, cgx);
+      const T vv = v * T(0.5) * (T(1) + p.dp[ic]);
+      vrel = cgy + vv;
+      sv = same_sign(vrel, cgy);
+    }
+    adxp[ic] = m_abs(-delpro * urel * cmtodeg);
+    adyp[ic] = m_abs(-delpro * vrel * cmtodeg);
+    dxup[ic] = su ? adxp[ic] : T(0); dxdw[ic] = su ? T(0) : adxp[ic];
+    dyup[ic] = sv ? adyp[ic] : T(0); dydw[ic] = sv ? T(0) : adyp[ic];
+    if (adxp[ic] > p.zd || adyp[ic] > xdella) fail = true;
+  }
+  const T dxx = p.zd - dxup[jx1] - dxdw[jx0];
+  const T dyy = xdella - dyup[jy1] - dydw[jy0];
+  T wgt[2];
+  wgt[jy0] = dxx * dyup[jy0] * p.ga;
+  wgt[jy1] = dxx * dydw[jy1] * p.ga;
+  for (int ic = 0; ic < 2; ic++) {
+    w.wlat[ic][0] = p.wl[ic] * wgt[ic];
+    w.wlat[ic][1] = (T(1) - p.wl[ic]) * wgt[ic];
+  }
+  w.wlon[jx0] = dyy * dxup[jx0] * p.ga;
+  w.wlon[jx1] = dyy * dxdw[jx1] * p.ga;
+  T wc4[4];
+  wc4[0] = dxup[jx0] * dyup[jy0] * p.ga;
+  wc4[1] = dxdw[jx1] * dyup[jy0] * p.ga;
+  wc4[2] = dxup[jx0] * dydw[jy1] * p.ga;
+  wc4[3] = dxdw[jx1] * dydw[jy1] * p.ga;
+  for (int icr = 0; icr < 4; icr++) {
+    const T wcv = p.wc[kc[icr]];
+    w.wcor[icr][0] = wcv * wc4[icr];
+    w.wcor[icr][1] = (T(1) - wcv) * wc4[icr];
+  }
+  T sumwn = (p.zd * (dydw[jy0] + dyup[jy1]) + xdella * (dxup[jx1] + dxdw[jx0]) - (dxdw[jx0] + dxup[jx1]) * (dydw[jy0] + dyup[jy1])) * p.ga;
+  w.wk[1] = (dthp + m_abs(dthp)) + (m_abs(dthm) - dthm);
+  w.wk[2] = -dthp + m_abs(dthp);
+  w.wk[0] = dthm + m_abs(dthm);
+  w.wm[0] = w.wm[1] = w.wm[2] = T(0);
+  if (cur) {
+    w.wm[1] = (fdp + m_abs(fdp)) + (m_abs(fdm) - fdm);
+    w.wm[2] = (-fdp + m_abs(fdp)) / fratio;
+    w.wm[0] = (fdm + m_abs(fdm)) * fratio;
+  }
+  const T one = T(1), zero = T(0);
+#define OUTR(x) ((x) > one || (x) < zero)
+  for (int i = 0; i < 2; i++) {
+    if (OUTR(w.wlon[i]) || OUTR(w.wlat[i][0]) || OUTR(w.wlat[i][1])) fail = true;
+  }
+  for (int i = 0; i < 4; i++)
+    if (OUTR(w.wcor[i][0]) || OUTR(w.wcor[i][1])) fail = true;
+  for (int i = 0; i < 3; i++)
+    if (OUTR(w.wk[i]) || OUTR(w.wm[i])) fail = true;
+  sumwn = sumwn + w.wk[1];
+  if (cur) sumwn = sumwn + w.wm[1];
+  if (OUTR(sumwn)) fail = true;
+#undef OUTR
+  w.sumwn = sumwn;
+  return fail;
+}
+
+// theta-dot and sigma-dot sums of one (point, K, M) (ctuw.F90:424-452, 471-493, 506-520) from the per-point REFR row
+template <typename T>
+__device__ __forceinline__ void ctu_refr_terms(const DevTab<T>* tab, int IREFRA, const T* rr, int slot, int k, int m, int NR, T tanph,
+                                               T sp, T sm, T delth0, T delfr0, T cg0, T om0, const T* cgrow, const T* omrow,
+                                               const T* wnrow, T& dthp, T& dthm, T& fdp, T& fdm) {
+#pragma clang fp contract(off)
+  const int NANG = tab->NANG;
+  const int kp1 = tab->KPM[k][2], km1 = tab->KPM[k][0];
+  const T drgp = tanph * sp, drgm = tanph * sm;
+  const bool cur = (IREFRA == 2 || IREFRA == 3);
+  T drdp = T(0), drdm = T(0), drcp = T(0), drcm = T(0);
+  if (IREFRA == 1) {
+    drdp = (rr[k] + rr[kp1]) * delth0;
+    drdm = (rr[k] + rr[km1]) * delth0;
+  }
+  const T mask = rr[REFR_MASK(NANG) + slot];
+  if (cur) {
+    drcp = mask * (rr[k] + rr[kp1]) * delth0;
+    drcm = mask * (rr[k] + rr[km1]) * delth0;
+  }
+  if (IREFRA == 0) {
+    dthp = drgp * cg0 + drcp;
+    dthm = drgm * cg0 + drcm;
+  } else {
+    dthp = drgp * cg0 + om0 * drdp + drcp;
+    dthm = drgm * cg0 + om0 * drdm + drcm;
+  }
+  fdp = fdm = T(0);
+  if (cur) {
+    const int mp1 = m + 1 < NR ? m + 1 : NR - 1, mm1 = m - 1 > 0 ? m - 1 : 0;
+    const T s0 = rr[NANG + k], omdd = rr[REFR_OMDD(NANG)];
+    const T sd = (s0 * cgrow[m] + omdd * omrow[m]) * wnrow[m];
+    const T sdp = (s0 * cgrow[mp1] + omdd * omrow[mp1]) * wnrow[mp1];
+    const T sdm = (s0 * cgrow[mm1] + omdd * omrow[mm1]) * wnrow[mm1];
+    const T dfp = delfr0 / tab->FR[m], dfm = delfr0 / tab->FR[mm1];
+    fdp = mask * (sd + sdp) * dfp;
+    fdm = mask * (sd + sdm) * dfm;
+  }
+}
+
+// PROPAGS2 for IREFRA = 1, 2, 3 with the weights rebuilt on the fly (and, with f1 == nullptr, the CFL / range checks of
+// CTUW alone: cflfail[ij] = 1 where one fails).  Same tile walk as k_propags2_otf; one thread per element.
+// IREFRA = 1: the eight-term stencil of propags2.F90:107-116; IREFRA = 2, 3: every neighbour in the order of
+// propags2.F90:130-186 -- a term whose weight is zero is not loaded (the reference's LLW* flags skip a term only when
+// its weight is zero at every point: adding the zero product changes nothing).
+#define GEN_TP 16
+template <typename T>
+__global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restrict__ tab, int IREFRA, const T* __restrict__ f1,
+                                                      T* __restrict__ f3, int ngy, T delpro, const int* __restrict__ kxlt,
+                                                      const T* __restrict__ zdello, T xdella, const T* __restrict__ cosph,
+                                                      const T* __restrict__ sinph, const int* __restrict__ klon,
+                                                      const int* __restrict__ klat, const int* __restrict__ kcor,
+                                                      const T* __restrict__ wlat, const T* __restrict__ wcor,
+                                                      const T* __restrict__ cg, const T* __restrict__ om, const T* __restrict__ wn,
+                                                      const T* __restrict__ cosphm1, const T* __restrict__ refr,
+                                                      int* __restrict__ cflfail, int slot, int kijs, int kijl, int m0, int m1,
+                                                      int copy_rest, int ntiles) {
+  extern __shared__ __align__(16) unsigned char gen_smem[];
+  const int NANG = tab->NANG, NFRE = tab->NFRE, NR = tab->NFRE_RED;
+  const int N = NANG * NFRE, RW = REFR_W(NANG);
+  const T CMTODEG = T(360.0) / tab->CIRC;
+  T DELTH0, DELFR0;
+  {
+#pragma clang fp contract(off)
+    DELTH0 = T(0.25) * delpro / tab->DELTH;
+    DELFR0 = T(0.25) * delpro / ((tab->FRATIO - T(1)) * tab->ZPI);
+  }
+  const bool cur = (IREFRA == 2 || IREFRA == 3);
+  CtuPoint<T>* sP = reinterpret_cast<CtuPoint<T>*>(gen_smem);
+  int* sI = reinterpret_cast<int*>(sP + GEN_TP);                    // [TP][16]
+  T* sB = reinterpret_cast<T*>(sI + GEN_TP * 16);                   // [TP][7][NFRE]: h0 h1 hy0 hy1 cg0 om wn
+  T* sR = sB + (size_t)GEN_TP * 7 * NFRE;                           // [TP][RW]
+  T* sK = sR + (size_t)GEN_TP * RW;                                 // [NANG][2]
+  for (int k = threadIdx.x; k < NANG; k += blockDim.x) {
+    T a, b;
+    ctu_dirfac(tab, k, DELTH0, T(1), a, b);
+    sK[2 * k] = a; sK[2 * k + 1] = b;
+  }
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int p0 = kijs + tile * GEN_TP;
+    const int np = min(GEN_TP, kijl - p0);
+    __syncthreads();
+    if (threadIdx.x < np) {
+      const int t = threadIdx.x, ij = p0 + t;
+      sP[t] = ctu_point(ij, ngy, kxlt, zdello, xdella, cosph, sinph, wlat, wcor, cosphm1);
+      int* q = sI + t * 16;
+      q[0] = ij;
+      q[1] = klon[ij * 2 + 0]; q[2] = klon[ij * 2 + 1];
+      for (int i = 0; i < 4; i++) q[3 + i] = klat[ij * 4 + i];
+      for (int i = 0; i < 8; i++) q[7 + i] = kcor[ij * 8 + i];
+    }
+    for (int it = threadIdx.x; it < np * RW; it += blockDim.x) sR[it] = refr[(size_t)p0 * RW + it];
+    __syncthreads();
+    for (int it = threadIdx.x; it < np * NFRE; it += blockDim.x) {
+      const int t = it / NFRE, m = it - t * NFRE;
+      const int* q = sI + t * 16;
+      T cgl[2], cgy0[2], cgy1[2];
+      for (int ic = 0; ic < 2; ic++) {
+        cgl[ic] = cg[(size_t)q[1 + ic] * NFRE + m];
+        cgy0[ic] = cg[(size_t)q[3 + 2 * ic] * NFRE + m];
+        cgy1[ic] = cg[(size_t)q[4 + 2 * ic] * NFRE + m];
+      }
+      const CtuBase<T> b = ctu_base(cg[(size_t)q[0] * NFRE + m], cgl, cgy0, cgy1, sP[t].wl, sP[t].dp);
+      T* o = sB + (size_t)t * 7 * NFRE + m;
+      o[0] = b.h[0]; o[NFRE] = b.h[1]; o[2 * NFRE] = b.hy[0]; o[3 * NFRE] = b.hy[1]; o[4 * NFRE] = b.cg0;
+      o[5 * NFRE] = om[(size_t)q[0] * NFRE + m];
+      o[6 * NFRE] = wn[(size_t)q[0] * NFRE + m];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < np * N; e += blockDim.x) {
+      const int t = e / N, el = e - t * N;
+      const int k = el / NFRE, m = el - k * NFRE;
+      const int* q = sI + t * 16;
+      const size_t own = (size_t)q[0] * N;
+      if (m < m0 || m >= m1) {
+        if (f1 && (copy_rest & 1)) f3[own + el] = f1[own + el];
+        continue;
+      }
+      const CtuPoint<T>& p = sP[t];
+      const int jx0 = tab->JXO[k][0], jx1 = tab->JXO[k][1], jy0 = tab->JYO[k][0], jy1 = tab->JYO[k][1];
+      const int* kc = tab->KCR[k];
+      const int km = tab->KPM[k][0], kp = tab->KPM[k][2];
+      const T* bb = sB + (size_t)t * 7 * NFRE;
+      CtuBase<T> b;
+      b.h[0] = bb[m]; b.h[1] = bb[NFRE + m]; b.hy[0] = bb[2 * NFRE + m]; b.hy[1] = bb[3 * NFRE + m]; b.cg0 = bb[4 * NFRE + m];
+      const T* rr = sR + (size_t)t * RW;
+      T dthp, dthm, fdp, fdm;
+      ctu_refr_terms(tab, IREFRA, rr, slot, k, m, NR, p.tanph, sK[2 * k], sK[2 * k + 1], DELTH0, DELFR0, b.cg0, bb[5 * NFRE + m],
+                     bb + 4 * NFRE, bb + 5 * NFRE, bb + 6 * NFRE, dthp, dthm, fdp, fdm);
+      CtuGenW<T> w;
+      const bool fail = ctu_wgen(b, tab->SINTH[k], tab->COSTH[k], p, xdella, delpro, CMTODEG, jx0, jx1, jy0, jy1, kc, cur,
+                                 rr[REFR_U(NANG)], rr[REFR_V(NANG)], dthp, dthm, fdp, fdm, tab->FRATIO, w);
+      if (!f1) {
+        if (fail) cflfail[q[0]] = 1;
+        continue;
+      }
+      const T* fo = f1 + own;
+      T r;
+      if (!cur) {
+        r = ctu_stencil(w.sumwn, w.wlon[jx0], w.wlat[jy0][0], w.wlat[jy0][1], w.wcor[0][0], w.wcor[0][1], w.wk[0], w.wk[2], fo[el],
+                        f1[(size_t)q[1 + jx0] * N + el], f1[(size_t)q[3 + 2 * jy0] * N + el], f1[(size_t)q[4 + 2 * jy0] * N + el],
+                        f1[(size_t)q[7 + 2 * kc[0]] * N + el], f1[(size_t)q[8 + 2 * kc[0]] * N + el], fo[km * NFRE + m],
+                        fo[kp * NFRE + m]);
+      } else {
+#pragma clang fp contract(off)
+        r = (T(1) - w.sumwn) * fo[el];
+#define TERM(wv, ptr) { const T wv_ = (wv); if (wv_ != T(0)) r = r + wv_ * (ptr); }
+        for (int ic = 0; ic < 2; ic++) TERM(w.wlon[ic], f1[(size_t)q[1 + ic] * N + el]);
+        for (int icl = 0; icl < 2; icl++) {
+          for (int ic = 0; ic < 2; ic++) TERM(w.wlat[ic][icl], f1[(size_t)q[3 + 2 * ic + icl] * N + el]);
+          for (int icr = 0; icr < 4; icr++) TERM(w.wcor[icr][icl], f1[(size_t)q[7 + 2 * kc[icr] + icl] * N + el]);
+        }
+        const int mm1 = m - 1 > 0 ? m - 1 : 0, mp1 = m + 1 < NR ? m + 1 : NR - 1;
+        TERM(w.wk[0], fo[km * NFRE + m]);
+        TERM(w.wm[0], fo[k * NFRE + mm1]);
+        TERM(w.wk[2], fo[kp * NFRE + m]);
+        TERM(w.wm[2], fo[k * NFRE + mp1]);
+#undef TERM
+      }
+      f3[own + el] = r;
+    }
+  }
+}
+
+// CURMASK of the second CTUW call (ctuw.F90:117-131): 0 where the first call failed
+template <typename T>
+__global__ void k_curmask(int n, int NANG, int slot, const int* __restrict__ cflfail, T* __restrict__ refr) {
+  const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ij < n) refr[(size_t)ij * REFR_W(NANG) + REFR_MASK(NANG) + slot] = (cflfail && cflfail[ij]) ? T(0) : T(1);
+}
+
 // NEWWIND (newwind.F90:126-161, ICODE_WND == 3)
 template <typename T>
 __global__ void k_newwind(const DevTab<T>* __restrict__ tab, int n, T* __restrict__ ff, const T* __restrict__ ffn) {
@@ -543,6 +892,44 @@ void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, 
 #undef OTF_ARGS
 }
 template <typename T>
+void launch_ctuwini_only(int n, int nland, const int* klat, const int* kcor, void* wlat, void* wcor, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_ctuwini<T>, dim3((n + 255) / 256), dim3(256), 0, s, n, nland, klat, kcor, (T*)wlat, (T*)wcor);
+}
+template <typename T>
+void launch_propdot(const void* tab, int n, int nland, int irefra, const int* kxlt, const void* zdello, double xdella, const void* cosph,
+                    const int* klon, const int* klat, const void* wlat, const void* cosphm1, const void* depth, const void* ue,
+                    const void* ve, void* refr, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_propdot<T>, dim3((n + 127) / 128), dim3(128), 0, s, (const DevTab<T>*)tab, n, nland, irefra, kxlt,
+                     (const T*)zdello, (T)xdella, (const T*)cosph, klon, klat, (const T*)wlat, (const T*)cosphm1, (const T*)depth,
+                     (const T*)ue, (const T*)ve, (T*)refr);
+}
+template <typename T>
+void launch_curmask(int n, int NANG, int slot, const int* cflfail, void* refr, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_curmask<T>, dim3((n + 255) / 256), dim3(256), 0, s, n, NANG, slot, cflfail, (T*)refr);
+}
+// f1 == nullptr: CFL / range checks only (cflfail); else the stencil
+template <typename T>
+void launch_propags2_gen(const void* tab, int irefra, const void* f1, void* f3, int ngy, double delpro, const int* kxlt,
+                         const void* zdello, double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat,
+                         const int* kcor, const void* wlat, const void* wcor, const void* cg, const void* om, const void* wn,
+                         const void* cosphm1, const void* refr, int* cflfail, int slot, int kijs, int kijl, int m0, int m1,
+                         int copy_rest, int dims, hipStream_t s) {
+  const int NANG = dims >> 16, NFRE = (dims >> 8) & 0xFF;
+  const int n = kijl - kijs;
+  if (n <= 0) return;
+  const int ntiles = (n + GEN_TP - 1) / GEN_TP;
+  const size_t shmem = GEN_TP * (sizeof(CtuPoint<T>) + 16 * sizeof(int)) +
+                       ((size_t)GEN_TP * 7 * NFRE + (size_t)GEN_TP * REFR_W(NANG) + 2 * NANG) * sizeof(T) + 16;
+  const int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
+  hipLaunchKernelGGL(k_propags2_gen<T>, dim3(grid), dim3(256), shmem, s, (const DevTab<T>*)tab, irefra, (const T*)f1, (T*)f3, ngy,
+                     (T)delpro, kxlt, (const T*)zdello, (T)xdella, (const T*)cosph, (const T*)sinph, klon, klat, kcor,
+                     (const T*)wlat, (const T*)wcor, (const T*)cg, (const T*)om, (const T*)wn, (const T*)cosphm1, (const T*)refr,
+                     cflfail, slot, kijs, kijl, m0, m1, copy_rest, ntiles);
+}
+template <typename T>
 void launch_newwind(const void* tab, int n, void* ff, const void* ffn, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_newwind<T>, dim3((n + 255) / 256), dim3(256), 0, s, (const DevTab<T>*)tab, n, (T*)ff, (const T*)ffn);
@@ -573,6 +960,14 @@ void launch_pack(const void* fl, const int* idx, int n, int rowlen, void* buf, h
                                const void*, const int*, const int*, const int*, void*, void*, const void*, const void*, void*,   \
                                int*, int, hipStream_t);                                                                           \
   template void launch_newwind<T>(const void*, int, void*, const void*, hipStream_t);                                             \
+  template void launch_propdot<T>(const void*, int, int, int, const int*, const void*, double, const void*, const int*,         \
+                                  const int*, const void*, const void*, const void*, const void*, const void*, void*, hipStream_t); \
+  template void launch_ctuwini_only<T>(int, int, const int*, const int*, void*, void*, hipStream_t);                               \
+  template void launch_curmask<T>(int, int, int, const int*, void*, hipStream_t);                                                      \
+  template void launch_propags2_gen<T>(const void*, int, const void*, void*, int, double, const int*, const void*, double,        \
+                                       const void*, const void*, const int*, const int*, const int*, const void*, const void*,   \
+                                       const void*, const void*, const void*, const void*, const void*, int*, int, int, int, int, \
+                                       int, int, int, hipStream_t);                                                                    \
   template void launch_propags2_otf<T>(const void*, const void*, void*, int, int, double, const int*, const void*, double,        \
                                        const void*, const void*, const int*, const int*, const int*, const void*, const void*,   \
                                        const void*, const void*, const int*, int, int, int, int, int, int, hipStream_t);         \

@@ -127,3 +127,17 @@ def depth_props(depth, tables, dtype) -> dict:
     gd = T(t.GAM_B_J) * d
     out["EMAXDPT"] = T(0.0625) * (gd * gd)
     return out
+
+
+def currents(grid, amp: float = 0.8, undefined_band: float = 10.0):
+    """Synthetic surface current (UCUR, VCUR) [m/s] on the sea points of `grid`: a smooth rotational pattern of
+    amplitude ~`amp`, exactly zero ("current field not defined", gradi.F90:170-180) poleward of 90-`undefined_band`
+    degrees and in one mid-latitude box.  Function of the geographic position only: identical for every decomposition."""
+    lat = np.deg2rad(np.asarray(grid.lat_deg, dtype=np.float64))
+    lon = np.deg2rad(np.asarray(grid.ixlg, dtype=np.float64) * np.asarray(grid.zdello)[grid.kxlt])
+    u = amp * np.cos(lat) * (0.6 * np.sin(2 * lon + 0.3) * np.cos(3 * lat) + 0.4 * np.cos(5 * lon) * np.sin(4 * lat))
+    v = amp * np.cos(lat) * (0.5 * np.cos(3 * lon - 0.7) * np.sin(2 * lat) + 0.3 * np.sin(7 * lon) * np.cos(5 * lat))
+    undef = (np.abs(np.rad2deg(lat)) > 90.0 - undefined_band) | ((np.abs(np.rad2deg(lat) - 20.0) < 8.0) & (np.abs(np.rad2deg(lon) - 200.0) < 15.0))
+    u[undef] = 0.0
+    v[undef] = 0.0
+    return u, v

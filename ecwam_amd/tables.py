@@ -79,8 +79,8 @@ class Config:
             raise NotImplementedError("IPHYS must be 0 (Janssen) or 1 (Ardhuin)")
         if self.isnonlin not in (0, 1):
             raise NotImplementedError("ISNONLIN=2 (TRANSF_SNL / PEAK_ANG) is a 'next' row (SURVEY.md 8f rank 4)")
-        if self.irefra != 0:
-            raise NotImplementedError("IREFRA != 0 (refraction weights) is a 'next' row (SURVEY.md 8f)")
+        if self.irefra not in (0, 1, 2, 3):
+            raise ValueError("IREFRA must be 0 (none), 1 (depth), 2 (currents) or 3 (depth + currents)")
         if self.icode != 3:
             raise NotImplementedError("only ICODE=3 (10 m wind forcing) is supported")
         if self.lwnemocouwrs or self.lwnemocoustrn:

@@ -87,18 +87,37 @@ class Wamintgr:
         self.ifrelfmax = ifrelfmax
         self.delpro_lf = delpro_lf
         self.weights_ready = False
+        # refraction (IREFRA = 1 depth, 2 currents, 3 both): per-point THD/S0/U/V/OMDD/CURMASK instead of the reference's
+        # THDD/THDC/SDOT and 21 weight arrays; PROPAGS2 rebuilds every weight on the fly
+        self.irefra = int(cfg.irefra)
+        self.llcflcuroff = True                 # mpuserin.F90:575
+        if self.irefra:
+            if weights != "otf":
+                raise ValueError("IREFRA != 0 runs with on-the-fly weights only")
+            self.refr = torch.zeros((self.n, 2 * NANG + 5), **z)
+            self.depth_ext = torch.zeros(self.nrows, **z)
+            self.u_ext = torch.zeros(self.nrows, **z)
+            self.v_ext = torch.zeros(self.nrows, **z)
+            self.omosnh2kd_ext = torch.zeros((self.nrows, NFRE), **z)
+            self.wavnum_ext = torch.zeros((self.nrows, NFRE), **z)
 
     # ---- synthetic initial state; identical for every decomposition
-    def init_synthetic(self, seed: int = 12345, chunk: int = 65536) -> None:
+    def init_synthetic(self, seed: int = 12345, chunk: int = 65536, currents: bool | None = None) -> None:
         g, d, t = self.grid, self.dom, self.t
         p = syn.point_params(g.nsea, seed=seed)
         self.params = p
         ext = d.ext_global()
         props_ext_cg = np.zeros((self.nrows, self.cfg.nfre), self.npdt)
+        if self.irefra:
+            om_ext = np.zeros((self.nrows, self.cfg.nfre), self.npdt)
+            wn_ext = np.zeros((self.nrows, self.cfg.nfre), self.npdt)
         for s in range(0, ext.size, chunk):
             sl = ext[s:s + chunk]
             pr = syn.depth_props(p["DEPTH"][sl], t, self.npdt)
             props_ext_cg[s:s + sl.size] = pr["CGROUP"]
+            if self.irefra:
+                om_ext[s:s + sl.size] = pr["OMOSNH2KD"]
+                wn_ext[s:s + sl.size] = pr["WAVNUM"]
             own = sl[(sl >= d.lo) & (sl < d.hi)]
             if own.size:
                 a, b = s, s + own.size  # owned rows come first in ext
@@ -111,15 +130,50 @@ class Wamintgr:
                 self.ff[a:b] = torch.from_numpy(ff).to(self.dev)
                 fl = syn.jonswap_spectra(t.FR, t.TH, p["FP"][own], p["THETAQ"][own], self.npdt)
                 self.fl1[a:b] = torch.from_numpy(fl).to(self.dev)
-        props_ext_cg[self.dom.nland] = syn.depth_props(np.array([float(t.BATHYMAX)]), t, self.npdt)["CGROUP"][0]  # WVPRPT_LAND
+        land = syn.depth_props(np.array([float(t.BATHYMAX)]), t, self.npdt)      # WVPRPT_LAND (initdpthflds.F90:85-88)
+        props_ext_cg[self.dom.nland] = land["CGROUP"][0]
         self.cgroup_ext = torch.from_numpy(props_ext_cg).to(self.dev)
+        if self.irefra:
+            # PROENVHALO (proenvhalo.F90:69-106): own + halo values, land slot = (WVPRPT_LAND, BATHYMAX, U = V = 0)
+            om_ext[self.dom.nland] = land["OMOSNH2KD"][0]
+            wn_ext[self.dom.nland] = land["WAVNUM"][0]
+            dep = np.full(self.nrows, float(t.BATHYMAX), self.npdt)
+            dep[: ext.size] = p["DEPTH"][ext]
+            u = np.zeros(self.nrows, self.npdt)
+            v = np.zeros(self.nrows, self.npdt)
+            if currents if currents is not None else self.irefra >= 2:
+                ug, vg = syn.currents(g)
+                u[: ext.size] = ug[ext]
+                v[: ext.size] = vg[ext]
+            self.set_environment(dep, u, v, om_ext, wn_ext)
         self.fl1[self.dom.nland].zero_()
         self.fl3[self.dom.nland].zero_()
+
+    def set_environment(self, depth_ext, u_ext, v_ext, omosnh2kd_ext, wavnum_ext) -> None:
+        """DEPTH / UCUR / VCUR [nrows] and OMOSNH2KD / WAVNUM [nrows][NFRE] including halo and land rows (what PROENVHALO
+        assembles): a new current field makes the next step rebuild the dot terms and re-check the weights (LLUPDTTD /
+        LUPDTWGHT, propag_wam.F90:175-236)."""
+        for dst, src in ((self.depth_ext, depth_ext), (self.u_ext, u_ext), (self.v_ext, v_ext), (self.omosnh2kd_ext, omosnh2kd_ext),
+                         (self.wavnum_ext, wavnum_ext)):
+            dst.copy_(torch.as_tensor(np.ascontiguousarray(src, dtype=self.npdt)))
+        self.weights_ready = False
 
     # ---- CTUWUPDT (ctuwupdt.F90:220-256): weights for the (sub-)step structure
     def build_weights(self) -> int:
         c = self.cfg
         self.cflfail.zero_()
+        if self.irefra:
+            # PROPDOT, then CTUWINI + CTUWDRV per frequency range (checks only: the weights are rebuilt inside PROPAGS2)
+            self.ctx.propdot(self.gd, self.depth_ext, self.u_ext, self.v_ext, self.refr)
+            a = (self.gd, self.cgroup_ext, self.omosnh2kd_ext, self.wavnum_ext, self.refr, self.cflfail)
+            if self.ifrelfmax <= 0:
+                self.ctx.ctuw_refra(*a, float(c.idelpro), 1, c.nfre_red, llcflcuroff=self.llcflcuroff, frange=0)
+            else:
+                self.ctx.ctuw_refra(*a, float(self.delpro_lf), 1, self.ifrelfmax, llcflcuroff=self.llcflcuroff, frange=0)
+                if self.ifrelfmax < c.nfre_red:
+                    self.ctx.ctuw_refra(*a, float(c.idelpro), self.ifrelfmax + 1, c.nfre_red, llcflcuroff=self.llcflcuroff, frange=1)
+            self.weights_ready = True
+            return int(self.cflfail.sum().item())
         # weights == "otf": w is None, CTUW only snaps WLAT/WCOR near land and runs the CFL / range checks
         if self.ifrelfmax <= 0:
             self.ctx.ctuw(self.gd, self.cgroup_ext, self.w, self.cflfail, float(c.idelpro), 1, c.nfre_red)
@@ -140,7 +194,10 @@ class Wamintgr:
         lf = 0 < self.ifrelfmax < c.nfre_red
 
         def advect(m1, m2, delpro, copy_rest):
-            if self.weights == "stored":
+            if self.irefra:
+                self.ctx.propags2_refra(self.fl1, self.fl3, g, self.cgroup_ext, self.omosnh2kd_ext, self.wavnum_ext, self.refr, delpro, 0,
+                                        self.n, m1, m2, copy_rest=copy_rest, frange=int(0 < self.ifrelfmax < m1))
+            elif self.weights == "stored":
                 self.ctx.propags2(self.fl1, self.fl3, g["klon"], g["klat"], g["kcor"], self.w, 0, self.n, m1, m2, copy_rest=copy_rest)
             else:
                 self.ctx.propags2_otf(self.fl1, self.fl3, g, self.cgroup_ext, delpro, 0, self.n, m1, m2, copy_rest=copy_rest,

@@ -161,6 +161,45 @@ int ecwam_hip_propags2_otf(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n, 
                            void *stream);
 
 /*
+ * Refraction, IREFRA = 1 (depth), 2 (currents), 3 (depth + currents) -- params.irefra selects it at ecwam_hip_create.
+ *
+ * ecwam_hip_propdot: GRADI + the per-point part of PROPDOT (gradi.F90:113-232, propdot.F90:108-196), called whenever the
+ * reference sets LLUPDTTD (new currents, propag_wam.F90:175-213).  Replaces the module arrays THDD/THDC/SDOT of yowubuf:
+ *   depth_ext, u_ext, v_ext [npts+1]  DEPTH / UCUR / VCUR incl. halo rows and the land slot as proenvhalo.F90:99-106
+ *                                     fills it (BATHYMAX, 0, 0)
+ *   wlat[ij][2]                       as read from the grid tables (before or after CTUWINI: GRADI only uses entries
+ *                                     CTUWINI never changes)
+ *   refr  out, real[n][2*NANG+5]:     THD(K) (THDD for IREFRA=1, THDC for 2/3), S0(K) (current-gradient factor of SDOT,
+ *                                     propdot.F90:172), U, V, OMDD (propdot.F90:126), CURMASK of frequency range 0 and 1 (=1)
+ *
+ * ecwam_hip_ctuw_refra: CTUWINI + CTUWDRV (ctuwupdt.F90:204-238, ctuwdrv.F90:93-118) without storing weights: snaps
+ * wlat/wcor, runs the CFL / range checks of every weight for frequencies [mstart,mend] with time step delpro, and when
+ * llcflcuroff != 0 and a point fails with currents, repeats them with the current refraction and frequency shift of that
+ * point switched off (its CURMASK in refr becomes 0, as ctuw.F90:117-131).  cflfail[n]: points still failing (the caller
+ * aborts, ctuwdrv.F90:124-146).  range = 0 for the only (or the fast-wave) frequency range, 1 for the slow-wave range of a
+ * split call (ctuwupdt.F90:220-256 runs CTUWDRV once per range, each with its own CURMASK); range 0 resets cflfail, range 1
+ * adds its failures to those of range 0.
+ *
+ * ecwam_hip_propags2_refra: PROPAGS2 (propags2.F90:99-192) with all weights rebuilt inside the stencil from the geometry,
+ * cgroup_ext, the point's own omosnh2kd/wavnum rows and refr.  IREFRA=1: the eight-term stencil with depth refraction in
+ * WKPMN; IREFRA=2/3: all 2+4+8 space neighbours, both direction and both frequency neighbours, in the reference's
+ * summation order.  Arguments as ecwam_hip_propags2_otf; range selects the CURMASK of ecwam_hip_ctuw_refra.
+ */
+int ecwam_hip_propdot(ecwam_hip_ctx *ctx, int n, int nland, const int *kxlt, const void *zdello, double xdella,
+                      const void *cosph, const int *klon, const int *klat, const void *wlat, const void *cosphm1_ext,
+                      const void *depth_ext, const void *u_ext, const void *v_ext, void *refr, void *stream);
+int ecwam_hip_ctuw_refra(ecwam_hip_ctx *ctx, int n, int nland, int ngy, double delpro, int mstart, int mend, const int *kxlt,
+                         const void *zdello, double xdella, const void *cosph, const void *sinph, const int *klon,
+                         const int *klat, const int *kcor, void *wlat, void *wcor, const void *cgroup_ext,
+                         const void *omosnh2kd_ext, const void *wavnum_ext, const void *cosphm1_ext, void *refr,
+                         int llcflcuroff, int range, int *cflfail, void *stream);
+int ecwam_hip_propags2_refra(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n, int ngy, double delpro, const int *kxlt,
+                             const void *zdello, double xdella, const void *cosph, const void *sinph, const int *klon,
+                             const int *klat, const int *kcor, const void *wlat, const void *wcor, const void *cgroup_ext,
+                             const void *omosnh2kd_ext, const void *wavnum_ext, const void *cosphm1_ext, const void *refr,
+                             int range, int kijs, int kijl, int nd3s, int nd3e, int copy_rest, void *stream);
+
+/*
  * IMPLSCH (implsch.F90:10-23) for local points [kijs,kijl) on device pointers (layouts above).
  *   fl1 inout, wvprpt in, ff inout, intf inout, mij out (1-based), xllws out
  *   wam2nemo: double[npts][13] inout, the WAVE2OCEAN members (always JWRO = double, yowdrvtype_config.yml:44-55) in the order

@@ -44,6 +44,7 @@ typedef float real;
 #define POW powf
 #define FMOD fmodf
 #define FABS fabsf
+#define COPYSIGN copysignf
 #define NINT(x) ((int)lroundf(x))
 #define FLOORI(x) ((int)floorf(x))
 #else
@@ -63,6 +64,7 @@ typedef double real;
 #define ACOS acos
 #define POW pow
 #define FABS fabs
+#define COPYSIGN copysign
 #define NINT(x) ((int)lround(x))
 #define FLOORI(x) ((int)floor(x))
 #endif

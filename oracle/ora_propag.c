@@ -232,10 +232,10 @@ void ora_propdot(int n, int nland, int IREFRA, const int *KXLT, const int *KLON,
         DVLAM = (V_EXT[ILP] - V_EXT[ILM]) / (C_(2.0) * DELLAM);
       }
       const real CGMAX = CURRENT_GRADIENT_MAX * COSPH[KX];
-      DUPHI = COPYSIGN(FMIN(FABS(DUPHI), CGMAX), DUPHI);
-      DVPHI = COPYSIGN(FMIN(FABS(DVPHI), CGMAX), DVPHI);
-      DULAM = COPYSIGN(FMIN(FABS(DULAM), CGMAX), DULAM);
-      DVLAM = COPYSIGN(FMIN(FABS(DVLAM), CGMAX), DVLAM);
+      DUPHI = COPYSIGN(RMIN(FABS(DUPHI), CGMAX), DUPHI);
+      DVPHI = COPYSIGN(RMIN(FABS(DVPHI), CGMAX), DVPHI);
+      DULAM = COPYSIGN(RMIN(FABS(DULAM), CGMAX), DULAM);
+      DVLAM = COPYSIGN(RMIN(FABS(DVLAM), CGMAX), DVLAM);
     }
     /* propdot.F90:108-196 */
     const real DCO = COSPHM1_EXT[IJ];

@@ -188,3 +188,69 @@ class Oracle:
                               self._p(w["SUMWN"]), self._p(w["WLONN"]), self._p(w["WLATN"]), self._p(w["WCORN"]), self._p(w["WKPMN"]),
                               C.c_int(nd3s), C.c_int(nd3e))
         return f3
+
+    # ---- IREFRA = 1, 2, 3: GRADI + PROPDOT, CTUWDRV/CTUW with every weight, the general PROPAGS2 branch -------------------------
+    def _grid_arrays(self, grid):
+        T = self.dtype
+        return dict(kxlt=np.ascontiguousarray(grid.kxlt, dtype=np.int32), klon=np.ascontiguousarray(grid.klon, dtype=np.int32),
+                    klat=np.ascontiguousarray(grid.klat, dtype=np.int32), kcor=np.ascontiguousarray(grid.kcor, dtype=np.int32),
+                    wlat=np.array(grid.wlat, dtype=T, order="C"), wcor=np.array(grid.wcor, dtype=T, order="C"),
+                    cosph=np.ascontiguousarray(grid.cosph, dtype=T), sinph=np.ascontiguousarray(grid.sinph, dtype=T),
+                    zdello=np.ascontiguousarray(grid.zdello, dtype=T), cosphm1=np.ascontiguousarray(grid.cosphm1_ext, dtype=T))
+
+    def propdot(self, grid, irefra, depth_ext, u_ext, v_ext, wavnum_ext, cgroup_ext, omosnh2kd_ext):
+        """THDC, THDD [n][NANG] and SDOT [n][NANG][NFRE_RED] (gradi.F90 + propdot.F90).  *_ext: [(npts+1)] / [(npts+1)][NFRE]
+        with the land slot filled as proenvhalo.F90:99-106 does."""
+        T = self.dtype
+        n, nland = grid.nsea, grid.nland
+        g = self._grid_arrays(grid)
+        creal = C.c_float if T == np.float32 else C.c_double
+        a = [np.ascontiguousarray(x, dtype=T) for x in (depth_ext, u_ext, v_ext, wavnum_ext, cgroup_ext, omosnh2kd_ext)]
+        thdc = np.zeros((n, self.NANG), T)
+        thdd = np.zeros((n, self.NANG), T)
+        sdot = np.zeros((n, self.NANG, self.NFRE_RED), T)
+        self.lib.ora_propdot(C.c_int(n), C.c_int(nland), C.c_int(irefra), self._p(g["kxlt"]), self._p(g["klon"]), self._p(g["klat"]),
+                             self._p(g["wlat"]), self._p(g["zdello"]), creal(grid.xdella), self._p(g["cosph"]), self._p(g["cosphm1"]),
+                             *[self._p(x) for x in a], self._p(thdc), self._p(thdd), self._p(sdot))
+        return dict(THDC=thdc, THDD=thdd, SDOT=sdot)
+
+    def ctu_weights_gen(self, grid, irefra, cgroup_ext, omosnh2kd_ext, u_ext, v_ext, dot, delpro, llcflcuroff=True, mstart=1, mend=None):
+        """CTUWINI + CTUWDRV/CTUW with all weights for IREFRA = 0..3 (`dot` = result of propdot)."""
+        T = self.dtype
+        n, nland = grid.nsea, grid.nland
+        NANG, NR = self.NANG, self.NFRE_RED
+        mend = NR if mend is None else mend
+        g = self._grid_arrays(grid)
+        wlatm1, wcorm1, dp = np.zeros((n, 2), T), np.zeros((n, 4), T), np.zeros((n, 2), T)
+        self.lib.ora_ctuwini(C.c_int(n), C.c_int(nland), C.c_int(grid.ngy), self._p(g["kxlt"]), self._p(g["cosph"]),
+                             self._p(g["cosphm1"]), self._p(g["klat"]), self._p(g["kcor"]), self._p(g["wlat"]), self._p(g["wcor"]),
+                             self._p(wlatm1), self._p(wcorm1), self._p(dp))
+        w = dict(SUMWN=np.zeros((n, NANG, NR), T), WLONN=np.zeros((n, NANG, NR, 2), T), WLATN=np.zeros((n, NANG, NR, 2, 2), T),
+                 WCORN=np.zeros((n, NANG, NR, 4, 2), T), WKPMN=np.zeros((n, NANG, NR, 3), T), WMPMN=np.zeros((n, NANG, NR, 3), T))
+        fail = np.zeros(n, np.int32)
+        curmask = np.ones(n, T)
+        creal = C.c_float if T == np.float32 else C.c_double
+        a = [np.ascontiguousarray(x, dtype=T) for x in (cgroup_ext, omosnh2kd_ext)]
+        uv = [np.ascontiguousarray(x, dtype=T) for x in (u_ext, v_ext)]
+        self.lib.ora_ctuw_gen.restype = C.c_int
+        nfail = self.lib.ora_ctuw_gen(C.c_int(n), C.c_int(irefra), C.c_int(int(llcflcuroff)), creal(delpro), C.c_int(mstart),
+                                      C.c_int(mend), self._p(g["kxlt"]), self._p(g["zdello"]), creal(grid.xdella), self._p(g["cosph"]),
+                                      self._p(g["sinph"]), self._p(g["klon"]), self._p(g["klat"]), self._p(g["wlat"]), self._p(g["wcor"]),
+                                      self._p(wlatm1), self._p(wcorm1), self._p(dp), self._p(a[0]), self._p(a[1]), self._p(g["cosphm1"]),
+                                      self._p(uv[0]), self._p(uv[1]), self._p(dot["THDC"]), self._p(dot["THDD"]), self._p(dot["SDOT"]),
+                                      self._p(curmask), self._p(w["SUMWN"]), self._p(w["WLONN"]), self._p(w["WLATN"]), self._p(w["WCORN"]),
+                                      self._p(w["WKPMN"]), self._p(w["WMPMN"]), self._p(fail))
+        w.update(WLAT=g["wlat"], WCOR=g["wcor"], NFAIL=nfail, FAIL=fail, CURMASK=curmask)
+        return w
+
+    def propags2_gen(self, grid, f1, w, nd3s=1, nd3e=None):
+        """propags2.F90:124-192 (the IREFRA = 2, 3 branch) with the weights of ctu_weights_gen."""
+        T = self.dtype
+        nd3e = self.NFRE_RED if nd3e is None else nd3e
+        f1 = np.ascontiguousarray(f1, dtype=T)
+        f3 = np.zeros_like(f1)
+        g = self._grid_arrays(grid)
+        self.lib.ora_propags2_gen(C.c_int(grid.nsea), self._p(f1), self._p(f3), self._p(g["klon"]), self._p(g["klat"]), self._p(g["kcor"]),
+                                  self._p(w["SUMWN"]), self._p(w["WLONN"]), self._p(w["WLATN"]), self._p(w["WCORN"]), self._p(w["WKPMN"]),
+                                  self._p(w["WMPMN"]), C.c_int(nd3s), C.c_int(nd3e))
+        return f3

@@ -44,7 +44,7 @@ def test_create_refuses_unsupported_configurations_without_a_gpu():
     h = lib.load()
     t = Tables(Config(nang=12, nfre=36, nfre_red=25), np.float32)
     tp, keep = lib.make_tables(t)
-    cases = [(dict(lciwa1=1), "SDICE1"), (dict(iphys=2), "IPHYS"), (dict(irefra=2), "IREFRA"), (dict(lwnemocouwrs=1), "LWNEMOCOUWRS"),
+    cases = [(dict(lciwa1=1), "SDICE1"), (dict(iphys=2), "IPHYS"), (dict(irefra=4), "IREFRA"), (dict(lwnemocouwrs=1), "LWNEMOCOUWRS"),
              (dict(nang=3), "NANG"), (dict(nfre_red=40), "NFRE_RED")]
     for changes, word in cases:
         p = lib.make_params(t)
@@ -290,3 +290,49 @@ def test_halo_exchange_gloo_world2(tmp_path):
            "--master-port", "29537", str(script), ROOT]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_oracle_refraction_restatement_invariants():
+    """CPU checks of the oracle's IREFRA /= 0 restatement (gradi / propdot / ctuwdrv / ctuw / propags2 general branch):
+    with IREFRA = 0 the general routines reproduce the plain ones (weights bit for bit, F3 up to the summation order);
+    with zero currents IREFRA = 2 has no frequency shift and no downwind weights; the LLCFLCUROFF second call masks
+    exactly the points that failed and leaves the others' weights untouched."""
+    import test_gpu_refraction as R
+    from oracle.oracle import Oracle
+
+    c = R._case("dp", 2, n_oct=12, nang=12, nred=25)
+    g, n = c["g"], c["n"]
+    o = Oracle(c["cfg"], "dp")
+    z = np.zeros(n + 1)
+    w0 = o.ctu_weights(g, c["cg"], 600.0)
+    dot0 = o.propdot(g, 0, c["dep"], z, z, c["wn"], c["cg"], c["om"])
+    wg = o.ctu_weights_gen(g, 0, c["cg"], c["om"], z, z, dot0, 600.0)
+    for k in ("SUMWN", "WLONN", "WLATN", "WCORN", "WKPMN"):
+        assert np.array_equal(w0[k], wg[k]), k
+    f3, f3g = o.propags2(g, c["f1"], w0), o.propags2_gen(g, c["f1"], wg)
+    assert np.abs(f3 - f3g).max() < 8 * np.finfo(float).eps * np.abs(f3).max()
+    # zero currents: only upwind weights, no frequency shift
+    dz = o.propdot(g, 2, c["dep"], z, z, c["wn"], c["cg"], c["om"])
+    wz = o.ctu_weights_gen(g, 2, c["cg"], c["om"], z, z, dz, 600.0)
+    assert not wz["WMPMN"].any() and not dz["THDC"].any()
+    assert np.array_equal(wz["SUMWN"], w0["SUMWN"])
+    # with currents: every weight in [0,1], the frequency shift is active, mass leaves only through land / the poles
+    d2 = o.propdot(g, 2, c["dep"], c["u"], c["v"], c["wn"], c["cg"], c["om"])
+    w2 = o.ctu_weights_gen(g, 2, c["cg"], c["om"], c["u"], c["v"], d2, 600.0)
+    assert w2["NFAIL"] == 0 and w2["WMPMN"].max() > 0
+    for k in ("SUMWN", "WLONN", "WLATN", "WCORN", "WKPMN", "WMPMN"):
+        assert w2[k].min() >= 0 and w2[k].max() <= 1
+    assert np.abs(d2["THDC"]).max() > 0 and np.abs(d2["SDOT"]).max() > 0
+    # current gradients are limited to CURRENT_GRADIENT_MAX * COSPH (gradi.F90:219-226): |THDC| <= 2 * that bound / cos(lat)
+    assert np.abs(d2["THDC"]).max() <= 4e-5
+    # second call: masked points == points that failed first; unmasked points keep their weights
+    cs = R._case("dp", 3, n_oct=12, nang=12, nred=25, delpro=900, cur_amp=6.0, smooth_depth=False)
+    os_ = Oracle(cs["cfg"], "dp")
+    ds = os_.propdot(cs["g"], 3, cs["dep"], cs["u"], cs["v"], cs["wn"], cs["cg"], cs["om"])
+    a = os_.ctu_weights_gen(cs["g"], 3, cs["cg"], cs["om"], cs["u"], cs["v"], ds, 900.0, llcflcuroff=False)
+    b = os_.ctu_weights_gen(cs["g"], 3, cs["cg"], cs["om"], cs["u"], cs["v"], ds, 900.0, llcflcuroff=True)
+    assert a["NFAIL"] > 0 and np.array_equal(b["CURMASK"] == 0, a["FAIL"] == 1)
+    keep = a["FAIL"] == 0
+    for k in ("SUMWN", "WKPMN", "WMPMN", "WLONN"):
+        assert np.array_equal(a[k][keep], b[k][keep]), k
+    assert not b["WMPMN"][~keep].any()

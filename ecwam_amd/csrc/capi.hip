@@ -192,8 +192,8 @@ int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int r
   if (p->nang < 4 || p->nang > MAXA || p->nfre < 8 || p->nfre > MAXF || p->nfre_red < 1 || p->nfre_red > p->nfre)
     return fail("ecwam_hip_create: NANG/NFRE/NFRE_RED out of the supported range");
   if (p->mlsthg > MAXMC || 2 * p->nsdsnth + 1 > MAXTAP || p->nwav_gc + 1 > MAXGC) return fail("ecwam_hip_create: table size exceeds library limits");
-  if ((p->iphys != 0 && p->iphys != 1) || (p->isnonlin != 0 && p->isnonlin != 1) || p->irefra < 0 || p->irefra > 3 || p->icode != 3)
-    return fail("ecwam_hip_create: only IPHYS=0/1, ISNONLIN=0/1, IREFRA=0..3, ICODE=3 are on the hot path (SURVEY.md 8a)");
+  if ((p->iphys != 0 && p->iphys != 1) || (p->isnonlin < 0 || p->isnonlin > 2) || p->irefra < 0 || p->irefra > 3 || p->icode != 3)
+    return fail("ecwam_hip_create: only IPHYS=0/1, ISNONLIN=0/1/2, IREFRA=0..3, ICODE=3 are on the hot path (SURVEY.md 8a)");
   if (p->lciwa1) return fail("ecwam_hip_create: SDICE1 (scattering attenuation table CIDEAC, sdice1.F90) not supported yet");
   if (p->lwnemocouwrs || p->lwnemocoustrn) return fail("ecwam_hip_create: LWNEMOCOUWRS (ice radiative stress from SLICE) / LWNEMOCOUSTRN (CIMSSTRN) not supported yet");
   HIPCHK(hipSetDevice(device));

@@ -929,6 +929,90 @@ __device__ T transf_d(const DevTab<T>& tb, T XK, T D) {
   return T(1);
 }
 
+// peak_ang.F90:76-174 per wave (lane = M for the frequency moments, lane = K for the peak search and the angular width)
+template <typename T>
+__device__ void peak_ang_w(const DevTab<T>& tb, const T* sF, const Lane<T>& L, T& XNU, T& SIG_TH) {
+  const int NFRE = L.NFRE, NAP = L.NAP;
+  const T ZEPS = T(10) * (sizeof(T) == 4 ? T(1.1920928955078125e-07) : T(2.220446049250313e-16));  // 10*EPSILON(ZEPSILON)
+  const int NSH = 1 + (int)(m_log(T(1.5)) / m_log(tb.FRATIO));
+  const T t2 = colsum(sF, L);
+  T w0 = T(0), w1 = T(0), w2 = T(0);
+  if (L.actm) {
+    const T fr = tb.FR[L.lane];
+    w0 = L.rDFIM; w1 = tb.DFIMFR[L.lane]; w2 = L.rDFIM * (fr * fr);
+  }
+  T S0, S1, S2, d0;
+  usum4(w0 * t2, w1 * t2, w2 * t2, T(0), S0, S1, S2, d0);
+  const T tl = lane_get(t2, NFRE - 1), frl = tb.FR[NFRE - 1];
+  S0 = (ZEPS + S0) + (tb.WETAIL * frl * tb.DELTH) * tl;
+  S1 = S1 + (tb.WP1TAIL * tb.DELTH * (frl * frl)) * tl;
+  S2 = S2 + (T(0.5) * tb.DELTH * (frl * frl * frl)) * tl;   // WP2TAIL = 0.5, yowfred.F90:54
+  XNU = (S0 > ZEPS) ? m_sqrt(m_max(ZEPS, S2 * S0 / (S1 * S1) - T(1))) : ZEPS;
+  // first maximum of F over M = 2..NFRE-1 in the reference's (M outer, K inner) order: smallest M attaining the maximum
+  T vmax = T(0);
+  int mm = 2;
+  if (L.act)
+    for (int m = 1; m < NFRE - 1; m++) {
+      const T f = sF[m * NAP + L.k];
+      if (f > vmax) { vmax = f; mm = m + 1; }
+    }
+  const T gmax = umax(L.act ? vmax : T(0));
+  const T cand = (L.act && gmax > T(0) && vmax == gmax) ? -T(mm) : -T(1.0e9);
+  const T mneg = umax(cand);
+  const int MMAX = __builtin_amdgcn_readfirstlane(gmax > T(0) ? (int)(-mneg) : 2);
+  const int MS = MMAX - NSH > 1 ? MMAX - NSH : 1, ME = MMAX + NSH < NFRE ? MMAX + NSH : NFRE;
+  const T sk = tb.SINTH[L.k], ck = tb.COSTH[L.k], thk = tb.TH[L.k];
+  T SUM_S = T(0), SUM_C = ZEPS, SUM1 = ZEPS, SUM2 = T(0);
+  for (int M = MS; M <= ME; M++) {
+    const T f = L.act ? sF[(M - 1) * NAP + L.k] : T(0);
+    T a, b;
+    usum2(sk * f, ck * f, a, b);
+    SUM_S = SUM_S + a;
+    SUM_C = SUM_C + b;
+    const T THMEAN = m_atan2(SUM_S, SUM_C);
+    const T dfim = lane_get(L.rDFIM, M - 1);
+    usum2(f * dfim, m_cos(thk - THMEAN) * f * dfim, a, b);
+    SUM1 = SUM1 + a;
+    SUM2 = SUM2 + b;
+  }
+  SIG_TH = (SUM1 > ZEPS) ? m_sqrt(T(2) * (T(1) - SUM2 / SUM1)) : T(0);
+}
+// transf_snl.F90:52-85
+template <typename T>
+__device__ T transf_snl_d(const DevTab<T>& tb, T XK0, T D, T XNU, T SIG_TH) {
+  const T EPS = T(0.0001), DKMAX = T(40.0), XKDMIN = T(0.75);
+  if (D < tb.BATHYMAX && D > T(0)) {
+    T X = XK0 * D;
+    if (X > DKMAX) return T(1);
+    const T XK = m_max(XK0, XKDMIN / D);
+    X = XK * D;
+    const T T_0 = m_tanh(X);
+    const T T_0_SQ = T_0 * T_0;
+    const T OM = m_sqrt(tb.G * XK * T_0);
+    const T C_0 = OM / XK;
+    const T C_S_SQ = tb.G * D;
+    T V_G;
+    if (X < EPS) V_G = C_0;
+    else V_G = T(0.5) * C_0 * (T(1) + T(2) * X / m_sinh(T(2) * X));
+    const T V_G_SQ = V_G * V_G;
+    const T a = T_0 - X * (T(1) - T_0_SQ);
+    const T DV_G = a * a + T(4) * (X * X) * T_0_SQ * (T(1) - T_0_SQ);
+    const T XNL_1 = (T(9) * (T_0_SQ * T_0_SQ) - T(10) * T_0_SQ + T(9)) / (T(8) * T_0_SQ * T_0);
+    const T b = T(2) * V_G - T(0.5) * C_0;
+    const T XNL_2 = (b * b / (tb.G * D - V_G_SQ) + T(1)) / X;
+    const T c = T(2) * C_0 + V_G * (T(1) - T_0_SQ);
+    const T XNL_4 = T(1) / (T(4) * T_0) * (c * c) / (C_S_SQ - V_G_SQ);
+    const T ALP = (T(1) - V_G_SQ / C_S_SQ) * (C_0 * C_0) / V_G_SQ;
+    const T s2 = SIG_TH * SIG_TH;
+    const T ZFAC = s2 / (s2 + ALP * (XNU * XNU));
+    const T XNL = XNL_1 - XNL_2 + ZFAC * XNL_4;
+    const T t4 = T_0_SQ * T_0_SQ;
+    const T r = (XNL * XNL) / (DV_G * (t4 * t4));
+    return m_max(m_min(T(10), r), T(0.1));
+  }
+  return T(1);
+}
+
 // One sweep over the DIA interactions MC = 1..NFRE+4 (snonlin.F90:126-494, ISNONLIN = 0, pull form of snonlin_pull above);
 // after interaction MC row R = MC-4 is final: SDIWBK, SBOTTOM, the implicit update
 // with its limiter and the WNFLUXES integrands (implsch.F90:294-395) are applied to it and F(:,R) is overwritten in place.
@@ -941,8 +1025,10 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
   ENHFR = T(1) + (T(5.5) / ENHFR) * (T(1) - T(.833) * ENHFR) * m_exp(-T(1.25) * ENHFR);
   const int NAP = L.NAP, NFRE = L.NFRE, NANG = L.NANG, k = L.k;
   // ISNONLIN = 1 (snonlin.F90:138-150): enhancement per interaction frequency, lane mc holds MC = mc+1 (MLSTHG <= 56 lanes)
-  const bool enh_mc = RARE && tb.ISNONLIN == 1;
+  const bool enh_mc = RARE && (tb.ISNONLIN == 1 || tb.ISNONLIN == 2);
   T rENH = ENHFR;
+  T XNU = T(0), SIG_TH = T(0);
+  if (RARE && tb.ISNONLIN == 2) peak_ang_w(tb, sF, L, XNU, SIG_TH);  // ISNONLIN = 2 (snonlin.F90:152-165), before any row is updated
   if (enh_mc && L.lane < tb.MLSTHG) {
     T XK;
     if (L.lane < NFRE) XK = rWAVNUM;
@@ -952,7 +1038,7 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
       const T w = tb.ZPIFR[NFRE - 1] * fr;
       XK = tb.GM1 * (w * w);
     }
-    rENH = m_max(m_min(T(10), transf_d(tb, XK, DEPTH)), T(0.1));
+    rENH = (tb.ISNONLIN == 2) ? transf_snl_d(tb, XK, DEPTH, XNU, SIG_TH) : m_max(m_min(T(10), transf_d(tb, XK, DEPTH)), T(0.1));
   }
   const int MFR1STFR = -tb.MFRSTLW + 1;
   const int MFRLSTFR = NFRE - tb.KFRH + MFR1STFR;

@@ -77,8 +77,8 @@ class Config:
     def validate(self) -> None:
         if self.iphys not in (0, 1):
             raise NotImplementedError("IPHYS must be 0 (Janssen) or 1 (Ardhuin)")
-        if self.isnonlin not in (0, 1):
-            raise NotImplementedError("ISNONLIN=2 (TRANSF_SNL / PEAK_ANG) is a 'next' row (SURVEY.md 8f rank 4)")
+        if self.isnonlin not in (0, 1, 2):
+            raise ValueError("ISNONLIN must be 0, 1 (TRANSF) or 2 (TRANSF_SNL with PEAK_ANG)")
         if self.irefra not in (0, 1, 2, 3):
             raise ValueError("IREFRA must be 0 (none), 1 (depth), 2 (currents) or 3 (depth + currents)")
         if self.icode != 3:

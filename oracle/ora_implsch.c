@@ -4,6 +4,7 @@
  * one sea point at a time (the reference's IJ loop is innermost and couples no points).
  * F(k,m) below is FL1(IJ,K,M) of the reference with 0-based k,m.
  */
+#include <float.h>
 #include "ora.h"
 
 #define NA ORA_MAXANG
@@ -928,13 +929,97 @@ static real transf(real XK, real D) {
   return C_(1.0);
 }
 
-/* snonlin.F90:126-494 (ISNONLIN = 0: depth scaling from AKMEAN; ISNONLIN = 1: TRANSF per interaction frequency) */
+/* peak_ang.F90:76-174: Longuet-Higgins spectral width XNU and angular width SIG_TH around the peak of the 2-D spectrum */
+static void peak_ang(const real *FL1, real *XNU, real *SIG_TH) {
+  const int NANG = S.NANG, NFRE = S.NFRE;
+#ifdef ORA_SINGLE
+  const real ZEPSILON = C_(10.) * FLT_EPSILON;
+#else
+  const real ZEPSILON = C_(10.) * DBL_EPSILON;
+#endif
+  const int NSH = 1 + (int)(LOG(C_(1.5)) / LOG(S.FRATIO));
+  real SUM0 = ZEPSILON, SUM1 = C_(0.), SUM2 = C_(0.), TEMP = C_(0.);
+  for (int M = 0; M < NFRE; M++) {
+    TEMP = F(0, M);
+    for (int K = 1; K < NANG; K++) TEMP = TEMP + F(K, M);
+    SUM0 = SUM0 + TEMP * S.DFIM[M];
+    SUM1 = SUM1 + TEMP * S.DFIMFR[M];
+    SUM2 = SUM2 + TEMP * (S.DFIM[M] * powi(S.FR[M], 2)); /* DFIMFR2, initmdl.F90:447 */
+  }
+  const real DELT25 = S.WETAIL * S.FR[NFRE - 1] * S.DELTH;
+  const real COEF_FR = S.WP1TAIL * S.DELTH * powi(S.FR[NFRE - 1], 2);
+  const real COEF_FR2 = C_(0.5) * S.DELTH * powi(S.FR[NFRE - 1], 3); /* WP2TAIL = 0.5, yowfred.F90:54 */
+  SUM0 = SUM0 + DELT25 * TEMP;
+  SUM1 = SUM1 + COEF_FR * TEMP;
+  SUM2 = SUM2 + COEF_FR2 * TEMP;
+  if (SUM0 > ZEPSILON) *XNU = SQRT(RMAX(ZEPSILON, SUM2 * SUM0 / powi(SUM1, 2) - C_(1.)));
+  else *XNU = ZEPSILON;
+  real XMAX = C_(0.);
+  int MMAX = 2;
+  for (int M = 2; M <= NFRE - 1; M++)
+    for (int K = 0; K < NANG; K++)
+      if (F(K, M - 1) > XMAX) { MMAX = M; XMAX = F(K, M - 1); }
+  SUM1 = ZEPSILON; SUM2 = C_(0.);
+  const int MMSTART = MMAX - NSH > 1 ? MMAX - NSH : 1, MMSTOP = MMAX + NSH < NFRE ? MMAX + NSH : NFRE;
+  real SUM_S = C_(0.), SUM_C = ZEPSILON;
+  for (int M = MMSTART; M <= MMSTOP; M++) {
+    for (int K = 0; K < NANG; K++) {
+      SUM_S = SUM_S + S.SINTH[K] * F(K, M - 1);
+      SUM_C = SUM_C + S.COSTH[K] * F(K, M - 1);
+    }
+    const real THMEAN = ATAN2(SUM_S, SUM_C);
+    for (int K = 0; K < NANG; K++) {
+      SUM1 = SUM1 + F(K, M - 1) * S.DFIM[M - 1];
+      SUM2 = SUM2 + COS(S.TH[K] - THMEAN) * F(K, M - 1) * S.DFIM[M - 1];
+    }
+  }
+  if (SUM1 > ZEPSILON) {
+    const real R1 = SUM2 / SUM1;
+    *SIG_TH = C_(1.0) * SQRT(C_(2.) * (C_(1.) - R1));
+  } else *SIG_TH = C_(0.);
+}
+
+/* transf_snl.F90:52-85: shallow-water enhancement with the finite-bandwidth correction (XNU, SIG_TH from PEAK_ANG) */
+static real transf_snl(real XK0, real D, real XNU, real SIG_TH) {
+  const real EPS = C_(0.0001), DKMAX = C_(40.0), XKDMIN = C_(0.75); /* yowpcons.F90:34, yowshal.F90:23 */
+  if (D < S.BATHYMAX && D > C_(0.)) {
+    real X = XK0 * D;
+    if (X > DKMAX) return C_(1.);
+    const real XK = RMAX(XK0, XKDMIN / D);
+    X = XK * D;
+    const real T_0 = TANH(X);
+    const real T_0_SQ = powi(T_0, 2);
+    const real OM = SQRT(S.G * XK * T_0);
+    const real C_0 = OM / XK;
+    const real C_S_SQ = S.G * D;
+    real V_G;
+    if (X < EPS) V_G = C_0;
+    else V_G = C_(0.5) * C_0 * (C_(1.) + C_(2.) * X / SINH(C_(2.) * X));
+    const real V_G_SQ = powi(V_G, 2);
+    const real DV_G = powi(T_0 - X * (C_(1.) - T_0_SQ), 2) + C_(4.) * powi(X, 2) * T_0_SQ * (C_(1.) - T_0_SQ);
+    const real XNL_1 = (C_(9.) * powi(T_0_SQ, 2) - C_(10.) * T_0_SQ + C_(9.)) / (C_(8.) * T_0_SQ * T_0);
+    const real XNL_2 = (powi(C_(2.) * V_G - C_(0.5) * C_0, 2) / (S.G * D - V_G_SQ) + C_(1.)) / X;
+    const real XNL_4 = C_(1.) / (C_(4.) * T_0) * powi(C_(2.) * C_0 + V_G * (C_(1.) - T_0_SQ), 2) / (C_S_SQ - V_G_SQ);
+    const real ALP = (C_(1.) - V_G_SQ / C_S_SQ) * powi(C_0, 2) / V_G_SQ;
+    const real ZFAC = powi(SIG_TH, 2) / (powi(SIG_TH, 2) + ALP * powi(XNU, 2));
+    const real XNL_3 = ZFAC * XNL_4;
+    const real XNL = XNL_1 - XNL_2 + XNL_3;
+    real r = powi(XNL, 2) / (DV_G * powi(T_0_SQ, 4));
+    return RMAX(RMIN(C_(10.), r), C_(0.1));
+  }
+  return C_(1.);
+}
+
+/* snonlin.F90:126-494 (ISNONLIN = 0: depth scaling from AKMEAN; ISNONLIN = 1: TRANSF per interaction frequency;
+ * ISNONLIN = 2: TRANSF_SNL with the spectral widths of PEAK_ANG) */
 static void snonlin(const real *FL1, real *FLD, real *SL, real DEPTH, real AKMEAN, const real *WAVNUM) {
   const int NANG = S.NANG, NFRE = S.NFRE;
   real ENHFR = RMAX(C_(0.75) * DEPTH * AKMEAN, C_(0.5));
   ENHFR = C_(1.0) + (C_(5.5) / ENHFR) * (C_(1.0) - C_(.833) * ENHFR) * EXP(-C_(1.25) * ENHFR);
   int MFR1STFR = -S.MFRSTLW + 1;
   int MFRLSTFR = NFRE - S.KFRH + MFR1STFR;
+  real XNU = C_(0.), SIG_TH = C_(0.);
+  if (S.c.isnonlin == 2) peak_ang(FL1, &XNU, &SIG_TH);
   for (int MC = 1; MC <= S.MLSTHG; MC++) {
     int MP = S.IKP[MC - 1], MP1 = S.IKP1[MC - 1], MM = S.IKM[MC - 1], MM1 = S.IKM1[MC - 1];
     const int *I5 = S.INLCOEF[MC - 1];
@@ -950,6 +1035,9 @@ static void snonlin(const real *FL1, real *FLD, real *SL, real DEPTH, real AKMEA
     if (S.c.isnonlin == 1) { /* snonlin.F90:138-150 */
       real XK = (MC <= NFRE) ? WAVNUM[MC - 1] : S.GM1 * powi(S.ZPIFR[NFRE - 1] * powi(S.FRATIO, MC - NFRE), 2);
       ENH = RMAX(RMIN(C_(10.0), transf(XK, DEPTH)), C_(0.1));
+    } else if (S.c.isnonlin == 2) { /* snonlin.F90:152-165 */
+      real XK = (MC <= NFRE) ? WAVNUM[MC - 1] : S.GM1 * powi(S.ZPIFR[NFRE - 1] * powi(S.FRATIO, MC - NFRE), 2);
+      ENH = transf_snl(XK, DEPTH, XNU, SIG_TH);
     }
     real FTEMP = S.AF11[MC - 1] * ENH;
     int branch = (MC > MFR1STFR && MC < MFRLSTFR) ? 0 : (MC >= MFRLSTFR ? 1 : 2);
@@ -1246,7 +1334,7 @@ static int implsch_point(real *FL1, real *XLLWS, point_t *p, real *dbg) {
   real F1MEAN, AKMEAN, XKMEAN, PHIWA;
   real FLM[NA], COSWDIF[NA], SINWDIF2[NA], TEMP[NF], RHOWGDFTH[NF], DELFL[NF];
   int LCFLX;
-  if (S.c.isnonlin != 0 && S.c.isnonlin != 1) return 2; /* ISNONLIN = 2 (TRANSF_SNL, PEAK_ANG): not restated */
+  if (S.c.isnonlin < 0 || S.c.isnonlin > 2) return 2;
   if (S.c.lciwa1 || S.c.lwnemocouibr) return 2; /* SDICE1 (CIDEAC scattering table) and the ice break-up coupling: not restated */
 
   DELT = (real)S.c.idelt;

@@ -151,10 +151,12 @@ def test_implsch_parity_iphys_0(api, prec, llnormagam):
 
 
 @pytest.mark.parametrize("prec", ["dp", "sp"])
-def test_implsch_parity_isnonlin_1(api, prec):
-    """ISNONLIN = 1: the DIA scaled per interaction frequency by TRANSF(k, depth) (snonlin.F90:138-150, transf.F90) on a
-    case with many intermediate-depth points."""
-    cfg = Config(nang=24, nfre=36, nfre_red=29, isnonlin=1)
+@pytest.mark.parametrize("isnonlin", [1, 2])
+def test_implsch_parity_isnonlin_1_2(api, prec, isnonlin):
+    """ISNONLIN = 1: the DIA scaled per interaction frequency by TRANSF(k, depth) (snonlin.F90:138-150, transf.F90);
+    ISNONLIN = 2: by TRANSF_SNL with the spectral widths XNU, SIG_TH of PEAK_ANG (snonlin.F90:152-165, transf_snl.F90,
+    peak_ang.F90) -- on a case with many intermediate-depth points."""
+    cfg = Config(nang=24, nfre=36, nfre_red=29, isnonlin=isnonlin)
     n = 900
     case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=51)
     dt = H.np_dtype(prec)

@@ -67,7 +67,7 @@ def cpu_baseline(nang: int, nfre: int, prec: str, target_s: float = 15.0) -> dic
     cfg = Config(nang=nang, nfre=nfre, nfre_red=nfre, idelt=450, idelpro=450)
     dt = np.float32 if prec == "sp" else np.float64
     t = Tables(cfg, dt)
-    o = Oracle(cfg, prec)
+    o = Oracle(cfg, prec, fast=True)     # same sources, built -O3 -march=x86-64-v3 (oracle/Makefile): timing only
     g = G.build_grid(48)
     n = g.nsea
     p = syn.point_params(n)
@@ -92,7 +92,7 @@ def cpu_baseline(nang: int, nfre: int, prec: str, target_s: float = 15.0) -> dic
             break
     return {"value": n * steps / el, "unit": "grid-point spectral steps/s", "cores": cores, "kind": "port",
             "sample": f"O48 all-ocean grid ({n} sea points), {nang}x{nfre} spectrum, {prec}, {steps} full steps "
-                      f"(PROPAGS2 + IMPLSCH), oracle/ C restatement with OpenMP over points, {cores} threads "
+                      f"(PROPAGS2 + IMPLSCH), oracle/ C restatement (speed build: gcc -O3 -march=x86-64-v3) with OpenMP over points, {cores} threads "
                       f"(host reports {os.cpu_count()} logical CPUs)"}
 
 

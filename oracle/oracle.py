@@ -31,10 +31,11 @@ class OraCfg(C.Structure):
 
 
 def build(force: bool = False) -> None:
-    need = force or not all(os.path.exists(os.path.join(_HERE, f)) for f in ("libora_sp.so", "libora_dp.so"))
+    libs = ("libora_sp.so", "libora_dp.so", "libora_sp_fast.so", "libora_dp_fast.so")
+    need = force or not all(os.path.exists(os.path.join(_HERE, f)) for f in libs)
     if not need:
-        src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in os.listdir(_HERE) if f.endswith((".c", ".h")))
-        so_m = min(os.path.getmtime(os.path.join(_HERE, f)) for f in ("libora_sp.so", "libora_dp.so"))
+        src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in os.listdir(_HERE) if f.endswith((".c", ".h")) or f == "Makefile")
+        so_m = min(os.path.getmtime(os.path.join(_HERE, f)) for f in libs)
         need = src_m > so_m
     if need:
         subprocess.run(["make", "-C", _HERE, "-s", "-B"], check=True)
@@ -44,12 +45,14 @@ class Oracle:
     """One initialised oracle instance (module state lives inside the shared object, like the
     Fortran modules it restates: one configuration per loaded library)."""
 
-    def __init__(self, cfg, precision: str = "dp"):
+    def __init__(self, cfg, precision: str = "dp", fast: bool = False):
+        """fast=True loads the speed build (vectorised, contraction on): for the CPU timing leg of bench.py only; every
+        parity check uses the default bit-reproducible build."""
         build()
         self.precision = precision
         self.dtype = np.float32 if precision == "sp" else np.float64
         # a private copy per instance so that sp/dp and several configs can coexist in one process
-        path = os.path.join(_HERE, f"libora_{precision}.so")
+        path = os.path.join(_HERE, f"libora_{precision}{'_fast' if fast else ''}.so")
         self._fresh_copy(path)
         assert self.lib.ora_real_size() == np.dtype(self.dtype).itemsize
         oc = OraCfg()

@@ -336,3 +336,17 @@ def test_oracle_refraction_restatement_invariants():
     for k in ("SUMWN", "WKPMN", "WMPMN", "WLONN"):
         assert np.array_equal(a[k][keep], b[k][keep]), k
     assert not b["WMPMN"][~keep].any()
+
+
+def test_speed_build_of_the_oracle_agrees_with_the_strict_build():
+    """bench.py times `Oracle(fast=True)` (same sources, -O3 -march=x86-64-v3, contraction on) as the CPU baseline; it must
+    compute the same thing as the bit-reproducible build every parity test uses (differences: FMA contraction and
+    vectorised summation order only)."""
+    from oracle.oracle import Oracle
+
+    cfg = Config(nang=24, nfre=36, nfre_red=29)
+    case = H.make_point_case(200, cfg, "dp", spectra="mixed", seed=3)
+    a = H.oracle_implsch(case, Oracle(cfg, "dp"))
+    b = H.oracle_implsch(case, Oracle(cfg, "dp", fast=True))
+    st = H.compare_implsch(a, b, case["tables"])
+    assert st["mij_flips"] == 0 and st["fl1_max_rel_peak_all"] < 1e-10 and st["swh_max_rel"] < 1e-12, st

@@ -23,6 +23,7 @@ struct DevTab {
   int IPHYS, IDAMPING;  // 0: SINPUT_JAN + SDISSIP_JAN, 1: SINPUT_ARD + SDISSIP_ARD (sinput.F90:102, sdissip.F90:76)
   int ISNONLIN;  // 0: DIA depth scaling from AKMEAN, 1: TRANSF per interaction frequency (snonlin.F90:126-150)
   int LCISCAL, LCIWA2, LCIWA3;  // sea-ice attenuation (implsch.F90:312-339, sdice2.F90, sdice3.F90)
+  int LCIWA1, LWNEMOCOUIBR, LWNEMOCOUSTRN, NICT, NICH;  // SDICE1 scattering table, ice break-up coupling, CIMSSTRN
   int NSDSNTH, NTAP, MFRSTLW, MLSTHG, KFRH, NWAV_GC;
   // timing diagnostics only (env ECWAM_HIP_DEBUG_SKIP): bit mask of IMPLSCH phases to skip -- 1 SINPUT, 2 STRESSO scalars,
   // 4 SDISSIP, 8 DIA, 16 TAUT_Z0, 32 spectrum store of the update, 64 WSIGSTAR/swell set-up/SDIWBK.  0 in production.
@@ -38,6 +39,8 @@ struct DevTab {
   T X0TAUHF, EPS1, FLMIN, CITHRSH, CIBLOCK, CITHRSH_TAIL, ZALPWRS, BATHYMAX, WSPMIN, WSPMIN_RESET_TAUW;
   T DAL1, DAL2, XLOGKRATIOM1_GC, SQRTGOSURFT;
   T CDICWA, ZALPFACB, ZALPFACX;
+  T ZIBRW_THRSH, TICMIN, DTIC, DHIC, HICMIN;
+  T CIDEAC[36 * 16];  // [ih][it], cigetdeac.F90:64-71: NICH = 36, NICT = 16
   T CDIS, DELTA_SDIS, CDISVIS;
   // per-frequency
   T FR[MAXF], DFIM[MAXF], DFIMOFR[MAXF], DFIMFR[MAXF], DFIM_SIM[MAXF], RHOWG_DFIM[MAXF], ZPIFR[MAXF], FR5[MAXF];
@@ -92,6 +95,8 @@ __device__ __forceinline__ float m_max(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ double m_max(double a, double b) { return fmax(a, b); }
 __device__ __forceinline__ float m_min(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ double m_min(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float m_floor(float x) { return floorf(x); }
+__device__ __forceinline__ double m_floor(double x) { return floor(x); }
 __device__ __forceinline__ float m_sign(float a, float b) { return copysignf(a, b); }
 __device__ __forceinline__ double m_sign(double a, double b) { return copysign(a, b); }
 __device__ __forceinline__ int m_nint(float x) { return (int)lroundf(x); }

@@ -929,6 +929,29 @@ __device__ T transf_d(const DevTab<T>& tb, T XK, T D) {
   return T(1);
 }
 
+// aki_ice.F90:60-112: wave number under an elastic ice sheet, Newton iteration (per lane)
+template <typename T>
+__device__ T aki_ice_d(T G, T XK, T DEPTH, T RHOW, T CITH) {
+  const T YMICE = T(5.5E+9), RMUICE = T(0.3), RHOI = T(922.5), EBS = T(0.000001), AKI_MAX = T(20.0);
+  if (CITH <= T(0)) return XK;
+  const T FICSTF = (YMICE * (CITH * CITH * CITH) / (T(12) * (T(1) - RMUICE * RMUICE))) / RHOW;
+  const T RDH = (RHOI / RHOW) * CITH;
+  const T OM2 = G * XK * m_tanh(XK * DEPTH);
+  T AKIOLD = T(0);
+  T AKI = m_min(XK, m_pow(OM2 / m_max(FICSTF, T(1)), T(0.2)));
+  for (int it = 0; it < 200 && m_abs(AKI - AKIOLD) > EBS * AKIOLD && AKI < AKI_MAX; it++) {
+    AKIOLD = AKI;
+    const T AKID = m_min(DEPTH * AKI, T(50.0));
+    const T a2 = AKI * AKI, a4 = a2 * a2;
+    const T Fv = FICSTF * (a4 * AKI) + G * AKI - OM2 * (RDH * AKI + T(1) / m_tanh(AKID));
+    const T sh = m_sinh(AKID);
+    const T FPRIME = T(5) * FICSTF * a4 + G - OM2 * (RDH - DEPTH / (sh * sh));
+    AKI = AKI - Fv / FPRIME;
+    if (AKI <= T(0)) AKI = AKI_MAX;
+  }
+  return AKI;
+}
+
 // peak_ang.F90:76-174 per wave (lane = M for the frequency moments, lane = K for the peak search and the angular width)
 template <typename T>
 __device__ void peak_ang_w(const DevTab<T>& tb, const T* sF, const Lane<T>& L, T& XNU, T& SIG_TH) {
@@ -1019,7 +1042,7 @@ __device__ T transf_snl_d(const DevTab<T>& tb, T XK0, T D, T XNU, T SIG_TH) {
 template <typename T, bool RARE>
 __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const Lane<T>& L, T rWAVNUM, T rCINV, T rXK2CG, T rRH, T UFRIC,
                              T coswdif, T RAORW, T DEPTH, T AKMEAN, T SDS, bool shallow_brk, T USFM, T FLM, T CICOVER, T CITHICK,
-                             T rCGROUP, T& a_t, T& a_x) {
+                             T rCGROUP, T IBRMEM, T& a_t, T& a_x, T& a_ice) {
   const int SKIP = tb.DBG_SKIP;
   T ENHFR = m_max(T(0.75) * DEPTH * AKMEAN, T(0.5));
   ENHFR = T(1) + (T(5.5) / ENHFR) * (T(1) - T(.833) * ENHFR) * m_exp(-T(1.25) * ENHFR);
@@ -1064,13 +1087,59 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
   a_t = T(0); a_x = T(0);
   // sea-ice attenuation between SDIWBK and SBOTTOM (implsch.F90:312-339; LWNEMOCOUIBR = F: ALPFAC = ZALPFACX)
   const bool ice_scal = tb.LICERUN && (RARE && tb.LCISCAL), ice2 = tb.LICERUN && (RARE && tb.LCIWA2), ice3 = tb.LICERUN && (RARE && tb.LCIWA3);
+  const bool ice1 = tb.LICERUN && (RARE && tb.LCIWA1), wrs = RARE && tb.LWNEMOCOUWRS;
   const T BETA = T(1) - CICOVER;
+  // ALPFAC (implsch.F90:195) and its reduction over broken ice (icebreak_modify_attenuation.F90:82-93)
+  T ALPFAC = tb.ZALPFACX;
+  if ((RARE && tb.LWNEMOCOUIBR) && IBRMEM <= tb.ZIBRW_THRSH) ALPFAC = T(1) / tb.ZALPFACX;
   T rICE3 = T(0), rICE2 = T(0);  // lane m: -CICV*ALP(M)*CGROUP(M) of SDICE3; CDICWA*WAVNUM(M)**2 of SDICE2
+  T rALP3 = T(0);                // lane m: FLDICE(M) = -ALP(M)*CGROUP(M) of SDICE3 (SLICE, sdice3.F90:143)
+  T rICE1 = T(0);                // lane m: FLDICE(M) = -ALP(M)*CGROUP(M) of SDICE1
   if (ice3 && L.actm) {
     const T CDICE = T(0.1274) * m_pow(tb.ZPI / m_sqrt(tb.G), T(4.5));
-    const T ALP = (T(2) * CDICE * m_pow(CITHICK, T(1.25)) * m_pow(tb.FR[L.lane], T(4.5))) * tb.ZALPFACX;
+    const T ALP = (T(2) * CDICE * m_pow(CITHICK, T(1.25)) * m_pow(tb.FR[L.lane], T(4.5))) * ALPFAC;
     rICE3 = -CICOVER * ALP * rCGROUP;
+    rALP3 = -ALP * rCGROUP;
   }
+  if (ice1) {  // sdice1.F90:104-163
+    const T CIFRGL = T(0.955), CIDMIN = T(20.0), CIFRGMT = T(2.0), A = T(200.0), C = T(300.0);
+    const int MAXICM = (int)(m_log(A / CIDMIN) / m_log(CIFRGMT));
+    T DINV = CIDMIN;
+    if (CITHICK > T(0)) {
+      const T CIDMAX = A + C * CICOVER;
+      int ICM = (int)(m_log(CIDMAX / CIDMIN) / m_log(CIFRGMT));
+      if (ICM > MAXICM) ICM = MAXICM;
+      T SN = T(0), SD = T(0), X = T(1), FI = T(1);
+      for (int I = 0; I <= ICM; I++) {   // X = (CIFRGMT**2*CIFRGL)**I, FI = CIFRGMT**I
+        SN = SN + X * CIDMAX / FI;
+        SD = SD + X;
+        X = X * (CIFRGMT * CIFRGMT * CIFRGL);
+        FI = FI * CIFRGMT;
+      }
+      DINV = T(1) / (SN / SD);
+    }
+    if (L.actm && CITHICK > T(0)) {
+      const int NICT = tb.NICT, NICH = tb.NICH;
+      const T TW = T(1) / tb.FR[L.lane];
+      int IT = (int)m_floor((TW - tb.TICMIN) / tb.DTIC + T(1));
+      IT = IT < 1 ? 1 : (IT > NICT ? NICT : IT);
+      const int IT1 = IT + 1 > NICT ? NICT : IT + 1;
+      const T WT1 = m_max(m_min(T(1), (TW - (tb.TICMIN + T(IT - 1) * tb.DTIC)) / tb.DTIC), T(0));
+      const T WT = T(1) - WT1;
+      int IH = (int)m_floor((CITHICK - tb.HICMIN) / tb.DHIC + T(1));
+      IH = IH < 1 ? 1 : (IH > NICH ? NICH : IH);
+      const int IH1 = IH + 1 > NICH ? NICH : IH + 1;
+      const T WH1 = m_max(m_min(T(1), (CITHICK - (tb.HICMIN + T(IH - 1) * tb.DHIC)) / tb.DHIC), T(0));
+      const T WH = T(1) - WH1;
+      const T* cd = tb.CIDEAC;
+      const T CI = WT * (WH * cd[(IH - 1) * NICT + IT - 1] + WH1 * cd[(IH1 - 1) * NICT + IT - 1]) +
+                   WT1 * (WH * cd[(IH - 1) * NICT + IT1 - 1] + WH1 * cd[(IH1 - 1) * NICT + IT1 - 1]);
+      rICE1 = -(m_exp(CI) * DINV * tb.ZALPFACB) * rCGROUP;
+    }
+  }
+  const T rCRI = rCINV * (L.actm ? tb.RHOWG_DFIM[L.lane] : T(0));  // lane m: CINV(M)*RHOWG_DFIM(M) of the ice stress (wnfluxes.F90:193-194)
+  const T EPSMIN1000 = tb.EPSMIN * T(1000);
+  a_ice = T(0);
   if (ice2 && L.actm) rICE2 = tb.CDICWA * (rWAVNUM * rWAVNUM);
   const T rLIM = USFM * (L.rCOFRM4 * DELT), rCR = rCINV * rRH;  // lane m: limiter bound and CINV*RHOWGDFTH of row M=m+1
 
@@ -1140,17 +1209,30 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
           if (flux_snl) ss = f_div(sl, m_max(T(1) - DELT5 * fld, T(1)));
           if (shallow_brk && m < tb.NFRE_RED) { sl = sl - SDS * f; fld = fld - SDS; }
           if (ice_scal) { sl = BETA * sl; fld = BETA * fld; }
+          T fldice_last = T(0);  // FLDICE of the last active SDICEn: each overwrites SLICE (sdice.F90:94-110)
+          if (ice1) {  // sdice1.F90:166-181
+            const T FLDICE = lane_get(rICE1, m);
+            sl = sl + CICOVER * (f * FLDICE);
+            fld = fld + CICOVER * FLDICE;
+            fldice_last = FLDICE;
+          }
           if (ice2) {  // sdice2.F90:97-121
             const T EWH = T(4) * m_sqrt(m_max(tb.EPSMIN, f * lane_get(L.rDFIM, m)));
             const T ALP = lane_get(rICE2, m) * EWH * tb.ZALPFACB;
             const T FLDICE = -ALP * lane_get(rCGROUP, m);
             sl = sl + CICOVER * (f * FLDICE);
             fld = fld + CICOVER * FLDICE;
+            fldice_last = FLDICE;
           }
           if (ice3) {  // sdice3.F90:139-160
             const T TEMP = lane_get(rICE3, m);
             sl = sl + f * TEMP;
             fld = fld + TEMP;
+            if (wrs) fldice_last = lane_get(rALP3, m);
+          }
+          if (wrs) {  // SLICE (sdice*.F90: F*FLDICE/GTEMP1) into the ice radiative stress integrand (wnfluxes.F90:178-196)
+            const T slice = f_div(f * fldice_last, m_max(T(1) - DELT5 * fldice_last, T(1)));
+            a_ice += lane_get(rCRI, m) * m_min(slice, -EPSMIN1000);
           }
           const T sbo = lane_get(rSBO, m);
           if (m < tb.NFRE_RED) { sl = sl + sbo * f; fld = fld + sbo; }
@@ -1218,12 +1300,13 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   {
     const T* wp = wvprpt + (size_t)ij * ECWAM_HIP_NWPR * NFRE;
     if (L.actm) { rWAVNUM = wp[L.lane]; rCINV = wp[2 * NFRE + L.lane]; rXK2CG = wp[3 * NFRE + L.lane]; rSTOKFAC = wp[4 * NFRE + L.lane]; }
-    if (L.actm && ((RARE && tb.LCIWA2) || (RARE && tb.LCIWA3))) rCGROUP = wp[NFRE + L.lane];
+    if (L.actm && ((RARE && tb.LCIWA1) || (RARE && tb.LCIWA2) || (RARE && tb.LCIWA3))) rCGROUP = wp[NFRE + L.lane];
   }
   const T ffv = (L.lane < ECWAM_HIP_NFF) ? ffa[(size_t)ij * ECWAM_HIP_NFF + L.lane] : T(0);
   const T AIRD = lane_get(ffv, 0), WDWAVE = lane_get(ffv, 1), CICOVER = lane_get(ffv, 2), WSWAVE = lane_get(ffv, 3);
   const T WSTAR = lane_get(ffv, 4), USTRA = lane_get(ffv, 5), VSTRA = lane_get(ffv, 6);
   const T EMAXDPT = lane_get(ffv, 14), DEPTH = lane_get(ffv, 15), CITHICK = lane_get(ffv, 13);
+  const T IBRMEM = (RARE && tb.LWNEMOCOUIBR) ? intfa[(size_t)ij * ECWAM_HIP_NINTF + 15] : T(1);  // ENVIRONMENT%IBRMEM (input slot)
   const T RAORW = m_max(AIRD, T(1)) * tb.ROWATERM1;
   // ---- stage 1 inputs: first TAUT_Z0 (depends on the forcing only)
   if (L.lane < 13) {
@@ -1437,9 +1520,9 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   // ---- SDISSIP + SNONLIN + update sweep
   const bool shallow_brk = tb.LBIWBK && (DEPTH < T(50.0));
   const T USFM = UFRIC * m_max(FMEANWS, FMEAN);
-  T a_t, a_x;
+  T a_t, a_x, a_ice;
   WSYNC();
-  source_sweep<T, RARE>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, rRH, UFRIC, coswdif, RAORW, DEPTH, AKMEAN, SDS, shallow_brk, USFM, FLM, CICOVER, CITHICK, rCGROUP, a_t, a_x);
+  source_sweep<T, RARE>(tb, sF, sFLD, L, rWAVNUM, rCINV, rXK2CG, rRH, UFRIC, coswdif, RAORW, DEPTH, AKMEAN, SDS, shallow_brk, USFM, FLM, CICOVER, CITHICK, rCGROUP, IBRMEM, a_t, a_x, a_ice);
   WSYNC();
   __syncthreads();  // stage 3 results
   const T TAUW = c[C_TAUW], TAUWDIR = c[C_TAUWDIR], PHIWA = c[C_PHIWA];
@@ -1451,14 +1534,19 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
 
   // ---- WNFLUXES (wnfluxes.F90:147-330), LWNEMOCOUWRS = F
   T TAUXD = T(0), TAUYD = T(0), TAUOCXD = T(0), TAUOCYD = T(0), TAUOC = T(0), PHIOCD = T(0), PHIEPS = T(0), PHIAW = T(0);
+  T TAUICX = T(0), TAUICY = T(0);
   if (tb.LCFLX) {
-    if (!L.act) { a_t = T(0); a_x = T(0); }
+    if (!L.act) { a_t = T(0); a_x = T(0); a_ice = T(0); }
+    if ((RARE && tb.LWNEMOCOUWRS)) {  // wnfluxes.F90:178-196, 267-271: stress on the ice, sign flipped
+      TAUICX = -(tb.ZALPWRS * usum(a_ice * tb.SINTH[L.k]));
+      TAUICY = -(tb.ZALPWRS * usum(a_ice * tb.COSTH[L.k]));
+    }
     const T PHILF = usum(a_t);
     const T XSTRESS = usum(a_x * tb.SINTH[L.k]);
     const T YSTRESS = usum(a_x * tb.COSTH[L.k]);
     const T EPSUS3 = tb.EPSUS * m_sqrt(tb.EPSUS);
     // wnfluxes.F90: with an explicit ice attenuation term the blending with the ice-covered fluxes starts at CICOVER = 0
-    const bool sdice_on = (RARE && tb.LCIWA2) || (RARE && tb.LCIWA3);
+    const bool sdice_on = (RARE && tb.LCIWA1) || (RARE && tb.LCIWA2) || (RARE && tb.LCIWA3);
     const T ZCITHRS = sdice_on ? T(0) : tb.CIBLOCK;
     const T CITHRSH_INV = sdice_on ? T(50) : T(1) / m_max(tb.CITHRSH, T(0.01));
     const T ZMAXEXP = sdice_on ? T(20) : T(10);
@@ -1504,7 +1592,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
       if (tb.LWNEMOTAUOC) { q[7] += (double)TAUOCXD; q[8] += (double)TAUOCYD; }
       else { q[7] += (double)TAUXD; q[8] += (double)TAUYD; }
       q[11] += (double)WSWAVE; q[12] += (double)PHIOCD;
-      q[9] += 0.0; q[10] += 0.0;
+      q[9] += (double)TAUICX; q[10] += (double)TAUICY;
     }
   }
 
@@ -1554,6 +1642,18 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
       q[1] = tb.LWNEMOCOUSTK ? (double)VSTOKES : 0.0;
     }
   }
+  T STRNMS = T(0);
+  if ((RARE && tb.LWNEMOCOUSTRN)) {  // cimsstrn.F90:86-118 with aki_ice.F90:60-112, lane = M
+    const T sume = colsum(sF, L);
+    T term = T(0);
+    if (L.actm) {
+      const T XKI = aki_ice_d(tb.G, rWAVNUM, DEPTH, tb.ROWATER, CITHICK);
+      const T E = T(0.5) * CITHICK * (XKI * XKI * XKI) / rWAVNUM;
+      if (sume > tb.FLMIN / tb.DELTH) term = (E * E) * sume * L.rDFIM;
+    }
+    STRNMS = usum(term);
+    if (tb.LWNEMOCOU && w2n && valid && L.lane == 0 && ((tb.LWNEMOCOUSEND && tb.LWCOU) || !tb.LWCOU)) w2n[(size_t)ij * 13 + 2] = (double)STRNMS;
+  }
   // XLLWS as reals into the FLD tile for the coalesced store
   if (L.act)
     for (int m = 0; m < NFRE; m++) sFLD[m * NAP + L.k] = ((xmask >> m) & 1ull) ? T(1) : T(0);
@@ -1572,9 +1672,9 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   }
   if (L.lane == 0) {
     sScr[7] = UFRIC; sScr[8] = TAUW; sScr[9] = TAUWDIR; sScr[10] = Z0M; sScr[11] = Z0B; sScr[12] = CHRNCK;
-    sScr[16 + 2] = USTOKES; sScr[16 + 3] = VSTOKES;
+    sScr[16 + 2] = USTOKES; sScr[16 + 3] = VSTOKES; sScr[16 + 4] = STRNMS;
     sScr[16 + 5] = TAUXD; sScr[16 + 6] = TAUYD; sScr[16 + 7] = TAUOCXD; sScr[16 + 8] = TAUOCYD; sScr[16 + 9] = TAUOC;
-    sScr[16 + 10] = T(0); sScr[16 + 11] = T(0); sScr[16 + 12] = PHIOCD; sScr[16 + 13] = PHIEPS; sScr[16 + 14] = PHIAW;
+    sScr[16 + 10] = TAUICX; sScr[16 + 11] = TAUICY; sScr[16 + 12] = PHIOCD; sScr[16 + 13] = PHIEPS; sScr[16 + 14] = PHIAW;
     if (valid) mij_out[ij] = MIJ;
   }
   WSYNC();
@@ -1583,7 +1683,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
     if (L.lane < ECWAM_HIP_NINTF) {
       const int i = L.lane;
       const bool fluxes = tb.LCFLX && (i >= 5 && i <= 14);
-      if (i == 2 || i == 3 || fluxes) intfa[(size_t)ij * ECWAM_HIP_NINTF + i] = sScr[16 + i];
+      if (i == 2 || i == 3 || fluxes || (i == 4 && (RARE && tb.LWNEMOCOUSTRN))) intfa[(size_t)ij * ECWAM_HIP_NINTF + i] = sScr[16 + i];
       if (tb.LWFLUX && (i == 0 || i == 1)) {
         const T v = (i == 0) ? ((EMEANWS < tb.WSEMEAN_MIN) ? tb.WSEMEAN_MIN : EMEANWS)
                              : ((EMEANWS < tb.WSEMEAN_MIN) ? T(2) * tb.FR[NFRE - 1] : FMEANWS);

@@ -34,6 +34,8 @@ _PARAM_LAYOUT = (
                                   "zalpwrs", "bathymax", "wspmin", "wspmin_reset_tauw", "cdis", "delta_sdis", "cdisvis"]]
     + [("idamping", C.c_int)]
     + [(n, C.c_double) for n in ["cdicwa", "zalpfacb", "zalpfacx"]]
+    + [("lwnemocouibr", C.c_int), ("zibrw_thrsh", C.c_double), ("nict", C.c_int), ("nich", C.c_int)]
+    + [(n, C.c_double) for n in ["ticmin", "dtic", "dhic", "hicmin"]]
     + [("mfrstlw", C.c_int), ("mlsthg", C.c_int), ("kfrh", C.c_int), ("dal1", C.c_double), ("dal2", C.c_double),
        ("nwav_gc", C.c_int), ("xlogkratiom1_gc", C.c_double), ("sqrtgosurft", C.c_double)]
 )
@@ -46,7 +48,7 @@ class Params(C.Structure):
 _TABLE_NAMES = ["fr", "dfim", "dfimofr", "dfimfr", "dfim_sim", "rhowg_dfim", "zpifr", "fr5", "cofrm4", "flmax", "th", "costh",
                 "sinth", "wtauhf", "swellft", "ikp", "ikp1", "ikm", "ikm1", "af11", "k1w", "k2w", "k11w", "k21w", "inlcoef",
                 "rnlcoef", "indicessat", "satweights", "kpm", "jxo", "jyo", "kcr", "xk_gc", "xkm_gc", "omega_gc", "omxkm3_gc",
-                "cm_gc", "c2osqrtvg_gc", "xkmsqrtvgoc2_gc", "om3gmkm_gc", "delkcc_gc_ns", "delkcc_omxkm3_gc"]
+                "cm_gc", "c2osqrtvg_gc", "xkmsqrtvgoc2_gc", "om3gmkm_gc", "delkcc_gc_ns", "delkcc_omxkm3_gc", "cideac"]
 _INT_TABLES = {"ikp", "ikp1", "ikm", "ikm1", "k1w", "k2w", "k11w", "k21w", "inlcoef", "indicessat", "kpm", "jxo", "jyo", "kcr"}
 
 

@@ -25,6 +25,8 @@ from __future__ import annotations
 
 import dataclasses
 
+import os
+
 import numpy as np
 
 JTOT_TAUHF = 19  # yowcoup.F90:60
@@ -70,6 +72,10 @@ class Config:
     lwnemocousend: bool = True     # mpuserin.F90:721-723
     lwnemocoustk: bool = True
     lwnemocoustrn: bool = False
+    zalpfacb: float = 1.0          # mpuserin.F90:780-786 (namelist NALINE)
+    zalpfacx: float = 1.0
+    zalpwrs: float = 1.0
+    zibrw_thrsh: float = 0.5
     wspmin: float = -1.0
     rnu: float = 1.5e-5            # runwam.F90:232
     rnum: float = 0.11 * 1.5e-5    # runwam.F90:233
@@ -83,14 +89,13 @@ class Config:
             raise ValueError("IREFRA must be 0 (none), 1 (depth), 2 (currents) or 3 (depth + currents)")
         if self.icode != 3:
             raise NotImplementedError("only ICODE=3 (10 m wind forcing) is supported")
-        if self.lwnemocouwrs or self.lwnemocoustrn:
-            raise NotImplementedError("wave radiative stress on ice (SLICE) and CIMSSTRN are 'next' rows (SURVEY.md 8f)")
-        if self.lciwa1 or self.lwnemocouibr:
-            raise NotImplementedError("SDICE1 (scattering table CIDEAC) and the ice break-up coupling are 'next' rows (SURVEY.md 8f)")
         if self.nfre_red <= 0:
             self.nfre_red = self.nfre
         if not (8 <= self.nfre <= 48 and 4 <= self.nang <= 48 and self.nfre_red <= self.nfre):
             raise ValueError("spectral dimensions out of the supported range")
+
+
+CIDEAC_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "cideac_kohout_meylan.txt")
 
 
 def powi(x, n: int):
@@ -252,7 +257,8 @@ class Tables:
         else:
             self.CITHRSH, self.CIBLOCK, self.CITHRSH_TAIL = T(1.0), T(1.0), T(0.1)
             self.CDICWA = T(0.01) if c.lciwa2 else T(0.0)          # ice-water drag coefficient, userin.F90:971-977
-        self.ZALPWRS, self.ZALPFACB, self.ZALPFACX = T(1.0), T(1.0), T(1.0)   # mpuserin.F90:780-782
+        self.ZALPWRS, self.ZALPFACB, self.ZALPFACX, self.ZIBRW_THRSH = T(c.zalpwrs), T(c.zalpfacb), T(c.zalpfacx), T(c.zibrw_thrsh)
+        self._cigetdeac()
         self.GAM_B_J, self.BATHYMAX, self.WSPMIN_RESET_TAUW = T(0.8), T(998.999), T(4.0)
         self._swellft()
         self._nlweigt()
@@ -261,6 +267,27 @@ class Tables:
         self._ctu_selectors()
 
     # tabu_swellft.F90: friction factor table over log10(a/z0); Kelvin functions ker/kei
+    def _cigetdeac(self) -> None:
+        """cigetdeac.F90:64-82,553-559: SDICE1's table of ln(attenuation per floe), CIDEAC(IT,IH), period TICMIN+(IT-1)*DTIC,
+        thickness HICMIN+(IH-1)*DHIC.  Periods 6..16 s are tabulated data (ecwam_amd/data/), period 1 s is an assumed linear
+        ramp -2 .. -1 over the thickness range, periods 2..5 s are interpolated between the two.  Stored [IH][IT]."""
+        T = self.dtype.type if hasattr(self.dtype, "type") else self.dtype
+        self.NICH, self.NICT = 36, 16
+        self.DHIC, self.TICMIN, self.DTIC, self.HICMIN = T(0.1), T(1.0), T(1.0), T(0.2)
+        raw = np.loadtxt(CIDEAC_DATA)
+        assert raw.shape == (self.NICH, 11)
+        c = np.zeros((self.NICT, self.NICH), dtype=T)
+        c[5:16, :] = raw.T.astype(T)
+        c[0, 0], c[0, self.NICH - 1] = T(-2.0), T(-1.0)
+        dhi = c[0, self.NICH - 1] - c[0, 0]
+        for ih in range(2, self.NICH):
+            c[0, ih - 1] = c[0, 0] + T(ih - 1) * dhi / T(self.NICH - 1)
+        for ih in range(self.NICH):
+            dci = c[5, ih] - c[0, ih]
+            for it in range(2, 6):
+                c[it - 1, ih] = c[0, ih] + dci * T(it - 1) * self.DTIC / (T(5) * self.DTIC)
+        self.CIDEAC = np.ascontiguousarray(c.T)          # [IH][IT] = Fortran storage order of CIDEAC(IT,IH)
+
     def _swellft(self) -> None:
         from scipy.special import kei, ker
 

@@ -77,6 +77,12 @@ typedef struct ecwam_hip_params {
   double x0tauhf, eps1, flmin, cithrsh, ciblock, cithrsh_tail, zalpwrs, bathymax, wspmin, wspmin_reset_tauw;
   double cdis, delta_sdis, cdisvis; int idamping; /* YOWPHYS / YOWSTAT: IPHYS=0 dissipation and swell damping switch */
   double cdicwa, zalpfacb, zalpfacx; /* YOWICE: SDICE2 drag coefficient, attenuation scale factors (sdice2.F90, implsch.F90:195) */
+  /* YOWICE / YOWCOUP: ice break-up coupling (icebreak_modify_attenuation.F90) and the SDICE1 scattering table geometry
+   * (cigetdeac.F90:64-71, yowice.F90:23) */
+  int lwnemocouibr;
+  double zibrw_thrsh;
+  int nict, nich;
+  double ticmin, dtic, dhic, hicmin;
   /* YOWINDN scalars */
   int mfrstlw, mlsthg, kfrh;
   double dal1, dal2;
@@ -103,6 +109,7 @@ typedef struct ecwam_hip_tables {
   const int *kpm, *jxo, *jyo, *kcr;                                                                   /* [NANG][3],[2],[2],[4] (yowubuf) */
   const void *xk_gc, *xkm_gc, *omega_gc, *omxkm3_gc, *cm_gc, *c2osqrtvg_gc, *xkmsqrtvgoc2_gc, *om3gmkm_gc, *delkcc_gc_ns,
       *delkcc_omxkm3_gc;                                                                              /* [NWAV_GC] */
+  const void *cideac;                                                                                 /* [NICH][NICT] = CIDEAC(IT,IH) (yowice); may be NULL unless LCIWA1 */
 } ecwam_hip_tables;
 
 typedef struct ecwam_hip_ctx ecwam_hip_ctx;
@@ -202,6 +209,7 @@ int ecwam_hip_propags2_refra(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n
 /*
  * IMPLSCH (implsch.F90:10-23) for local points [kijs,kijl) on device pointers (layouts above).
  *   fl1 inout, wvprpt in, ff inout, intf inout, mij out (1-based), xllws out
+ *   intf[ij][15] (the spare slot of the 16-wide row) carries the INPUT ENVIRONMENT%IBRMEM when LWNEMOCOUIBR
  *   wam2nemo: double[npts][13] inout, the WAVE2OCEAN members (always JWRO = double, yowdrvtype_config.yml:44-55) in the order
  *             NEMOUSTOKES NEMOVSTOKES NEMOSTRN NPHIEPS NTAUOC NSWH NMWP NEMOTAUX NEMOTAUY NEMOTAUICX NEMOTAUICY NEMOWSWAVE
  *             NEMOPHIF; updated as wnfluxes.F90:304-328 (LNUPD = T) and stokestrn.F90:75-88 do; required when LWNEMOCOU,

@@ -108,6 +108,8 @@ typedef struct {
   int lwnemocouwrs, lwnemocouibr, lwnemotauoc, lwnemocousend, lwnemocoustk;
   double wspmin;   /* set by ora_init from llgcbz0 unless > 0 */
   double rnu, rnum; /* air viscosity (runwam.F90:232-233) */
+  int lwnemocoustrn;
+  double zalpfacb, zalpfacx, zalpwrs, zibrw_thrsh; /* mpuserin.F90:780-786 */
 } ora_cfg;
 
 /* module-level state (YOWFRED, YOWPHYS, YOWINDN, YOWPCONS, YOWCOUP, YOWICE, YOWTABL, YOWUBUF selectors) */
@@ -149,7 +151,10 @@ typedef struct {
   /* YOWTABL */
   real EPS1, SWELLFT[ORA_IAB + 1]; /* 1-based like the reference */
   /* YOWICE / YOWSHAL / YOWWIND */
-  real FLMIN, CITHRSH, CIBLOCK, CITHRSH_TAIL, CDICWA, ZALPFACX, ZALPFACB, ZALPWRS;
+  real FLMIN, CITHRSH, CIBLOCK, CITHRSH_TAIL, CDICWA, ZALPFACX, ZALPFACB, ZALPWRS, ZIBRW_THRSH;
+  /* SDICE1 table (cigetdeac.F90): CIDEAC[IT-1][IH-1] */
+  int NICT, NICH;
+  real TICMIN, DTIC, DHIC, HICMIN, CIDEAC[16][36];
   real CDIS, DELTA_SDIS, CDISVIS; /* IPHYS = 0 dissipation (sdissip_jan.F90) */
   int IDAMPING;
   real GAM_B_J, BATHYMAX, WSPMIN, WSPMIN_RESET_TAUW;

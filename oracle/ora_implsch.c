@@ -19,6 +19,7 @@ typedef struct {
   real AIRD, WDWAVE, CICOVER, WSWAVE, WSTAR, USTRA, VSTRA;
   real UFRIC, TAUW, TAUWDIR, Z0M, Z0B, CHRNCK, CITHICK;
   /* inout integrated fields */
+  real IBRMEM; /* ENVIRONMENT%IBRMEM (in) */
   real WSEMEAN, WSFMEAN, USTOKES, VSTOKES, STRNMS;
   real TAUXD, TAUYD, TAUOCXD, TAUOCYD, TAUOC, TAUICX, TAUICY, PHIOCD, PHIEPS, PHIAW;
   /* NEMO (JWRO = double) */
@@ -1131,30 +1132,86 @@ static void sdiwbk(const real *FL1, real *FLD, real *SL, real DEPTH, real EMAXDP
   }
 }
 
-/* sdice2.F90:97-121: attenuation by ice-water drag (SLICE only feeds WNFLUXES under LWNEMOCOUWRS and is not kept) */
-static void sdice2(const real *FL1, real *FLD, real *SL, const real *WAVNUM, const real *CGROUP, real CICV) {
+/* sdice1.F90:104-185: scattering attenuation (Kohout & Meylan table CIDEAC, floe-size distribution of Dumont et al. 2011).
+ * Every SDICEn overwrites the whole of SLICE (INTENT(OUT)): the last active one is what WNFLUXES sees. */
+static void sdice1(const real *FL1, real *FLD, real *SL, real *SLICE, const real *CGROUP, real CICV, real CITH) {
   const int NANG = S.NANG, NFRE = S.NFRE;
+  const real DELT5 = (real)S.c.ximp * (real)S.c.idelt;
+  const real CIFRGL = C_(0.955), CIDMIN = C_(20.0), CIFRGMT = C_(2.0), A = C_(200.0), C = C_(300.0);
+  const int MAXICM = (int)(LOG(A / CIDMIN) / LOG(CIFRGMT));
+  real DINV;
+  if (CITH > C_(0.0)) {
+    real CIDMAX = A + C * CICV;
+    int ICM = (int)(LOG(CIDMAX / CIDMIN) / LOG(CIFRGMT));
+    if (ICM > MAXICM) ICM = MAXICM;
+    real SN = C_(0.0), SD = C_(0.0);
+    for (int I = 0; I <= ICM; I++) {
+      real X = powi(powi(CIFRGMT, 2) * CIFRGL, I);
+      SN = SN + X * CIDMAX / powi(CIFRGMT, I);
+      SD = SD + X;
+    }
+    DINV = C_(1.0) / (SN / SD);
+  } else DINV = CIDMIN;
+  for (int M = 0; M < NFRE; M++) {
+    real ALP = C_(0.0);
+    if (CITH > C_(0.0)) {
+      real TW = C_(1.0) / S.FR[M];
+      int IT = FLOORI((TW - S.TICMIN) / S.DTIC + 1);
+      IT = IT < 1 ? 1 : (IT > S.NICT ? S.NICT : IT);
+      int IT1 = IT + 1 > S.NICT ? S.NICT : IT + 1;
+      real WT1 = RMAX(RMIN(C_(1.0), (TW - (S.TICMIN + (IT - 1) * S.DTIC)) / S.DTIC), C_(0.0));
+      real WT = C_(1.0) - WT1;
+      int IH = FLOORI((CITH - S.HICMIN) / S.DHIC + 1);
+      IH = IH < 1 ? 1 : (IH > S.NICH ? S.NICH : IH);
+      int IH1 = IH + 1 > S.NICH ? S.NICH : IH + 1;
+      real WH1 = RMAX(RMIN(C_(1.), (CITH - (S.HICMIN + (IH - 1) * S.DHIC)) / S.DHIC), C_(0.0));
+      real WH = C_(1.0) - WH1;
+      real CI = WT * (WH * S.CIDEAC[IT - 1][IH - 1] + WH1 * S.CIDEAC[IT - 1][IH1 - 1]) +
+                WT1 * (WH * S.CIDEAC[IT1 - 1][IH - 1] + WH1 * S.CIDEAC[IT1 - 1][IH1 - 1]);
+      ALP = EXP(CI) * DINV * S.ZALPFACB;
+    }
+    for (int K = 0; K < NANG; K++) {
+      real FLDICE = -ALP * CGROUP[M];
+      X3(SLICE, K, M) = F(K, M) * FLDICE;
+      X3(SL, K, M) = X3(SL, K, M) + CICV * X3(SLICE, K, M);
+      X3(FLD, K, M) = X3(FLD, K, M) + CICV * FLDICE;
+      real GTEMP1 = RMAX((C_(1.0) - DELT5 * FLDICE), C_(1.0));
+      X3(SLICE, K, M) = X3(SLICE, K, M) / GTEMP1;
+    }
+  }
+}
+/* sdice2.F90:97-121: attenuation by ice-water drag */
+static void sdice2(const real *FL1, real *FLD, real *SL, real *SLICE, const real *WAVNUM, const real *CGROUP, real CICV) {
+  const int NANG = S.NANG, NFRE = S.NFRE;
+  const real DELT5 = (real)S.c.ximp * (real)S.c.idelt;
   for (int M = 0; M < NFRE; M++)
     for (int K = 0; K < NANG; K++) {
       real EWH = C_(4.0) * SQRT(RMAX(S.EPSMIN, F(K, M) * S.DFIM[M]));
       real XK2 = WAVNUM[M] * WAVNUM[M];
       real ALP = S.CDICWA * XK2 * EWH * S.ZALPFACB;
       real FLDICE = -ALP * CGROUP[M];
-      real SLICE = F(K, M) * FLDICE;
-      X3(SL, K, M) = X3(SL, K, M) + CICV * SLICE;
+      X3(SLICE, K, M) = F(K, M) * FLDICE;
+      X3(SL, K, M) = X3(SL, K, M) + CICV * X3(SLICE, K, M);
       X3(FLD, K, M) = X3(FLD, K, M) + CICV * FLDICE;
+      real GTEMP1 = RMAX((C_(1.0) - DELT5 * FLDICE), C_(1.0));
+      X3(SLICE, K, M) = X3(SLICE, K, M) / GTEMP1;
     }
 }
 /* sdice3.F90:103-160, IMODEL = 2 (Yu, Rogers & Wang 2022): viscous attenuation ~ CITH**1.25 FR**4.5 */
-static void sdice3(const real *FL1, real *FLD, real *SL, const real *CGROUP, real CICV, real CITH, real ALPFAC) {
+static void sdice3(const real *FL1, real *FLD, real *SL, real *SLICE, const real *CGROUP, real CICV, real CITH, real ALPFAC) {
   const int NANG = S.NANG, NFRE = S.NFRE;
+  const real DELT5 = (real)S.c.ximp * (real)S.c.idelt;
   real CDICE = C_(0.1274) * POW(S.ZPI / SQRT(S.G), C_(4.5));
   for (int M = 0; M < NFRE; M++) {
     real ALP = (C_(2.0) * CDICE * POW(CITH, C_(1.25)) * POW(S.FR[M], C_(4.5))) * ALPFAC;
     for (int K = 0; K < NANG; K++) {
+      real FLDICE = -ALP * CGROUP[M];
+      X3(SLICE, K, M) = F(K, M) * FLDICE;
       real TEMP = -CICV * ALP * CGROUP[M];
       X3(SL, K, M) = X3(SL, K, M) + F(K, M) * TEMP;
       X3(FLD, K, M) = X3(FLD, K, M) + TEMP;
+      real GTEMP1 = RMAX((C_(1.0) - DELT5 * FLDICE), C_(1.0));
+      X3(SLICE, K, M) = X3(SLICE, K, M) / GTEMP1;
     }
   }
 }
@@ -1177,8 +1234,8 @@ static void sbottom(const real *FL1, real *FLD, real *SL, const real *WAVNUM, re
   }
 }
 
-/* wnfluxes.F90:147-330 (SLICE contributions only under LWNEMOCOUWRS, with SLICE = 0 as set in implsch.F90:205-213) */
-static void wnfluxes(point_t *p, const real *RHOWGDFTH, const real *SSURF, real PHIWA, real EM, real F1, int LNUPD) {
+/* wnfluxes.F90:147-330 */
+static void wnfluxes(point_t *p, const real *RHOWGDFTH, const real *SSURF, const real *SLICE, real PHIWA, real EM, real F1, int LNUPD) {
   const int NANG = S.NANG, NFRE = S.NFRE;
   const real PHIOC_ICE = C_(-3.75), PHIAW_ICE = C_(3.75);
   const real C1 = C_(1.03E-3), C2 = C_(0.04E-3), P1 = C_(1.48), P2 = C_(-0.21), CDMAX_LOC = C_(0.003);
@@ -1195,11 +1252,11 @@ static void wnfluxes(point_t *p, const real *RHOWGDFTH, const real *SSURF, real 
   PHILF = C_(0.0); XSTRESS = C_(0.0); YSTRESS = C_(0.0); XSTRESSICE = C_(0.0); YSTRESSICE = C_(0.0);
   if (S.c.lwnemocouwrs) {
     for (int M = 0; M < NFRE; M++) {
-      SUMXICE = S.SINTH[0] * RMIN(C_(0.0), -EPSMIN1000);
-      SUMYICE = S.COSTH[0] * RMIN(C_(0.0), -EPSMIN1000);
+      SUMXICE = S.SINTH[0] * RMIN(X3(SLICE, 0, M), -EPSMIN1000);
+      SUMYICE = S.COSTH[0] * RMIN(X3(SLICE, 0, M), -EPSMIN1000);
       for (int K = 1; K < NANG; K++) {
-        SUMXICE = SUMXICE + S.SINTH[K] * RMIN(C_(0.0), -EPSMIN1000);
-        SUMYICE = SUMYICE + S.COSTH[K] * RMIN(C_(0.0), -EPSMIN1000);
+        SUMXICE = SUMXICE + S.SINTH[K] * RMIN(X3(SLICE, K, M), -EPSMIN1000);
+        SUMYICE = SUMYICE + S.COSTH[K] * RMIN(X3(SLICE, K, M), -EPSMIN1000);
       }
       XSTRESSICE = XSTRESSICE + S.ZALPWRS * SUMXICE * p->CINV[M] * S.RHOWG_DFIM[M];
       YSTRESSICE = YSTRESSICE + S.ZALPWRS * SUMYICE * p->CINV[M] * S.RHOWG_DFIM[M];
@@ -1327,15 +1384,49 @@ static void stokesdrift(const real *FL1, const real *STOKFAC, real WSWAVE, real 
 }
 
 /* implsch.F90:183-463 for one point. Returns nonzero on an abort branch. */
+/* aki_ice.F90:60-112: wave number under an elastic ice sheet (Fox & Squire 1991), Newton iteration */
+static real aki_ice(real G, real XK, real DEPTH, real RHOW, real CITH) {
+  const real YMICE = C_(5.5E+9), RMUICE = C_(0.3), RHOI = C_(922.5), EBS = C_(0.000001), AKI_MAX = C_(20.0);
+  if (CITH <= C_(0.0)) return XK;
+  real FICSTF = (YMICE * powi(CITH, 3) / (12 * (1 - powi(RMUICE, 2)))) / RHOW;
+  real RDH = (RHOI / RHOW) * CITH;
+  real OM2 = G * XK * TANH(XK * DEPTH);
+  real AKIOLD = C_(0.0);
+  real AKI = RMIN(XK, POW(OM2 / RMAX(FICSTF, C_(1.0)), C_(0.2)));
+  while (FABS(AKI - AKIOLD) > EBS * AKIOLD && AKI < AKI_MAX) {
+    AKIOLD = AKI;
+    real AKID = RMIN(DEPTH * AKI, C_(50.0));
+    real Fv = FICSTF * powi(AKI, 5) + G * AKI - OM2 * (RDH * AKI + C_(1.) / TANH(AKID));
+    real FPRIME = C_(5.) * FICSTF * powi(AKI, 4) + G - OM2 * (RDH - DEPTH / powi(SINH(AKID), 2));
+    AKI = AKI - Fv / FPRIME;
+    if (AKI <= C_(0.0)) AKI = AKI_MAX;
+  }
+  return AKI;
+}
+/* cimsstrn.F90:86-118: mean square wave strain in the sea ice */
+static real cimsstrn(const real *FL1, const real *WAVNUM, real DEPTH, real CITHICK) {
+  const int NANG = S.NANG, NFRE = S.NFRE;
+  const real F1LIM = S.FLMIN / S.DELTH;
+  real STRN = C_(0.0);
+  for (int M = 0; M < NFRE; M++) {
+    real XKI = aki_ice(S.G, WAVNUM[M], DEPTH, S.ROWATER, CITHICK);
+    real E = C_(0.5) * CITHICK * powi(XKI, 3) / WAVNUM[M];
+    real SUME = C_(0.0);
+    for (int K = 0; K < NANG; K++) SUME = SUME + F(K, M);
+    if (SUME > F1LIM) STRN = STRN + powi(E, 2) * SUME * S.DFIM[M];
+  }
+  return STRN;
+}
+
 static int implsch_point(real *FL1, real *XLLWS, point_t *p, real *dbg) {
   const int NANG = S.NANG, NFRE = S.NFRE;
-  static __thread real FLD[NA * NF], SL[NA * NF], SPOS[NA * NF], SSOURCE[NA * NF];
+  static __thread real FLD[NA * NF], SL[NA * NF], SPOS[NA * NF], SSOURCE[NA * NF], SLICE[NA * NF];
   real DELT, DELTM, DELT5, GTEMP1, GTEMP2, FLHAB, RAORW, EMEAN, FMEAN, HALP = 0, EMEANWS, FMEANWS, USFM;
   real F1MEAN, AKMEAN, XKMEAN, PHIWA;
   real FLM[NA], COSWDIF[NA], SINWDIF2[NA], TEMP[NF], RHOWGDFTH[NF], DELFL[NF];
   int LCFLX;
   if (S.c.isnonlin < 0 || S.c.isnonlin > 2) return 2;
-  if (S.c.lciwa1 || S.c.lwnemocouibr) return 2; /* SDICE1 (CIDEAC scattering table) and the ice break-up coupling: not restated */
+  if (S.c.lciwa1 && S.NICT == 0) return 2; /* SDICE1 needs ora_set_cideac */
 
   DELT = (real)S.c.idelt;
   DELTM = C_(1.0) / DELT;
@@ -1347,6 +1438,8 @@ static int implsch_point(real *FL1, real *XLLWS, point_t *p, real *dbg) {
     real s = SIN(S.TH[K] - p->WDWAVE);
     SINWDIF2[K] = s * s;
   }
+  if (S.c.lwnemocouwrs) /* implsch.F90:205-213 (the SDICEn overwrite it when active) */
+    for (int i = 0; i < NANG * NFRE; i++) SLICE[i] = C_(0.0);
   if (S.c.lbiwbk) sdepthlim(p->EMAXDPT, FL1);
   fkmean(FL1, p->WAVNUM, &EMEAN, &FMEAN, &F1MEAN, &AKMEAN, &XKMEAN);
   for (int K = 0; K < NANG; K++) {
@@ -1374,9 +1467,12 @@ static int implsch_point(real *FL1, real *XLLWS, point_t *p, real *dbg) {
       real BETA = C_(1.0) - p->CICOVER;
       for (int i = 0; i < NANG * NFRE; i++) { SL[i] = BETA * SL[i]; FLD[i] = BETA * FLD[i]; }
     }
-    /* LWNEMOCOUIBR = F: ALPFAC keeps ZALPFACX (implsch.F90:195) */
-    if (S.c.lciwa2) sdice2(FL1, FLD, SL, p->WAVNUM, p->CGROUP, p->CICOVER);
-    if (S.c.lciwa3) sdice3(FL1, FLD, SL, p->CGROUP, p->CICOVER, p->CITHICK, S.ZALPFACX);
+    real ALPFAC = S.ZALPFACX; /* implsch.F90:195 */
+    /* icebreak_modify_attenuation.F90:82-93: broken ice attenuates less */
+    if (S.c.lwnemocouibr && p->IBRMEM <= S.ZIBRW_THRSH) ALPFAC = C_(1.0) / S.ZALPFACX;
+    if (S.c.lciwa1) sdice1(FL1, FLD, SL, SLICE, p->CGROUP, p->CICOVER, p->CITHICK);
+    if (S.c.lciwa2) sdice2(FL1, FLD, SL, SLICE, p->WAVNUM, p->CGROUP, p->CICOVER);
+    if (S.c.lciwa3) sdice3(FL1, FLD, SL, SLICE, p->CGROUP, p->CICOVER, p->CITHICK, ALPFAC);
   }
   sbottom(FL1, FLD, SL, p->WAVNUM, p->DEPTH);
 
@@ -1395,7 +1491,7 @@ static int implsch_point(real *FL1, real *XLLWS, point_t *p, real *dbg) {
       X3(SSOURCE, K, M) = X3(SSOURCE, K, M) + DELTM * RMIN(S.FLMAX[M] - F(K, M), C_(0.0));
       F(K, M) = RMIN(F(K, M), S.FLMAX[M]);
     }
-  if (LCFLX) wnfluxes(p, RHOWGDFTH, SSOURCE, PHIWA, EMEAN, F1MEAN, 1);
+  if (LCFLX) wnfluxes(p, RHOWGDFTH, SSOURCE, SLICE, PHIWA, EMEAN, F1MEAN, 1);
 
   fkmean(FL1, p->WAVNUM, &EMEAN, &FMEAN, &F1MEAN, &AKMEAN, &XKMEAN);
   femeanws(FL1, XLLWS, &FMEANWS, &EMEANWS);
@@ -1406,10 +1502,12 @@ static int implsch_point(real *FL1, real *XLLWS, point_t *p, real *dbg) {
   }
   if (S.c.licerun && S.c.lmaskice) setice(FL1, p->CICOVER, COSWDIF);
   stokesdrift(FL1, p->STOKFAC, p->WSWAVE, p->WDWAVE, p->CICOVER, &p->USTOKES, &p->VSTOKES);
+  if (S.c.lwnemocoustrn) p->STRNMS = cimsstrn(FL1, p->WAVNUM, p->DEPTH, p->CITHICK); /* stokestrn.F90:69-71 */
   /* stokestrn.F90:77-89: NEMO copies only when LWNEMOCOU */
   if (S.c.lwnemocou && ((S.c.lwnemocousend && S.c.lwcou) || !S.c.lwcou)) {
     if (S.c.lwnemocoustk) { p->NEMOUSTOKES = p->USTOKES; p->NEMOVSTOKES = p->VSTOKES; }
     else { p->NEMOUSTOKES = 0.0; p->NEMOVSTOKES = 0.0; }
+    if (S.c.lwnemocoustrn) p->NEMOSTRN = p->STRNMS;
   }
   return 0;
 }
@@ -1429,6 +1527,10 @@ int ora_implsch(int n, real *FL1, const real *WAVNUM, const real *CGROUP, const 
                 const real *STOKFAC, const real *ENV, real *FF, real *INTF, int *MIJ, real *XLLWS, real *DBG) {
   return ora_implsch_w2n(n, FL1, WAVNUM, CGROUP, CINV, XK2CG, STOKFAC, ENV, FF, INTF, MIJ, XLLWS, DBG, NULL);
 }
+/* ENVIRONMENT%IBRMEM of the next ora_implsch* call (NULL: 1 = solid ice everywhere) */
+static const real *g_ibrmem = NULL;
+void ora_set_ibrmem(const real *ibrmem) { g_ibrmem = ibrmem; }
+
 int ora_implsch_w2n(int n, real *FL1, const real *WAVNUM, const real *CGROUP, const real *CINV, const real *XK2CG,
                     const real *STOKFAC, const real *ENV, real *FF, real *INTF, int *MIJ, real *XLLWS, real *DBG, double *W2N) {
   const int NANG = S.NANG, NFRE = S.NFRE;
@@ -1440,6 +1542,7 @@ int ora_implsch_w2n(int n, real *FL1, const real *WAVNUM, const real *CGROUP, co
     p.WAVNUM = WAVNUM + (size_t)ij * NFRE; p.CGROUP = CGROUP + (size_t)ij * NFRE; p.CINV = CINV + (size_t)ij * NFRE;
     p.XK2CG = XK2CG + (size_t)ij * NFRE; p.STOKFAC = STOKFAC + (size_t)ij * NFRE;
     p.EMAXDPT = ENV[ij * 2]; p.DEPTH = ENV[ij * 2 + 1];
+    p.IBRMEM = g_ibrmem ? g_ibrmem[ij] : C_(1.0);
     real *ff = FF + (size_t)ij * 14, *it = INTF + (size_t)ij * 15;
     p.AIRD = ff[0]; p.WDWAVE = ff[1]; p.CICOVER = ff[2]; p.WSWAVE = ff[3]; p.WSTAR = ff[4]; p.USTRA = ff[5]; p.VSTRA = ff[6];
     p.UFRIC = ff[7]; p.TAUW = ff[8]; p.TAUWDIR = ff[9]; p.Z0M = ff[10]; p.Z0B = ff[11]; p.CHRNCK = ff[12]; p.CITHICK = ff[13];

@@ -24,6 +24,7 @@ void ora_default_cfg(ora_cfg *c) {
   c->lwvflx_snl = 1; c->lwflux = 0; c->lwfluxout = 1; c->lwnemocou = 0; c->lwcou = 0; c->lwcouast = 1;
   c->lwnemocouwrs = 0; c->lwnemocouibr = 0; c->lwnemotauoc = 0; c->lwnemocousend = 1; c->lwnemocoustk = 1;
   c->wspmin = -1.0;
+  c->lwnemocoustrn = 0; c->zalpfacb = 1.0; c->zalpfacx = 1.0; c->zalpwrs = 1.0; c->zibrw_thrsh = 0.5; /* mpuserin.F90:780-786 */
   c->rnu = 1.5E-5; c->rnum = 0.11 * 1.5E-5;
 }
 
@@ -590,7 +591,7 @@ int ora_init(const ora_cfg *c) {
   S.FLMIN = C_(0.00001);
   if (c->lmaskice) { S.CITHRSH = C_(0.3); S.CIBLOCK = C_(0.0); S.CITHRSH_TAIL = S.CITHRSH; S.CDICWA = C_(0.0); }
   else { S.CITHRSH = C_(1.0); S.CIBLOCK = C_(1.0); S.CITHRSH_TAIL = C_(0.1); S.CDICWA = c->lciwa2 ? C_(0.01) : C_(0.0); } /* userin.F90:971-977 */
-  S.ZALPFACX = C_(1.0); S.ZALPFACB = C_(1.0); S.ZALPWRS = C_(1.0);                                          /* mpuserin.F90:780-782 */
+  S.ZALPFACX = (real)S.c.zalpfacx; S.ZALPFACB = (real)S.c.zalpfacb; S.ZALPWRS = (real)S.c.zalpwrs; S.ZIBRW_THRSH = (real)S.c.zibrw_thrsh;
   S.GAM_B_J = C_(0.8); S.BATHYMAX = C_(998.999); S.WSPMIN_RESET_TAUW = C_(4.0);
 
   /* ctuwupdt.F90:97-161 */
@@ -649,4 +650,22 @@ int ora_get(const char *name, double *out, int cap) {
   if (!strcmp(name, "INDICESSAT")) { int w = 2 * S.NSDSNTH + 1, n = NANG * w; for (int i = 0; i < n && i < cap; i++) out[i] = S.INDICESSAT[i / w][i % w]; return n; }
   if (!strcmp(name, "SATWEIGHTS")) { int w = 2 * S.NSDSNTH + 1, n = NANG * w; for (int i = 0; i < n && i < cap; i++) out[i] = (double)S.SATWEIGHTS[i / w][i % w]; return n; }
   return -1;
+}
+
+/* cigetdeac.F90:64-82, 553-559: the SDICE1 table from its tabulated block raw[36][11] = CIDEAC(6:16, IH) (data file of the
+ * product, ecwam_amd/data/cideac_kohout_meylan.txt, passed in by the test harness) */
+void ora_set_cideac(const double *raw) {
+  S.NICH = 36; S.DHIC = C_(0.1);
+  S.NICT = 16; S.TICMIN = C_(1.0); S.DTIC = C_(1.0);
+  S.HICMIN = C_(0.2); /* yowice.F90:23 */
+  for (int IH = 1; IH <= S.NICH; IH++)
+    for (int IT = 6; IT <= 16; IT++) S.CIDEAC[IT - 1][IH - 1] = (real)raw[(IH - 1) * 11 + (IT - 6)];
+  S.CIDEAC[0][0] = C_(-2.00);
+  S.CIDEAC[0][S.NICH - 1] = C_(-1.00);
+  real DHI = S.CIDEAC[0][S.NICH - 1] - S.CIDEAC[0][0];
+  for (int IH = 2; IH <= S.NICH - 1; IH++) S.CIDEAC[0][IH - 1] = S.CIDEAC[0][0] + (IH - 1) * DHI / (S.NICH - 1);
+  for (int IH = 1; IH <= S.NICH; IH++) {
+    real DCI = S.CIDEAC[5][IH - 1] - S.CIDEAC[0][IH - 1];
+    for (int IT = 2; IT <= 5; IT++) S.CIDEAC[IT - 1][IH - 1] = S.CIDEAC[0][IH - 1] + DCI * (IT - 1) * S.DTIC / (5 * S.DTIC);
+  }
 }

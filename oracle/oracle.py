@@ -27,6 +27,8 @@ class OraCfg(C.Structure):
         ("lwnemocouwrs", C.c_int), ("lwnemocouibr", C.c_int), ("lwnemotauoc", C.c_int), ("lwnemocousend", C.c_int),
         ("lwnemocoustk", C.c_int),
         ("wspmin", C.c_double), ("rnu", C.c_double), ("rnum", C.c_double),
+        ("lwnemocoustrn", C.c_int), ("zalpfacb", C.c_double), ("zalpfacx", C.c_double), ("zalpwrs", C.c_double),
+        ("zibrw_thrsh", C.c_double),
     ]
 
 
@@ -63,6 +65,10 @@ class Oracle:
         rc = self.lib.ora_init(C.byref(oc))
         if rc:
             raise RuntimeError(f"ora_init failed rc={rc}")
+        if getattr(cfg, "lciwa1", False):   # SDICE1's tabulated block: the product's data file (cigetdeac.F90:85-552)
+            raw = np.ascontiguousarray(np.loadtxt(os.path.join(_HERE, "..", "ecwam_amd", "data", "cideac_kohout_meylan.txt")), dtype=np.float64)
+            assert raw.shape == (36, 11)
+            self.lib.ora_set_cideac(raw.ctypes.data_as(C.c_void_p))
         self.cfg = cfg
         self.NANG, self.NFRE = cfg.nang, cfg.nfre
         self.NFRE_RED = cfg.nfre_red if cfg.nfre_red > 0 else cfg.nfre
@@ -98,10 +104,12 @@ class Oracle:
                                self._p(out["XK2CG"]), self._p(out["OMOSNH2KD"]), self._p(out["STOKFAC"]), self._p(out["EMAXDPT"]))
         return out
 
-    def implsch(self, fl1, wavnum, cgroup, cinv, xk2cg, stokfac, env, ff, intf, want_dbg=False, w2n=None):
-        """All arrays are copied; returns dict(FL1, XLLWS, MIJ, FF, INTF[, DBG])."""
+    def implsch(self, fl1, wavnum, cgroup, cinv, xk2cg, stokfac, env, ff, intf, want_dbg=False, w2n=None, ibrmem=None):
+        """All arrays are copied; returns dict(FL1, XLLWS, MIJ, FF, INTF[, DBG]).  ibrmem: ENVIRONMENT%IBRMEM [n] (LWNEMOCOUIBR)."""
         n = fl1.shape[0]
         T = self.dtype
+        ib = None if ibrmem is None else np.ascontiguousarray(ibrmem, dtype=T)
+        self.lib.ora_set_ibrmem(None if ib is None else self._p(ib))
         fl1 = np.array(fl1, dtype=T, order="C")
         ff = np.array(ff, dtype=T, order="C")
         intf = np.array(intf, dtype=T, order="C")

@@ -35,7 +35,7 @@ def make_point_case(n: int, cfg: Config, prec: str, seed: int = 12345, spectra: 
 def oracle_implsch(case: dict, oracle, want_dbg=False) -> dict:
     pr = case["props"]
     return oracle.implsch(case["FL1"], pr["WAVNUM"], pr["CGROUP"], pr["CINV"], pr["XK2CG"], pr["STOKFAC"], case["ENV"], case["FF"],
-                          case["INTF"], want_dbg=want_dbg)
+                          case["INTF"], want_dbg=want_dbg, w2n=case.get("W2N"), ibrmem=case.get("IBRMEM"))
 
 
 def pack_device_inputs(case: dict):
@@ -49,6 +49,7 @@ def pack_device_inputs(case: dict):
     ff[:, 14:16] = case["ENV"]
     intf = np.zeros((n, 16), dt)
     intf[:, :15] = case["INTF"]
+    intf[:, 15] = case.get("IBRMEM", 1.0)      # input slot: ENVIRONMENT%IBRMEM (read when LWNEMOCOUIBR)
     return wv, ff, intf
 
 
@@ -63,10 +64,13 @@ def gpu_implsch(case: dict, ctx, want_dbg=False) -> dict:
     mij = torch.zeros(n, dtype=torch.int32, device=dev)
     xllws = torch.zeros_like(fl1)
     dbg = torch.zeros((n, 32), dtype=fl1.dtype, device=dev) if want_dbg else None
-    ctx.implsch(0, n, fl1, twv, tff, tintf, mij, xllws, dbg)
+    w2n = torch.from_numpy(np.array(case["W2N"], dtype=np.float64)).to(dev) if case.get("W2N") is not None else None
+    ctx.implsch(0, n, fl1, twv, tff, tintf, mij, xllws, dbg, wam2nemo=w2n)
     torch.cuda.synchronize()
     out = dict(FL1=fl1.cpu().numpy(), XLLWS=xllws.cpu().numpy(), MIJ=mij.cpu().numpy(), FF=tff.cpu().numpy()[:, :14],
                INTF=tintf.cpu().numpy()[:, :15])
+    if w2n is not None:
+        out["W2N"] = w2n.cpu().numpy()
     if want_dbg:
         out["DBG"] = dbg.cpu().numpy()
     return out

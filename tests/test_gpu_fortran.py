@@ -26,7 +26,7 @@ def _write_case(path, m, cfg, grid, nproma, nstep):
     tp, keep = L.make_tables(t)
     with open(path, "wb") as f:
         hdr = np.array([cfg.nang, cfg.nfre, cfg.nfre_red, nproma, nchnk, n, grid.ngy, cfg.idelt, cfg.idelpro,
-                        np.dtype(dt).itemsize, nstep, ctypes.sizeof(params)], dtype=np.int32)
+                        np.dtype(dt).itemsize, nstep, ctypes.sizeof(params), len(keep)], dtype=np.int32)
         f.write(hdr.tobytes())
         f.write(bytes(params))
         for a in keep:

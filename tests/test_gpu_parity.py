@@ -127,6 +127,87 @@ def test_implsch_parity_sea_ice_attenuation(api, prec, flags):
     assert np.max(np.abs(ref0["FL1"] - ref["FL1"])) > 0
 
 
+def _ice_case(cfg, prec, n=1024, seed=21):
+    case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=seed)
+    rng = np.random.default_rng(5)
+    dt = H.np_dtype(prec)
+    case["FF"][:, 2] = np.where(rng.uniform(size=n) < 0.6, rng.uniform(0.0, 1.0, n), 0.0).astype(dt)   # CICOVER
+    cith = rng.uniform(0.0, 4.2, n)
+    cith[rng.uniform(size=n) < 0.1] = 0.0                                                             # no ice thickness: the CITH <= 0 branches
+    case["FF"][:, 13] = cith.astype(dt)                                                               # CITHICK (beyond both table ends)
+    case["IBRMEM"] = np.where(rng.uniform(size=n) < 0.5, 0.0, 1.0).astype(dt)                        # broken / solid ice
+    return case
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+@pytest.mark.parametrize("flags", [dict(lciwa1=True), dict(lciwa1=True, lciwa3=True, lciscal=True, lwnemocouibr=True, zalpfacx=2.0, zalpfacb=0.7)])
+def test_implsch_parity_sdice1_and_ice_breakup(api, prec, flags):
+    """SDICE1 (scattering attenuation from the Kohout & Meylan table CIDEAC with the floe-size distribution of Dumont et al.,
+    sdice1.F90:104-185, cigetdeac.F90) alone, and together with SDICE3 under the ice break-up coupling LWNEMOCOUIBR
+    (ALPFAC = 1/ZALPFACX where IBRMEM <= ZIBRW_THRSH, icebreak_modify_attenuation.F90:82-93)."""
+    cfg = Config(nang=24, nfre=36, nfre_red=29, **flags)
+    case = _ice_case(cfg, prec)
+    n = case["n"]
+    ref = H.oracle_implsch(case, _oracle(cfg, prec))
+    ctx = api.HipContext(case["tables"])
+    got = H.gpu_implsch(case, ctx)
+    st = H.compare_implsch(ref, got, case["tables"])
+    ctx.close()
+    assert np.isfinite(got["FL1"]).all() and np.isfinite(got["INTF"]).all()
+    if prec == "dp":
+        assert st["mij_flips"] == 0 and st["xllws_bins_diff"] == 0, st
+        assert st["fl1_max_rel_peak_all"] < 1e-10 and st["swh_max_rel"] < 1e-12, st
+        assert st["ff_max_rel_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
+    else:
+        assert st["mij_flips"] <= n * 0.005 and st["xllws_pts_diff"] <= n * 0.005, st
+        assert st["fl1_max_rel_peak_clean"] < 1e-4 and st["swh_max_rel"] < 1e-5, st
+        assert st["ff_max_rel_clean"] < 1e-4 and st["intf_max_rel_clean"] < 5e-3, st
+    # the options act: without SDICE1 / with solid ice everywhere the oracle answers differently
+    dt = H.np_dtype(prec)
+    f0 = {k: v for k, v in flags.items() if k != "lciwa1"}
+    cfg0 = Config(nang=24, nfre=36, nfre_red=29, **f0)
+    c0 = dict(case); c0["cfg"] = cfg0; c0["tables"] = Tables(cfg0, dt)
+    assert np.max(np.abs(H.oracle_implsch(c0, _oracle(cfg0, prec))["FL1"] - ref["FL1"])) > 0
+    if flags.get("lwnemocouibr"):
+        c1 = dict(case); c1["IBRMEM"] = np.ones(n, dt)
+        assert np.max(np.abs(H.oracle_implsch(c1, _oracle(cfg, prec))["FL1"] - ref["FL1"])) > 0
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+@pytest.mark.parametrize("flags", [dict(lciwa1=True, lciwa2=True, lciwa3=True, lmaskice=False), dict(lciwa1=True), dict(lciwa2=True, lmaskice=False), dict()])
+def test_ice_radiative_stress_and_strain(api, prec, flags):
+    """LWNEMOCOUWRS: TAUICX/Y = -ZALPWRS * integral of MIN(SLICE, -1000 EPSMIN) (wnfluxes.F90:178-196, 267-271), SLICE being
+    the contribution of the LAST active SDICEn (each overwrites it, sdice.F90:94-110) or zero without any (implsch.F90:205-213);
+    LWNEMOCOUSTRN: the mean square strain of CIMSSTRN with the ice-coupled wave number AKI_ICE; both copied / accumulated
+    into WAVE2OCEAN (NEMOSTRN, NEMOTAUICX/Y)."""
+    cfg = Config(nang=24, nfre=36, nfre_red=29, lwnemocou=True, lwnemocouwrs=True, lwnemocoustrn=True, zalpwrs=0.8, **flags)
+    case = _ice_case(cfg, prec, n=768, seed=33)
+    n = case["n"]
+    case["W2N"] = np.random.default_rng(2).uniform(-1.0, 1.0, (n, 13))
+    ref = H.oracle_implsch(case, _oracle(cfg, prec))
+    ctx = api.HipContext(case["tables"])
+    got = H.gpu_implsch(case, ctx)
+    ctx.close()
+    tol = 1e-10 if prec == "dp" else 2e-4
+    real_stress = any(flags.get(k) for k in ("lciwa1", "lciwa2", "lciwa3"))
+    for col in (4, 10, 11):      # STRNMS, TAUICX, TAUICY
+        r, g = ref["INTF"][:, col].astype(float), got["INTF"][:, col].astype(float)
+        if col != 4 and not real_stress:
+            # SLICE = 0: the integrand is the constant floor -1000 EPSMIN, its directional integral SUM_K sin/cos(TH(K)) is
+            # rounding noise of zero on both sides
+            assert np.abs(r).max() < 1e-20 and np.abs(g).max() < 1e-20
+            continue
+        sc = max(np.abs(r).max(), 1e-300)
+        assert np.abs(g - r).max() < tol * sc, (col, np.abs(g - r).max() / sc)
+    for col in (2, 9, 10):       # NEMOSTRN (copy), NEMOTAUICX/Y (accumulated onto the initial values)
+        r, g = ref["W2N"][:, col], got["W2N"][:, col]
+        assert np.abs(g - r).max() < tol * max(np.abs(r).max(), 1e-300), col
+    assert np.abs(ref["INTF"][:, 4]).max() > 0
+    if real_stress:
+        assert np.abs(ref["INTF"][:, 10]).max() > 1e-6                 # a real stress, not the floor
+        assert np.abs(ref["W2N"][:, 9] - case["W2N"][:, 9]).max() > 1e-6
+
+
 @pytest.mark.parametrize("prec", ["dp", "sp"])
 @pytest.mark.parametrize("llnormagam", [False, True])
 def test_implsch_parity_iphys_0(api, prec, llnormagam):

@@ -44,12 +44,13 @@ def test_create_refuses_unsupported_configurations_without_a_gpu():
     h = lib.load()
     t = Tables(Config(nang=12, nfre=36, nfre_red=25), np.float32)
     tp, keep = lib.make_tables(t)
-    cases = [(dict(lciwa1=1), "SDICE1"), (dict(iphys=2), "IPHYS"), (dict(irefra=4), "IREFRA"), (dict(lwnemocouwrs=1), "LWNEMOCOUWRS"),
+    cases = [(dict(lciwa1=1), "SDICE1"), (dict(iphys=2), "IPHYS"), (dict(irefra=4), "IREFRA"), (dict(isnonlin=3), "ISNONLIN"),
              (dict(nang=3), "NANG"), (dict(nfre_red=40), "NFRE_RED")]
     for changes, word in cases:
         p = lib.make_params(t)
         for k, v in changes.items():
             setattr(p, k, v)
+        tp.cideac = None if "lciwa1" in changes else keep[-1].ctypes.data_as(C.c_void_p)   # SDICE1 without its table is refused
         ctx = C.c_void_p()
         rc = h.ecwam_hip_create(C.byref(p), C.byref(tp), 4, 0, C.byref(ctx))
         assert rc != 0 and not ctx.value

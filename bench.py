@@ -81,15 +81,7 @@ def cpu_baseline(nang: int, nfre: int, prec: str, target_s: float = 15.0) -> dic
     cg_ext[:n] = pr["CGROUP"]
     cg_ext[n] = syn.depth_props(np.array([998.999]), t, dt)["CGROUP"][0]
     w = o.ctu_weights(g, cg_ext, float(cfg.idelpro))
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        f3 = o.propags2(g, fl, w)
-        r = o.implsch(f3[:n], pr["WAVNUM"], pr["CGROUP"], pr["CINV"], pr["XK2CG"], pr["STOKFAC"], env, ff, intf)
-        fl[:n], ff = r["FL1"], r["FF"]
-        steps += 1
-        el = time.perf_counter() - t0
-        if el > target_s or steps >= 50:
-            break
+    steps, el = o.timed_steps(g, fl, w, pr, env, ff, intf, max_steps=200, target_s=target_s)   # C calls only, arrays prepared once
     return {"value": n * steps / el, "unit": "grid-point spectral steps/s", "cores": cores, "kind": "port",
             "sample": f"O48 all-ocean grid ({n} sea points), {nang}x{nfre} spectrum, {prec}, {steps} full steps "
                       f"(PROPAGS2 + IMPLSCH), oracle/ C restatement (speed build: gcc -O3 -march=x86-64-v3) with OpenMP over points, {cores} threads "

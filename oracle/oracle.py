@@ -265,3 +265,35 @@ class Oracle:
                                   self._p(w["SUMWN"]), self._p(w["WLONN"]), self._p(w["WLATN"]), self._p(w["WCORN"]), self._p(w["WKPMN"]),
                                   self._p(w["WMPMN"]), C.c_int(nd3s), C.c_int(nd3e))
         return f3
+
+    def timed_steps(self, grid, fl, w, props, env, ff, intf, max_steps=50, target_s=15.0):
+        """bench.py's cpu_baseline leg: full steps (PROPAGS2 + IMPLSCH) in place on prepared arrays; returns (steps, seconds)
+        of the C calls alone (no Python-side copies inside the timed region)."""
+        import time
+
+        T = self.dtype
+        n = grid.nsea
+        f1 = np.ascontiguousarray(fl, dtype=T)
+        f3 = np.zeros_like(f1)
+        g = self._grid_arrays(grid)
+        a = [np.ascontiguousarray(props[k], dtype=T) for k in ("WAVNUM", "CGROUP", "CINV", "XK2CG", "STOKFAC")]
+        env = np.ascontiguousarray(env, dtype=T)
+        ff = np.array(ff, dtype=T, order="C")
+        intf = np.array(intf, dtype=T, order="C")
+        xllws = np.zeros((n, self.NANG, self.NFRE), T)
+        mij = np.zeros(n, np.int32)
+        self.lib.ora_set_ibrmem(None)
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            self.lib.ora_propags2(C.c_int(0), C.c_int(n), self._p(f1), self._p(f3), self._p(g["klon"]), self._p(g["klat"]),
+                                  self._p(g["kcor"]), self._p(w["SUMWN"]), self._p(w["WLONN"]), self._p(w["WLATN"]), self._p(w["WCORN"]),
+                                  self._p(w["WKPMN"]), C.c_int(1), C.c_int(self.NFRE_RED))
+            rc = self.lib.ora_implsch_w2n(C.c_int(n), self._p(f3), *(self._p(x) for x in a), self._p(env), self._p(ff), self._p(intf),
+                                          self._p(mij), self._p(xllws), None, None)
+            if rc:
+                raise RuntimeError(f"ora_implsch abort branch rc={rc}")
+            f1, f3 = f3, f1          # the land row of both buffers is zero
+            steps += 1
+            el = time.perf_counter() - t0
+            if el > target_s or steps >= max_steps:
+                return steps, el

@@ -101,6 +101,8 @@ def main() -> None:
     ap.add_argument("--weights", default="otf", choices=["otf", "stored"],
                     help="CTU weights rebuilt inside PROPAGS2 (default) or streamed from the stored W array")
     ap.add_argument("--strip", type=int, default=0, help="longitude-strip width of the advection work order (0: natural order)")
+    ap.add_argument("--irefra", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="refraction: 0 none (BASELINE configurations), 1 depth, 2 currents, 3 both (synthetic current field)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,7 +121,7 @@ def main() -> None:
     # time step: 450 s at O320 (the 900 s of the reference's 24-direction O320 yml violates the CTU stability criterion
     # with 36 directions near the poles of the all-ocean grid, ctuw.F90:637); scaled with the grid spacing beyond
     dt = 450 if ng <= 320 else max(15, int(450 * 320 / ng) // 15 * 15)
-    cfg = Config(nang=a.nang, nfre=a.nfre, nfre_red=a.nfre, idelt=dt, idelpro=dt)
+    cfg = Config(nang=a.nang, nfre=a.nfre, nfre_red=a.nfre, idelt=dt, idelpro=dt, irefra=a.irefra)
     grid = G.build_grid(ng)
     m = Wamintgr(cfg, grid, a.prec, device=local_rank, rank=rank, nranks=world, weights=a.weights, strip_width=a.strip)
     m.init_synthetic()
@@ -163,7 +165,9 @@ def main() -> None:
         w = 4 if a.prec == "sp" else 8
         N, NR = a.nang * a.nfre, a.nang * cfg.nfre_red
         b_impl = w * (3 * N + 5 * a.nfre + 55)          # F r+w, XLLWS w, 5 per-frequency props, ~55 scalars
-        if a.weights == "stored":
+        if a.irefra:
+            b_prop = w * (2 * NR + 3 * a.nfre + 2 * a.nang + 18) + 60   # + own OMOSNH2KD / WAVNUM rows and the REFR row
+        elif a.weights == "stored":
             b_prop = w * 10 * NR + 56                    # 8 weights + F1 + F3, 14 int32 neighbour ids
         else:
             b_prop = w * (2 * NR + a.nfre + 13) + 60     # F1 + F3 + own CGROUP row + point geometry, 15 int32 ids
@@ -177,7 +181,7 @@ def main() -> None:
         # valid for the workload they were taken on: the default O320 / 36x36 / sp / on-the-fly-weights run on one GPU.
         traffic = None
         tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic_pmc.json")
-        if world == 1 and ng == 320 and a.prec == "sp" and a.nang == 36 and a.nfre == 36 and a.weights == "otf" and os.path.exists(tf):
+        if world == 1 and ng == 320 and a.prec == "sp" and a.nang == 36 and a.nfre == 36 and a.weights == "otf" and not a.irefra and os.path.exists(tf):
             with open(tf) as fh:
                 pm = json.load(fh).get(dom, {})
             if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
@@ -201,7 +205,8 @@ def main() -> None:
             "vs_baseline": None, "dtype": "f32" if a.prec == "sp" else "f64", "data": "synthetic",
             "config": {"workload": f"O{ng} all-ocean octahedral grid, {grid.nsea} sea points, {a.nang} dir x {a.nfre} freq "
                                    f"(NFRE_RED={cfg.nfre_red}), full WAMINTGR step = PROPAGS2 advection + NEWWIND + IMPLSCH, "
-                                   f"IDELT=IDELPRO={dt} s, flag set A (IPHYS=1, ISNONLIN=0, LLGCBZ0=F, LLNORMAGAM=F)",
+                                   f"IDELT=IDELPRO={dt} s, flag set A (IPHYS=1, ISNONLIN=0, LLGCBZ0=F, LLNORMAGAM=F)"
+                                   + (f", IREFRA={a.irefra} (synthetic currents)" if a.irefra else ""),
                        "points_per_gpu": m.n, "halo_points": m.dom.nh, "parallelism": f"sea-point block x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic},

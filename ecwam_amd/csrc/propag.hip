@@ -533,13 +533,17 @@ struct CtuGenW {
 };
 template <typename T>
 __device__ __forceinline__ bool same_sign(T a, T b) { return __builtin_signbit(a) == __builtin_signbit(b); }
+// No array is indexed with a run-time value (JXO/JYO/KCR entries select through conditionals): everything stays in registers.
 template <typename T>
+__device__ __forceinline__ T sel2(int i, T a0, T a1) { return i ? a1 : a0; }
+template <typename T, bool CHECK>
 __device__ __forceinline__ bool ctu_wgen(const CtuBase<T>& b, T sink, T cosk, const CtuPoint<T>& p, T xdella, T delpro, T cmtodeg,
                                          int jx0, int jx1, int jy0, int jy1, const int* kc, bool cur, T u, T v, T dthp, T dthm,
                                          T fdp, T fdm, T fratio, CtuGenW<T>& w) {
 #pragma clang fp contract(off)
   T adxp[2], adyp[2], dxup[2], dxdw[2], dyup[2], dydw[2];
   bool fail = false;
+#pragma unroll
   for (int ic = 0; ic < 2; ic++) {
     const T cgx = b.h[ic] * sink * p.cpm1;
     const T cgy = b.hy[ic] * cosk;
@@ -557,30 +561,39 @@ __device__ __forceinline__ bool ctu_wgen(const CtuBase<T>& b, T sink, T cosk, co
     adyp[ic] = m_abs(-delpro * vrel * cmtodeg);
     dxup[ic] = su ? adxp[ic] : T(0); dxdw[ic] = su ? T(0) : adxp[ic];
     dyup[ic] = sv ? adyp[ic] : T(0); dydw[ic] = sv ? T(0) : adyp[ic];
-    if (adxp[ic] > p.zd || adyp[ic] > xdella) fail = true;
+    if (CHECK && (adxp[ic] > p.zd || adyp[ic] > xdella)) fail = true;
   }
-  const T dxx = p.zd - dxup[jx1] - dxdw[jx0];
-  const T dyy = xdella - dyup[jy1] - dydw[jy0];
-  T wgt[2];
-  wgt[jy0] = dxx * dyup[jy0] * p.ga;
-  wgt[jy1] = dxx * dydw[jy1] * p.ga;
-  for (int ic = 0; ic < 2; ic++) {
-    w.wlat[ic][0] = p.wl[ic] * wgt[ic];
-    w.wlat[ic][1] = (T(1) - p.wl[ic]) * wgt[ic];
-  }
-  w.wlon[jx0] = dyy * dxup[jx0] * p.ga;
-  w.wlon[jx1] = dyy * dxdw[jx1] * p.ga;
+  // the JXO / JYO selections (jx1 = 1 - jx0, jy1 = 1 - jy0)
+  const T dxup_0 = sel2(jx0, dxup[0], dxup[1]), dxup_1 = sel2(jx1, dxup[0], dxup[1]);   // DXUP(JXO(K,1)), DXUP(JXO(K,2))
+  const T dxdw_0 = sel2(jx0, dxdw[0], dxdw[1]), dxdw_1 = sel2(jx1, dxdw[0], dxdw[1]);
+  const T dyup_0 = sel2(jy0, dyup[0], dyup[1]), dyup_1 = sel2(jy1, dyup[0], dyup[1]);
+  const T dydw_0 = sel2(jy0, dydw[0], dydw[1]), dydw_1 = sel2(jy1, dydw[0], dydw[1]);
+  const T dxx = p.zd - dxup_1 - dxdw_0;
+  const T dyy = xdella - dyup_1 - dydw_0;
+  const T wgt_a = dxx * dyup_0 * p.ga;  // WEIGHT(JYO(K,1))
+  const T wgt_b = dxx * dydw_1 * p.ga;  // WEIGHT(JYO(K,2))
+  const T wgt0 = sel2(jy0, wgt_a, wgt_b), wgt1 = sel2(jy0, wgt_b, wgt_a);  // WEIGHT(1), WEIGHT(2)
+  w.wlat[0][0] = p.wl[0] * wgt0;
+  w.wlat[0][1] = (T(1) - p.wl[0]) * wgt0;
+  w.wlat[1][0] = p.wl[1] * wgt1;
+  w.wlat[1][1] = (T(1) - p.wl[1]) * wgt1;
+  const T wlon_a = dyy * dxup_0 * p.ga;  // WLONN(JXO(K,1))
+  const T wlon_b = dyy * dxdw_1 * p.ga;  // WLONN(JXO(K,2))
+  w.wlon[0] = sel2(jx0, wlon_a, wlon_b);
+  w.wlon[1] = sel2(jx0, wlon_b, wlon_a);
   T wc4[4];
-  wc4[0] = dxup[jx0] * dyup[jy0] * p.ga;
-  wc4[1] = dxdw[jx1] * dyup[jy0] * p.ga;
-  wc4[2] = dxup[jx0] * dydw[jy1] * p.ga;
-  wc4[3] = dxdw[jx1] * dydw[jy1] * p.ga;
+  wc4[0] = dxup_0 * dyup_0 * p.ga;
+  wc4[1] = dxdw_1 * dyup_0 * p.ga;
+  wc4[2] = dxup_0 * dydw_1 * p.ga;
+  wc4[3] = dxdw_1 * dydw_1 * p.ga;
+#pragma unroll
   for (int icr = 0; icr < 4; icr++) {
-    const T wcv = p.wc[kc[icr]];
+    const int kk = kc[icr];
+    const T wcv = kk == 0 ? p.wc[0] : (kk == 1 ? p.wc[1] : (kk == 2 ? p.wc[2] : p.wc[3]));
     w.wcor[icr][0] = wcv * wc4[icr];
     w.wcor[icr][1] = (T(1) - wcv) * wc4[icr];
   }
-  T sumwn = (p.zd * (dydw[jy0] + dyup[jy1]) + xdella * (dxup[jx1] + dxdw[jx0]) - (dxdw[jx0] + dxup[jx1]) * (dydw[jy0] + dyup[jy1])) * p.ga;
+  T sumwn = (p.zd * (dydw_0 + dyup_1) + xdella * (dxup_1 + dxdw_0) - (dxdw_0 + dxup_1) * (dydw_0 + dyup_1)) * p.ga;
   w.wk[1] = (dthp + m_abs(dthp)) + (m_abs(dthm) - dthm);
   w.wk[2] = -dthp + m_abs(dthp);
   w.wk[0] = dthm + m_abs(dthm);
@@ -592,68 +605,35 @@ __device__ __forceinline__ bool ctu_wgen(const CtuBase<T>& b, T sink, T cosk, co
   }
   const T one = T(1), zero = T(0);
 #define OUTR(x) ((x) > one || (x) < zero)
-  for (int i = 0; i < 2; i++) {
-    if (OUTR(w.wlon[i]) || OUTR(w.wlat[i][0]) || OUTR(w.wlat[i][1])) fail = true;
+  if (CHECK) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      if (OUTR(w.wlon[i]) || OUTR(w.wlat[i][0]) || OUTR(w.wlat[i][1])) fail = true;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (OUTR(w.wcor[i][0]) || OUTR(w.wcor[i][1])) fail = true;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+      if (OUTR(w.wk[i]) || OUTR(w.wm[i])) fail = true;
   }
-  for (int i = 0; i < 4; i++)
-    if (OUTR(w.wcor[i][0]) || OUTR(w.wcor[i][1])) fail = true;
-  for (int i = 0; i < 3; i++)
-    if (OUTR(w.wk[i]) || OUTR(w.wm[i])) fail = true;
   sumwn = sumwn + w.wk[1];
   if (cur) sumwn = sumwn + w.wm[1];
-  if (OUTR(sumwn)) fail = true;
+  if (CHECK && OUTR(sumwn)) fail = true;
 #undef OUTR
   w.sumwn = sumwn;
   return fail;
 }
 
-// theta-dot and sigma-dot sums of one (point, K, M) (ctuw.F90:424-452, 471-493, 506-520) from the per-point REFR row
-template <typename T>
-__device__ __forceinline__ void ctu_refr_terms(const DevTab<T>* tab, int IREFRA, const T* rr, int slot, int k, int m, int NR, T tanph,
-                                               T sp, T sm, T delth0, T delfr0, T cg0, T om0, const T* cgrow, const T* omrow,
-                                               const T* wnrow, T& dthp, T& dthm, T& fdp, T& fdm) {
-#pragma clang fp contract(off)
-  const int NANG = tab->NANG;
-  const int kp1 = tab->KPM[k][2], km1 = tab->KPM[k][0];
-  const T drgp = tanph * sp, drgm = tanph * sm;
-  const bool cur = (IREFRA == 2 || IREFRA == 3);
-  T drdp = T(0), drdm = T(0), drcp = T(0), drcm = T(0);
-  if (IREFRA == 1) {
-    drdp = (rr[k] + rr[kp1]) * delth0;
-    drdm = (rr[k] + rr[km1]) * delth0;
-  }
-  const T mask = rr[REFR_MASK(NANG) + slot];
-  if (cur) {
-    drcp = mask * (rr[k] + rr[kp1]) * delth0;
-    drcm = mask * (rr[k] + rr[km1]) * delth0;
-  }
-  if (IREFRA == 0) {
-    dthp = drgp * cg0 + drcp;
-    dthm = drgm * cg0 + drcm;
-  } else {
-    dthp = drgp * cg0 + om0 * drdp + drcp;
-    dthm = drgm * cg0 + om0 * drdm + drcm;
-  }
-  fdp = fdm = T(0);
-  if (cur) {
-    const int mp1 = m + 1 < NR ? m + 1 : NR - 1, mm1 = m - 1 > 0 ? m - 1 : 0;
-    const T s0 = rr[NANG + k], omdd = rr[REFR_OMDD(NANG)];
-    const T sd = (s0 * cgrow[m] + omdd * omrow[m]) * wnrow[m];
-    const T sdp = (s0 * cgrow[mp1] + omdd * omrow[mp1]) * wnrow[mp1];
-    const T sdm = (s0 * cgrow[mm1] + omdd * omrow[mm1]) * wnrow[mm1];
-    const T dfp = delfr0 / tab->FR[m], dfm = delfr0 / tab->FR[mm1];
-    fdp = mask * (sd + sdp) * dfp;
-    fdm = mask * (sd + sdm) * dfm;
-  }
-}
-
 // PROPAGS2 for IREFRA = 1, 2, 3 with the weights rebuilt on the fly (and, with f1 == nullptr, the CFL / range checks of
-// CTUW alone: cflfail[ij] = 1 where one fails).  Same tile walk as k_propags2_otf; one thread per element.
+// CTUW alone: cflfail[ij] = 1 where one fails).  Same tile structure as k_propags2_otf: a thread owns VW consecutive
+// frequencies of one (point, direction) and moves 16 bytes per access.
 // IREFRA = 1: the eight-term stencil of propags2.F90:107-116; IREFRA = 2, 3: every neighbour in the order of
-// propags2.F90:130-186 -- a term whose weight is zero is not loaded (the reference's LLW* flags skip a term only when
-// its weight is zero at every point: adding the zero product changes nothing).
+// propags2.F90:130-186 -- a neighbour whose VW weights are all zero is not loaded (the reference's LLW* flags skip a term
+// only when its weight is zero at every point: adding a zero product changes nothing).
+// theta-dot (ctuw.F90:424-452, 471-493) and sigma-dot (ctuw.F90:506-520) sums are formed per thread from the REFR row.
 #define GEN_TP 16
-template <typename T>
+template <typename T, int VW, bool CHECK>
 __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restrict__ tab, int IREFRA, const T* __restrict__ f1,
                                                       T* __restrict__ f3, int ngy, T delpro, const int* __restrict__ kxlt,
                                                       const T* __restrict__ zdello, T xdella, const T* __restrict__ cosph,
@@ -666,8 +646,9 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
                                                       int copy_rest, int ntiles) {
   extern __shared__ __align__(16) unsigned char gen_smem[];
   const int NANG = tab->NANG, NFRE = tab->NFRE, NR = tab->NFRE_RED;
-  const int N = NANG * NFRE, RW = REFR_W(NANG);
+  const int N = NANG * NFRE, RW = REFR_W(NANG), NV = N / VW, FV = NFRE / VW;
   const T CMTODEG = T(360.0) / tab->CIRC;
+  const T FRATIO = tab->FRATIO;
   T DELTH0, DELFR0;
   {
 #pragma clang fp contract(off)
@@ -680,10 +661,16 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
   T* sB = reinterpret_cast<T*>(sI + GEN_TP * 16);                   // [TP][7][NFRE]: h0 h1 hy0 hy1 cg0 om wn
   T* sR = sB + (size_t)GEN_TP * 7 * NFRE;                           // [TP][RW]
   T* sK = sR + (size_t)GEN_TP * RW;                                 // [NANG][2]
+  T* sDF = sK + 2 * NANG;                                           // [2][NFRE]: DELFR0/FR(M), DELFR0/FR(MAX(1,M-1))
   for (int k = threadIdx.x; k < NANG; k += blockDim.x) {
     T a, b;
     ctu_dirfac(tab, k, DELTH0, T(1), a, b);
     sK[2 * k] = a; sK[2 * k + 1] = b;
+  }
+  for (int m = threadIdx.x; m < NFRE; m += blockDim.x) {
+#pragma clang fp contract(off)
+    sDF[m] = DELFR0 / tab->FR[m];
+    sDF[NFRE + m] = DELFR0 / tab->FR[m > 0 ? m - 1 : 0];
   }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int p0 = kijs + tile * GEN_TP;
@@ -716,57 +703,162 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
       o[6 * NFRE] = wn[(size_t)q[0] * NFRE + m];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < np * N; e += blockDim.x) {
-      const int t = e / N, el = e - t * N;
-      const int k = el / NFRE, m = el - k * NFRE;
+    for (int e = threadIdx.x; e < np * NV; e += blockDim.x) {
+      const int t = e / NV, ev = e - t * NV;
+      const int k = ev / FV, m = (ev - k * FV) * VW;
       const int* q = sI + t * 16;
       const size_t own = (size_t)q[0] * N;
+      const int el = k * NFRE + m;
+      typedef VecIO<T, VW> IO;
       if (m < m0 || m >= m1) {
-        if (f1 && (copy_rest & 1)) f3[own + el] = f1[own + el];
+        if (f1 && (copy_rest & 1)) {
+          T v[VW];
+          IO::ld(f1 + own + el, v);
+          IO::st(f3 + own + el, v);
+        }
         continue;
       }
       const CtuPoint<T>& p = sP[t];
       const int jx0 = tab->JXO[k][0], jx1 = tab->JXO[k][1], jy0 = tab->JYO[k][0], jy1 = tab->JYO[k][1];
       const int* kc = tab->KCR[k];
       const int km = tab->KPM[k][0], kp = tab->KPM[k][2];
+      const T sink = tab->SINTH[k], cosk = tab->COSTH[k];
       const T* bb = sB + (size_t)t * 7 * NFRE;
-      CtuBase<T> b;
-      b.h[0] = bb[m]; b.h[1] = bb[NFRE + m]; b.hy[0] = bb[2 * NFRE + m]; b.hy[1] = bb[3 * NFRE + m]; b.cg0 = bb[4 * NFRE + m];
       const T* rr = sR + (size_t)t * RW;
-      T dthp, dthm, fdp, fdm;
-      ctu_refr_terms(tab, IREFRA, rr, slot, k, m, NR, p.tanph, sK[2 * k], sK[2 * k + 1], DELTH0, DELFR0, b.cg0, bb[5 * NFRE + m],
-                     bb + 4 * NFRE, bb + 5 * NFRE, bb + 6 * NFRE, dthp, dthm, fdp, fdm);
-      CtuGenW<T> w;
-      const bool fail = ctu_wgen(b, tab->SINTH[k], tab->COSTH[k], p, xdella, delpro, CMTODEG, jx0, jx1, jy0, jy1, kc, cur,
-                                 rr[REFR_U(NANG)], rr[REFR_V(NANG)], dthp, dthm, fdp, fdm, tab->FRATIO, w);
-      if (!f1) {
+      const T u = rr[REFR_U(NANG)], v = rr[REFR_V(NANG)];
+      // direction refraction of (point, K): DRG*, DRD*, DRC* (ctuw.F90:424-452)
+      T drgp, drgm, drdp = T(0), drdm = T(0), drcp = T(0), drcm = T(0);
+      const T mask = rr[REFR_MASK(NANG) + slot];
+      T s0 = T(0), omdd = T(0);
+      {
+#pragma clang fp contract(off)
+        drgp = p.tanph * sK[2 * k];
+        drgm = p.tanph * sK[2 * k + 1];
+        if (IREFRA == 1) {
+          drdp = (rr[k] + rr[kp]) * DELTH0;
+          drdm = (rr[k] + rr[km]) * DELTH0;
+        }
+        if (cur) {
+          drcp = mask * (rr[k] + rr[kp]) * DELTH0;
+          drcm = mask * (rr[k] + rr[km]) * DELTH0;
+          s0 = rr[NANG + k];
+          omdd = rr[REFR_OMDD(NANG)];
+        }
+      }
+      T bh0[VW], bh1[VW], by0[VW], by1[VW], bc0[VW], bom[VW], bwn[VW];
+      IO::ld(bb + m, bh0); IO::ld(bb + NFRE + m, bh1); IO::ld(bb + 2 * NFRE + m, by0); IO::ld(bb + 3 * NFRE + m, by1);
+      IO::ld(bb + 4 * NFRE + m, bc0); IO::ld(bb + 5 * NFRE + m, bom);
+      // SDOT(K, M-1 .. M+VW) (propdot.F90:185-186) with the MPM clamps of ctuwupdt.F90:96-100
+      T sd[VW + 2];
+      if (cur) {
+#pragma clang fp contract(off)
+        IO::ld(bb + 6 * NFRE + m, bwn);
+#pragma unroll
+        for (int c = 0; c < VW; c++) sd[c + 1] = (s0 * bc0[c] + omdd * bom[c]) * bwn[c];
+        const int ml = m > 0 ? m - 1 : 0, mh = m + VW < NR ? m + VW : NR - 1;
+        sd[0] = (s0 * bb[4 * NFRE + ml] + omdd * bb[5 * NFRE + ml]) * bb[6 * NFRE + ml];
+        sd[VW + 1] = (mh == m + VW) ? (s0 * bb[4 * NFRE + mh] + omdd * bb[5 * NFRE + mh]) * bb[6 * NFRE + mh] : sd[VW];
+        if (m + VW > NR) {  // vector straddles NFRE_RED (only when NFRE_RED is not a multiple of VW): clamp inside too
+#pragma unroll
+          for (int c = 0; c < VW; c++)
+            if (m + c >= NR) sd[c + 1] = sd[NR - m];
+        }
+      }
+      CtuGenW<T> w[VW];
+      bool fail = false;
+#pragma unroll
+      for (int c = 0; c < VW; c++) {
+        CtuBase<T> b;
+        b.h[0] = bh0[c]; b.h[1] = bh1[c]; b.hy[0] = by0[c]; b.hy[1] = by1[c]; b.cg0 = bc0[c];
+        T dthp, dthm, fdp = T(0), fdm = T(0);
+        {
+#pragma clang fp contract(off)
+          if (IREFRA == 0) {
+            dthp = drgp * b.cg0 + drcp;
+            dthm = drgm * b.cg0 + drcm;
+          } else {
+            dthp = drgp * b.cg0 + bom[c] * drdp + drcp;
+            dthm = drgm * b.cg0 + bom[c] * drdm + drcm;
+          }
+          if (cur) {
+            const int mc = m + c;
+            fdp = mask * (sd[c + 1] + (mc + 1 < NR ? sd[c + 2] : sd[c + 1])) * sDF[mc];
+            fdm = mask * (sd[c + 1] + sd[c]) * sDF[NFRE + mc];
+          }
+        }
+        if (m + c < m1)
+          fail |= ctu_wgen<T, CHECK>(b, sink, cosk, p, xdella, delpro, CMTODEG, jx0, jx1, jy0, jy1, kc, cur, u, v, dthp, dthm, fdp, fdm, FRATIO, w[c]);
+      }
+      if (CHECK) {
         if (fail) cflfail[q[0]] = 1;
         continue;
       }
       const T* fo = f1 + own;
-      T r;
+      T fown[VW], r[VW];
+      IO::ld(fo + el, fown);
       if (!cur) {
-        r = ctu_stencil(w.sumwn, w.wlon[jx0], w.wlat[jy0][0], w.wlat[jy0][1], w.wcor[0][0], w.wcor[0][1], w.wk[0], w.wk[2], fo[el],
-                        f1[(size_t)q[1 + jx0] * N + el], f1[(size_t)q[3 + 2 * jy0] * N + el], f1[(size_t)q[4 + 2 * jy0] * N + el],
-                        f1[(size_t)q[7 + 2 * kc[0]] * N + el], f1[(size_t)q[8 + 2 * kc[0]] * N + el], fo[km * NFRE + m],
-                        fo[kp * NFRE + m]);
+        T flon[VW], fla1[VW], fla2[VW], fco1[VW], fco2[VW], fkm[VW], fkp[VW];
+        IO::ld(f1 + (size_t)q[1 + jx0] * N + el, flon);
+        IO::ld(f1 + (size_t)q[3 + 2 * jy0] * N + el, fla1);
+        IO::ld(f1 + (size_t)q[4 + 2 * jy0] * N + el, fla2);
+        IO::ld(f1 + (size_t)q[7 + 2 * kc[0]] * N + el, fco1);
+        IO::ld(f1 + (size_t)q[8 + 2 * kc[0]] * N + el, fco2);
+        IO::ld(fo + km * NFRE + m, fkm);
+        IO::ld(fo + kp * NFRE + m, fkp);
+#pragma unroll
+        for (int c = 0; c < VW; c++)
+          r[c] = ctu_stencil(w[c].sumwn, sel2(jx0, w[c].wlon[0], w[c].wlon[1]), sel2(jy0, w[c].wlat[0][0], w[c].wlat[1][0]),
+                             sel2(jy0, w[c].wlat[0][1], w[c].wlat[1][1]), w[c].wcor[0][0], w[c].wcor[0][1], w[c].wk[0], w[c].wk[2],
+                             fown[c], flon[c], fla1[c], fla2[c], fco1[c], fco2[c], fkm[c], fkp[c]);
       } else {
 #pragma clang fp contract(off)
-        r = (T(1) - w.sumwn) * fo[el];
-#define TERM(wv, ptr) { const T wv_ = (wv); if (wv_ != T(0)) r = r + wv_ * (ptr); }
-        for (int ic = 0; ic < 2; ic++) TERM(w.wlon[ic], f1[(size_t)q[1 + ic] * N + el]);
+#pragma unroll
+        for (int c = 0; c < VW; c++) r[c] = (T(1) - w[c].sumwn) * fown[c];
+        // one neighbour: loaded when any of the VW weights is non-zero
+#define TERMV(WEXPR, PTR)                                                     \
+  {                                                                           \
+    bool any_ = false;                                                        \
+    _Pragma("unroll") for (int c = 0; c < VW; c++) { any_ |= ((WEXPR) != T(0)); } \
+    if (any_) {                                                               \
+      T fn_[VW];                                                              \
+      IO::ld((PTR), fn_);                                                     \
+      _Pragma("unroll") for (int c = 0; c < VW; c++) { const T wv_ = (WEXPR); if (wv_ != T(0)) r[c] = r[c] + wv_ * fn_[c]; } \
+    }                                                                         \
+  }
+#pragma unroll
+        for (int ic = 0; ic < 2; ic++) TERMV(w[c].wlon[ic], f1 + (size_t)q[1 + ic] * N + el);
+#pragma unroll
         for (int icl = 0; icl < 2; icl++) {
-          for (int ic = 0; ic < 2; ic++) TERM(w.wlat[ic][icl], f1[(size_t)q[3 + 2 * ic + icl] * N + el]);
-          for (int icr = 0; icr < 4; icr++) TERM(w.wcor[icr][icl], f1[(size_t)q[7 + 2 * kc[icr] + icl] * N + el]);
+#pragma unroll
+          for (int ic = 0; ic < 2; ic++) TERMV(w[c].wlat[ic][icl], f1 + (size_t)q[3 + 2 * ic + icl] * N + el);
+#pragma unroll
+          for (int icr = 0; icr < 4; icr++) TERMV(w[c].wcor[icr][icl], f1 + (size_t)q[7 + 2 * kc[icr] + icl] * N + el);
         }
-        const int mm1 = m - 1 > 0 ? m - 1 : 0, mp1 = m + 1 < NR ? m + 1 : NR - 1;
-        TERM(w.wk[0], fo[km * NFRE + m]);
-        TERM(w.wm[0], fo[k * NFRE + mm1]);
-        TERM(w.wk[2], fo[kp * NFRE + m]);
-        TERM(w.wm[2], fo[k * NFRE + mp1]);
-#undef TERM
+#undef TERMV
+        // direction and frequency neighbours of the own spectrum: IC = -1 then +1, WKPMN before WMPMN (propags2.F90:170-186)
+        T fkm[VW], fkp[VW];
+        IO::ld(fo + km * NFRE + m, fkm);
+        IO::ld(fo + kp * NFRE + m, fkp);
+        const T flo = fo[k * NFRE + (m > 0 ? m - 1 : 0)];
+        const int mh = m + VW < NR ? m + VW : NR - 1;
+        const T fhi = fo[k * NFRE + mh];
+#pragma unroll
+        for (int c = 0; c < VW; c++) {
+          const T fm1 = (c == 0) ? flo : fown[c - 1];
+          T fp1 = (c == VW - 1) ? fhi : fown[c + 1];
+          if (m + c + 1 > NR - 1) fp1 = fown[c];            // MPM(M,+1) = MIN(NFRE_RED, M+1)
+          if (w[c].wk[0] != T(0)) r[c] = r[c] + w[c].wk[0] * fkm[c];
+          if (w[c].wm[0] != T(0)) r[c] = r[c] + w[c].wm[0] * fm1;
+          if (w[c].wk[2] != T(0)) r[c] = r[c] + w[c].wk[2] * fkp[c];
+          if (w[c].wm[2] != T(0)) r[c] = r[c] + w[c].wm[2] * fp1;
+        }
       }
-      f3[own + el] = r;
+      if (m + VW > m1) {  // partial vector at the end of the range (VW == 1 never gets here)
+#pragma unroll
+        for (int c = 0; c < VW; c++)
+          if (m + c >= m1) r[c] = (copy_rest & 1) ? fown[c] : f3[own + el + c];
+      }
+      IO::st(f3 + own + el, r);
     }
   }
 }
@@ -917,17 +1009,32 @@ void launch_propags2_gen(const void* tab, int irefra, const void* f1, void* f3, 
                          const int* kcor, const void* wlat, const void* wcor, const void* cg, const void* om, const void* wn,
                          const void* cosphm1, const void* refr, int* cflfail, int slot, int kijs, int kijl, int m0, int m1,
                          int copy_rest, int dims, hipStream_t s) {
-  const int NANG = dims >> 16, NFRE = (dims >> 8) & 0xFF;
+  const int NANG = dims >> 16, NFRE = (dims >> 8) & 0xFF, NR = dims & 0xFF;
   const int n = kijl - kijs;
   if (n <= 0) return;
   const int ntiles = (n + GEN_TP - 1) / GEN_TP;
   const size_t shmem = GEN_TP * (sizeof(CtuPoint<T>) + 16 * sizeof(int)) +
-                       ((size_t)GEN_TP * 7 * NFRE + (size_t)GEN_TP * REFR_W(NANG) + 2 * NANG) * sizeof(T) + 16;
+                       ((size_t)GEN_TP * 7 * NFRE + (size_t)GEN_TP * REFR_W(NANG) + 2 * NANG + 2 * NFRE) * sizeof(T) + 16;
   const int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
-  hipLaunchKernelGGL(k_propags2_gen<T>, dim3(grid), dim3(256), shmem, s, (const DevTab<T>*)tab, irefra, (const T*)f1, (T*)f3, ngy,
-                     (T)delpro, kxlt, (const T*)zdello, (T)xdella, (const T*)cosph, (const T*)sinph, klon, klat, kcor,
-                     (const T*)wlat, (const T*)wcor, (const T*)cg, (const T*)om, (const T*)wn, (const T*)cosphm1, (const T*)refr,
-                     cflfail, slot, kijs, kijl, m0, m1, copy_rest, ntiles);
+  constexpr int W = VecOf<T>::W;
+  const bool aligned = ((uintptr_t)f1 % 16 == 0) && ((uintptr_t)f3 % 16 == 0);
+#define GEN_ARGS                                                                                                               \
+  (const DevTab<T>*)tab, irefra, (const T*)f1, (T*)f3, ngy, (T)delpro, kxlt, (const T*)zdello, (T)xdella, (const T*)cosph,       \
+      (const T*)sinph, klon, klat, kcor, (const T*)wlat, (const T*)wcor, (const T*)cg, (const T*)om, (const T*)wn,             \
+      (const T*)cosphm1, (const T*)refr, cflfail, slot, kijs, kijl, m0, m1, copy_rest, ntiles
+  // 8 bytes per lane is the fastest width here (measured at O320 sp: 7.9 ms, against 9.2 ms at 16 bytes and 9.0 ms scalar):
+  // the VW sets of 21 weights a thread keeps live cost more occupancy than the wider accesses save
+  int vw = 2;
+  { const char* e_ = getenv("ECWAM_HIP_GEN_VW"); if (e_) vw = atoi(e_); }  // diagnostics
+  if (!f1)
+    hipLaunchKernelGGL((k_propags2_gen<T, 1, true>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
+  else if (vw >= W && aligned && NFRE % W == 0 && NR % W == 0 && m0 % W == 0 && m1 % W == 0)
+    hipLaunchKernelGGL((k_propags2_gen<T, W, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
+  else if (vw >= 2 && aligned && NFRE % 2 == 0 && NR % 2 == 0 && m0 % 2 == 0 && m1 % 2 == 0)
+    hipLaunchKernelGGL((k_propags2_gen<T, 2, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
+  else
+    hipLaunchKernelGGL((k_propags2_gen<T, 1, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
+#undef GEN_ARGS
 }
 template <typename T>
 void launch_newwind(const void* tab, int n, void* ff, const void* ffn, hipStream_t s) {

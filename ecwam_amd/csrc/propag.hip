@@ -977,8 +977,12 @@ void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, 
   (const DevTab<T>*)tab, (const T*)f1, (T*)f3, n_geom, ngy, (T)delpro, kxlt, (const T*)zdello, (T)xdella, (const T*)cosph,     \
       (const T*)sinph, klon, klat, kcor, (const T*)wlat, (const T*)wcor, (const T*)cg, (const T*)cosphm1, order, kijs, kijl, m0, \
       m1, copy_rest, ntiles
-  if (aligned && NFRE % W == 0 && m0 % W == 0 && m1 % W == 0)
+  int vw = W;
+  { const char* e_ = getenv("ECWAM_HIP_OTF_VW"); if (e_) vw = atoi(e_); }  // diagnostics
+  if (vw >= W && aligned && NFRE % W == 0 && m0 % W == 0 && m1 % W == 0)
     hipLaunchKernelGGL((k_propags2_otf<T, W>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
+  else if (vw >= 2 && aligned && NFRE % 2 == 0 && m0 % 2 == 0 && m1 % 2 == 0)
+    hipLaunchKernelGGL((k_propags2_otf<T, 2>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
   else
     hipLaunchKernelGGL((k_propags2_otf<T, 1>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
 #undef OTF_ARGS

@@ -57,6 +57,19 @@ class LocalDomain:
         """global index of every local row except land"""
         return np.concatenate([np.arange(self.lo, self.hi), self.halo_global])
 
+    def interior(self) -> tuple:
+        """[a, b): the longest run of owned rows whose advection stencil reads no halo row.  The owned range is a
+        latitude band, so the rows that do read one sit at its two ends: [0, a) and [b, n).  Lets the halo exchange run
+        while the interior is advected."""
+        n, nl = self.n, self.nland
+        nb = np.concatenate([self.klon.reshape(n, -1), self.klat.reshape(n, -1), self.kcor.reshape(n, -1)], axis=1)
+        needs = np.flatnonzero(((nb >= n) & (nb < nl)).any(axis=1))
+        if needs.size == 0:
+            return 0, n
+        edges = np.concatenate([[-1], needs, [n]])
+        g = int(np.argmax(np.diff(edges)))
+        return int(edges[g] + 1), int(edges[g + 1])
+
 
 def local_domain(grid, rank: int, nranks: int) -> LocalDomain:
     bounds = split_points(grid.nsea, nranks)

@@ -26,9 +26,11 @@ class HaloExchange:
         self.send_idx = {p: torch.from_numpy(np.ascontiguousarray(ix)).to(device) for p, ix in dom.send.items()}
         self.bufs = {}
 
-    def __call__(self, fl: torch.Tensor) -> None:
+    def start(self, fl: torch.Tensor) -> list:
+        """Pack the rows the neighbours need and post every send / receive; returns the pending requests.  Until `finish`
+        the caller must leave the halo rows [n, n+nh) of `fl` alone (the receives land there) -- the owned rows may be read."""
         if self.dom.nranks == 1:
-            return
+            return []
         import torch.distributed as dist
 
         ops = []
@@ -43,9 +45,15 @@ class HaloExchange:
             ops.append(dist.P2POp(dist.isend, buf, p))
         for p, (dst0, cnt) in sorted(self.dom.recv.items()):
             ops.append(dist.P2POp(dist.irecv, fl[dst0:dst0 + cnt], p))
-        if ops:
-            for r in dist.batch_isend_irecv(ops):
-                r.wait()
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    @staticmethod
+    def finish(reqs: list) -> None:
+        for r in reqs:
+            r.wait()
+
+    def __call__(self, fl: torch.Tensor) -> None:
+        self.finish(self.start(fl))
 
 
 class Wamintgr:
@@ -64,6 +72,7 @@ class Wamintgr:
         self.n, self.nrows = self.dom.n, self.dom.nrows
         self.gd = api.grid_to_device(grid, self.dtype, self.dev, local=self.dom)
         self.halo = HaloExchange(self.dom, self.dev, self.ctx)
+        self.interior = self.dom.interior()      # rows [a, b) whose stencil reads no halo row
         NANG, NFRE, NR = cfg.nang, cfg.nfre, cfg.nfre_red
         z = dict(dtype=self.dtype, device=self.dev)
         self.fl1 = torch.zeros((self.nrows, NANG, NFRE), **z)
@@ -193,30 +202,53 @@ class Wamintgr:
         c, g = self.cfg, self.gd
         lf = 0 < self.ifrelfmax < c.nfre_red
 
-        def advect(m1, m2, delpro, copy_rest):
+        def advect_rows(k0, k1, m1, m2, delpro, copy_rest):
+            if k1 <= k0:
+                return
             if self.irefra:
-                self.ctx.propags2_refra(self.fl1, self.fl3, g, self.cgroup_ext, self.omosnh2kd_ext, self.wavnum_ext, self.refr, delpro, 0,
-                                        self.n, m1, m2, copy_rest=copy_rest, frange=int(0 < self.ifrelfmax < m1))
+                self.ctx.propags2_refra(self.fl1, self.fl3, g, self.cgroup_ext, self.omosnh2kd_ext, self.wavnum_ext, self.refr, delpro, k0,
+                                        k1, m1, m2, copy_rest=copy_rest, frange=int(0 < self.ifrelfmax < m1))
             elif self.weights == "stored":
-                self.ctx.propags2(self.fl1, self.fl3, g["klon"], g["klat"], g["kcor"], self.w, 0, self.n, m1, m2, copy_rest=copy_rest)
+                self.ctx.propags2(self.fl1, self.fl3, g["klon"], g["klat"], g["kcor"], self.w, k0, k1, m1, m2, copy_rest=copy_rest)
             else:
-                self.ctx.propags2_otf(self.fl1, self.fl3, g, self.cgroup_ext, delpro, 0, self.n, m1, m2, copy_rest=copy_rest,
+                self.ctx.propags2_otf(self.fl1, self.fl3, g, self.cgroup_ext, delpro, k0, k1, m1, m2, copy_rest=copy_rest,
                                       order=self.order)
 
-        self.halo(self.fl1)
+        def advect(m1, m2, delpro, copy_rest, rows=None):
+            k0, k1 = rows if rows is not None else (0, self.n)
+            advect_rows(k0, k1, m1, m2, delpro, copy_rest)
+
+        def exchange_and_advect(passes):
+            """MPEXCHNG + PROPAGS2 (propag_wam.F90:166,247-313) with the exchange hidden behind the interior: post the halo
+            exchange, advect the rows that read no halo row, wait, advect the two ends of the band."""
+            overlap = self.dom.nranks > 1 and self.order is None
+            if not overlap:
+                self.halo(self.fl1)
+                for a in passes:
+                    advect(*a)
+                return
+            ia, ib = self.interior
+            reqs = self.halo.start(self.fl1)
+            for a in passes:
+                advect(*a, rows=(ia, ib))
+            self.halo.finish(reqs)
+            for a in passes:
+                advect(*a, rows=(0, ia))
+                advect(*a, rows=(ib, self.n))
+
         if self.weights == "stored" or self.ifrelfmax <= 0:
-            advect(1, c.nfre_red, float(c.idelpro), True)      # stored W already carries the per-range time steps
+            exchange_and_advect([(1, c.nfre_red, float(c.idelpro), True)])      # stored W already carries the per-range time steps
         else:
-            advect(1, self.ifrelfmax, float(self.delpro_lf), True)
+            passes = [(1, self.ifrelfmax, float(self.delpro_lf), True)]
             if lf:
-                advect(self.ifrelfmax + 1, c.nfre_red, float(c.idelpro), False)
+                passes.append((self.ifrelfmax + 1, c.nfre_red, float(c.idelpro), False))
+            exchange_and_advect(passes)
         if lf:
             nstep_lf = int(round(float(c.idelpro) / float(self.delpro_lf)))
             for _ in range(2, nstep_lf + 1):
                 # FL1_EXT(:,:,1:IFRELFMAX) <- FL3_EXT ; exchange ; PROPAGS2 on the fast waves only
                 self.fl1[: self.n, :, : self.ifrelfmax] = self.fl3[: self.n, :, : self.ifrelfmax]
-                self.halo(self.fl1)
-                advect(1, self.ifrelfmax, float(self.delpro_lf), False)
+                exchange_and_advect([(1, self.ifrelfmax, float(self.delpro_lf), False)])
         self.fl1, self.fl3 = self.fl3, self.fl1
 
     def newwind(self) -> None:

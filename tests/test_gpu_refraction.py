@@ -175,37 +175,61 @@ def test_zero_currents_reduce_to_the_plain_scheme(api):
     ctx.close()
 
 
-@pytest.mark.parametrize("irefra", [2, 3])
-def test_decomposed_refraction_step_is_bit_identical(api, irefra):
-    """Wamintgr with currents on 3 emulated ranks (halo rows of DEPTH/UCUR/VCUR from the global fields, as PROENVHALO
-    exchanges them) reproduces the single-domain run bit for bit."""
+class _LateHalo:
+    """Stands in for HaloExchange on emulated ranks: the halo rows hold NaN until `finish`, so an interior pass that read
+    one would poison its result."""
+
+    def __init__(self, m, source):
+        self.m, self.source = m, source
+
+    def start(self, fl):
+        fl[self.m.n: self.m.n + self.m.dom.nh] = float("nan")
+        return []
+
+    def finish(self, reqs):
+        glob = self.source()
+        hg = torch.from_numpy(np.asarray(self.m.dom.halo_global, dtype=np.int64)).to(glob.device)
+        self.m.fl1[self.m.n: self.m.n + self.m.dom.nh] = glob[hg]
+
+    def __call__(self, fl):
+        self.finish(self.start(fl))
+
+
+@pytest.mark.parametrize("irefra,weights", [(0, "otf"), (0, "stored"), (2, "otf"), (3, "otf")])
+def test_decomposed_step_with_overlapped_exchange_is_bit_identical(api, irefra, weights):
+    """Wamintgr.propag on 3 emulated ranks -- halo exchange posted, interior rows advected, exchange completed, the two
+    ends of the band advected (what `bench.py --gpus N` runs; with currents the halo rows of DEPTH/UCUR/VCUR come from the
+    global fields as PROENVHALO exchanges them) -- reproduces the single-domain run bit for bit."""
     from ecwam_amd import grid as G
     from ecwam_amd.wamintgr import Wamintgr
 
     cfg = Config(nang=12, nfre=36, nfre_red=28, idelt=600, idelpro=600, irefra=irefra)
     g = G.build_grid(20, mask="continents")
-    ref = Wamintgr(cfg, g, "sp")
+    ref = Wamintgr(cfg, g, "sp", weights=weights)
     ref.init_synthetic(seed=11)
     assert ref.build_weights() == 0
     nr = 3
     parts = []
+    snapshot = {}
     for r in range(nr):
-        m = Wamintgr(cfg, g, "sp", rank=r, nranks=nr)
+        m = Wamintgr(cfg, g, "sp", rank=r, nranks=nr, weights=weights)
         m.init_synthetic(seed=11)
         assert m.build_weights() == 0
-        m.halo = lambda fl: None
+        a, b = m.interior
+        assert 0 < a < b < m.n or r in (0, nr - 1)                 # a band in the middle has halo readers at both ends
+        assert b - a > 0.5 * m.n
+        m.halo = _LateHalo(m, lambda: snapshot["glob"])
         parts.append(m)
-    assert float(ref.refr[:, 2 * cfg.nang].abs().max()) > 0.1     # currents present
+    if irefra:
+        assert float(ref.refr[:, 2 * cfg.nang].abs().max()) > 0.1     # currents present
     for _ in range(2):
         ref.step()
-        glob = torch.cat([m.fl1[: m.n] for m in parts])
-        for m in parts:
-            hg = torch.from_numpy(np.asarray(m.dom.halo_global, dtype=np.int64)).to(glob.device)
-            m.fl1[m.n: m.n + m.dom.nh] = glob[hg]
+        snapshot["glob"] = torch.cat([m.fl1[: m.n] for m in parts])   # owned rows of every rank at the old time level
         for m in parts:
             m.step()
     torch.cuda.synchronize()
     got = torch.cat([m.fl1[: m.n] for m in parts]).cpu().numpy()
+    assert np.isfinite(got).all()
     assert np.array_equal(got, ref.fl1[: g.nsea].cpu().numpy())
     for m in parts + [ref]:
         m.ctx.close()

@@ -1666,3 +1666,28 @@ void ora_outbs(int n, const real *FL1a, real ZMISS, real *OUT) {
     o[3] = EM;
   }
 }
+
+/* ---- single routines exposed for the known-answer tests (tests/test_known_answers.py) ------------------------------------ */
+/* SNONLIN alone: SL, FLD start at zero */
+void ora_snonlin(real *FL1, real DEPTH, real AKMEAN, const real *WAVNUM, real *SL, real *FLD) {
+  for (int i = 0; i < S.NANG * S.NFRE; i++) { SL[i] = C_(0.0); FLD[i] = C_(0.0); }
+  snonlin(FL1, FLD, SL, DEPTH, AKMEAN, WAVNUM);
+}
+/* SBOTTOM alone */
+void ora_sbottom(real *FL1, const real *WAVNUM, real DEPTH, real *SL, real *FLD) {
+  for (int i = 0; i < S.NANG * S.NFRE; i++) { SL[i] = C_(0.0); FLD[i] = C_(0.0); }
+  sbottom(FL1, FLD, SL, WAVNUM, DEPTH);
+}
+/* SDISSIP_ARD alone */
+void ora_sdissip_ard(real *FL1, const real *WAVNUM, const real *XK2CG, real UFRIC, real WDWAVE, real AIRD, real *SL, real *FLD) {
+  real COSWDIF[NA];
+  for (int K = 0; K < S.NANG; K++) COSWDIF[K] = COS(S.TH[K] - WDWAVE);
+  for (int i = 0; i < S.NANG * S.NFRE; i++) { SL[i] = C_(0.0); FLD[i] = C_(0.0); }
+  sdissip_ard(FL1, FLD, SL, WAVNUM, XK2CG, UFRIC, COSWDIF, RMAX(AIRD, C_(1.0)) * S.ROWATERM1);
+}
+/* AIRSEA / TAUT_Z0 alone (ICODE_WND = 3, first guess from the drag law: IUSFG = 0); out[4] = USTAR, Z0, Z0B, CHRNCK */
+void ora_taut_z0(real U10, real UDIR, real TAUW, real TAUWDIR, real HALP, real RNFAC, real *out) {
+  real US = C_(0.0), Z0 = C_(0.0), Z0B = C_(0.0), CH = C_(0.0);
+  taut_z0(0, HALP, U10, UDIR, TAUW, TAUWDIR, RNFAC, &US, &Z0, &Z0B, &CH);
+  out[0] = US; out[1] = Z0; out[2] = Z0B; out[3] = CH;
+}

@@ -173,7 +173,7 @@ __global__ void k_selftest(int* nbad) {
 extern "C" {
 
 const char* ecwam_hip_last_error(void) { return g_err.c_str(); }
-int ecwam_hip_abi_version(void) { return 1; }
+int ecwam_hip_abi_version(void) { return ECWAM_HIP_ABI_VERSION; }
 
 int ecwam_hip_selftest(int device) {
   HIPCHK(hipSetDevice(device));

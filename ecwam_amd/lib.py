@@ -61,6 +61,7 @@ EXPORTS = ["ecwam_hip_last_error", "ecwam_hip_abi_version", "ecwam_hip_selftest"
            "ecwam_hip_points_to_chunks", "ecwam_hip_pack_rows", "ecwam_hip_unpack_rows", "ecwam_hip_malloc", "ecwam_hip_free",
            "ecwam_hip_memcpy_h2d", "ecwam_hip_memcpy_d2h", "ecwam_hip_memset", "ecwam_hip_sync"]
 
+ABI_VERSION = 2        # include/ecwam_hip.h ECWAM_HIP_ABI_VERSION
 _lib = None
 
 
@@ -77,6 +78,9 @@ def load() -> C.CDLL:
     import torch  # noqa: F401
     lib = C.CDLL(LIBPATH)
     lib.ecwam_hip_last_error.restype = C.c_char_p
+    lib.ecwam_hip_abi_version.restype = C.c_int
+    if lib.ecwam_hip_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIBPATH}: ABI version {lib.ecwam_hip_abi_version()} but this binding is written for {ABI_VERSION}; rebuild the extension")
     for name in EXPORTS[1:]:
         getattr(lib, name).restype = C.c_int
     vp, ci, cd = C.c_void_p, C.c_int, C.c_double

@@ -37,6 +37,9 @@ extern "C" {
 #endif
 
 #define ECWAM_HIP_MAXANG 48
+/* bumped whenever ecwam_hip_params / ecwam_hip_tables or an entry point changes: 2 = refraction entry points, SDICE1 table and
+ * ice break-up parameters added.  ecwam_hip_abi_version() returns the value the library was built with. */
+#define ECWAM_HIP_ABI_VERSION 2
 #define ECWAM_HIP_MAXFRE 48
 #define ECWAM_HIP_MAXMC 56     /* MLSTHG = NFRE - ISM <= 48 + 8 */
 #define ECWAM_HIP_MAXTAP 47    /* 2*NSDSNTH+1, NSDSNTH <= NANG/2-1 */

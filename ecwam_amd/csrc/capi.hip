@@ -58,7 +58,7 @@ static int build_tab(const ecwam_hip_params* p, const ecwam_hip_tables* t, DevTa
   d->LWFLUX = p->lwflux; d->LCFLX = (p->lwflux || p->lwfluxout || p->lwnemocou); d->LWNEMOCOU = p->lwnemocou; d->LWCOU = p->lwcou;
   d->LWCOUAST = p->lwcouast; d->LWNEMOCOUWRS = p->lwnemocouwrs;
   d->LWNEMOTAUOC = p->lwnemotauoc; d->LWNEMOCOUSEND = p->lwnemocousend; d->LWNEMOCOUSTK = p->lwnemocoustk;
-  d->ISNONLIN = p->isnonlin; d->IPHYS = p->iphys; d->IDAMPING = p->idamping;
+  d->ICODE = p->icode; d->ISNONLIN = p->isnonlin; d->IPHYS = p->iphys; d->IDAMPING = p->idamping;
   d->LCISCAL = p->lciscal; d->LCIWA2 = p->lciwa2; d->LCIWA3 = p->lciwa3;
   d->LCIWA1 = p->lciwa1; d->LWNEMOCOUIBR = p->lwnemocouibr; d->LWNEMOCOUSTRN = p->lwnemocoustrn; d->NICT = p->nict; d->NICH = p->nich;
   for (int i = 0; i < 36 * 16; i++) d->CIDEAC[i] = T(0);
@@ -196,8 +196,8 @@ int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int r
   if (p->nang < 4 || p->nang > MAXA || p->nfre < 8 || p->nfre > MAXF || p->nfre_red < 1 || p->nfre_red > p->nfre)
     return fail("ecwam_hip_create: NANG/NFRE/NFRE_RED out of the supported range");
   if (p->mlsthg > MAXMC || 2 * p->nsdsnth + 1 > MAXTAP || p->nwav_gc + 1 > MAXGC) return fail("ecwam_hip_create: table size exceeds library limits");
-  if ((p->iphys != 0 && p->iphys != 1) || (p->isnonlin < 0 || p->isnonlin > 2) || p->irefra < 0 || p->irefra > 3 || p->icode != 3)
-    return fail("ecwam_hip_create: only IPHYS=0/1, ISNONLIN=0/1/2, IREFRA=0..3, ICODE=3 are on the hot path (SURVEY.md 8a)");
+  if ((p->iphys != 0 && p->iphys != 1) || (p->isnonlin < 0 || p->isnonlin > 2) || p->irefra < 0 || p->irefra > 3 || p->icode < 1 || p->icode > 3)
+    return fail("ecwam_hip_create: only IPHYS=0/1, ISNONLIN=0/1/2, IREFRA=0..3, ICODE=1..3 are on the hot path (SURVEY.md 8a)");
   if (p->lciwa1 && (!t->cideac || p->nict < 2 || p->nich < 2 || p->nict * p->nich > 36 * 16))
     return fail("ecwam_hip_create: LCIWA1 (SDICE1) needs the CIDEAC table (tables.cideac, NICT*NICH <= 576)");
   HIPCHK(hipSetDevice(device));
@@ -207,14 +207,14 @@ int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int r
     std::vector<DevTab<float>> h(1);
     build_tab<float>(p, t, h.data());
     c->implsch_variant = h[0].DIA_PULL ? 2 : 1;
-    if ((p->llgcbz0 || p->lciwa1 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou || p->lwnemocouwrs || p->lwnemocoustrn || p->isnonlin || p->iphys == 0) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
+    if ((p->llgcbz0 || p->lciwa1 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou || p->lwnemocouwrs || p->lwnemocoustrn || p->isnonlin || p->iphys == 0 || p->icode != 3) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
     HIPCHK(hipMalloc(&c->dtab, sizeof(DevTab<float>)));
     HIPCHK(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<float>), hipMemcpyHostToDevice));
   } else {
     std::vector<DevTab<double>> h(1);
     build_tab<double>(p, t, h.data());
     c->implsch_variant = h[0].DIA_PULL ? 2 : 1;
-    if ((p->llgcbz0 || p->lciwa1 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou || p->lwnemocouwrs || p->lwnemocoustrn || p->isnonlin || p->iphys == 0) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
+    if ((p->llgcbz0 || p->lciwa1 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou || p->lwnemocouwrs || p->lwnemocoustrn || p->isnonlin || p->iphys == 0 || p->icode != 3) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
     HIPCHK(hipMalloc(&c->dtab, sizeof(DevTab<double>)));
     HIPCHK(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<double>), hipMemcpyHostToDevice));
   }
@@ -393,7 +393,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   int rc, variant = c->implsch_variant;
   { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_VARIANT"); if (e_ && atoi(e_) == 1) variant = 1; }  // diagnostics: force the 3-tile kernel
   if (c->p.llnormagam) variant |= 16;
-  if (c->p.llgcbz0 || c->p.lciwa1 || c->p.lciwa2 || c->p.lciwa3 || c->p.lciscal || c->p.lwnemocou || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin || c->p.iphys == 0) variant |= 32;
+  if (c->p.llgcbz0 || c->p.lciwa1 || c->p.lciwa2 || c->p.lciwa3 || c->p.lciscal || c->p.lwnemocou || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin || c->p.iphys == 0 || c->p.icode != 3) variant |= 32;
   DISPATCH(rc = launch_implsch<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s),
            rc = launch_implsch<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s));
   if (rc) return fail("ecwam_hip_implsch: unsupported spectral size for the LDS tiling");

@@ -21,6 +21,7 @@ struct DevTab {
   int LWVFLX_SNL, LWFLUX, LCFLX, LWNEMOCOU, LWCOU, LWCOUAST, LWNEMOCOUWRS;
   int LWNEMOTAUOC, LWNEMOCOUSEND, LWNEMOCOUSTK;
   int IPHYS, IDAMPING;  // 0: SINPUT_JAN + SDISSIP_JAN, 1: SINPUT_ARD + SDISSIP_ARD (sinput.F90:102, sdissip.F90:76)
+  int ICODE;     // 3: forcing by U10 (TAUT_Z0 gives u*); 1, 2: forcing by u* (Z0WAVE, U10 from the log profile; airsea.F90:93-117)
   int ISNONLIN;  // 0: DIA depth scaling from AKMEAN, 1: TRANSF per interaction frequency (snonlin.F90:126-150)
   int LCISCAL, LCIWA2, LCIWA3;  // sea-ice attenuation (implsch.F90:312-339, sdice2.F90, sdice3.F90)
   int LCIWA1, LWNEMOCOUIBR, LWNEMOCOUSTRN, NICT, NICH;  // SDICE1 scattering table, ice break-up coupling, CIMSSTRN

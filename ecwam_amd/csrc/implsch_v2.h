@@ -1303,7 +1303,8 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
     if (L.actm && ((RARE && tb.LCIWA1) || (RARE && tb.LCIWA2) || (RARE && tb.LCIWA3))) rCGROUP = wp[NFRE + L.lane];
   }
   const T ffv = (L.lane < ECWAM_HIP_NFF) ? ffa[(size_t)ij * ECWAM_HIP_NFF + L.lane] : T(0);
-  const T AIRD = lane_get(ffv, 0), WDWAVE = lane_get(ffv, 1), CICOVER = lane_get(ffv, 2), WSWAVE = lane_get(ffv, 3);
+  const T AIRD = lane_get(ffv, 0), WDWAVE = lane_get(ffv, 1), CICOVER = lane_get(ffv, 2);
+  T WSWAVE = lane_get(ffv, 3);  // replaced by the log-profile wind after the first AIRSEA when the forcing is u* (ICODE 1, 2)
   const T WSTAR = lane_get(ffv, 4), USTRA = lane_get(ffv, 5), VSTRA = lane_get(ffv, 6);
   const T EMAXDPT = lane_get(ffv, 14), DEPTH = lane_get(ffv, 15), CITHICK = lane_get(ffv, 13);
   const T IBRMEM = (RARE && tb.LWNEMOCOUIBR) ? intfa[(size_t)ij * ECWAM_HIP_NINTF + 15] : T(1);  // ENVIRONMENT%IBRMEM (input slot)
@@ -1323,12 +1324,23 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
     T UFRIC = q[C_UFRIC], Z0M = q[C_Z0M], Z0B = q[C_Z0B], CHRNCK = q[C_CHRNCK];
     q[C_SINWD] = m_sin(q[C_WDWAVE]); q[C_COSWD] = m_cos(q[C_WDWAVE]);  // once per point, for every later use
     if (SKIP & 2) { q[C_TWSIN] = m_sin(q[C_TAUWDIR]); q[C_TWCOS] = m_cos(q[C_TAUWDIR]); }  // ablation runs only
-    if ((RARE && tb.LLGCBZ0)) q[C_TWCOS] = m_cos(q[C_WDWAVE] - q[C_TAUWDIR]);  // COSDIFF of the first TAUT_Z0, which runs per wave below
-    else if (!(SKIP & 16)) taut_z0_a(tb, 0, q[C_WSWAVE], q[C_WDWAVE], q[C_TAUW], q[C_TAUWDIR], UFRIC, Z0M, Z0B, CHRNCK);
-    q[C_UFRIC] = UFRIC; q[C_Z0M] = Z0M; q[C_Z0B] = Z0B; q[C_CHRNCK] = CHRNCK;
-    T RNFAC = T(1);
+    T RNFAC = T(1);  // sinflx.F90:116-120, from the wind speed on entry
     if (tb.LLNORMAGAM && tb.LLCAPCHNK) RNFAC = T(1) + tb.DTHRN_A * (T(1) + m_tanh(q[C_WSWAVE] - tb.DTHRN_U));
     q[C_RNFAC] = RNFAC;
+    if ((RARE && tb.ICODE != 3)) {
+      // friction-velocity forcing (airsea.F90:100-117): Z0WAVE (z0wave.F90:73-92), then U10 from the log profile
+      const T U10 = q[C_WSWAVE], TAUW0 = q[C_TAUW];
+      const T ALPHAOG = (tb.LLCAPCHNK ? chnkmin(tb, U10) : tb.ALPHA) * tb.GM1;
+      const T UST2 = UFRIC * UFRIC, UST3 = UST2 * UFRIC;
+      const T ARG = m_max(UST2 - TAUW0, tb.EPS1);
+      Z0M = ALPHAOG * UST3 / m_sqrt(ARG);
+      Z0B = ALPHAOG * UST2;
+      CHRNCK = tb.G * Z0M / UST2;
+      q[C_WSWAVE] = m_max((T(1) / tb.XKAPPA) * UFRIC * (m_log(tb.XNLEV) - m_log(Z0M)), tb.WSPMIN);
+      if (tb.LLGCBZ0) q[C_TWCOS] = m_cos(q[C_WDWAVE] - q[C_TAUWDIR]);
+    } else if ((RARE && tb.LLGCBZ0)) q[C_TWCOS] = m_cos(q[C_WDWAVE] - q[C_TAUWDIR]);  // COSDIFF of the first TAUT_Z0, which runs per wave below
+    else if (!(SKIP & 16)) taut_z0_a(tb, 0, q[C_WSWAVE], q[C_WDWAVE], q[C_TAUW], q[C_TAUWDIR], UFRIC, Z0M, Z0B, CHRNCK);
+    q[C_UFRIC] = UFRIC; q[C_Z0M] = Z0M; q[C_Z0B] = Z0B; q[C_CHRNCK] = CHRNCK;
   }
 
   // ---- implsch.F90:183-203 (overlaps stage 1)
@@ -1370,7 +1382,10 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   }
   __syncthreads();  // stage 1 results
   T UFRIC = c[C_UFRIC], Z0M = c[C_Z0M];
-  const T RNFAC = c[C_RNFAC], sinwd = c[C_SINWD], coswd = c[C_COSWD];
+  T RNFAC = c[C_RNFAC];
+  const T sinwd = c[C_SINWD], coswd = c[C_COSWD];
+  const bool usforc = RARE && tb.ICODE != 3;
+  if (usforc) WSWAVE = c[C_WSWAVE];
   // LLGCBZ0: HALPHAP (sinflx.F90:130) and the gravity-capillary TAUT_Z0 per wave, STRESS_GC's wavenumber sum across the lanes
   const bool gcb = (RARE && tb.LLGCBZ0) != 0;
   T HALP = T(0);
@@ -1378,7 +1393,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
     HALP = halphap_w(tb, sF, L, rWAVNUM, coswdif);
     T Z0Bv = c[C_Z0B], CH = c[C_CHRNCK];
     const T cosd = c[C_TWCOS], tauw0 = c[C_TAUW];
-    if (!(SKIP & 16)) taut_z0_b_w(tb, L.lane, 0, HALP, WSWAVE, cosd, tauw0, RNFAC, UFRIC, Z0M, Z0Bv, CH);
+    if (!(SKIP & 16) && !usforc) taut_z0_b_w(tb, L.lane, 0, HALP, WSWAVE, cosd, tauw0, RNFAC, UFRIC, Z0M, Z0Bv, CH);
     WSYNC();
     if (L.lane == 0) { c[C_UFRIC] = UFRIC; c[C_Z0M] = Z0M; c[C_Z0B] = Z0Bv; c[C_CHRNCK] = CH; c[C_HALP] = HALP; }
   }
@@ -1475,6 +1490,10 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   __syncthreads();
   UFRIC = c[C_UFRIC]; Z0M = c[C_Z0M];
   const T SDS = c[C_SDS];
+  if (usforc && tb.LLNORMAGAM && tb.LLCAPCHNK) {  // second SINFLX call: RNFAC from the updated wind speed (sinflx.F90:116-120)
+    RNFAC = T(1) + tb.DTHRN_A * (T(1) + m_tanh(WSWAVE - tb.DTHRN_U));
+    if (L.lane == 0) c[C_RNFAC] = RNFAC;   // read by stage 3 (STRESSO of the second call), two barriers from here
+  }
   if (gcb) {
     T Z0Bv = c[C_Z0B], CH = c[C_CHRNCK];
     const T cosd = coswd * c[C_TWCOS] + sinwd * c[C_TWSIN], tauw1 = c[C_TAUW];
@@ -1671,7 +1690,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
     }
   }
   if (L.lane == 0) {
-    sScr[7] = UFRIC; sScr[8] = TAUW; sScr[9] = TAUWDIR; sScr[10] = Z0M; sScr[11] = Z0B; sScr[12] = CHRNCK;
+    sScr[7] = UFRIC; sScr[8] = TAUW; sScr[9] = TAUWDIR; sScr[10] = Z0M; sScr[11] = Z0B; sScr[12] = CHRNCK; sScr[3] = WSWAVE;
     sScr[16 + 2] = USTOKES; sScr[16 + 3] = VSTOKES; sScr[16 + 4] = STRNMS;
     sScr[16 + 5] = TAUXD; sScr[16 + 6] = TAUYD; sScr[16 + 7] = TAUOCXD; sScr[16 + 8] = TAUOCYD; sScr[16 + 9] = TAUOC;
     sScr[16 + 10] = TAUICX; sScr[16 + 11] = TAUICY; sScr[16 + 12] = PHIOCD; sScr[16 + 13] = PHIEPS; sScr[16 + 14] = PHIAW;
@@ -1679,7 +1698,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
   }
   WSYNC();
   if (valid) {
-    if (L.lane >= 7 && L.lane <= 12) ffa[(size_t)ij * ECWAM_HIP_NFF + L.lane] = sScr[L.lane];
+    if ((L.lane >= 7 && L.lane <= 12) || (usforc && L.lane == 3)) ffa[(size_t)ij * ECWAM_HIP_NFF + L.lane] = sScr[L.lane];
     if (L.lane < ECWAM_HIP_NINTF) {
       const int i = L.lane;
       const bool fluxes = tb.LCFLX && (i >= 5 && i <= 14);

@@ -870,19 +870,28 @@ __global__ void k_curmask(int n, int NANG, int slot, const int* __restrict__ cfl
   if (ij < n) refr[(size_t)ij * REFR_W(NANG) + REFR_MASK(NANG) + slot] = (cflfail && cflfail[ij]) ? T(0) : T(1);
 }
 
-// NEWWIND (newwind.F90:126-161, ICODE_WND == 3)
+// NEWWIND (newwind.F90:126-161)
 template <typename T>
 __global__ void k_newwind(const DevTab<T>* __restrict__ tab, int n, T* __restrict__ ff, const T* __restrict__ ffn) {
   int ij = blockIdx.x * blockDim.x + threadIdx.x;
   if (ij >= n) return;
   T* f = ff + (size_t)ij * ECWAM_HIP_NFF;
   const T* g = ffn + (size_t)ij * ECWAM_HIP_NFF;
-  const T wght = T(1) / m_max(tab->WSPMIN_RESET_TAUW, tab->EPSMIN);
-  T u = g[3];
-  f[3] = u;
-  if (u < tab->WSPMIN_RESET_TAUW) {
-    T tl = wght * (tab->ACD + tab->BCD * u) * (u * u * u);
-    f[8] = m_min(f[8], tl);
+  if (tab->ICODE == 3) {
+    const T wght = T(1) / m_max(tab->WSPMIN_RESET_TAUW, tab->EPSMIN);
+    T u = g[3];
+    f[3] = u;
+    if (u < tab->WSPMIN_RESET_TAUW) {
+      T tl = wght * (tab->ACD + tab->BCD * u) * (u * u * u);
+      f[8] = m_min(f[8], tl);
+    }
+  } else {  // friction-velocity forcing (newwind.F90:141-149), USTMIN_RESET_TAUW = 0.08 (yowwind.F90:20)
+    const T us = g[7];
+    f[7] = us;
+    const T r = tab->ALPHA / f[12];
+    T tw = (us * us) * (T(1) - r * r);
+    if (us < T(0.08)) tw = T(0);
+    f[8] = tw;
   }
   f[1] = g[1]; f[0] = g[0]; f[4] = g[4]; f[2] = g[2]; f[13] = g[13]; f[5] = g[5]; f[6] = g[6];
 }

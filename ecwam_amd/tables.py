@@ -87,8 +87,8 @@ class Config:
             raise ValueError("ISNONLIN must be 0, 1 (TRANSF) or 2 (TRANSF_SNL with PEAK_ANG)")
         if self.irefra not in (0, 1, 2, 3):
             raise ValueError("IREFRA must be 0 (none), 1 (depth), 2 (currents) or 3 (depth + currents)")
-        if self.icode != 3:
-            raise NotImplementedError("only ICODE=3 (10 m wind forcing) is supported")
+        if self.icode not in (1, 2, 3):
+            raise ValueError("ICODE must be 3 (10 m wind), 1 or 2 (friction velocity / stress forcing)")
         if self.nfre_red <= 0:
             self.nfre_red = self.nfre
         if not (8 <= self.nfre <= 48 and 4 <= self.nang <= 48 and self.nfre_red <= self.nfre):

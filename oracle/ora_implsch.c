@@ -294,10 +294,26 @@ static void taut_z0(int IUSFG, real HALP, real UTOP, real UDIR, real TAUW, real 
   }
 }
 
-/* airsea.F90:93-127 (ICODE_WND == 3 branch; Z0WAVE branch for ICODE 1/2 is not on any config's path) */
+/* z0wave.F90:73-92: roughness from the friction velocity and the wave stress */
+static void z0wave(real US, real TAUW, real UTOP, real *Z0, real *Z0B, real *CHRNCK) {
+  const real ALPHAOG = (S.c.llcapchnk ? chnkmin(UTOP) : S.ALPHA) * S.GM1;
+  const real UST2 = powi(US, 2), UST3 = powi(US, 3);
+  const real ARG = RMAX(UST2 - TAUW, S.EPS1);
+  *Z0 = ALPHAOG * UST3 / SQRT(ARG);
+  *Z0B = ALPHAOG * UST2;
+  *CHRNCK = S.G * (*Z0) / UST2;
+}
+/* airsea.F90:93-127: ICODE_WND = 3 (U10 given: TAUT_Z0 gives US), 1 or 2 (US given: Z0WAVE, then U10 from the log profile) */
 static int airsea(real HALP, real *U10, real U10DIR, real TAUW, real TAUWDIR, real RNFAC,
                   real *US, real *Z0, real *Z0B, real *CHRNCK, int ICODE_WND, int IUSFG) {
   if (ICODE_WND == 3) { taut_z0(IUSFG, HALP, *U10, U10DIR, TAUW, TAUWDIR, RNFAC, US, Z0, Z0B, CHRNCK); return 0; }
+  if (ICODE_WND == 1 || ICODE_WND == 2) {
+    z0wave(*US, TAUW, *U10, Z0, Z0B, CHRNCK);
+    const real XKAPPAD = C_(1.0) / S.XKAPPA, XLOGLEV = LOG(S.XNLEV);
+    *U10 = XKAPPAD * (*US) * (XLOGLEV - LOG(*Z0));
+    *U10 = RMAX(*U10, S.WSPMIN);
+    return 0;
+  }
   return 1;
 }
 
@@ -1617,16 +1633,23 @@ void ora_depthprpt(int n, const real *DEPTH, real *WAVNUM, real *CINV, real *CGR
   }
 }
 
-/* newwind.F90:105-161 (ICODE_WND == 3 branch); FFN = FF_NEXT [n][14] same member order as FF */
+/* newwind.F90:105-161; FFN = FF_NEXT [n][14] same member order as FF */
 void ora_newwind(int n, real *FF, const real *FFN) {
   real WGHT = C_(1.0) / RMAX(S.WSPMIN_RESET_TAUW, S.EPSMIN);
+  const real USTMIN_RESET_TAUW = C_(0.08); /* yowwind.F90:20 */
   for (int ij = 0; ij < n; ij++) {
     real *f = FF + (size_t)ij * 14;
     const real *g = FFN + (size_t)ij * 14;
-    f[3] = g[3];
-    if (f[3] < S.WSPMIN_RESET_TAUW) {
-      real TLWMAX = WGHT * (S.ACD + S.BCD * f[3]) * (f[3] * f[3] * f[3]);
-      f[8] = RMIN(f[8], TLWMAX);
+    if (S.c.icode == 3) {
+      f[3] = g[3];
+      if (f[3] < S.WSPMIN_RESET_TAUW) {
+        real TLWMAX = WGHT * (S.ACD + S.BCD * f[3]) * (f[3] * f[3] * f[3]);
+        f[8] = RMIN(f[8], TLWMAX);
+      }
+    } else { /* friction velocity forcing: :141-149 */
+      f[7] = g[7];
+      f[8] = powi(f[7], 2) * (C_(1.0) - powi(S.ALPHA / f[12], 2));
+      if (f[7] < USTMIN_RESET_TAUW) f[8] = C_(0.0);
     }
     f[1] = g[1]; f[0] = g[0]; f[4] = g[4]; f[2] = g[2]; f[13] = g[13]; f[5] = g[5]; f[6] = g[6];
   }

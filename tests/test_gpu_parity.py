@@ -453,6 +453,47 @@ def test_advection_properties_full_size_spectrum(api, prec):
 
 
 @pytest.mark.parametrize("prec", ["dp", "sp"])
+@pytest.mark.parametrize("flags", [dict(), dict(llnormagam=True), dict(llgcbz0=True, llnormagam=True)])
+def test_implsch_parity_friction_velocity_forcing(api, prec, flags):
+    """ICODE = 1 (the forcing field is the friction velocity): the first AIRSEA of SINFLX derives the roughness with Z0WAVE
+    and the 10 m wind from the log profile (airsea.F90:100-117, z0wave.F90), FF_NOW%WSWAVE becomes an OUTPUT, the second call
+    runs TAUT_Z0 on that wind (sinflx.F90:105-115) with RNFAC re-evaluated from it; NEWWIND takes UFRIC from FF_NEXT and
+    resets TAUW (newwind.F90:141-149)."""
+    cfg = Config(nang=24, nfre=36, nfre_red=29, icode=1, **flags)
+    n = 900
+    case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=61)
+    dt = H.np_dtype(prec)
+    case["FF"][:, 3] = dt(7.0)                                   # a stale wind speed: only CHNKMIN of Z0WAVE reads it
+    ref = H.oracle_implsch(case, _oracle(cfg, prec))
+    ctx = api.HipContext(case["tables"])
+    got = H.gpu_implsch(case, ctx)
+    st = H.compare_implsch(ref, got, case["tables"])
+    tol = 1e-11 if prec == "dp" else 2e-5
+    assert np.max(np.abs(got["FF"][:, 3].astype(float) - ref["FF"][:, 3].astype(float)) / ref["FF"][:, 3]) < tol    # WSWAVE written back
+    assert np.max(np.abs(ref["FF"][:, 3] - 7.0)) > 1.0
+    if prec == "dp":
+        assert st["mij_flips"] == 0 and st["fl1_max_rel_peak_all"] < 1e-10 and st["ff_max_rel_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
+    else:
+        assert st["mij_flips"] <= n * 0.005 and st["fl1_max_rel_peak_clean"] < 1e-4 and st["swh_max_rel"] < 1e-5, st
+        assert st["ff_max_rel_clean"] < 1e-4 and st["intf_max_rel_clean"] < 5e-3, st
+    # NEWWIND, friction-velocity branch
+    rng = np.random.default_rng(1)
+    ff = rng.uniform(0.05, 1.0, (n, 16)).astype(dt)
+    ff[:, 12] = rng.uniform(0.008, 0.03, n).astype(dt)          # CHRNCK
+    ffn = rng.uniform(0.02, 1.2, (n, 16)).astype(dt)
+    o = _oracle(cfg, prec)
+    want = o.newwind(ff[:, :14], ffn[:, :14])
+    tff = torch.from_numpy(ff.copy()).to(ctx.device)
+    ctx.newwind(tff, torch.from_numpy(ffn).to(ctx.device))
+    g2 = tff.cpu().numpy()
+    eps = np.finfo(dt).eps
+    assert np.array_equal(g2[:, 7], ffn[:, 7]) and np.array_equal(g2[:, 3], ff[:, 3])      # UFRIC taken over, WSWAVE untouched
+    assert np.max(np.abs(g2[:, 8].astype(float) - want[:, 8].astype(float))) < 8 * eps * np.abs(want[:, 8]).max()
+    assert (want[:, 8] == 0).any() and (want[:, 8] != 0).any()                              # both sides of USTMIN_RESET_TAUW
+    ctx.close()
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
 def test_newwind_and_layout(api, prec):
     cfg = Config(nang=12, nfre=36, nfre_red=25)
     dt = H.np_dtype(prec)

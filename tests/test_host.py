@@ -44,7 +44,7 @@ def test_create_refuses_unsupported_configurations_without_a_gpu():
     h = lib.load()
     t = Tables(Config(nang=12, nfre=36, nfre_red=25), np.float32)
     tp, keep = lib.make_tables(t)
-    cases = [(dict(lciwa1=1), "SDICE1"), (dict(iphys=2), "IPHYS"), (dict(irefra=4), "IREFRA"), (dict(isnonlin=3), "ISNONLIN"),
+    cases = [(dict(lciwa1=1), "SDICE1"), (dict(iphys=2), "IPHYS"), (dict(irefra=4), "IREFRA"), (dict(isnonlin=3), "ISNONLIN"), (dict(icode=4), "ICODE"),
              (dict(nang=3), "NANG"), (dict(nfre_red=40), "NFRE_RED")]
     for changes, word in cases:
         p = lib.make_params(t)

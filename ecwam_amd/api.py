@@ -70,6 +70,16 @@ class HipContext:
             raise ValueError(f"{name}: expected contiguous int32 cuda tensor of shape {tuple(shape)}, got {t.dtype} {tuple(t.shape)}")
         return t.data_ptr()
 
+    # -- LSUBGRID: OBS[n][8][NFRE] = OBSLAT(:,M,1:2), OBSLON(:,M,1:2), OBSCOR(:,M,1:4); the tensor is kept alive here
+    def set_obstructions(self, obs) -> None:
+        if obs is None:
+            self._obs = None
+            self._chk(self.lib.ecwam_hip_set_obstructions(self._h, None, 0))
+            return
+        n = obs.shape[0]
+        self._obs = obs
+        self._chk(self.lib.ecwam_hip_set_obstructions(self._h, self._real(obs, (n, 8, self.NFRE), "OBS"), n))
+
     # -- PROPAGS2(F1,F3,NINF,NSUP,KIJS,KIJL,NANG,ND3SF1,ND3EF1,ND3S,ND3E)  (propags2.F90:10)
     def propags2(self, f1, f3, klon, klat, kcor, w, kijs, kijl, nd3s=1, nd3e=None, copy_rest=True, check_indices=False):
         nd3e = self.NR if nd3e is None else nd3e

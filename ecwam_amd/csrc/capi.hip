@@ -25,16 +25,18 @@ struct ecwam_hip_ctx {
   void* dtab;  // DevTab<T> in device memory
   int implsch_variant;  // 2: two-tile fused-sweep kernel (needs the DIA rotation structure), 1: three-tile kernel
   ecwam_hip_params p;
+  const void* obs = nullptr;  // LSUBGRID: device OBS[n_obs][8][NFRE] (ecwam_hip_set_obstructions), read by CTUW / PROPAGS2
+  int n_obs = 0;
 };
 
 // launchers implemented in propag.hip / implsch.hip
 template <typename T> void launch_propags2(const void*, const void*, void*, const int*, const int*, const int*, const void*, int, int, int, int, int, int, hipStream_t);
-template <typename T> void launch_ctuw(const void*, int, int, int, double, int, int, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, void*, void*, const void*, const void*, void*, int*, int, hipStream_t);
+template <typename T> void launch_ctuw(const void*, int, int, int, double, int, int, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, void*, void*, const void*, const void*, void*, int*, int, const void*, hipStream_t);
 template <typename T> void launch_ctuwini_only(int, int, const int*, const int*, void*, void*, hipStream_t);
 template <typename T> void launch_propdot(const void*, int, int, int, const int*, const void*, double, const void*, const int*, const int*, const void*, const void*, const void*, const void*, const void*, void*, hipStream_t);
 template <typename T> void launch_curmask(int, int, int, const int*, void*, hipStream_t);
-template <typename T> void launch_propags2_gen(const void*, int, const void*, void*, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const void*, const void*, const void*, int*, int, int, int, int, int, int, int, hipStream_t);
-template <typename T> void launch_propags2_otf(const void*, const void*, void*, int, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const int*, int, int, int, int, int, int, hipStream_t);
+template <typename T> void launch_propags2_gen(const void*, int, const void*, void*, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const void*, const void*, const void*, int*, int, int, int, int, int, int, int, const void*, hipStream_t);
+template <typename T> void launch_propags2_otf(const void*, const void*, void*, int, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const int*, int, int, int, int, int, int, const void*, hipStream_t);
 template <typename T> int launch_outbs(const void*, int, int, const void*, double, void*, int, int, hipStream_t);
 template <typename T> void launch_norm(const void*, int, int, double, double*, int, hipStream_t);
 template <typename T> void launch_newwind(const void*, int, void*, const void*, hipStream_t);
@@ -238,6 +240,13 @@ int ecwam_hip_destroy(ecwam_hip_ctx* c) {
     }                            \
   } while (0)
 
+int ecwam_hip_set_obstructions(ecwam_hip_ctx* c, const void* obs, int n) {
+  if (!c) return fail("null context");
+  if (n < 0 || (obs && n == 0)) return fail("ecwam_hip_set_obstructions: bad size");
+  c->obs = obs; c->n_obs = obs ? n : 0;
+  return 0;
+}
+
 int ecwam_hip_propags2(ecwam_hip_ctx* c, const void* f1, void* f3, const int* klon, const int* klat, const int* kcor, const void* w,
                        int kijs, int kijl, int nd3s, int nd3e, int copy_rest, void* stream) {
   if (!c) return fail("null context");
@@ -259,9 +268,10 @@ int ecwam_hip_ctuw(ecwam_hip_ctx* c, int n, int nland, int ngy, double delpro, i
   if (n < 0 || mstart < 1 || mend > c->NFRE_RED || mend < mstart) return fail("ecwam_hip_ctuw: bad range");
   if (n > 0 && (!kxlt || !zdello || !cosph || !sinph || !klon || !klat || !kcor || !wlat || !wcor || !cgroup_ext || !cosphm1_ext || !cflfail))
     return fail("ecwam_hip_ctuw: null pointer");
+  if (c->obs && n > c->n_obs) return fail("ecwam_hip_ctuw: more points than the obstruction table holds");
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH(launch_ctuw<float>(c->dtab, n, nland, ngy, delpro, mstart - 1, mend, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, w, cflfail, c->NANG, s),
-           launch_ctuw<double>(c->dtab, n, nland, ngy, delpro, mstart - 1, mend, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, w, cflfail, c->NANG, s));
+  DISPATCH(launch_ctuw<float>(c->dtab, n, nland, ngy, delpro, mstart - 1, mend, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, w, cflfail, c->NANG, c->obs, s),
+           launch_ctuw<double>(c->dtab, n, nland, ngy, delpro, mstart - 1, mend, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, w, cflfail, c->NANG, c->obs, s));
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -276,12 +286,13 @@ int ecwam_hip_propags2_otf(ecwam_hip_ctx* c, const void* f1, void* f3, int n, in
   if (kijl > kijs && (!f1 || !f3 || !kxlt || !zdello || !cosph || !sinph || !klon || !klat || !kcor || !wlat || !wcor || !cgroup_ext || !cosphm1_ext))
     return fail("ecwam_hip_propags2_otf: null pointer");
   if (f1 == f3) return fail("ecwam_hip_propags2_otf: F1 and F3 must not alias");
+  if (c->obs && kijl > c->n_obs) return fail("ecwam_hip_propags2_otf: more points than the obstruction table holds");
   hipStream_t s = (hipStream_t)stream;
   const int N = (c->NANG << 16) | (c->NFRE << 8) | c->NFRE_RED;
   copy_rest = copy_rest ? 1 : 0;
   { const char* e_ = getenv("ECWAM_HIP_OTF_WALK"); if (e_ && atoi(e_) == 0) copy_rest |= 2; }  // diagnostics: plain grid-stride tile walk
-  DISPATCH(launch_propags2_otf<float>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, s),
-           launch_propags2_otf<double>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, s));
+  DISPATCH(launch_propags2_otf<float>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, c->obs, s),
+           launch_propags2_otf<double>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, c->obs, s));
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -311,8 +322,8 @@ static int propags2_gen_launch(ecwam_hip_ctx* c, const char* who, const void* f1
                       !wavnum_ext || !cosphm1_ext || !refr))
     return fail((std::string(who) + ": null pointer").c_str());
   const int N = (c->NANG << 16) | (c->NFRE << 8) | c->NFRE_RED;
-  DISPATCH(launch_propags2_gen<float>(c->dtab, c->p.irefra, f1, f3, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, omosnh2kd_ext, wavnum_ext, cosphm1_ext, refr, cflfail, slot, kijs, kijl, m0, m1, copy_rest, N, s),
-           launch_propags2_gen<double>(c->dtab, c->p.irefra, f1, f3, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, omosnh2kd_ext, wavnum_ext, cosphm1_ext, refr, cflfail, slot, kijs, kijl, m0, m1, copy_rest, N, s));
+  DISPATCH(launch_propags2_gen<float>(c->dtab, c->p.irefra, f1, f3, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, omosnh2kd_ext, wavnum_ext, cosphm1_ext, refr, cflfail, slot, kijs, kijl, m0, m1, copy_rest, N, c->obs, s),
+           launch_propags2_gen<double>(c->dtab, c->p.irefra, f1, f3, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, omosnh2kd_ext, wavnum_ext, cosphm1_ext, refr, cflfail, slot, kijs, kijl, m0, m1, copy_rest, N, c->obs, s));
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -377,6 +388,7 @@ int ecwam_hip_propags2_refra(ecwam_hip_ctx* c, const void* f1, void* f3, int n, 
     return fail("ecwam_hip_propags2_refra: bad range");
   if (kijl > kijs && (!f1 || !f3)) return fail("ecwam_hip_propags2_refra: null pointer");
   if (f1 == f3) return fail("ecwam_hip_propags2_refra: F1 and F3 must not alias");
+  if (c->obs && kijl > c->n_obs) return fail("ecwam_hip_propags2_refra: more points than the obstruction table holds");
   return propags2_gen_launch(c, "ecwam_hip_propags2_refra", f1, f3, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat,
                              wcor, cgroup_ext, omosnh2kd_ext, wavnum_ext, cosphm1_ext, refr, nullptr, range, kijs, kijl, nd3s - 1, nd3e,
                              copy_rest ? 1 : 0, (hipStream_t)stream);

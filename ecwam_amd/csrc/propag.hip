@@ -247,6 +247,18 @@ __device__ __forceinline__ void ctu_dirfac(const DevTab<T>* tab, int k, T delth0
   tsm = tanph * sm;
 }
 
+// Sub-grid obstructions (LSUBGRID, ctuw.F90:703-733): after the checks, the space weights of the neighbours are scaled by the
+// transmission coefficients OBS[ij][8][NFRE] = OBSLAT(IJ,M,1:2), OBSLON(IJ,M,1:2), OBSCOR(IJ,M,1:4); SUMWN keeps its value
+// (what the obstruction blocks is lost).  o points at plane 0 of (ij, m), planes are `stride` apart.
+template <typename T>
+__device__ __forceinline__ void ctu_obstruct8(T* w8, const T* o, int stride, int jx0, int jy0, int kc) {
+#pragma clang fp contract(off)
+  const T olon = o[(2 + jx0) * stride], olat = o[jy0 * stride], ocor = o[(4 + kc) * stride];
+  w8[1] = w8[1] * olon;
+  w8[2] = w8[2] * olat; w8[3] = w8[3] * olat;
+  w8[4] = w8[4] * ocor; w8[5] = w8[5] * ocor;
+}
+
 // One thread per (ij,K,M): stores the eight weights (w != nullptr) and raises the CFL flag of the point.
 template <typename T>
 __global__ void __launch_bounds__(256) k_ctuw(const DevTab<T>* __restrict__ tab, int n, int ngy, T delpro, int m0, int m1,
@@ -255,7 +267,7 @@ __global__ void __launch_bounds__(256) k_ctuw(const DevTab<T>* __restrict__ tab,
                                               const int* __restrict__ klon, const int* __restrict__ klat,
                                               const T* __restrict__ wlat, const T* __restrict__ wcor,
                                               const T* __restrict__ cg, const T* __restrict__ cosphm1, T* __restrict__ w,
-                                              int* __restrict__ cflfail) {
+                                              int* __restrict__ cflfail, const T* __restrict__ obs) {
   const int NANG = tab->NANG, NFRE = tab->NFRE, NR = tab->NFRE_RED;
   const int nm = m1 - m0;
   const long long total = (long long)n * NANG * nm;
@@ -279,6 +291,7 @@ __global__ void __launch_bounds__(256) k_ctuw(const DevTab<T>* __restrict__ tab,
     const bool fail = ctu_w8(b, tab->SINTH[k], tab->COSTH[k], p.cpm1, p.zd, xdella, p.ga, delpro, CMTODEG, jx0, jx1, jy0, jy1,
                              p.wl[jy0], p.wc[kc], tsp, tsm, w8);
     if (fail) cflfail[ij] = 1;
+    if (obs) ctu_obstruct8(w8, obs + (size_t)ij * 8 * NFRE + m, NFRE, jx0, jy0, kc);
     if (w) {
       const size_t ws = (size_t)NANG * NR;
       const size_t wb = (size_t)ij * 8 * ws + (size_t)k * NR + m;
@@ -312,7 +325,7 @@ template <typename T> struct VecIO<T, 1> {
   static __device__ __forceinline__ void ld(const T* p, T* o) { o[0] = p[0]; }
   static __device__ __forceinline__ void st(T* p, const T* o) { p[0] = o[0]; }
 };
-template <typename T, int VW>
+template <typename T, int VW, bool OBS>
 __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restrict__ tab, const T* __restrict__ f1, T* __restrict__ f3,
                                                       int n_geom, int ngy, T delpro, const int* __restrict__ kxlt,
                                                       const T* __restrict__ zdello, T xdella, const T* __restrict__ cosph,
@@ -321,7 +334,7 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
                                                       const T* __restrict__ wlat, const T* __restrict__ wcor,
                                                       const T* __restrict__ cg, const T* __restrict__ cosphm1,
                                                       const int* __restrict__ order, int kijs, int kijl, int m0, int m1,
-                                                      int copy_rest, int ntiles) {
+                                                      int copy_rest, int ntiles, const T* __restrict__ obs) {
   extern __shared__ __align__(16) unsigned char otf_smem[];
   const int NANG = tab->NANG, NFRE = tab->NFRE;
   const int N = NANG * NFRE, NV = N / VW, FV = NFRE / VW;
@@ -332,6 +345,7 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
   int* sI = reinterpret_cast<int*>(sP + OTF_TP);                    // [TP][16]: ij, ilon[2], ilat[2][2], icor[4][2]
   T* sB = reinterpret_cast<T*>(sI + OTF_TP * 16);                   // [TP][5][NFRE]
   T* sK = sB + (size_t)OTF_TP * 5 * NFRE;                           // [NANG][2]: (SINTH+SINTH(K+1))*DELTH0/R, same for K-1
+  T* sO = sK + 2 * NANG;                                            // OBS: [TP][8][NFRE] transmission coefficients
   for (int k = threadIdx.x; k < NANG; k += blockDim.x) {
     T a, b;
     ctu_dirfac(tab, k, DELTH0, T(1), a, b);  // TANPH applied per point below: TANPH*SP is formed as in k_ctuw
@@ -373,6 +387,10 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
         const CtuBase<T> b = ctu_base(cg[(size_t)q[0] * NFRE + m], cgl, cgy0, cgy1, sP[t].wl, sP[t].dp);
         T* o = sB + (size_t)t * 5 * NFRE + m;
         o[0] = b.h[0]; o[NFRE] = b.h[1]; o[2 * NFRE] = b.hy[0]; o[3 * NFRE] = b.hy[1]; o[4 * NFRE] = b.cg0;
+        if (OBS) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) sO[((size_t)t * 8 + i) * NFRE + m] = obs[((size_t)q[0] * 8 + i) * NFRE + m];
+        }
       }
     }
     __syncthreads();
@@ -420,6 +438,7 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
         b.h[0] = bh0[c]; b.h[1] = bh1[c]; b.hy[0] = by0[c]; b.hy[1] = by1[c]; b.cg0 = bc0[c];
         T w8[8];
         (void)ctu_w8(b, sink, cosk, p.cpm1, p.zd, xdella, p.ga, delpro, CMTODEG, jx0, jx1, jy0, jy1, p.wl[jy0], p.wc[kc], tsp, tsm, w8);
+        if (OBS) ctu_obstruct8(w8, sO + (size_t)t * 8 * NFRE + m + c, NFRE, jx0, jy0, kc);
         const T a = ctu_stencil(w8[0], w8[1], w8[2], w8[3], w8[4], w8[5], w8[6], w8[7], fo[c], flon[c], fla1[c], fla2[c], fco1[c],
                                 fco2[c], fkm[c], fkp[c]);
         r[c] = a;
@@ -633,7 +652,7 @@ __device__ __forceinline__ bool ctu_wgen(const CtuBase<T>& b, T sink, T cosk, co
 // only when its weight is zero at every point: adding a zero product changes nothing).
 // theta-dot (ctuw.F90:424-452, 471-493) and sigma-dot (ctuw.F90:506-520) sums are formed per thread from the REFR row.
 #define GEN_TP 16
-template <typename T, int VW, bool CHECK>
+template <typename T, int VW, bool CHECK, bool OBS>
 __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restrict__ tab, int IREFRA, const T* __restrict__ f1,
                                                       T* __restrict__ f3, int ngy, T delpro, const int* __restrict__ kxlt,
                                                       const T* __restrict__ zdello, T xdella, const T* __restrict__ cosph,
@@ -643,7 +662,7 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
                                                       const T* __restrict__ cg, const T* __restrict__ om, const T* __restrict__ wn,
                                                       const T* __restrict__ cosphm1, const T* __restrict__ refr,
                                                       int* __restrict__ cflfail, int slot, int kijs, int kijl, int m0, int m1,
-                                                      int copy_rest, int ntiles) {
+                                                      int copy_rest, int ntiles, const T* __restrict__ obs) {
   extern __shared__ __align__(16) unsigned char gen_smem[];
   const int NANG = tab->NANG, NFRE = tab->NFRE, NR = tab->NFRE_RED;
   const int N = NANG * NFRE, RW = REFR_W(NANG), NV = N / VW, FV = NFRE / VW;
@@ -662,6 +681,7 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
   T* sR = sB + (size_t)GEN_TP * 7 * NFRE;                           // [TP][RW]
   T* sK = sR + (size_t)GEN_TP * RW;                                 // [NANG][2]
   T* sDF = sK + 2 * NANG;                                           // [2][NFRE]: DELFR0/FR(M), DELFR0/FR(MAX(1,M-1))
+  T* sO = sDF + 2 * NFRE;                                           // OBS: [TP][8][NFRE] transmission coefficients (LSUBGRID)
   for (int k = threadIdx.x; k < NANG; k += blockDim.x) {
     T a, b;
     ctu_dirfac(tab, k, DELTH0, T(1), a, b);
@@ -701,6 +721,10 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
       o[0] = b.h[0]; o[NFRE] = b.h[1]; o[2 * NFRE] = b.hy[0]; o[3 * NFRE] = b.hy[1]; o[4 * NFRE] = b.cg0;
       o[5 * NFRE] = om[(size_t)q[0] * NFRE + m];
       o[6 * NFRE] = wn[(size_t)q[0] * NFRE + m];
+      if (OBS) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) sO[((size_t)t * 8 + i) * NFRE + m] = obs[((size_t)q[0] * 8 + i) * NFRE + m];
+      }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < np * NV; e += blockDim.x) {
@@ -788,6 +812,22 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
         }
         if (m + c < m1)
           fail |= ctu_wgen<T, CHECK>(b, sink, cosk, p, xdella, delpro, CMTODEG, jx0, jx1, jy0, jy1, kc, cur, u, v, dthp, dthm, fdp, fdm, FRATIO, w[c]);
+        if (OBS && !CHECK) {  // ctuw.F90:703-733, after the checks
+#pragma clang fp contract(off)
+          const T* o = sO + (size_t)t * 8 * NFRE + m + c;
+#pragma unroll
+          for (int ic = 0; ic < 2; ic++) {
+            w[c].wlon[ic] = w[c].wlon[ic] * o[(2 + ic) * NFRE];
+            w[c].wlat[ic][0] = w[c].wlat[ic][0] * o[ic * NFRE];
+            w[c].wlat[ic][1] = w[c].wlat[ic][1] * o[ic * NFRE];
+          }
+#pragma unroll
+          for (int icr = 0; icr < 4; icr++) {
+            const T oc = o[(4 + kc[icr]) * NFRE];
+            w[c].wcor[icr][0] = w[c].wcor[icr][0] * oc;
+            w[c].wcor[icr][1] = w[c].wcor[icr][1] * oc;
+          }
+        }
       }
       if (CHECK) {
         if (fail) cflfail[q[0]] = 1;
@@ -960,24 +1000,26 @@ void launch_propags2(const void* tab, const void* f1, void* f3, const int* klon,
 template <typename T>
 void launch_ctuw(const void* tab, int n, int nland, int ngy, double delpro, int m0, int m1, const int* kxlt, const void* zdello,
                  double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat, const int* kcor,
-                 void* wlat, void* wcor, const void* cg, const void* cosphm1, void* w, int* cflfail, int NANG, hipStream_t s) {
+                 void* wlat, void* wcor, const void* cg, const void* cosphm1, void* w, int* cflfail, int NANG, const void* obs,
+                 hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_ctuwini<T>, dim3((n + 255) / 256), dim3(256), 0, s, n, nland, klat, kcor, (T*)wlat, (T*)wcor);
   long long total = (long long)n * NANG * (m1 - m0);
   hipLaunchKernelGGL(k_ctuw<T>, dim3(grid_for(total)), dim3(256), 0, s, (const DevTab<T>*)tab, n, ngy, (T)delpro, m0, m1, kxlt,
                      (const T*)zdello, (T)xdella, (const T*)cosph, (const T*)sinph, klon, klat, (const T*)wlat, (const T*)wcor,
-                     (const T*)cg, (const T*)cosphm1, (T*)w, cflfail);
+                     (const T*)cg, (const T*)cosphm1, (T*)w, cflfail, (const T*)obs);
 }
 template <typename T>
 void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, int ngy, double delpro, const int* kxlt,
                          const void* zdello, double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat,
                          const int* kcor, const void* wlat, const void* wcor, const void* cg, const void* cosphm1, const int* order,
-                         int kijs, int kijl, int m0, int m1, int copy_rest, int dims, hipStream_t s) {
+                         int kijs, int kijl, int m0, int m1, int copy_rest, int dims, const void* obs, hipStream_t s) {
   const int NANG = dims >> 16, NFRE = (dims >> 8) & 0xFF;
   const int n = kijl - kijs;
   if (n <= 0) return;
   const int ntiles = (n + OTF_TP - 1) / OTF_TP;
-  const size_t shmem = OTF_TP * (sizeof(CtuPoint<T>) + 16 * sizeof(int)) + ((size_t)OTF_TP * 5 * NFRE + 2 * NANG) * sizeof(T) + 16;
+  const size_t shmem = OTF_TP * (sizeof(CtuPoint<T>) + 16 * sizeof(int)) +
+                       ((size_t)OTF_TP * (obs ? 13 : 5) * NFRE + 2 * NANG) * sizeof(T) + 16;
   int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
   grid = (grid + 7) & ~7;  // whole rounds of the 8 XCDs
   constexpr int W = VecOf<T>::W;
@@ -985,15 +1027,19 @@ void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, 
 #define OTF_ARGS                                                                                                              \
   (const DevTab<T>*)tab, (const T*)f1, (T*)f3, n_geom, ngy, (T)delpro, kxlt, (const T*)zdello, (T)xdella, (const T*)cosph,     \
       (const T*)sinph, klon, klat, kcor, (const T*)wlat, (const T*)wcor, (const T*)cg, (const T*)cosphm1, order, kijs, kijl, m0, \
-      m1, copy_rest, ntiles
+      m1, copy_rest, ntiles, (const T*)obs
   int vw = W;
   { const char* e_ = getenv("ECWAM_HIP_OTF_VW"); if (e_) vw = atoi(e_); }  // diagnostics
-  if (vw >= W && aligned && NFRE % W == 0 && m0 % W == 0 && m1 % W == 0)
-    hipLaunchKernelGGL((k_propags2_otf<T, W>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
+  const bool vec = vw >= W && aligned && NFRE % W == 0 && m0 % W == 0 && m1 % W == 0;
+  if (obs) {  // LSUBGRID
+    if (vec) hipLaunchKernelGGL((k_propags2_otf<T, W, true>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
+    else hipLaunchKernelGGL((k_propags2_otf<T, 1, true>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
+  } else if (vec)
+    hipLaunchKernelGGL((k_propags2_otf<T, W, false>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
   else if (vw >= 2 && aligned && NFRE % 2 == 0 && m0 % 2 == 0 && m1 % 2 == 0)
-    hipLaunchKernelGGL((k_propags2_otf<T, 2>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
+    hipLaunchKernelGGL((k_propags2_otf<T, 2, false>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
   else
-    hipLaunchKernelGGL((k_propags2_otf<T, 1>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
+    hipLaunchKernelGGL((k_propags2_otf<T, 1, false>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
 #undef OTF_ARGS
 }
 template <typename T>
@@ -1021,32 +1067,37 @@ void launch_propags2_gen(const void* tab, int irefra, const void* f1, void* f3, 
                          const void* zdello, double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat,
                          const int* kcor, const void* wlat, const void* wcor, const void* cg, const void* om, const void* wn,
                          const void* cosphm1, const void* refr, int* cflfail, int slot, int kijs, int kijl, int m0, int m1,
-                         int copy_rest, int dims, hipStream_t s) {
+                         int copy_rest, int dims, const void* obs, hipStream_t s) {
   const int NANG = dims >> 16, NFRE = (dims >> 8) & 0xFF, NR = dims & 0xFF;
   const int n = kijl - kijs;
   if (n <= 0) return;
   const int ntiles = (n + GEN_TP - 1) / GEN_TP;
   const size_t shmem = GEN_TP * (sizeof(CtuPoint<T>) + 16 * sizeof(int)) +
-                       ((size_t)GEN_TP * 7 * NFRE + (size_t)GEN_TP * REFR_W(NANG) + 2 * NANG + 2 * NFRE) * sizeof(T) + 16;
+                       ((size_t)GEN_TP * (obs && f1 ? 15 : 7) * NFRE + (size_t)GEN_TP * REFR_W(NANG) + 2 * NANG + 2 * NFRE) * sizeof(T) + 16;
   const int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
   constexpr int W = VecOf<T>::W;
   const bool aligned = ((uintptr_t)f1 % 16 == 0) && ((uintptr_t)f3 % 16 == 0);
 #define GEN_ARGS                                                                                                               \
   (const DevTab<T>*)tab, irefra, (const T*)f1, (T*)f3, ngy, (T)delpro, kxlt, (const T*)zdello, (T)xdella, (const T*)cosph,       \
       (const T*)sinph, klon, klat, kcor, (const T*)wlat, (const T*)wcor, (const T*)cg, (const T*)om, (const T*)wn,             \
-      (const T*)cosphm1, (const T*)refr, cflfail, slot, kijs, kijl, m0, m1, copy_rest, ntiles
+      (const T*)cosphm1, (const T*)refr, cflfail, slot, kijs, kijl, m0, m1, copy_rest, ntiles, (const T*)obs
   // 8 bytes per lane is the fastest width here (measured at O320 sp: 7.9 ms, against 9.2 ms at 16 bytes and 9.0 ms scalar):
   // the VW sets of 21 weights a thread keeps live cost more occupancy than the wider accesses save
   int vw = 2;
   { const char* e_ = getenv("ECWAM_HIP_GEN_VW"); if (e_) vw = atoi(e_); }  // diagnostics
+  const bool v4 = vw >= W && aligned && NFRE % W == 0 && NR % W == 0 && m0 % W == 0 && m1 % W == 0;
+  const bool v2 = vw >= 2 && aligned && NFRE % 2 == 0 && NR % 2 == 0 && m0 % 2 == 0 && m1 % 2 == 0;
   if (!f1)
-    hipLaunchKernelGGL((k_propags2_gen<T, 1, true>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
-  else if (vw >= W && aligned && NFRE % W == 0 && NR % W == 0 && m0 % W == 0 && m1 % W == 0)
-    hipLaunchKernelGGL((k_propags2_gen<T, W, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
-  else if (vw >= 2 && aligned && NFRE % 2 == 0 && NR % 2 == 0 && m0 % 2 == 0 && m1 % 2 == 0)
-    hipLaunchKernelGGL((k_propags2_gen<T, 2, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
+    hipLaunchKernelGGL((k_propags2_gen<T, 1, true, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
+  else if (obs) {
+    if (v2) hipLaunchKernelGGL((k_propags2_gen<T, 2, false, true>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
+    else hipLaunchKernelGGL((k_propags2_gen<T, 1, false, true>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
+  } else if (v4)
+    hipLaunchKernelGGL((k_propags2_gen<T, W, false, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
+  else if (v2)
+    hipLaunchKernelGGL((k_propags2_gen<T, 2, false, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
   else
-    hipLaunchKernelGGL((k_propags2_gen<T, 1, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
+    hipLaunchKernelGGL((k_propags2_gen<T, 1, false, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
 #undef GEN_ARGS
 }
 template <typename T>
@@ -1078,7 +1129,7 @@ void launch_pack(const void* fl, const int* idx, int n, int rowlen, void* buf, h
                                    int, int, int, int, hipStream_t);                                                              \
   template void launch_ctuw<T>(const void*, int, int, int, double, int, int, const int*, const void*, double, const void*,       \
                                const void*, const int*, const int*, const int*, void*, void*, const void*, const void*, void*,   \
-                               int*, int, hipStream_t);                                                                           \
+                               int*, int, const void*, hipStream_t);                                                              \
   template void launch_newwind<T>(const void*, int, void*, const void*, hipStream_t);                                             \
   template void launch_propdot<T>(const void*, int, int, int, const int*, const void*, double, const void*, const int*,         \
                                   const int*, const void*, const void*, const void*, const void*, const void*, void*, hipStream_t); \
@@ -1087,10 +1138,10 @@ void launch_pack(const void* fl, const int* idx, int n, int rowlen, void* buf, h
   template void launch_propags2_gen<T>(const void*, int, const void*, void*, int, double, const int*, const void*, double,        \
                                        const void*, const void*, const int*, const int*, const int*, const void*, const void*,   \
                                        const void*, const void*, const void*, const void*, const void*, int*, int, int, int, int, \
-                                       int, int, int, hipStream_t);                                                                    \
+                                       int, int, int, const void*, hipStream_t);                                                                    \
   template void launch_propags2_otf<T>(const void*, const void*, void*, int, int, double, const int*, const void*, double,        \
                                        const void*, const void*, const int*, const int*, const int*, const void*, const void*,   \
-                                       const void*, const void*, const int*, int, int, int, int, int, int, hipStream_t);         \
+                                       const void*, const void*, const int*, int, int, int, int, int, int, const void*, hipStream_t); \
   template void launch_c2p<T>(const void*, void*, int, int, int, int, int, hipStream_t);                                          \
   template void launch_p2c<T>(const void*, void*, int, int, int, int, int, hipStream_t);                                          \
   template void launch_pack<T>(const void*, const int*, int, int, void*, hipStream_t);

@@ -141,3 +141,20 @@ def currents(grid, amp: float = 0.8, undefined_band: float = 10.0):
     u[undef] = 0.0
     v[undef] = 0.0
     return u, v
+
+
+def obstructions(grid, nfre: int, seed: int = 99, fraction: float = 0.25):
+    """Synthetic sub-grid obstruction (transmission) coefficients OBS[n][8][NFRE] = OBSLAT(IJ,M,1:2), OBSLON(IJ,M,1:2),
+    OBSCOR(IJ,M,1:4) (getbobstrct.F90 reads the real ones from the grid file): 1 (open) at most points, 0.3 .. 1 at a
+    seeded fraction, weaker blocking for the longer waves (low frequencies diffract around small islands), 0 in a few
+    directions.  Function of the global point index only."""
+    rng = np.random.default_rng(seed)
+    n = grid.nsea
+    obs = np.ones((n, 8, nfre))
+    hit = rng.uniform(size=(n, 8)) < fraction
+    base = rng.uniform(0.3, 1.0, (n, 8))
+    base[rng.uniform(size=(n, 8)) < 0.02] = 0.0
+    ramp = np.linspace(0.0, 1.0, nfre)[None, None, :]            # short waves are blocked fully, long ones half as much
+    val = 1.0 - (1.0 - base[:, :, None]) * (0.5 + 0.5 * ramp)
+    obs[hit] = val[hit]
+    return obs

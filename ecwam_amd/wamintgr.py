@@ -158,6 +158,16 @@ class Wamintgr:
         self.fl1[self.dom.nland].zero_()
         self.fl3[self.dom.nland].zero_()
 
+    def set_obstructions(self, obs_global) -> None:
+        """LSUBGRID: OBS[nsea][8][NFRE] for ALL sea points (this rank keeps its owned rows); None switches it off.  The
+        weights change: the next step re-runs the CTUW checks (and rebuilds W in the stored-weight scheme)."""
+        if obs_global is None:
+            self.ctx.set_obstructions(None)
+        else:
+            own = np.ascontiguousarray(np.asarray(obs_global)[self.dom.lo:self.dom.hi], dtype=self.npdt)
+            self.ctx.set_obstructions(torch.from_numpy(own).to(self.dev))
+        self.weights_ready = False
+
     def set_environment(self, depth_ext, u_ext, v_ext, omosnh2kd_ext, wavnum_ext) -> None:
         """DEPTH / UCUR / VCUR [nrows] and OMOSNH2KD / WAVNUM [nrows][NFRE] including halo and land rows (what PROENVHALO
         assembles): a new current field makes the next step rebuild the dot terms and re-check the weights (LLUPDTTD /

@@ -128,6 +128,14 @@ int ecwam_hip_create(const ecwam_hip_params *p, const ecwam_hip_tables *t, int r
 int ecwam_hip_destroy(ecwam_hip_ctx *ctx);
 
 /*
+ * LSUBGRID: sub-grid obstructions of YOWUBUF (OBSLAT, OBSLON, OBSCOR; getbobstrct.F90 reads them, ctuw.F90:703-733 scales
+ * the space weights with them).  obs: device real OBS[n][8][NFRE], planes OBSLAT(IJ,M,1:2), OBSLON(IJ,M,1:2), OBSCOR(IJ,M,1:4)
+ * (values in [0,1], 1 = open); the library keeps the POINTER (the caller owns the memory) and every later ecwam_hip_ctuw /
+ * ecwam_hip_propags2_otf / ecwam_hip_propags2_refra applies it.  obs = NULL switches it off (LSUBGRID = F, the default).
+ */
+int ecwam_hip_set_obstructions(ecwam_hip_ctx *ctx, const void *obs, int n);
+
+/*
  * PROPAGS2 (propags2.F90:10, IREFRA=0 branch :99-121) on device pointers.
  *   f1, f3      FL[npts+1][NANG][NFRE]; only rows [kijs,kijl) of f3 are written; frequencies
  *               [nd3s-1, nd3e) are advected (1-based inclusive as in the reference);

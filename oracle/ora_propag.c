@@ -11,6 +11,28 @@
  */
 #include "ora.h"
 
+/* LSUBGRID: OBS[ij][8][NFRE] = OBSLAT(IJ,M,1:2), OBSLON(IJ,M,1:2), OBSCOR(IJ,M,1:4) used by the next ora_ctuw* calls (NULL: none) */
+static const real *g_obs = NULL;
+void ora_set_obstructions(const real *obs) { g_obs = obs; }
+/* ctuw.F90:703-733: the blocking coefficients scale the weights of the surrounding points (after the checks; SUMWN untouched) */
+static void apply_obstructions(int n, int MSTART, int MEND, real *WLONN, real *WLATN, real *WCORN) {
+  const int NANG = S.NANG, NFRE = S.NFRE, NR = S.NFRE_RED;
+  if (!g_obs) return;
+  for (int IJ = 0; IJ < n; IJ++)
+    for (int K = 0; K < NANG; K++)
+      for (int M = MSTART - 1; M < MEND; M++) {
+        size_t b = ((size_t)IJ * NANG + K) * NR + M;
+        const real *o = g_obs + (size_t)IJ * 8 * NFRE + M;
+        for (int IC = 0; IC < 2; IC++) {
+          for (int ICL = 0; ICL < 2; ICL++) WLATN[(b * 2 + IC) * 2 + ICL] = WLATN[(b * 2 + IC) * 2 + ICL] * o[IC * NFRE];
+          WLONN[b * 2 + IC] = WLONN[b * 2 + IC] * o[(2 + IC) * NFRE];
+        }
+        for (int ICR = 0; ICR < 4; ICR++)
+          for (int ICL = 0; ICL < 2; ICL++)
+            WCORN[(b * 4 + ICR) * 2 + ICL] = WCORN[(b * 4 + ICR) * 2 + ICL] * o[(4 + (S.KCR[K][ICR] - 1)) * NFRE];
+      }
+}
+
 /* ctuwini.F90:58-99 (mutates WLAT/WCOR near land) + :157-164 (DP) */
 void ora_ctuwini(int n, int nland, int ngy, const int *KXLT, const real *COSPH, const real *COSPHM1_EXT,
                  const int *KLAT, const int *KCOR, real *WLAT, real *WCOR, real *WLATM1, real *WCORM1, real *DP) {
@@ -140,6 +162,7 @@ int ora_ctuw(int n, int nland, real DELPRO, int MSTART, int MEND, const int *KXL
       }
   int nfail = 0;
   for (int IJ = 0; IJ < n; IJ++) nfail += LCFLFAIL[IJ];
+  if (!nfail) apply_obstructions(n, MSTART, MEND, WLONN, WLATN, WCORN); /* ctuw.F90:691-733: only reached without a failure */
   return nfail;
 }
 
@@ -429,6 +452,7 @@ int ora_ctuw_gen(int n, int IREFRA, int LLCFLCUROFF, real DELPRO, int MSTART, in
     nfail = 0;
     for (int IJ = 0; IJ < n; IJ++) nfail += LCFLFAIL[IJ];
   }
+  if (!nfail) apply_obstructions(n, MSTART, MEND, WLONN, WLATN, WCORN);
   return nfail;
 }
 

@@ -147,6 +147,11 @@ class Oracle:
         self.lib.ora_newwind(C.c_int(ff.shape[0]), self._p(ff), self._p(ffn))
         return ff
 
+    def set_obstructions(self, obs):
+        """LSUBGRID: OBS[n][8][NFRE] (OBSLAT 1:2, OBSLON 1:2, OBSCOR 1:4 per frequency) for the following ctu_weights* calls."""
+        self._obs = None if obs is None else np.ascontiguousarray(obs, dtype=self.dtype)
+        self.lib.ora_set_obstructions(None if self._obs is None else self._p(self._obs))
+
     def ctu_weights(self, grid, cgroup_ext, delpro, mstart=1, mend=None):
         """CTUWINI + CTUW for all owned points of `grid` (a ecwam_amd.grid.Grid-like object).
         cgroup_ext: [(npts+1)][NFRE] incl. land row.  Returns dict of reference-shaped weight arrays and

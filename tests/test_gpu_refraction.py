@@ -233,3 +233,114 @@ def test_decomposed_step_with_overlapped_exchange_is_bit_identical(api, irefra, 
     assert np.array_equal(got, ref.fl1[: g.nsea].cpu().numpy())
     for m in parts + [ref]:
         m.ctx.close()
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+@pytest.mark.parametrize("irefra", [0, 2])
+def test_subgrid_obstructions(api, prec, irefra):
+    """LSUBGRID (ctuw.F90:703-733): the transmission coefficients OBSLAT/OBSLON/OBSCOR scale the space weights of the
+    neighbours after the checks; SUMWN is left alone (blocked energy is lost).  Stored weights, on-the-fly weights and the
+    refraction kernel against the oracle; switching the table off restores the plain result."""
+    from ecwam_amd import synthetic as syn
+
+    c = _case(prec, irefra)
+    cfg, n, NR, g = c["cfg"], c["n"], c["cfg"].nfre_red, c["g"]
+    obs = syn.obstructions(g, cfg.nfre).astype(H.np_dtype(prec))
+    from oracle.oracle import Oracle
+    o = Oracle(cfg, prec)
+    o.set_obstructions(obs)
+    if irefra:
+        dot = o.propdot(g, irefra, c["dep"], c["u"], c["v"], c["wn"], c["cg"], c["om"])
+        w = o.ctu_weights_gen(g, irefra, c["cg"], c["om"], c["u"], c["v"], dot, float(cfg.idelpro))
+        f3ref = o.propags2_gen(g, c["f1"], w)
+    else:
+        w = o.ctu_weights(g, c["cg"], float(cfg.idelpro))
+        f3ref = o.propags2(g, c["f1"], w)
+    assert w["NFAIL"] == 0
+    o.set_obstructions(None)
+    w0 = o.ctu_weights(g, c["cg"], float(cfg.idelpro))
+    assert np.array_equal(w0["SUMWN"], w["SUMWN"]) if not irefra else True
+    assert (w["WLONN"] <= o.ctu_weights_gen(g, irefra, c["cg"], c["om"], c["u"], c["v"], dot, float(cfg.idelpro))["WLONN"]).all() if irefra else (w["WLONN"] <= w0["WLONN"]).all()
+    ctx = api.HipContext(c["t"])
+    dev = ctx.device
+    gd = api.grid_to_device(g, ctx.dtype, dev)
+    td = {k: torch.from_numpy(c[k]).to(dev) for k in ("cg", "om", "wn", "dep", "u", "v", "f1")}
+    tobs = torch.from_numpy(obs).to(dev)
+    ctx.set_obstructions(tobs)
+    fail = torch.zeros(n, dtype=torch.int32, device=dev)
+    eps = np.finfo(H.np_dtype(prec)).eps
+    fsc = np.abs(f3ref).max()
+    if irefra:
+        refr = torch.zeros((n, 2 * cfg.nang + 5), dtype=ctx.dtype, device=dev)
+        ctx.propdot(gd, td["dep"], td["u"], td["v"], refr)
+        ctx.ctuw_refra(gd, td["cg"], td["om"], td["wn"], refr, fail, float(cfg.idelpro))
+        f3 = torch.full_like(td["f1"], -7.0)
+        ctx.propags2_refra(td["f1"], f3, gd, td["cg"], td["om"], td["wn"], refr, float(cfg.idelpro), 0, n)
+        torch.cuda.synchronize()
+        got = f3.cpu().numpy()
+        assert np.abs(got[:n, :, :NR].astype(float) - f3ref[:n, :, :NR].astype(float)).max() < 32 * eps * fsc
+        ctx.set_obstructions(None)
+        f3b = torch.full_like(td["f1"], -7.0)
+        ctx.propags2_refra(td["f1"], f3b, gd, td["cg"], td["om"], td["wn"], refr, float(cfg.idelpro), 0, n)
+        torch.cuda.synchronize()
+        assert np.abs(f3b.cpu().numpy()[:n] - got[:n]).max() > 1e3 * eps * fsc       # the table acted
+    else:
+        wdev = torch.zeros((n, 8, cfg.nang * NR), dtype=ctx.dtype, device=dev)
+        ctx.ctuw(gd, td["cg"], wdev, fail, float(cfg.idelpro))
+        f3s = torch.full_like(td["f1"], -7.0)
+        ctx.propags2(td["f1"], f3s, gd["klon"], gd["klat"], gd["kcor"], wdev, 0, n)
+        f3o = torch.full_like(td["f1"], -7.0)
+        ctx.propags2_otf(td["f1"], f3o, gd, td["cg"], float(cfg.idelpro), 0, n)
+        f3p = torch.full_like(td["f1"], -7.0)
+        ctx.propags2_otf(td["f1"], f3p, gd, td["cg"], float(cfg.idelpro), 3, n - 2, 1, 5, copy_rest=False)   # scalar kernel variant
+        torch.cuda.synchronize()
+        got = f3o.cpu().numpy()
+        assert np.array_equal(got, f3s.cpu().numpy())                                # stored and on-the-fly: same bits
+        assert np.array_equal(f3p.cpu().numpy()[3:n - 2, :, :5], got[3:n - 2, :, :5])
+        assert np.abs(got[:n, :, :NR].astype(float) - f3ref[:n, :, :NR].astype(float)).max() < 16 * eps * fsc
+        ctx.set_obstructions(None)
+        f3b = torch.full_like(td["f1"], -7.0)
+        ctx.propags2_otf(td["f1"], f3b, gd, td["cg"], float(cfg.idelpro), 0, n)
+        torch.cuda.synchronize()
+        plain = o.propags2(g, c["f1"], w0)
+        assert np.abs(f3b.cpu().numpy()[:n, :, :NR].astype(float) - plain[:n, :, :NR].astype(float)).max() < 16 * eps * fsc
+        assert np.abs(f3b.cpu().numpy()[:n] - got[:n]).max() > 1e3 * eps * fsc
+        # energy only leaves: the obstructed field never exceeds the open one
+        assert (got[:n, :, :NR] <= f3b.cpu().numpy()[:n, :, :NR] * (1 + 8 * eps) + 1e-300).all()
+    assert int(fail.sum()) == 0
+    ctx.close()
+
+
+def test_decomposed_step_with_obstructions_is_bit_identical(api):
+    from ecwam_amd import grid as G, synthetic as syn
+    from ecwam_amd.wamintgr import Wamintgr
+
+    cfg = Config(nang=12, nfre=36, nfre_red=28, idelt=600, idelpro=600)
+    g = G.build_grid(20, mask="continents")
+    obs = syn.obstructions(g, cfg.nfre)
+    ref = Wamintgr(cfg, g, "sp")
+    ref.init_synthetic(seed=11)
+    ref.set_obstructions(obs)
+    assert ref.build_weights() == 0
+    plain = Wamintgr(cfg, g, "sp")
+    plain.init_synthetic(seed=11)
+    parts, snapshot = [], {}
+    for r in range(3):
+        m = Wamintgr(cfg, g, "sp", rank=r, nranks=3)
+        m.init_synthetic(seed=11)
+        m.set_obstructions(obs)
+        assert m.build_weights() == 0
+        m.halo = _LateHalo(m, lambda: snapshot["glob"])
+        parts.append(m)
+    for _ in range(2):
+        ref.step()
+        plain.step()
+        snapshot["glob"] = torch.cat([m.fl1[: m.n] for m in parts])
+        for m in parts:
+            m.step()
+    torch.cuda.synchronize()
+    got = torch.cat([m.fl1[: m.n] for m in parts]).cpu().numpy()
+    assert np.array_equal(got, ref.fl1[: g.nsea].cpu().numpy())
+    assert not np.array_equal(got, plain.fl1[: g.nsea].cpu().numpy())
+    for m in parts + [ref, plain]:
+        m.ctx.close()

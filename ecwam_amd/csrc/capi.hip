@@ -209,14 +209,14 @@ int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int r
     std::vector<DevTab<float>> h(1);
     build_tab<float>(p, t, h.data());
     c->implsch_variant = h[0].DIA_PULL ? 2 : 1;
-    if ((p->llgcbz0 || p->lciwa1 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou || p->lwnemocouwrs || p->lwnemocoustrn || p->isnonlin || p->iphys == 0 || p->icode != 3) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
+    if ((p->llgcbz0 || p->lciwa1 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou || p->lwnemocouwrs || p->lwnemocoustrn || p->isnonlin || p->iphys == 0 || p->icode != 3 || !p->lwvflx_snl) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
     HIPCHK(hipMalloc(&c->dtab, sizeof(DevTab<float>)));
     HIPCHK(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<float>), hipMemcpyHostToDevice));
   } else {
     std::vector<DevTab<double>> h(1);
     build_tab<double>(p, t, h.data());
     c->implsch_variant = h[0].DIA_PULL ? 2 : 1;
-    if ((p->llgcbz0 || p->lciwa1 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou || p->lwnemocouwrs || p->lwnemocoustrn || p->isnonlin || p->iphys == 0 || p->icode != 3) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
+    if ((p->llgcbz0 || p->lciwa1 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou || p->lwnemocouwrs || p->lwnemocoustrn || p->isnonlin || p->iphys == 0 || p->icode != 3 || !p->lwvflx_snl) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
     HIPCHK(hipMalloc(&c->dtab, sizeof(DevTab<double>)));
     HIPCHK(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<double>), hipMemcpyHostToDevice));
   }
@@ -405,7 +405,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   int rc, variant = c->implsch_variant;
   { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_VARIANT"); if (e_ && atoi(e_) == 1) variant = 1; }  // diagnostics: force the 3-tile kernel
   if (c->p.llnormagam) variant |= 16;
-  if (c->p.llgcbz0 || c->p.lciwa1 || c->p.lciwa2 || c->p.lciwa3 || c->p.lciscal || c->p.lwnemocou || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin || c->p.iphys == 0 || c->p.icode != 3) variant |= 32;
+  if (c->p.llgcbz0 || c->p.lciwa1 || c->p.lciwa2 || c->p.lciwa3 || c->p.lciscal || c->p.lwnemocou || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin || c->p.iphys == 0 || c->p.icode != 3 || !c->p.lwvflx_snl) variant |= 32;
   DISPATCH(rc = launch_implsch<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s),
            rc = launch_implsch<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s));
   if (rc) return fail("ecwam_hip_implsch: unsupported spectral size for the LDS tiling");

@@ -1207,6 +1207,7 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
           // --- SSOURCE, SDIWBK, SBOTTOM, new spectrum
           T ss = T(0);
           if (flux_snl) ss = f_div(sl, m_max(T(1) - DELT5 * fld, T(1)));
+          else if (RARE && tb.LCFLX) ss = fldw * f;  // LWVFLX_SNL = F: SL after SDISSIP, before SNONLIN, unmodulated (implsch.F90:280-288)
           if (shallow_brk && m < tb.NFRE_RED) { sl = sl - SDS * f; fld = fld - SDS; }
           if (ice_scal) { sl = BETA * sl; fld = BETA * fld; }
           T fldice_last = T(0);  // FLDICE of the last active SDICEn: each overwrites SLICE (sdice.F90:94-110)

@@ -264,6 +264,28 @@ def test_implsch_parity_isnonlin_1_2(api, prec, isnonlin):
 
 
 @pytest.mark.parametrize("prec", ["dp", "sp"])
+def test_implsch_fluxes_without_the_nonlinear_transfer(api, prec):
+    """LWVFLX_SNL = F (implsch.F90:280-288): the ocean fluxes integrate the source function as it stands after SDISSIP,
+    before SNONLIN and without the implicit factor."""
+    cfg = Config(nang=24, nfre=36, nfre_red=29, lwvflx_snl=False)
+    n = 512
+    case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=71)
+    ref = H.oracle_implsch(case, _oracle(cfg, prec))
+    ctx = api.HipContext(case["tables"])
+    got = H.gpu_implsch(case, ctx)
+    st = H.compare_implsch(ref, got, case["tables"])
+    ctx.close()
+    if prec == "dp":
+        assert st["mij_flips"] == 0 and st["fl1_max_rel_peak_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
+    else:
+        assert st["mij_flips"] <= n * 0.005 and st["fl1_max_rel_peak_clean"] < 1e-4 and st["intf_max_rel_clean"] < 5e-3, st
+    cfg1 = Config(nang=24, nfre=36, nfre_red=29)
+    c1 = dict(case); c1["cfg"] = cfg1; c1["tables"] = Tables(cfg1, H.np_dtype(prec))
+    r1 = H.oracle_implsch(c1, _oracle(cfg1, prec))
+    assert np.array_equal(r1["FL1"], ref["FL1"]) and np.max(np.abs(r1["INTF"][:, 12] - ref["INTF"][:, 12])) > 0   # only the fluxes change
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
 @pytest.mark.parametrize("tauoc", [True, False])
 def test_implsch_wam2nemo_outputs(api, prec, tauoc):
     """LWNEMOCOU: the 13 WAVE2OCEAN members (always double) -- instantaneous NPHIEPS/NTAUOC/NSWH/NMWP/NEMO*STOKES and the

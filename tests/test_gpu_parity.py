@@ -263,6 +263,42 @@ def test_implsch_parity_isnonlin_1_2(api, prec, isnonlin):
     assert np.max(np.abs(r0["FL1"] - ref["FL1"])) > 0                             # the option acts
 
 
+_SWEEP = [dict(llcapchnk=False), dict(lbiwbk=False), dict(licerun=False), dict(lmaskice=False), dict(lwamrsetci=False),
+          dict(lwflux=True), dict(lwfluxout=False), dict(lwcouast=False), dict(lwcou=True), dict(lwcou=True, lwnemocou=True, lwnemocousend=False),
+          dict(lwnemocou=True, lwnemocoustk=False), dict(ximp=0.5), dict(idelt=300), dict(llcapchnk=False, llnormagam=True),
+          dict(llgcbz0=True, llcapchnk=False), dict(licerun=False, lwnemocou=True), dict(lwfluxout=False, lwflux=False),
+          dict(iphys=0, lwamrsetci=False), dict(iphys=0, lbiwbk=False, lwflux=True)]
+
+
+@pytest.mark.parametrize("flags", _SWEEP, ids=lambda f: ",".join(f"{k}={v}" for k, v in f.items()))
+def test_implsch_single_flag_sweep(api, flags):
+    """Every switch the IMPLSCH tree consults, flipped away from its default one (or two) at a time, double precision,
+    with partial ice cover, shallow points and a non-zero atmospheric stress input: device against oracle."""
+    prec = "dp"
+    cfg = Config(nang=24, nfre=36, nfre_red=29, **flags)
+    n = 384
+    case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=81)
+    rng = np.random.default_rng(12)
+    case["FF"][:, 2] = np.where(rng.uniform(size=n) < 0.5, rng.uniform(0.0, 1.0, n), 0.0)      # CICOVER
+    case["FF"][:, 13] = rng.uniform(0.0, 2.0, n)                                              # CITHICK
+    case["FF"][:, 5] = np.where(rng.uniform(size=n) < 0.5, rng.uniform(-0.3, 0.3, n), 0.0)     # USTRA
+    case["FF"][:, 6] = np.where(case["FF"][:, 5] != 0, rng.uniform(-0.3, 0.3, n), 0.0)         # VSTRA
+    if cfg.lwnemocou:
+        case["W2N"] = rng.uniform(-1.0, 1.0, (n, 13))
+    ref = H.oracle_implsch(case, _oracle(cfg, prec))
+    ctx = api.HipContext(case["tables"])
+    got = H.gpu_implsch(case, ctx)
+    st = H.compare_implsch(ref, got, case["tables"])
+    ctx.close()
+    assert st["mij_flips"] == 0 and st["xllws_bins_diff"] == 0, st
+    assert st["fl1_max_rel_peak_all"] < 1e-10 and st["ff_max_rel_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
+    r, g = ref["INTF"][:, :2].astype(float), got["INTF"][:, :2].astype(float)                  # WSEMEAN, WSFMEAN (LWFLUX)
+    assert np.max(np.abs(g - r) / np.maximum(np.abs(r), 1e-30)) < 1e-10
+    if cfg.lwnemocou:
+        sc = np.maximum(np.abs(ref["W2N"]).max(axis=0, keepdims=True), 1e-12)
+        assert np.max(np.abs(got["W2N"] - ref["W2N"]) / sc) < 1e-10
+
+
 @pytest.mark.parametrize("prec", ["dp", "sp"])
 def test_implsch_fluxes_without_the_nonlinear_transfer(api, prec):
     """LWVFLX_SNL = F (implsch.F90:280-288): the ocean fluxes integrate the source function as it stands after SDISSIP,

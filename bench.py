@@ -101,6 +101,10 @@ def main() -> None:
     ap.add_argument("--weights", default="otf", choices=["otf", "stored"],
                     help="CTU weights rebuilt inside PROPAGS2 (default) or streamed from the stored W array")
     ap.add_argument("--strip", type=int, default=0, help="longitude-strip width of the advection work order (0: natural order)")
+    ap.add_argument("--adv-per-source", type=int, default=1,
+                    help="advection steps per source-term step (1: the O320 configuration; 2: O1280's native 450 s / 900 s ratio)")
+    ap.add_argument("--ifrelfmax", type=int, default=0,
+                    help="fast waves: frequencies 1..IFRELFMAX advected with two sub-steps of half the time step (O1280: 5)")
     ap.add_argument("--irefra", type=int, default=0, choices=[0, 1, 2, 3],
                     help="refraction: 0 none (BASELINE configurations), 1 depth, 2 currents, 3 both (synthetic current field)")
     a = ap.parse_args()
@@ -123,7 +127,8 @@ def main() -> None:
     dt = 450 if ng <= 320 else max(15, int(450 * 320 / ng) // 15 * 15)
     cfg = Config(nang=a.nang, nfre=a.nfre, nfre_red=a.nfre, idelt=dt, idelpro=dt, irefra=a.irefra)
     grid = G.build_grid(ng)
-    m = Wamintgr(cfg, grid, a.prec, device=local_rank, rank=rank, nranks=world, weights=a.weights, strip_width=a.strip)
+    m = Wamintgr(cfg, grid, a.prec, device=local_rank, rank=rank, nranks=world, weights=a.weights, strip_width=a.strip,
+                 ifrelfmax=a.ifrelfmax, delpro_lf=(dt / 2.0 if a.ifrelfmax else None))
     m.init_synthetic()
     nfail = m.build_weights()
     if nfail:
@@ -135,15 +140,22 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
+    def step_untimed():
+        for _ in range(a.adv_per_source):
+            m.propag()
+        m.newwind()
+        m.implsch()
+
     for _ in range(a.warmup):
-        m.step()
+        step_untimed()
     sync()
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(a.steps)]
     t0 = time.perf_counter()
     for s in range(a.steps):
         e = ev[s]
         e[0].record()
-        m.propag()            # halo exchange (N > 1) + PROPAGS2
+        for _ in range(a.adv_per_source):
+            m.propag()        # halo exchange (N > 1) + PROPAGS2 (+ fast-wave sub-steps)
         e[1].record()
         m.newwind()
         e[2].record()
@@ -172,7 +184,8 @@ def main() -> None:
         else:
             b_prop = w * (2 * NR + a.nfre + 13) + 60     # F1 + F3 + own CGROUP row + point geometry, 15 int32 ids
         kern = {
-            "propags2": {"ms": t_prop, "alg_bytes": b_prop * m.n, "gbs": b_prop * m.n / t_prop / 1e6},
+            "propags2": {"ms": t_prop, "alg_bytes": b_prop * m.n * a.adv_per_source,
+                         "gbs": b_prop * m.n * a.adv_per_source / t_prop / 1e6},
             "implsch": {"ms": t_impl, "alg_bytes": b_impl * m.n, "gbs": b_impl * m.n / t_impl / 1e6},
         }
         dom = max(kern, key=lambda k: kern[k]["ms"])
@@ -206,7 +219,9 @@ def main() -> None:
             "config": {"workload": f"O{ng} all-ocean octahedral grid, {grid.nsea} sea points, {a.nang} dir x {a.nfre} freq "
                                    f"(NFRE_RED={cfg.nfre_red}), full WAMINTGR step = PROPAGS2 advection + NEWWIND + IMPLSCH, "
                                    f"IDELT=IDELPRO={dt} s, flag set A (IPHYS=1, ISNONLIN=0, LLGCBZ0=F, LLNORMAGAM=F)"
-                                   + (f", IREFRA={a.irefra} (synthetic currents)" if a.irefra else ""),
+                                   + (f", IREFRA={a.irefra} (synthetic currents)" if a.irefra else "")
+                                   + (f", {a.adv_per_source} advection steps per source step" if a.adv_per_source != 1 else "")
+                                   + (f", fast waves M<={a.ifrelfmax} in two sub-steps" if a.ifrelfmax else ""),
                        "points_per_gpu": m.n, "halo_points": m.dom.nh, "parallelism": f"sea-point block x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic},

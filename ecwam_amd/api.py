@@ -116,7 +116,8 @@ class HipContext:
 
     # -- PROPAGS2 with on-the-fly CTU weights (no W array): same result as ctuw() + propags2()
     def propags2_otf(self, f1, f3, grid_dev: dict, cgroup_ext, delpro: float, kijs, kijl, nd3s=1, nd3e=None, copy_rest=True,
-                     order=None):
+                     order=None, ifrelfmax: int = 0, delpro_lf: float | None = None):
+        """ifrelfmax > 0: frequencies 1..ifrelfmax advance with delpro_lf, the others with delpro, in the same pass."""
         nd3e = self.NR if nd3e is None else nd3e
         g = grid_dev
         n, nland, ngy = g["n"], g["nland"], g["ngy"]
@@ -126,13 +127,22 @@ class HipContext:
         po = None if order is None else self._int(order, (order.shape[0],), "ORDER")
         if order is not None and order.shape[0] < kijl:
             raise ValueError("PROPAGS2: ORDER shorter than KIJL")
+        dlf = float(delpro if delpro_lf is None else delpro_lf)
         args = [self._real(f1, (nrow, self.NANG, self.NFRE), "F1"), self._real(f3, (nrow, self.NANG, self.NFRE), "F3"), n, ngy,
-                float(delpro), self._int(g["kxlt"], (n,), "KXLT"), self._real(g["zdello"], (ngy,), "ZDELLO"), float(g["xdella"]),
-                self._real(g["cosph"], (ngy,), "COSPH"), self._real(g["sinph"], (ngy,), "SINPH"),
+                float(delpro), dlf, int(ifrelfmax), self._int(g["kxlt"], (n,), "KXLT"), self._real(g["zdello"], (ngy,), "ZDELLO"),
+                float(g["xdella"]), self._real(g["cosph"], (ngy,), "COSPH"), self._real(g["sinph"], (ngy,), "SINPH"),
                 self._int(g["klon"], (n, 2), "KLON"), self._int(g["klat"], (n, 2, 2), "KLAT"), self._int(g["kcor"], (n, 4, 2), "KCOR"),
                 self._real(g["wlat"], (n, 2), "WLAT"), self._real(g["wcor"], (n, 4), "WCOR"),
                 self._real(cgroup_ext, (nrow, self.NFRE), "CGROUP_EXT"), self._real(g["cosphm1_ext"], (nrow,), "COSPHM1_EXT"), po]
-        self._chk(self.lib.ecwam_hip_propags2_otf(self._h, *args, kijs, kijl, nd3s, nd3e, int(copy_rest), _stream_ptr()))
+        self._chk(self.lib.ecwam_hip_propags2_otf_split(self._h, *args, kijs, kijl, nd3s, nd3e, int(copy_rest), _stream_ptr()))
+
+    # -- FL1_EXT(:,:,M1:M2) <- FL3_EXT between the fast-wave sub-steps (propag_wam.F90:287-291)
+    def copy_freq_range(self, src, dst, n, m_first, m_last):
+        shape = (src.shape[0], self.NANG, self.NFRE)
+        if n > src.shape[0] or dst.shape != src.shape:
+            raise ValueError("copy_freq_range: shapes")
+        self._chk(self.lib.ecwam_hip_copy_freq_range(self._h, self._real(src, shape, "SRC"), self._real(dst, shape, "DST"), n, m_first,
+                                                     m_last, _stream_ptr()))
 
     # -- refraction (IREFRA = 1, 2, 3): GRADI + PROPDOT per point, CTUWDRV checks, PROPAGS2 with all weights on the fly
     def _geom(self, g, n, ngy):

@@ -334,22 +334,27 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
                                                       const T* __restrict__ wlat, const T* __restrict__ wcor,
                                                       const T* __restrict__ cg, const T* __restrict__ cosphm1,
                                                       const int* __restrict__ order, int kijs, int kijl, int m0, int m1,
-                                                      int copy_rest, int ntiles, const T* __restrict__ obs) {
+                                                      int copy_rest, int ntiles, const T* __restrict__ obs, int mlf, T delpro_lf) {
+  // mlf > 0: frequencies [0, mlf) (the fast waves, IFRELFMAX) advance with delpro_lf, the others with delpro, in one pass
+  // (propag_wam.F90:247-283 calls PROPAGS2 once per range)
   extern __shared__ __align__(16) unsigned char otf_smem[];
   const int NANG = tab->NANG, NFRE = tab->NFRE;
   const int N = NANG * NFRE, NV = N / VW, FV = NFRE / VW;
   const T CMTODEG = T(360.0) / tab->CIRC;
   const T DELTH0 = T(0.25) * delpro / tab->DELTH;
+  const T DELTH0_LF = T(0.25) * delpro_lf / tab->DELTH;
   // LDS: point scalars, neighbour indices, CtuBase per (point, frequency) as 5 planes, direction factors
   CtuPoint<T>* sP = reinterpret_cast<CtuPoint<T>*>(otf_smem);
   int* sI = reinterpret_cast<int*>(sP + OTF_TP);                    // [TP][16]: ij, ilon[2], ilat[2][2], icor[4][2]
   T* sB = reinterpret_cast<T*>(sI + OTF_TP * 16);                   // [TP][5][NFRE]
-  T* sK = sB + (size_t)OTF_TP * 5 * NFRE;                           // [NANG][2]: (SINTH+SINTH(K+1))*DELTH0/R, same for K-1
-  T* sO = sK + 2 * NANG;                                            // OBS: [TP][8][NFRE] transmission coefficients
+  T* sK = sB + (size_t)OTF_TP * 5 * NFRE;                           // [NANG][4]: (SINTH+SINTH(K+1))*DELTH0/R, same for K-1; both for DELTH0_LF
+  T* sO = sK + 4 * NANG;                                            // OBS: [TP][8][NFRE] transmission coefficients
   for (int k = threadIdx.x; k < NANG; k += blockDim.x) {
     T a, b;
     ctu_dirfac(tab, k, DELTH0, T(1), a, b);  // TANPH applied per point below: TANPH*SP is formed as in k_ctuw
-    sK[2 * k] = a; sK[2 * k + 1] = b;
+    sK[4 * k] = a; sK[4 * k + 1] = b;
+    ctu_dirfac(tab, k, DELTH0_LF, T(1), a, b);
+    sK[4 * k + 2] = a; sK[4 * k + 3] = b;
   }
   // XCD-aware tile walk: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own 4 MiB L2.  XCD x
   // walks the contiguous tile range [x*tpx, (x+1)*tpx) so that a spectrum fetched as somebody's neighbour is still in that
@@ -377,7 +382,7 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
     for (int it = threadIdx.x; it < np * NFRE; it += blockDim.x) {
       const int t = it / NFRE, m = it - t * NFRE;
       const int* q = sI + t * 16;
-      if (m >= m0 && m < m1) {
+      if (m >= (m0 / VW) * VW && m < ((m1 + VW - 1) / VW) * VW) {   // whole vectors around the range (their spare lanes are computed, not stored)
         T cgl[2], cgy0[2], cgy1[2];
         for (int ic = 0; ic < 2; ic++) {
           cgl[ic] = cg[(size_t)q[1 + ic] * NFRE + m];
@@ -401,7 +406,7 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
       const size_t own = (size_t)q[0] * N;
       const int el = k * NFRE + m;
       typedef VecIO<T, VW> IO;
-      if (m < m0 || m >= m1) {
+      if (m + VW <= m0 || m >= m1) {   // no element of this vector is advected
         if (copy_rest & 1) {
           T v[VW];
           IO::ld(f1 + own + el, v);
@@ -409,15 +414,18 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
         }
         continue;
       }
+      const bool partial = (VW > 1) && (m < m0 || m + VW > m1);   // the range boundary cuts this vector
       const CtuPoint<T>& p = sP[t];
       const int jx0 = tab->JXO[k][0], jx1 = tab->JXO[k][1], jy0 = tab->JYO[k][0], jy1 = tab->JYO[k][1], kc = tab->KCR[k][0];
       const int km = tab->KPM[k][0], kp = tab->KPM[k][2];
       const T sink = tab->SINTH[k], cosk = tab->COSTH[k];
-      T tsp, tsm;
+      T tsp, tsm, tsp_lf, tsm_lf;
       {
 #pragma clang fp contract(off)
-        tsp = p.tanph * sK[2 * k];
-        tsm = p.tanph * sK[2 * k + 1];
+        tsp = p.tanph * sK[4 * k];
+        tsm = p.tanph * sK[4 * k + 1];
+        tsp_lf = p.tanph * sK[4 * k + 2];
+        tsm_lf = p.tanph * sK[4 * k + 3];
       }
       T fo[VW], flon[VW], fla1[VW], fla2[VW], fco1[VW], fco2[VW], fkm[VW], fkp[VW];
       IO::ld(f1 + own + el, fo);
@@ -436,12 +444,24 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
       for (int c = 0; c < VW; c++) {
         CtuBase<T> b;
         b.h[0] = bh0[c]; b.h[1] = bh1[c]; b.hy[0] = by0[c]; b.hy[1] = by1[c]; b.cg0 = bc0[c];
+        const bool lf = (m + c) < mlf;
         T w8[8];
-        (void)ctu_w8(b, sink, cosk, p.cpm1, p.zd, xdella, p.ga, delpro, CMTODEG, jx0, jx1, jy0, jy1, p.wl[jy0], p.wc[kc], tsp, tsm, w8);
+        (void)ctu_w8(b, sink, cosk, p.cpm1, p.zd, xdella, p.ga, lf ? delpro_lf : delpro, CMTODEG, jx0, jx1, jy0, jy1, p.wl[jy0], p.wc[kc],
+                     lf ? tsp_lf : tsp, lf ? tsm_lf : tsm, w8);
         if (OBS) ctu_obstruct8(w8, sO + (size_t)t * 8 * NFRE + m + c, NFRE, jx0, jy0, kc);
         const T a = ctu_stencil(w8[0], w8[1], w8[2], w8[3], w8[4], w8[5], w8[6], w8[7], fo[c], flon[c], fla1[c], fla2[c], fco1[c],
                                 fco2[c], fkm[c], fkp[c]);
         r[c] = a;
+      }
+      if (partial) {  // elements outside [m0, m1): carried over from F1 (copy_rest) or left as they are in F3
+        T keep[VW];
+        if (copy_rest & 1) {
+#pragma unroll
+          for (int c = 0; c < VW; c++) keep[c] = fo[c];
+        } else IO::ld(f3 + own + el, keep);
+#pragma unroll
+        for (int c = 0; c < VW; c++)
+          if (m + c < m0 || m + c >= m1) r[c] = keep[c];
       }
       IO::st(f3 + own + el, r);
     }
@@ -964,6 +984,19 @@ __global__ void k_points_to_chunks(const T* __restrict__ pt, T* __restrict__ ch,
   }
 }
 
+// F(:,:,m0:m1-1) of rows [0,n) from src to dst: FL1_EXT(:,:,1:IFRELFMAX) <- FL3_EXT between the fast-wave sub-steps
+// (propag_wam.F90:287-291); one thread per (row, K, m)
+template <typename T>
+__global__ void k_copy_freq_range(const T* __restrict__ src, T* __restrict__ dst, int n, int NANG, int NFRE, int m0, int m1) {
+  const int nm = m1 - m0;
+  const long long total = (long long)n * NANG * nm;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const long long run = g / nm;
+    const int m = m0 + (int)(g - run * nm);
+    dst[run * NFRE + m] = src[run * NFRE + m];
+  }
+}
+
 template <typename T>
 __global__ void k_pack_rows(const T* __restrict__ fl, const int* __restrict__ idx, int n, int rowlen, T* __restrict__ buf) {
   const long long total = (long long)n * rowlen;
@@ -1013,13 +1046,13 @@ template <typename T>
 void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, int ngy, double delpro, const int* kxlt,
                          const void* zdello, double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat,
                          const int* kcor, const void* wlat, const void* wcor, const void* cg, const void* cosphm1, const int* order,
-                         int kijs, int kijl, int m0, int m1, int copy_rest, int dims, const void* obs, hipStream_t s) {
+                         int kijs, int kijl, int m0, int m1, int copy_rest, int dims, const void* obs, int mlf, double delpro_lf, hipStream_t s) {
   const int NANG = dims >> 16, NFRE = (dims >> 8) & 0xFF;
   const int n = kijl - kijs;
   if (n <= 0) return;
   const int ntiles = (n + OTF_TP - 1) / OTF_TP;
   const size_t shmem = OTF_TP * (sizeof(CtuPoint<T>) + 16 * sizeof(int)) +
-                       ((size_t)OTF_TP * (obs ? 13 : 5) * NFRE + 2 * NANG) * sizeof(T) + 16;
+                       ((size_t)OTF_TP * (obs ? 13 : 5) * NFRE + 4 * NANG) * sizeof(T) + 16;
   int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
   grid = (grid + 7) & ~7;  // whole rounds of the 8 XCDs
   constexpr int W = VecOf<T>::W;
@@ -1027,16 +1060,16 @@ void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, 
 #define OTF_ARGS                                                                                                              \
   (const DevTab<T>*)tab, (const T*)f1, (T*)f3, n_geom, ngy, (T)delpro, kxlt, (const T*)zdello, (T)xdella, (const T*)cosph,     \
       (const T*)sinph, klon, klat, kcor, (const T*)wlat, (const T*)wcor, (const T*)cg, (const T*)cosphm1, order, kijs, kijl, m0, \
-      m1, copy_rest, ntiles, (const T*)obs
+      m1, copy_rest, ntiles, (const T*)obs, mlf, (T)delpro_lf
   int vw = W;
   { const char* e_ = getenv("ECWAM_HIP_OTF_VW"); if (e_) vw = atoi(e_); }  // diagnostics
-  const bool vec = vw >= W && aligned && NFRE % W == 0 && m0 % W == 0 && m1 % W == 0;
+  const bool vec = vw >= W && aligned && NFRE % W == 0;   // a range boundary inside a vector is handled by the kernel
   if (obs) {  // LSUBGRID
     if (vec) hipLaunchKernelGGL((k_propags2_otf<T, W, true>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
     else hipLaunchKernelGGL((k_propags2_otf<T, 1, true>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
   } else if (vec)
     hipLaunchKernelGGL((k_propags2_otf<T, W, false>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
-  else if (vw >= 2 && aligned && NFRE % 2 == 0 && m0 % 2 == 0 && m1 % 2 == 0)
+  else if (vw >= 2 && aligned && NFRE % 2 == 0)
     hipLaunchKernelGGL((k_propags2_otf<T, 2, false>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
   else
     hipLaunchKernelGGL((k_propags2_otf<T, 1, false>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
@@ -1118,6 +1151,12 @@ void launch_p2c(const void* pt, void* ch, int nproma, int nchnk, int npts, int n
   hipLaunchKernelGGL(k_points_to_chunks<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)pt, (T*)ch, nproma, nchnk, npts, n2, n3);
 }
 template <typename T>
+void launch_copy_freq_range(const void* src, void* dst, int n, int NANG, int NFRE, int m0, int m1, hipStream_t s) {
+  long long total = (long long)n * NANG * (m1 - m0);
+  if (total <= 0) return;
+  hipLaunchKernelGGL(k_copy_freq_range<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)src, (T*)dst, n, NANG, NFRE, m0, m1);
+}
+template <typename T>
 void launch_pack(const void* fl, const int* idx, int n, int rowlen, void* buf, hipStream_t s) {
   long long total = (long long)n * rowlen;
   if (total <= 0) return;
@@ -1141,9 +1180,11 @@ void launch_pack(const void* fl, const int* idx, int n, int rowlen, void* buf, h
                                        int, int, int, const void*, hipStream_t);                                                                    \
   template void launch_propags2_otf<T>(const void*, const void*, void*, int, int, double, const int*, const void*, double,        \
                                        const void*, const void*, const int*, const int*, const int*, const void*, const void*,   \
-                                       const void*, const void*, const int*, int, int, int, int, int, int, const void*, hipStream_t); \
+                                       const void*, const void*, const int*, int, int, int, int, int, int, const void*, int, double,   \
+                                       hipStream_t);                                                                              \
   template void launch_c2p<T>(const void*, void*, int, int, int, int, int, hipStream_t);                                          \
   template void launch_p2c<T>(const void*, void*, int, int, int, int, int, hipStream_t);                                          \
+  template void launch_copy_freq_range<T>(const void*, void*, int, int, int, int, int, hipStream_t);                               \
   template void launch_pack<T>(const void*, const int*, int, int, void*, hipStream_t);
 INST(float)
 INST(double)

@@ -212,7 +212,7 @@ class Wamintgr:
         c, g = self.cfg, self.gd
         lf = 0 < self.ifrelfmax < c.nfre_red
 
-        def advect_rows(k0, k1, m1, m2, delpro, copy_rest):
+        def advect_rows(k0, k1, m1, m2, delpro, copy_rest, split=0):
             if k1 <= k0:
                 return
             if self.irefra:
@@ -222,11 +222,11 @@ class Wamintgr:
                 self.ctx.propags2(self.fl1, self.fl3, g["klon"], g["klat"], g["kcor"], self.w, k0, k1, m1, m2, copy_rest=copy_rest)
             else:
                 self.ctx.propags2_otf(self.fl1, self.fl3, g, self.cgroup_ext, delpro, k0, k1, m1, m2, copy_rest=copy_rest,
-                                      order=self.order)
+                                      order=self.order, ifrelfmax=split, delpro_lf=self.delpro_lf if split else None)
 
-        def advect(m1, m2, delpro, copy_rest, rows=None):
+        def advect(m1, m2, delpro, copy_rest, split=0, rows=None):
             k0, k1 = rows if rows is not None else (0, self.n)
-            advect_rows(k0, k1, m1, m2, delpro, copy_rest)
+            advect_rows(k0, k1, m1, m2, delpro, copy_rest, split)
 
         def exchange_and_advect(passes):
             """MPEXCHNG + PROPAGS2 (propag_wam.F90:166,247-313) with the exchange hidden behind the interior: post the halo
@@ -246,8 +246,12 @@ class Wamintgr:
                 advect(*a, rows=(0, ia))
                 advect(*a, rows=(ib, self.n))
 
+        otf_plain = self.weights == "otf" and not self.irefra
         if self.weights == "stored" or self.ifrelfmax <= 0:
             exchange_and_advect([(1, c.nfre_red, float(c.idelpro), True)])      # stored W already carries the per-range time steps
+        elif otf_plain:
+            # fast and slow waves in ONE pass, each with its own time step (the reference calls PROPAGS2 per range)
+            exchange_and_advect([(1, c.nfre_red, float(c.idelpro), True, self.ifrelfmax if lf else c.nfre_red)])
         else:
             passes = [(1, self.ifrelfmax, float(self.delpro_lf), True)]
             if lf:
@@ -257,7 +261,7 @@ class Wamintgr:
             nstep_lf = int(round(float(c.idelpro) / float(self.delpro_lf)))
             for _ in range(2, nstep_lf + 1):
                 # FL1_EXT(:,:,1:IFRELFMAX) <- FL3_EXT ; exchange ; PROPAGS2 on the fast waves only
-                self.fl1[: self.n, :, : self.ifrelfmax] = self.fl3[: self.n, :, : self.ifrelfmax]
+                self.ctx.copy_freq_range(self.fl3, self.fl1, self.n, 1, self.ifrelfmax)
                 exchange_and_advect([(1, self.ifrelfmax, float(self.delpro_lf), False)])
         self.fl1, self.fl3 = self.fl3, self.fl1
 

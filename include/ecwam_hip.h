@@ -179,6 +179,20 @@ int ecwam_hip_propags2_otf(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n, 
                            void *stream);
 
 /*
+ * The fast / slow wave split of PROPAG_WAM (IFRELFMAX > 0, propag_wam.F90:247-313) in one pass: frequencies 1..ifrelfmax advance
+ * with delpro_lf, the others with delpro (the reference calls PROPAGS2 once per range with separately built weights).
+ * ifrelfmax = 0: identical to ecwam_hip_propags2_otf.  Bit-identical to the two separate calls.
+ */
+int ecwam_hip_propags2_otf_split(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n, int ngy, double delpro, double delpro_lf,
+                                 int ifrelfmax, const int *kxlt, const void *zdello, double xdella, const void *cosph,
+                                 const void *sinph, const int *klon, const int *klat, const int *kcor, const void *wlat,
+                                 const void *wcor, const void *cgroup_ext, const void *cosphm1_ext, const int *order, int kijs,
+                                 int kijl, int nd3s, int nd3e, int copy_rest, void *stream);
+/* dst[ij][K][m_first-1 .. m_last-1] = src[...] for rows [0,n): FL1_EXT(:,:,1:IFRELFMAX) = FL3_EXT(...) between the fast-wave
+ * sub-steps (propag_wam.F90:287-291) */
+int ecwam_hip_copy_freq_range(ecwam_hip_ctx *ctx, const void *src, void *dst, int n, int m_first, int m_last, void *stream);
+
+/*
  * Refraction, IREFRA = 1 (depth), 2 (currents), 3 (depth + currents) -- params.irefra selects it at ecwam_hip_create.
  *
  * ecwam_hip_propdot: GRADI + the per-point part of PROPDOT (gradi.F90:113-232, propdot.F90:108-196), called whenever the

@@ -128,8 +128,9 @@ class HipContext:
         if order is not None and order.shape[0] < kijl:
             raise ValueError("PROPAGS2: ORDER shorter than KIJL")
         dlf = float(delpro if delpro_lf is None else delpro_lf)
-        args = [self._real(f1, (nrow, self.NANG, self.NFRE), "F1"), self._real(f3, (nrow, self.NANG, self.NFRE), "F3"), n, ngy,
-                float(delpro), dlf, int(ifrelfmax), self._int(g["kxlt"], (n,), "KXLT"), self._real(g["zdello"], (ngy,), "ZDELLO"),
+        in_nfre = int(f1.shape[2])          # NFRE, or the width of a compact fast-wave buffer [nrow][NANG][in_nfre]
+        args = [self._real(f1, (nrow, self.NANG, in_nfre), "F1"), self._real(f3, (f3.shape[0], self.NANG, self.NFRE), "F3"), n, ngy,
+                float(delpro), dlf, int(ifrelfmax), 0 if in_nfre == self.NFRE else in_nfre, self._int(g["kxlt"], (n,), "KXLT"), self._real(g["zdello"], (ngy,), "ZDELLO"),
                 float(g["xdella"]), self._real(g["cosph"], (ngy,), "COSPH"), self._real(g["sinph"], (ngy,), "SINPH"),
                 self._int(g["klon"], (n, 2), "KLON"), self._int(g["klat"], (n, 2, 2), "KLAT"), self._int(g["kcor"], (n, 4, 2), "KCOR"),
                 self._real(g["wlat"], (n, 2), "WLAT"), self._real(g["wcor"], (n, 4), "WCOR"),
@@ -138,11 +139,13 @@ class HipContext:
 
     # -- FL1_EXT(:,:,M1:M2) <- FL3_EXT between the fast-wave sub-steps (propag_wam.F90:287-291)
     def copy_freq_range(self, src, dst, n, m_first, m_last):
+        """dst may be a compact buffer [nrow][NANG][w] with w >= m_last."""
         shape = (src.shape[0], self.NANG, self.NFRE)
-        if n > src.shape[0] or dst.shape != src.shape:
+        w = int(dst.shape[2])
+        if n > src.shape[0] or n > dst.shape[0] or w < m_last:
             raise ValueError("copy_freq_range: shapes")
-        self._chk(self.lib.ecwam_hip_copy_freq_range(self._h, self._real(src, shape, "SRC"), self._real(dst, shape, "DST"), n, m_first,
-                                                     m_last, _stream_ptr()))
+        self._chk(self.lib.ecwam_hip_copy_freq_range(self._h, self._real(src, shape, "SRC"), self._real(dst, (dst.shape[0], self.NANG, w), "DST"),
+                                                     n, m_first, m_last, 0 if w == self.NFRE else w, _stream_ptr()))
 
     # -- refraction (IREFRA = 1, 2, 3): GRADI + PROPDOT per point, CTUWDRV checks, PROPAGS2 with all weights on the fly
     def _geom(self, g, n, ngy):

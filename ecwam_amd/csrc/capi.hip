@@ -36,8 +36,8 @@ template <typename T> void launch_ctuwini_only(int, int, const int*, const int*,
 template <typename T> void launch_propdot(const void*, int, int, int, const int*, const void*, double, const void*, const int*, const int*, const void*, const void*, const void*, const void*, const void*, void*, hipStream_t);
 template <typename T> void launch_curmask(int, int, int, const int*, void*, hipStream_t);
 template <typename T> void launch_propags2_gen(const void*, int, const void*, void*, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const void*, const void*, const void*, int*, int, int, int, int, int, int, int, const void*, hipStream_t);
-template <typename T> void launch_propags2_otf(const void*, const void*, void*, int, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const int*, int, int, int, int, int, int, const void*, int, double, hipStream_t);
-template <typename T> void launch_copy_freq_range(const void*, void*, int, int, int, int, int, hipStream_t);
+template <typename T> void launch_propags2_otf(const void*, const void*, void*, int, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const int*, int, int, int, int, int, int, const void*, int, double, int, hipStream_t);
+template <typename T> void launch_copy_freq_range(const void*, void*, int, int, int, int, int, int, hipStream_t);
 template <typename T> int launch_outbs(const void*, int, int, const void*, double, void*, int, int, hipStream_t);
 template <typename T> void launch_norm(const void*, int, int, double, double*, int, hipStream_t);
 template <typename T> void launch_newwind(const void*, int, void*, const void*, hipStream_t);
@@ -278,13 +278,16 @@ int ecwam_hip_ctuw(ecwam_hip_ctx* c, int n, int nland, int ngy, double delpro, i
 }
 
 int ecwam_hip_propags2_otf_split(ecwam_hip_ctx* c, const void* f1, void* f3, int n, int ngy, double delpro, double delpro_lf, int ifrelfmax,
-                                 const int* kxlt, const void* zdello, double xdella, const void* cosph, const void* sinph, const int* klon,
+                                 int in_nfre, const int* kxlt, const void* zdello, double xdella, const void* cosph, const void* sinph, const int* klon,
                                  const int* klat, const int* kcor, const void* wlat, const void* wcor, const void* cgroup_ext,
                                  const void* cosphm1_ext, const int* order, int kijs, int kijl, int nd3s, int nd3e, int copy_rest,
                                  void* stream) {
   if (!c) return fail("null context");
   if (kijl < kijs || kijs < 0 || kijl > n || nd3s < 1 || nd3e > c->NFRE_RED || nd3e < nd3s - 1 || ifrelfmax < 0 || ifrelfmax > c->NFRE_RED)
     return fail("ecwam_hip_propags2_otf: bad range");
+  if (in_nfre == 0) in_nfre = c->NFRE;
+  if (in_nfre != c->NFRE && (in_nfre < nd3e || in_nfre > c->NFRE || copy_rest))
+    return fail("ecwam_hip_propags2_otf: a compact input buffer must hold every advected frequency and cannot be combined with copy_rest");
   if (kijl > kijs && (!f1 || !f3 || !kxlt || !zdello || !cosph || !sinph || !klon || !klat || !kcor || !wlat || !wcor || !cgroup_ext || !cosphm1_ext))
     return fail("ecwam_hip_propags2_otf: null pointer");
   if (f1 == f3) return fail("ecwam_hip_propags2_otf: F1 and F3 must not alias");
@@ -293,8 +296,8 @@ int ecwam_hip_propags2_otf_split(ecwam_hip_ctx* c, const void* f1, void* f3, int
   const int N = (c->NANG << 16) | (c->NFRE << 8) | c->NFRE_RED;
   copy_rest = copy_rest ? 1 : 0;
   { const char* e_ = getenv("ECWAM_HIP_OTF_WALK"); if (e_ && atoi(e_) == 0) copy_rest |= 2; }  // diagnostics: plain grid-stride tile walk
-  DISPATCH(launch_propags2_otf<float>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, c->obs, ifrelfmax, delpro_lf, s),
-           launch_propags2_otf<double>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, c->obs, ifrelfmax, delpro_lf, s));
+  DISPATCH(launch_propags2_otf<float>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, c->obs, ifrelfmax, delpro_lf, in_nfre, s),
+           launch_propags2_otf<double>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, c->obs, ifrelfmax, delpro_lf, in_nfre, s));
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -303,17 +306,18 @@ int ecwam_hip_propags2_otf(ecwam_hip_ctx* c, const void* f1, void* f3, int n, in
                            double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat, const int* kcor,
                            const void* wlat, const void* wcor, const void* cgroup_ext, const void* cosphm1_ext, const int* order,
                            int kijs, int kijl, int nd3s, int nd3e, int copy_rest, void* stream) {
-  return ecwam_hip_propags2_otf_split(c, f1, f3, n, ngy, delpro, delpro, 0, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor,
+  return ecwam_hip_propags2_otf_split(c, f1, f3, n, ngy, delpro, delpro, 0, 0, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor,
                                       cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s, nd3e, copy_rest, stream);
 }
 
-int ecwam_hip_copy_freq_range(ecwam_hip_ctx* c, const void* src, void* dst, int n, int m_first, int m_last, void* stream) {
+int ecwam_hip_copy_freq_range(ecwam_hip_ctx* c, const void* src, void* dst, int n, int m_first, int m_last, int dst_nfre, void* stream) {
   if (!c) return fail("null context");
-  if (n < 0 || m_first < 1 || m_last > c->NFRE || m_last < m_first - 1) return fail("ecwam_hip_copy_freq_range: bad range");
+  if (dst_nfre == 0) dst_nfre = c->NFRE;
+  if (n < 0 || m_first < 1 || m_last > c->NFRE || m_last < m_first - 1 || m_last > dst_nfre) return fail("ecwam_hip_copy_freq_range: bad range");
   if (n > 0 && (!src || !dst)) return fail("ecwam_hip_copy_freq_range: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH(launch_copy_freq_range<float>(src, dst, n, c->NANG, c->NFRE, m_first - 1, m_last, s),
-           launch_copy_freq_range<double>(src, dst, n, c->NANG, c->NFRE, m_first - 1, m_last, s));
+  DISPATCH(launch_copy_freq_range<float>(src, dst, n, c->NANG, c->NFRE, m_first - 1, m_last, dst_nfre, s),
+           launch_copy_freq_range<double>(src, dst, n, c->NANG, c->NFRE, m_first - 1, m_last, dst_nfre, s));
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -334,12 +334,14 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
                                                       const T* __restrict__ wlat, const T* __restrict__ wcor,
                                                       const T* __restrict__ cg, const T* __restrict__ cosphm1,
                                                       const int* __restrict__ order, int kijs, int kijl, int m0, int m1,
-                                                      int copy_rest, int ntiles, const T* __restrict__ obs, int mlf, T delpro_lf) {
+                                                      int copy_rest, int ntiles, const T* __restrict__ obs, int mlf, T delpro_lf, int in_k) {
+  // in_k: frequencies per direction in the INPUT rows (NFRE, or the width of a compact fast-wave buffer [ij][K][in_k]);
+  // the output rows always have the FL layout.
   // mlf > 0: frequencies [0, mlf) (the fast waves, IFRELFMAX) advance with delpro_lf, the others with delpro, in one pass
   // (propag_wam.F90:247-283 calls PROPAGS2 once per range)
   extern __shared__ __align__(16) unsigned char otf_smem[];
   const int NANG = tab->NANG, NFRE = tab->NFRE;
-  const int N = NANG * NFRE, NV = N / VW, FV = NFRE / VW;
+  const int N = NANG * NFRE, NIN = NANG * in_k, FV = in_k / VW, NV = NANG * FV;
   const T CMTODEG = T(360.0) / tab->CIRC;
   const T DELTH0 = T(0.25) * delpro / tab->DELTH;
   const T DELTH0_LF = T(0.25) * delpro_lf / tab->DELTH;
@@ -403,13 +405,13 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
       const int t = e / NV, ev = e - t * NV;
       const int k = ev / FV, m = (ev - k * FV) * VW;
       const int* q = sI + t * 16;
-      const size_t own = (size_t)q[0] * N;
-      const int el = k * NFRE + m;
+      const size_t own = (size_t)q[0] * N, own_in = (size_t)q[0] * NIN;
+      const int el = k * NFRE + m, el_in = k * in_k + m;
       typedef VecIO<T, VW> IO;
       if (m + VW <= m0 || m >= m1) {   // no element of this vector is advected
         if (copy_rest & 1) {
           T v[VW];
-          IO::ld(f1 + own + el, v);
+          IO::ld(f1 + own_in + el_in, v);
           IO::st(f3 + own + el, v);
         }
         continue;
@@ -428,14 +430,14 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
         tsm_lf = p.tanph * sK[4 * k + 3];
       }
       T fo[VW], flon[VW], fla1[VW], fla2[VW], fco1[VW], fco2[VW], fkm[VW], fkp[VW];
-      IO::ld(f1 + own + el, fo);
-      IO::ld(f1 + (size_t)q[1 + jx0] * N + el, flon);
-      IO::ld(f1 + (size_t)q[3 + 2 * jy0] * N + el, fla1);
-      IO::ld(f1 + (size_t)q[4 + 2 * jy0] * N + el, fla2);
-      IO::ld(f1 + (size_t)q[7 + 2 * kc] * N + el, fco1);
-      IO::ld(f1 + (size_t)q[8 + 2 * kc] * N + el, fco2);
-      IO::ld(f1 + own + km * NFRE + m, fkm);
-      IO::ld(f1 + own + kp * NFRE + m, fkp);
+      IO::ld(f1 + own_in + el_in, fo);
+      IO::ld(f1 + (size_t)q[1 + jx0] * NIN + el_in, flon);
+      IO::ld(f1 + (size_t)q[3 + 2 * jy0] * NIN + el_in, fla1);
+      IO::ld(f1 + (size_t)q[4 + 2 * jy0] * NIN + el_in, fla2);
+      IO::ld(f1 + (size_t)q[7 + 2 * kc] * NIN + el_in, fco1);
+      IO::ld(f1 + (size_t)q[8 + 2 * kc] * NIN + el_in, fco2);
+      IO::ld(f1 + own_in + km * in_k + m, fkm);
+      IO::ld(f1 + own_in + kp * in_k + m, fkp);
       const T* bb = sB + (size_t)t * 5 * NFRE + m;
       T bh0[VW], bh1[VW], by0[VW], by1[VW], bc0[VW];
       IO::ld(bb, bh0); IO::ld(bb + NFRE, bh1); IO::ld(bb + 2 * NFRE, by0); IO::ld(bb + 3 * NFRE, by1); IO::ld(bb + 4 * NFRE, bc0);
@@ -987,13 +989,15 @@ __global__ void k_points_to_chunks(const T* __restrict__ pt, T* __restrict__ ch,
 // F(:,:,m0:m1-1) of rows [0,n) from src to dst: FL1_EXT(:,:,1:IFRELFMAX) <- FL3_EXT between the fast-wave sub-steps
 // (propag_wam.F90:287-291); one thread per (row, K, m)
 template <typename T>
-__global__ void k_copy_freq_range(const T* __restrict__ src, T* __restrict__ dst, int n, int NANG, int NFRE, int m0, int m1) {
+__global__ void k_copy_freq_range(const T* __restrict__ src, T* __restrict__ dst, int n, int NANG, int NFRE, int m0, int m1,
+                                  int dst_nfre) {
+  // dst rows have dst_nfre frequencies per direction (NFRE: same layout; less: a compact fast-wave buffer)
   const int nm = m1 - m0;
   const long long total = (long long)n * NANG * nm;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
     const long long run = g / nm;
     const int m = m0 + (int)(g - run * nm);
-    dst[run * NFRE + m] = src[run * NFRE + m];
+    dst[run * dst_nfre + m] = src[run * NFRE + m];
   }
 }
 
@@ -1046,8 +1050,10 @@ template <typename T>
 void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, int ngy, double delpro, const int* kxlt,
                          const void* zdello, double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat,
                          const int* kcor, const void* wlat, const void* wcor, const void* cg, const void* cosphm1, const int* order,
-                         int kijs, int kijl, int m0, int m1, int copy_rest, int dims, const void* obs, int mlf, double delpro_lf, hipStream_t s) {
+                         int kijs, int kijl, int m0, int m1, int copy_rest, int dims, const void* obs, int mlf, double delpro_lf, int in_k,
+                         hipStream_t s) {
   const int NANG = dims >> 16, NFRE = (dims >> 8) & 0xFF;
+  if (in_k <= 0) in_k = NFRE;
   const int n = kijl - kijs;
   if (n <= 0) return;
   const int ntiles = (n + OTF_TP - 1) / OTF_TP;
@@ -1060,16 +1066,16 @@ void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, 
 #define OTF_ARGS                                                                                                              \
   (const DevTab<T>*)tab, (const T*)f1, (T*)f3, n_geom, ngy, (T)delpro, kxlt, (const T*)zdello, (T)xdella, (const T*)cosph,     \
       (const T*)sinph, klon, klat, kcor, (const T*)wlat, (const T*)wcor, (const T*)cg, (const T*)cosphm1, order, kijs, kijl, m0, \
-      m1, copy_rest, ntiles, (const T*)obs, mlf, (T)delpro_lf
+      m1, copy_rest, ntiles, (const T*)obs, mlf, (T)delpro_lf, in_k
   int vw = W;
   { const char* e_ = getenv("ECWAM_HIP_OTF_VW"); if (e_) vw = atoi(e_); }  // diagnostics
-  const bool vec = vw >= W && aligned && NFRE % W == 0;   // a range boundary inside a vector is handled by the kernel
+  const bool vec = vw >= W && aligned && NFRE % W == 0 && in_k % W == 0;   // a range boundary inside a vector is handled by the kernel
   if (obs) {  // LSUBGRID
     if (vec) hipLaunchKernelGGL((k_propags2_otf<T, W, true>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
     else hipLaunchKernelGGL((k_propags2_otf<T, 1, true>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
   } else if (vec)
     hipLaunchKernelGGL((k_propags2_otf<T, W, false>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
-  else if (vw >= 2 && aligned && NFRE % 2 == 0)
+  else if (vw >= 2 && aligned && NFRE % 2 == 0 && in_k % 2 == 0)
     hipLaunchKernelGGL((k_propags2_otf<T, 2, false>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
   else
     hipLaunchKernelGGL((k_propags2_otf<T, 1, false>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
@@ -1151,10 +1157,11 @@ void launch_p2c(const void* pt, void* ch, int nproma, int nchnk, int npts, int n
   hipLaunchKernelGGL(k_points_to_chunks<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)pt, (T*)ch, nproma, nchnk, npts, n2, n3);
 }
 template <typename T>
-void launch_copy_freq_range(const void* src, void* dst, int n, int NANG, int NFRE, int m0, int m1, hipStream_t s) {
+void launch_copy_freq_range(const void* src, void* dst, int n, int NANG, int NFRE, int m0, int m1, int dst_nfre, hipStream_t s) {
   long long total = (long long)n * NANG * (m1 - m0);
   if (total <= 0) return;
-  hipLaunchKernelGGL(k_copy_freq_range<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)src, (T*)dst, n, NANG, NFRE, m0, m1);
+  hipLaunchKernelGGL(k_copy_freq_range<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)src, (T*)dst, n, NANG, NFRE, m0, m1,
+                     dst_nfre);
 }
 template <typename T>
 void launch_pack(const void* fl, const int* idx, int n, int rowlen, void* buf, hipStream_t s) {
@@ -1181,10 +1188,10 @@ void launch_pack(const void* fl, const int* idx, int n, int rowlen, void* buf, h
   template void launch_propags2_otf<T>(const void*, const void*, void*, int, int, double, const int*, const void*, double,        \
                                        const void*, const void*, const int*, const int*, const int*, const void*, const void*,   \
                                        const void*, const void*, const int*, int, int, int, int, int, int, const void*, int, double,   \
-                                       hipStream_t);                                                                              \
+                                       int, hipStream_t);                                                                              \
   template void launch_c2p<T>(const void*, void*, int, int, int, int, int, hipStream_t);                                          \
   template void launch_p2c<T>(const void*, void*, int, int, int, int, int, hipStream_t);                                          \
-  template void launch_copy_freq_range<T>(const void*, void*, int, int, int, int, int, hipStream_t);                               \
+  template void launch_copy_freq_range<T>(const void*, void*, int, int, int, int, int, int, hipStream_t);                             \
   template void launch_pack<T>(const void*, const int*, int, int, void*, hipStream_t);
 INST(float)
 INST(double)

@@ -35,10 +35,10 @@ class HaloExchange:
 
         ops = []
         for p, ix in sorted(self.send_idx.items()):
-            buf = self.bufs.get(p)
-            if buf is None or buf.dtype != fl.dtype:
-                buf = self.bufs[p] = torch.empty((ix.numel(),) + tuple(fl.shape[1:]), dtype=fl.dtype, device=fl.device)
-            if fl.is_cuda and self.ctx is not None:
+            buf = self.bufs.get((p, int(fl.shape[2])))
+            if buf is None or buf.dtype != fl.dtype or buf.shape[1:] != fl.shape[1:]:
+                buf = self.bufs[(p, int(fl.shape[2]))] = torch.empty((ix.numel(),) + tuple(fl.shape[1:]), dtype=fl.dtype, device=fl.device)
+            if fl.is_cuda and self.ctx is not None and fl.shape[2] == self.ctx.NFRE:
                 self.ctx.pack_rows(fl, ix, buf)
             else:
                 torch.index_select(fl, 0, ix.long(), out=buf)
@@ -95,6 +95,12 @@ class Wamintgr:
         self.cflfail = torch.zeros(self.n, dtype=torch.int32, device=self.dev)
         self.ifrelfmax = ifrelfmax
         self.delpro_lf = delpro_lf
+        # fast waves between the sub-steps: compact rows [ij][K][LFP] (a frequency sub-range of the full rows would touch every
+        # cache line of the spectra; these are 36/LFP times smaller, for the stencil and for the halo exchange)
+        self.g1 = None
+        if 0 < ifrelfmax < cfg.nfre_red and weights == "otf" and not int(cfg.irefra):
+            lfp = min(cfg.nfre, (ifrelfmax + 3) // 4 * 4)
+            self.g1 = torch.zeros((self.nrows, NANG, lfp), **z)
         self.weights_ready = False
         # refraction (IREFRA = 1 depth, 2 currents, 3 both): per-point THD/S0/U/V/OMDD/CURMASK instead of the reference's
         # THDD/THDC/SDOT and 21 weight arrays; PROPAGS2 rebuilds every weight on the fly
@@ -212,8 +218,11 @@ class Wamintgr:
         c, g = self.cfg, self.gd
         lf = 0 < self.ifrelfmax < c.nfre_red
 
-        def advect_rows(k0, k1, m1, m2, delpro, copy_rest, split=0):
+        def advect_rows(k0, k1, m1, m2, delpro, copy_rest, split=0, src=None):
             if k1 <= k0:
+                return
+            if src is not None and src is not self.fl1:      # compact fast-wave rows -> fast-wave slots of FL3
+                self.ctx.propags2_otf(src, self.fl3, g, self.cgroup_ext, delpro, k0, k1, m1, m2, copy_rest=False, order=self.order)
                 return
             if self.irefra:
                 self.ctx.propags2_refra(self.fl1, self.fl3, g, self.cgroup_ext, self.omosnh2kd_ext, self.wavnum_ext, self.refr, delpro, k0,
@@ -224,27 +233,29 @@ class Wamintgr:
                 self.ctx.propags2_otf(self.fl1, self.fl3, g, self.cgroup_ext, delpro, k0, k1, m1, m2, copy_rest=copy_rest,
                                       order=self.order, ifrelfmax=split, delpro_lf=self.delpro_lf if split else None)
 
-        def advect(m1, m2, delpro, copy_rest, split=0, rows=None):
+        def advect(m1, m2, delpro, copy_rest, split=0, rows=None, src=None):
             k0, k1 = rows if rows is not None else (0, self.n)
-            advect_rows(k0, k1, m1, m2, delpro, copy_rest, split)
+            advect_rows(k0, k1, m1, m2, delpro, copy_rest, split, src)
 
-        def exchange_and_advect(passes):
+        def exchange_and_advect(passes, src=None):
             """MPEXCHNG + PROPAGS2 (propag_wam.F90:166,247-313) with the exchange hidden behind the interior: post the halo
-            exchange, advect the rows that read no halo row, wait, advect the two ends of the band."""
+            exchange, advect the rows that read no halo row, wait, advect the two ends of the band.  src: the buffer whose
+            halo rows are exchanged and that the stencil reads (FL1, or the compact fast-wave buffer)."""
+            src = self.fl1 if src is None else src
             overlap = self.dom.nranks > 1 and self.order is None
             if not overlap:
-                self.halo(self.fl1)
+                self.halo(src)
                 for a in passes:
-                    advect(*a)
+                    advect(*a, src=src)
                 return
             ia, ib = self.interior
-            reqs = self.halo.start(self.fl1)
+            reqs = self.halo.start(src)
             for a in passes:
-                advect(*a, rows=(ia, ib))
+                advect(*a, rows=(ia, ib), src=src)
             self.halo.finish(reqs)
             for a in passes:
-                advect(*a, rows=(0, ia))
-                advect(*a, rows=(ib, self.n))
+                advect(*a, rows=(0, ia), src=src)
+                advect(*a, rows=(ib, self.n), src=src)
 
         otf_plain = self.weights == "otf" and not self.irefra
         if self.weights == "stored" or self.ifrelfmax <= 0:
@@ -261,8 +272,12 @@ class Wamintgr:
             nstep_lf = int(round(float(c.idelpro) / float(self.delpro_lf)))
             for _ in range(2, nstep_lf + 1):
                 # FL1_EXT(:,:,1:IFRELFMAX) <- FL3_EXT ; exchange ; PROPAGS2 on the fast waves only
-                self.ctx.copy_freq_range(self.fl3, self.fl1, self.n, 1, self.ifrelfmax)
-                exchange_and_advect([(1, self.ifrelfmax, float(self.delpro_lf), False)])
+                if self.g1 is not None:
+                    self.ctx.copy_freq_range(self.fl3, self.g1, self.n, 1, self.ifrelfmax)
+                    exchange_and_advect([(1, self.ifrelfmax, float(self.delpro_lf), False)], src=self.g1)
+                else:
+                    self.ctx.copy_freq_range(self.fl3, self.fl1, self.n, 1, self.ifrelfmax)
+                    exchange_and_advect([(1, self.ifrelfmax, float(self.delpro_lf), False)])
         self.fl1, self.fl3 = self.fl3, self.fl1
 
     def newwind(self) -> None:

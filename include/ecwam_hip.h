@@ -182,15 +182,19 @@ int ecwam_hip_propags2_otf(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n, 
  * The fast / slow wave split of PROPAG_WAM (IFRELFMAX > 0, propag_wam.F90:247-313) in one pass: frequencies 1..ifrelfmax advance
  * with delpro_lf, the others with delpro (the reference calls PROPAGS2 once per range with separately built weights).
  * ifrelfmax = 0: identical to ecwam_hip_propags2_otf.  Bit-identical to the two separate calls.
+ * in_nfre: 0 (f1 has the FL layout) or the width of a COMPACT input buffer f1[npts+1][NANG][in_nfre] that holds only the first
+ * in_nfre frequencies of every direction (the fast waves between sub-steps: with M fastest in memory a frequency sub-range of
+ * the full rows touches every cache line; the compact rows are 4.5x smaller at IFRELFMAX = 5).  f3 always has the FL layout.
  */
 int ecwam_hip_propags2_otf_split(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n, int ngy, double delpro, double delpro_lf,
-                                 int ifrelfmax, const int *kxlt, const void *zdello, double xdella, const void *cosph,
+                                 int ifrelfmax, int in_nfre, const int *kxlt, const void *zdello, double xdella, const void *cosph,
                                  const void *sinph, const int *klon, const int *klat, const int *kcor, const void *wlat,
                                  const void *wcor, const void *cgroup_ext, const void *cosphm1_ext, const int *order, int kijs,
                                  int kijl, int nd3s, int nd3e, int copy_rest, void *stream);
 /* dst[ij][K][m_first-1 .. m_last-1] = src[...] for rows [0,n): FL1_EXT(:,:,1:IFRELFMAX) = FL3_EXT(...) between the fast-wave
- * sub-steps (propag_wam.F90:287-291) */
-int ecwam_hip_copy_freq_range(ecwam_hip_ctx *ctx, const void *src, void *dst, int n, int m_first, int m_last, void *stream);
+ * sub-steps (propag_wam.F90:287-291).  dst_nfre: 0 (dst has the FL layout) or the width of a compact buffer dst[..][NANG][dst_nfre] */
+int ecwam_hip_copy_freq_range(ecwam_hip_ctx *ctx, const void *src, void *dst, int n, int m_first, int m_last, int dst_nfre,
+                              void *stream);
 
 /*
  * Refraction, IREFRA = 1 (depth), 2 (currents), 3 (depth + currents) -- params.irefra selects it at ecwam_hip_create.

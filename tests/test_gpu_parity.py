@@ -629,18 +629,20 @@ def test_wamintgr_two_steps_matches_oracle(api):
     m.ctx.close()
 
 
-@pytest.mark.parametrize("prec,weights", [("sp", "otf"), ("dp", "stored")])
-def test_decomposed_step_is_bit_identical_on_device(api, prec, weights):
+@pytest.mark.parametrize("prec,weights,lf", [("sp", "otf", 4), ("sp", "otf", 5), ("dp", "otf", 5), ("dp", "stored", 4)])
+def test_decomposed_step_is_bit_identical_on_device(api, prec, weights, lf):
     """The multi-GPU path on ONE device: the grid split into 3 contiguous sea-point ranges (local renumbering, halo rows,
     land slot: decomp.local_domain, as `bench.py --gpus N` uses it), each advanced by its own Wamintgr with the halo rows
     filled by hand from the neighbours' owned rows (what HaloExchange does over RCCL), must reproduce the single-domain
-    run bit for bit after two full WAMINTGR steps, sub-stepped fast waves included."""
+    run bit for bit after two full WAMINTGR steps, sub-stepped fast waves included.  The single-domain run goes through
+    Wamintgr.propag (fast and slow waves in one pass, the sub-step on the compact fast-wave buffer); the ranks are driven with the
+    separate per-range calls of the reference's sequence on the full rows: both must give the same bits (lf = 5 cuts a 16-byte vector)."""
     from ecwam_amd import grid as G
     from ecwam_amd.wamintgr import Wamintgr
 
     cfg = Config(nang=12, nfre=36, nfre_red=28, idelt=900, idelpro=900)
     g = G.build_grid(20, mask="continents")
-    kw = dict(ifrelfmax=4, delpro_lf=450.0, weights=weights)
+    kw = dict(ifrelfmax=lf, delpro_lf=450.0, weights=weights)
     ref = Wamintgr(cfg, g, prec, **kw)
     ref.init_synthetic(seed=11)
     nr = 3
@@ -670,16 +672,16 @@ def test_decomposed_step_is_bit_identical_on_device(api, prec, weights):
             if weights == "stored":
                 m.ctx.propags2(m.fl1, m.fl3, m.gd["klon"], m.gd["klat"], m.gd["kcor"], m.w, 0, m.n, 1, c.nfre_red, copy_rest=True)
             else:
-                m.ctx.propags2_otf(m.fl1, m.fl3, m.gd, m.cgroup_ext, 450.0, 0, m.n, 1, 4, copy_rest=True)
-                m.ctx.propags2_otf(m.fl1, m.fl3, m.gd, m.cgroup_ext, 900.0, 0, m.n, 5, c.nfre_red, copy_rest=False)
+                m.ctx.propags2_otf(m.fl1, m.fl3, m.gd, m.cgroup_ext, 450.0, 0, m.n, 1, lf, copy_rest=True)
+                m.ctx.propags2_otf(m.fl1, m.fl3, m.gd, m.cgroup_ext, 900.0, 0, m.n, lf + 1, c.nfre_red, copy_rest=False)
         for m in parts:
-            m.fl1[: m.n, :, :4] = m.fl3[: m.n, :, :4]
+            m.fl1[: m.n, :, :lf] = m.fl3[: m.n, :, :lf]
         exchange()
         for m in parts:
             if weights == "stored":
-                m.ctx.propags2(m.fl1, m.fl3, m.gd["klon"], m.gd["klat"], m.gd["kcor"], m.w, 0, m.n, 1, 4, copy_rest=False)
+                m.ctx.propags2(m.fl1, m.fl3, m.gd["klon"], m.gd["klat"], m.gd["kcor"], m.w, 0, m.n, 1, lf, copy_rest=False)
             else:
-                m.ctx.propags2_otf(m.fl1, m.fl3, m.gd, m.cgroup_ext, 450.0, 0, m.n, 1, 4, copy_rest=False)
+                m.ctx.propags2_otf(m.fl1, m.fl3, m.gd, m.cgroup_ext, 450.0, 0, m.n, 1, lf, copy_rest=False)
             m.fl1, m.fl3 = m.fl3, m.fl1
             m.newwind()
             m.implsch()

@@ -580,10 +580,12 @@ __device__ __forceinline__ T sel2(int i, T a0, T a1) { return i ? a1 : a0; }
 template <typename T, bool CHECK>
 __device__ __forceinline__ bool ctu_wgen(const CtuBase<T>& b, T sink, T cosk, const CtuPoint<T>& p, T xdella, T delpro, T cmtodeg,
                                          int jx0, int jx1, int jy0, int jy1, const int* kc, bool cur, T u, T v, T dthp, T dthm,
-                                         T fdp, T fdm, T fratio, CtuGenW<T>& w) {
+                                         T fdp, T fdm, T fratio, CtuGenW<T>& w, bool& flipped) {
+  // flipped: the current turns the advection velocity against the group velocity somewhere (a downwind weight is non-zero)
 #pragma clang fp contract(off)
   T adxp[2], adyp[2], dxup[2], dxdw[2], dyup[2], dydw[2];
   bool fail = false;
+  flipped = false;
 #pragma unroll
   for (int ic = 0; ic < 2; ic++) {
     const T cgx = b.h[ic] * sink * p.cpm1;
@@ -597,6 +599,7 @@ __device__ __forceinline__ bool ctu_wgen(const CtuBase<T>& b, T sink, T cosk, co
       const T vv = v * T(0.5) * (T(1) + p.dp[ic]);
       vrel = cgy + vv;
       sv = same_sign(vrel, cgy);
+      if (!su || !sv) flipped = true;
     }
     adxp[ic] = m_abs(-delpro * urel * cmtodeg);
     adyp[ic] = m_abs(-delpro * vrel * cmtodeg);
@@ -811,7 +814,7 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
         }
       }
       CtuGenW<T> w[VW];
-      bool fail = false;
+      bool fail = false, flipped = false;
 #pragma unroll
       for (int c = 0; c < VW; c++) {
         CtuBase<T> b;
@@ -832,8 +835,11 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
             fdm = mask * (sd[c + 1] + sd[c]) * sDF[NFRE + mc];
           }
         }
-        if (m + c < m1)
-          fail |= ctu_wgen<T, CHECK>(b, sink, cosk, p, xdella, delpro, CMTODEG, jx0, jx1, jy0, jy1, kc, cur, u, v, dthp, dthm, fdp, fdm, FRATIO, w[c]);
+        {
+          bool fl_;
+          const bool f_ = ctu_wgen<T, CHECK>(b, sink, cosk, p, xdella, delpro, CMTODEG, jx0, jx1, jy0, jy1, kc, cur, u, v, dthp, dthm, fdp, fdm, FRATIO, w[c], fl_);
+          if (m + c < m1) { fail |= f_; flipped |= fl_; }
+        }
         if (OBS && !CHECK) {  // ctuw.F90:703-733, after the checks
 #pragma clang fp contract(off)
           const T* o = sO + (size_t)t * 8 * NFRE + m + c;
@@ -872,6 +878,38 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
           r[c] = ctu_stencil(w[c].sumwn, sel2(jx0, w[c].wlon[0], w[c].wlon[1]), sel2(jy0, w[c].wlat[0][0], w[c].wlat[1][0]),
                              sel2(jy0, w[c].wlat[0][1], w[c].wlat[1][1]), w[c].wcor[0][0], w[c].wcor[0][1], w[c].wk[0], w[c].wk[2],
                              fown[c], flon[c], fla1[c], fla2[c], fco1[c], fco2[c], fkm[c], fkp[c]);
+      } else if (__builtin_amdgcn_ballot_w64(flipped) == 0ull) {
+        // no lane of this wave has an upwind switch: the downwind weights are all zero and only the five upwind space
+        // neighbours can contribute, in the order the general sequence below visits them (adding a zero product is harmless)
+#pragma clang fp contract(off)
+        T flon[VW], fla1[VW], fla2[VW], fco1[VW], fco2[VW], fkm[VW], fkp[VW];
+        IO::ld(f1 + (size_t)q[1 + jx0] * N + el, flon);
+        IO::ld(f1 + (size_t)q[3 + 2 * jy0] * N + el, fla1);
+        IO::ld(f1 + (size_t)q[4 + 2 * jy0] * N + el, fla2);
+        IO::ld(f1 + (size_t)q[7 + 2 * kc[0]] * N + el, fco1);
+        IO::ld(f1 + (size_t)q[8 + 2 * kc[0]] * N + el, fco2);
+        IO::ld(fo + km * NFRE + m, fkm);
+        IO::ld(fo + kp * NFRE + m, fkp);
+        const T flo = fo[k * NFRE + (m > 0 ? m - 1 : 0)];
+        const int mh = m + VW < NR ? m + VW : NR - 1;
+        const T fhi = fo[k * NFRE + mh];
+#pragma unroll
+        for (int c = 0; c < VW; c++) {
+          const T fm1 = (c == 0) ? flo : fown[c - 1];
+          T fp1 = (c == VW - 1) ? fhi : fown[c + 1];
+          if (m + c + 1 > NR - 1) fp1 = fown[c];
+          T a = (T(1) - w[c].sumwn) * fown[c];
+          a = a + sel2(jx0, w[c].wlon[0], w[c].wlon[1]) * flon[c];
+          a = a + sel2(jy0, w[c].wlat[0][0], w[c].wlat[1][0]) * fla1[c];
+          a = a + w[c].wcor[0][0] * fco1[c];
+          a = a + sel2(jy0, w[c].wlat[0][1], w[c].wlat[1][1]) * fla2[c];
+          a = a + w[c].wcor[0][1] * fco2[c];
+          a = a + w[c].wk[0] * fkm[c];
+          a = a + w[c].wm[0] * fm1;
+          a = a + w[c].wk[2] * fkp[c];
+          a = a + w[c].wm[2] * fp1;
+          r[c] = a;
+        }
       } else {
 #pragma clang fp contract(off)
 #pragma unroll

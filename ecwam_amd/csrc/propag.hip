@@ -211,6 +211,45 @@ __device__ __forceinline__ bool ctu_w8(const CtuBase<T>& b, T sink, T cosk, T cp
   w8[0] = sumwn; w8[1] = wlonn; w8[2] = wlatn1; w8[3] = wlatn2; w8[4] = wcorn1; w8[5] = wcorn2; w8[6] = wkm; w8[7] = wkp;
   return fail;
 }
+// ctu_w8 + ctu_stencil on TWO frequencies at a time as packed-fp32 operands (v_pk_mul_f32 / v_pk_add_f32): the same operations
+// in the same order per component, contraction off, hence the same bits as the scalar helpers -- at half the instruction issue
+// (the advection kernel spends 2/3 of its time issuing vector instructions).  No checks here: k_ctuw does them once.
+typedef float F2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ F2 v_abs2(F2 x) { F2 r = {fabsf(x.x), fabsf(x.y)}; return r; }
+__device__ __forceinline__ F2 ctu_w8_stencil_pk(F2 h0, F2 h1, F2 hy0, F2 hy1, F2 cg0, float sink, float cosk, float cpm1, float zd,
+                                                float xdella, float ga, F2 delpro, float cmtodeg, int jx0, int jy0, float wl_jy0,
+                                                float wc_kc, F2 tsp, F2 tsm, F2 f0, F2 f1, F2 f2, F2 f3, F2 f4, F2 f5, F2 f6, F2 f7) {
+#pragma clang fp contract(off)
+  const F2 adx0 = v_abs2(-delpro * (h0 * sink * cpm1) * cmtodeg), adx1 = v_abs2(-delpro * (h1 * sink * cpm1) * cmtodeg);
+  const F2 ady0 = v_abs2(-delpro * (hy0 * cosk) * cmtodeg), ady1 = v_abs2(-delpro * (hy1 * cosk) * cmtodeg);
+  const F2 adx_a = jx0 ? adx1 : adx0, adx_b = jx0 ? adx0 : adx1;   // ADXP(JXO(K,1)), ADXP(JXO(K,2))
+  const F2 ady_a = jy0 ? ady1 : ady0, ady_b = jy0 ? ady0 : ady1;
+  const F2 dxx = zd - adx_b;
+  const F2 dyy = xdella - ady_b;
+  const F2 wgt_lat = dxx * ady_a * ga;
+  const F2 wlatn1 = wl_jy0 * wgt_lat;
+  const F2 wlatn2 = (1.0f - wl_jy0) * wgt_lat;
+  const F2 wlonn = dyy * adx_a * ga;
+  const F2 wgt_cor = adx_a * ady_a * ga;
+  const F2 wcorn1 = wc_kc * wgt_cor;
+  const F2 wcorn2 = (1.0f - wc_kc) * wgt_cor;
+  F2 sumwn = (zd * ady_b + xdella * adx_b - adx_b * ady_b) * ga;
+  const F2 dthp = tsp * cg0;
+  const F2 dthm = tsm * cg0;
+  const F2 wk0 = (dthp + v_abs2(dthp)) + (v_abs2(dthm) - dthm);
+  const F2 wkp = -dthp + v_abs2(dthp);
+  const F2 wkm = dthm + v_abs2(dthm);
+  sumwn = sumwn + wk0;
+  F2 r = (1.0f - sumwn) * f0;
+  r = r + wlonn * f1;
+  r = r + wlatn1 * f2;
+  r = r + wlatn2 * f3;
+  r = r + wcorn1 * f4;
+  r = r + wcorn2 * f5;
+  r = r + wkm * f6;
+  r = r + wkp * f7;
+  return r;
+}
 // per-point scalars of the weights (ctuw.F90:146-170, 407-420)
 template <typename T>
 struct CtuPoint {
@@ -442,6 +481,22 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
       T bh0[VW], bh1[VW], by0[VW], by1[VW], bc0[VW];
       IO::ld(bb, bh0); IO::ld(bb + NFRE, bh1); IO::ld(bb + 2 * NFRE, by0); IO::ld(bb + 3 * NFRE, by1); IO::ld(bb + 4 * NFRE, bc0);
       T r[VW];
+      if constexpr (sizeof(T) == 4 && (VW % 2 == 0) && !OBS) {
+        // two frequencies per packed-fp32 operand
+#pragma unroll
+        for (int c = 0; c < VW; c += 2) {
+          const bool lf0 = (m + c) < mlf, lf1 = (m + c + 1) < mlf;
+          const F2 dl = {lf0 ? (float)delpro_lf : (float)delpro, lf1 ? (float)delpro_lf : (float)delpro};
+          const F2 sp2 = {lf0 ? (float)tsp_lf : (float)tsp, lf1 ? (float)tsp_lf : (float)tsp};
+          const F2 sm2 = {lf0 ? (float)tsm_lf : (float)tsm, lf1 ? (float)tsm_lf : (float)tsm};
+#define P2(a) F2{(float)a[c], (float)a[c + 1]}
+          const F2 rr = ctu_w8_stencil_pk(P2(bh0), P2(bh1), P2(by0), P2(by1), P2(bc0), (float)sink, (float)cosk, (float)p.cpm1, (float)p.zd,
+                                          (float)xdella, (float)p.ga, dl, (float)CMTODEG, jx0, jy0, (float)p.wl[jy0], (float)p.wc[kc], sp2,
+                                          sm2, P2(fo), P2(flon), P2(fla1), P2(fla2), P2(fco1), P2(fco2), P2(fkm), P2(fkp));
+#undef P2
+          r[c] = (T)rr.x; r[c + 1] = (T)rr.y;
+        }
+      } else
 #pragma unroll
       for (int c = 0; c < VW; c++) {
         CtuBase<T> b;

@@ -26,7 +26,8 @@ def _write_case(path, m, cfg, grid, nproma, nstep):
     tp, keep = L.make_tables(t)
     with open(path, "wb") as f:
         hdr = np.array([cfg.nang, cfg.nfre, cfg.nfre_red, nproma, nchnk, n, grid.ngy, cfg.idelt, cfg.idelpro,
-                        np.dtype(dt).itemsize, nstep, ctypes.sizeof(params), len(keep)], dtype=np.int32)
+                        np.dtype(dt).itemsize, nstep, ctypes.sizeof(params), len(keep), int(m.ifrelfmax),
+                        int(m.delpro_lf or 0)], dtype=np.int32)
         f.write(hdr.tobytes())
         f.write(bytes(params))
         for a in keep:
@@ -57,8 +58,8 @@ def _write_case(path, m, cfg, grid, nproma, nstep):
     return nchnk
 
 
-@pytest.mark.parametrize("prec", ["sp", "dp"])
-def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec):
+@pytest.mark.parametrize("prec,lf", [("sp", 0), ("dp", 0), ("sp", 5)])
+def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec, lf):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from ecwam_amd import build, grid as G
@@ -69,7 +70,7 @@ def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec):
         build.build_fortran()
     cfg = Config(nang=12, nfre=36, nfre_red=25, idelt=900, idelpro=900)
     g = G.build_grid(16, mask="continents")
-    m = Wamintgr(cfg, g, prec)
+    m = Wamintgr(cfg, g, prec, ifrelfmax=lf, delpro_lf=450.0 if lf else None)    # lf: fast waves M <= lf in two sub-steps
     m.init_synthetic(seed=21)
     nproma, nstep = 24, 2
     case, out = str(tmp_path / "case.bin"), str(tmp_path / "out.bin")

@@ -270,25 +270,38 @@ dist.init_process_group("gloo")
 g = G.build_grid(16, mask="continents")
 d = decomp.local_domain(g, rank, world)
 rng = np.random.default_rng(42)
-glob = rng.uniform(0, 1, (g.nsea, 4, 6))          # same on every rank
-fl = torch.zeros((d.nrows, 4, 6), dtype=torch.float64)
-fl[: d.n] = torch.from_numpy(glob[d.lo:d.hi])
-HaloExchange(d, torch.device("cpu"))(fl)
-exp = glob[d.halo_global]
-ok = np.array_equal(fl[d.n:d.n + d.nh].numpy(), exp) and float(fl[d.nland].abs().sum()) == 0.0 and d.nh > 0
+h = HaloExchange(d, torch.device("cpu"))
+ok = d.nh > 0
+for shape in ((4, 6), (4, 2), (4, 6)):                 # full rows, compact fast-wave rows, full rows again (buffers per shape)
+    glob = rng.uniform(0, 1, (g.nsea,) + shape)        # same on every rank
+    fl = torch.zeros((d.nrows,) + shape, dtype=torch.float64)
+    fl[: d.n] = torch.from_numpy(glob[d.lo:d.hi])
+    reqs = h.start(fl)                                 # posted ...
+    a, b = d.interior()
+    interior_sum = float(fl[a:b].sum())                # ... the interior rows are usable meanwhile ...
+    h.finish(reqs)                                     # ... the halo rows after the wait
+    ok = ok and np.array_equal(fl[d.n:d.n + d.nh].numpy(), glob[d.halo_global]) and float(fl[d.nland].abs().sum()) == 0.0
+    ok = ok and abs(interior_sum - glob[d.lo + a:d.lo + b].sum()) < 1e-9
+    # the rows outside [a, b) are exactly those that read a halo row
+    nb = np.concatenate([d.klon.reshape(d.n, -1), d.klat.reshape(d.n, -1), d.kcor.reshape(d.n, -1)], 1)
+    needs = ((nb >= d.n) & (nb < d.nland)).any(1)
+    ok = ok and not needs[a:b].any()
 t = torch.tensor([1 if ok else 0]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
 dist.destroy_process_group()
 sys.exit(0 if int(t) == 1 else 3)
 '''
 
 
-def test_halo_exchange_gloo_world2(tmp_path):
-    """N>1 path on CPU: two processes, gloo backend, the same HaloExchange object the GPU path uses."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_gloo(tmp_path, world):
+    """N>1 path on CPU: `world` processes, gloo backend, the same HaloExchange object the GPU path uses, through the
+    start / finish pair Wamintgr.propag overlaps with the interior, for full rows and for compact fast-wave rows."""
     script = tmp_path / "w.py"
     script.write_text(GLOO_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29537", str(script), ROOT]
+    port = str(29537 + world)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", port, str(script), ROOT]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 

@@ -364,3 +364,22 @@ def test_speed_build_of_the_oracle_agrees_with_the_strict_build():
     b = H.oracle_implsch(case, Oracle(cfg, "dp", fast=True))
     st = H.compare_implsch(a, b, case["tables"])
     assert st["mij_flips"] == 0 and st["fl1_max_rel_peak_all"] < 1e-10 and st["swh_max_rel"] < 1e-12, st
+
+
+def test_oracle_regression_vectors():
+    """tests/golden/oracle_regression_dp.npz (tools/make_oracle_regression.py): frozen outputs of this repository's own oracle
+    for small seeded cases.  Regression only -- they say nothing about the reference.  Tolerance 1e-9 of each array's scale: libm
+    may differ between the machine that wrote them and the one that checks them."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_oracle_regression as M
+
+    want = np.load(os.path.join(ROOT, "tests", "golden", "oracle_regression_dp.npz"))
+    got = M.cases()
+    assert set(want.files) == set(got)
+    for k in want.files:
+        a, b = np.asarray(want[k], dtype=np.float64), np.asarray(got[k], dtype=np.float64)
+        assert a.shape == b.shape, k
+        if k.endswith("_MIJ"):
+            assert np.array_equal(a, b), k
+        else:
+            assert np.max(np.abs(a - b)) <= 1e-9 * max(np.max(np.abs(a)), 1e-300), k

@@ -220,7 +220,7 @@ class HipContext:
         if not (0 <= kijs <= kijl <= min(nrow, out.shape[0])):
             raise ValueError("OUTBS: KIJS/KIJL outside the operands")
         self._chk(self.lib.ecwam_hip_outbs(self._h, kijs, kijl, self._real(fl1, (nrow, self.NANG, self.NFRE), "FL1"), float(zmiss),
-                                           self._real(out, (out.shape[0], 4), "OUT"), _stream_ptr()))
+                                           self._real(out, (out.shape[0], 5), "OUT"), _stream_ptr()))
 
     def outwnorm(self, field, column: int, n: int, zmiss: float = -999.0):
         """(average, minimum, maximum, count) of field[:n, column] over the values != zmiss."""

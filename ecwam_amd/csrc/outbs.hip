@@ -1,6 +1,6 @@
 // Integrated output parameters on the device: the OUTBLOCK parameters the reference validates a run
-// with -- significant wave height, mean direction, mean period (outblock.F90:204,223-243 with FEMEAN femean.F90:84-121 and
-// STHQ sthq.F90:75-120) -- and the OUTWNORM statistics (average / minimum / maximum / non-missing count, outwnorm.F90), so
+// with -- significant wave height, mean direction, mean period, peak period (outblock.F90:204,223-263 with FEMEAN
+// femean.F90:84-121, STHQ sthq.F90:75-120 and DOMINANT_PERIOD dominant_period.F90:76-112) -- and the OUTWNORM statistics (average / minimum / maximum / non-missing count, outwnorm.F90), so
 // that a device-resident run can be checked without copying the spectra back.
 #include "dev.h"
 
@@ -47,8 +47,23 @@ __global__ void __launch_bounds__(256) k_outbs(const DevTab<T>* __restrict__ tp,
   if (CI == T(0)) CI = tb.EPSMIN;
   T THQ = m_atan2(SI, CI);
   if (THQ < T(0)) THQ = THQ + tb.ZPI;
+  // DOMINANT_PERIOD: lane = K finds its maximum, lane = M sums the cropped directions in the reference's order
+  T fmx = T(0);
+  if (actk)
+    for (int m = 0; m < NFRE; m++) fmx = m_max(fmx, sF[m * NAP + lane]);
+  const T FCROP = T(0.1) * umax(actk ? fmx : T(0));
+  T f1d = T(0);
+  if (actm) {
+    const T* p = sF + lane * NAP;
+    for (int kk = 0; kk < NANG; kk++)
+      if (p[kk] > FCROP) f1d = f1d + p[kk] * tb.DELTH;
+    f1d = (f1d * f1d) * (f1d * f1d);
+  }
+  T EM4, DP;
+  usum2(actm ? tb.DFIM[lane] * f1d : T(0), actm ? tb.DFIMFR[lane] * f1d : T(0), EM4, DP);
+  DP = (EM4 > T(0) && DP > tb.EPSMIN) ? EM4 / DP : T(0);
   if (lane == 0) {
-    T* o = out + (size_t)ij * 4;
+    T* o = out + (size_t)ij * 5;
     const T DEG = T(180.0) / tb.PI;
     o[0] = T(4) * m_sqrt(m_max(EM, T(0)));
     T d = DEG * THQ + T(180.0);
@@ -56,6 +71,7 @@ __global__ void __launch_bounds__(256) k_outbs(const DevTab<T>* __restrict__ tp,
     o[1] = d;
     o[2] = (FM > T(0)) ? T(1) / FM : zmiss;
     o[3] = EM;
+    o[4] = (DP > T(0)) ? DP : zmiss;
   }
 }
 

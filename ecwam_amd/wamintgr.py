@@ -304,9 +304,9 @@ class Wamintgr:
         a = restart.read_fl(path, self.n, self.cfg.nang, self.cfg.nfre, self.npdt)
         self.fl1[: self.n] = torch.from_numpy(a).to(self.dev)
 
-    # ---- OUTBS subset on the device: [n][4] = swh, mean direction, mean period, EM; norms = OUTWNORM (avg, min, max, count)
+    # ---- OUTBS subset on the device: [n][5] = swh, mean direction, mean period, EM, peak period; norms = OUTWNORM (avg, min, max, count)
     def outbs(self) -> torch.Tensor:
-        out = torch.zeros((self.n, 4), dtype=self.dtype, device=self.dev)
+        out = torch.zeros((self.n, 5), dtype=self.dtype, device=self.dev)
         self.ctx.outbs(0, self.n, self.fl1, out)
         return out
 

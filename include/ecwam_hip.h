@@ -250,8 +250,8 @@ int ecwam_hip_implsch(ecwam_hip_ctx *ctx, int kijs, int kijl, void *fl1, const v
 
 /*
  * Integrated output parameters without a spectrum copy-back (the device-side part of OUTBS: outblock.F90:204,223-243,
- * LSECONDORDER=F) for rows [kijs,kijl):  out[npts][4] = significant wave height 4*SQRT(EM) (FEMEAN), mean direction in
- * degrees / meteorological convention (STHQ), mean period 1/FM or zmiss, EM.
+ * LSECONDORDER=F) for rows [kijs,kijl):  out[npts][5] = significant wave height 4*SQRT(EM) (FEMEAN), mean direction in
+ * degrees / meteorological convention (STHQ), mean period 1/FM or zmiss, EM, peak period pp1d (DOMINANT_PERIOD) or zmiss.
  * ecwam_hip_outwnorm: the OUTWNORM statistics of one such field: result[4] (HOST doubles) = average, minimum, maximum over the
  * n values field[i*stride] that differ from zmiss, and their count (outwnorm.F90).  Synchronises the stream.
  */

@@ -1656,7 +1656,8 @@ void ora_newwind(int n, real *FF, const real *FFN) {
 }
 
 /* outblock.F90:204,223-243 for the parameters 1-3 (LSECONDORDER = F: FL2ND = FL1): FEMEAN (femean.F90:84-121), STHQ
- * (sthq.F90:75-120).  OUT [n][4] = SWH, MWD (degrees, meteorological convention), MWP (or ZMISS), EM. */
+ * (sthq.F90:75-120), DOMINANT_PERIOD (dominant_period.F90:76-112, the pp1d parameter, outblock.F90:256-263).
+ * OUT [n][5] = SWH, MWD (degrees, meteorological convention), MWP (or ZMISS), EM, PP1D (or ZMISS). */
 void ora_outbs(int n, const real *FL1a, real ZMISS, real *OUT) {
   const int NANG = S.NANG, NFRE = S.NFRE;
 #pragma omp parallel for schedule(static)
@@ -1682,11 +1683,28 @@ void ora_outbs(int n, const real *FL1a, real ZMISS, real *OUT) {
     if (CI == C_(0.0)) CI = S.EPSMIN;
     THQ = ATAN2(SI, CI);
     if (THQ < C_(0.0)) THQ = THQ + S.ZPI;
-    real *o = OUT + (size_t)ij * 4;
+    /* dominant_period.F90:76-112 */
+    real FCROP = C_(0.0), EM4 = C_(0.0), DP = C_(0.0);
+    for (int M = 0; M < NFRE; M++)
+      for (int K = 0; K < NANG; K++)
+        if (F(K, M) > FCROP) FCROP = F(K, M);
+    FCROP = C_(0.1) * FCROP;
+    for (int M = 0; M < NFRE; M++) {
+      real F1D4 = C_(0.0);
+      for (int K = 0; K < NANG; K++)
+        if (F(K, M) > FCROP) F1D4 = F1D4 + F(K, M) * S.DELTH;
+      F1D4 = powi(F1D4, 4);
+      EM4 = EM4 + S.DFIM[M] * F1D4;
+      DP = DP + S.DFIMFR[M] * F1D4;
+    }
+    if (EM4 > C_(0.0) && DP > S.EPSMIN) DP = EM4 / DP;
+    else DP = C_(0.0);
+    real *o = OUT + (size_t)ij * 5;
     o[0] = C_(4.0) * SQRT(RMAX(EM, C_(0.0)));
     o[1] = FMOD(S.DEG * THQ + C_(180.0), C_(360.0));
     o[2] = (FM > C_(0.0)) ? C_(1.0) / FM : ZMISS;
     o[3] = EM;
+    o[4] = (DP > C_(0.0)) ? DP : ZMISS;
   }
 }
 

@@ -133,10 +133,10 @@ class Oracle:
         return out
 
     def outbs(self, fl1, zmiss=-999.0):
-        """OUTBLOCK parameters 1-3: returns [n][4] = SWH, MWD [deg], MWP (or zmiss), EM."""
+        """OUTBLOCK parameters 1-3 and 6: returns [n][5] = SWH, MWD [deg], MWP (or zmiss), EM, PP1D (or zmiss)."""
         fl1 = np.ascontiguousarray(fl1, dtype=self.dtype)
         n = fl1.shape[0]
-        out = np.zeros((n, 4), dtype=self.dtype)
+        out = np.zeros((n, 5), dtype=self.dtype)
         zm = C.c_float(zmiss) if self.dtype == np.float32 else C.c_double(zmiss)
         self.lib.ora_outbs(C.c_int(n), self._p(fl1), zm, self._p(out))
         return out

@@ -696,8 +696,8 @@ def test_decomposed_step_is_bit_identical_on_device(api, prec, weights, lf):
 
 @pytest.mark.parametrize("prec", ["dp", "sp"])
 def test_outbs_parameters_and_norms(api, prec):
-    """Device-side OUTBS subset: swh / mean direction / mean period per point against the oracle's
-    FEMEAN + STHQ restatement, and the OUTWNORM statistics against numpy, with missing values."""
+    """Device-side OUTBS subset: swh / mean direction / mean period / peak period (pp1d) per point against
+    the oracle's FEMEAN + STHQ + DOMINANT_PERIOD restatement, and the OUTWNORM statistics against numpy, with missing values."""
     cfg = Config(nang=36, nfre=36, nfre_red=36)
     n = 3001
     case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=17)
@@ -706,7 +706,7 @@ def test_outbs_parameters_and_norms(api, prec):
     ctx = api.HipContext(case["tables"])
     dev = ctx.device
     fl1 = torch.from_numpy(case["FL1"]).to(dev)
-    out = torch.full((n, 4), -1.0, dtype=fl1.dtype, device=dev)
+    out = torch.full((n, 5), -1.0, dtype=fl1.dtype, device=dev)
     ctx.outbs(7, n - 3, fl1, out)
     torch.cuda.synchronize()
     got = out.cpu().numpy()
@@ -715,6 +715,9 @@ def test_outbs_parameters_and_norms(api, prec):
     tol = 1e-12 if prec == "dp" else 2e-6
     assert np.max(np.abs(g[:, 0] - r[:, 0]) / np.maximum(r[:, 0], 1e-3)) < tol            # swh
     assert np.max(np.abs(g[:, 2] - r[:, 2]) / r[:, 2]) < tol                                # mean period
+    assert np.max(np.abs(g[:, 4] - r[:, 4]) / np.abs(r[:, 4])) < 4 * tol                   # peak period (a 4th power inside)
+    assert r[:, 4].min() > 1.0 and r[:, 4].max() < 30.0 and np.median(r[:, 4] / r[:, 2]) > 1.0   # a period, mostly longer than the mean one
+    assert _oracle(cfg, prec).outbs(case["FL1"][5:6])[0, 4] == -999.0                       # empty spectrum: missing value
     dd = np.abs(g[:, 1] - r[:, 1]); dd = np.minimum(dd, 360.0 - dd)                         # direction, cyclic
     assert np.max(dd) < (1e-9 if prec == "dp" else 2e-2)
     # norms, with missing values

@@ -373,7 +373,10 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
                                                       const T* __restrict__ wlat, const T* __restrict__ wcor,
                                                       const T* __restrict__ cg, const T* __restrict__ cosphm1,
                                                       const int* __restrict__ order, int kijs, int kijl, int m0, int m1,
-                                                      int copy_rest, int ntiles, const T* __restrict__ obs, int mlf, T delpro_lf, int in_k) {
+                                                      int copy_rest, int ntiles, const T* __restrict__ obs, int mlf, T delpro_lf, int in_k,
+                                                      T* __restrict__ gout, int gout_k) {
+  // gout (optional): the first gout_k frequencies of every advected direction are ALSO written to the compact buffer
+  // gout[ij][K][gout_k] (the fast waves the next sub-step starts from: saves extracting them from the FL3 rows afterwards)
   // in_k: frequencies per direction in the INPUT rows (NFRE, or the width of a compact fast-wave buffer [ij][K][in_k]);
   // the output rows always have the FL layout.
   // mlf > 0: frequencies [0, mlf) (the fast waves, IFRELFMAX) advance with delpro_lf, the others with delpro, in one pass
@@ -521,6 +524,7 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
           if (m + c < m0 || m + c >= m1) r[c] = keep[c];
       }
       IO::st(f3 + own + el, r);
+      if (gout && m < gout_k) IO::st(gout + ((size_t)q[0] * NANG + k) * gout_k + m, r);
     }
   }
 }
@@ -1144,7 +1148,7 @@ void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, 
                          const void* zdello, double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat,
                          const int* kcor, const void* wlat, const void* wcor, const void* cg, const void* cosphm1, const int* order,
                          int kijs, int kijl, int m0, int m1, int copy_rest, int dims, const void* obs, int mlf, double delpro_lf, int in_k,
-                         hipStream_t s) {
+                         void* gout, int gout_k, hipStream_t s) {
   const int NANG = dims >> 16, NFRE = (dims >> 8) & 0xFF;
   if (in_k <= 0) in_k = NFRE;
   const int n = kijl - kijs;
@@ -1159,9 +1163,10 @@ void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, 
 #define OTF_ARGS                                                                                                              \
   (const DevTab<T>*)tab, (const T*)f1, (T*)f3, n_geom, ngy, (T)delpro, kxlt, (const T*)zdello, (T)xdella, (const T*)cosph,     \
       (const T*)sinph, klon, klat, kcor, (const T*)wlat, (const T*)wcor, (const T*)cg, (const T*)cosphm1, order, kijs, kijl, m0, \
-      m1, copy_rest, ntiles, (const T*)obs, mlf, (T)delpro_lf, in_k
+      m1, copy_rest, ntiles, (const T*)obs, mlf, (T)delpro_lf, in_k, (T*)gout, gout_k
   int vw = W;
   { const char* e_ = getenv("ECWAM_HIP_OTF_VW"); if (e_) vw = atoi(e_); }  // diagnostics
+  if (gout && (gout_k % W != 0 || (uintptr_t)gout % 16 != 0)) gout = nullptr;   // checked by the caller; never taken
   const bool vec = vw >= W && aligned && NFRE % W == 0 && in_k % W == 0;   // a range boundary inside a vector is handled by the kernel
   if (obs) {  // LSUBGRID
     if (vec) hipLaunchKernelGGL((k_propags2_otf<T, W, true>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
@@ -1281,7 +1286,7 @@ void launch_pack(const void* fl, const int* idx, int n, int rowlen, void* buf, h
   template void launch_propags2_otf<T>(const void*, const void*, void*, int, int, double, const int*, const void*, double,        \
                                        const void*, const void*, const int*, const int*, const int*, const void*, const void*,   \
                                        const void*, const void*, const int*, int, int, int, int, int, int, const void*, int, double,   \
-                                       int, hipStream_t);                                                                              \
+                                       int, void*, int, hipStream_t);                                                                              \
   template void launch_c2p<T>(const void*, void*, int, int, int, int, int, hipStream_t);                                          \
   template void launch_p2c<T>(const void*, void*, int, int, int, int, int, hipStream_t);                                          \
   template void launch_copy_freq_range<T>(const void*, void*, int, int, int, int, int, int, hipStream_t);                             \

@@ -91,7 +91,7 @@ def load() -> C.CDLL:
     lib.ecwam_hip_propags2.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
     lib.ecwam_hip_ctuw.argtypes = [vp, ci, ci, ci, cd, ci, ci, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ecwam_hip_propags2_otf.argtypes = [vp, vp, vp, ci, ci, cd, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
-    lib.ecwam_hip_propags2_otf_split.argtypes = [vp, vp, vp, ci, ci, cd, cd, ci, ci, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    lib.ecwam_hip_propags2_otf_split.argtypes = [vp, vp, vp, ci, ci, cd, cd, ci, ci, vp, ci, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
     lib.ecwam_hip_copy_freq_range.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
     lib.ecwam_hip_propdot.argtypes = [vp, ci, ci, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ecwam_hip_ctuw_refra.argtypes = [vp, ci, ci, ci, cd, ci, ci, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp]

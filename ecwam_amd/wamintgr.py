@@ -231,7 +231,8 @@ class Wamintgr:
                 self.ctx.propags2(self.fl1, self.fl3, g["klon"], g["klat"], g["kcor"], self.w, k0, k1, m1, m2, copy_rest=copy_rest)
             else:
                 self.ctx.propags2_otf(self.fl1, self.fl3, g, self.cgroup_ext, delpro, k0, k1, m1, m2, copy_rest=copy_rest,
-                                      order=self.order, ifrelfmax=split, delpro_lf=self.delpro_lf if split else None)
+                                      order=self.order, ifrelfmax=split, delpro_lf=self.delpro_lf if split else None,
+                                      gout=self.g1 if split else None)   # the fast waves also into the compact buffer
 
         def advect(m1, m2, delpro, copy_rest, split=0, rows=None, src=None):
             k0, k1 = rows if rows is not None else (0, self.n)
@@ -270,10 +271,11 @@ class Wamintgr:
             exchange_and_advect(passes)
         if lf:
             nstep_lf = int(round(float(c.idelpro) / float(self.delpro_lf)))
-            for _ in range(2, nstep_lf + 1):
+            for isub in range(2, nstep_lf + 1):
                 # FL1_EXT(:,:,1:IFRELFMAX) <- FL3_EXT ; exchange ; PROPAGS2 on the fast waves only
                 if self.g1 is not None:
-                    self.ctx.copy_freq_range(self.fl3, self.g1, self.n, 1, self.ifrelfmax)
+                    if isub > 2:      # the first pass wrote the compact buffer itself
+                        self.ctx.copy_freq_range(self.fl3, self.g1, self.n, 1, self.ifrelfmax)
                     exchange_and_advect([(1, self.ifrelfmax, float(self.delpro_lf), False)], src=self.g1)
                 else:
                     self.ctx.copy_freq_range(self.fl3, self.fl1, self.n, 1, self.ifrelfmax)

@@ -185,9 +185,11 @@ int ecwam_hip_propags2_otf(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n, 
  * in_nfre: 0 (f1 has the FL layout) or the width of a COMPACT input buffer f1[npts+1][NANG][in_nfre] that holds only the first
  * in_nfre frequencies of every direction (the fast waves between sub-steps: with M fastest in memory a frequency sub-range of
  * the full rows touches every cache line; the compact rows are 4.5x smaller at IFRELFMAX = 5).  f3 always has the FL layout.
+ * gout (may be NULL): compact buffer gout[npts+1][NANG][gout_nfre] that ALSO receives the first gout_nfre advected frequencies of
+ * every direction (what the next fast-wave sub-step starts from; gout_nfre a multiple of 16 bytes).
  */
 int ecwam_hip_propags2_otf_split(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n, int ngy, double delpro, double delpro_lf,
-                                 int ifrelfmax, int in_nfre, const int *kxlt, const void *zdello, double xdella, const void *cosph,
+                                 int ifrelfmax, int in_nfre, void *gout, int gout_nfre, const int *kxlt, const void *zdello, double xdella, const void *cosph,
                                  const void *sinph, const int *klon, const int *klat, const int *kcor, const void *wlat,
                                  const void *wcor, const void *cgroup_ext, const void *cosphm1_ext, const int *order, int kijs,
                                  int kijl, int nd3s, int nd3e, int copy_rest, void *stream);

@@ -27,7 +27,7 @@ def _write_case(path, m, cfg, grid, nproma, nstep):
     with open(path, "wb") as f:
         hdr = np.array([cfg.nang, cfg.nfre, cfg.nfre_red, nproma, nchnk, n, grid.ngy, cfg.idelt, cfg.idelpro,
                         np.dtype(dt).itemsize, nstep, ctypes.sizeof(params), len(keep), int(m.ifrelfmax),
-                        int(m.delpro_lf or 0)], dtype=np.int32)
+                        int(m.delpro_lf or 0), int(cfg.irefra != 0), int(bool(getattr(m, 'llcflcuroff', False)))], dtype=np.int32)
         f.write(hdr.tobytes())
         f.write(bytes(params))
         for a in keep:
@@ -55,11 +55,14 @@ def _write_case(path, m, cfg, grid, nproma, nstep):
         ff = m.ff.cpu().numpy()
         for i in range(16):
             f.write(F(chunk(ff[:, i]), dt))
+        if cfg.irefra:
+            for a in (m.depth_ext, m.u_ext, m.v_ext, m.omosnh2kd_ext, m.wavnum_ext):
+                f.write(F(a.cpu().numpy(), dt))
     return nchnk
 
 
-@pytest.mark.parametrize("prec,lf", [("sp", 0), ("dp", 0), ("sp", 5)])
-def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec, lf):
+@pytest.mark.parametrize("prec,lf,irefra", [("sp", 0, 0), ("dp", 0, 0), ("sp", 5, 0), ("sp", 0, 2), ("dp", 0, 3)])
+def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec, lf, irefra):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from ecwam_amd import build, grid as G
@@ -68,10 +71,12 @@ def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec, lf):
     exe = build.fortran_exe(prec)
     if not os.path.exists(exe):
         build.build_fortran()
-    cfg = Config(nang=12, nfre=36, nfre_red=25, idelt=900, idelpro=900)
+    cfg = Config(nang=12, nfre=36, nfre_red=25, idelt=900, idelpro=900, irefra=irefra)
     g = G.build_grid(16, mask="continents")
     m = Wamintgr(cfg, g, prec, ifrelfmax=lf, delpro_lf=450.0 if lf else None)    # lf: fast waves M <= lf in two sub-steps
     m.init_synthetic(seed=21)
+    m.llcflcuroff = irefra != 3     # refraction: ECWAM_HIP_SET_ENVIRONMENT on the Fortran side, with and without LLCFLCUROFF
+    assert m.nrows == g.nsea + 1
     nproma, nstep = 24, 2
     case, out = str(tmp_path / "case.bin"), str(tmp_path / "out.bin")
     nchnk = _write_case(case, m, cfg, g, nproma, nstep)

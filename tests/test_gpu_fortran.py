@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-def _write_case(path, m, cfg, grid, nproma, nstep):
+def _write_case(path, m, cfg, grid, nproma, nstep, obs=None):
     from ecwam_amd import lib as L, synthetic as syn
 
     t = m.t
@@ -27,7 +27,8 @@ def _write_case(path, m, cfg, grid, nproma, nstep):
     with open(path, "wb") as f:
         hdr = np.array([cfg.nang, cfg.nfre, cfg.nfre_red, nproma, nchnk, n, grid.ngy, cfg.idelt, cfg.idelpro,
                         np.dtype(dt).itemsize, nstep, ctypes.sizeof(params), len(keep), int(m.ifrelfmax),
-                        int(m.delpro_lf or 0), int(cfg.irefra != 0), int(bool(getattr(m, 'llcflcuroff', False)))], dtype=np.int32)
+                        int(m.delpro_lf or 0), int(cfg.irefra != 0), int(bool(getattr(m, 'llcflcuroff', False))),
+                        int(obs is not None)], dtype=np.int32)
         f.write(hdr.tobytes())
         f.write(bytes(params))
         for a in keep:
@@ -58,11 +59,15 @@ def _write_case(path, m, cfg, grid, nproma, nstep):
         if cfg.irefra:
             for a in (m.depth_ext, m.u_ext, m.v_ext, m.omosnh2kd_ext, m.wavnum_ext):
                 f.write(F(a.cpu().numpy(), dt))
+        if obs is not None:   # OBS[n][8][NFRE] -> OBSLAT(N,NFRE_RED,2), OBSLON(N,NFRE_RED,2), OBSCOR(N,NFRE_RED,4)
+            o = np.moveaxis(np.asarray(obs)[:, :, :cfg.nfre_red], 1, 2)
+            f.write(F(o[:, :, 0:2], dt) + F(o[:, :, 2:4], dt) + F(o[:, :, 4:8], dt))
     return nchnk
 
 
-@pytest.mark.parametrize("prec,lf,irefra", [("sp", 0, 0), ("dp", 0, 0), ("sp", 5, 0), ("sp", 0, 2), ("dp", 0, 3)])
-def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec, lf, irefra):
+@pytest.mark.parametrize("prec,lf,irefra,subgrid", [("sp", 0, 0, False), ("dp", 0, 0, False), ("sp", 5, 0, False), ("sp", 0, 2, False),
+                                                    ("dp", 0, 3, False), ("sp", 0, 0, True), ("sp", 0, 2, True)])
+def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec, lf, irefra, subgrid):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from ecwam_amd import build, grid as G
@@ -77,9 +82,15 @@ def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec, lf, irefra):
     m.init_synthetic(seed=21)
     m.llcflcuroff = irefra != 3     # refraction: ECWAM_HIP_SET_ENVIRONMENT on the Fortran side, with and without LLCFLCUROFF
     assert m.nrows == g.nsea + 1
+    obs = None
+    if subgrid:     # LSUBGRID: ECWAM_HIP_SET_SUBGRID on the Fortran side
+        from ecwam_amd import synthetic as syn
+        obs = syn.obstructions(g, cfg.nfre, seed=5)
+        obs[:, :, cfg.nfre_red:] = 1.0
+        m.set_obstructions(obs)
     nproma, nstep = 24, 2
     case, out = str(tmp_path / "case.bin"), str(tmp_path / "out.bin")
-    nchnk = _write_case(case, m, cfg, g, nproma, nstep)
+    nchnk = _write_case(case, m, cfg, g, nproma, nstep, obs)
     r = subprocess.run([exe, case, out], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
     for _ in range(nstep):

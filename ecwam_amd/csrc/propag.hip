@@ -404,13 +404,21 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
   int* sI = reinterpret_cast<int*>(sP + OTF_TP);                    // [TP][16]: ij, ilon[2], ilat[2][2], icor[4][2]
   T* sB = reinterpret_cast<T*>(sI + OTF_TP * 16);                   // [TP][5][NFRE]
   T* sK = sB + (size_t)OTF_TP * 5 * NFRE;                           // [NANG][4]: (SINTH+SINTH(K+1))*DELTH0/R, same for K-1; both for DELTH0_LF
-  T* sO = sK + 4 * NANG;                                            // OBS: [TP][8][NFRE] transmission coefficients
+  T* sT = sK + 4 * NANG;                                            // [NANG][2]: SINTH, COSTH
+  int* sD = reinterpret_cast<int*>(sT + 2 * NANG);                  // [NANG][8]: JXO(K,1:2), JYO(K,1:2), KCR(K,1), KPM(K,-1), KPM(K,1)
+  T* sO = reinterpret_cast<T*>(sD + 8 * NANG);                      // OBS: [TP][8][NFRE] transmission coefficients
+  // the per-direction tables go to LDS once per block: read from the DevTab in global memory inside the stencil loop they
+  // were seven more loads in front of every group of gathers, through the same L1 miss queue the gathers wait in
   for (int k = threadIdx.x; k < NANG; k += blockDim.x) {
     T a, b;
     ctu_dirfac(tab, k, DELTH0, T(1), a, b);  // TANPH applied per point below: TANPH*SP is formed as in k_ctuw
     sK[4 * k] = a; sK[4 * k + 1] = b;
     ctu_dirfac(tab, k, DELTH0_LF, T(1), a, b);
     sK[4 * k + 2] = a; sK[4 * k + 3] = b;
+    sT[2 * k] = tab->SINTH[k]; sT[2 * k + 1] = tab->COSTH[k];
+    int* d = sD + 8 * k;
+    d[0] = tab->JXO[k][0]; d[1] = tab->JXO[k][1]; d[2] = tab->JYO[k][0]; d[3] = tab->JYO[k][1]; d[4] = tab->KCR[k][0];
+    d[5] = tab->KPM[k][0]; d[6] = tab->KPM[k][2]; d[7] = 0;
   }
   // XCD-aware tile walk: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own 4 MiB L2.  XCD x
   // walks the contiguous tile range [x*tpx, (x+1)*tpx) so that a spectrum fetched as somebody's neighbour is still in that
@@ -472,9 +480,10 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
       }
       const bool partial = (VW > 1) && (m < m0 || m + VW > m1);   // the range boundary cuts this vector
       const CtuPoint<T>& p = sP[t];
-      const int jx0 = tab->JXO[k][0], jx1 = tab->JXO[k][1], jy0 = tab->JYO[k][0], jy1 = tab->JYO[k][1], kc = tab->KCR[k][0];
-      const int km = tab->KPM[k][0], kp = tab->KPM[k][2];
-      const T sink = tab->SINTH[k], cosk = tab->COSTH[k];
+      const int* dk = sD + 8 * k;
+      const int jx0 = dk[0], jx1 = dk[1], jy0 = dk[2], jy1 = dk[3], kc = dk[4];
+      const int km = dk[5], kp = dk[6];
+      const T sink = sT[2 * k], cosk = sT[2 * k + 1];
       T tsp, tsm, tsp_lf, tsm_lf;
       {
 #pragma clang fp contract(off)
@@ -1167,7 +1176,7 @@ void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, 
   if (n <= 0) return;
   const int ntiles = (n + OTF_TP - 1) / OTF_TP;
   const size_t shmem = OTF_TP * (sizeof(CtuPoint<T>) + 16 * sizeof(int)) +
-                       ((size_t)OTF_TP * (obs ? 13 : 5) * NFRE + 4 * NANG) * sizeof(T) + 16;
+                       ((size_t)OTF_TP * (obs ? 13 : 5) * NFRE + 6 * NANG) * sizeof(T) + 8 * NANG * sizeof(int) + 16;
   int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
   grid = (grid + 7) & ~7;  // whole rounds of the 8 XCDs
   constexpr int W = VecOf<T>::W;

@@ -786,11 +786,18 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
   T* sR = sB + (size_t)GEN_TP * 7 * NFRE;                           // [TP][RW]
   T* sK = sR + (size_t)GEN_TP * RW;                                 // [NANG][2]
   T* sDF = sK + 2 * NANG;                                           // [2][NFRE]: DELFR0/FR(M), DELFR0/FR(MAX(1,M-1))
-  T* sO = sDF + 2 * NFRE;                                           // OBS: [TP][8][NFRE] transmission coefficients (LSUBGRID)
-  for (int k = threadIdx.x; k < NANG; k += blockDim.x) {
+  T* sT = sDF + 2 * NFRE;                                           // [NANG][2]: SINTH, COSTH
+  int* sD = reinterpret_cast<int*>(sT + 2 * NANG);                  // [NANG][12]: JXO(K,1:2), JYO(K,1:2), KPM(K,-1), KPM(K,1), -, -, KCR(K,1:4)
+  T* sO = reinterpret_cast<T*>(sD + 12 * NANG);                     // OBS: [TP][8][NFRE] transmission coefficients (LSUBGRID)
+  for (int k = threadIdx.x; k < NANG; k += blockDim.x) {            // per-direction tables: LDS instead of global loads in the stencil loop
     T a, b;
     ctu_dirfac(tab, k, DELTH0, T(1), a, b);
     sK[2 * k] = a; sK[2 * k + 1] = b;
+    sT[2 * k] = tab->SINTH[k]; sT[2 * k + 1] = tab->COSTH[k];
+    int* d = sD + 12 * k;
+    d[0] = tab->JXO[k][0]; d[1] = tab->JXO[k][1]; d[2] = tab->JYO[k][0]; d[3] = tab->JYO[k][1];
+    d[4] = tab->KPM[k][0]; d[5] = tab->KPM[k][2]; d[6] = 0; d[7] = 0;
+    for (int i = 0; i < 4; i++) d[8 + i] = tab->KCR[k][i];
   }
   for (int m = threadIdx.x; m < NFRE; m += blockDim.x) {
 #pragma clang fp contract(off)
@@ -848,10 +855,11 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
         continue;
       }
       const CtuPoint<T>& p = sP[t];
-      const int jx0 = tab->JXO[k][0], jx1 = tab->JXO[k][1], jy0 = tab->JYO[k][0], jy1 = tab->JYO[k][1];
-      const int* kc = tab->KCR[k];
-      const int km = tab->KPM[k][0], kp = tab->KPM[k][2];
-      const T sink = tab->SINTH[k], cosk = tab->COSTH[k];
+      const int* dk = sD + 12 * k;
+      const int jx0 = dk[0], jx1 = dk[1], jy0 = dk[2], jy1 = dk[3];
+      const int* kc = dk + 8;
+      const int km = dk[4], kp = dk[5];
+      const T sink = sT[2 * k], cosk = sT[2 * k + 1];
       const T* bb = sB + (size_t)t * 7 * NFRE;
       const T* rr = sR + (size_t)t * RW;
       const T u = rr[REFR_U(NANG)], v = rr[REFR_V(NANG)];
@@ -1231,7 +1239,7 @@ void launch_propags2_gen(const void* tab, int irefra, const void* f1, void* f3, 
   if (n <= 0) return;
   const int ntiles = (n + GEN_TP - 1) / GEN_TP;
   const size_t shmem = GEN_TP * (sizeof(CtuPoint<T>) + 16 * sizeof(int)) +
-                       ((size_t)GEN_TP * (obs && f1 ? 15 : 7) * NFRE + (size_t)GEN_TP * REFR_W(NANG) + 2 * NANG + 2 * NFRE) * sizeof(T) + 16;
+                       ((size_t)GEN_TP * (obs && f1 ? 15 : 7) * NFRE + (size_t)GEN_TP * REFR_W(NANG) + 4 * NANG + 2 * NFRE) * sizeof(T) + 12 * NANG * sizeof(int) + 16;
   const int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
   constexpr int W = VecOf<T>::W;
   const bool aligned = ((uintptr_t)f1 % 16 == 0) && ((uintptr_t)f3 % 16 == 0);

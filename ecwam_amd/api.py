@@ -217,6 +217,23 @@ class HipContext:
             pw = wam2nemo.data_ptr()
         self._chk(self.lib.ecwam_hip_implsch(self._h, kijs, kijl, *a, pw, pd, _stream_ptr()))
 
+    # -- SNONLIN alone in the three-points-per-wavefront layout (diagnostic seam, include/ecwam_hip.h)
+    def snonlin3(self, fl1, depth, akmean, mode: int = 0):
+        """Returns (SL, FLD) as [n][NANG][NFRE] tensors (re-ordered from the kernel's [n][NFRE][18][2] pair layout)."""
+        n = fl1.shape[0]
+        if self.dtype != torch.float32 or self.NANG != 36:
+            raise ValueError("SNONLIN3: single precision and NANG = 36 only")
+        p1 = self._real(fl1, (n, self.NANG, self.NFRE), "FL1")
+        pd, pa = self._real(depth, (n,), "DEPTH"), self._real(akmean, (n,), "AKMEAN")
+        sl = torch.empty((n, self.NFRE, 18, 2), dtype=self.dtype, device=self.device)
+        fld = torch.empty_like(sl)
+        self._chk(self.lib.ecwam_hip_snonlin3(self._h, n, p1, pd, pa, sl.data_ptr(), fld.data_ptr(), int(mode), _stream_ptr()))
+
+        def std(x):   # [n][M][j][h] -> [n][K = j + 18 h][M]
+            return x.permute(0, 3, 2, 1).reshape(n, 36, self.NFRE)
+
+        return std(sl), std(fld)
+
     # -- OUTBS subset (outblock.F90 parameters 1-3) and OUTWNORM statistics, on the device
     def outbs(self, kijs, kijl, fl1, out, zmiss: float = -999.0):
         nrow = fl1.shape[0]

@@ -260,6 +260,17 @@ int ecwam_hip_implsch(ecwam_hip_ctx *ctx, int kijs, int kijl, void *fl1, const v
 int ecwam_hip_outbs(ecwam_hip_ctx *ctx, int kijs, int kijl, const void *fl1, double zmiss, void *out, void *stream);
 int ecwam_hip_outwnorm(ecwam_hip_ctx *ctx, const void *field, int stride, int n, double zmiss, double *result, void *stream);
 
+/*
+ * SNONLIN alone (snonlin.F90:10-13, 100-330: the discrete interaction approximation; ISNONLIN = 0, single precision,
+ * NANG = 36) in the three-points-per-wavefront lane layout planned for the next IMPLSCH kernel: a
+ * diagnostic seam to validate and time that layout, not used by ecwam_hip_implsch.  fl1: device float FL1[n][NANG][NFRE];
+ * depth, akmean: device float [n] (WVENVI%DEPTH, AKMEAN of FKMEAN); sl, fld: device float [n][NFRE][18][2], the
+ * contributions SNONLIN adds to SL and FLD (starting from zero), direction K = j + 18 h at [..][j][h].
+ * mode 0: the DIA; mode 1: load / store only (SL = F, FLD = 0: the timing baseline).  Returns non-zero for other configurations.
+ */
+int ecwam_hip_snonlin3(ecwam_hip_ctx *ctx, int n, const void *fl1, const void *depth, const void *akmean, void *sl, void *fld,
+                       int mode, void *stream);
+
 /* NEWWIND forcing hand-over (newwind.F90:126-161, ICODE_WND=3): FF <- FF_NEXT members + TAUW cap */
 int ecwam_hip_newwind(ecwam_hip_ctx *ctx, int n, void *ff, const void *ff_next, void *stream);
 

@@ -803,3 +803,41 @@ def test_implsch_parity_48_directions(api, prec):
         assert st["mij_flips"] == 0 and st["fl1_max_rel_peak_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
     else:
         assert st["mij_flips"] <= 2 and st["fl1_max_rel_peak_clean"] < 1e-4 and st["swh_max_rel"] < 1e-5, st
+
+
+def test_snonlin_three_points_per_wavefront_layout(api):
+    """ecwam_hip_snonlin3 (the DIA in the lane layout of the next IMPLSCH kernel: three points per wavefront, direction pairs
+    packed) against the oracle's SNONLIN, SL and FLD from zero.  Single precision: within 2e-5 of the point's largest |SL| / |FLD|
+    (the device contracts multiply-adds, the oracle does not)."""
+    import ctypes as C
+
+    cfg = Config(nang=36, nfre=36, nfre_red=36)
+    n = 1000          # not a multiple of 3 points x 2 waves per block
+    case = H.make_point_case(n, cfg, "sp", spectra="mixed", seed=31)
+    t = case["tables"]
+    for kh in range(2):   # the layout relies on the interaction tables being rotations of the directions
+        for name in ("K1W", "K2W", "K11W", "K21W"):
+            a = np.asarray(getattr(t, name))[:, kh] - 1 if np.asarray(getattr(t, name)).shape[0] == 36 else np.asarray(getattr(t, name))[kh] - 1
+            assert np.array_equal((a[:18] + 18) % 36, a[18:] % 36), name
+    o = _oracle(cfg, "sp")
+    depth = case["ENV"][:, 1].astype(np.float32)
+    ak = case["props"]["WAVNUM"][:, 10].astype(np.float32)
+    ref_sl, ref_fld = np.zeros_like(case["FL1"]), np.zeros_like(case["FL1"])
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for i in range(n):
+        fl = np.ascontiguousarray(case["FL1"][i])
+        wn = np.ascontiguousarray(case["props"]["WAVNUM"][i])
+        sl, fld = np.zeros_like(fl), np.zeros_like(fl)
+        o.lib.ora_snonlin(p(fl), C.c_float(float(depth[i])), C.c_float(float(ak[i])), p(wn), p(sl), p(fld))
+        ref_sl[i], ref_fld[i] = sl, fld
+    ctx = api.HipContext(t)
+    dev = ctx.device
+    sl, fld = ctx.snonlin3(torch.from_numpy(case["FL1"]).to(dev), torch.from_numpy(depth).to(dev), torch.from_numpy(ak).to(dev))
+    torch.cuda.synchronize()
+    sl, fld = sl.cpu().numpy().astype(float), fld.cpu().numpy().astype(float)
+    for got, ref in ((sl, ref_sl.astype(float)), (fld, ref_fld.astype(float))):
+        scale = np.abs(ref).max(axis=(1, 2), keepdims=True) + 1e-300
+        assert np.isfinite(got).all() and np.max(np.abs(got - ref) / scale) < 2e-5
+    base_sl, _ = ctx.snonlin3(torch.from_numpy(case["FL1"]).to(dev), torch.from_numpy(depth).to(dev), torch.from_numpy(ak).to(dev), mode=1)
+    assert np.array_equal(base_sl.cpu().numpy(), case["FL1"])      # the load / store baseline returns the spectrum itself
+    ctx.close()

@@ -8,7 +8,7 @@
 // rotation crosses K = 18 an odd number of times: one ds_bpermute per half plus a select, per-lane constants.
 //
 // This file is a self-contained entry point (the reference's SNONLIN seam, SL and FLD starting from zero) used to validate the
-// layout against the oracle and to time the DIA in it against k_implsch2's (tools/time_snonlin3.py); IMPLSCH itself still
+// layout (tests/test_gpu_parity.py) and to time the DIA in it against k_implsch2's (tools/time_snonlin3.py); IMPLSCH itself still
 // runs k_implsch2.
 #include <hip/hip_runtime.h>
 

@@ -39,6 +39,7 @@ template <typename T> void launch_propags2_gen(const void*, int, const void*, vo
 template <typename T> void launch_propags2_otf(const void*, const void*, void*, int, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const int*, int, int, int, int, int, int, const void*, int, double, int, void*, int, hipStream_t);
 template <typename T> void launch_copy_freq_range(const void*, void*, int, int, int, int, int, int, hipStream_t);
 template <typename T> int launch_outbs(const void*, int, int, const void*, double, void*, int, int, hipStream_t);
+int launch_sinput3(const void*, int, int, int, const void*, const void*, const void*, void*, void*, void*, void*, int, hipStream_t);
 int launch_snonlin3(const void*, int, int, int, int, const void*, const void*, const void*, void*, void*, int, hipStream_t);
 template <typename T> void launch_norm(const void*, int, int, double, double*, int, hipStream_t);
 template <typename T> void launch_newwind(const void*, int, void*, const void*, hipStream_t);
@@ -461,6 +462,18 @@ int ecwam_hip_snonlin3(ecwam_hip_ctx* c, int n, const void* fl1, const void* dep
   if (c->real_bytes != 4 || c->p.isnonlin != 0) return fail("ecwam_hip_snonlin3: single precision, ISNONLIN = 0 only");
   if (launch_snonlin3(c->dtab, c->NANG, c->NFRE, c->implsch_variant == 2, n, fl1, depth, akmean, sl, fld, mode, (hipStream_t)stream))
     return fail("ecwam_hip_snonlin3: needs NANG = 36 and interaction tables with the rotation structure");
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ecwam_hip_sinput3(ecwam_hip_ctx* c, int n, const void* fl1, const void* wvprpt, const void* pt, void* fld, void* spos, void* xllws,
+                      void* xys, int mode, void* stream) {
+  if (!c) return fail("null context");
+  if (n < 0 || (n > 0 && (!fl1 || !wvprpt || !pt || !fld || !spos || !xllws || !xys))) return fail("ecwam_hip_sinput3: bad arguments");
+  if (c->real_bytes != 4 || c->p.iphys != 1 || c->p.llnormagam || c->p.tauwshelter == 0.0)
+    return fail("ecwam_hip_sinput3: single precision, IPHYS = 1, LLNORMAGAM = F, TAUWSHELTER /= 0 only");
+  if (launch_sinput3(c->dtab, c->NANG, c->NFRE, n, fl1, wvprpt, pt, fld, spos, xllws, xys, mode, (hipStream_t)stream))
+    return fail("ecwam_hip_sinput3: needs NANG = 36");
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -182,3 +182,189 @@ int launch_snonlin3(const void* tab, int nang, int nfre, int dia_pull, int n, co
                        (const float*)depth, (const float*)akmean, (float*)sl, (float*)fld);
   return 0;
 }
+
+// =====================================================================================================================
+// SINPUT_ARD (sinput_ard.F90:153-520) in the same lane layout: the second SINFLX call (NGST = 2, LLSNEG = T) with the
+// sheltering recurrence (TAUWSHELTER /= 0), LLNORMAGAM = F.  Per row M the stress of each gust state over all 36
+// directions is an all-reduce within the point's 18 lanes (no DPP: the groups straddle the 16-lane rows), two
+// quantities per packed operand.
+// in : pt[n][12] = UFRIC, Z0M, RAORW, SIG_N, TEMP2, PTURB, AIRD_PVISC, SIN(WDWAVE), COS(WDWAVE), -, -, -
+//      wvprpt[n][5][NFRE] (WAVNUM, CGROUP, CINV, XK2CG, STOKFAC: the rows IMPLSCH receives)
+// out: fld, spos, xllws [n][NFRE][18][2]; xys[n][NFRE][4] = SUM_K SPOS*SINTH, SUM_K SPOS*COSTH, SUM_K SPOS, -
+// =====================================================================================================================
+__device__ __forceinline__ F2 s3_same(F2 v, int addr) {   // both halves from the same lane, no swap
+  F2 r;
+  r.x = s3_bperm(addr, v.x);
+  r.y = s3_bperm(addr, v.y);
+  return r;
+}
+// sums over the 18 lanes of a point, every lane gets them: x and y are two independent quantities
+__device__ __forceinline__ F2 s3_allsum(F2 v, int a9, int a3, int a6, int a1, int a2) {
+  v = v + s3_same(v, a9);
+  v = v + (s3_same(v, a3) + s3_same(v, a6));
+  v = v + (s3_same(v, a1) + s3_same(v, a2));
+  return v;
+}
+
+#define S3_NFAC 8
+template <int WPB, int MODE>
+__global__ void __launch_bounds__(64 * WPB) k_sinput3(const DevTab<float>* __restrict__ tp, int n, const float* __restrict__ fl1,
+                                                      const float* __restrict__ wvprpt, const float* __restrict__ pt,
+                                                      float* __restrict__ fld, float* __restrict__ spos, float* __restrict__ xllws,
+                                                      float* __restrict__ xys) {
+  extern __shared__ __align__(16) unsigned char s3_smem[];
+  const DevTab<float>& tb = *tp;
+  const int NANG = tb.NANG, NFRE = tb.NFRE, N = NANG * NFRE;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int p = lane / S3_GROUP, j = lane - p * S3_GROUP;
+  const int ij0 = (blockIdx.x * WPB + wave) * S3_PTS;
+  if (ij0 >= n) return;
+  const bool grp = p < S3_PTS;
+  const bool act = grp && (ij0 + p < n);
+  const int ij = act ? ij0 + p : ij0;
+  float* sF = reinterpret_cast<float*>(s3_smem) + (size_t)wave * S3_PTS * (N + S3_NFAC * NFRE);
+  float* sFac = sF + S3_PTS * N;   // [point][M][S3_NFAC]: ZCN, CNSN, CONSTF, DSTAB1, TEMP1, CINV, RHOWG_DFIM, -
+  for (int q = 0; q < S3_PTS; q++) {
+    if (ij0 + q >= n) break;
+    const float* g = fl1 + (size_t)(ij0 + q) * N;
+    float* t = sF + q * N;
+    for (int e = lane; e < N; e += 64) {
+      const int k = e / NFRE, m = e - k * NFRE;
+      t[m * NANG + 2 * (k % S3_GROUP) + k / S3_GROUP] = g[e];
+    }
+  }
+  // ---- per-point scalars, replicated over the point's lanes
+  const float* q = pt + (size_t)ij * 12;
+  const float UFRIC = q[0], Z0M = q[1], RAORW = q[2], SIG_N = q[3], TEMP2 = q[4], PTURB = q[5], AIRD_PVISC = q[6];
+  const float sinwd = q[7], coswd = q[8];
+  const float CONST1 = tb.BETAMAXOXKAPPA2, ABS_TAUWSHELTER = fabsf(tb.TAUWSHELTER);
+  const float FU = fabsf(tb.SWELLF3), FUD = tb.SWELLF2, ROGOROAIR = tb.G / RAORW;
+  // ---- per-frequency factors of the point (sinput_ard.F90:340-354, 379-388): lane j evaluates M = j+1 and j+19
+  if (act) {
+    const float* wp = wvprpt + (size_t)ij * ECWAM_HIP_NWPR * NFRE;
+    for (int m = j; m < NFRE; m += S3_GROUP) {
+      const float SIG = tb.ZPIFR[m], WAVNUM = wp[m], CINV = wp[2 * NFRE + m];
+      float* f = sFac + ((size_t)p * NFRE + m) * S3_NFAC;
+      f[0] = __logf(WAVNUM * Z0M);
+      f[1] = (SIG * CONST1) * RAORW;
+      f[2] = ROGOROAIR * CINV * tb.DFIM[m];
+      f[3] = (-tb.SWELLF5 * 2.0f * f_sqrt(2.0f * tb.RNU * SIG)) * AIRD_PVISC * WAVNUM;
+      f[4] = (-tb.SWELLF * 16.0f * (SIG * SIG) / tb.G) * RAORW;
+      f[5] = CINV;
+      f[6] = tb.RHOWG_DFIM[m];
+      f[7] = 0.f;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const float* tF = sF + (grp ? p : 0) * N + 2 * j;
+  const float* tFac = sFac + (size_t)(grp ? p : 0) * NFRE * S3_NFAC;
+  const size_t orow = (size_t)ij * NFRE * NANG + 2 * j;
+  if (MODE == 1) {   // load / store only
+    if (act)
+      for (int m = 0; m < NFRE; m++) {
+        const F2 f = *reinterpret_cast<const F2*>(tF + m * NANG);
+        *reinterpret_cast<F2*>(fld + orow + (size_t)m * NANG) = f;
+        *reinterpret_cast<F2*>(spos + orow + (size_t)m * NANG) = f;
+        *reinterpret_cast<F2*>(xllws + orow + (size_t)m * NANG) = F2{0.f, 0.f};
+        if (j == 0) *reinterpret_cast<float4*>(xys + ((size_t)ij * NFRE + m) * 4) = float4{0.f, 0.f, 0.f, 0.f};
+      }
+    return;
+  }
+  const int base = (grp ? p : 0) * S3_GROUP;
+#define S3_ROT(r) (4 * (base + ((j + (r)) >= S3_GROUP ? j + (r) - S3_GROUP : j + (r))))
+  const int a9 = S3_ROT(9), a3 = S3_ROT(3), a6 = S3_ROT(6), a1 = S3_ROT(1), a2 = S3_ROT(2);
+#undef S3_ROT
+  const F2 sinth = {tb.SINTH[j], tb.SINTH[j + S3_GROUP]}, costh = {tb.COSTH[j], tb.COSTH[j + S3_GROUP]};
+  const float XKAPPA = tb.XKAPPA, ZALP = tb.ZALP;
+  float USTP[2], XSTRESS[2] = {0.f, 0.f}, YSTRESS[2] = {0.f, 0.f}, TAUX[2], TAUY[2];
+  USTP[0] = UFRIC * (1.0f + SIG_N);
+  USTP[1] = UFRIC * (1.0f - SIG_N);
+#pragma unroll
+  for (int ig = 0; ig < 2; ig++) {
+    const float USG2 = USTP[ig] * USTP[ig];
+    TAUX[ig] = USG2 * sinwd;
+    TAUY[ig] = USG2 * coswd;
+  }
+  for (int m = 0; m < NFRE; m++) {
+    const float4 fa = *reinterpret_cast<const float4*>(tFac + m * S3_NFAC);      // ZCN, CNSN, CONSTF, DSTAB1
+    const float2 fb = *reinterpret_cast<const float2*>(tFac + m * S3_NFAC + 4);   // TEMP1, CINV
+    const float ZCN = fa.x, CNSN = fa.y, CONSTF = fa.z, DSTAB1 = fa.w, TEMP1 = fb.x, cinv_m = fb.y;
+    const F2 f = *reinterpret_cast<const F2*>(tF + m * NANG);
+    F2 SLP[2], FLP[2];
+    bool xl0 = false, xl1 = false;   // XLLWS of the two halves
+#pragma unroll
+    for (int ig = 0; ig < 2; ig++) {
+      const float TAUPX = TAUX[ig] - ABS_TAUWSHELTER * XSTRESS[ig];
+      const float TAUPY = TAUY[ig] - ABS_TAUWSHELTER * YSTRESS[ig];
+      const float h2 = TAUPX * TAUPX + TAUPY * TAUPY;
+      const bool zero = !(h2 > 0.f);
+      const float rh = f_rsq(h2);
+      const float h = zero ? 0.f : h2 * rh;
+      const float COSU = zero ? 1.f : TAUPY * rh, SINU = zero ? 0.f : TAUPX * rh;
+      USTP[ig] = f_sqrt(h);
+      const float UCN = USTP[ig] * cinv_m;
+      const float UCNZALPD = XKAPPA * f_rcp(UCN + ZALP);
+      const F2 coslp = costh * COSU + sinth * SINU;
+      F2 gam0 = {0.f, 0.f};
+      {
+        const bool c0 = coslp.x > 0.01f, c1 = coslp.y > 0.01f;
+        const float Z0 = ZCN + UCNZALPD * f_rcp(coslp.x), Z1 = ZCN + UCNZALPD * f_rcp(coslp.y);
+        const bool n0 = c0 && (Z0 < 0.f), n1 = c1 && (Z1 < 0.f);
+        if (__builtin_amdgcn_ballot_w64(n0 || n1) != 0ull) {
+          const F2 ZL = {Z0, Z1};
+          const F2 Z2X = ZL * ZL * (coslp * UCN);
+          const F2 ex = {f_exp(Z0), f_exp(Z1)};
+          const F2 g = ex * Z2X * Z2X * CNSN;
+          gam0.x = n0 ? g.x : 0.f;
+          gam0.y = n1 ? g.y : 0.f;
+          xl0 = xl0 || n0;
+          xl1 = xl1 || n1;
+        }
+      }
+      const F2 DSTAB2 = TEMP1 * (TEMP2 + (FU + FUD * coslp) * USTP[ig]);
+      const F2 dstab = DSTAB1 + PTURB * DSTAB2;
+      FLP[ig] = gam0 + dstab;
+      SLP[ig] = gam0 * f;
+    }
+    const F2 sp = 0.5f * (SLP[0] + SLP[1]);
+    const F2 fl = 0.5f * (FLP[0] + FLP[1]);
+    // directional integrals of the row: (X, Y) per gust state and (SUM SLP) of both, every lane of the point gets them
+    F2 xs[2], ss;
+    const bool anygrow = __builtin_amdgcn_ballot_w64(xl0 || xl1) != 0ull;
+    if (anygrow) {
+#pragma unroll
+      for (int ig = 0; ig < 2; ig++) {
+        const F2 sx = grp ? SLP[ig] * sinth : F2{0.f, 0.f}, sy = grp ? SLP[ig] * costh : F2{0.f, 0.f};
+        xs[ig] = s3_allsum(F2{sx.x + sx.y, sy.x + sy.y}, a9, a3, a6, a1, a2);
+        XSTRESS[ig] = XSTRESS[ig] + CONSTF * xs[ig].x;
+        YSTRESS[ig] = YSTRESS[ig] + CONSTF * xs[ig].y;
+      }
+      ss = s3_allsum(grp ? F2{SLP[0].x + SLP[0].y, SLP[1].x + SLP[1].y} : F2{0.f, 0.f}, a9, a3, a6, a1, a2);
+    } else {
+      xs[0] = xs[1] = ss = F2{0.f, 0.f};
+    }
+    if (act) {
+      *reinterpret_cast<F2*>(fld + orow + (size_t)m * NANG) = fl;
+      *reinterpret_cast<F2*>(spos + orow + (size_t)m * NANG) = sp;
+      *reinterpret_cast<F2*>(xllws + orow + (size_t)m * NANG) = F2{xl0 ? 1.f : 0.f, xl1 ? 1.f : 0.f};
+      if (j == 0)
+        *reinterpret_cast<float4*>(xys + ((size_t)ij * NFRE + m) * 4) =
+            float4{0.5f * (xs[0].x + xs[1].x), 0.5f * (xs[0].y + xs[1].y), 0.5f * (ss.x + ss.y), 0.f};
+    }
+  }
+}
+
+int launch_sinput3(const void* tab, int nang, int nfre, int n, const void* fl1, const void* wvprpt, const void* pt, void* fld,
+                   void* spos, void* xllws, void* xys, int mode, hipStream_t s) {
+  if (nang != 2 * S3_GROUP) return 1;
+  if (n <= 0) return 0;
+  constexpr int WPB = 2;
+  const size_t shmem = (size_t)WPB * S3_PTS * (nang * nfre + S3_NFAC * nfre) * sizeof(float);
+  const int blocks = (n + WPB * S3_PTS - 1) / (WPB * S3_PTS);
+#define S3_ARGS (const DevTab<float>*)tab, n, (const float*)fl1, (const float*)wvprpt, (const float*)pt, (float*)fld, (float*)spos, (float*)xllws, (float*)xys
+  if (mode == 1) hipLaunchKernelGGL((k_sinput3<WPB, 1>), dim3(blocks), dim3(64 * WPB), shmem, s, S3_ARGS);
+  else hipLaunchKernelGGL((k_sinput3<WPB, 0>), dim3(blocks), dim3(64 * WPB), shmem, s, S3_ARGS);
+#undef S3_ARGS
+  return 0;
+}

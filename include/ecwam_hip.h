@@ -270,6 +270,15 @@ int ecwam_hip_outwnorm(ecwam_hip_ctx *ctx, const void *field, int stride, int n,
  */
 int ecwam_hip_snonlin3(ecwam_hip_ctx *ctx, int n, const void *fl1, const void *depth, const void *akmean, void *sl, void *fld,
                        int mode, void *stream);
+/*
+ * SINPUT_ARD alone (sinput_ard.F90:10-14, 153-520) in the same lane layout: the second SINFLX call (NGST = 2, LLSNEG = T), sheltering
+ * on (TAUWSHELTER /= 0), LLNORMAGAM = F, single precision, NANG = 36.  pt: device float [n][12] = UFRIC, Z0M, RAORW, SIG_N, TEMP2,
+ * PTURB, AIRD_PVISC (the swell-damping set-up of sinput_ard.F90:213-258), SIN(WDWAVE), COS(WDWAVE), 3 spare; wvprpt as for
+ * ecwam_hip_implsch.  Out: fld (FLD), spos (SPOS), xllws [n][NFRE][18][2] as above; xys [n][NFRE][4] = SUM_K SPOS*SINTH,
+ * SUM_K SPOS*COSTH, SUM_K SPOS, 0 (what STRESSO integrates).  mode as above.
+ */
+int ecwam_hip_sinput3(ecwam_hip_ctx *ctx, int n, const void *fl1, const void *wvprpt, const void *pt, void *fld, void *spos,
+                      void *xllws, void *xys, int mode, void *stream);
 
 /* NEWWIND forcing hand-over (newwind.F90:126-161, ICODE_WND=3): FF <- FF_NEXT members + TAUW cap */
 int ecwam_hip_newwind(ecwam_hip_ctx *ctx, int n, void *ff, const void *ff_next, void *stream);

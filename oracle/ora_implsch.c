@@ -348,6 +348,8 @@ static real wsigstar(real WSWAVE, real UFRIC, real Z0M, real WSTAR) {
 }
 
 /* sinput_ard.F90:153-520 */
+/* SIG_N, TEMP2, PTURB, AIRD_PVISC of the last sinput_ard call of this thread (read by ora_sinput_ard only) */
+static __thread real sinput_aux[4];
 static void sinput_ard(int NGST, int LLSNEG, const real *FL1, const real *WAVNUM, const real *CINV, const real *XK2CG,
                        real WDWAVE, real WSWAVE, real UFRIC, real Z0M, const real *COSWDIF, const real *SINWDIF2,
                        real RAORW, real WSTAR, real RNFAC, real *FLD, real *SL, real *SPOS, real *XLLWS) {
@@ -412,6 +414,7 @@ static void sinput_ard(int NGST, int LLSNEG, const real *FL1, const real *WAVNUM
     AIRD_PVISC = PVISC * RAORW;
   }
 
+  sinput_aux[0] = SIG_N; sinput_aux[1] = TEMP2; sinput_aux[2] = PTURB; sinput_aux[3] = AIRD_PVISC;
   if (NGST == 1) USTP[0] = UFRIC;
   else { USTP[0] = UFRIC * (C_(1.0) + SIG_N); USTP[1] = UFRIC * (C_(1.0) - SIG_N); }
   for (IGST = 0; IGST < NGST; IGST++) USTPM1[IGST] = C_(1.0) / RMAX(USTP[IGST], S.EPSUS);
@@ -1713,6 +1716,18 @@ void ora_outbs(int n, const real *FL1a, real ZMISS, real *OUT) {
 void ora_snonlin(real *FL1, real DEPTH, real AKMEAN, const real *WAVNUM, real *SL, real *FLD) {
   for (int i = 0; i < S.NANG * S.NFRE; i++) { SL[i] = C_(0.0); FLD[i] = C_(0.0); }
   snonlin(FL1, FLD, SL, DEPTH, AKMEAN, WAVNUM);
+}
+/* SINPUT_ARD alone (sinput_ard.F90:153-520); aux[4] = SIG_N, TEMP2, PTURB, AIRD_PVISC as the routine formed them */
+void ora_sinput_ard(int NGST, int LLSNEG, real *FL1, const real *WAVNUM, const real *CINV, const real *XK2CG, real WDWAVE, real WSWAVE,
+                    real UFRIC, real Z0M, real AIRD, real WSTAR, real RNFAC, real *FLD, real *SL, real *SPOS, real *XLLWS, real *aux) {
+  real COSWDIF[NA], SINWDIF2[NA];
+  for (int K = 0; K < S.NANG; K++) {
+    COSWDIF[K] = COS(S.TH[K] - WDWAVE);
+    SINWDIF2[K] = SIN(S.TH[K] - WDWAVE) * SIN(S.TH[K] - WDWAVE);
+  }
+  sinput_ard(NGST, LLSNEG, FL1, WAVNUM, CINV, XK2CG, WDWAVE, WSWAVE, UFRIC, Z0M, COSWDIF, SINWDIF2, RMAX(AIRD, C_(1.0)) * S.ROWATERM1, WSTAR,
+             RNFAC, FLD, SL, SPOS, XLLWS);
+  for (int i = 0; i < 4; i++) aux[i] = sinput_aux[i];
 }
 /* SBOTTOM alone */
 void ora_sbottom(real *FL1, const real *WAVNUM, real DEPTH, real *SL, real *FLD) {

@@ -43,6 +43,30 @@ def main():
         out[mode] = e0.elapsed_time(e1) / reps
     print(f"points {n}: load/store only {out[1]:.3f} ms, with the DIA {out[0]:.3f} ms -> DIA {out[0] - out[1]:.3f} ms "
           f"({(out[0] - out[1]) * 131072 / n:.3f} ms per 131072 points; k_implsch2: 0.96 ms)")
+    # SINPUT_ARD, second SINFLX call (two gust states): k_implsch2 spends 1.28 ms per 131072 points on its three state evaluations
+    # (4.92 ms with, 3.64 ms without SINPUT), i.e. ~0.85 ms on the two of this call
+    pr, ff = base["props"], base["FF"]
+    wv = np.stack([pr[k] for k in ("WAVNUM", "CGROUP", "CINV", "XK2CG", "STOKFAC")], 1).astype(np.float32)
+    pt = np.zeros((4096, 12), np.float32)
+    pt[:, 0], pt[:, 1] = ff[:, 7], ff[:, 10]
+    pt[:, 2] = np.maximum(ff[:, 0], 1.0) * float(base["tables"].ROWATERM1)
+    pt[:, 3], pt[:, 4], pt[:, 5], pt[:, 6] = 0.1, 0.05, 0.5, 0.0006
+    pt[:, 7], pt[:, 8] = np.sin(ff[:, 1]), np.cos(ff[:, 1])
+    twv = torch.from_numpy(np.tile(wv, (rep, 1, 1))[:n].copy()).to(ctx.device)
+    tpt = torch.from_numpy(np.tile(pt, (rep, 1))[:n].copy()).to(ctx.device)
+    for mode in (1, 0):
+        for _ in range(3):
+            ctx.sinput3(fl, twv, tpt, mode)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ctx.sinput3(fl, twv, tpt, mode)
+        e1.record()
+        torch.cuda.synchronize()
+        out[mode] = e0.elapsed_time(e1) / 20
+    print(f"points {n}: load/store only {out[1]:.3f} ms, with SINPUT_ARD (2 gust states) {out[0]:.3f} ms -> {out[0] - out[1]:.3f} ms "
+          f"({(out[0] - out[1]) * 131072 / n:.3f} ms per 131072 points; k_implsch2: ~0.85 ms for this call)")
 
 
 if __name__ == "__main__":

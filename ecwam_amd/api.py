@@ -248,6 +248,17 @@ class HipContext:
                                              int(mode), _stream_ptr()))
         return [x.permute(0, 3, 2, 1).reshape(n, 36, self.NFRE) for x in o] + [xys]
 
+    def sdissip3(self, fl1, wvprpt, pt, mode: int = 0):
+        """SDISSIP_ARD alone in the three-points-per-wavefront layout; returns the dissipation coefficient as [n][NANG][NFRE]."""
+        n = fl1.shape[0]
+        if self.dtype != torch.float32 or self.NANG != 36:
+            raise ValueError("SDISSIP3: single precision and NANG = 36 only")
+        p1 = self._real(fl1, (n, self.NANG, self.NFRE), "FL1")
+        pw, pp = self._real(wvprpt, (n, NWPR, self.NFRE), "WVPRPT"), self._real(pt, (n, 12), "PT")
+        o = torch.empty((n, self.NFRE, 18, 2), dtype=self.dtype, device=self.device)
+        self._chk(self.lib.ecwam_hip_sdissip3(self._h, n, p1, pw, pp, o.data_ptr(), int(mode), _stream_ptr()))
+        return o.permute(0, 3, 2, 1).reshape(n, 36, self.NFRE)
+
     # -- OUTBS subset (outblock.F90 parameters 1-3) and OUTWNORM statistics, on the device
     def outbs(self, kijs, kijl, fl1, out, zmiss: float = -999.0):
         nrow = fl1.shape[0]

@@ -40,6 +40,7 @@ template <typename T> void launch_propags2_otf(const void*, const void*, void*, 
 template <typename T> void launch_copy_freq_range(const void*, void*, int, int, int, int, int, int, hipStream_t);
 template <typename T> int launch_outbs(const void*, int, int, const void*, double, void*, int, int, hipStream_t);
 int launch_sinput3(const void*, int, int, int, const void*, const void*, const void*, void*, void*, void*, void*, int, hipStream_t);
+int launch_sdissip3(const void*, int, int, int, int, const void*, const void*, const void*, void*, int, hipStream_t);
 int launch_snonlin3(const void*, int, int, int, int, const void*, const void*, const void*, void*, void*, int, hipStream_t);
 template <typename T> void launch_norm(const void*, int, int, double, double*, int, hipStream_t);
 template <typename T> void launch_newwind(const void*, int, void*, const void*, hipStream_t);
@@ -474,6 +475,16 @@ int ecwam_hip_sinput3(ecwam_hip_ctx* c, int n, const void* fl1, const void* wvpr
     return fail("ecwam_hip_sinput3: single precision, IPHYS = 1, LLNORMAGAM = F, TAUWSHELTER /= 0 only");
   if (launch_sinput3(c->dtab, c->NANG, c->NFRE, n, fl1, wvprpt, pt, fld, spos, xllws, xys, mode, (hipStream_t)stream))
     return fail("ecwam_hip_sinput3: needs NANG = 36");
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ecwam_hip_sdissip3(ecwam_hip_ctx* c, int n, const void* fl1, const void* wvprpt, const void* pt, void* fld, int mode, void* stream) {
+  if (!c) return fail("null context");
+  if (n < 0 || (n > 0 && (!fl1 || !wvprpt || !pt || !fld))) return fail("ecwam_hip_sdissip3: bad arguments");
+  if (c->real_bytes != 4 || c->p.iphys != 1) return fail("ecwam_hip_sdissip3: single precision, IPHYS = 1 only");
+  if (launch_sdissip3(c->dtab, c->NANG, c->NFRE, 2 * c->p.nsdsnth + 1, n, fl1, wvprpt, pt, fld, mode, (hipStream_t)stream))
+    return fail("ecwam_hip_sdissip3: needs NANG = 36 and at most 17 taps");
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -368,3 +368,115 @@ int launch_sinput3(const void* tab, int nang, int nfre, int n, const void* fl1, 
 #undef S3_ARGS
   return 0;
 }
+
+// =====================================================================================================================
+// SDISSIP_ARD (sdissip_ard.F90:117-314, SSDSC3 = 0) in the same lane layout.  The saturation filter reads the 2*NSDSNTH+1
+// neighbouring directions straight from the pair tile at rotated addresses (one ds_read_b32 per half and tap: no half
+// swap needed, the address of each half is a per-lane constant); the directional maximum of a row is an 18-lane all-reduce.
+// in : pt[n][12] (UFRIC at 0, RAORW at 2, COS/SIN of WDWAVE at 8/7), wvprpt as above.  out: fld [n][NFRE][18][2].
+// =====================================================================================================================
+#define S3_MAXTAP 17
+template <int WPB, int MODE>
+__global__ void __launch_bounds__(64 * WPB) k_sdissip3(const DevTab<float>* __restrict__ tp, int n, const float* __restrict__ fl1,
+                                                       const float* __restrict__ wvprpt, const float* __restrict__ pt,
+                                                       float* __restrict__ fld) {
+  extern __shared__ __align__(16) unsigned char s3_smem[];
+  const DevTab<float>& tb = *tp;
+  const int NANG = tb.NANG, NFRE = tb.NFRE, N = NANG * NFRE;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int p = lane / S3_GROUP, j = lane - p * S3_GROUP;
+  const int ij0 = (blockIdx.x * WPB + wave) * S3_PTS;
+  if (ij0 >= n) return;
+  const bool grp = p < S3_PTS;
+  const bool act = grp && (ij0 + p < n);
+  const int ij = act ? ij0 + p : ij0;
+  float* sF = reinterpret_cast<float*>(s3_smem) + (size_t)wave * S3_PTS * (N + 4 * NFRE);
+  float* sFac = sF + S3_PTS * N;   // [point][M][4]: FACSAT, SIG, WAVNUM, -
+  for (int q = 0; q < S3_PTS; q++) {
+    if (ij0 + q >= n) break;
+    const float* g = fl1 + (size_t)(ij0 + q) * N;
+    float* t = sF + q * N;
+    for (int e = lane; e < N; e += 64) {
+      const int k = e / NFRE, m = e - k * NFRE;
+      t[m * NANG + 2 * (k % S3_GROUP) + k / S3_GROUP] = g[e];
+    }
+  }
+  const float* q = pt + (size_t)ij * 12;
+  const float UFRIC = q[0], RAORW = q[2], sinwd = q[7], coswd = q[8];
+  if (act) {
+    const float* wp = wvprpt + (size_t)ij * ECWAM_HIP_NWPR * NFRE;
+    const float TPIINV = 1.0f / tb.ZPI;
+    for (int m = j; m < NFRE; m += S3_GROUP) {
+      float* f = sFac + ((size_t)p * NFRE + m) * 4;
+      f[0] = wp[m] * TPIINV * wp[3 * NFRE + m];
+      f[1] = tb.ZPIFR[m];
+      f[2] = wp[m];
+      f[3] = 0.f;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const float* tP = sF + (grp ? p : 0) * N;
+  const float* tF = tP + 2 * j;
+  const float* tFac = sFac + (size_t)(grp ? p : 0) * NFRE * 4;
+  const size_t orow = (size_t)ij * NFRE * NANG + 2 * j;
+  if (MODE == 1) {
+    if (act)
+      for (int m = 0; m < NFRE; m++) *reinterpret_cast<F2*>(fld + orow + (size_t)m * NANG) = *reinterpret_cast<const F2*>(tF + m * NANG);
+    return;
+  }
+  const int ntap = tb.NTAP;   // <= S3_MAXTAP (checked by the launcher)
+  int o0[S3_MAXTAP], o1[S3_MAXTAP];
+  F2 wgt[S3_MAXTAP];
+#pragma unroll
+  for (int t = 0; t < S3_MAXTAP; t++) {
+    const int tt = t < ntap ? t : 0;
+    const int k0 = tb.INDICESSAT[tt][j], k1 = tb.INDICESSAT[tt][j + S3_GROUP];
+    o0[t] = 2 * (k0 % S3_GROUP) + k0 / S3_GROUP;
+    o1[t] = 2 * (k1 % S3_GROUP) + k1 / S3_GROUP;
+    wgt[t] = t < ntap ? F2{tb.SATWEIGHTS[tt][j], tb.SATWEIGHTS[tt][j + S3_GROUP]} : F2{0.f, 0.f};
+  }
+  const int base = (grp ? p : 0) * S3_GROUP;
+#define S3_ROT(r) (4 * (base + ((j + (r)) >= S3_GROUP ? j + (r) - S3_GROUP : j + (r))))
+  const int a9 = S3_ROT(9), a3 = S3_ROT(3), a6 = S3_ROT(6), a1 = S3_ROT(1), a2 = S3_ROT(2);
+#undef S3_ROT
+  const float TMP03 = 1.0f / (tb.SDSBR * tb.MICHE), SSDSC4 = tb.SSDSC4;
+  const float c2 = tb.SSDSC2 * tb.SSDSC6, c2m1 = tb.SSDSC2 * (1.0f - tb.SSDSC6);
+  const bool turb = tb.SSDSC5 != 0.f;
+  const float FACTURB = turb ? (2.0f * tb.SSDSC5 / tb.G) * RAORW * UFRIC * UFRIC : 0.f;
+  const F2 coswdif = F2{tb.COSTH[j], tb.COSTH[j + S3_GROUP]} * coswd + F2{tb.SINTH[j], tb.SINTH[j + S3_GROUP]} * sinwd;
+  for (int m = 0; m < NFRE; m++) {
+    const float* row = tP + m * NANG;
+    const float4 fa = *reinterpret_cast<const float4*>(tFac + m * 4);
+    F2 b = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < S3_MAXTAP; t++) b = b + wgt[t] * F2{row[o0[t]], row[o1[t]]};
+    b = b * fa.x;
+    float bm = grp ? fmaxf(b.x, b.y) : 0.f;
+    bm = fmaxf(bm, s3_bperm(a9, bm));
+    bm = fmaxf(bm, fmaxf(s3_bperm(a3, bm), s3_bperm(a6, bm)));
+    bm = fmaxf(bm, fmaxf(s3_bperm(a1, bm), s3_bperm(a2, bm)));
+    const float a0 = fmaxf(0.f, bm * TMP03 - SSDSC4);
+    const F2 t1 = b * TMP03 - SSDSC4;
+    const F2 a1v = {fmaxf(0.f, t1.x), fmaxf(0.f, t1.y)};
+    F2 D = (c2 * fa.y) * (a0 * a0) + (c2m1 * fa.y) * (a1v * a1v);
+    if (turb) D = D - (fa.y * fa.z * FACTURB) * coswdif;
+    if (act) *reinterpret_cast<F2*>(fld + orow + (size_t)m * NANG) = D;
+  }
+}
+
+int launch_sdissip3(const void* tab, int nang, int nfre, int ntap, int n, const void* fl1, const void* wvprpt, const void* pt, void* fld,
+                    int mode, hipStream_t s) {
+  if (nang != 2 * S3_GROUP || ntap > S3_MAXTAP) return 1;
+  if (n <= 0) return 0;
+  constexpr int WPB = 2;
+  const size_t shmem = (size_t)WPB * S3_PTS * (nang * nfre + 4 * nfre) * sizeof(float);
+  const int blocks = (n + WPB * S3_PTS - 1) / (WPB * S3_PTS);
+  if (mode == 1)
+    hipLaunchKernelGGL((k_sdissip3<WPB, 1>), dim3(blocks), dim3(64 * WPB), shmem, s, (const DevTab<float>*)tab, n, (const float*)fl1,
+                       (const float*)wvprpt, (const float*)pt, (float*)fld);
+  else
+    hipLaunchKernelGGL((k_sdissip3<WPB, 0>), dim3(blocks), dim3(64 * WPB), shmem, s, (const DevTab<float>*)tab, n, (const float*)fl1,
+                       (const float*)wvprpt, (const float*)pt, (float*)fld);
+  return 0;
+}

@@ -279,6 +279,9 @@ int ecwam_hip_snonlin3(ecwam_hip_ctx *ctx, int n, const void *fl1, const void *d
  */
 int ecwam_hip_sinput3(ecwam_hip_ctx *ctx, int n, const void *fl1, const void *wvprpt, const void *pt, void *fld, void *spos,
                       void *xllws, void *xys, int mode, void *stream);
+/* SDISSIP_ARD alone (sdissip_ard.F90:10-12, 117-314; SSDSC3 = 0) in the same layout: fld [n][NFRE][18][2] = the dissipation
+ * coefficient D (SL = D*F); pt as for ecwam_hip_sinput3 (UFRIC, RAORW, SIN / COS of WDWAVE are read). */
+int ecwam_hip_sdissip3(ecwam_hip_ctx *ctx, int n, const void *fl1, const void *wvprpt, const void *pt, void *fld, int mode, void *stream);
 
 /* NEWWIND forcing hand-over (newwind.F90:126-161, ICODE_WND=3): FF <- FF_NEXT members + TAUW cap */
 int ecwam_hip_newwind(ecwam_hip_ctx *ctx, int n, void *ff, const void *ff_next, void *stream);

@@ -895,3 +895,40 @@ def test_sinput_three_points_per_wavefront_layout(api):
     scale = np.abs(want).max(axis=(1, 2), keepdims=True) + 1e-300
     assert np.max((np.abs(xys[:, :, :3] - want) / scale)[clean]) < 5e-4
     ctx.close()
+
+
+def test_sdissip_three_points_per_wavefront_layout(api):
+    """ecwam_hip_sdissip3 (SDISSIP_ARD in the three-points-per-wavefront layout: saturation filter from rotated reads of the pair
+    tile, directional maximum as an 18-lane all-reduce) against the oracle's SDISSIP_ARD: the coefficient D = FLD within 2e-5 of the
+    point's largest |D|."""
+    import ctypes as C
+
+    cfg = Config(nang=36, nfre=36, nfre_red=36)
+    n = 1000
+    case = H.make_point_case(n, cfg, "sp", spectra="mixed", seed=51)
+    t = case["tables"]
+    o = _oracle(cfg, "sp")
+    pr, ff = case["props"], case["FF"]
+    ref = np.zeros((n, 36, 36), np.float32)
+    pt = np.zeros((n, 12), np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    f32 = C.c_float
+    for i in range(n):
+        fl = np.ascontiguousarray(case["FL1"][i])
+        wn, xk = np.ascontiguousarray(pr["WAVNUM"][i]), np.ascontiguousarray(pr["XK2CG"][i])
+        sl, fld = np.zeros((36, 36), np.float32), np.zeros((36, 36), np.float32)
+        aird, wd, ufric = float(ff[i, 0]), float(ff[i, 1]), float(ff[i, 7])
+        o.lib.ora_sdissip_ard(p(fl), p(wn), p(xk), f32(ufric), f32(wd), f32(aird), p(sl), p(fld))
+        ref[i] = fld
+        pt[i, 0], pt[i, 2] = ufric, max(aird, 1.0) * float(t.ROWATERM1)
+        pt[i, 7], pt[i, 8] = np.sin(np.float32(wd)), np.cos(np.float32(wd))
+    ctx = api.HipContext(t)
+    dev = ctx.device
+    wv = np.stack([pr[k] for k in ("WAVNUM", "CGROUP", "CINV", "XK2CG", "STOKFAC")], 1).astype(np.float32)
+    got = ctx.sdissip3(torch.from_numpy(case["FL1"]).to(dev), torch.from_numpy(wv).to(dev), torch.from_numpy(pt).to(dev))
+    torch.cuda.synchronize()
+    got = got.cpu().numpy().astype(float)
+    r = ref.astype(float)
+    scale = np.abs(r).max(axis=(1, 2), keepdims=True) + 1e-300
+    assert np.isfinite(got).all() and np.abs(r).max() > 0 and np.max(np.abs(got - r) / scale) < 2e-5
+    ctx.close()

@@ -68,6 +68,21 @@ def main():
     print(f"points {n}: load/store only {out[1]:.3f} ms, with SINPUT_ARD (2 gust states) {out[0]:.3f} ms -> {out[0] - out[1]:.3f} ms "
           f"({(out[0] - out[1]) * 131072 / n:.3f} ms per 131072 points; k_implsch2: ~0.85 ms for this call)")
 
+    # SDISSIP_ARD: k_implsch2 spends 0.63 ms per 131072 points on it (4.92 ms with, 4.29 ms without)
+    for mode in (1, 0):
+        for _ in range(3):
+            ctx.sdissip3(fl, twv, tpt, mode)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ctx.sdissip3(fl, twv, tpt, mode)
+        e1.record()
+        torch.cuda.synchronize()
+        out[mode] = e0.elapsed_time(e1) / 20
+    print(f"points {n}: load/store only {out[1]:.3f} ms, with SDISSIP_ARD {out[0]:.3f} ms -> {out[0] - out[1]:.3f} ms "
+          f"({(out[0] - out[1]) * 131072 / n:.3f} ms per 131072 points; k_implsch2: 0.63 ms)")
+
 
 if __name__ == "__main__":
     main()

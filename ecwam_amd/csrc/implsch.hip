@@ -1040,6 +1040,7 @@ __global__ void __launch_bounds__(64 * WPB) k_implsch(const DevTab<T>* __restric
 }
 
 #include "implsch_v2.h"
+#include "implsch_v3.h"
 
 template <typename T>
 int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws,
@@ -1050,6 +1051,27 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
   const bool rare = (variant & 32) != 0;   // any of LLGCBZ0 / LCIWA2 / LCIWA3 / LCISCAL / LWNEMOCOU: the build that carries those branches
   variant &= 15;
   const bool variant2 = (variant == 2);
+  if constexpr (sizeof(T) == 4) {
+    // third kernel generation (three points per wavefront, implsch_v3.h): flag set A, 36 directions; opt-in while it is being completed
+    const char* e3 = getenv("ECWAM_HIP_IMPLSCH_V3");
+    if (e3 && atoi(e3) && variant2 && !norma && !rare && NANG == 2 * V3G && NFRE <= 64 && !w2n && !dbg) {
+      const size_t per3 = (size_t)((V3P * (NANG * NFRE + V3_NFAC * NFRE + 7 * NFRE) + V3P * NSC + 3) & ~3) * sizeof(float);
+      int wpb3 = 1;
+      { const char* ew = getenv("ECWAM_HIP_V3_WPB"); if (ew) wpb3 = atoi(ew); }   // diagnostics
+#define LAUNCH3(W)                                                                                                             \
+  do {                                                                                                                         \
+    const size_t shmem = per3 * W;                                                                                             \
+    if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_implsch3<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+    hipLaunchKernelGGL((k_implsch3<W>), dim3((n + V3P * W - 1) / (V3P * W)), dim3(64 * W), shmem, s, (const DevTab<float>*)tab, kijs, \
+                       kijl, (float*)fl1, (const float*)wvprpt, (float*)ff, (float*)intf, mij, (float*)xllws);                 \
+  } while (0)
+      if (wpb3 == 4) LAUNCH3(4);
+      else if (wpb3 == 2) LAUNCH3(2);
+      else LAUNCH3(1);
+#undef LAUNCH3
+      return 0;
+    }
+  }
   const int ntile = (variant == 2) ? 2 : 3;
   const int NAP = variant2 ? NANG : (NANG | 1);
   const int nscr = variant2 ? 0 : 64;

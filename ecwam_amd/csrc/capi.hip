@@ -435,6 +435,8 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   int rc, variant = c->implsch_variant;
   { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_VARIANT"); if (e_ && atoi(e_) == 1) variant = 1; }  // diagnostics: force the 3-tile kernel
   if (c->p.llnormagam) variant |= 16;
+  // third kernel generation (implsch_v3.h): single precision, 36 directions, at most 17 saturation taps, at most 64 frequencies
+  if (c->real_bytes == 4 && c->NANG == 36 && 2 * c->p.nsdsnth + 1 <= 17 && c->NFRE <= 64 && c->p.mlsthg >= c->NFRE) variant |= 64;
   if (c->p.llgcbz0 || c->p.lciwa1 || c->p.lciwa2 || c->p.lciwa3 || c->p.lciscal || c->p.lwnemocou || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin || c->p.iphys == 0 || c->p.icode != 3 || !c->p.lwvflx_snl) variant |= 32;
   DISPATCH(rc = launch_implsch<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s),
            rc = launch_implsch<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s));

@@ -1048,13 +1048,15 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
   const int n = kijl - kijs;
   if (n <= 0) return 0;
   const bool norma = (variant & 16) != 0;  // LLNORMAGAM, packed by capi.hip
+  const bool v3ok = (variant & 64) != 0;   // the configuration fits the three-points-per-wavefront kernel (capi.hip)
   const bool rare = (variant & 32) != 0;   // any of LLGCBZ0 / LCIWA2 / LCIWA3 / LCISCAL / LWNEMOCOU: the build that carries those branches
   variant &= 15;
   const bool variant2 = (variant == 2);
   if constexpr (sizeof(T) == 4) {
-    // third kernel generation (three points per wavefront, implsch_v3.h): flag set A, 36 directions; opt-in while it is being completed
+    // third kernel generation (three points per wavefront, implsch_v3.h): flag set A without the optional branches, 36 directions.
+    // ECWAM_HIP_IMPLSCH_V3=0 falls back to k_implsch2 (diagnostics, and the parity test that keeps both generations checked)
     const char* e3 = getenv("ECWAM_HIP_IMPLSCH_V3");
-    if (e3 && atoi(e3) && variant2 && !norma && !rare && NANG == 2 * V3G && NFRE <= 64 && !w2n && !dbg) {
+    if (!(e3 && atoi(e3) == 0) && v3ok && variant2 && !norma && !rare && NANG == 2 * V3G && !w2n && !dbg) {
       const size_t per3 = (size_t)((V3P * (NANG * NFRE + V3_NFAC * NFRE + 7 * NFRE) + V3P * NSC + 3) & ~3) * sizeof(float);
       int wpb3 = 1;
       { const char* ew = getenv("ECWAM_HIP_V3_WPB"); if (ew) wpb3 = atoi(ew); }   // diagnostics

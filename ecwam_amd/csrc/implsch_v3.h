@@ -180,7 +180,7 @@ __device__ void v3_sinput(const DevTab<float>& tb, const V3Ctx& L, float UFRIC, 
 }
 
 template <int WPB>
-__global__ void __launch_bounds__(64 * WPB) k_implsch3(const DevTab<float>* __restrict__ tp, int kijs, int kijl, float* __restrict__ fl1,
+__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))) k_implsch3(const DevTab<float>* __restrict__ tp, int kijs, int kijl, float* __restrict__ fl1,
                                                        const float* __restrict__ wvprpt, float* __restrict__ ffa,
                                                        float* __restrict__ intfa, int* __restrict__ mij_out, float* __restrict__ xllws) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -222,12 +222,19 @@ __global__ void __launch_bounds__(64 * WPB) k_implsch3(const DevTab<float>* __re
   float* c = L.c;
 
   // ---- spectra F[ij][K][M] (coalesced) -> pair tile; a short last wave replicates its last point
-  for (int q = 0; q < V3P; q++) {
-    const float* g = fl1 + (size_t)(ij0 + (q < n ? q : n - 1)) * N;
-    float* t = sF + q * N;
-    for (int e = lane; e < N; e += 64) {
-      const int k = e / NFRE, m = e - k * NFRE;
-      t[m * NANG + 2 * (k % V3G) + k / V3G] = g[e];
+  {
+    const float rnf = 1.0f / (float)NFRE;
+    const bool full = (n == V3P);   // the three blocks are contiguous in memory: one flat loop keeps all the loads in flight
+    for (int q = 0; q < (full ? 1 : V3P); q++) {
+      const float* g = fl1 + (size_t)(ij0 + (q < n ? q : n - 1)) * N;
+      float* t = sF + q * N;
+      const int cnt = full ? V3P * N : N;
+      for (int e = lane; e < cnt; e += 64) {
+        const int kq = (int)(((float)e + 0.5f) * rnf);          // e / NFRE (exact for these sizes), kq = point * NANG + K
+        const int m = e - kq * NFRE;
+        const int pq = (kq >= 2 * NANG) ? 2 : (kq >= NANG ? 1 : 0), k = kq - pq * NANG;
+        t[pq * N + m * NANG + 2 * (k >= V3G ? k - V3G : k) + (k >= V3G ? 1 : 0)] = g[e];
+      }
     }
   }
   // ---- point scalars + first TAUT_Z0, one lane per point (sinflx.F90:105-122)
@@ -690,12 +697,14 @@ __global__ void __launch_bounds__(64 * WPB) k_implsch3(const DevTab<float>* __re
   WSYNC();
   // ---- store FL1 (coalesced, from the pair tile), XLLWS from tile order to [K][M] in place is done by the caller's layout
   //      conversion below; per-point scalars
-  for (int q = 0; q < n; q++) {
-    float* g = fl1 + (size_t)(ij0 + q) * N;
-    const float* t = sF + q * N;
-    for (int e = lane; e < N; e += 64) {
-      const int k = e / NFRE, m = e - k * NFRE;
-      g[e] = t[m * NANG + 2 * (k % V3G) + k / V3G];
+  {
+    const float rnf = 1.0f / (float)NFRE;
+    float* g = fl1 + (size_t)ij0 * N;
+    for (int e = lane; e < n * N; e += 64) {
+      const int kq = (int)(((float)e + 0.5f) * rnf);
+      const int m = e - kq * NFRE;
+      const int pq = (kq >= 2 * NANG) ? 2 : (kq >= NANG ? 1 : 0), k = kq - pq * NANG;
+      g[e] = sF[pq * N + m * NANG + 2 * (k >= V3G ? k - V3G : k) + (k >= V3G ? 1 : 0)];
     }
   }
   if (L.act) {   // XLLWS(K,M) of the second SINFLX call: every wind-input row parked in this block has been read by now

@@ -49,6 +49,17 @@ def test_wavefront_primitives(api):
 @pytest.mark.parametrize("prec", ["dp", "sp"])
 @pytest.mark.parametrize("llnormagam", [False, True])
 def test_implsch_parity(api, nang, nred, prec, llnormagam):
+    _implsch_parity(api, nang, nred, prec, llnormagam)
+
+
+def test_implsch_parity_second_generation_kernel(api, monkeypatch):
+    """36 directions / single precision / flag set A runs the three-points-per-wavefront kernel (k_implsch3) by default; the
+    one-point-per-wavefront kernel (k_implsch2: every other configuration) stays checked on that configuration too."""
+    monkeypatch.setenv("ECWAM_HIP_IMPLSCH_V3", "0")
+    _implsch_parity(api, 36, 36, "sp", False)
+
+
+def _implsch_parity(api, nang, nred, prec, llnormagam):
     cfg = Config(nang=nang, nfre=36, nfre_red=nred, llnormagam=llnormagam)
     n = 1537  # ragged: not a multiple of the 4 waves per block
     case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=777)

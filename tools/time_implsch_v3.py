@@ -25,7 +25,7 @@ twv = torch.from_numpy(wv).to(dev).repeat(rep, 1, 1)[:n].contiguous()
 tff0 = torch.from_numpy(ff).to(dev).repeat(rep, 1)[:n].contiguous()
 tin0 = torch.from_numpy(intf).to(dev).repeat(rep, 1)[:n].contiguous()
 res = {}
-for v3 in (0, 1):
+for v3 in (0, 1):  # 0: k_implsch2, 1 (the default): k_implsch3
     os.environ["ECWAM_HIP_IMPLSCH_V3"] = str(v3)
     ts = []
     for it in range(4):

@@ -1057,7 +1057,7 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
     // ECWAM_HIP_IMPLSCH_V3=0 falls back to k_implsch2 (diagnostics, and the parity test that keeps both generations checked)
     const char* e3 = getenv("ECWAM_HIP_IMPLSCH_V3");
     if (!(e3 && atoi(e3) == 0) && v3ok && variant2 && !norma && !rare && NANG == 2 * V3G && !w2n && !dbg) {
-      const size_t per3 = (size_t)((V3P * (NANG * NFRE + V3_NFAC * NFRE + 7 * NFRE) + V3P * NSC + 3) & ~3) * sizeof(float);
+      const size_t per3 = (size_t)((V3P * (NANG * NFRE + V3_NFAC * NFRE + 4 * NFRE) + V3P * NSC + 3) & ~3) * sizeof(float);
       int wpb3 = 1;
       { const char* ew = getenv("ECWAM_HIP_V3_WPB"); if (ew) wpb3 = atoi(ew); }   // diagnostics
 #define LAUNCH3(W)                                                                                                             \

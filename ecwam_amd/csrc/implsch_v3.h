@@ -13,10 +13,10 @@
 typedef float V3F2 __attribute__((ext_vector_type(2)));
 #define V3G 18
 #define V3P 3
-#define V3_NFAC 8
+#define V3_NFAC 6
 #define V3_MAXTAP 17
 // per (point, M); the frequency-only module tables (DFIM, ZPIFR, RHOWG_DFIM ...) are read from the DevTab with a uniform index (scalar loads)
-enum { FA_WAVNUM = 0, FA_CINV, FA_STOK, FA_TA, FA_TX, FA_SBO, FA_FACSAT, FA_RT };
+enum { FA_WAVNUM = 0, FA_CINV, FA_STOK, FA_SQ, FA_SBO, FA_XK2CG };   // FA_SQ = SQRT(WAVNUM)
 
 __device__ __forceinline__ float v3_bperm(int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); }
 __device__ __forceinline__ V3F2 v3_pull(V3F2 v, int addr, bool swap) {
@@ -60,7 +60,7 @@ struct V3Ctx {
   V3Rot rot;
   V3F2 sinth, costh;
   // module tables per frequency, lane m holds M = m+1: broadcast with v_readlane inside the M loops (no scalar loads there)
-  float rDFIM, rDFIMOFR, rDFIMFR, rZPIFR, rRHOWG, rCOFRM4, rFLMAX;
+  float rDFIM, rDFIMOFR, rDFIMFR, rZPIFR, rRHOWG, rCOFRM4, rFLMAX, rC5;   // rC5 = -SWELLF5*2*SQRT(2*NU_AIR*SIG) (sinput_ard.F90:343)
 };
 
 // SINPUT_ARD (sinput_ard.F90:153-520) for one SINFLX call; see k_sinput3 (snonlin3.hip) for the layout.  Outputs: XLLWS masks of the
@@ -75,17 +75,8 @@ __device__ void v3_sinput(const DevTab<float>& tb, const V3Ctx& L, float UFRIC, 
   const float CONST1 = tb.BETAMAXOXKAPPA2, ABS_TAUWSHELTER = fabsf(tb.TAUWSHELTER);
   const float FU = fabsf(tb.SWELLF3), FUD = tb.SWELLF2, ROGOROAIR = tb.G / RAORW;
   const float AVG = 1.0f / (float)NGST;
-  if (L.grp) {
-    for (int m = L.j; m < NFRE; m += V3G) {
-      const float* fa = L.tFac + m * V3_NFAC;
-      const float SIG = tb.ZPIFR[m], WAVNUM = fa[FA_WAVNUM], CINV = fa[FA_CINV];
-      float* f = L.tSin + m * 4;
-      f[0] = m_log(WAVNUM * Z0M);
-      f[1] = ROGOROAIR * CINV * tb.DFIM[m];
-      f[2] = LLSNEG ? (-tb.SWELLF5 * 2.0f * m_sqrt(2.0f * tb.RNU * SIG)) * AIRD_PVISC * WAVNUM : 0.f;
-      f[3] = 0.f;
-    }
-  }
+  if (L.grp)
+    for (int m = L.j; m < NFRE; m += V3G) L.tSin[m] = m_log(L.tFac[m * V3_NFAC + FA_WAVNUM] * Z0M);
   WSYNC();
   const float XKAPPA = tb.XKAPPA, ZALP = tb.ZALP;
   float USTP[2], XSTRESS[2] = {0.f, 0.f}, YSTRESS[2] = {0.f, 0.f}, TAUX[2], TAUY[2];
@@ -100,9 +91,10 @@ __device__ void v3_sinput(const DevTab<float>& tb, const V3Ctx& L, float UFRIC, 
   xm0 = 0ull; xm1 = 0ull;
   wse = V3F2{0.f, 0.f}; wslast = V3F2{0.f, 0.f}; apl = V3F2{0.f, 0.f};
   for (int m = 0; m < NFRE; m++) {
-    const float4 fa = *reinterpret_cast<const float4*>(L.tSin + m * 4);      // ZCN, CONSTF, DSTAB1, -
     const float SIGm = lane_get(L.rZPIFR, m);
-    const float ZCN = fa.x, CONSTF = fa.y, DSTAB1 = fa.z, cinv_m = L.tFac[m * V3_NFAC + FA_CINV];
+    const float ZCN = L.tSin[m], cinv_m = L.tFac[m * V3_NFAC + FA_CINV];
+    const float CONSTF = ROGOROAIR * cinv_m * lane_get(L.rDFIM, m);
+    const float DSTAB1 = LLSNEG ? (lane_get(L.rC5, m) * AIRD_PVISC) * L.tFac[m * V3_NFAC + FA_WAVNUM] : 0.f;
     const float CNSN = (SIGm * CONST1) * RAORW;
     const float TEMP1 = LLSNEG ? (-tb.SWELLF * 16.0f * (SIGm * SIGm) / tb.G) * RAORW : 0.f;
     const V3F2 f = *reinterpret_cast<const V3F2*>(L.tF + m * NANG);
@@ -200,14 +192,14 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1
   L.act = L.grp && L.p < n;
   const int p = L.grp ? L.p : 0;
   const int ij = ij0 + (L.act ? L.p : 0);
-  const int per_wave = (V3P * (N + V3_NFAC * NFRE + 4 * NFRE + 3 * NFRE) + V3P * NSC + 3) & ~3;
+  const int per_wave = (V3P * (N + V3_NFAC * NFRE + NFRE + 3 * NFRE) + V3P * NSC + 3) & ~3;
   float* sF = reinterpret_cast<float*>(smem_raw) + (size_t)wave * per_wave;
   float* sFac = sF + V3P * N;
   float* sSin = sFac + V3P * V3_NFAC * NFRE;
-  float* sRow = sSin + V3P * 4 * NFRE;
+  float* sRow = sSin + V3P * NFRE;
   float* sSC = sRow + V3P * 3 * NFRE;   // [3][NSC]
   L.tP = sF + p * N; L.tF = L.tP + 2 * j; L.tFw = sF + p * N + 2 * j;
-  L.tFac = sFac + p * V3_NFAC * NFRE; L.tSin = sSin + p * 4 * NFRE; L.tRow = sRow + p * 3 * NFRE; L.c = sSC + p * NSC;
+  L.tFac = sFac + p * V3_NFAC * NFRE; L.tSin = sSin + p * NFRE; L.tRow = sRow + p * 3 * NFRE; L.c = sSC + p * NSC;
   const int base = p * V3G;
 #define V3_ROT(r) (4 * (base + ((j + (r)) >= V3G ? j + (r) - V3G : j + (r))))
   L.rot.a9 = V3_ROT(9); L.rot.a3 = V3_ROT(3); L.rot.a6 = V3_ROT(6); L.rot.a1 = V3_ROT(1); L.rot.a2 = V3_ROT(2);
@@ -216,6 +208,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1
     const int mi = lane < NFRE ? lane : 0;
     L.rDFIM = tb.DFIM[mi]; L.rDFIMOFR = tb.DFIMOFR[mi]; L.rDFIMFR = tb.DFIMFR[mi]; L.rZPIFR = tb.ZPIFR[mi]; L.rRHOWG = tb.RHOWG_DFIM[mi];
     L.rCOFRM4 = tb.COFRM4[mi]; L.rFLMAX = tb.FLMAX[mi];
+    L.rC5 = -tb.SWELLF5 * 2.0f * m_sqrt(2.0f * tb.RNU * tb.ZPIFR[mi]);
   }
   L.sinth = V3F2{tb.SINTH[j], tb.SINTH[j + V3G]};
   L.costh = V3F2{tb.COSTH[j], tb.COSTH[j + V3G]};
@@ -260,16 +253,13 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1
     const float TPIINV = 1.0f / tb.ZPI;
     for (int m = j; m < NFRE; m += V3G) {
       float* f = sFac + (p * NFRE + m) * V3_NFAC;
-      const float WAVNUM = wp[m], XK2CG = wp[3 * NFRE + m], dfim = tb.DFIM[m];
+      const float WAVNUM = wp[m], XK2CG = wp[3 * NFRE + m];
       const float sq = m_sqrt(WAVNUM);
-      f[FA_WAVNUM] = WAVNUM; f[FA_CINV] = wp[2 * NFRE + m];
+      f[FA_WAVNUM] = WAVNUM; f[FA_CINV] = wp[2 * NFRE + m]; f[FA_XK2CG] = XK2CG; f[FA_SQ] = sq;
       f[FA_STOK] = (m < tb.NFRE_ODD) ? wp[4 * NFRE + m] * tb.DFIM_SIM[m] : 0.f;
-      f[FA_TA] = dfim / sq; f[FA_TX] = sq * dfim;
       float sbo = 0.f;   // sbottom.F90:79-89
       if (m < tb.NFRE_RED && DEPTH < tb.BATHYMAX) sbo = (-2.0f * 0.038f * tb.GM1) * WAVNUM / m_sinh(m_min(2.0f * DEPTH * WAVNUM, 50.0f));
       f[FA_SBO] = sbo;
-      f[FA_FACSAT] = WAVNUM * TPIINV * XK2CG;
-      f[FA_RT] = 1.0f / XK2CG / WAVNUM;
     }
   }
   WSYNC();
@@ -289,8 +279,9 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1
       const float t = L.grp ? f.x + f.y : 0.f;
       const float* fa = L.tFac + m * V3_NFAC;
       s0 = s0 + V3F2{lane_get(L.rDFIM, m), lane_get(L.rDFIMOFR, m)} * t;
-      s1 = s1 + V3F2{lane_get(L.rDFIMFR, m), fa[FA_TA]} * t;
-      s2.x = s2.x + fa[FA_TX] * t;
+      const float dfm = lane_get(L.rDFIM, m), sqm = fa[FA_SQ];
+      s1 = s1 + V3F2{lane_get(L.rDFIMFR, m), dfm / sqm} * t;
+      s2.x = s2.x + (sqm * dfm) * t;
       if (m == NFRE - 1) s2.y = t;
     }
     s0 = v3_allsum(s0, L.rot); s1 = v3_allsum(s1, L.rot); s2 = v3_allsum(s2, L.rot);
@@ -566,7 +557,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1
           V3F2 bsat = z2;
 #pragma unroll
           for (int t = 0; t < V3_MAXTAP; t++) bsat = bsat + wgt[t] * V3F2{row[o0[t]], row[o1[t]]};
-          bsat = bsat * fa[FA_FACSAT];
+          bsat = bsat * (fa[FA_WAVNUM] * (1.0f / tb.ZPI) * fa[FA_XK2CG]);
           const float bm = v3_allmax(L.grp ? fmaxf(bsat.x, bsat.y) : 0.f, L.rot);
           const float sig = lane_get(L.rZPIFR, m);
           const float d0 = m_max(0.f, bm * TMP03 - SSDSC4);
@@ -662,10 +653,11 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1
     femws_finish(we, wl, FMEANWS, EMEANWS);
   }
   if (L.grp) {  // imphftail.F90
-    const float T1 = L.tFac[(MIJ - 1) * V3_NFAC + FA_RT];
+    auto rt = [&](int m) { const float* fa = L.tFac + m * V3_NFAC; return 1.0f / fa[FA_XK2CG] / fa[FA_WAVNUM]; };
+    const float T1 = rt(MIJ - 1);
     const V3F2 tf = *reinterpret_cast<const V3F2*>(L.tF + (MIJ - 1) * NANG);
     for (int m = MIJ; m < NFRE; m++) {
-      const float tm = L.tFac[m * V3_NFAC + FA_RT] / T1;
+      const float tm = rt(m) / T1;
       *reinterpret_cast<V3F2*>(L.tFw + m * NANG) = V3F2{m_max(tm * tf.x, FLM.x), m_max(tm * tf.y, FLM.y)};
     }
   }

@@ -217,6 +217,10 @@ class HipContext:
             pw = wam2nemo.data_ptr()
         self._chk(self.lib.ecwam_hip_implsch(self._h, kijs, kijl, *a, pw, pd, _stream_ptr()))
 
+    def set_implsch_generation(self, gen: int) -> None:
+        """Cap the IMPLSCH kernel generation (2, 3, 4; 0 = automatic): include/ecwam_hip.h ecwam_hip_set_implsch_generation."""
+        self._chk(self.lib.ecwam_hip_set_implsch_generation(self._h, int(gen)))
+
     # -- SNONLIN alone in the three-points-per-wavefront layout (diagnostic seam, include/ecwam_hip.h)
     def snonlin3(self, fl1, depth, akmean, mode: int = 0):
         """Returns (SL, FLD) as [n][NANG][NFRE] tensors (re-ordered from the kernel's [n][NFRE][18][2] pair layout)."""

@@ -24,6 +24,9 @@ struct ecwam_hip_ctx {
   int NANG, NFRE, NFRE_RED;
   void* dtab;  // DevTab<T> in device memory
   int implsch_variant;  // 2: two-tile fused-sweep kernel (needs the DIA rotation structure), 1: three-tile kernel
+  // fourth kernel generation (implsch_v4.h): DIA rotations K1 = K -+ r1, K2 = K +- r2, NSDSNTH = nh; ok = the tables have that structure
+  int v4_ok = 0, v4_r1 = 0, v4_r2 = 0, v4_nh = 0;
+  int implsch_gen = 0;  // 0: the fastest kernel generation that covers the configuration; 2 / 3 / 4: at most that generation (tests)
   ecwam_hip_params p;
   const void* obs = nullptr;  // LSUBGRID: device OBS[n_obs][8][NFRE] (ecwam_hip_set_obstructions), read by CTUW / PROPAGS2
   int n_obs = 0;
@@ -48,6 +51,30 @@ template <typename T> void launch_c2p(const void*, void*, int, int, int, int, in
 template <typename T> void launch_p2c(const void*, void*, int, int, int, int, int, hipStream_t);
 template <typename T> void launch_pack(const void*, const int*, int, int, void*, hipStream_t);
 template <typename T> int launch_implsch(const void*, int, int, void*, const void*, void*, void*, int*, void*, double*, void*, int, int, int, hipStream_t);
+template <typename T> int launch_implsch4(const void*, int, int, void*, const void*, void*, void*, int*, void*, int, int, int, int, int, hipStream_t);
+
+// Does the fourth kernel generation cover these tables?  It needs the pull-form DIA structure with K1W = K -+ r1, K11W = K1W -+ 1,
+// K2W = K +- r2, K21W = K2W +- 1 (kh = 1 / 2) and saturation weights that depend on the tap only (init_sdiss_ardh.F90:88-94: they
+// are COS**2 of a multiple of DELTH, equal for all K up to rounding).
+template <typename T>
+static void v4_probe(const DevTab<T>& h, ecwam_hip_ctx* c) {
+  c->v4_ok = 0;
+  const int NANG = h.NANG;
+  if (!h.DIA_PULL || (NANG & 1) || h.NFRE != 36) return;
+  const int r1 = (NANG - h.K1W[0][0]) % NANG, r2 = h.K2W[0][0];
+  if (h.D11[0] != -1 || h.D21[0] != 1 || h.D11[1] != 1 || h.D21[1] != -1) return;
+  if (h.K1W[1][0] != r1 % NANG || h.K2W[1][0] != (NANG - r2) % NANG) return;
+  T wmax = T(0);
+  for (int t = 0; t < h.NTAP; t++) wmax = wmax > h.SATWEIGHTS[t][NANG / 2] ? wmax : h.SATWEIGHTS[t][NANG / 2];
+  const T eps = sizeof(T) == 4 ? T(1.2e-7) : T(2.3e-16);
+  for (int t = 0; t < h.NTAP; t++)
+    for (int k = 0; k < NANG; k++) {
+      const T d = h.SATWEIGHTS[t][k] - h.SATWEIGHTS[t][NANG / 2];
+      if ((d < 0 ? -d : d) > T(16) * eps * wmax) return;
+      if (h.INDICESSAT[t][k] != ((k - h.NSDSNTH + t) % NANG + NANG) % NANG) return;
+    }
+  c->v4_r1 = r1; c->v4_r2 = r2; c->v4_nh = h.NSDSNTH; c->v4_ok = 1;
+}
 
 template <typename T>
 static void cpv(T* dst, const void* src, int n) {
@@ -69,7 +96,10 @@ static int build_tab(const ecwam_hip_params* p, const ecwam_hip_tables* t, DevTa
   d->LCIWA1 = p->lciwa1; d->LWNEMOCOUIBR = p->lwnemocouibr; d->LWNEMOCOUSTRN = p->lwnemocoustrn; d->NICT = p->nict; d->NICH = p->nich;
   for (int i = 0; i < 36 * 16; i++) d->CIDEAC[i] = T(0);
   if (p->lciwa1 && t->cideac) cpv(d->CIDEAC, t->cideac, p->nict * p->nich);
+  d->DBG_SKIP = 0;
+#ifdef ECWAM_HIP_DIAGNOSTICS   // timing builds only (tools/): phases of IMPLSCH skipped / early returns; never in the product library
   { const char* e_ = getenv("ECWAM_HIP_DEBUG_SKIP"); d->DBG_SKIP = e_ ? atoi(e_) : 0; }
+#endif
   d->NSDSNTH = p->nsdsnth; d->NTAP = 2 * p->nsdsnth + 1; d->MFRSTLW = p->mfrstlw; d->MLSTHG = ML; d->KFRH = p->kfrh; d->NWAV_GC = p->nwav_gc;
 #define S_(dst, src) d->dst = (T)p->src
   S_(ZIBRW_THRSH, zibrw_thrsh); S_(TICMIN, ticmin); S_(DTIC, dtic); S_(DHIC, dhic); S_(HICMIN, hicmin);
@@ -213,6 +243,7 @@ int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int r
     std::vector<DevTab<float>> h(1);
     build_tab<float>(p, t, h.data());
     c->implsch_variant = h[0].DIA_PULL ? 2 : 1;
+    v4_probe<float>(h[0], c);
     if ((p->llgcbz0 || p->lciwa1 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou || p->lwnemocouwrs || p->lwnemocoustrn || p->isnonlin || p->iphys == 0 || p->icode != 3 || !p->lwvflx_snl) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
     HIPCHK(hipMalloc(&c->dtab, sizeof(DevTab<float>)));
     HIPCHK(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<float>), hipMemcpyHostToDevice));
@@ -220,6 +251,7 @@ int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int r
     std::vector<DevTab<double>> h(1);
     build_tab<double>(p, t, h.data());
     c->implsch_variant = h[0].DIA_PULL ? 2 : 1;
+    v4_probe<double>(h[0], c);
     if ((p->llgcbz0 || p->lciwa1 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou || p->lwnemocouwrs || p->lwnemocoustrn || p->isnonlin || p->iphys == 0 || p->icode != 3 || !p->lwvflx_snl) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
     HIPCHK(hipMalloc(&c->dtab, sizeof(DevTab<double>)));
     HIPCHK(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<double>), hipMemcpyHostToDevice));
@@ -438,10 +470,24 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   // third kernel generation (implsch_v3.h): single precision, 36 directions, at most 17 saturation taps, at most 64 frequencies
   if (c->real_bytes == 4 && c->NANG == 36 && 2 * c->p.nsdsnth + 1 <= 17 && c->NFRE <= 64 && c->p.mlsthg >= c->NFRE) variant |= 64;
   if (c->p.llgcbz0 || c->p.lciwa1 || c->p.lciwa2 || c->p.lciwa3 || c->p.lciscal || c->p.lwnemocou || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin || c->p.iphys == 0 || c->p.icode != 3 || !c->p.lwvflx_snl) variant |= 32;
+  // fourth kernel generation (implsch_v4.h): flag set A without the optional branches, single and double precision
+  if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !(variant & (16 | 32)) && (variant & 15) == 2 && !wam2nemo && !dbg) {
+    DISPATCH(rc = launch_implsch4<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, s),
+             rc = launch_implsch4<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, s));
+    if (rc == 0) { HIPCHK(hipGetLastError()); return 0; }
+  }
+  if (c->implsch_gen == 2) variant &= ~64;
   DISPATCH(rc = launch_implsch<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s),
            rc = launch_implsch<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s));
   if (rc) return fail("ecwam_hip_implsch: unsupported spectral size for the LDS tiling");
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ecwam_hip_set_implsch_generation(ecwam_hip_ctx* c, int gen) {
+  if (!c) return fail("null context");
+  if (gen != 0 && gen != 2 && gen != 3 && gen != 4) return fail("ecwam_hip_set_implsch_generation: 0 (automatic), 2, 3 or 4");
+  c->implsch_gen = gen;
   return 0;
 }
 

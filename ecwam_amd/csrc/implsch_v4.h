@@ -1,0 +1,818 @@
+// IMPLSCH, fourth kernel generation (implsch.F90:10-468 and the routines it inlines on flag set A): PP sea points per wavefront,
+// G = NANG/2 lanes per point, lane j of a point owns the ADJACENT direction pair (K = 2j, 2j+1).  Single and double precision,
+// NANG = 36 / 24 / 12 (PP = 3 / 5 / 10), NFRE = 36.
+//
+// What changed against implsch_v3.h, and why (tools/ubench_valu.hip, profiles/r02_ubench_valu.txt, MI355X):
+//   * ds_bpermute_b32 costs 6 cycles of the CU's single LDS pipe per wave instruction, ds_read_b32 / ds_read_b64 cost 2: the 53
+//     bpermutes per interaction frequency of k_implsch3 kept the LDS pipe ~70 % busy during the sweep.  Here every rotation in K
+//     is a ds_read_b64 of an LDS row at a per-lane wrapped address (the lane's pair shifted by an even number of directions;
+//     odd shifts take one half from each of two even shifts): the DIA gathers read four staged rows (the frequency-interpolated
+//     spectra), the DIA increments are staged in three rows and pulled back rotated, the 2 NSDSNTH + 1 taps of the saturation
+//     filter are NSDSNTH + 1 reads of the row itself.  No half swaps (v_cndmask), no per-tap address registers.
+//   * v_pk_fma_f32 issues at 4.4 cycles per wave instruction against 2.6 for v_fma_f32 when two waves share a SIMD: packing halves
+//     the instruction count but buys 15 % of issue time, so nothing here depends on it (the code is plain scalar arithmetic on the
+//     two halves of a pair and compiles for double precision as it stands).
+//   * the tile is [M][point][K] (K fastest, natural order): the coalesced load / store are 16-byte global accesses with the
+//     (K, M) transposition done by four 4-byte LDS accesses at immediate offsets -- 5 instead of 45 vector instructions per element.
+//   * the row integrals of SINPUT live in registers of the lane that owns the frequency (no LDS table), the SINPUT factor
+//     LOG(WAVNUM Z0M) shares the factor table: 20 424 B of LDS per wave (sp, NANG = 36): 8 waves per CU as before, the limit.
+// The lane-per-point scalar stages (TAUT_Z0, STRESSO / TAU_PHI_HF, WSIGSTAR, swell set-up, SDIWBK) are those of implsch_v2.h.
+#pragma once
+
+#define V4_NFRE 36
+// phase timing (tools/time_v4_phases.sh): a diagnostics build (-DECWAM_HIP_DIAGNOSTICS) returns early at the phase boundary DBG_SKIP
+#ifdef ECWAM_HIP_DIAGNOSTICS
+#define V4_PHASE_EXIT(k) do { if (tb.DBG_SKIP == (k)) return; } while (0)
+#else
+#define V4_PHASE_EXIT(k) do { } while (0)
+#endif
+#define V4_NSTG 4
+#define V4_NFAC 6
+enum { F4_WAVNUM = 0, F4_CINV, F4_BSC, F4_SQ, F4_SBO, F4_ZCN };   // F4_BSC = WAVNUM XK2CG / 2 pi, F4_SQ = SQRT(WAVNUM), F4_ZCN = LOG(WAVNUM Z0M)
+
+template <typename T>
+using V2 = T __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float v4_bp(int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); }
+__device__ __forceinline__ double v4_bp(int addr, double v) {
+  const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+template <typename T>
+__device__ __forceinline__ V2<T> v4_same(V2<T> v, int addr) {
+  V2<T> r;
+  r.x = v4_bp(addr, v.x);
+  r.y = v4_bp(addr, v.y);
+  return r;
+}
+// all-reduce over the G lanes of a point: G = 18: rotations by 9, then 3 and 6, then 1 and 2; G = 12: 6, 3, then 1 and 2; G = 6: 3, then
+// 1 and 2 (byte addresses of the source lanes)
+struct V4Rot { int a0, a1, a2, a3, a4; };
+template <int G, typename T>
+__device__ __forceinline__ V2<T> v4_allsum(V2<T> v, const V4Rot& r) {
+  v = v + v4_same<T>(v, r.a0);
+  if (G == 18) v = v + (v4_same<T>(v, r.a1) + v4_same<T>(v, r.a2));
+  if (G == 12) v = v + v4_same<T>(v, r.a1);
+  v = v + (v4_same<T>(v, r.a3) + v4_same<T>(v, r.a4));
+  return v;
+}
+template <int G, typename T>
+__device__ __forceinline__ T v4_allmax(T v, const V4Rot& r) {
+  v = m_max(v, v4_bp(r.a0, v));
+  if (G == 18) v = m_max(v, m_max(v4_bp(r.a1, v), v4_bp(r.a2, v)));
+  if (G == 12) v = m_max(v, v4_bp(r.a1, v));
+  v = m_max(v, m_max(v4_bp(r.a3, v), v4_bp(r.a4, v)));
+  return v;
+}
+
+// the pair (X(2j+r), X(2j+r+1)) of an LDS row; sh[i] = index of element (2j + 2(i-NSH)) mod NANG of the lane's point in a row
+template <typename T, int NSH, int r>
+__device__ __forceinline__ V2<T> v4_at(const T* row, const int (&sh)[2 * NSH + 1]) {
+  if constexpr ((r & 1) == 0) {
+    return *reinterpret_cast<const V2<T>*>(row + sh[r / 2 + NSH]);
+  } else {
+    const V2<T> a = *reinterpret_cast<const V2<T>*>(row + sh[(r - 1) / 2 + NSH]);
+    const V2<T> b = *reinterpret_cast<const V2<T>*>(row + sh[(r + 1) / 2 + NSH]);
+    return V2<T>{a.y, b.x};
+  }
+}
+
+template <typename T, int PP, bool RARE>
+__device__ __forceinline__ void v4_stresso(const DevTab<T>& tb, T* sSC, int lane, bool LLPHIWA) {
+  if constexpr (PP <= 3) {
+    stresso_stage<T, PP, RARE>(tb, sSC, lane, LLPHIWA);
+  } else {
+    stresso_stage<T, 3, RARE>(tb, sSC, lane, LLPHIWA);
+    WSYNC();
+    v4_stresso<T, PP - 3, RARE>(tb, sSC + 3 * NSC, lane, LLPHIWA);
+  }
+}
+
+template <typename T, int NANG_, int PP_>
+struct V4Ctx {
+  int lane, p, j;
+  bool grp, act;
+  T* tile;      // row 0 of the wave's tile [M][point][K]
+  int own;      // p NANG + 2j: the lane's pair inside a row
+  T* fac;       // factor table of the point [M][V4_NFAC]
+  T* c;         // scalars of the point [NSC]
+  V4Rot rot;
+  V2<T> sinth, costh;
+  // module tables per frequency, lane m holds M = m+1: broadcast with v_readlane inside the M loops
+  T rDFIM, rDFIMOFR, rDFIMFR, rZPIFR, rRHOWG, rCOFRM4, rFLMAX, rC5;   // rC5 = -SWELLF5 2 SQRT(2 NU_AIR SIG) (sinput_ard.F90:343)
+};
+
+// SINPUT_ARD (sinput_ard.F90:153-520) for one SINFLX call.  Outputs: XLLWS masks of the two directions of the lane (bit m), the row
+// integrals X, Y, S of the frequencies the lane owns (m = s G + j), the FEMEANWS integrands (wse: x = SUM DFIM F, y = SUM DFIMOFR F
+// over the windsea bins; wslast = windsea part of the last row), apl (negative wind input per direction) and -- LLSNEG -- the
+// wind-input coefficient of every row into gfl (the point's XLLWS block, [M][K]).
+template <typename T, int NANG, int PP, int NGST, bool LLSNEG>
+__device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UFRIC, T Z0M, T RAORW, T SIG_N, T TEMP2, T PTURB, T AIRD_PVISC,
+                          T sinwd, T coswd, T* __restrict__ gfl, unsigned long long& xm0, unsigned long long& xm1, V2<T>& wse,
+                          V2<T>& wslast, V2<T>& apl, T (&rX)[V4_NFRE / (NANG / 2)], T (&rY)[V4_NFRE / (NANG / 2)],
+                          T (&rS)[V4_NFRE / (NANG / 2)]) {
+  constexpr int G = NANG / 2, NFRE = V4_NFRE, RS = PP * NANG, NS = NFRE / G;
+  const T CONST1 = tb.BETAMAXOXKAPPA2, ABS_TAUWSHELTER = m_abs(tb.TAUWSHELTER);
+  const T FU = m_abs(tb.SWELLF3), FUD = tb.SWELLF2, ROGOROAIR = tb.G / RAORW;
+  const T AVG = T(1) / T(NGST);
+  if (L.grp)
+    for (int m = L.j; m < NFRE; m += G) L.fac[m * V4_NFAC + F4_ZCN] = m_log(L.fac[m * V4_NFAC + F4_WAVNUM] * Z0M);
+  WSYNC();
+  const T XKAPPA = tb.XKAPPA, ZALP = tb.ZALP;
+  T USTP[2], XSTRESS[2] = {T(0), T(0)}, YSTRESS[2] = {T(0), T(0)}, TAUX[2], TAUY[2];
+  if (NGST == 1) USTP[0] = UFRIC;
+  else { USTP[0] = UFRIC * (T(1) + SIG_N); USTP[1] = UFRIC * (T(1) - SIG_N); }
+#pragma unroll
+  for (int ig = 0; ig < NGST; ig++) {
+    const T USG2 = USTP[ig] * USTP[ig];
+    TAUX[ig] = USG2 * sinwd;
+    TAUY[ig] = USG2 * coswd;
+  }
+  xm0 = 0ull; xm1 = 0ull;
+  const V2<T> z2 = {T(0), T(0)};
+  wse = z2; wslast = z2; apl = z2;
+#pragma unroll
+  for (int s = 0; s < NS; s++) { rX[s] = T(0); rY[s] = T(0); rS[s] = T(0); }
+  const T* tF = L.tile + L.own;
+  for (int m = 0; m < NFRE; m++) {
+    const T SIGm = lane_get(L.rZPIFR, m);
+    const T* fa = L.fac + m * V4_NFAC;
+    const T ZCN = fa[F4_ZCN], cinv_m = fa[F4_CINV];
+    const T CONSTF = ROGOROAIR * cinv_m * lane_get(L.rDFIM, m);
+    const T DSTAB1 = LLSNEG ? (lane_get(L.rC5, m) * AIRD_PVISC) * fa[F4_WAVNUM] : T(0);
+    const T CNSN = (SIGm * CONST1) * RAORW;
+    const T TEMP1 = LLSNEG ? (-tb.SWELLF * T(16) * (SIGm * SIGm) / tb.G) * RAORW : T(0);
+    const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
+    V2<T> SLP[2], FLP[2];
+    bool xl0 = false, xl1 = false;
+#pragma unroll
+    for (int ig = 0; ig < NGST; ig++) {
+      const T TAUPX = TAUX[ig] - ABS_TAUWSHELTER * XSTRESS[ig];
+      const T TAUPY = TAUY[ig] - ABS_TAUWSHELTER * YSTRESS[ig];
+      const T h2 = TAUPX * TAUPX + TAUPY * TAUPY;
+      const bool zero = !(h2 > T(0));
+      const T rh = f_rsq(h2);
+      const T h = zero ? T(0) : h2 * rh;
+      const T COSU = zero ? T(1) : TAUPY * rh, SINU = zero ? T(0) : TAUPX * rh;
+      USTP[ig] = f_sqrt(h);
+      const T UCN = USTP[ig] * cinv_m;
+      const T UCNZALPD = XKAPPA * f_rcp(UCN + ZALP);
+      const V2<T> coslp = L.costh * COSU + L.sinth * SINU;
+      V2<T> gam0 = z2;
+      {
+        const bool c0 = coslp.x > T(0.01), c1 = coslp.y > T(0.01);
+        const T Z0 = ZCN + UCNZALPD * f_rcp(coslp.x), Z1 = ZCN + UCNZALPD * f_rcp(coslp.y);
+        const bool n0 = c0 && (Z0 < T(0)), n1 = c1 && (Z1 < T(0));
+        if (__builtin_amdgcn_ballot_w64(n0 || n1) != 0ull) {
+          const V2<T> ZL = {Z0, Z1};
+          const V2<T> Z2X = ZL * ZL * (coslp * UCN);
+          const V2<T> ex = {f_exp(Z0), f_exp(Z1)};
+          const V2<T> g = ex * Z2X * Z2X * CNSN;
+          gam0.x = n0 ? g.x : T(0);
+          gam0.y = n1 ? g.y : T(0);
+          xl0 = xl0 || n0;
+          xl1 = xl1 || n1;
+        }
+      }
+      V2<T> dstab = z2;
+      if (LLSNEG) {
+        const V2<T> DSTAB2 = TEMP1 * (TEMP2 + (FU + FUD * coslp) * USTP[ig]);
+        dstab = DSTAB1 + PTURB * DSTAB2;
+      }
+      FLP[ig] = gam0 + dstab;
+      SLP[ig] = gam0 * f;
+    }
+    V2<T> sp = SLP[0], fl = FLP[0];
+    if (NGST == 2) { sp = sp + SLP[1]; fl = fl + FLP[1]; }
+    sp = AVG * sp;
+    fl = AVG * fl;
+    const bool anygrow = __builtin_amdgcn_ballot_w64(xl0 || xl1) != 0ull;
+    T xrow = T(0), yrow = T(0), srow = T(0);
+    if (anygrow) {
+#pragma unroll
+      for (int ig = 0; ig < NGST; ig++) {
+        const V2<T> sx = L.grp ? SLP[ig] * L.sinth : z2, sy = L.grp ? SLP[ig] * L.costh : z2;
+        const V2<T> xs = v4_allsum<G, T>(V2<T>{sx.x + sx.y, sy.x + sy.y}, L.rot);
+        XSTRESS[ig] = XSTRESS[ig] + CONSTF * xs.x;
+        YSTRESS[ig] = YSTRESS[ig] + CONSTF * xs.y;
+        xrow += xs.x;
+        yrow += xs.y;
+      }
+      if (LLSNEG) srow = v4_allsum<G, T>(L.grp ? V2<T>{sp.x + sp.y, T(0)} : z2, L.rot).x;
+      xrow = AVG * xrow; yrow = AVG * yrow;
+    }
+    {  // the lane that owns frequency m keeps its row integrals
+      const int ms = m / G, mj = m - ms * G;
+      const bool mine = (L.j == mj);
+#pragma unroll
+      for (int s = 0; s < NS; s++) {
+        const bool w = mine && (ms == s);
+        rX[s] = w ? xrow : rX[s];
+        rY[s] = w ? yrow : rY[s];
+        rS[s] = w ? srow : rS[s];
+      }
+    }
+    if (LLSNEG) {
+      apl = apl + (fl * f - sp) * lane_get(L.rRHOWG, m);
+      if (L.act) *reinterpret_cast<V2<T>*>(gfl + (size_t)m * NANG) = fl;
+    }
+    if (xl0) xm0 |= (1ull << m);
+    if (xl1) xm1 |= (1ull << m);
+    const V2<T> x = {xl0 ? f.x : T(0), xl1 ? f.y : T(0)};
+    wse = wse + V2<T>{lane_get(L.rDFIM, m), lane_get(L.rDFIMOFR, m)} * (x.x + x.y);
+    wslast = x;
+  }
+  WSYNC();
+}
+
+template <typename T, int NANG, int PP, int R1, int R2, int NH>
+// at most 256 VGPRs: the double-precision instantiations otherwise take 340+ registers (AGPRs as spill space) and that build returned
+// wrong WNFLUXES sums on gfx950 / ROCm 7.2 (tools/implsch_gens.py; -O1 and the 256-register build agree with the oracle to 1e-13)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__ fl1, const T* __restrict__ wvprpt, T* __restrict__ ffa,
+           T* __restrict__ intfa, int* __restrict__ mij_out, T* __restrict__ xllws) {
+  constexpr int G = NANG / 2, NFRE = V4_NFRE, N = NANG * NFRE, RS = PP * NANG, NS = NFRE / G;
+  constexpr int NSH = (NH + 1) / 2;          // even shifts -2 NSH .. 2 NSH cover the taps -NH .. NH+1 and the DIA rotations
+  constexpr int NTAP = 2 * NH + 1;
+  constexpr int VEC = 16 / (int)sizeof(T);   // elements per 16-byte global access
+  static_assert(PP * G <= 64 && NFRE % G == 0 && NFRE % VEC == 0 && R2 + 2 <= 2 * NSH + 1, "layout");
+  typedef T VT __attribute__((ext_vector_type(VEC)));
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const DevTab<T>& tb = *tp;
+  T* sT = reinterpret_cast<T*>(smem_raw);          // [NFRE + V4_NSTG][PP][NANG]
+  T* sStg = sT + NFRE * RS;                        // the staging rows
+  T* sFac = sT + (NFRE + V4_NSTG) * RS;            // [PP][NFRE][V4_NFAC]
+  T* sSC = sFac + PP * NFRE * V4_NFAC;             // [PP][NSC]
+  V4Ctx<T, NANG, PP> L;
+  L.lane = threadIdx.x & 63;
+  const int lane = L.lane;
+  const int pl = lane / G;
+  L.grp = pl < PP;
+  L.p = L.grp ? pl : 0;                            // spare lanes shadow point 0 (reads only)
+  L.j = lane - pl * G;
+  if (!L.grp) L.j = lane - PP * G < G ? lane - PP * G : 0;
+  const int p = L.p, j = L.j;
+  const int ij0 = kijs + blockIdx.x * PP;
+  if (ij0 >= kijl) return;
+  const int n = kijl - ij0 < PP ? kijl - ij0 : PP;   // points of this wave; a short last wave replicates its last point
+  L.act = L.grp && p < n;
+  const int ij = ij0 + (p < n ? p : n - 1);
+  L.tile = sT; L.own = p * NANG + 2 * j;
+  L.fac = sFac + p * NFRE * V4_NFAC; L.c = sSC + p * NSC;
+  int sh[2 * NSH + 1];
+#pragma unroll
+  for (int i = 0; i <= 2 * NSH; i++) {
+    int k = 2 * j + 2 * (i - NSH);
+    k = k < 0 ? k + NANG : (k >= NANG ? k - NANG : k);
+    sh[i] = p * NANG + k;
+  }
+  {
+    const int base = p * G;
+#define V4_ROT(r) (4 * (base + ((j + (r)) >= G ? j + (r) - G : j + (r))))
+    if (G == 18) { L.rot.a0 = V4_ROT(9); L.rot.a1 = V4_ROT(3); L.rot.a2 = V4_ROT(6); }
+    if (G == 12) { L.rot.a0 = V4_ROT(6); L.rot.a1 = V4_ROT(3); L.rot.a2 = 0; }
+    if (G == 6) { L.rot.a0 = V4_ROT(3); L.rot.a1 = 0; L.rot.a2 = 0; }
+    L.rot.a3 = V4_ROT(1); L.rot.a4 = V4_ROT(2);
+#undef V4_ROT
+  }
+  {
+    const int mi = lane < NFRE ? lane : 0;
+    L.rDFIM = tb.DFIM[mi]; L.rDFIMOFR = tb.DFIMOFR[mi]; L.rDFIMFR = tb.DFIMFR[mi]; L.rZPIFR = tb.ZPIFR[mi]; L.rRHOWG = tb.RHOWG_DFIM[mi];
+    L.rCOFRM4 = tb.COFRM4[mi]; L.rFLMAX = tb.FLMAX[mi];
+    L.rC5 = -tb.SWELLF5 * T(2) * m_sqrt(T(2) * tb.RNU * tb.ZPIFR[mi]);
+  }
+  L.sinth = V2<T>{tb.SINTH[2 * j], tb.SINTH[2 * j + 1]};
+  L.costh = V2<T>{tb.COSTH[2 * j], tb.COSTH[2 * j + 1]};
+  T* c = L.c;
+  const T* tF = sT + L.own;        // the lane's pair in row 0
+  T* tFw = sT + L.own;
+
+  // ---- spectra F[ij][K][M] -> tile [M][point][K]: 16-byte global loads, the VEC frequencies of a chunk go to VEC rows
+  {
+    constexpr int NV = N / VEC;             // chunks per point
+    const float rnv = 1.0f / (float)NV, rnf = 1.0f / (float)(NFRE / VEC);
+    for (int v = lane; v < PP * NV; v += 64) {
+      const int pq = (int)(((float)v + 0.5f) * rnv);       // v / NV (exact for these sizes)
+      const int w = v - pq * NV;
+      const int k = (int)(((float)w + 0.5f) * rnf);         // w / (NFRE / VEC)
+      const int m0 = (w - k * (NFRE / VEC)) * VEC;
+      const VT val = *reinterpret_cast<const VT*>(fl1 + (size_t)(ij0 + (pq < n ? pq : n - 1)) * N + (size_t)w * VEC);
+      T* d = sT + m0 * RS + pq * NANG + k;
+#pragma unroll
+      for (int i = 0; i < VEC; i++) d[i * RS] = val[i];
+    }
+  }
+  // ---- point scalars + first TAUT_Z0, one lane per point (sinflx.F90:105-122)
+  if (lane < PP) {
+    const int pid = ij0 + (lane < n ? lane : n - 1);
+    const T* ff = ffa + (size_t)pid * ECWAM_HIP_NFF;
+    T* q = sSC + lane * NSC;
+    const T AIRD = ff[0], WDWAVE = ff[1], WSWAVE = ff[3];
+    q[C_AIRD] = AIRD; q[C_WDWAVE] = WDWAVE; q[C_WSWAVE] = WSWAVE; q[C_WSTAR] = ff[4];
+    q[C_TAUW] = ff[8]; q[C_TAUWDIR] = ff[9];
+    q[C_RAORW] = m_max(AIRD, T(1)) * tb.ROWATERM1; q[C_EMAXDPT] = ff[14]; q[C_DEPTH] = ff[15];
+    q[C_SINWD] = m_sin(WDWAVE); q[C_COSWD] = m_cos(WDWAVE);
+    q[C_RNFAC] = T(1);
+    T UFRIC = ff[7], Z0M = ff[10], Z0B = ff[11], CHRNCK = ff[12];
+    taut_z0_a(tb, 0, WSWAVE, WDWAVE, ff[8], ff[9], UFRIC, Z0M, Z0B, CHRNCK);
+    q[C_UFRIC] = UFRIC; q[C_Z0M] = Z0M; q[C_Z0B] = Z0B; q[C_CHRNCK] = CHRNCK;
+    q[C_SPARE] = ff[2];   // CICOVER
+  }
+  // ---- per-frequency factors of the point: lane j fills M = j+1, j+1+G, ...
+  if (L.grp) {
+    const T* wp = wvprpt + (size_t)ij * ECWAM_HIP_NWPR * NFRE;
+    const T DEPTHv = ffa[(size_t)ij * ECWAM_HIP_NFF + 15];
+    for (int m = j; m < NFRE; m += G) {
+      T* f = L.fac + m * V4_NFAC;
+      const T WAVNUM = wp[m], XK2CG = wp[3 * NFRE + m];
+      f[F4_WAVNUM] = WAVNUM; f[F4_CINV] = wp[2 * NFRE + m]; f[F4_BSC] = WAVNUM * (T(1) / tb.ZPI) * XK2CG; f[F4_SQ] = m_sqrt(WAVNUM);
+      T sbo = T(0);   // sbottom.F90:79-89
+      if (m < tb.NFRE_RED && DEPTHv < tb.BATHYMAX) sbo = (-T(2) * T(0.038) * tb.GM1) * WAVNUM / m_sinh(m_min(T(2) * DEPTHv * WAVNUM, T(50)));
+      f[F4_SBO] = sbo;
+    }
+  }
+  WSYNC();
+  V4_PHASE_EXIT(201);
+  const T AIRD = c[C_AIRD], WSWAVE = c[C_WSWAVE], RAORW = c[C_RAORW], EMAXDPT = c[C_EMAXDPT], DEPTH = c[C_DEPTH];
+  const T sinwd = c[C_SINWD], coswd = c[C_COSWD], CICOVER = c[C_SPARE];
+  const V2<T> coswdif = L.costh * coswd + L.sinth * sinwd;
+  const T frl = tb.FR[NFRE - 1];
+  const T DELT25 = tb.WETAIL * frl * tb.DELTH;
+  const V2<T> z2 = {T(0), T(0)};
+  const V2<T> cpos = {m_max(T(0), coswdif.x), m_max(T(0), coswdif.y)};
+  const V2<T> FLM = ((T(1) - T(0.9) * m_min(CICOVER, T(0.99))) * tb.FLMIN) * (cpos * cpos);
+
+  // FKMEAN (fkmean.F90:94-150) from per-lane sums over M and one all-reduce per pair of quantities
+  auto fkmean_finish = [&](V2<T> s0, V2<T> s1, V2<T> s2, T& EM, T& FM1, T& F1, T& AK, T& XK) {
+    s0 = v4_allsum<G, T>(s0, L.rot); s1 = v4_allsum<G, T>(s1, L.rot); s2 = v4_allsum<G, T>(s2, L.rot);
+    const T COEFM1 = tb.FRTAIL * tb.DELTH;
+    const T COEF1 = tb.WP1TAIL * tb.DELTH * frl * frl;
+    const T COEFA = COEFM1 * m_sqrt(tb.G) / tb.ZPI;
+    const T COEFX = COEF1 * (tb.ZPI / m_sqrt(tb.G));
+    const T tl = s2.y;
+    EM = tb.EPSMIN + s0.x + DELT25 * tl;
+    FM1 = EM / (tb.EPSMIN + s0.y + COEFM1 * tl);
+    F1 = (tb.EPSMIN + s1.x + COEF1 * tl) / EM;
+    AK = tb.EPSMIN + s1.y + COEFA * tl;
+    AK = (EM / AK) * (EM / AK);
+    XK = tb.EPSMIN + s2.x + COEFX * tl;
+    XK = (XK / EM) * (XK / EM);
+  };
+  auto fkmean4 = [&](T& EM, T& FM1, T& F1, T& AK, T& XK) {
+    V2<T> s0 = z2, s1 = z2, s2 = z2;   // (EM, FM), (F1, AK), (XK, last row)
+    for (int m = 0; m < NFRE; m++) {
+      const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
+      const T t = L.grp ? f.x + f.y : T(0);
+      const T dfm = lane_get(L.rDFIM, m), sqm = L.fac[m * V4_NFAC + F4_SQ];
+      s0 = s0 + V2<T>{dfm, lane_get(L.rDFIMOFR, m)} * t;
+      s1 = s1 + V2<T>{lane_get(L.rDFIMFR, m), dfm / sqm} * t;
+      s2.x = s2.x + (sqm * dfm) * t;
+      if (m == NFRE - 1) s2.y = t;
+    }
+    fkmean_finish(s0, s1, s2, EM, FM1, F1, AK, XK);
+  };
+
+  // ---- SDEPTHLIM (sdepthlim.F90:64-78, semean.F90:82-120), FKMEAN, the tail of sinflx.F90:124-128 and the orbital integrals of the
+  //      swell damping (sinput_ard.F90:213-222) in two passes over the tile
+  T EMEAN, FMEAN, F1MEAN, AKMEAN, XKMEAN;
+  {
+    T sc = T(1);
+    if (tb.LBIWBK) {
+      V2<T> s = z2;
+      for (int m = 0; m < NFRE; m++) {
+        const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
+        const T t = L.grp ? f.x + f.y : T(0);
+        s.x = s.x + lane_get(L.rDFIM, m) * t;
+        if (m == NFRE - 1) s.y = t;
+      }
+      s = v4_allsum<G, T>(s, L.rot);
+      const T EM = tb.EPSMIN + s.x + DELT25 * s.y;
+      sc = m_min(EMAXDPT / EM, T(1));
+    }
+    V2<T> s0 = z2, s1 = z2, s2 = z2, so = z2;
+    for (int m = 0; m < NFRE; m++) {
+      V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
+      if (tb.LBIWBK) { f = f * sc; f.x = m_max(f.x, tb.EPSMIN); f.y = m_max(f.y, tb.EPSMIN); }
+      const T t = L.grp ? f.x + f.y : T(0);
+      const T dfm = lane_get(L.rDFIM, m), sqm = L.fac[m * V4_NFAC + F4_SQ], sig = lane_get(L.rZPIFR, m);
+      s0 = s0 + V2<T>{dfm, lane_get(L.rDFIMOFR, m)} * t;
+      s1 = s1 + V2<T>{lane_get(L.rDFIMFR, m), dfm / sqm} * t;
+      s2.x = s2.x + (sqm * dfm) * t;
+      if (m == NFRE - 1) {
+        s2.y = t;
+        f.x = m_max(f.x, FLM.x); f.y = m_max(f.y, FLM.y);   // the orbital integrals see the raised tail
+      }
+      const T to = L.grp ? f.x + f.y : T(0);
+      so = so + V2<T>{dfm * (sig * sig), dfm} * to;
+      if (L.grp && (tb.LBIWBK || m == NFRE - 1)) *reinterpret_cast<V2<T>*>(tFw + m * RS) = f;
+    }
+    fkmean_finish(s0, s1, s2, EMEAN, FMEAN, F1MEAN, AKMEAN, XKMEAN);
+    so = v4_allsum<G, T>(so, L.rot);
+    if (L.grp && j == 0) { c[C_UORBT] = tb.EPSMIN + so.x; c[C_AORB] = tb.EPSMIN + so.y; c[C_EMEAN] = EMEAN; c[C_F1MEAN] = F1MEAN; }
+  }
+  WSYNC();
+  V4_PHASE_EXIT(202);
+  T UFRIC = c[C_UFRIC], Z0M = c[C_Z0M];
+
+  auto femws_finish = [&](V2<T> wse, V2<T> wslast, T& FM, T& EMW) {
+    const V2<T> s = v4_allsum<G, T>(L.grp ? V2<T>{wse.x, wse.y} : z2, L.rot);
+    const T t2 = v4_allsum<G, T>(L.grp ? V2<T>{wslast.x + wslast.y, T(0)} : z2, L.rot).x;
+    const T em = tb.EPSMIN + s.x + DELT25 * t2;
+    const T fm = tb.EPSMIN + s.y + (tb.FRTAIL * tb.DELTH) * t2;
+    FM = em / fm;
+    EMW = em;
+  };
+  auto frcutindex4 = [&](T FMEANWS, T UF) -> int {   // frcutindex.F90:84-97
+    const T FPMH = tb.TAILFACTOR / tb.FR[0];
+    const T FPPM = tb.TAILFACTOR_PM * tb.G / (tb.FRIC * tb.ZPIFR[0]);
+    int MIJ = NFRE;
+    if (CICOVER <= tb.CITHRSH_TAIL) {
+      const T FPM4 = m_max(m_max(FMEANWS, FMEAN) * FPMH, FPPM / m_max(UF, tb.EPSMIN));
+      MIJ = m_nint(m_log10(FPM4) * tb.FLOGSPRDM1) + 1;
+      MIJ = MIJ < 1 ? 1 : (MIJ > NFRE ? NFRE : MIJ);
+    }
+    return MIJ;
+  };
+  auto rrh = [&](int m, int MIJ) -> T {   // RHOWGDFTH(M), zero above MIJ, halved at MIJ (frcutindex.F90:98-107)
+    T r = T(0);
+    if (m + 1 <= MIJ) {
+      r = tb.RHOWG_DFIM[m];
+      if (m + 1 == MIJ && MIJ != NFRE) r = T(0.5) * r;
+    }
+    return r;
+  };
+  T rX[NS], rY[NS], rS[NS];
+  // stress sums below the cut-off and the F(:,MIJ) integrals of TAU_PHI_HF (stresso.F90:148-173, tau_phi_hf.F90:170-196)
+  auto post_stress = [&](int MIJ, V2<T> apl, bool phiwa) {
+    V2<T> s = z2;
+    T sp = T(0);
+    if (L.grp) {
+#pragma unroll
+      for (int q = 0; q < NS; q++) {
+        const int m = q * G + j;
+        const T w = rrh(m, MIJ);
+        const T wx = w * L.fac[m * V4_NFAC + F4_CINV];
+        s = s + V2<T>{wx * rX[q], wx * rY[q]};
+        sp += w * rS[q];
+      }
+    }
+    s = v4_allsum<G, T>(s, L.rot);
+    T PH = T(0);
+    if (phiwa) PH = v4_allsum<G, T>(L.grp ? V2<T>{apl.x + apl.y + sp, T(0)} : z2, L.rot).x;
+    const V2<T> fm = L.grp ? *reinterpret_cast<const V2<T>*>(tF + (MIJ - 1) * RS) : z2;
+    const V2<T> fc2 = fm * cpos * cpos, fc3 = fc2 * cpos;
+    const V2<T> h = v4_allsum<G, T>(V2<T>{fc3.x + fc3.y, fc2.x + fc2.y}, L.rot);
+    if (L.grp && j == 0) {
+      c[C_XS] = s.x; c[C_YS] = s.y; c[C_F1DCOS3] = tb.DELTH * h.x; c[C_F1DCOS2] = tb.DELTH * h.y; c[C_F1DSIN2] = T(0); c[C_F1D] = T(0);
+      c[C_MIJ] = (T)MIJ;
+      if (phiwa) c[C_PHIWA] = PH;
+    }
+  };
+
+  // ---- first SINFLX call (sinflx.F90:105-183): MIJ and the wave stress only
+  unsigned long long xm0, xm1;
+  V2<T> wse, wslast, apl;
+  T FMEANWS, EMW;
+  v4_sinput<T, NANG, PP, 1, false>(tb, L, UFRIC, Z0M, RAORW, T(0), T(0), T(0), T(0), sinwd, coswd, nullptr, xm0, xm1, wse, wslast, apl, rX, rY, rS);
+  femws_finish(wse, wslast, FMEANWS, EMW);
+  int MIJ = frcutindex4(FMEANWS, UFRIC);
+  post_stress(MIJ, apl, false);
+  WSYNC();
+  V4_PHASE_EXIT(203);
+  // ---- stage 2: STRESSO scalars, second TAUT_Z0, WSIGSTAR, swell set-up, SDIWBK
+  v4_stresso<T, PP, false>(tb, sSC, lane, false);
+  WSYNC();
+  if (lane < PP) {
+    T* q = sSC + lane * NSC;
+    T UF = q[C_UFRIC], Z0 = q[C_Z0M], Z0Bv = q[C_Z0B], CH = q[C_CHRNCK];
+    taut_z0_c(tb, 1, q[C_WSWAVE], q[C_COSWD] * q[C_TWCOS] + q[C_SINWD] * q[C_TWSIN], q[C_TAUW], UF, Z0, Z0Bv, CH);
+    q[C_UFRIC] = UF; q[C_Z0M] = Z0; q[C_Z0B] = Z0Bv; q[C_CHRNCK] = CH;
+    q[C_SIGN] = wsigstar(tb, q[C_WSWAVE], UF, Z0, q[C_WSTAR]);
+    swell_setup_pt(tb, q);
+    q[C_SDS] = sdiwbk_pt(tb, q[C_EMAXDPT], q[C_EMEAN], q[C_F1MEAN], q[C_DEPTH]);
+  }
+  WSYNC();
+  UFRIC = c[C_UFRIC]; Z0M = c[C_Z0M];
+  const T SDS = c[C_SDS];
+  V4_PHASE_EXIT(204);
+  // ---- second SINFLX call: wind-input coefficient (parked in the point's XLLWS block, [M][K]), XLLWS, MIJ, wave stress, PHIWA
+  T* gx = xllws + (size_t)ij * N + 2 * j;   // this lane's pair in row 0 of the block
+  v4_sinput<T, NANG, PP, 2, true>(tb, L, UFRIC, Z0M, RAORW, c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], sinwd, coswd, gx, xm0, xm1, wse,
+                                  wslast, apl, rX, rY, rS);
+  femws_finish(wse, wslast, FMEANWS, EMW);
+  MIJ = frcutindex4(FMEANWS, UFRIC);
+  post_stress(MIJ, apl, true);
+  WSYNC();
+  V4_PHASE_EXIT(205);
+  // ---- stage 3: STRESSO of the second call (TAUW, TAUWDIR, PHIWA)
+  v4_stresso<T, PP, false>(tb, sSC, lane, true);
+  WSYNC();
+  V4_PHASE_EXIT(206);
+
+  // ---- SDISSIP + SNONLIN + update sweep (implsch.F90:262-392)
+  V2<T> a_t = z2, a_x = z2;
+  {
+    T ENHFR = m_max(T(0.75) * DEPTH * AKMEAN, T(0.5));
+    ENHFR = T(1) + (T(5.5) / ENHFR) * (T(1) - T(0.833) * ENHFR) * m_exp(-T(1.25) * ENHFR);
+    const int MFR1STFR = -tb.MFRSTLW + 1;
+    const int MFRLSTFR = NFRE - tb.KFRH + MFR1STFR;
+    const T DAL1 = tb.DAL1, DAL2 = tb.DAL2;
+    T wt[NTAP];   // SATWEIGHTS depend on the tap only (checked by ecwam_hip_create): wave-uniform
+#pragma unroll
+    for (int t = 0; t < NTAP; t++) wt[t] = tb.SATWEIGHTS[t][NANG / 2];
+    const T TMP03 = T(1) / (tb.SDSBR * tb.MICHE), SSDSC4 = tb.SSDSC4;
+    const T c2 = tb.SSDSC2 * tb.SSDSC6, c2m1 = tb.SSDSC2 * (T(1) - tb.SSDSC6);
+    const bool turb = tb.SSDSC5 != T(0);
+    const T FACTURB = turb ? (T(2) * tb.SSDSC5 / tb.G) * RAORW * UFRIC * UFRIC : T(0);
+    const T DELT = (T)tb.IDELT, DELTM = T(1) / DELT, DELT5 = tb.XIMP * DELT;
+    const bool shallow_brk = tb.LBIWBK && (DEPTH < T(50));
+    const T USFM = UFRIC * m_max(FMEANWS, FMEAN);
+    const bool flux_snl = tb.LCFLX && tb.LWVFLX_SNL;
+    T* st0 = sStg;            // staging rows: up / AD, vp / DELAM, um / DELAP, vm
+    T* st1 = sStg + RS;
+    T* st2 = sStg + 2 * RS;
+    T* st3 = sStg + 3 * RS;
+
+    V2<T> aS[8], aF[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { aS[i] = z2; aF[i] = z2; }
+    // wind-input rows (parked in the XLLWS block by the second SINFLX call) come back through a ring of eight prefetched rows:
+    // slot jj holds row MCb + jj - 4 while block MCb is processed and is refilled with row MCb + jj + 4 as soon as it is consumed
+    V2<T> wiq[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int mr = i - 4 < 0 ? i + 4 : i - 4;   // rows 4..7 in slots 0..3 (block 0 updates rows -4..3: slots 4..7 hold rows 0..3)
+      wiq[i] = (L.act && mr < NFRE) ? *reinterpret_cast<const V2<T>*>(gx + (size_t)mr * NANG) : z2;
+    }
+    for (int MCb = 0; MCb < tb.MLSTHG + 4; MCb += 8) {
+#pragma unroll
+      for (int jj = 0; jj < 8; jj++) {
+        const int MC = MCb + 1 + jj;
+        const int c0 = (1 + jj) & 7, cm = (1 + jj + 4) & 7, cm1 = (1 + jj + 5) & 7, cp = (1 + jj + 2) & 7, cp1 = (1 + jj + 3) & 7;
+        if (MC <= tb.MLSTHG) {
+          const int IC = tb.INLCOEF[MC - 1][0], IP = tb.INLCOEF[MC - 1][1], IP1 = tb.INLCOEF[MC - 1][2];
+          const int IM = tb.INLCOEF[MC - 1][3], IM1 = tb.INLCOEF[MC - 1][4];
+          const T* R = tb.RNLCOEF[MC - 1];
+          const T FTAIL = R[0], GW1 = R[1], GW2 = R[2], GW3 = R[3], GW4 = R[4];
+          const T FKLAMPA = R[5], FKLAMPB = R[6], FKLAMP2 = R[7], FKLAMP1 = R[8];
+          const T FKLAPA2 = R[9], FKLAPB2 = R[10], FKLAP12 = R[11], FKLAP22 = R[12];
+          const T GW5 = R[13], GW6 = R[14], GW7 = R[15], GW8 = R[16];
+          const T FKLAMMA = R[17], FKLAMMB = R[18], FKLAMM2 = R[19], FKLAMM1 = R[20];
+          const T FKLAMA2 = R[21], FKLAMB2 = R[22], FKLAM12 = R[23], FKLAM22 = R[24];
+          const T FTEMP = tb.AF11[MC - 1] * ENHFR;
+          const bool mid = (MC > MFR1STFR && MC < MFRLSTFR);
+          const V2<T> fIP = *reinterpret_cast<const V2<T>*>(tF + IP * RS), fIP1 = *reinterpret_cast<const V2<T>*>(tF + IP1 * RS);
+          const V2<T> fIM = *reinterpret_cast<const V2<T>*>(tF + IM * RS), fIM1 = *reinterpret_cast<const V2<T>*>(tF + IM1 * RS);
+          V2<T> FIJ = *reinterpret_cast<const V2<T>*>(tF + IC * RS);
+          if (!mid) FIJ = FIJ * FTAIL;
+          // frequency-interpolated rows of the + and - quadruplet legs, staged for the rotated reads (snonlin.F90:236-262)
+          const V2<T> up = GW1 * fIP + GW3 * fIP1, vp = GW2 * fIP + GW4 * fIP1;
+          const V2<T> um = GW5 * fIM + GW7 * fIM1, vm = GW6 * fIM + GW8 * fIM1;
+          if (L.grp) {
+            *reinterpret_cast<V2<T>*>(st0 + L.own) = up; *reinterpret_cast<V2<T>*>(st1 + L.own) = vp;
+            *reinterpret_cast<V2<T>*>(st2 + L.own) = um; *reinterpret_cast<V2<T>*>(st3 + L.own) = vm;
+          }
+          WSYNC();
+          V2<T> SAPk[2], SAMk[2];
+          // kh = 0: K1 = K - R1, K11 = K - R1 - 1, K2 = K + R2, K21 = K + R2 + 1; kh = 1 mirrored
+          SAPk[0] = (R1 == 0 ? up : v4_at<T, NSH, -R1>(st0, sh)) + v4_at<T, NSH, -(R1 + 1)>(st1, sh);
+          SAMk[0] = v4_at<T, NSH, R2>(st2, sh) + v4_at<T, NSH, R2 + 1>(st3, sh);
+          SAPk[1] = (R1 == 0 ? up : v4_at<T, NSH, R1>(st0, sh)) + v4_at<T, NSH, R1 + 1>(st1, sh);
+          SAMk[1] = v4_at<T, NSH, -R2>(st2, sh) + v4_at<T, NSH, -(R2 + 1)>(st3, sh);
+          WSYNC();
+          const V2<T> FCEN = FTEMP * FIJ;
+#pragma unroll
+          for (int kh = 0; kh < 2; kh++) {
+            const V2<T> SAP = SAPk[kh], SAM = SAMk[kh];
+            V2<T> FAD1 = FIJ * (SAP + SAM);
+            const V2<T> FAD2 = FAD1 - T(2) * SAP * SAM;
+            FAD1 = FAD1 + FAD2;
+            const V2<T> AD = FAD2 * FCEN;
+            const V2<T> DELAD = FAD1 * FTEMP;
+            const V2<T> DELAP = (FIJ - T(2) * SAM) * DAL1 * FCEN;
+            const V2<T> DELAM = (FIJ - T(2) * SAP) * DAL2 * FCEN;
+            if (L.grp) {
+              *reinterpret_cast<V2<T>*>(st0 + L.own) = AD; *reinterpret_cast<V2<T>*>(st1 + L.own) = DELAM;
+              *reinterpret_cast<V2<T>*>(st2 + L.own) = DELAP;
+            }
+            WSYNC();
+            V2<T> A2, A2s, A1, A1s, D2, D2s, P1, P1s;
+            if (kh == 0) {
+              A2 = v4_at<T, NSH, -R2>(st0, sh); A2s = v4_at<T, NSH, -(R2 + 1)>(st0, sh);
+              A1 = (R1 == 0) ? AD : v4_at<T, NSH, R1>(st0, sh); A1s = v4_at<T, NSH, R1 + 1>(st0, sh);
+              D2 = v4_at<T, NSH, -R2>(st1, sh); D2s = v4_at<T, NSH, -(R2 + 1)>(st1, sh);
+              P1 = (R1 == 0) ? DELAP : v4_at<T, NSH, R1>(st2, sh); P1s = v4_at<T, NSH, R1 + 1>(st2, sh);
+            } else {
+              A2 = v4_at<T, NSH, R2>(st0, sh); A2s = v4_at<T, NSH, R2 + 1>(st0, sh);
+              A1 = (R1 == 0) ? AD : v4_at<T, NSH, -R1>(st0, sh); A1s = v4_at<T, NSH, -(R1 + 1)>(st0, sh);
+              D2 = v4_at<T, NSH, R2>(st1, sh); D2s = v4_at<T, NSH, R2 + 1>(st1, sh);
+              P1 = (R1 == 0) ? DELAP : v4_at<T, NSH, -R1>(st2, sh); P1s = v4_at<T, NSH, -(R1 + 1)>(st2, sh);
+            }
+            WSYNC();
+            aS[c0] -= T(2) * AD;
+            aF[c0] -= T(2) * DELAD;
+            aS[cm] += A2 * FKLAMM1 + A2s * FKLAMM2;
+            aF[cm] += D2 * FKLAM12 + D2s * FKLAM22;
+            aS[cm1] += A2 * FKLAMMA + A2s * FKLAMMB;
+            aF[cm1] += D2 * FKLAMA2 + D2s * FKLAMB2;
+            aS[cp] += A1 * FKLAMP1 + A1s * FKLAMP2;
+            aF[cp] += P1 * FKLAP12 + P1s * FKLAP22;
+            aS[cp1] += A1 * FKLAMPA + A1s * FKLAMPB;
+            aF[cp1] += P1 * FKLAPA2 + P1s * FKLAPB2;
+          }
+        }
+        const int m = MC - 5;  // 0-based row MC-4: no later interaction reads or feeds it
+        if (m >= 0 && m < NFRE) {
+          const T* row = sT + m * RS;
+          const T* fa = L.fac + m * V4_NFAC;
+          // dissipation coefficient of the row (sdissip_ard.F90:117-314), from the not yet updated row: element e = F(2j - 2 NSH + e)
+          T el[4 * NSH + 2];
+#pragma unroll
+          for (int i = 0; i <= 2 * NSH; i++) {
+            const V2<T> v = *reinterpret_cast<const V2<T>*>(row + sh[i]);
+            el[2 * i] = v.x; el[2 * i + 1] = v.y;
+          }
+          const V2<T> f = {el[2 * NSH], el[2 * NSH + 1]};
+          V2<T> bsat = z2;
+#pragma unroll
+          for (int t = 0; t < NTAP; t++) {
+            bsat.x += wt[t] * el[2 * NSH - NH + t];
+            bsat.y += wt[t] * el[2 * NSH - NH + t + 1];
+          }
+          bsat = bsat * fa[F4_BSC];
+          const T bm = v4_allmax<G, T>(L.grp ? m_max(bsat.x, bsat.y) : T(0), L.rot);
+          const T sig = lane_get(L.rZPIFR, m);
+          const T d0 = m_max(T(0), bm * TMP03 - SSDSC4);
+          const V2<T> t1 = bsat * TMP03 - SSDSC4;
+          const V2<T> d1 = {m_max(T(0), t1.x), m_max(T(0), t1.y)};
+          V2<T> D = (c2 * sig) * (d0 * d0) + (c2m1 * sig) * (d1 * d1);
+          if (turb) D = D - (sig * fa[F4_WAVNUM] * FACTURB) * coswdif;
+          const V2<T> wi = wiq[jj];   // wind input of the second SINFLX call
+          const V2<T> fldw = D + wi;
+          V2<T> sl = fldw * f + aS[cm];
+          V2<T> fld = fldw + aF[cm];
+          V2<T> ss = z2;
+          if (flux_snl) {
+            const V2<T> den = {m_max(T(1) - DELT5 * fld.x, T(1)), m_max(T(1) - DELT5 * fld.y, T(1))};
+            ss = V2<T>{f_div(sl.x, den.x), f_div(sl.y, den.y)};
+          }
+          if (shallow_brk && m < tb.NFRE_RED) { sl = sl - SDS * f; fld = fld - SDS; }
+          if (m < tb.NFRE_RED) { const T sbo = fa[F4_SBO]; sl = sl + sbo * f; fld = fld + sbo; }
+          const T lim = USFM * (lane_get(L.rCOFRM4, m) * DELT), flmax = lane_get(L.rFLMAX, m);
+          V2<T> fn;
+          {
+            const T G0 = f_div(DELT * sl.x, m_max(T(1) - DELT5 * fld.x, T(1))), G1 = f_div(DELT * sl.y, m_max(T(1) - DELT5 * fld.y, T(1)));
+            fn.x = m_max(f.x + m_sign(m_min(m_abs(G0), lim), G0), FLM.x);
+            fn.y = m_max(f.y + m_sign(m_min(m_abs(G1), lim), G1), FLM.y);
+          }
+          ss.x = ss.x + DELTM * m_min(flmax - fn.x, T(0));
+          ss.y = ss.y + DELTM * m_min(flmax - fn.y, T(0));
+          fn.x = m_min(fn.x, flmax); fn.y = m_min(fn.y, flmax);
+          WSYNC();
+          if (L.grp) *reinterpret_cast<V2<T>*>(tFw + m * RS) = fn;
+          T rh = T(0);   // RHOWGDFTH(M) (frcutindex.F90:98-107); MIJ differs between the points of the wave
+          if (m + 1 <= MIJ) { rh = lane_get(L.rRHOWG, m); if (m + 1 == MIJ && MIJ != NFRE) rh = T(0.5) * rh; }
+          a_t = a_t + rh * ss;
+          a_x = a_x + (fa[F4_CINV] * rh) * ss;
+        }
+        aS[cm] = z2;
+        aF[cm] = z2;
+        {
+          const int mn = MC - 5 + 8;
+          if (mn >= 0 && mn < NFRE && L.act) wiq[jj] = *reinterpret_cast<const V2<T>*>(gx + (size_t)mn * NANG);
+        }
+        WSYNC();
+      }
+    }
+  }
+  WSYNC();
+  V4_PHASE_EXIT(207);
+  const T TAUW = c[C_TAUW], TAUWDIR = c[C_TAUWDIR], PHIWA = c[C_PHIWA], Z0B = c[C_Z0B], CHRNCK = c[C_CHRNCK];
+
+  // ---- WNFLUXES (wnfluxes.F90:147-330), LWNEMOCOU = F
+  T TAUXD = T(0), TAUYD = T(0), TAUOCXD = T(0), TAUOCYD = T(0), TAUOC = T(0), PHIOCD = T(0), PHIEPS = T(0), PHIAW = T(0);
+  if (tb.LCFLX) {
+    const V2<T> sx = a_x * L.sinth, sy = a_x * L.costh;
+    const V2<T> r0 = v4_allsum<G, T>(L.grp ? V2<T>{a_t.x + a_t.y, sx.x + sx.y} : z2, L.rot);
+    const T YSTRESS = v4_allsum<G, T>(L.grp ? V2<T>{sy.x + sy.y, T(0)} : z2, L.rot).x;
+    const T PHILF = r0.x, XSTRESS = r0.y;
+    const T EPSUS3 = tb.EPSUS * m_sqrt(tb.EPSUS);
+    T OOVAL = T(1), USTAR = UFRIC;
+    if (tb.LICERUN && tb.LWAMRSETCI && CICOVER > tb.CIBLOCK) {
+      OOVAL = m_exp(-m_min(m_pow4(CICOVER * (T(1) / m_max(tb.CITHRSH, T(0.01)))), T(10)));
+      const T U10P = m_max(WSWAVE, tb.EPSU10);
+      const T CD_BULK = m_min((T(1.03E-3) + T(0.04E-3) * m_pow(U10P, T(1.48))) * m_pow(U10P, T(-0.21)), T(0.003));
+      const T CD_WAVE = (UFRIC / U10P) * (UFRIC / U10P);
+      const T CD_ICE = OOVAL * CD_WAVE + (T(1) - OOVAL) * CD_BULK;
+      USTAR = m_max(m_sqrt(CD_ICE) * U10P, tb.EPSUS);
+    }
+    const T TAU = AIRD * m_max(USTAR * USTAR, tb.EPSUS);
+    TAUXD = TAU * sinwd;
+    TAUYD = TAU * coswd;
+    TAUOCXD = TAUXD - OOVAL * XSTRESS;
+    TAUOCYD = TAUYD - OOVAL * YSTRESS;
+    const T TAUO = m_sqrt(TAUOCXD * TAUOCXD + TAUOCYD * TAUOCYD);
+    TAUOC = m_min(m_max(TAUO / TAU, tb.TAUOCMIN), tb.TAUOCMAX);
+    const T USTRA = ffa[(size_t)ij * ECWAM_HIP_NFF + 5], VSTRA = ffa[(size_t)ij * ECWAM_HIP_NFF + 6];
+    if (tb.LWCOUAST && (USTRA != T(0) || VSTRA != T(0))) { TAUXD = USTRA; TAUOCXD = USTRA * TAUOC; TAUYD = VSTRA; TAUOCYD = VSTRA * TAUOC; }
+    const T XN = AIRD * m_max(USTAR * USTAR * USTAR, EPSUS3);
+    PHIOCD = OOVAL * (PHILF - PHIWA) + (T(1) - OOVAL) * T(-3.75) * XN;
+    PHIEPS = m_min(m_max(PHIOCD / XN, tb.PHIEPSMIN), tb.PHIEPSMAX);
+    PHIOCD = PHIEPS * XN;
+    PHIAW = OOVAL * PHIWA / XN + (T(1) - OOVAL) * T(3.75);
+  }
+
+  // ---- second FKMEAN / FEMEANWS, IMPHFTAIL, SETICE, STOKESDRIFT (implsch.F90:422-462)
+  fkmean4(EMEAN, FMEAN, F1MEAN, AKMEAN, XKMEAN);
+  T EMEANWS;
+  {
+    V2<T> we = z2, wl = z2;
+    for (int m = 0; m < NFRE; m++) {
+      const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
+      const V2<T> x = {((xm0 >> m) & 1ull) ? f.x : T(0), ((xm1 >> m) & 1ull) ? f.y : T(0)};
+      we = we + V2<T>{lane_get(L.rDFIM, m), lane_get(L.rDFIMOFR, m)} * (x.x + x.y);
+      wl = x;
+    }
+    femws_finish(we, wl, FMEANWS, EMEANWS);
+  }
+  if (L.grp) {  // imphftail.F90: TEMP2(M) / TEMP1 = (XK2CG WAVNUM)(MIJ) / (XK2CG WAVNUM)(M)
+    const T B1 = L.fac[(MIJ - 1) * V4_NFAC + F4_BSC];
+    const V2<T> tf = *reinterpret_cast<const V2<T>*>(tF + (MIJ - 1) * RS);
+    for (int m = MIJ; m < NFRE; m++) {
+      const T tm = B1 / L.fac[m * V4_NFAC + F4_BSC];
+      *reinterpret_cast<V2<T>*>(tFw + m * RS) = V2<T>{m_max(tm * tf.x, FLM.x), m_max(tm * tf.y, FLM.y)};
+    }
+  }
+  if (tb.LICERUN && tb.LMASKICE && L.grp) {  // setice.F90:67-86
+    T CIREDUC, ICEFREE;
+    if (CICOVER > tb.CITHRSH) { CIREDUC = m_max(tb.EPSMIN, T(1) - CICOVER); ICEFREE = T(0); }
+    else { CIREDUC = T(0); ICEFREE = T(1); }
+    const V2<T> add = (CIREDUC * tb.FLMIN) * (cpos * cpos);
+    for (int m = 0; m < NFRE; m++) *reinterpret_cast<V2<T>*>(tFw + m * RS) = *reinterpret_cast<const V2<T>*>(tF + m * RS) * ICEFREE + add;
+  }
+  T USTOKES, VSTOKES;
+  {  // stokesdrift.F90:89-142
+    const int MO = tb.NFRE_ODD;
+    const T fo = tb.FR[MO - 1];
+    const T CONST = T(2) * tb.DELTH * (tb.ZPI * tb.ZPI * tb.ZPI) / tb.G * m_pow4(fo);
+    const T* stk = wvprpt + (size_t)ij * ECWAM_HIP_NWPR * NFRE + 4 * NFRE;   // STOKFAC(M) of the point (same address in its G lanes)
+    V2<T> a = z2;
+    for (int m = 0; m < MO; m++) a = a + (stk[m] * tb.DFIM_SIM[m]) * *reinterpret_cast<const V2<T>*>(tF + m * RS);
+    a = a + CONST * *reinterpret_cast<const V2<T>*>(tF + (MO - 1) * RS);
+    const V2<T> ax = a * L.sinth, ay = a * L.costh;
+    const V2<T> s = v4_allsum<G, T>(L.grp ? V2<T>{ax.x + ax.y, ay.x + ay.y} : z2, L.rot);
+    USTOKES = s.x; VSTOKES = s.y;
+    if (tb.LICERUN && tb.LWAMRSETCI && CICOVER > tb.CITHRSH) {
+      USTOKES = T(0.016) * WSWAVE * sinwd * (T(1) - CICOVER);
+      VSTOKES = T(0.016) * WSWAVE * coswd * (T(1) - CICOVER);
+    }
+    USTOKES = m_min(m_max(USTOKES, T(-1.5)), T(1.5));
+    VSTOKES = m_min(m_max(VSTOKES, T(-1.5)), T(1.5));
+  }
+  WSYNC();
+  // ---- store FL1 (16-byte chunks gathered from VEC rows of the tile), XLLWS(K,M) from the bit masks, per-point scalars
+  {
+    constexpr int NV = N / VEC;
+    const float rnv = 1.0f / (float)NV, rnf = 1.0f / (float)(NFRE / VEC);
+    for (int v = lane; v < n * NV; v += 64) {
+      const int pq = (int)(((float)v + 0.5f) * rnv);
+      const int w = v - pq * NV;
+      const int k = (int)(((float)w + 0.5f) * rnf);
+      const int m0 = (w - k * (NFRE / VEC)) * VEC;
+      const T* d = sT + m0 * RS + pq * NANG + k;
+      VT val;
+#pragma unroll
+      for (int i = 0; i < VEC; i++) val[i] = d[i * RS];
+      *reinterpret_cast<VT*>(fl1 + (size_t)(ij0 + pq) * N + (size_t)w * VEC) = val;
+    }
+  }
+  if (L.act) {   // every wind-input row parked in this block has been read by now
+    T* x0 = xllws + (size_t)ij * N + (size_t)(2 * j) * NFRE;   // rows K = 2j and 2j+1 are contiguous
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+      const unsigned long long xm = h ? xm1 : xm0;
+      for (int m = 0; m < NFRE; m += VEC) {
+        VT val;
+#pragma unroll
+        for (int i = 0; i < VEC; i++) val[i] = ((xm >> (m + i)) & 1ull) ? T(1) : T(0);
+        *reinterpret_cast<VT*>(x0 + h * NFRE + m) = val;
+      }
+    }
+  }
+  if (L.act && j == 0) {
+    T* fo = ffa + (size_t)ij * ECWAM_HIP_NFF;
+    fo[7] = UFRIC; fo[8] = TAUW; fo[9] = TAUWDIR; fo[10] = Z0M; fo[11] = Z0B; fo[12] = CHRNCK;
+    T* io = intfa + (size_t)ij * ECWAM_HIP_NINTF;
+    io[2] = USTOKES; io[3] = VSTOKES;
+    if (tb.LCFLX) {
+      io[5] = TAUXD; io[6] = TAUYD; io[7] = TAUOCXD; io[8] = TAUOCYD; io[9] = TAUOC; io[10] = T(0); io[11] = T(0);
+      io[12] = PHIOCD; io[13] = PHIEPS; io[14] = PHIAW;
+    }
+    if (tb.LWFLUX) {
+      io[0] = (EMEANWS < tb.WSEMEAN_MIN) ? tb.WSEMEAN_MIN : EMEANWS;
+      io[1] = (EMEANWS < tb.WSEMEAN_MIN) ? T(2) * tb.FR[NFRE - 1] : FMEANWS;
+    }
+    mij_out[ij] = MIJ;
+  }
+}

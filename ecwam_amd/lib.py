@@ -57,7 +57,7 @@ class TablePtrs(C.Structure):
 
 
 EXPORTS = ["ecwam_hip_last_error", "ecwam_hip_abi_version", "ecwam_hip_selftest", "ecwam_hip_create", "ecwam_hip_destroy", "ecwam_hip_set_obstructions", "ecwam_hip_propags2",
-           "ecwam_hip_ctuw", "ecwam_hip_propags2_otf", "ecwam_hip_propags2_otf_split", "ecwam_hip_copy_freq_range", "ecwam_hip_propdot", "ecwam_hip_ctuw_refra", "ecwam_hip_propags2_refra", "ecwam_hip_implsch", "ecwam_hip_outbs", "ecwam_hip_snonlin3", "ecwam_hip_sinput3", "ecwam_hip_sdissip3", "ecwam_hip_outwnorm", "ecwam_hip_newwind", "ecwam_hip_chunks_to_points",
+           "ecwam_hip_ctuw", "ecwam_hip_propags2_otf", "ecwam_hip_propags2_otf_split", "ecwam_hip_copy_freq_range", "ecwam_hip_propdot", "ecwam_hip_ctuw_refra", "ecwam_hip_propags2_refra", "ecwam_hip_implsch", "ecwam_hip_set_implsch_generation", "ecwam_hip_outbs", "ecwam_hip_snonlin3", "ecwam_hip_sinput3", "ecwam_hip_sdissip3", "ecwam_hip_outwnorm", "ecwam_hip_newwind", "ecwam_hip_chunks_to_points",
            "ecwam_hip_points_to_chunks", "ecwam_hip_pack_rows", "ecwam_hip_unpack_rows", "ecwam_hip_malloc", "ecwam_hip_free",
            "ecwam_hip_memcpy_h2d", "ecwam_hip_memcpy_d2h", "ecwam_hip_memset", "ecwam_hip_sync"]
 
@@ -97,6 +97,7 @@ def load() -> C.CDLL:
     lib.ecwam_hip_ctuw_refra.argtypes = [vp, ci, ci, ci, cd, ci, ci, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp]
     lib.ecwam_hip_propags2_refra.argtypes = [vp, vp, vp, ci, ci, cd, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     lib.ecwam_hip_implsch.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ecwam_hip_set_implsch_generation.argtypes = [vp, ci]
     lib.ecwam_hip_outbs.argtypes = [vp, ci, ci, vp, cd, vp, vp]
     lib.ecwam_hip_snonlin3.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, vp]
     lib.ecwam_hip_sinput3.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp]

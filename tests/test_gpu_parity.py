@@ -5,9 +5,12 @@ seeded inputs.  Tolerances (stated per the north star "within a stated floating-
            and libm differ); MIJ and XLLWS identical.
   single : discrete decisions (MIJ = NINT(..), XLLWS = [ZLOG<0]) may flip at isolated points when a reduction that
            the kernel sums in wavefront order lands within 1 ulp of a threshold; such points are counted (<= 0.5 %)
-           and excluded from the bin-wise check.  On the rest: spectral bins within 1e-4 of the point's spectral
-           peak, significant wave height within 1e-5, forcing outputs within 1e-4, flux outputs within 5e-3 of the
-           field scale (they are differences of nearly cancelling integrals).
+           and excluded from the bin-wise check.  On the rest: spectral bins within 5e-6 of the point's spectral
+           peak (observed 8e-7), significant wave height within 1e-6 (the reference's own relative_tolerance for single
+           precision, tests/etopo1_oper_an_fc_O48.yml; observed 4e-7), forcing outputs within 5e-5 (observed 8e-6), flux
+           outputs within 1e-3 of the field scale (observed 1.3e-4: they are differences of nearly cancelling integrals);
+           bins off by more than 1e-5 of their own value: below 0.5 % of all bins (observed 0.12 %, all of them
+           at the noise floor, 1e-10 of the peak).
 """
 import numpy as np
 import pytest
@@ -27,6 +30,23 @@ def api():
     from ecwam_amd import api as _api
 
     return _api
+
+
+def _assert_implsch_stats(st, n, prec, flip_budget=0.005):
+    """Gates of every IMPLSCH parity test.  dp: 1e-10 (observed 1e-15..1e-13).  sp: thresholds ~10x the observed errors (spectra
+    8e-7 of the peak, swh 4e-7, forcing 8e-6, fluxes 1.3e-4), the reference's own swh tolerance 1e-6
+    (tests/etopo1_oper_an_fc_O48.yml relative_tolerance), and SURVEY H4: bins off by more than 1e-5 of their own value stay below
+    0.5 % of all bins (the noise-floor bins, 1e-10 of the peak, are where that happens)."""
+    if prec == "dp":
+        assert st["mij_flips"] == 0 and st["xllws_bins_diff"] == 0, st
+        assert st["fl1_max_rel_peak_all"] < 1e-10 and st["swh_max_rel"] < 1e-12, st
+        assert st["ff_max_rel_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
+        assert st["fl1_frac_bins_gt_1e-5"] == 0.0 and st["fl1_max_rel_bin_clean"] < 1e-9, st
+    else:
+        assert st["mij_flips"] <= n * flip_budget and st["xllws_pts_diff"] <= n * flip_budget, st
+        assert st["fl1_max_rel_peak_clean"] < 5e-6 and st["swh_max_rel"] < 1e-6, st
+        assert st["ff_max_rel_clean"] < 5e-5 and st["intf_max_rel_clean"] < 1e-3, st
+        assert st["fl1_frac_bins_gt_1e-5"] < 5e-3, st
 
 
 def _oracle(cfg, prec):
@@ -52,30 +72,25 @@ def test_implsch_parity(api, nang, nred, prec, llnormagam):
     _implsch_parity(api, nang, nred, prec, llnormagam)
 
 
-def test_implsch_parity_second_generation_kernel(api, monkeypatch):
-    """36 directions / single precision / flag set A runs the three-points-per-wavefront kernel (k_implsch3) by default; the
-    one-point-per-wavefront kernel (k_implsch2: every other configuration) stays checked on that configuration too."""
-    monkeypatch.setenv("ECWAM_HIP_IMPLSCH_V3", "0")
-    _implsch_parity(api, 36, 36, "sp", False)
+@pytest.mark.parametrize("nang,nred,prec,gen", [(36, 36, "sp", 2), (36, 36, "sp", 3), (36, 36, "dp", 2), (24, 29, "sp", 2), (12, 25, "dp", 2)])
+def test_implsch_parity_older_kernel_generations(api, nang, nred, prec, gen):
+    """Flag set A runs the fourth kernel generation (k_implsch4: several points per wavefront on adjacent direction pairs) by
+    default; the one-point-per-wavefront kernel (k_implsch2: every other configuration) and k_implsch3 stay checked on those
+    configurations too (ecwam_hip_set_implsch_generation caps the choice)."""
+    _implsch_parity(api, nang, nred, prec, False, gen=gen)
 
 
-def _implsch_parity(api, nang, nred, prec, llnormagam):
+def _implsch_parity(api, nang, nred, prec, llnormagam, gen=0):
     cfg = Config(nang=nang, nfre=36, nfre_red=nred, llnormagam=llnormagam)
     n = 1537  # ragged: not a multiple of the 4 waves per block
     case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=777)
     ref = H.oracle_implsch(case, _oracle(cfg, prec))
     ctx = api.HipContext(case["tables"])
+    ctx.set_implsch_generation(gen)
     got = H.gpu_implsch(case, ctx)
     st = H.compare_implsch(ref, got, case["tables"])
     assert np.isfinite(got["FL1"]).all() and np.isfinite(got["FF"]).all() and np.isfinite(got["INTF"]).all()
-    if prec == "dp":
-        assert st["mij_flips"] == 0 and st["xllws_bins_diff"] == 0, st
-        assert st["fl1_max_rel_peak_all"] < 1e-10 and st["swh_max_rel"] < 1e-12, st
-        assert st["ff_max_rel_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
-    else:
-        assert st["mij_flips"] <= n * 0.005 and st["xllws_pts_diff"] <= n * 0.005, st
-        assert st["fl1_max_rel_peak_clean"] < 1e-4 and st["swh_max_rel"] < 1e-5, st
-        assert st["ff_max_rel_clean"] < 1e-4 and st["intf_max_rel_clean"] < 5e-3, st
+    _assert_implsch_stats(st, n, prec)
     ctx.close()
 
 
@@ -93,14 +108,7 @@ def test_implsch_parity_flag_set_b(api, nang, nred, prec):
     ctx.close()
     n = 1536
     assert np.isfinite(got["FL1"]).all() and np.isfinite(got["FF"]).all() and np.isfinite(got["INTF"]).all()
-    if prec == "dp":
-        assert st["mij_flips"] == 0 and st["xllws_bins_diff"] == 0, st
-        assert st["fl1_max_rel_peak_all"] < 1e-10 and st["swh_max_rel"] < 1e-12, st
-        assert st["ff_max_rel_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
-    else:
-        assert st["mij_flips"] <= n * 0.005 and st["xllws_pts_diff"] <= n * 0.005, st
-        assert st["fl1_max_rel_peak_clean"] < 1e-4 and st["swh_max_rel"] < 1e-5, st
-        assert st["ff_max_rel_clean"] < 1e-4 and st["intf_max_rel_clean"] < 5e-3, st
+    _assert_implsch_stats(st, n, prec)
 
 
 @pytest.mark.parametrize("prec", ["dp", "sp"])
@@ -121,14 +129,7 @@ def test_implsch_parity_sea_ice_attenuation(api, prec, flags):
     st = H.compare_implsch(ref, got, case["tables"])
     ctx.close()
     assert np.isfinite(got["FL1"]).all() and np.isfinite(got["INTF"]).all()
-    if prec == "dp":
-        assert st["mij_flips"] == 0 and st["xllws_bins_diff"] == 0, st
-        assert st["fl1_max_rel_peak_all"] < 1e-10 and st["swh_max_rel"] < 1e-12, st
-        assert st["ff_max_rel_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
-    else:
-        assert st["mij_flips"] <= n * 0.005 and st["xllws_pts_diff"] <= n * 0.005, st
-        assert st["fl1_max_rel_peak_clean"] < 1e-4 and st["swh_max_rel"] < 1e-5, st
-        assert st["ff_max_rel_clean"] < 1e-4 and st["intf_max_rel_clean"] < 5e-3, st
+    _assert_implsch_stats(st, n, prec)
     # the attenuation must actually have acted: the same case without the flags gives a different answer
     cfg0 = Config(nang=24, nfre=36, nfre_red=29, lmaskice=flags.get("lmaskice", True))
     case0 = dict(case); case0["cfg"] = cfg0
@@ -165,14 +166,7 @@ def test_implsch_parity_sdice1_and_ice_breakup(api, prec, flags):
     st = H.compare_implsch(ref, got, case["tables"])
     ctx.close()
     assert np.isfinite(got["FL1"]).all() and np.isfinite(got["INTF"]).all()
-    if prec == "dp":
-        assert st["mij_flips"] == 0 and st["xllws_bins_diff"] == 0, st
-        assert st["fl1_max_rel_peak_all"] < 1e-10 and st["swh_max_rel"] < 1e-12, st
-        assert st["ff_max_rel_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
-    else:
-        assert st["mij_flips"] <= n * 0.005 and st["xllws_pts_diff"] <= n * 0.005, st
-        assert st["fl1_max_rel_peak_clean"] < 1e-4 and st["swh_max_rel"] < 1e-5, st
-        assert st["ff_max_rel_clean"] < 1e-4 and st["intf_max_rel_clean"] < 5e-3, st
+    _assert_implsch_stats(st, n, prec)
     # the options act: without SDICE1 / with solid ice everywhere the oracle answers differently
     dt = H.np_dtype(prec)
     f0 = {k: v for k, v in flags.items() if k != "lciwa1"}
@@ -238,8 +232,8 @@ def test_implsch_parity_iphys_0(api, prec, llnormagam):
         assert st["fl1_max_rel_peak_all"] < 1e-10 and st["ff_max_rel_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
     else:
         assert st["mij_flips"] <= n * 0.005 and st["xllws_pts_diff"] <= n * 0.005, st
-        assert st["fl1_max_rel_peak_clean"] < 1e-4 and st["swh_max_rel"] < 1e-5, st
-        assert st["ff_max_rel_clean"] < 1e-4 and st["intf_max_rel_clean"] < 5e-3, st
+        assert st["fl1_max_rel_peak_clean"] < 5e-6 and st["swh_max_rel"] < 1e-6, st
+        assert st["ff_max_rel_clean"] < 5e-5 and st["intf_max_rel_clean"] < 1e-3, st
 
 
 @pytest.mark.parametrize("prec", ["dp", "sp"])
@@ -267,7 +261,7 @@ def test_implsch_parity_isnonlin_1_2(api, prec, isnonlin):
     if prec == "dp":
         assert st["mij_flips"] == 0 and st["fl1_max_rel_peak_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
     else:
-        assert st["mij_flips"] <= n * 0.005 and st["fl1_max_rel_peak_clean"] < 1e-4 and st["swh_max_rel"] < 1e-5, st
+        assert st["mij_flips"] <= n * 0.005 and st["fl1_max_rel_peak_clean"] < 5e-6 and st["swh_max_rel"] < 1e-6, st
     cfg0 = Config(nang=24, nfre=36, nfre_red=29)
     c0 = dict(case); c0["cfg"] = cfg0; c0["tables"] = Tables(cfg0, dt)
     r0 = H.oracle_implsch(c0, _oracle(cfg0, prec))
@@ -325,7 +319,7 @@ def test_implsch_fluxes_without_the_nonlinear_transfer(api, prec):
     if prec == "dp":
         assert st["mij_flips"] == 0 and st["fl1_max_rel_peak_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
     else:
-        assert st["mij_flips"] <= n * 0.005 and st["fl1_max_rel_peak_clean"] < 1e-4 and st["intf_max_rel_clean"] < 5e-3, st
+        assert st["mij_flips"] <= n * 0.005 and st["fl1_max_rel_peak_clean"] < 5e-6 and st["intf_max_rel_clean"] < 1e-3, st
     cfg1 = Config(nang=24, nfre=36, nfre_red=29)
     c1 = dict(case); c1["cfg"] = cfg1; c1["tables"] = Tables(cfg1, H.np_dtype(prec))
     r1 = H.oracle_implsch(c1, _oracle(cfg1, prec))
@@ -543,8 +537,8 @@ def test_implsch_parity_friction_velocity_forcing(api, prec, flags):
     if prec == "dp":
         assert st["mij_flips"] == 0 and st["fl1_max_rel_peak_all"] < 1e-10 and st["ff_max_rel_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
     else:
-        assert st["mij_flips"] <= n * 0.005 and st["fl1_max_rel_peak_clean"] < 1e-4 and st["swh_max_rel"] < 1e-5, st
-        assert st["ff_max_rel_clean"] < 1e-4 and st["intf_max_rel_clean"] < 5e-3, st
+        assert st["mij_flips"] <= n * 0.005 and st["fl1_max_rel_peak_clean"] < 5e-6 and st["swh_max_rel"] < 1e-6, st
+        assert st["ff_max_rel_clean"] < 5e-5 and st["intf_max_rel_clean"] < 1e-3, st
     # NEWWIND, friction-velocity branch
     rng = np.random.default_rng(1)
     ff = rng.uniform(0.05, 1.0, (n, 16)).astype(dt)
@@ -796,7 +790,7 @@ def test_implsch_three_tile_fallback_kernel(api, prec, monkeypatch):
     if prec == "dp":
         assert st["mij_flips"] == 0 and st["fl1_max_rel_peak_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
     else:
-        assert st["mij_flips"] <= 3 and st["fl1_max_rel_peak_clean"] < 1e-4 and st["swh_max_rel"] < 1e-5, st
+        assert st["mij_flips"] <= 3 and st["fl1_max_rel_peak_clean"] < 5e-6 and st["swh_max_rel"] < 1e-6, st
 
 
 @pytest.mark.parametrize("prec", ["dp", "sp"])
@@ -813,7 +807,7 @@ def test_implsch_parity_48_directions(api, prec):
     if prec == "dp":
         assert st["mij_flips"] == 0 and st["fl1_max_rel_peak_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
     else:
-        assert st["mij_flips"] <= 2 and st["fl1_max_rel_peak_clean"] < 1e-4 and st["swh_max_rel"] < 1e-5, st
+        assert st["mij_flips"] <= 2 and st["fl1_max_rel_peak_clean"] < 5e-6 and st["swh_max_rel"] < 1e-6, st
 
 
 def test_snonlin_three_points_per_wavefront_layout(api):
@@ -945,24 +939,26 @@ def test_sdissip_three_points_per_wavefront_layout(api):
     ctx.close()
 
 
-def test_implsch_kernel_generations_agree(api, monkeypatch):
-    """k_implsch3 (three points per wavefront, the default for 36 directions / single precision / flag set A) against k_implsch2 on
-    the same inputs, with a point count that leaves a short last wavefront: MIJ and XLLWS identical, spectra within 5e-5 of the
-    point's spectral peak (observed 1.5e-5; each is within 1e-4 of the oracle), forcing outputs within 5e-5 of their scale (both sum in wavefront order, in different groupings)."""
+def test_implsch_kernel_generations_agree(api):
+    """k_implsch4 (the default on flag set A) against k_implsch3 and k_implsch2 on the same inputs, with a point count that leaves a
+    short last wavefront in either layout: MIJ and XLLWS identical, spectra within 5e-6 of the point's spectral peak (observed
+    1.5e-6), forcing outputs within 5e-5 of their scale (all three sum in wavefront order, in different groupings)."""
     cfg = Config(nang=36, nfre=36, nfre_red=36)
     n = 4 * 1024 + 1
     case = H.make_point_case(n, cfg, "sp", spectra="mixed", seed=2024)
     out = {}
-    for gen in ("0", "1"):
-        monkeypatch.setenv("ECWAM_HIP_IMPLSCH_V3", gen)
-        ctx = api.HipContext(case["tables"])
+    ctx = api.HipContext(case["tables"])
+    for gen in (2, 3, 4):
+        ctx.set_implsch_generation(gen)
         out[gen] = H.gpu_implsch(case, ctx)
-        ctx.close()
-    a, b = out["0"], out["1"]
-    assert np.array_equal(a["MIJ"], b["MIJ"]) and np.array_equal(a["XLLWS"], b["XLLWS"])
-    peak = np.abs(a["FL1"]).max(axis=(1, 2), keepdims=True).astype(float)
-    assert np.max(np.abs(a["FL1"].astype(float) - b["FL1"].astype(float)) / peak) < 5e-5
-    ffs = np.abs(a["FF"]).max(axis=0, keepdims=True).astype(float) + 1e-30
-    assert np.max(np.abs(a["FF"].astype(float) - b["FF"].astype(float)) / ffs) < 5e-5
-    st = H.compare_implsch(a, b, case["tables"])
-    assert st["intf_max_rel_all"] < 5e-3, st
+    ctx.close()
+    b = out[4]
+    for gen in (2, 3):
+        a = out[gen]
+        assert np.array_equal(a["MIJ"], b["MIJ"]) and np.array_equal(a["XLLWS"], b["XLLWS"]), gen
+        peak = np.abs(a["FL1"]).max(axis=(1, 2), keepdims=True).astype(float)
+        assert np.max(np.abs(a["FL1"].astype(float) - b["FL1"].astype(float)) / peak) < 5e-6, gen
+        ffs = np.abs(a["FF"]).max(axis=0, keepdims=True).astype(float) + 1e-30
+        assert np.max(np.abs(a["FF"].astype(float) - b["FF"].astype(float)) / ffs) < 5e-5, gen
+        st = H.compare_implsch(a, b, case["tables"])
+        assert st["intf_max_rel_all"] < 5e-3, (gen, st)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# diagnostics: arbitrary PMC sets on the IMPLSCH profiling driver.  usage: PMC="A B C" [N=32768] [PREC=sp] bash tools/pmc_run.sh
+# diagnostics: arbitrary PMC sets on the IMPLSCH profiling driver.  usage: PMC="A B C" [N=32768] [PREC=sp] [GEN=0|2|3|4] bash tools/pmc_run.sh
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-N=${N:-32768}; PREC=${PREC:-sp}; TAG=${TAG:-x}
+N=${N:-32768}; PREC=${PREC:-sp}; TAG=${TAG:-x}; GEN=${GEN:-0}
 rm -rf gpurun_out/pmc_$TAG
-rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d gpurun_out/pmc_$TAG -- python3 tools/prof_implsch.py $PREC $N > /dev/null 2>&1
+rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d gpurun_out/pmc_$TAG -- python3 tools/prof_implsch.py $PREC $N $GEN > /dev/null 2>&1
 python3 - <<PY
 import csv,glob,collections
 f=glob.glob('gpurun_out/pmc_$TAG/*/*counter_collection.csv')[0]

@@ -17,6 +17,8 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 131072
 cfg = Config(nang=36, nfre=36, nfre_red=36, idelt=450, idelpro=450)
 case = H.make_point_case(4096, cfg, prec, spectra="mixed")
 ctx = api.HipContext(case["tables"])
+if len(sys.argv) > 3:
+    ctx.set_implsch_generation(int(sys.argv[3]))
 dev = ctx.device
 wv, ff, intf = H.pack_device_inputs(case)
 rep = n // 4096

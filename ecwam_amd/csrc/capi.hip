@@ -60,7 +60,7 @@ template <typename T>
 static void v4_probe(const DevTab<T>& h, ecwam_hip_ctx* c) {
   c->v4_ok = 0;
   const int NANG = h.NANG;
-  if (!h.DIA_PULL || (NANG & 1) || h.NFRE != 36) return;
+  if (!h.DIA_PULL || !h.V4_ROWS || (NANG & 1) || h.NFRE != 36) return;
   const int r1 = (NANG - h.K1W[0][0]) % NANG, r2 = h.K2W[0][0];
   if (h.D11[0] != -1 || h.D21[0] != 1 || h.D11[1] != 1 || h.D21[1] != -1) return;
   if (h.K1W[1][0] != r1 % NANG || h.K2W[1][0] != (NANG - r2) % NANG) return;
@@ -71,6 +71,8 @@ static void v4_probe(const DevTab<T>& h, ecwam_hip_ctx* c) {
     for (int k = 0; k < NANG; k++) {
       const T d = h.SATWEIGHTS[t][k] - h.SATWEIGHTS[t][NANG / 2];
       if ((d < 0 ? -d : d) > T(16) * eps * wmax) return;
+      const T e = h.SATWEIGHTS[t][NANG / 2] - h.SATWEIGHTS[h.NTAP - 1 - t][NANG / 2];   // symmetric about the centre tap
+      if ((e < 0 ? -e : e) > T(16) * eps * wmax) return;
       if (h.INDICESSAT[t][k] != ((k - h.NSDSNTH + t) % NANG + NANG) % NANG) return;
     }
   c->v4_r1 = r1; c->v4_r2 = r2; c->v4_nh = h.NSDSNTH; c->v4_ok = 1;
@@ -158,6 +160,19 @@ static int build_tab(const ecwam_hip_params* p, const ecwam_hip_tables* t, DevTa
   for (int i = 0; i < ML; i++) {
     for (int j = 0; j < 5; j++) d->INLCOEF[i][j] = t->inlcoef[i * 5 + j] - 1;
     for (int j = 0; j < 25; j++) d->RNLCOEF[i][j] = ((const T*)t->rnlcoef)[i * 25 + j];
+  }
+  d->V4_ROWS = 1;
+  for (int i = 0; i < ML; i++) {
+    // gather set (words 0..11): FTAIL, GW1..GW8, AF11; scatter set (words 12..27): FKLAMPA .. FKLAP22, FKLAMMA .. FKLAM22
+    for (int j = 0; j < 32; j++) d->DIACF[i][j] = T(0);
+    d->DIACF[i][0] = d->RNLCOEF[i][0];
+    for (int j = 0; j < 4; j++) { d->DIACF[i][1 + j] = d->RNLCOEF[i][1 + j]; d->DIACF[i][5 + j] = d->RNLCOEF[i][13 + j]; }
+    d->DIACF[i][9] = d->AF11[i];
+    for (int j = 0; j < 8; j++) { d->DIACF[i][12 + j] = d->RNLCOEF[i][5 + j]; d->DIACF[i][20 + j] = d->RNLCOEF[i][17 + j]; }
+    const int MC = i + 1;
+    auto cl = [&](int r) { return (r < 1 ? 1 : (r > NFRE ? NFRE : r)) - 1; };
+    const int want[5] = {cl(MC), cl(MC + 2), cl(MC + 3), cl(MC - 4), cl(MC - 3)};
+    for (int j = 0; j < 5; j++) if (d->INLCOEF[i][j] != want[j]) d->V4_ROWS = 0;
   }
   const int ntap = 2 * p->nsdsnth + 1;
   for (int k = 0; k < NANG; k++)

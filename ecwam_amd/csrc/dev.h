@@ -59,6 +59,11 @@ struct DevTab {
   int IK1[2][MAXA], IK2[2][MAXA], D11[2], D21[2], DIA_PULL;
   int INLCOEF[MAXMC][5];                                         // 0-based frequency
   T RNLCOEF[MAXMC][25];
+  // k_implsch4: one 32-word record per interaction frequency, read with 16-byte loads: words 0..11 the gather set (FTAIL, GW1..GW8,
+  // AF11, 2 spare), words 12..27 the scatter set (RNLCOEF(6:13), RNLCOEF(18:25)); V4_ROWS = 1 when INLCOEF equals the clamped
+  // MC, MC+2, MC+3, MC-4, MC-3
+  alignas(16) T DIACF[MAXMC][32];
+  int V4_ROWS;
   // saturation filter: [k2][k] so that lanes (k) read consecutive words
   int INDICESSAT[MAXTAP][MAXA];  // 0-based direction
   T SATWEIGHTS[MAXTAP][MAXA];

@@ -14,8 +14,12 @@
 //     two halves of a pair and compiles for double precision as it stands).
 //   * the tile is [M][point][K] (K fastest, natural order): the coalesced load / store are 16-byte global accesses with the
 //     (K, M) transposition done by four 4-byte LDS accesses at immediate offsets -- 5 instead of 45 vector instructions per element.
-//   * the row integrals of SINPUT live in registers of the lane that owns the frequency (no LDS table), the SINPUT factor
-//     LOG(WAVNUM Z0M) shares the factor table: 20 424 B of LDS per wave (sp, NANG = 36): 8 waves per CU as before, the limit.
+//   * the row integrals of SINPUT live in registers of the lane that owns the frequency (no LDS table); the planes SQRT(WAVNUM) and
+//     LOG(WAVNUM Z0M) of the factor table double as staging rows during the sweep: 20 424 B of LDS per wave (sp, NANG = 36), 8 waves
+//     per CU as before -- the limit: 24 sea points per CU is what 160 KB hold.
+//   * with two waves per SIMD a wave issues one instruction per ~5.3 cycles whatever its kind, and a third of its life was spent in
+//     s_waitcnt: the sweep is software-pipelined (three LDS round trips per interaction frequency instead of eight, see there),
+//     scalar loads are gone from it (their lgkmcnt is shared with the LDS and returns out of order), no store is predicated.
 // The lane-per-point scalar stages (TAUT_Z0, STRESSO / TAU_PHI_HF, WSIGSTAR, swell set-up, SDIWBK) are those of implsch_v2.h.
 #pragma once
 
@@ -27,8 +31,10 @@
 #define V4_PHASE_EXIT(k) do { } while (0)
 #endif
 #define V4_NSTG 4
-#define V4_NFAC 6
-enum { F4_WAVNUM = 0, F4_CINV, F4_BSC, F4_SQ, F4_SBO, F4_ZCN };   // F4_BSC = WAVNUM XK2CG / 2 pi, F4_SQ = SQRT(WAVNUM), F4_ZCN = LOG(WAVNUM Z0M)
+#define V4_NFAC 6   // words per (point, frequency) of the factor table: [M][4] BSC, SBO, CINV, WAVNUM + the planes SQ and ZCN
+
+#define V4SYNC() WSYNC()
+#define V4_WPE_MIN(T) (sizeof(T) == 4 ? 2 : 1)
 
 template <typename T>
 using V2 = T __attribute__((ext_vector_type(2)));
@@ -92,16 +98,26 @@ __device__ __forceinline__ void v4_stresso(const DevTab<T>& tb, T* sSC, int lane
 template <typename T, int NANG_, int PP_>
 struct V4Ctx {
   int lane, p, j;
-  bool grp, act;
-  T* tile;      // row 0 of the wave's tile [M][point][K]
-  int own;      // p NANG + 2j: the lane's pair inside a row
-  T* fac;       // factor table of the point [M][V4_NFAC]
-  T* c;         // scalars of the point [NSC]
+  T* tile;        // row 0 of the wave's tile [M][point][K]
+  int own;        // p NANG + 2j: the lane's pair inside a row
+  T* fac4;        // [M][4] of the point: BSC, SBO, CINV, WAVNUM
+  T* sq;          // [M] SQRT(WAVNUM)
+  T* zcn;         // [M] LOG(WAVNUM Z0M) of the current SINFLX call
+  T* c;           // scalars of the point [NSC]
   V4Rot rot;
   V2<T> sinth, costh;
   // module tables per frequency, lane m holds M = m+1: broadcast with v_readlane inside the M loops
   T rDFIM, rDFIMOFR, rDFIMFR, rZPIFR, rRHOWG, rCOFRM4, rFLMAX, rC5;   // rC5 = -SWELLF5 2 SQRT(2 NU_AIR SIG) (sinput_ard.F90:343)
 };
+enum { Q4_BSC = 0, Q4_SBO, Q4_CINV, Q4_WAVNUM };   // Q4_BSC = WAVNUM XK2CG / 2 pi
+
+// a VGPR that holds zero without the compiler knowing: added to a wave-uniform address it turns the load into a vector load
+// (vmcnt, registers usable as VALU operands) instead of a scalar load (lgkmcnt shared with the LDS, out of order)
+__device__ __forceinline__ int v4_opaque_zero() {
+  int z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  return z;
+}
 
 // SINPUT_ARD (sinput_ard.F90:153-520) for one SINFLX call.  Outputs: XLLWS masks of the two directions of the lane (bit m), the row
 // integrals X, Y, S of the frequencies the lane owns (m = s G + j), the FEMEANWS integrands (wse: x = SUM DFIM F, y = SUM DFIMOFR F
@@ -116,8 +132,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
   const T CONST1 = tb.BETAMAXOXKAPPA2, ABS_TAUWSHELTER = m_abs(tb.TAUWSHELTER);
   const T FU = m_abs(tb.SWELLF3), FUD = tb.SWELLF2, ROGOROAIR = tb.G / RAORW;
   const T AVG = T(1) / T(NGST);
-  if (L.grp)
-    for (int m = L.j; m < NFRE; m += G) L.fac[m * V4_NFAC + F4_ZCN] = m_log(L.fac[m * V4_NFAC + F4_WAVNUM] * Z0M);
+  for (int m = L.j; m < NFRE; m += G) L.zcn[m] = m_log(L.fac4[m * 4 + Q4_WAVNUM] * Z0M);
   WSYNC();
   const T XKAPPA = tb.XKAPPA, ZALP = tb.ZALP;
   T USTP[2], XSTRESS[2] = {T(0), T(0)}, YSTRESS[2] = {T(0), T(0)}, TAUX[2], TAUY[2];
@@ -135,15 +150,24 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
 #pragma unroll
   for (int s = 0; s < NS; s++) { rX[s] = T(0); rY[s] = T(0); rS[s] = T(0); }
   const T* tF = L.tile + L.own;
+  // operands of the next row are read one row ahead (the row itself, CINV / WAVNUM, LOG(WAVNUM Z0M))
+  V2<T> f_n = *reinterpret_cast<const V2<T>*>(tF);
+  V2<T> cw_n = *reinterpret_cast<const V2<T>*>(L.fac4 + Q4_CINV);
+  T zcn_n = L.zcn[0];
   for (int m = 0; m < NFRE; m++) {
+    const V2<T> f = f_n, cw = cw_n;
+    const T ZCN = zcn_n, cinv_m = cw.x;
+    {
+      const int mn = m + 1 < NFRE ? m + 1 : m;
+      f_n = *reinterpret_cast<const V2<T>*>(tF + mn * RS);
+      cw_n = *reinterpret_cast<const V2<T>*>(L.fac4 + mn * 4 + Q4_CINV);
+      zcn_n = L.zcn[mn];
+    }
     const T SIGm = lane_get(L.rZPIFR, m);
-    const T* fa = L.fac + m * V4_NFAC;
-    const T ZCN = fa[F4_ZCN], cinv_m = fa[F4_CINV];
     const T CONSTF = ROGOROAIR * cinv_m * lane_get(L.rDFIM, m);
-    const T DSTAB1 = LLSNEG ? (lane_get(L.rC5, m) * AIRD_PVISC) * fa[F4_WAVNUM] : T(0);
+    const T DSTAB1 = LLSNEG ? (lane_get(L.rC5, m) * AIRD_PVISC) * cw.y : T(0);
     const T CNSN = (SIGm * CONST1) * RAORW;
     const T TEMP1 = LLSNEG ? (-tb.SWELLF * T(16) * (SIGm * SIGm) / tb.G) * RAORW : T(0);
-    const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
     V2<T> SLP[2], FLP[2];
     bool xl0 = false, xl1 = false;
 #pragma unroll
@@ -192,14 +216,14 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
     if (anygrow) {
 #pragma unroll
       for (int ig = 0; ig < NGST; ig++) {
-        const V2<T> sx = L.grp ? SLP[ig] * L.sinth : z2, sy = L.grp ? SLP[ig] * L.costh : z2;
+        const V2<T> sx = SLP[ig] * L.sinth, sy = SLP[ig] * L.costh;
         const V2<T> xs = v4_allsum<G, T>(V2<T>{sx.x + sx.y, sy.x + sy.y}, L.rot);
         XSTRESS[ig] = XSTRESS[ig] + CONSTF * xs.x;
         YSTRESS[ig] = YSTRESS[ig] + CONSTF * xs.y;
         xrow += xs.x;
         yrow += xs.y;
       }
-      if (LLSNEG) srow = v4_allsum<G, T>(L.grp ? V2<T>{sp.x + sp.y, T(0)} : z2, L.rot).x;
+      if (LLSNEG) srow = v4_allsum<G, T>(V2<T>{sp.x + sp.y, T(0)}, L.rot).x;
       xrow = AVG * xrow; yrow = AVG * yrow;
     }
     {  // the lane that owns frequency m keeps its row integrals
@@ -215,7 +239,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
     }
     if (LLSNEG) {
       apl = apl + (fl * f - sp) * lane_get(L.rRHOWG, m);
-      if (L.act) *reinterpret_cast<V2<T>*>(gfl + (size_t)m * NANG) = fl;
+      *reinterpret_cast<V2<T>*>(gfl + (size_t)m * NANG) = fl;
     }
     if (xl0) xm0 |= (1ull << m);
     if (xl1) xm1 |= (1ull << m);
@@ -226,40 +250,44 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
   WSYNC();
 }
 
+// One wavefront advances PP sea points.  Lanes beyond PP G shadow lanes of point 0 and the points of a short last wave shadow its
+// last point: shadows run the same instructions on the same data, so their LDS and global stores repeat their original's values
+// at the same addresses -- no store is predicated.
 template <typename T, int NANG, int PP, int R1, int R2, int NH>
-// at most 256 VGPRs: the double-precision instantiations otherwise take 340+ registers (AGPRs as spill space) and that build returned
-// wrong WNFLUXES sums on gfx950 / ROCm 7.2 (tools/implsch_gens.py; -O1 and the 256-register build agree with the oracle to 1e-13)
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// single precision: two waves per SIMD (LDS: 8 waves per CU), at most 256 VGPRs; double precision: the LDS holds one wave per SIMD
+// (40 KB per wave) and the kernel may use the whole register file (340 registers: no scratch)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(V4_WPE_MIN(T), 2)))
 k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__ fl1, const T* __restrict__ wvprpt, T* __restrict__ ffa,
            T* __restrict__ intfa, int* __restrict__ mij_out, T* __restrict__ xllws) {
   constexpr int G = NANG / 2, NFRE = V4_NFRE, N = NANG * NFRE, RS = PP * NANG, NS = NFRE / G;
   constexpr int NSH = (NH + 1) / 2;          // even shifts -2 NSH .. 2 NSH cover the taps -NH .. NH+1 and the DIA rotations
   constexpr int NTAP = 2 * NH + 1;
   constexpr int VEC = 16 / (int)sizeof(T);   // elements per 16-byte global access
-  static_assert(PP * G <= 64 && NFRE % G == 0 && NFRE % VEC == 0 && R2 + 2 <= 2 * NSH + 1, "layout");
+  constexpr int NC = NFRE / VEC;             // 16-byte chunks per direction
+  static_assert(PP * G <= 64 && NFRE % G == 0 && NFRE % VEC == 0 && R2 + 2 <= 2 * NSH + 1 && PP * NFRE >= RS, "layout");
   typedef T VT __attribute__((ext_vector_type(VEC)));
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const DevTab<T>& tb = *tp;
   T* sT = reinterpret_cast<T*>(smem_raw);          // [NFRE + V4_NSTG][PP][NANG]
-  T* sStg = sT + NFRE * RS;                        // the staging rows
-  T* sFac = sT + (NFRE + V4_NSTG) * RS;            // [PP][NFRE][V4_NFAC]
-  T* sSC = sFac + PP * NFRE * V4_NFAC;             // [PP][NSC]
+  T* sStg = sT + NFRE * RS;                        // staging rows 0..3
+  T* sFac4 = sT + (NFRE + V4_NSTG) * RS;           // [PP][NFRE][4]
+  T* sPl = sFac4 + PP * NFRE * 4;                  // [2][PP][NFRE]: SQRT(WAVNUM), LOG(WAVNUM Z0M); staging rows 4, 5 during the sweep
+  T* sSC = sPl + 2 * PP * NFRE;                    // [PP][NSC]
   V4Ctx<T, NANG, PP> L;
   L.lane = threadIdx.x & 63;
   const int lane = L.lane;
-  const int pl = lane / G;
-  L.grp = pl < PP;
-  L.p = L.grp ? pl : 0;                            // spare lanes shadow point 0 (reads only)
-  L.j = lane - pl * G;
-  if (!L.grp) L.j = lane - PP * G < G ? lane - PP * G : 0;
+  {
+    const int pl = lane / G;
+    L.p = pl < PP ? pl : 0;                        // spare lanes shadow point 0
+    L.j = lane - pl * G;
+  }
   const int p = L.p, j = L.j;
   const int ij0 = kijs + blockIdx.x * PP;
   if (ij0 >= kijl) return;
   const int n = kijl - ij0 < PP ? kijl - ij0 : PP;   // points of this wave; a short last wave replicates its last point
-  L.act = L.grp && p < n;
   const int ij = ij0 + (p < n ? p : n - 1);
   L.tile = sT; L.own = p * NANG + 2 * j;
-  L.fac = sFac + p * NFRE * V4_NFAC; L.c = sSC + p * NSC;
+  L.fac4 = sFac4 + p * NFRE * 4; L.sq = sPl + p * NFRE; L.zcn = sPl + (PP + p) * NFRE; L.c = sSC + p * NSC;
   int sh[2 * NSH + 1];
 #pragma unroll
   for (int i = 0; i <= 2 * NSH; i++) {
@@ -288,19 +316,33 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   const T* tF = sT + L.own;        // the lane's pair in row 0
   T* tFw = sT + L.own;
 
-  // ---- spectra F[ij][K][M] -> tile [M][point][K]: 16-byte global loads, the VEC frequencies of a chunk go to VEC rows
+  // ---- spectra F[ij][K][M] -> tile [M][point][K]: 16-byte global loads (chunk w of a point = direction w / NC, frequencies
+  //      VEC (w % NC) ..), the VEC frequencies of a chunk go to VEC rows; all the loads are issued before the first LDS store
   {
-    constexpr int NV = N / VEC;             // chunks per point
-    const float rnv = 1.0f / (float)NV, rnf = 1.0f / (float)(NFRE / VEC);
-    for (int v = lane; v < PP * NV; v += 64) {
-      const int pq = (int)(((float)v + 0.5f) * rnv);       // v / NV (exact for these sizes)
-      const int w = v - pq * NV;
-      const int k = (int)(((float)w + 0.5f) * rnf);         // w / (NFRE / VEC)
-      const int m0 = (w - k * (NFRE / VEC)) * VEC;
-      const VT val = *reinterpret_cast<const VT*>(fl1 + (size_t)(ij0 + (pq < n ? pq : n - 1)) * N + (size_t)w * VEC);
-      T* d = sT + m0 * RS + pq * NANG + k;
+    constexpr int NV = N / VEC, NIT = (NV + 63) / 64;   // chunks per point, iterations per point
+    VT val[PP][NIT];
 #pragma unroll
-      for (int i = 0; i < VEC; i++) d[i * RS] = val[i];
+    for (int q = 0; q < PP; q++) {
+      const T* g = fl1 + (size_t)(ij0 + (q < n ? q : n - 1)) * N;
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int w = lane + 64 * it;
+        if (w < NV) val[q][it] = *reinterpret_cast<const VT*>(g + (size_t)w * VEC);
+      }
+    }
+    int k = lane / NC, r = lane - k * NC;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int w = lane + 64 * it;
+      if (w < NV) {
+        T* d = sT + (r * VEC) * RS + k;
+#pragma unroll
+        for (int q = 0; q < PP; q++)
+#pragma unroll
+          for (int i = 0; i < VEC; i++) d[i * RS + q * NANG] = val[q][it][i];
+      }
+      k += 64 / NC; r += 64 % NC;
+      if (r >= NC) { r -= NC; k += 1; }
     }
   }
   // ---- point scalars + first TAUT_Z0, one lane per point (sinflx.F90:105-122)
@@ -320,16 +362,16 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     q[C_SPARE] = ff[2];   // CICOVER
   }
   // ---- per-frequency factors of the point: lane j fills M = j+1, j+1+G, ...
-  if (L.grp) {
-    const T* wp = wvprpt + (size_t)ij * ECWAM_HIP_NWPR * NFRE;
+  const T* wp = wvprpt + (size_t)ij * ECWAM_HIP_NWPR * NFRE;
+  {
     const T DEPTHv = ffa[(size_t)ij * ECWAM_HIP_NFF + 15];
     for (int m = j; m < NFRE; m += G) {
-      T* f = L.fac + m * V4_NFAC;
+      T* f = L.fac4 + m * 4;
       const T WAVNUM = wp[m], XK2CG = wp[3 * NFRE + m];
-      f[F4_WAVNUM] = WAVNUM; f[F4_CINV] = wp[2 * NFRE + m]; f[F4_BSC] = WAVNUM * (T(1) / tb.ZPI) * XK2CG; f[F4_SQ] = m_sqrt(WAVNUM);
+      f[Q4_WAVNUM] = WAVNUM; f[Q4_CINV] = wp[2 * NFRE + m]; f[Q4_BSC] = WAVNUM * (T(1) / tb.ZPI) * XK2CG; L.sq[m] = m_sqrt(WAVNUM);
       T sbo = T(0);   // sbottom.F90:79-89
       if (m < tb.NFRE_RED && DEPTHv < tb.BATHYMAX) sbo = (-T(2) * T(0.038) * tb.GM1) * WAVNUM / m_sinh(m_min(T(2) * DEPTHv * WAVNUM, T(50)));
-      f[F4_SBO] = sbo;
+      f[Q4_SBO] = sbo;
     }
   }
   WSYNC();
@@ -363,8 +405,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     V2<T> s0 = z2, s1 = z2, s2 = z2;   // (EM, FM), (F1, AK), (XK, last row)
     for (int m = 0; m < NFRE; m++) {
       const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
-      const T t = L.grp ? f.x + f.y : T(0);
-      const T dfm = lane_get(L.rDFIM, m), sqm = L.fac[m * V4_NFAC + F4_SQ];
+      const T t = f.x + f.y;
+      const T dfm = lane_get(L.rDFIM, m), sqm = L.sq[m];
       s0 = s0 + V2<T>{dfm, lane_get(L.rDFIMOFR, m)} * t;
       s1 = s1 + V2<T>{lane_get(L.rDFIMFR, m), dfm / sqm} * t;
       s2.x = s2.x + (sqm * dfm) * t;
@@ -382,7 +424,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       V2<T> s = z2;
       for (int m = 0; m < NFRE; m++) {
         const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
-        const T t = L.grp ? f.x + f.y : T(0);
+        const T t = f.x + f.y;
         s.x = s.x + lane_get(L.rDFIM, m) * t;
         if (m == NFRE - 1) s.y = t;
       }
@@ -394,8 +436,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     for (int m = 0; m < NFRE; m++) {
       V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
       if (tb.LBIWBK) { f = f * sc; f.x = m_max(f.x, tb.EPSMIN); f.y = m_max(f.y, tb.EPSMIN); }
-      const T t = L.grp ? f.x + f.y : T(0);
-      const T dfm = lane_get(L.rDFIM, m), sqm = L.fac[m * V4_NFAC + F4_SQ], sig = lane_get(L.rZPIFR, m);
+      const T t = f.x + f.y;
+      const T dfm = lane_get(L.rDFIM, m), sqm = L.sq[m], sig = lane_get(L.rZPIFR, m);
       s0 = s0 + V2<T>{dfm, lane_get(L.rDFIMOFR, m)} * t;
       s1 = s1 + V2<T>{lane_get(L.rDFIMFR, m), dfm / sqm} * t;
       s2.x = s2.x + (sqm * dfm) * t;
@@ -403,21 +445,21 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         s2.y = t;
         f.x = m_max(f.x, FLM.x); f.y = m_max(f.y, FLM.y);   // the orbital integrals see the raised tail
       }
-      const T to = L.grp ? f.x + f.y : T(0);
+      const T to = f.x + f.y;
       so = so + V2<T>{dfm * (sig * sig), dfm} * to;
-      if (L.grp && (tb.LBIWBK || m == NFRE - 1)) *reinterpret_cast<V2<T>*>(tFw + m * RS) = f;
+      if (tb.LBIWBK || m == NFRE - 1) *reinterpret_cast<V2<T>*>(tFw + m * RS) = f;
     }
     fkmean_finish(s0, s1, s2, EMEAN, FMEAN, F1MEAN, AKMEAN, XKMEAN);
     so = v4_allsum<G, T>(so, L.rot);
-    if (L.grp && j == 0) { c[C_UORBT] = tb.EPSMIN + so.x; c[C_AORB] = tb.EPSMIN + so.y; c[C_EMEAN] = EMEAN; c[C_F1MEAN] = F1MEAN; }
+    if (j == 0) { c[C_UORBT] = tb.EPSMIN + so.x; c[C_AORB] = tb.EPSMIN + so.y; c[C_EMEAN] = EMEAN; c[C_F1MEAN] = F1MEAN; }
   }
   WSYNC();
   V4_PHASE_EXIT(202);
   T UFRIC = c[C_UFRIC], Z0M = c[C_Z0M];
 
   auto femws_finish = [&](V2<T> wse, V2<T> wslast, T& FM, T& EMW) {
-    const V2<T> s = v4_allsum<G, T>(L.grp ? V2<T>{wse.x, wse.y} : z2, L.rot);
-    const T t2 = v4_allsum<G, T>(L.grp ? V2<T>{wslast.x + wslast.y, T(0)} : z2, L.rot).x;
+    const V2<T> s = v4_allsum<G, T>(wse, L.rot);
+    const T t2 = v4_allsum<G, T>(V2<T>{wslast.x + wslast.y, T(0)}, L.rot).x;
     const T em = tb.EPSMIN + s.x + DELT25 * t2;
     const T fm = tb.EPSMIN + s.y + (tb.FRTAIL * tb.DELTH) * t2;
     FM = em / fm;
@@ -447,23 +489,21 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   auto post_stress = [&](int MIJ, V2<T> apl, bool phiwa) {
     V2<T> s = z2;
     T sp = T(0);
-    if (L.grp) {
 #pragma unroll
-      for (int q = 0; q < NS; q++) {
-        const int m = q * G + j;
-        const T w = rrh(m, MIJ);
-        const T wx = w * L.fac[m * V4_NFAC + F4_CINV];
-        s = s + V2<T>{wx * rX[q], wx * rY[q]};
-        sp += w * rS[q];
-      }
+    for (int q = 0; q < NS; q++) {
+      const int m = q * G + j;
+      const T w = rrh(m, MIJ);
+      const T wx = w * L.fac4[m * 4 + Q4_CINV];
+      s = s + V2<T>{wx * rX[q], wx * rY[q]};
+      sp += w * rS[q];
     }
     s = v4_allsum<G, T>(s, L.rot);
     T PH = T(0);
-    if (phiwa) PH = v4_allsum<G, T>(L.grp ? V2<T>{apl.x + apl.y + sp, T(0)} : z2, L.rot).x;
-    const V2<T> fm = L.grp ? *reinterpret_cast<const V2<T>*>(tF + (MIJ - 1) * RS) : z2;
+    if (phiwa) PH = v4_allsum<G, T>(V2<T>{apl.x + apl.y + sp, T(0)}, L.rot).x;
+    const V2<T> fm = *reinterpret_cast<const V2<T>*>(tF + (MIJ - 1) * RS);
     const V2<T> fc2 = fm * cpos * cpos, fc3 = fc2 * cpos;
     const V2<T> h = v4_allsum<G, T>(V2<T>{fc3.x + fc3.y, fc2.x + fc2.y}, L.rot);
-    if (L.grp && j == 0) {
+    if (j == 0) {
       c[C_XS] = s.x; c[C_YS] = s.y; c[C_F1DCOS3] = tb.DELTH * h.x; c[C_F1DCOS2] = tb.DELTH * h.y; c[C_F1DSIN2] = T(0); c[C_F1D] = T(0);
       c[C_MIJ] = (T)MIJ;
       if (phiwa) c[C_PHIWA] = PH;
@@ -510,7 +550,15 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   WSYNC();
   V4_PHASE_EXIT(206);
 
-  // ---- SDISSIP + SNONLIN + update sweep (implsch.F90:262-392)
+  // ---- SDISSIP + SNONLIN + update sweep (implsch.F90:262-392), software-pipelined over the interaction frequencies MC = 1 .. MLSTHG:
+  //   (1) LDS reads of the five rows interaction MC gathers from, of the row the dissipation is evaluated for (MC-4, one interaction
+  //       ahead of its update) and of the factors of the row that is updated (MC-5): issued at the end of the previous interaction;
+  //   (2) frequency-interpolated rows of the two quadruplet legs -> staging rows 0..3, rotated reads; saturation spectrum of row MC-4;
+  //   (3) the DIA products of both mirror images -> staging rows 0..5, rotated reads;
+  //   (4) increments into the register ring of eight rows; row MC-5 is complete: dissipation, limiter, new spectrum, fluxes.
+  //   One LDS round trip between the stages; the directional maximum of the saturation spectrum (three dependent lane exchanges)
+  //   rides along, one exchange per stage.  The coefficient record of the next interaction and the parked wind-input row come
+  //   from global memory as vector loads one interaction (eight rows) ahead.
   V2<T> a_t = z2, a_x = z2;
   {
     T ENHFR = m_max(T(0.75) * DEPTH * AKMEAN, T(0.5));
@@ -518,9 +566,9 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     const int MFR1STFR = -tb.MFRSTLW + 1;
     const int MFRLSTFR = NFRE - tb.KFRH + MFR1STFR;
     const T DAL1 = tb.DAL1, DAL2 = tb.DAL2;
-    T wt[NTAP];   // SATWEIGHTS depend on the tap only (checked by ecwam_hip_create): wave-uniform
+    T wt[NH + 1];   // SATWEIGHTS depend on the tap only and are symmetric (checked by ecwam_hip_create): wave-uniform, taps -NH .. 0
 #pragma unroll
-    for (int t = 0; t < NTAP; t++) wt[t] = tb.SATWEIGHTS[t][NANG / 2];
+    for (int t = 0; t <= NH; t++) wt[t] = tb.SATWEIGHTS[t][NANG / 2];
     const T TMP03 = T(1) / (tb.SDSBR * tb.MICHE), SSDSC4 = tb.SSDSC4;
     const T c2 = tb.SSDSC2 * tb.SSDSC6, c2m1 = tb.SSDSC2 * (T(1) - tb.SSDSC6);
     const bool turb = tb.SSDSC5 != T(0);
@@ -529,127 +577,149 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     const bool shallow_brk = tb.LBIWBK && (DEPTH < T(50));
     const T USFM = UFRIC * m_max(FMEANWS, FMEAN);
     const bool flux_snl = tb.LCFLX && tb.LWVFLX_SNL;
-    T* st0 = sStg;            // staging rows: up / AD, vp / DELAM, um / DELAP, vm
+    const int NRED = tb.NFRE_RED, MLST = tb.MLSTHG;
+    T* st0 = sStg;            // staging rows: up / AD(kh=1), vp / DELAM(1), um / DELAP(1), vm / AD(2), DELAM(2), DELAP(2)
     T* st1 = sStg + RS;
     T* st2 = sStg + 2 * RS;
     T* st3 = sStg + 3 * RS;
-
+    T* st4 = sPl;
+    T* st5 = sPl + PP * NFRE;
     V2<T> aS[8], aF[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) { aS[i] = z2; aF[i] = z2; }
-    // wind-input rows (parked in the XLLWS block by the second SINFLX call) come back through a ring of eight prefetched rows:
-    // slot jj holds row MCb + jj - 4 while block MCb is processed and is refilled with row MCb + jj + 4 as soon as it is consumed
-    V2<T> wiq[8];
+    // wind-input rows (parked in the XLLWS block by the second SINFLX call) come back through a ring of four prefetched rows:
+    // slot jj & 3 holds row MC-5 while interaction MC is processed and is refilled with row MC-1 as soon as it is consumed
+    V2<T> wiq[4];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int mr = i - 4 < 0 ? i + 4 : i - 4;   // rows 4..7 in slots 0..3 (block 0 updates rows -4..3: slots 4..7 hold rows 0..3)
-      wiq[i] = (L.act && mr < NFRE) ? *reinterpret_cast<const V2<T>*>(gx + (size_t)mr * NANG) : z2;
-    }
-    for (int MCb = 0; MCb < tb.MLSTHG + 4; MCb += 8) {
+    for (int i = 0; i < 4; i++) wiq[i] = *reinterpret_cast<const V2<T>*>(gx + (size_t)i * NANG);   // rows 0..3, first used by MC = 5..8
+    auto clampr = [&](int r) { return r < 0 ? 0 : (r > NFRE - 1 ? NFRE - 1 : r); };
+    // carried from one interaction to the next: saturation spectrum of row MC-4 with its directional maximum (last exchange in
+    // flight), that row's frequency and un-updated values
+    V2<T> bs_p = z2, f_p = z2;
+    T bm_p = T(0), e3_p = T(0), e4_p = T(0), sig_p = T(0);
+    for (int MCb = 0; MCb < MLST; MCb += 8) {
 #pragma unroll
       for (int jj = 0; jj < 8; jj++) {
         const int MC = MCb + 1 + jj;
         const int c0 = (1 + jj) & 7, cm = (1 + jj + 4) & 7, cm1 = (1 + jj + 5) & 7, cp = (1 + jj + 2) & 7, cp1 = (1 + jj + 3) & 7;
-        if (MC <= tb.MLSTHG) {
-          const int IC = tb.INLCOEF[MC - 1][0], IP = tb.INLCOEF[MC - 1][1], IP1 = tb.INLCOEF[MC - 1][2];
-          const int IM = tb.INLCOEF[MC - 1][3], IM1 = tb.INLCOEF[MC - 1][4];
-          const T* R = tb.RNLCOEF[MC - 1];
-          const T FTAIL = R[0], GW1 = R[1], GW2 = R[2], GW3 = R[3], GW4 = R[4];
-          const T FKLAMPA = R[5], FKLAMPB = R[6], FKLAMP2 = R[7], FKLAMP1 = R[8];
-          const T FKLAPA2 = R[9], FKLAPB2 = R[10], FKLAP12 = R[11], FKLAP22 = R[12];
-          const T GW5 = R[13], GW6 = R[14], GW7 = R[15], GW8 = R[16];
-          const T FKLAMMA = R[17], FKLAMMB = R[18], FKLAMM2 = R[19], FKLAMM1 = R[20];
-          const T FKLAMA2 = R[21], FKLAMB2 = R[22], FKLAM12 = R[23], FKLAM22 = R[24];
-          const T FTEMP = tb.AF11[MC - 1] * ENHFR;
-          const bool mid = (MC > MFR1STFR && MC < MFRLSTFR);
-          const V2<T> fIP = *reinterpret_cast<const V2<T>*>(tF + IP * RS), fIP1 = *reinterpret_cast<const V2<T>*>(tF + IP1 * RS);
-          const V2<T> fIM = *reinterpret_cast<const V2<T>*>(tF + IM * RS), fIM1 = *reinterpret_cast<const V2<T>*>(tF + IM1 * RS);
-          V2<T> FIJ = *reinterpret_cast<const V2<T>*>(tF + IC * RS);
-          if (!mid) FIJ = FIJ * FTAIL;
-          // frequency-interpolated rows of the + and - quadruplet legs, staged for the rotated reads (snonlin.F90:236-262)
-          const V2<T> up = GW1 * fIP + GW3 * fIP1, vp = GW2 * fIP + GW4 * fIP1;
-          const V2<T> um = GW5 * fIM + GW7 * fIM1, vm = GW6 * fIM + GW8 * fIM1;
-          if (L.grp) {
-            *reinterpret_cast<V2<T>*>(st0 + L.own) = up; *reinterpret_cast<V2<T>*>(st1 + L.own) = vp;
-            *reinterpret_cast<V2<T>*>(st2 + L.own) = um; *reinterpret_cast<V2<T>*>(st3 + L.own) = vm;
-          }
-          WSYNC();
-          V2<T> SAPk[2], SAMk[2];
-          // kh = 0: K1 = K - R1, K11 = K - R1 - 1, K2 = K + R2, K21 = K + R2 + 1; kh = 1 mirrored
-          SAPk[0] = (R1 == 0 ? up : v4_at<T, NSH, -R1>(st0, sh)) + v4_at<T, NSH, -(R1 + 1)>(st1, sh);
-          SAMk[0] = v4_at<T, NSH, R2>(st2, sh) + v4_at<T, NSH, R2 + 1>(st3, sh);
-          SAPk[1] = (R1 == 0 ? up : v4_at<T, NSH, R1>(st0, sh)) + v4_at<T, NSH, R1 + 1>(st1, sh);
-          SAMk[1] = v4_at<T, NSH, -R2>(st2, sh) + v4_at<T, NSH, -(R2 + 1)>(st3, sh);
-          WSYNC();
-          const V2<T> FCEN = FTEMP * FIJ;
-#pragma unroll
-          for (int kh = 0; kh < 2; kh++) {
-            const V2<T> SAP = SAPk[kh], SAM = SAMk[kh];
-            V2<T> FAD1 = FIJ * (SAP + SAM);
-            const V2<T> FAD2 = FAD1 - T(2) * SAP * SAM;
-            FAD1 = FAD1 + FAD2;
-            const V2<T> AD = FAD2 * FCEN;
-            const V2<T> DELAD = FAD1 * FTEMP;
-            const V2<T> DELAP = (FIJ - T(2) * SAM) * DAL1 * FCEN;
-            const V2<T> DELAM = (FIJ - T(2) * SAP) * DAL2 * FCEN;
-            if (L.grp) {
-              *reinterpret_cast<V2<T>*>(st0 + L.own) = AD; *reinterpret_cast<V2<T>*>(st1 + L.own) = DELAM;
-              *reinterpret_cast<V2<T>*>(st2 + L.own) = DELAP;
-            }
-            WSYNC();
-            V2<T> A2, A2s, A1, A1s, D2, D2s, P1, P1s;
-            if (kh == 0) {
-              A2 = v4_at<T, NSH, -R2>(st0, sh); A2s = v4_at<T, NSH, -(R2 + 1)>(st0, sh);
-              A1 = (R1 == 0) ? AD : v4_at<T, NSH, R1>(st0, sh); A1s = v4_at<T, NSH, R1 + 1>(st0, sh);
-              D2 = v4_at<T, NSH, -R2>(st1, sh); D2s = v4_at<T, NSH, -(R2 + 1)>(st1, sh);
-              P1 = (R1 == 0) ? DELAP : v4_at<T, NSH, R1>(st2, sh); P1s = v4_at<T, NSH, R1 + 1>(st2, sh);
-            } else {
-              A2 = v4_at<T, NSH, R2>(st0, sh); A2s = v4_at<T, NSH, R2 + 1>(st0, sh);
-              A1 = (R1 == 0) ? AD : v4_at<T, NSH, -R1>(st0, sh); A1s = v4_at<T, NSH, -(R1 + 1)>(st0, sh);
-              D2 = v4_at<T, NSH, R2>(st1, sh); D2s = v4_at<T, NSH, R2 + 1>(st1, sh);
-              P1 = (R1 == 0) ? DELAP : v4_at<T, NSH, -R1>(st2, sh); P1s = v4_at<T, NSH, -(R1 + 1)>(st2, sh);
-            }
-            WSYNC();
-            aS[c0] -= T(2) * AD;
-            aF[c0] -= T(2) * DELAD;
-            aS[cm] += A2 * FKLAMM1 + A2s * FKLAMM2;
-            aF[cm] += D2 * FKLAM12 + D2s * FKLAM22;
-            aS[cm1] += A2 * FKLAMMA + A2s * FKLAMMB;
-            aF[cm1] += D2 * FKLAMA2 + D2s * FKLAMB2;
-            aS[cp] += A1 * FKLAMP1 + A1s * FKLAMP2;
-            aF[cp] += P1 * FKLAP12 + P1s * FKLAP22;
-            aS[cp1] += A1 * FKLAMPA + A1s * FKLAMPB;
-            aF[cp1] += P1 * FKLAPA2 + P1s * FKLAPB2;
-          }
-        }
-        const int m = MC - 5;  // 0-based row MC-4: no later interaction reads or feeds it
-        if (m >= 0 && m < NFRE) {
-          const T* row = sT + m * RS;
-          const T* fa = L.fac + m * V4_NFAC;
-          // dissipation coefficient of the row (sdissip_ard.F90:117-314), from the not yet updated row: element e = F(2j - 2 NSH + e)
-          T el[4 * NSH + 2];
+        const int m = MC - 5;   // row that is complete after this interaction
+        // ---- stage 1: LDS reads: the five rows interaction MC gathers from (INLCOEF by formula, checked by ecwam_hip_create), the row
+        //      the dissipation is evaluated for (MC-4: one interaction ahead of its update) and the factors of row MC-5
+        const int IC = clampr(MC - 1), IP = clampr(MC + 1), IP1 = clampr(MC + 2), IM = clampr(MC - 5), IM1 = clampr(MC - 4);
+        const V2<T> fIC = *reinterpret_cast<const V2<T>*>(tF + IC * RS);
+        const V2<T> fIP = *reinterpret_cast<const V2<T>*>(tF + IP * RS), fIP1 = *reinterpret_cast<const V2<T>*>(tF + IP1 * RS);
+        const V2<T> fIM = *reinterpret_cast<const V2<T>*>(tF + IM * RS), fIM1 = *reinterpret_cast<const V2<T>*>(tF + IM1 * RS);
+        T el[4 * NSH + 2];                // row MC-4: element e = F(2j - 2 NSH + e)
+        {
+          const T* row = sT + IM1 * RS;
 #pragma unroll
           for (int i = 0; i <= 2 * NSH; i++) {
             const V2<T> v = *reinterpret_cast<const V2<T>*>(row + sh[i]);
             el[2 * i] = v.x; el[2 * i + 1] = v.y;
           }
-          const V2<T> f = {el[2 * NSH], el[2 * NSH + 1]};
-          V2<T> bsat = z2;
-#pragma unroll
-          for (int t = 0; t < NTAP; t++) {
-            bsat.x += wt[t] * el[2 * NSH - NH + t];
-            bsat.y += wt[t] * el[2 * NSH - NH + t + 1];
-          }
-          bsat = bsat * fa[F4_BSC];
-          const T bm = v4_allmax<G, T>(L.grp ? m_max(bsat.x, bsat.y) : T(0), L.rot);
-          const T sig = lane_get(L.rZPIFR, m);
+        }
+        const T bscn = L.fac4[IM1 * 4 + Q4_BSC];
+        const V2<T> qf0 = *reinterpret_cast<const V2<T>*>(L.fac4 + IM * 4), qf1 = *reinterpret_cast<const V2<T>*>(L.fac4 + IM * 4 + 2);
+        // meanwhile: the dissipation coefficient of row m (sdissip_ard.F90:117-314) from the saturation spectrum and the maximum the
+        // previous interaction left in flight
+        V2<T> Dcur;
+        const V2<T> fcur = f_p;
+        {
+          const T bm = m_max(bm_p, m_max(e3_p, e4_p));
           const T d0 = m_max(T(0), bm * TMP03 - SSDSC4);
-          const V2<T> t1 = bsat * TMP03 - SSDSC4;
+          const V2<T> t1 = bs_p * TMP03 - SSDSC4;
           const V2<T> d1 = {m_max(T(0), t1.x), m_max(T(0), t1.y)};
-          V2<T> D = (c2 * sig) * (d0 * d0) + (c2m1 * sig) * (d1 * d1);
-          if (turb) D = D - (sig * fa[F4_WAVNUM] * FACTURB) * coswdif;
-          const V2<T> wi = wiq[jj];   // wind input of the second SINFLX call
-          const V2<T> fldw = D + wi;
+          Dcur = (c2 * sig_p) * (d0 * d0) + (c2m1 * sig_p) * (d1 * d1);
+        }
+        // ---- coefficient record of the interaction (wave-uniform)
+        const T* cg = tb.DIACF[MC - 1];
+        const T* cs = cg + 12;
+        const T FTAIL = cg[0], GW1 = cg[1], GW2 = cg[2], GW3 = cg[3], GW4 = cg[4], GW5 = cg[5], GW6 = cg[6], GW7 = cg[7], GW8 = cg[8];
+        const T FTEMP = cg[9] * ENHFR;
+        const T FKLAMPA = cs[0], FKLAMPB = cs[1], FKLAMP2 = cs[2], FKLAMP1 = cs[3];
+        const T FKLAPA2 = cs[4], FKLAPB2 = cs[5], FKLAP12 = cs[6], FKLAP22 = cs[7];
+        const T FKLAMMA = cs[8], FKLAMMB = cs[9], FKLAMM2 = cs[10], FKLAMM1 = cs[11];
+        const T FKLAMA2 = cs[12], FKLAMB2 = cs[13], FKLAM12 = cs[14], FKLAM22 = cs[15];
+        const bool mid = (MC > MFR1STFR && MC < MFRLSTFR);
+        // ---- stage 2: frequency-interpolated rows of the + and - legs (snonlin.F90:236-262) -> staging rows, rotated reads;
+        //      saturation spectrum of row MC-4 (SATWEIGHTS symmetric about the centre tap) and the first exchange of its maximum
+        const V2<T> FIJ = mid ? fIC : fIC * FTAIL;
+        const V2<T> up = GW1 * fIP + GW3 * fIP1, vp = GW2 * fIP + GW4 * fIP1;
+        const V2<T> um = GW5 * fIM + GW7 * fIM1, vm = GW6 * fIM + GW8 * fIM1;
+        *reinterpret_cast<V2<T>*>(st0 + L.own) = up; *reinterpret_cast<V2<T>*>(st1 + L.own) = vp;
+        *reinterpret_cast<V2<T>*>(st2 + L.own) = um; *reinterpret_cast<V2<T>*>(st3 + L.own) = vm;
+        V4SYNC();
+        // kh = 1: K1 = K - R1, K11 = K - R1 - 1, K2 = K + R2, K21 = K + R2 + 1; kh = 2 mirrored
+        V2<T> SAPk[2], SAMk[2];
+        SAPk[0] = (R1 == 0 ? up : v4_at<T, NSH, -R1>(st0, sh)) + v4_at<T, NSH, -(R1 + 1)>(st1, sh);
+        SAMk[0] = v4_at<T, NSH, R2>(st2, sh) + v4_at<T, NSH, R2 + 1>(st3, sh);
+        SAPk[1] = (R1 == 0 ? up : v4_at<T, NSH, R1>(st0, sh)) + v4_at<T, NSH, R1 + 1>(st1, sh);
+        SAMk[1] = v4_at<T, NSH, -R2>(st2, sh) + v4_at<T, NSH, -(R2 + 1)>(st3, sh);
+        V2<T> bsat = {wt[NH] * el[2 * NSH], wt[NH] * el[2 * NSH + 1]};
+#pragma unroll
+        for (int d = 1; d <= NH; d++) {
+          bsat.x += wt[NH - d] * (el[2 * NSH - d] + el[2 * NSH + d]);
+          bsat.y += wt[NH - d] * (el[2 * NSH + 1 - d] + el[2 * NSH + 1 + d]);
+        }
+        bsat = bsat * bscn;
+        T bm1 = m_max(bsat.x, bsat.y);
+        const T e0 = v4_bp(L.rot.a0, bm1);
+        V4SYNC();
+        // ---- stage 3: the DIA products of the two mirror images (snonlin.F90:264-306), one after the other through staging rows 0..2
+        const V2<T> FCEN = FTEMP * FIJ;
+        T e1 = T(0), e2 = T(0), e3 = T(0), e4 = T(0);
+        // (the always-true test splits the basic block: scheduled as one block, the eight unrolled interactions need 340 VGPRs)
+        if (MC <= MLST)
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++) {
+          const V2<T> SAP = SAPk[kh], SAM = SAMk[kh];
+          V2<T> FAD1 = FIJ * (SAP + SAM);
+          const V2<T> FAD2 = FAD1 - T(2) * SAP * SAM;
+          FAD1 = FAD1 + FAD2;
+          const V2<T> AD = FAD2 * FCEN;
+          const V2<T> DELAD = FAD1 * FTEMP;
+          const V2<T> DELAP = (FIJ - T(2) * SAM) * DAL1 * FCEN;
+          const V2<T> DELAM = (FIJ - T(2) * SAP) * DAL2 * FCEN;
+          *reinterpret_cast<V2<T>*>(st0 + L.own) = AD; *reinterpret_cast<V2<T>*>(st1 + L.own) = DELAM;
+          *reinterpret_cast<V2<T>*>(st2 + L.own) = DELAP;
+          V4SYNC();
+          V2<T> A2, A2s, A1, A1s, D2, D2s, P1, P1s;
+          if (kh == 0) {
+            A2 = v4_at<T, NSH, -R2>(st0, sh); A2s = v4_at<T, NSH, -(R2 + 1)>(st0, sh);
+            A1 = (R1 == 0) ? AD : v4_at<T, NSH, R1>(st0, sh); A1s = v4_at<T, NSH, R1 + 1>(st0, sh);
+            D2 = v4_at<T, NSH, -R2>(st1, sh); D2s = v4_at<T, NSH, -(R2 + 1)>(st1, sh);
+            P1 = (R1 == 0) ? DELAP : v4_at<T, NSH, R1>(st2, sh); P1s = v4_at<T, NSH, R1 + 1>(st2, sh);
+            bm1 = m_max(bm1, e0);
+            if (G == 18) { e1 = v4_bp(L.rot.a1, bm1); e2 = v4_bp(L.rot.a2, bm1); }
+            if (G == 12) e1 = v4_bp(L.rot.a1, bm1);
+          } else {
+            A2 = v4_at<T, NSH, R2>(st0, sh); A2s = v4_at<T, NSH, R2 + 1>(st0, sh);
+            A1 = (R1 == 0) ? AD : v4_at<T, NSH, -R1>(st0, sh); A1s = v4_at<T, NSH, -(R1 + 1)>(st0, sh);
+            D2 = v4_at<T, NSH, R2>(st1, sh); D2s = v4_at<T, NSH, R2 + 1>(st1, sh);
+            P1 = (R1 == 0) ? DELAP : v4_at<T, NSH, -R1>(st2, sh); P1s = v4_at<T, NSH, -(R1 + 1)>(st2, sh);
+            if (G == 18) bm1 = m_max(bm1, m_max(e1, e2));
+            if (G == 12) bm1 = m_max(bm1, e1);
+            e3 = v4_bp(L.rot.a3, bm1); e4 = v4_bp(L.rot.a4, bm1);
+          }
+          V4SYNC();
+          aS[c0] -= T(2) * AD;
+          aF[c0] -= T(2) * DELAD;
+          aS[cm] += A2 * FKLAMM1 + A2s * FKLAMM2;
+          aF[cm] += D2 * FKLAM12 + D2s * FKLAM22;
+          aS[cm1] += A2 * FKLAMMA + A2s * FKLAMMB;
+          aF[cm1] += D2 * FKLAMA2 + D2s * FKLAMB2;
+          aS[cp] += A1 * FKLAMP1 + A1s * FKLAMP2;
+          aF[cp] += P1 * FKLAP12 + P1s * FKLAP22;
+          aS[cp1] += A1 * FKLAMPA + A1s * FKLAMPB;
+          aF[cp1] += P1 * FKLAPA2 + P1s * FKLAPB2;
+        }
+        // ---- row m = MC-5 is complete: no later interaction reads or feeds it
+        if (m >= 0) {
+          const V2<T> f = fcur;
+          const T cofr = lane_get(L.rCOFRM4, m), flmax = lane_get(L.rFLMAX, m), rhowg = lane_get(L.rRHOWG, m);
+          const V2<T> wi = wiq[jj & 3];   // wind input of the second SINFLX call
+          if (turb) Dcur = Dcur - (lane_get(L.rZPIFR, m) * qf1.y * FACTURB) * coswdif;
+          const V2<T> fldw = Dcur + wi;
           V2<T> sl = fldw * f + aS[cm];
           V2<T> fld = fldw + aF[cm];
           V2<T> ss = z2;
@@ -657,9 +727,9 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
             const V2<T> den = {m_max(T(1) - DELT5 * fld.x, T(1)), m_max(T(1) - DELT5 * fld.y, T(1))};
             ss = V2<T>{f_div(sl.x, den.x), f_div(sl.y, den.y)};
           }
-          if (shallow_brk && m < tb.NFRE_RED) { sl = sl - SDS * f; fld = fld - SDS; }
-          if (m < tb.NFRE_RED) { const T sbo = fa[F4_SBO]; sl = sl + sbo * f; fld = fld + sbo; }
-          const T lim = USFM * (lane_get(L.rCOFRM4, m) * DELT), flmax = lane_get(L.rFLMAX, m);
+          if (shallow_brk && m < NRED) { sl = sl - SDS * f; fld = fld - SDS; }
+          if (m < NRED) { const T sbo = qf0.y; sl = sl + sbo * f; fld = fld + sbo; }
+          const T lim = USFM * (cofr * DELT);
           V2<T> fn;
           {
             const T G0 = f_div(DELT * sl.x, m_max(T(1) - DELT5 * fld.x, T(1))), G1 = f_div(DELT * sl.y, m_max(T(1) - DELT5 * fld.y, T(1)));
@@ -669,24 +739,24 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
           ss.x = ss.x + DELTM * m_min(flmax - fn.x, T(0));
           ss.y = ss.y + DELTM * m_min(flmax - fn.y, T(0));
           fn.x = m_min(fn.x, flmax); fn.y = m_min(fn.y, flmax);
-          WSYNC();
-          if (L.grp) *reinterpret_cast<V2<T>*>(tFw + m * RS) = fn;
+          *reinterpret_cast<V2<T>*>(tFw + m * RS) = fn;
           T rh = T(0);   // RHOWGDFTH(M) (frcutindex.F90:98-107); MIJ differs between the points of the wave
-          if (m + 1 <= MIJ) { rh = lane_get(L.rRHOWG, m); if (m + 1 == MIJ && MIJ != NFRE) rh = T(0.5) * rh; }
+          if (m + 1 <= MIJ) { rh = rhowg; if (m + 1 == MIJ && MIJ != NFRE) rh = T(0.5) * rh; }
           a_t = a_t + rh * ss;
-          a_x = a_x + (fa[F4_CINV] * rh) * ss;
+          a_x = a_x + (qf1.x * rh) * ss;
         }
         aS[cm] = z2;
         aF[cm] = z2;
         {
-          const int mn = MC - 5 + 8;
-          if (mn >= 0 && mn < NFRE && L.act) wiq[jj] = *reinterpret_cast<const V2<T>*>(gx + (size_t)mn * NANG);
+          const int mn = m + 4;
+          if (mn >= 4 && mn < NFRE) wiq[jj & 3] = *reinterpret_cast<const V2<T>*>(gx + (size_t)mn * NANG);
         }
-        WSYNC();
+        bs_p = bsat; f_p = V2<T>{el[2 * NSH], el[2 * NSH + 1]}; bm_p = bm1; e3_p = e3; e4_p = e4; sig_p = lane_get(L.rZPIFR, clampr(m + 1));
+        V4SYNC();
       }
     }
   }
-  WSYNC();
+  V4SYNC();
   V4_PHASE_EXIT(207);
   const T TAUW = c[C_TAUW], TAUWDIR = c[C_TAUWDIR], PHIWA = c[C_PHIWA], Z0B = c[C_Z0B], CHRNCK = c[C_CHRNCK];
 
@@ -694,8 +764,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   T TAUXD = T(0), TAUYD = T(0), TAUOCXD = T(0), TAUOCYD = T(0), TAUOC = T(0), PHIOCD = T(0), PHIEPS = T(0), PHIAW = T(0);
   if (tb.LCFLX) {
     const V2<T> sx = a_x * L.sinth, sy = a_x * L.costh;
-    const V2<T> r0 = v4_allsum<G, T>(L.grp ? V2<T>{a_t.x + a_t.y, sx.x + sx.y} : z2, L.rot);
-    const T YSTRESS = v4_allsum<G, T>(L.grp ? V2<T>{sy.x + sy.y, T(0)} : z2, L.rot).x;
+    const V2<T> r0 = v4_allsum<G, T>(V2<T>{a_t.x + a_t.y, sx.x + sx.y}, L.rot);
+    const T YSTRESS = v4_allsum<G, T>(V2<T>{sy.x + sy.y, T(0)}, L.rot).x;
     const T PHILF = r0.x, XSTRESS = r0.y;
     const T EPSUS3 = tb.EPSUS * m_sqrt(tb.EPSUS);
     T OOVAL = T(1), USTAR = UFRIC;
@@ -723,7 +793,9 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     PHIAW = OOVAL * PHIWA / XN + (T(1) - OOVAL) * T(3.75);
   }
 
-  // ---- second FKMEAN / FEMEANWS, IMPHFTAIL, SETICE, STOKESDRIFT (implsch.F90:422-462)
+  // ---- second FKMEAN / FEMEANWS, IMPHFTAIL, SETICE, STOKESDRIFT (implsch.F90:422-462); the SQRT(WAVNUM) plane was a staging row
+  for (int m = j; m < NFRE; m += G) L.sq[m] = m_sqrt(L.fac4[m * 4 + Q4_WAVNUM]);
+  WSYNC();
   fkmean4(EMEAN, FMEAN, F1MEAN, AKMEAN, XKMEAN);
   T EMEANWS;
   {
@@ -736,15 +808,15 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     }
     femws_finish(we, wl, FMEANWS, EMEANWS);
   }
-  if (L.grp) {  // imphftail.F90: TEMP2(M) / TEMP1 = (XK2CG WAVNUM)(MIJ) / (XK2CG WAVNUM)(M)
-    const T B1 = L.fac[(MIJ - 1) * V4_NFAC + F4_BSC];
+  {  // imphftail.F90: TEMP2(M) / TEMP1 = (XK2CG WAVNUM)(MIJ) / (XK2CG WAVNUM)(M)
+    const T B1 = L.fac4[(MIJ - 1) * 4 + Q4_BSC];
     const V2<T> tf = *reinterpret_cast<const V2<T>*>(tF + (MIJ - 1) * RS);
     for (int m = MIJ; m < NFRE; m++) {
-      const T tm = B1 / L.fac[m * V4_NFAC + F4_BSC];
+      const T tm = B1 / L.fac4[m * 4 + Q4_BSC];
       *reinterpret_cast<V2<T>*>(tFw + m * RS) = V2<T>{m_max(tm * tf.x, FLM.x), m_max(tm * tf.y, FLM.y)};
     }
   }
-  if (tb.LICERUN && tb.LMASKICE && L.grp) {  // setice.F90:67-86
+  if (tb.LICERUN && tb.LMASKICE) {  // setice.F90:67-86
     T CIREDUC, ICEFREE;
     if (CICOVER > tb.CITHRSH) { CIREDUC = m_max(tb.EPSMIN, T(1) - CICOVER); ICEFREE = T(0); }
     else { CIREDUC = T(0); ICEFREE = T(1); }
@@ -756,12 +828,12 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     const int MO = tb.NFRE_ODD;
     const T fo = tb.FR[MO - 1];
     const T CONST = T(2) * tb.DELTH * (tb.ZPI * tb.ZPI * tb.ZPI) / tb.G * m_pow4(fo);
-    const T* stk = wvprpt + (size_t)ij * ECWAM_HIP_NWPR * NFRE + 4 * NFRE;   // STOKFAC(M) of the point (same address in its G lanes)
+    const T* stk = wp + 4 * NFRE;   // STOKFAC(M) of the point (same address in its G lanes)
     V2<T> a = z2;
     for (int m = 0; m < MO; m++) a = a + (stk[m] * tb.DFIM_SIM[m]) * *reinterpret_cast<const V2<T>*>(tF + m * RS);
     a = a + CONST * *reinterpret_cast<const V2<T>*>(tF + (MO - 1) * RS);
     const V2<T> ax = a * L.sinth, ay = a * L.costh;
-    const V2<T> s = v4_allsum<G, T>(L.grp ? V2<T>{ax.x + ax.y, ay.x + ay.y} : z2, L.rot);
+    const V2<T> s = v4_allsum<G, T>(V2<T>{ax.x + ax.y, ay.x + ay.y}, L.rot);
     USTOKES = s.x; VSTOKES = s.y;
     if (tb.LICERUN && tb.LWAMRSETCI && CICOVER > tb.CITHRSH) {
       USTOKES = T(0.016) * WSWAVE * sinwd * (T(1) - CICOVER);
@@ -773,25 +845,33 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   WSYNC();
   // ---- store FL1 (16-byte chunks gathered from VEC rows of the tile), XLLWS(K,M) from the bit masks, per-point scalars
   {
-    constexpr int NV = N / VEC;
-    const float rnv = 1.0f / (float)NV, rnf = 1.0f / (float)(NFRE / VEC);
-    for (int v = lane; v < n * NV; v += 64) {
-      const int pq = (int)(((float)v + 0.5f) * rnv);
-      const int w = v - pq * NV;
-      const int k = (int)(((float)w + 0.5f) * rnf);
-      const int m0 = (w - k * (NFRE / VEC)) * VEC;
-      const T* d = sT + m0 * RS + pq * NANG + k;
-      VT val;
+    constexpr int NV = N / VEC, NIT = (NV + 63) / 64;
+    int k = lane / NC, r = lane - k * NC;
 #pragma unroll
-      for (int i = 0; i < VEC; i++) val[i] = d[i * RS];
-      *reinterpret_cast<VT*>(fl1 + (size_t)(ij0 + pq) * N + (size_t)w * VEC) = val;
+    for (int it = 0; it < NIT; it++) {
+      const int w = lane + 64 * it;
+      if (w < NV) {
+        const T* d = sT + (r * VEC) * RS + k;
+#pragma unroll
+        for (int q = 0; q < PP; q++) {
+          if (q < n) {
+            VT val;
+#pragma unroll
+            for (int i = 0; i < VEC; i++) val[i] = d[i * RS + q * NANG];
+            *reinterpret_cast<VT*>(fl1 + (size_t)(ij0 + q) * N + (size_t)w * VEC) = val;
+          }
+        }
+      }
+      k += 64 / NC; r += 64 % NC;
+      if (r >= NC) { r -= NC; k += 1; }
     }
   }
-  if (L.act) {   // every wind-input row parked in this block has been read by now
+  {   // every wind-input row parked in this block has been read by now
     T* x0 = xllws + (size_t)ij * N + (size_t)(2 * j) * NFRE;   // rows K = 2j and 2j+1 are contiguous
 #pragma unroll 1
     for (int h = 0; h < 2; h++) {
       const unsigned long long xm = h ? xm1 : xm0;
+#pragma unroll
       for (int m = 0; m < NFRE; m += VEC) {
         VT val;
 #pragma unroll
@@ -800,7 +880,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       }
     }
   }
-  if (L.act && j == 0) {
+  if (j == 0) {
     T* fo = ffa + (size_t)ij * ECWAM_HIP_NFF;
     fo[7] = UFRIC; fo[8] = TAUW; fo[9] = TAUWDIR; fo[10] = Z0M; fo[11] = Z0B; fo[12] = CHRNCK;
     T* io = intfa + (size_t)ij * ECWAM_HIP_NINTF;

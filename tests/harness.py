@@ -101,6 +101,10 @@ def compare_implsch(ref: dict, got: dict, tables) -> dict:
     ebin = rel_err(got["FL1"], ref["FL1"], 1e-300)
     st["fl1_max_rel_bin_clean"] = float(ebin[clean].max()) if clean.any() else 0.0
     st["fl1_frac_bins_gt_1e-5"] = float((ebin > 1e-5).mean())
+    # the same over the bins that carry energy (above 1e-6 of the point's peak): SURVEY H4's criterion without the noise floor,
+    # where EPSMIN / FLMIN-sized values differ by 1e-5 of themselves and 1e-15 of the peak
+    sig = np.abs(ref["FL1"].astype(np.float64)) > 1e-6 * peak
+    st["fl1_frac_sig_bins_gt_1e-5"] = float((ebin[sig] > 1e-5).mean()) if sig.any() else 0.0
     dfim = np.asarray(tables.DFIM, dtype=np.float64)
     hs_r = 4 * np.sqrt((ref["FL1"].astype(np.float64).sum(1) * dfim).sum(1))
     hs_g = 4 * np.sqrt((got["FL1"].astype(np.float64).sum(1) * dfim).sum(1))

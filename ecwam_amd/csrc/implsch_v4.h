@@ -702,16 +702,17 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
             e3 = v4_bp(L.rot.a3, bm1); e4 = v4_bp(L.rot.a4, bm1);
           }
           V4SYNC();
+          // (one fused multiply-add per term: the reference adds the two terms of a row one after the other as well)
           aS[c0] -= T(2) * AD;
           aF[c0] -= T(2) * DELAD;
-          aS[cm] += A2 * FKLAMM1 + A2s * FKLAMM2;
-          aF[cm] += D2 * FKLAM12 + D2s * FKLAM22;
-          aS[cm1] += A2 * FKLAMMA + A2s * FKLAMMB;
-          aF[cm1] += D2 * FKLAMA2 + D2s * FKLAMB2;
-          aS[cp] += A1 * FKLAMP1 + A1s * FKLAMP2;
-          aF[cp] += P1 * FKLAP12 + P1s * FKLAP22;
-          aS[cp1] += A1 * FKLAMPA + A1s * FKLAMPB;
-          aF[cp1] += P1 * FKLAPA2 + P1s * FKLAPB2;
+          aS[cm] += A2 * FKLAMM1; aS[cm] += A2s * FKLAMM2;
+          aF[cm] += D2 * FKLAM12; aF[cm] += D2s * FKLAM22;
+          aS[cm1] += A2 * FKLAMMA; aS[cm1] += A2s * FKLAMMB;
+          aF[cm1] += D2 * FKLAMA2; aF[cm1] += D2s * FKLAMB2;
+          aS[cp] += A1 * FKLAMP1; aS[cp] += A1s * FKLAMP2;
+          aF[cp] += P1 * FKLAP12; aF[cp] += P1s * FKLAP22;
+          aS[cp1] += A1 * FKLAMPA; aS[cp1] += A1s * FKLAMPB;
+          aF[cp1] += P1 * FKLAPA2; aF[cp1] += P1s * FKLAPB2;
         }
         // ---- row m = MC-5 is complete: no later interaction reads or feeds it
         if (m >= 0) {

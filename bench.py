@@ -5,8 +5,9 @@ One "step" = one WAMINTGR cycle on synthetic forcing: advection (halo exchange +
 IMPLSCH over every owned sea point, state resident in HBM.  Workload at N=1: octahedral
 O320 all-ocean grid (421 080 sea points), 36 directions x 36 frequencies, single precision -- the
 configuration BASELINE.json's metric is quoted on.  For N>1 (one process per GPU, launched by
-torch.distributed.run) the per-GPU work is held fixed (weak scaling): grid O<round(320*sqrt(N))>, sharded
-into contiguous sea-point ranges with a point-to-point halo exchange over RCCL.
+torch.distributed.run) the per-GPU work is held fixed (weak scaling) on BASELINE.json's own grids: O453 at N=2, O640 at N=4,
+O1280 at N=8 (configs 4 and 5; O1280 / 8 is 2x the per-GPU points of O320), sharded into contiguous sea-point ranges with a
+point-to-point halo exchange over RCCL.
 
 Prints ONE JSON line on rank 0.
 """
@@ -121,7 +122,7 @@ def main() -> None:
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    ng = a.grid or int(round(320 * math.sqrt(world)))
+    ng = a.grid or {1: 320, 2: 453, 4: 640, 8: 1280}.get(world, int(round(320 * math.sqrt(world))))
     # time step: 450 s at O320 (the 900 s of the reference's 24-direction O320 yml violates the CTU stability criterion
     # with 36 directions near the poles of the all-ocean grid, ctuw.F90:637); scaled with the grid spacing beyond
     dt = 450 if ng <= 320 else max(15, int(450 * 320 / ng) // 15 * 15)
@@ -130,6 +131,7 @@ def main() -> None:
     m = Wamintgr(cfg, grid, a.prec, device=local_rank, rank=rank, nranks=world, weights=a.weights, strip_width=a.strip,
                  ifrelfmax=a.ifrelfmax, delpro_lf=(dt / 2.0 if a.ifrelfmax else None))
     m.init_synthetic()
+    m.ff_next = m.ff.clone()      # NEWWIND hands the (unchanged synthetic) forcing over every step: k_newwind is part of the step
     nfail = m.build_weights()
     if nfail:
         raise SystemExit(f"CFL violated at {nfail} points")
@@ -189,30 +191,35 @@ def main() -> None:
             "implsch": {"ms": t_impl, "alg_bytes": b_impl * m.n, "gbs": b_impl * m.n / t_impl / 1e6},
         }
         dom = max(kern, key=lambda k: kern[k]["ms"])
-        # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh; FETCH_SIZE / WRITE_SIZE in
-        # KiB, FETCH doubled for the 16 B/lane streams of PROPAGS2 as MI355X_MICROARCH.md prescribes for gfx950).  Only
-        # valid for the workload they were taken on: the default O320 / 36x36 / sp / on-the-fly-weights run on one GPU.
+        # Figures below tagged "source: committed_pmc" are NOT measured in this run: they come from the committed rocprofv3 PMC
+        # summaries under profiles/ (tools/pmc_traffic.sh, tools/pmc_implsch_sets.sh) and are only attached to the workload they were
+        # taken on (default O320 / 36x36 / sp / on-the-fly weights, one GPU).  FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is
+        # doubled as MI355X_MICROARCH.md prescribes for gfx950 (calibrated on a 16 B/lane copy: profiles/r02_fetch_size_calibration.json).
+        prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        default_wl = world == 1 and ng == 320 and a.prec == "sp" and a.nang == 36 and a.nfre == 36 and a.weights == "otf" and not a.irefra
         traffic = None
-        tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic_pmc.json")
-        if world == 1 and ng == 320 and a.prec == "sp" and a.nang == 36 and a.nfre == 36 and a.weights == "otf" and not a.irefra and os.path.exists(tf):
+        tf = os.path.join(prof, "r02_hbm_traffic_pmc.json")
+        if default_wl and os.path.exists(tf):
             with open(tf) as fh:
                 pm = json.load(fh).get(dom, {})
             if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
-                traffic = 1024.0 * ((2.0 if dom == "propags2" else 1.0) * pm["FETCH_SIZE"] + pm["WRITE_SIZE"])
-        # IMPLSCH is bound by the vector-ALU issue rate, not by HBM or MFMA (SURVEY.md 8d asks for this figure next to the HBM
-        # fraction): busy fraction of the SIMD time from the committed PMC pass, wave instructions per point and the issue-rate
-        # ceiling they imply (256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz)
+                traffic = 1024.0 * (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"])
+        # IMPLSCH is bound by instruction issue and LDS latency at two waves per SIMD, not by HBM or MFMA (SURVEY.md 8d asks for
+        # this figure next to the HBM fraction).  Issue ceiling: 1024 SIMDs x clock / (VALU instructions per point x cycles per
+        # instruction), 2.6 cycles per wave64 VALU instruction with >= 2 waves per SIMD as measured by tools/ubench_valu.hip
+        # (profiles/r02_ubench_valu.txt; the guide's figure is 2, a wave alone issues one per 5.3 cycles).
         valu = None
-        pf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_implsch_pmc.json")
-        if os.path.exists(pf) and a.prec == "sp":
+        pf = os.path.join(prof, "r02_implsch_pmc.json")
+        if default_wl and os.path.exists(pf):
             with open(pf) as fh:
                 pm = json.load(fh)
-            ceil_pts = 256 * 4 * 2.4e9 / 4.0 / (pm["SQ_ACTIVE_INST_VALU_quadcycles"])
-            valu = {"kernel": "implsch", "valu_busy_fraction_pmc": pm["valu_busy_fraction"],
-                    "valu_insts_per_point": pm["SQ_INSTS_VALU"], "issue_ceiling_points_per_s": ceil_pts,
+            ceil_pts = 256 * 4 * 2.4e9 / (2.6 * pm["SQ_INSTS_VALU"])
+            valu = {"kernel": "implsch", "source": "committed_pmc", "file": "profiles/r02_implsch_pmc.json",
+                    "valu_busy_fraction_pmc": pm["valu_busy_fraction"], "valu_insts_per_point": pm["SQ_INSTS_VALU"],
+                    "cycles_per_valu_inst_assumed": 2.6, "issue_ceiling_points_per_s": ceil_pts,
                     "achieved_points_per_s": m.n / (t_impl * 1e-3), "frac_of_issue_ceiling": m.n / (t_impl * 1e-3) / ceil_pts}
         out = {
-            "metric": "grid-point spectral steps/sec (whole node) at O320, 36dir x 36freq",
+            "metric": f"grid-point spectral steps/sec (whole node) at O{ng}, {a.nang}dir x {a.nfre}freq",
             "value": grid.nsea * a.steps / el, "unit": "grid-point spectral steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if a.prec == "sp" else "f64", "data": "synthetic",
@@ -224,7 +231,8 @@ def main() -> None:
                                    + (f", fast waves M<={a.ifrelfmax} in two sub-steps" if a.ifrelfmax else ""),
                        "points_per_gpu": m.n, "halo_points": m.dom.nh, "parallelism": f"sea-point block x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic},
+                         "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "committed_pmc: profiles/r02_hbm_traffic_pmc.json" if traffic is not None else None},
             "kernels": kern,
             "valu": valu,
             "finite": finite,

@@ -106,6 +106,12 @@ def main() -> None:
                     help="advection steps per source-term step (1: the O320 configuration; 2: O1280's native 450 s / 900 s ratio)")
     ap.add_argument("--ifrelfmax", type=int, default=0,
                     help="fast waves: frequencies 1..IFRELFMAX advected with two sub-steps of half the time step (O1280: 5)")
+    ap.add_argument("--halo", default="torch", choices=["torch", "lib", "host"],
+                    help="halo exchange: torch.distributed P2P (RCCL), the library's own RCCL exchange (ecwam_hip_halo_start/_finish), "
+                         "or host staged through the CPU backend")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal of the N>1 code on ONE GPU: every rank uses device 0, process group on gloo, host-staged halo")
+    ap.add_argument("--dump", default="", help="write the owned spectra of every rank to <path>.<rank>.npy after the last step")
     ap.add_argument("--irefra", type=int, default=0, choices=[0, 1, 2, 3],
                     help="refraction: 0 none (BASELINE configurations), 1 depth, 2 currents, 3 both (synthetic current field)")
     a = ap.parse_args()
@@ -115,12 +121,18 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.share_gpu:
+        local_rank, a.halo = 0, "host"
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            # "cpu:gloo,cuda:nccl": the host-staged halo moves CPU tensors, everything else goes over RCCL
+            dist.init_process_group("cpu:gloo,cuda:nccl" if a.halo == "host" else "nccl", device_id=torch.device("cuda", local_rank))
 
     ng = a.grid or {1: 320, 2: 453, 4: 640, 8: 1280}.get(world, int(round(320 * math.sqrt(world))))
     # time step: 450 s at O320 (the 900 s of the reference's 24-direction O320 yml violates the CTU stability criterion
@@ -129,7 +141,7 @@ def main() -> None:
     cfg = Config(nang=a.nang, nfre=a.nfre, nfre_red=a.nfre, idelt=dt, idelpro=dt, irefra=a.irefra)
     grid = G.build_grid(ng)
     m = Wamintgr(cfg, grid, a.prec, device=local_rank, rank=rank, nranks=world, weights=a.weights, strip_width=a.strip,
-                 ifrelfmax=a.ifrelfmax, delpro_lf=(dt / 2.0 if a.ifrelfmax else None))
+                 ifrelfmax=a.ifrelfmax, delpro_lf=(dt / 2.0 if a.ifrelfmax else None), halo_transport=a.halo)
     m.init_synthetic()
     m.ff_next = m.ff.clone()      # NEWWIND hands the (unchanged synthetic) forcing over every step: k_newwind is part of the step
     nfail = m.build_weights()
@@ -168,9 +180,11 @@ def main() -> None:
     t_prop = sum(e[0].elapsed_time(e[1]) for e in ev) / a.steps
     t_impl = sum(e[2].elapsed_time(e[3]) for e in ev) / a.steps
     if dist is not None:
-        tt = torch.tensor([el, t_prop, t_impl], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([el, t_prop, t_impl], dtype=torch.float64, device="cpu" if a.share_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el, t_prop, t_impl = (float(x) for x in tt.cpu())
+    if a.dump:
+        np.save(f"{a.dump}.{rank}.npy", m.fl1[: m.n].cpu().numpy())
     swh = m.swh()
     finite = bool(torch.isfinite(swh).all().item())
     swh_avg, swh_min, swh_max, _ = m.swh_norm()      # OUTWNORM of the significant wave height, computed on the device
@@ -229,7 +243,8 @@ def main() -> None:
                                    + (f", IREFRA={a.irefra} (synthetic currents)" if a.irefra else "")
                                    + (f", {a.adv_per_source} advection steps per source step" if a.adv_per_source != 1 else "")
                                    + (f", fast waves M<={a.ifrelfmax} in two sub-steps" if a.ifrelfmax else ""),
-                       "points_per_gpu": m.n, "halo_points": m.dom.nh, "parallelism": f"sea-point block x{world}"},
+                       "points_per_gpu": m.n, "halo_points": m.dom.nh, "parallelism": f"sea-point block x{world}",
+                       "halo": a.halo if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "committed_pmc: profiles/r02_hbm_traffic_pmc.json" if traffic is not None else None},

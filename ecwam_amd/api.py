@@ -321,6 +321,49 @@ class HipContext:
                                                  self._real(fl, (fl.shape[0], self.NANG, self.NFRE), "FL"), dst0, _stream_ptr()))
 
 
+    # -- MPEXCHNG inside the library (include/ecwam_hip.h: ecwam_hip_halo_*)
+    def halo_setup(self, dom) -> None:
+        """dom: decomp.LocalDomain.  Peers in ascending rank order; send lists concatenated in that order."""
+        peers = sorted(set(dom.send) | set(dom.recv))
+        self._halo_peers = peers
+        pa = np.asarray(peers, dtype=np.int32)
+        sc = np.asarray([len(dom.send.get(p, ())) for p in peers], dtype=np.int32)
+        si = np.concatenate([np.asarray(dom.send[p], dtype=np.int32) for p in peers if p in dom.send]) if sc.sum() else np.zeros(0, np.int32)
+        rd = np.asarray([dom.recv.get(p, (0, 0))[0] for p in peers], dtype=np.int32)
+        rc = np.asarray([dom.recv.get(p, (0, 0))[1] for p in peers], dtype=np.int32)
+        self._halo_send_cnt, self._halo_recv_cnt = sc, rc
+        ptr = lambda a: a.ctypes.data if a.size else None
+        self._chk(self.lib.ecwam_hip_halo_setup(self._h, dom.rank, dom.nranks, len(peers), ptr(pa), ptr(sc), ptr(si), ptr(rd), ptr(rc)))
+
+    def comm_unique_id(self) -> bytes:
+        import ctypes
+        buf = ctypes.create_string_buffer(128)
+        self._chk(self.lib.ecwam_hip_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, uid: bytes) -> None:
+        if len(uid) != 128:
+            raise ValueError("RCCL unique id: 128 bytes")
+        self._chk(self.lib.ecwam_hip_comm_init(self._h, uid))
+
+    def _rows(self, fl):
+        if not (fl.is_cuda and fl.is_contiguous() and fl.dtype == self.dtype and fl.dim() == 3):
+            raise ValueError("halo: expected a contiguous device tensor [rows][NANG][M] of the context's precision")
+        return int(fl.shape[1] * fl.shape[2])
+
+    def halo_start(self, fl) -> None:
+        self._chk(self.lib.ecwam_hip_halo_start(self._h, fl.data_ptr(), self._rows(fl), _stream_ptr()))
+
+    def halo_finish(self) -> None:
+        self._chk(self.lib.ecwam_hip_halo_finish(self._h, _stream_ptr()))
+
+    def halo_pack_host(self, fl, host_send) -> None:
+        self._chk(self.lib.ecwam_hip_halo_pack_host(self._h, fl.data_ptr(), self._rows(fl), host_send.data_ptr(), _stream_ptr()))
+
+    def halo_unpack_host(self, fl, host_recv) -> None:
+        self._chk(self.lib.ecwam_hip_halo_unpack_host(self._h, fl.data_ptr(), self._rows(fl), host_recv.data_ptr(), _stream_ptr()))
+
+
 def grid_to_device(grid, dtype, device, lo: int = 0, hi: int | None = None, local=None) -> dict:
     """Upload the grid tables of points [lo,hi) (or a decomp.LocalDomain) as the dict `HipContext.ctuw` expects."""
     npdt = np.float32 if dtype == torch.float32 else np.float64

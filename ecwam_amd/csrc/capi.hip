@@ -5,6 +5,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is loaded with dlopen when a communicator is asked for
+
 #include "dev.h"
 
 static thread_local std::string g_err;
@@ -27,6 +30,17 @@ struct ecwam_hip_ctx {
   // fourth kernel generation (implsch_v4.h): DIA rotations K1 = K -+ r1, K2 = K +- r2, NSDSNTH = nh; ok = the tables have that structure
   int v4_ok = 0, v4_r1 = 0, v4_r2 = 0, v4_nh = 0;
   int implsch_gen = 0;  // 0: the fastest kernel generation that covers the configuration; 2 / 3 / 4: at most that generation (tests)
+  // advection halo exchange (MPEXCHNG): peers, the owned rows each of them needs (concatenated in peer order) and where their rows
+  // land; RCCL communicator + a stream of its own so that the exchange runs beside the interior stencil
+  int rank = 0, nranks = 1;
+  std::vector<int> peer, send_cnt, send_off, recv_dst0, recv_cnt;
+  int n_send = 0, n_recv = 0;
+  int* d_send_idx = nullptr;
+  void* d_send_buf = nullptr;
+  size_t send_buf_bytes = 0;
+  ncclComm_t comm = nullptr;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_done = nullptr;
   ecwam_hip_params p;
   const void* obs = nullptr;  // LSUBGRID: device OBS[n_obs][8][NFRE] (ecwam_hip_set_obstructions), read by CTUW / PROPAGS2
   int n_obs = 0;
@@ -221,6 +235,47 @@ __global__ void k_selftest(int* nbad) {
   if (bad) atomicAdd(nbad, bad);
 }
 
+
+// ---- RCCL through dlopen: the library has no link-time dependency on it (single-GPU hosts never load it) ---------------------------
+struct RcclApi {
+  void* h = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+static RcclApi g_rccl;
+static int rccl_load() {
+  if (g_rccl.h) return 0;
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return fail(std::string("RCCL not found (dlopen librccl.so.1): ") + dlerror());
+#define SYM_(f) g_rccl.f = (decltype(g_rccl.f))dlsym(h, "nccl" #f); if (!g_rccl.f) return fail("librccl: symbol nccl" #f " missing")
+  SYM_(GetUniqueId); SYM_(CommInitRank); SYM_(CommDestroy); SYM_(GroupStart); SYM_(GroupEnd); SYM_(Send); SYM_(Recv); SYM_(GetErrorString);
+#undef SYM_
+  g_rccl.h = h;
+  return 0;
+}
+#define NCCLCHK(x)                                                                                   \
+  do {                                                                                               \
+    ncclResult_t r_ = (x);                                                                           \
+    if (r_ != ncclSuccess) return fail(std::string(#x) + ": " + g_rccl.GetErrorString(r_));        \
+  } while (0)
+
+static void halo_release(ecwam_hip_ctx* c) {
+  if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  if (c->d_send_idx) (void)hipFree(c->d_send_idx);
+  if (c->d_send_buf) (void)hipFree(c->d_send_buf);
+  if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+  c->comm = nullptr; c->d_send_idx = nullptr; c->d_send_buf = nullptr; c->ev_packed = c->ev_done = nullptr; c->comm_stream = nullptr;
+}
+
 extern "C" {
 
 const char* ecwam_hip_last_error(void) { return g_err.c_str(); }
@@ -278,6 +333,7 @@ int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int r
 int ecwam_hip_destroy(ecwam_hip_ctx* c) {
   if (!c) return 0;
   if (c->dtab) (void)hipFree(c->dtab);
+  halo_release(c);
   delete c;
   return 0;
 }
@@ -611,6 +667,136 @@ int ecwam_hip_unpack_rows(ecwam_hip_ctx* c, const void* buf, int n, void* fl, in
   if (n <= 0) return 0;
   const size_t row = (size_t)c->NANG * c->NFRE * c->real_bytes;
   HIPCHK(hipMemcpyAsync((char*)fl + (size_t)dst0 * row, buf, (size_t)n * row, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+// ---- MPEXCHNG inside the library (mpexchng.F90:141-231) -----------------------------------------------------------------------------
+int ecwam_hip_halo_setup(ecwam_hip_ctx* c, int rank, int nranks, int npeers, const int* peer, const int* send_count, const int* send_idx,
+                         const int* recv_dst0, const int* recv_count) {
+  if (!c) return fail("null context");
+  if (nranks < 1 || rank < 0 || rank >= nranks || npeers < 0 || (npeers > 0 && (!peer || !send_count || !recv_dst0 || !recv_count)))
+    return fail("ecwam_hip_halo_setup: bad arguments");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->d_send_idx) { (void)hipFree(c->d_send_idx); c->d_send_idx = nullptr; }
+  c->rank = rank; c->nranks = nranks;
+  c->peer.assign(peer, peer + npeers); c->send_cnt.assign(send_count, send_count + npeers);
+  c->recv_dst0.assign(recv_dst0, recv_dst0 + npeers); c->recv_cnt.assign(recv_count, recv_count + npeers);
+  c->send_off.resize(npeers);
+  c->n_send = 0; c->n_recv = 0;
+  for (int i = 0; i < npeers; i++) {
+    if (peer[i] < 0 || peer[i] >= nranks || peer[i] == rank || send_count[i] < 0 || recv_count[i] < 0 || recv_dst0[i] < 0)
+      return fail("ecwam_hip_halo_setup: bad peer entry");
+    c->send_off[i] = c->n_send; c->n_send += send_count[i]; c->n_recv += recv_count[i];
+  }
+  if (c->n_send > 0) {
+    if (!send_idx) return fail("ecwam_hip_halo_setup: send_idx missing");
+    HIPCHK(hipMalloc(&c->d_send_idx, (size_t)c->n_send * sizeof(int)));
+    HIPCHK(hipMemcpy(c->d_send_idx, send_idx, (size_t)c->n_send * sizeof(int), hipMemcpyHostToDevice));
+  }
+  if (!c->comm_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  }
+  return 0;
+}
+
+int ecwam_hip_halo_counts(ecwam_hip_ctx* c, int* n_send, int* n_recv) {
+  if (!c || !n_send || !n_recv) return fail("ecwam_hip_halo_counts: null argument");
+  *n_send = c->n_send; *n_recv = c->n_recv;
+  return 0;
+}
+
+int ecwam_hip_comm_unique_id(void* id128) {
+  if (!id128) return fail("ecwam_hip_comm_unique_id: null argument");
+  if (rccl_load()) return 1;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId");
+  NCCLCHK(g_rccl.GetUniqueId((ncclUniqueId*)id128));
+  return 0;
+}
+
+int ecwam_hip_comm_init(ecwam_hip_ctx* c, const void* id128) {
+  if (!c || !id128) return fail("ecwam_hip_comm_init: null argument");
+  if (c->nranks < 2) return 0;
+  if (rccl_load()) return 1;
+  HIPCHK(hipSetDevice(c->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  NCCLCHK(g_rccl.CommInitRank(&c->comm, c->nranks, id, c->rank));
+  return 0;
+}
+
+static int halo_pack(ecwam_hip_ctx* c, const void* fl, int rowlen, hipStream_t s) {
+  const size_t need = (size_t)c->n_send * rowlen * c->real_bytes;
+  if (need > c->send_buf_bytes) {
+    if (c->d_send_buf) HIPCHK(hipFree(c->d_send_buf));
+    c->d_send_buf = nullptr; c->send_buf_bytes = 0;
+    HIPCHK(hipMalloc(&c->d_send_buf, need));
+    c->send_buf_bytes = need;
+  }
+  if (c->n_send > 0) {
+    DISPATCH(launch_pack<float>(fl, c->d_send_idx, c->n_send, rowlen, c->d_send_buf, s),
+             launch_pack<double>(fl, c->d_send_idx, c->n_send, rowlen, c->d_send_buf, s));
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
+int ecwam_hip_halo_start(ecwam_hip_ctx* c, void* fl, int rowlen, void* stream) {
+  if (!c) return fail("null context");
+  if (c->nranks < 2 || c->peer.empty()) return 0;
+  if (!fl || rowlen < 1) return fail("ecwam_hip_halo_start: bad arguments");
+  if (!c->comm) return fail("ecwam_hip_halo_start: no communicator (ecwam_hip_comm_init)");
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(c->device));
+  if (halo_pack(c, fl, rowlen, s)) return 1;
+  HIPCHK(hipEventRecord(c->ev_packed, s));                     // everything enqueued on `stream` so far, the pack included
+  HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
+  const size_t rb = (size_t)rowlen * c->real_bytes;
+  NCCLCHK(g_rccl.GroupStart());
+  for (size_t i = 0; i < c->peer.size(); i++) {
+    if (c->send_cnt[i] > 0)
+      NCCLCHK(g_rccl.Send((const char*)c->d_send_buf + (size_t)c->send_off[i] * rb, (size_t)c->send_cnt[i] * rb, ncclChar, c->peer[i], c->comm, c->comm_stream));
+    if (c->recv_cnt[i] > 0)
+      NCCLCHK(g_rccl.Recv((char*)fl + (size_t)c->recv_dst0[i] * rb, (size_t)c->recv_cnt[i] * rb, ncclChar, c->peer[i], c->comm, c->comm_stream));
+  }
+  NCCLCHK(g_rccl.GroupEnd());
+  HIPCHK(hipEventRecord(c->ev_done, c->comm_stream));
+  return 0;
+}
+
+int ecwam_hip_halo_finish(ecwam_hip_ctx* c, void* stream) {
+  if (!c) return fail("null context");
+  if (c->nranks < 2 || c->peer.empty()) return 0;
+  HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->ev_done, 0));
+  return 0;
+}
+
+int ecwam_hip_halo_pack_host(ecwam_hip_ctx* c, const void* fl, int rowlen, void* host_send, void* stream) {
+  if (!c) return fail("null context");
+  if (c->n_send == 0) return 0;
+  if (!fl || !host_send || rowlen < 1) return fail("ecwam_hip_halo_pack_host: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(c->device));
+  if (halo_pack(c, fl, rowlen, s)) return 1;
+  HIPCHK(hipMemcpyAsync(host_send, c->d_send_buf, (size_t)c->n_send * rowlen * c->real_bytes, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+
+int ecwam_hip_halo_unpack_host(ecwam_hip_ctx* c, void* fl, int rowlen, const void* host_recv, void* stream) {
+  if (!c) return fail("null context");
+  if (c->n_recv == 0) return 0;
+  if (!fl || !host_recv || rowlen < 1) return fail("ecwam_hip_halo_unpack_host: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t rb = (size_t)rowlen * c->real_bytes;
+  size_t off = 0;
+  for (size_t i = 0; i < c->peer.size(); i++) {
+    if (c->recv_cnt[i] > 0)
+      HIPCHK(hipMemcpyAsync((char*)fl + (size_t)c->recv_dst0[i] * rb, (const char*)host_recv + off, (size_t)c->recv_cnt[i] * rb, hipMemcpyHostToDevice, s));
+    off += (size_t)c->recv_cnt[i] * rb;
+  }
+  HIPCHK(hipStreamSynchronize(s));
   return 0;
 }
 

@@ -18,13 +18,35 @@ from .tables import Config, Tables
 
 
 class HaloExchange:
-    """MPEXCHNG (mpexchng.F90:141-206): pack -> isend/irecv per neighbouring rank -> halo rows."""
+    """MPEXCHNG (mpexchng.F90:141-206): pack -> point-to-point exchange with the neighbouring ranks -> halo rows.
 
-    def __init__(self, dom: decomp.LocalDomain, device, ctx=None):
+    transport "torch": torch.distributed P2P (backend "nccl" = RCCL) on tensors packed by ecwam_hip_pack_rows.
+    transport "lib":   the library's own exchange (ecwam_hip_halo_start / _finish: RCCL loaded by the library, its own stream) --
+                       what a Fortran host calls; the unique id travels through torch.distributed here, MPI_Bcast there.
+    transport "host":  host-staged (ecwam_hip_halo_pack_host / _unpack_host) with the segments exchanged through the process
+                       group's CPU backend (gloo): an MPI without device pointers, or several ranks sharing one GPU in tests."""
+
+    def __init__(self, dom: decomp.LocalDomain, device, ctx=None, transport: str = "torch"):
         self.dom = dom
         self.ctx = ctx
+        self.transport = transport
+        if transport not in ("torch", "lib", "host"):
+            raise ValueError("halo transport: torch, lib or host")
         self.send_idx = {p: torch.from_numpy(np.ascontiguousarray(ix)).to(device) for p, ix in dom.send.items()}
         self.bufs = {}
+        if transport != "torch" and dom.nranks > 1:
+            if ctx is None:
+                raise ValueError("library halo transports need the HipContext")
+            ctx.halo_setup(dom)
+            if transport == "lib":
+                import torch.distributed as dist
+                uid = torch.zeros(128, dtype=torch.uint8)
+                if dom.rank == 0:
+                    uid = torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8).clone()
+                on_gpu = dist.get_backend() == "nccl"
+                t = uid.to(device) if on_gpu else uid
+                dist.broadcast(t, src=0)
+                ctx.comm_init(bytes(t.cpu().numpy().tobytes()))
 
     def start(self, fl: torch.Tensor) -> list:
         """Pack the rows the neighbours need and post every send / receive; returns the pending requests.  Until `finish`
@@ -33,6 +55,24 @@ class HaloExchange:
             return []
         import torch.distributed as dist
 
+        if self.transport == "lib":
+            self.ctx.halo_start(fl)
+            return [None]
+        if self.transport == "host":
+            rl = int(fl.shape[1] * fl.shape[2])
+            sc, rc = self.ctx._halo_send_cnt, self.ctx._halo_recv_cnt
+            hs = torch.empty((int(sc.sum()), rl), dtype=fl.dtype).pin_memory()
+            hr = torch.empty((int(rc.sum()), rl), dtype=fl.dtype).pin_memory()
+            self.ctx.halo_pack_host(fl, hs)
+            ops, so, ro = [], 0, 0
+            for p, ns, nr in zip(self.ctx._halo_peers, sc, rc):
+                if ns:
+                    ops.append(dist.P2POp(dist.isend, hs[so:so + int(ns)], p))
+                if nr:
+                    ops.append(dist.P2POp(dist.irecv, hr[ro:ro + int(nr)], p))
+                so += int(ns); ro += int(nr)
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            return [("host", reqs, fl, hr, hs)]
         ops = []
         for p, ix in sorted(self.send_idx.items()):
             buf = self.bufs.get((p, int(fl.shape[2])))
@@ -47,10 +87,17 @@ class HaloExchange:
             ops.append(dist.P2POp(dist.irecv, fl[dst0:dst0 + cnt], p))
         return dist.batch_isend_irecv(ops) if ops else []
 
-    @staticmethod
-    def finish(reqs: list) -> None:
+    def finish(self, reqs: list) -> None:
         for r in reqs:
-            r.wait()
+            if r is None:
+                self.ctx.halo_finish()
+            elif isinstance(r, tuple):
+                _, rr, fl, hr, _hs = r
+                for q in rr:
+                    q.wait()
+                self.ctx.halo_unpack_host(fl, hr)
+            else:
+                r.wait()
 
     def __call__(self, fl: torch.Tensor) -> None:
         self.finish(self.start(fl))
@@ -60,7 +107,8 @@ class Wamintgr:
     """Device-resident WAMINTGR for one rank."""
 
     def __init__(self, cfg: Config, grid, prec: str = "sp", device: int = 0, rank: int = 0, nranks: int = 1,
-                 ifrelfmax: int = 0, delpro_lf: float | None = None, weights: str = "otf", strip_width: int = 0):
+                 ifrelfmax: int = 0, delpro_lf: float | None = None, weights: str = "otf", strip_width: int = 0,
+                 halo_transport: str = "torch"):
         # weights: "otf" rebuilds the CTU weights inside PROPAGS2 (no W array, default); "stored" keeps the reference's
         # scheme (CTUW once into W[ij][8][NANG*NFRE_RED], PROPAGS2 streams them).  Bit-identical results.
         self.cfg, self.grid, self.prec = cfg, grid, prec
@@ -71,7 +119,7 @@ class Wamintgr:
         self.dom = decomp.local_domain(grid, rank, nranks)
         self.n, self.nrows = self.dom.n, self.dom.nrows
         self.gd = api.grid_to_device(grid, self.dtype, self.dev, local=self.dom)
-        self.halo = HaloExchange(self.dom, self.dev, self.ctx)
+        self.halo = HaloExchange(self.dom, self.dev, self.ctx, transport=halo_transport)
         self.interior = self.dom.interior()      # rows [a, b) whose stencil reads no halo row
         NANG, NFRE, NR = cfg.nang, cfg.nfre, cfg.nfre_red
         z = dict(dtype=self.dtype, device=self.dev)

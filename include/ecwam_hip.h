@@ -310,6 +310,33 @@ int ecwam_hip_points_to_chunks(ecwam_hip_ctx *ctx, const void *points, void *chu
 int ecwam_hip_pack_rows(ecwam_hip_ctx *ctx, const void *fl, const int *idx, int n, void *buf, void *stream);
 int ecwam_hip_unpack_rows(ecwam_hip_ctx *ctx, const void *buf, int n, void *fl, int dst0, void *stream);
 
+/*
+ * MPEXCHNG inside the library (mpexchng.F90:141-231: pack the rows the neighbouring ranks need, point-to-point exchange,
+ * receive into the halo rows): what a Fortran host needs to run the sea-point block decomposition (mpdecomp.F90:58-100) on
+ * several GPUs, one process per GPU.
+ *   ecwam_hip_halo_setup: rank / nranks of this process and, per neighbouring rank i < npeers: peer[i], send_count[i] owned local
+ *     rows to send (send_idx: their 0-based local indices, the npeers lists concatenated), and the contiguous halo segment
+ *     [recv_dst0[i], recv_dst0[i] + recv_count[i]) of the local row space their rows land in (the reference's NTOPE / IJTOPE and
+ *     NFROMPE / NIJSTART).
+ *   transport 1, RCCL over xGMI (librccl is loaded with dlopen on first use): ecwam_hip_comm_unique_id on rank 0 gives the 128-byte
+ *     id the host broadcasts (MPI_Bcast); ecwam_hip_comm_init(ctx, id) on every rank (collective).  ecwam_hip_halo_start packs on
+ *     `stream` and posts the grouped sends / receives on the library's own stream (the receives write fl's halo rows; rowlen = reals
+ *     per row: NANG*NFRE, or NANG*LFP for the compact fast-wave rows); work enqueued on `stream` afterwards overlaps with the
+ *     exchange and must not touch fl's halo rows until ecwam_hip_halo_finish(ctx, stream) has made `stream` wait for it.
+ *   transport 2, host staged (an MPI library without device-pointer support; several ranks on one GPU in tests):
+ *     ecwam_hip_halo_pack_host fills host_send (n_send rows, peer order, ecwam_hip_halo_counts gives the sizes) and synchronises; the
+ *     host exchanges the segments; ecwam_hip_halo_unpack_host copies host_recv (n_recv rows, peer order) into the halo rows.
+ */
+int ecwam_hip_halo_setup(ecwam_hip_ctx *ctx, int rank, int nranks, int npeers, const int *peer, const int *send_count,
+                         const int *send_idx, const int *recv_dst0, const int *recv_count);
+int ecwam_hip_halo_counts(ecwam_hip_ctx *ctx, int *n_send, int *n_recv);
+int ecwam_hip_comm_unique_id(void *id128);
+int ecwam_hip_comm_init(ecwam_hip_ctx *ctx, const void *id128);
+int ecwam_hip_halo_start(ecwam_hip_ctx *ctx, void *fl, int rowlen, void *stream);
+int ecwam_hip_halo_finish(ecwam_hip_ctx *ctx, void *stream);
+int ecwam_hip_halo_pack_host(ecwam_hip_ctx *ctx, const void *fl, int rowlen, void *host_send, void *stream);
+int ecwam_hip_halo_unpack_host(ecwam_hip_ctx *ctx, void *fl, int rowlen, const void *host_recv, void *stream);
+
 /* Device-memory helpers for hosts without their own HIP binding (the Fortran layer): the counterpart of FIELD_API's
  * device allocation / GET_DEVICE_DATA / SYNC_HOST copies (drvtype_mod.fypp:116-480).  `stream` may be NULL. */
 int ecwam_hip_malloc(ecwam_hip_ctx *ctx, unsigned long long bytes, void **dptr);

@@ -1,0 +1,40 @@
+"""The N>1 code of bench.py on ONE GPU (-m gpu): two fresh child processes (torch.distributed.run, gloo) share device 0 and exchange the
+advection halo host-staged through the library (ecwam_hip_halo_setup / _pack_host / _unpack_host); decomposition, overlap of the
+exchange with the interior stencil, IMPLSCH on each band, the all_reduce of the timings -- everything bench.py --gpus N runs except
+the RCCL transport itself, which needs one GPU per rank.  The spectra after a few steps equal the single-rank run bit for bit."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, env):
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_bench_two_ranks_on_one_gpu_match_single_rank(tmp_path, nranks):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--grid", "48", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    one = _run([sys.executable, "bench.py", "--gpus", "1", "--dump", str(tmp_path / "one")] + common, env)
+    port = 29500 + (os.getpid() % 2000) + nranks
+    many = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}", "--master-addr", "127.0.0.1",
+                 "--master-port", str(port), "bench.py", "--gpus", str(nranks), "--share-gpu", "--dump", str(tmp_path / "many")] + common, env)
+    assert many["n_gpus"] == nranks and many["config"]["halo"] == "host" and many["finite"] and one["finite"]
+    a = np.load(str(tmp_path / "one") + ".0.npy")
+    b = np.concatenate([np.load(str(tmp_path / "many") + f".{r}.npy") for r in range(nranks)])
+    assert a.shape == b.shape and np.array_equal(a, b)
+    assert many["value"] > 0 and abs(many["swh_norm_rank0"]["max"]) < 50

@@ -282,10 +282,23 @@ class HipContext:
         return tuple(res)
 
     # -- NEWWIND (newwind.F90:126-161)
-    def newwind(self, ff, ff_next):
+    def newwind(self, ff, ff_next, icode_wnd: int | None = None):
+        """icode_wnd: ICODE_CPL of a coupled run (newwind.F90:120-124); default ICODE of the parameters."""
         n = ff.shape[0]
-        self._chk(self.lib.ecwam_hip_newwind(self._h, n, self._real(ff, (n, NFF), "FF"), self._real(ff_next, (n, NFF), "FF_NEXT"),
-                                             _stream_ptr()))
+        a = (self._h, n, self._real(ff, (n, NFF), "FF"), self._real(ff_next, (n, NFF), "FF_NEXT"))
+        if icode_wnd is None:
+            self._chk(self.lib.ecwam_hip_newwind(*a, _stream_ptr()))
+        else:
+            self._chk(self.lib.ecwam_hip_newwind_icode(*a, int(icode_wnd), _stream_ptr()))
+
+    def nosource(self, kijs, kijl, fl1, mij, xllws):
+        """LLSOURCE = F (wamintgr.F90:152-160): FL1 = MAX(FL1, EPSMIN), MIJ = NFRE, XLLWS = 0 on rows [kijs, kijl)."""
+        nrow = fl1.shape[0]
+        if not (0 <= kijs <= kijl <= min(nrow, mij.shape[0], xllws.shape[0])):
+            raise ValueError("NOSOURCE: KIJS/KIJL outside the operands")
+        self._chk(self.lib.ecwam_hip_nosource(self._h, kijs, kijl, self._real(fl1, (nrow, self.NANG, self.NFRE), "FL1"),
+                                              self._int(mij, (mij.shape[0],), "MIJ"),
+                                              self._real(xllws, (xllws.shape[0], self.NANG, self.NFRE), "XLLWS"), _stream_ptr()))
 
     # -- layout conversion (propag_wam.F90:124-137, 373-400)
     def chunks_to_points(self, chunked, points, nproma, nchnk, npts, n2, n3):

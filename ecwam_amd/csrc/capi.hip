@@ -60,7 +60,8 @@ int launch_sinput3(const void*, int, int, int, const void*, const void*, const v
 int launch_sdissip3(const void*, int, int, int, int, const void*, const void*, const void*, void*, int, hipStream_t);
 int launch_snonlin3(const void*, int, int, int, int, const void*, const void*, const void*, void*, void*, int, hipStream_t);
 template <typename T> void launch_norm(const void*, int, int, double, double*, int, hipStream_t);
-template <typename T> void launch_newwind(const void*, int, void*, const void*, hipStream_t);
+template <typename T> void launch_newwind(const void*, int, void*, const void*, int, hipStream_t);
+template <typename T> void launch_nosource(const void*, int, int, int, void*, void*, int*, hipStream_t);
 template <typename T> void launch_c2p(const void*, void*, int, int, int, int, int, hipStream_t);
 template <typename T> void launch_p2c(const void*, void*, int, int, int, int, int, hipStream_t);
 template <typename T> void launch_pack(const void*, const int*, int, int, void*, hipStream_t);
@@ -530,7 +531,8 @@ int ecwam_hip_propags2_refra(ecwam_hip_ctx* c, const void* f1, void* f3, int n, 
 int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws,
                       double* wam2nemo, void* dbg, void* stream) {
   if (!c) return fail("null context");
-  if (kijl < kijs) return fail("ecwam_hip_implsch: bad range");
+  if (kijl < kijs || kijs < 0) return fail("ecwam_hip_implsch: bad range");
+  HIPCHK(hipSetDevice(c->device));
   if (kijl > kijs && (!fl1 || !wvprpt || !ff || !intf || !mij || !xllws)) return fail("ecwam_hip_implsch: null pointer");
   if (kijl > kijs && c->p.lwnemocou && !wam2nemo) return fail("ecwam_hip_implsch: LWNEMOCOU needs the WAVE2OCEAN buffer");
   if (!c->p.lwnemocou) wam2nemo = nullptr;
@@ -624,12 +626,40 @@ int ecwam_hip_outwnorm(ecwam_hip_ctx* c, const void* field, int stride, int n, d
   return 0;
 }
 
-int ecwam_hip_newwind(ecwam_hip_ctx* c, int n, void* ff, const void* ff_next, void* stream) {
+int ecwam_hip_newwind_icode(ecwam_hip_ctx* c, int n, void* ff, const void* ff_next, int icode_wnd, void* stream) {
   if (!c) return fail("null context");
   if (n > 0 && (!ff || !ff_next)) return fail("ecwam_hip_newwind: null pointer");
+  if (icode_wnd < 1 || icode_wnd > 3) return fail("ecwam_hip_newwind: ICODE_WND must be 1, 2 or 3");
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH(launch_newwind<float>(c->dtab, n, ff, ff_next, s), launch_newwind<double>(c->dtab, n, ff, ff_next, s));
+  DISPATCH(launch_newwind<float>(c->dtab, n, ff, ff_next, icode_wnd, s), launch_newwind<double>(c->dtab, n, ff, ff_next, icode_wnd, s));
   HIPCHK(hipGetLastError());
+  return 0;
+}
+int ecwam_hip_newwind(ecwam_hip_ctx* c, int n, void* ff, const void* ff_next, void* stream) {
+  if (!c) return fail("null context");
+  return ecwam_hip_newwind_icode(c, n, ff, ff_next, c->p.icode, stream);
+}
+
+int ecwam_hip_nosource(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, int* mij, void* xllws, void* stream) {
+  if (!c) return fail("null context");
+  if (kijs < 0 || kijl < kijs) return fail("ecwam_hip_nosource: bad range");
+  if (kijl > kijs && (!fl1 || !mij || !xllws)) return fail("ecwam_hip_nosource: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH(launch_nosource<float>(c->dtab, kijs, kijl, c->NANG * c->NFRE, fl1, xllws, mij, s),
+           launch_nosource<double>(c->dtab, kijs, kijl, c->NANG * c->NFRE, fl1, xllws, mij, s));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ecwam_hip_host_register(ecwam_hip_ctx* c, void* host, unsigned long long bytes) {
+  if (!c || !host) return fail("ecwam_hip_host_register: null argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipHostRegister(host, bytes, hipHostRegisterDefault));
+  return 0;
+}
+int ecwam_hip_host_unregister(ecwam_hip_ctx* c, void* host) {
+  if (!c || !host) return fail("ecwam_hip_host_unregister: null argument");
+  HIPCHK(hipHostUnregister(host));
   return 0;
 }
 

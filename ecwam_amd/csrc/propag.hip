@@ -1060,12 +1060,12 @@ __global__ void k_curmask(int n, int NANG, int slot, const int* __restrict__ cfl
 
 // NEWWIND (newwind.F90:126-161)
 template <typename T>
-__global__ void k_newwind(const DevTab<T>* __restrict__ tab, int n, T* __restrict__ ff, const T* __restrict__ ffn) {
+__global__ void k_newwind(const DevTab<T>* __restrict__ tab, int n, T* __restrict__ ff, const T* __restrict__ ffn, int icode_wnd) {
   int ij = blockIdx.x * blockDim.x + threadIdx.x;
   if (ij >= n) return;
   T* f = ff + (size_t)ij * ECWAM_HIP_NFF;
   const T* g = ffn + (size_t)ij * ECWAM_HIP_NFF;
-  if (tab->ICODE == 3) {
+  if (icode_wnd == 3) {   // ICODE_WND = ICODE_CPL when LWCOU, ICODE otherwise (newwind.F90:120-124)
     const T wght = T(1) / m_max(tab->WSPMIN_RESET_TAUW, tab->EPSMIN);
     T u = g[3];
     f[3] = u;
@@ -1267,9 +1267,26 @@ void launch_propags2_gen(const void* tab, int irefra, const void* f1, void* f3, 
 #undef GEN_ARGS
 }
 template <typename T>
-void launch_newwind(const void* tab, int n, void* ff, const void* ffn, hipStream_t s) {
+void launch_newwind(const void* tab, int n, void* ff, const void* ffn, int icode_wnd, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_newwind<T>, dim3((n + 255) / 256), dim3(256), 0, s, (const DevTab<T>*)tab, n, (T*)ff, (const T*)ffn);
+  hipLaunchKernelGGL(k_newwind<T>, dim3((n + 255) / 256), dim3(256), 0, s, (const DevTab<T>*)tab, n, (T*)ff, (const T*)ffn, icode_wnd);
+}
+// NO SOURCE TERM CONTRIBUTION (wamintgr.F90:152-160): FL1 = MAX(FL1, EPSMIN), MIJ = NFRE, XLLWS = 0 on rows [kijs, kijl)
+template <typename T>
+__global__ void k_nosource(const DevTab<T>* __restrict__ tab, long long e0, long long e1, T* __restrict__ fl1, T* __restrict__ xllws, int kijs,
+                           int kijl, int* __restrict__ mij) {
+  const T eps = tab->EPSMIN;
+  for (long long g = e0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; g < e1; g += (long long)gridDim.x * blockDim.x) {
+    fl1[g] = m_max(fl1[g], eps);
+    xllws[g] = T(0);
+  }
+  for (int ij = kijs + blockIdx.x * blockDim.x + threadIdx.x; ij < kijl; ij += gridDim.x * blockDim.x) mij[ij] = tab->NFRE;
+}
+template <typename T>
+void launch_nosource(const void* tab, int kijs, int kijl, int rowlen, void* fl1, void* xllws, int* mij, hipStream_t s) {
+  if (kijl <= kijs) return;
+  const long long e0 = (long long)kijs * rowlen, e1 = (long long)kijl * rowlen;
+  hipLaunchKernelGGL(k_nosource<T>, dim3(grid_for(e1 - e0)), dim3(256), 0, s, (const DevTab<T>*)tab, e0, e1, (T*)fl1, (T*)xllws, kijs, kijl, mij);
 }
 template <typename T>
 void launch_c2p(const void* ch, void* pt, int nproma, int nchnk, int npts, int n2, int n3, hipStream_t s) {
@@ -1303,7 +1320,8 @@ void launch_pack(const void* fl, const int* idx, int n, int rowlen, void* buf, h
   template void launch_ctuw<T>(const void*, int, int, int, double, int, int, const int*, const void*, double, const void*,       \
                                const void*, const int*, const int*, const int*, void*, void*, const void*, const void*, void*,   \
                                int*, int, const void*, hipStream_t);                                                              \
-  template void launch_newwind<T>(const void*, int, void*, const void*, hipStream_t);                                             \
+  template void launch_newwind<T>(const void*, int, void*, const void*, int, hipStream_t);                                        \
+  template void launch_nosource<T>(const void*, int, int, int, void*, void*, int*, hipStream_t);                                  \
   template void launch_propdot<T>(const void*, int, int, int, const int*, const void*, double, const void*, const int*,         \
                                   const int*, const void*, const void*, const void*, const void*, const void*, void*, hipStream_t); \
   template void launch_ctuwini_only<T>(int, int, const int*, const int*, void*, void*, hipStream_t);                               \

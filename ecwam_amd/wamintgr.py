@@ -337,12 +337,19 @@ class Wamintgr:
     def implsch(self) -> None:
         self.ctx.implsch(0, self.n, self.fl1, self.wvprpt, self.ff, self.intf, self.mij, self.xllws)
 
-    def step(self, advect: bool = True, source: bool = True) -> None:
+    def nosource(self) -> None:
+        """NO SOURCE TERM CONTRIBUTION (wamintgr.F90:152-160, LLSOURCE = F)."""
+        self.ctx.nosource(0, self.n, self.fl1, self.mij, self.xllws)
+
+    def step(self, advect: bool = True, source: bool = True, llsource: bool = True) -> None:
         if advect:
             self.propag()
         self.newwind()
         if source:
-            self.implsch()
+            if llsource:
+                self.implsch()
+            else:
+                self.nosource()
 
     # ---- restart spectra in the reference's file layout (writefl.F90:110-118, one record per rank)
     def write_restart(self, path: str) -> None:

@@ -290,8 +290,13 @@ int ecwam_hip_sinput3(ecwam_hip_ctx *ctx, int n, const void *fl1, const void *wv
  * coefficient D (SL = D*F); pt as for ecwam_hip_sinput3 (UFRIC, RAORW, SIN / COS of WDWAVE are read). */
 int ecwam_hip_sdissip3(ecwam_hip_ctx *ctx, int n, const void *fl1, const void *wvprpt, const void *pt, void *fld, int mode, void *stream);
 
-/* NEWWIND forcing hand-over (newwind.F90:126-161, ICODE_WND=3): FF <- FF_NEXT members + TAUW cap */
+/* NEWWIND forcing hand-over (newwind.F90:126-161): FF <- FF_NEXT members + TAUW cap.  ecwam_hip_newwind takes ICODE_WND = ICODE
+ * of the parameters; a coupled host (LWCOU) passes ICODE_CPL through ecwam_hip_newwind_icode (newwind.F90:120-124). */
 int ecwam_hip_newwind(ecwam_hip_ctx *ctx, int n, void *ff, const void *ff_next, void *stream);
+int ecwam_hip_newwind_icode(ecwam_hip_ctx *ctx, int n, void *ff, const void *ff_next, int icode_wnd, void *stream);
+/* The LLSOURCE = F branch of WAMINTGR (wamintgr.F90:152-160) on device rows [kijs, kijl): FL1 = MAX(FL1, EPSMIN), MIJ = NFRE,
+ * XLLWS = 0. */
+int ecwam_hip_nosource(ecwam_hip_ctx *ctx, int kijs, int kijl, void *fl1, int *mij, void *xllws, void *stream);
 
 /*
  * Layout conversion between the reference's chunked host-shaped arrays and the device layout
@@ -345,6 +350,9 @@ int ecwam_hip_memcpy_h2d(ecwam_hip_ctx *ctx, void *dst_dev, const void *src_host
 int ecwam_hip_memcpy_d2h(ecwam_hip_ctx *ctx, void *dst_host, const void *src_dev, unsigned long long bytes, void *stream);
 int ecwam_hip_memset(ecwam_hip_ctx *ctx, void *dst_dev, int value, unsigned long long bytes, void *stream);
 int ecwam_hip_sync(ecwam_hip_ctx *ctx, void *stream);
+/* Page-lock host arrays the host keeps copying to / from (the reference pins its fields when WAM_HAVE_CUDA, wvalloc.F90:49-52) */
+int ecwam_hip_host_register(ecwam_hip_ctx *ctx, void *host, unsigned long long bytes);
+int ecwam_hip_host_unregister(ecwam_hip_ctx *ctx, void *host);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-def _write_case(path, m, cfg, grid, nproma, nstep, obs=None):
+def _write_case(path, m, cfg, grid, nproma, nstep, obs=None, nosource=False):
     from ecwam_amd import lib as L, synthetic as syn
 
     t = m.t
@@ -28,7 +28,7 @@ def _write_case(path, m, cfg, grid, nproma, nstep, obs=None):
         hdr = np.array([cfg.nang, cfg.nfre, cfg.nfre_red, nproma, nchnk, n, grid.ngy, cfg.idelt, cfg.idelpro,
                         np.dtype(dt).itemsize, nstep, ctypes.sizeof(params), len(keep), int(m.ifrelfmax),
                         int(m.delpro_lf or 0), int(cfg.irefra != 0), int(bool(getattr(m, 'llcflcuroff', False))),
-                        int(obs is not None)], dtype=np.int32)
+                        int(obs is not None), int(nosource)], dtype=np.int32)
         f.write(hdr.tobytes())
         f.write(bytes(params))
         for a in keep:
@@ -65,9 +65,12 @@ def _write_case(path, m, cfg, grid, nproma, nstep, obs=None):
     return nchnk
 
 
-@pytest.mark.parametrize("prec,lf,irefra,subgrid", [("sp", 0, 0, False), ("dp", 0, 0, False), ("sp", 5, 0, False), ("sp", 0, 2, False),
-                                                    ("dp", 0, 3, False), ("sp", 0, 0, True), ("sp", 0, 2, True)])
-def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec, lf, irefra, subgrid):
+@pytest.mark.parametrize("prec,lf,irefra,subgrid,nosource", [("sp", 0, 0, False, False), ("dp", 0, 0, False, False), ("sp", 5, 0, False, False),
+                                                             ("sp", 0, 2, False, False), ("dp", 0, 3, False, False), ("sp", 0, 0, True, False),
+                                                             ("sp", 0, 2, True, False), ("sp", 0, 0, False, True), ("dp", 5, 0, False, True)])
+def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec, lf, irefra, subgrid, nosource):
+    """nosource: YOWSTAT's LLSOURCE = F -- the branch of wamintgr.F90:152-160 (FL1 = MAX(FL1, EPSMIN), MIJ = NFRE, XLLWS = 0) runs on the
+    device copies (ecwam_hip_nosource); the advected spectra still hold exact zeros from the land neighbours before the clamp."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from ecwam_amd import build, grid as G
@@ -90,12 +93,15 @@ def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec, lf, irefra, su
         m.set_obstructions(obs)
     nproma, nstep = 24, 2
     case, out = str(tmp_path / "case.bin"), str(tmp_path / "out.bin")
-    nchnk = _write_case(case, m, cfg, g, nproma, nstep, obs)
+    nchnk = _write_case(case, m, cfg, g, nproma, nstep, obs, nosource=nosource)
     r = subprocess.run([exe, case, out], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
     for _ in range(nstep):
-        m.step()
+        m.step(llsource=not nosource)
     torch.cuda.synchronize()
+    if nosource:
+        epsmin = float(m.t.EPSMIN)
+        assert float(m.fl1[: g.nsea].min()) >= epsmin and int(m.mij.min()) == cfg.nfre == int(m.mij.max()) and float(m.xllws.abs().max()) == 0.0
     dt = m.npdt
     n = g.nsea
     raw = np.fromfile(out, dtype=np.uint8)

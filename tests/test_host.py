@@ -28,7 +28,8 @@ def test_c_abi_exports_every_declared_symbol():
     assert h.ecwam_hip_abi_version() == int(re.search(r"#define ECWAM_HIP_ABI_VERSION (\d+)", hdr).group(1)) == 2
     # the parameter struct seen from Python has the size the C compiler gives it
     src = '#include "ecwam_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu", sizeof(ecwam_hip_params), sizeof(ecwam_hip_tables));return 0;}'
-    exe = os.path.join(ROOT, "ecwam_amd", "lib", "_abi_sizes")
+    import tempfile
+    exe = os.path.join(tempfile.mkdtemp(), "abi_sizes")
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
     a, b = (int(x) for x in subprocess.run([exe], capture_output=True, check=True).stdout.split())
     import ctypes

@@ -84,6 +84,10 @@ def cpu_baseline(nang: int, nfre: int, prec: str, target_s: float = 15.0) -> dic
     w = o.ctu_weights(g, cg_ext, float(cfg.idelpro))
     steps, el = o.timed_steps(g, fl, w, pr, env, ff, intf, max_steps=200, target_s=target_s)   # C calls only, arrays prepared once
     return {"value": n * steps / el, "unit": "grid-point spectral steps/s", "cores": cores, "kind": "port",
+            "implsch_only": n * steps / o.t_implsch, "propags2_only": n * steps / o.t_propags2,
+            "note": "the C restatement integrates one sea point at a time (scalar inner loops over K and M; the reference blocks NPROMA "
+                    "points innermost and vectorises over them, implsch.F90:152-170), unpinned against the reference (DESIGN.md section 4): "
+                    "a lower bound of what the reference's OpenMP path does on these cores, not a measurement of it",
             "sample": f"O48 all-ocean grid ({n} sea points), {nang}x{nfre} spectrum, {prec}, {steps} full steps "
                       f"(PROPAGS2 + IMPLSCH), oracle/ C restatement (speed build: gcc -O3 -march=x86-64-v3) with OpenMP over points, {cores} threads "
                       f"(host reports {os.cpu_count()} logical CPUs)"}

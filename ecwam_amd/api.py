@@ -221,48 +221,6 @@ class HipContext:
         """Cap the IMPLSCH kernel generation (2, 3, 4; 0 = automatic): include/ecwam_hip.h ecwam_hip_set_implsch_generation."""
         self._chk(self.lib.ecwam_hip_set_implsch_generation(self._h, int(gen)))
 
-    # -- SNONLIN alone in the three-points-per-wavefront layout (diagnostic seam, include/ecwam_hip.h)
-    def snonlin3(self, fl1, depth, akmean, mode: int = 0):
-        """Returns (SL, FLD) as [n][NANG][NFRE] tensors (re-ordered from the kernel's [n][NFRE][18][2] pair layout)."""
-        n = fl1.shape[0]
-        if self.dtype != torch.float32 or self.NANG != 36:
-            raise ValueError("SNONLIN3: single precision and NANG = 36 only")
-        p1 = self._real(fl1, (n, self.NANG, self.NFRE), "FL1")
-        pd, pa = self._real(depth, (n,), "DEPTH"), self._real(akmean, (n,), "AKMEAN")
-        sl = torch.empty((n, self.NFRE, 18, 2), dtype=self.dtype, device=self.device)
-        fld = torch.empty_like(sl)
-        self._chk(self.lib.ecwam_hip_snonlin3(self._h, n, p1, pd, pa, sl.data_ptr(), fld.data_ptr(), int(mode), _stream_ptr()))
-
-        def std(x):   # [n][M][j][h] -> [n][K = j + 18 h][M]
-            return x.permute(0, 3, 2, 1).reshape(n, 36, self.NFRE)
-
-        return std(sl), std(fld)
-
-    def sinput3(self, fl1, wvprpt, pt, mode: int = 0):
-        """SINPUT_ARD alone (second SINFLX call) in the three-points-per-wavefront layout; returns FLD, SPOS, XLLWS as [n][NANG][NFRE]
-        and the row integrals [n][NFRE][4] (include/ecwam_hip.h)."""
-        n = fl1.shape[0]
-        if self.dtype != torch.float32 or self.NANG != 36:
-            raise ValueError("SINPUT3: single precision and NANG = 36 only")
-        p1 = self._real(fl1, (n, self.NANG, self.NFRE), "FL1")
-        pw, pp = self._real(wvprpt, (n, NWPR, self.NFRE), "WVPRPT"), self._real(pt, (n, 12), "PT")
-        o = [torch.empty((n, self.NFRE, 18, 2), dtype=self.dtype, device=self.device) for _ in range(3)]
-        xys = torch.empty((n, self.NFRE, 4), dtype=self.dtype, device=self.device)
-        self._chk(self.lib.ecwam_hip_sinput3(self._h, n, p1, pw, pp, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), xys.data_ptr(),
-                                             int(mode), _stream_ptr()))
-        return [x.permute(0, 3, 2, 1).reshape(n, 36, self.NFRE) for x in o] + [xys]
-
-    def sdissip3(self, fl1, wvprpt, pt, mode: int = 0):
-        """SDISSIP_ARD alone in the three-points-per-wavefront layout; returns the dissipation coefficient as [n][NANG][NFRE]."""
-        n = fl1.shape[0]
-        if self.dtype != torch.float32 or self.NANG != 36:
-            raise ValueError("SDISSIP3: single precision and NANG = 36 only")
-        p1 = self._real(fl1, (n, self.NANG, self.NFRE), "FL1")
-        pw, pp = self._real(wvprpt, (n, NWPR, self.NFRE), "WVPRPT"), self._real(pt, (n, 12), "PT")
-        o = torch.empty((n, self.NFRE, 18, 2), dtype=self.dtype, device=self.device)
-        self._chk(self.lib.ecwam_hip_sdissip3(self._h, n, p1, pw, pp, o.data_ptr(), int(mode), _stream_ptr()))
-        return o.permute(0, 3, 2, 1).reshape(n, 36, self.NFRE)
-
     # -- OUTBS subset (outblock.F90 parameters 1-3) and OUTWNORM statistics, on the device
     def outbs(self, kijs, kijl, fl1, out, zmiss: float = -999.0):
         nrow = fl1.shape[0]

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libecwam_hip.so")
-SOURCES = ["capi.hip", "propag.hip", "implsch.hip", "implsch4.hip", "outbs.hip", "snonlin3.hip"]
+SOURCES = ["capi.hip", "propag.hip", "implsch.hip", "implsch4.hip", "outbs.hip"]
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # IMPLSCH is VALU-issue bound: single-precision divide/sqrt by the hardware reciprocal / square root plus one
 # refinement (<= 2.5 ulp) instead of the correctly rounded sequences; double precision is unaffected.
@@ -19,7 +19,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 
 
 INCLUDE = os.path.join(HERE, "..", "include", "ecwam_hip.h")
-DEPS = {"capi.hip": ["dev.h"], "propag.hip": ["dev.h"], "implsch.hip": ["dev.h", "implsch_v1.h", "implsch_v2.h", "implsch_v3.h"], "implsch4.hip": ["dev.h", "implsch_v1.h", "implsch_v2.h", "implsch_v4.h"], "outbs.hip": ["dev.h"], "snonlin3.hip": ["dev.h"]}
+DEPS = {"capi.hip": ["dev.h"], "propag.hip": ["dev.h"], "implsch.hip": ["dev.h", "implsch_v1.h", "implsch_v2.h"], "implsch4.hip": ["dev.h", "implsch_v1.h", "implsch_v2.h", "implsch_v4.h"], "outbs.hip": ["dev.h"]}
 
 
 def _obj_stale(src: str, obj: str) -> bool:

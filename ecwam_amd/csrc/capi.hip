@@ -29,7 +29,7 @@ struct ecwam_hip_ctx {
   int implsch_variant;  // 2: two-tile fused-sweep kernel (needs the DIA rotation structure), 1: three-tile kernel
   // fourth kernel generation (implsch_v4.h): DIA rotations K1 = K -+ r1, K2 = K +- r2, NSDSNTH = nh; ok = the tables have that structure
   int v4_ok = 0, v4_r1 = 0, v4_r2 = 0, v4_nh = 0;
-  int implsch_gen = 0;  // 0: the fastest kernel generation that covers the configuration; 2 / 3 / 4: at most that generation (tests)
+  int implsch_gen = 0;  // 0: the fastest kernel generation that covers the configuration; 1 / 2 / 4: at most that generation (tests)
   // advection halo exchange (MPEXCHNG): peers, the owned rows each of them needs (concatenated in peer order) and where their rows
   // land; RCCL communicator + a stream of its own so that the exchange runs beside the interior stencil
   int rank = 0, nranks = 1;
@@ -56,9 +56,6 @@ template <typename T> void launch_propags2_gen(const void*, int, const void*, vo
 template <typename T> void launch_propags2_otf(const void*, const void*, void*, int, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const int*, int, int, int, int, int, int, const void*, int, double, int, void*, int, hipStream_t);
 template <typename T> void launch_copy_freq_range(const void*, void*, int, int, int, int, int, int, hipStream_t);
 template <typename T> int launch_outbs(const void*, int, int, const void*, double, void*, int, int, hipStream_t);
-int launch_sinput3(const void*, int, int, int, const void*, const void*, const void*, void*, void*, void*, void*, int, hipStream_t);
-int launch_sdissip3(const void*, int, int, int, int, const void*, const void*, const void*, void*, int, hipStream_t);
-int launch_snonlin3(const void*, int, int, int, int, const void*, const void*, const void*, void*, void*, int, hipStream_t);
 template <typename T> void launch_norm(const void*, int, int, double, double*, int, hipStream_t);
 template <typename T> void launch_newwind(const void*, int, void*, const void*, int, hipStream_t);
 template <typename T> void launch_nosource(const void*, int, int, int, void*, void*, int*, hipStream_t);
@@ -404,7 +401,9 @@ int ecwam_hip_propags2_otf_split(ecwam_hip_ctx* c, const void* f1, void* f3, int
   hipStream_t s = (hipStream_t)stream;
   const int N = (c->NANG << 16) | (c->NFRE << 8) | c->NFRE_RED;
   copy_rest = copy_rest ? 1 : 0;
-  { const char* e_ = getenv("ECWAM_HIP_OTF_WALK"); if (e_ && atoi(e_) == 0) copy_rest |= 2; }  // diagnostics: plain grid-stride tile walk
+#ifdef ECWAM_HIP_DIAGNOSTICS
+  { const char* e_ = getenv("ECWAM_HIP_OTF_WALK"); if (e_ && atoi(e_) == 0) copy_rest |= 2; }  // plain grid-stride tile walk
+#endif
   DISPATCH(launch_propags2_otf<float>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, c->obs, ifrelfmax, delpro_lf, in_nfre, gout, gout_nfre, s),
            launch_propags2_otf<double>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, c->obs, ifrelfmax, delpro_lf, in_nfre, gout, gout_nfre, s));
   HIPCHK(hipGetLastError());
@@ -538,10 +537,8 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   if (!c->p.lwnemocou) wam2nemo = nullptr;
   hipStream_t s = (hipStream_t)stream;
   int rc, variant = c->implsch_variant;
-  { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_VARIANT"); if (e_ && atoi(e_) == 1) variant = 1; }  // diagnostics: force the 3-tile kernel
+  if (c->implsch_gen == 1) variant = 1;   // tests: the three-tile kernel (its own case: interaction tables without the rotation structure)
   if (c->p.llnormagam) variant |= 16;
-  // third kernel generation (implsch_v3.h): single precision, 36 directions, at most 17 saturation taps, at most 64 frequencies
-  if (c->real_bytes == 4 && c->NANG == 36 && 2 * c->p.nsdsnth + 1 <= 17 && c->NFRE <= 64 && c->p.mlsthg >= c->NFRE) variant |= 64;
   if (c->p.llgcbz0 || c->p.lciwa1 || c->p.lciwa2 || c->p.lciwa3 || c->p.lciscal || c->p.lwnemocou || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin || c->p.iphys == 0 || c->p.icode != 3 || !c->p.lwvflx_snl) variant |= 32;
   // fourth kernel generation (implsch_v4.h): flag set A without the optional branches, single and double precision
   if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !(variant & (16 | 32)) && (variant & 15) == 2 && !wam2nemo && !dbg) {
@@ -549,7 +546,6 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
              rc = launch_implsch4<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, s));
     if (rc == 0) { HIPCHK(hipGetLastError()); return 0; }
   }
-  if (c->implsch_gen == 2) variant &= ~64;
   DISPATCH(rc = launch_implsch<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s),
            rc = launch_implsch<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s));
   if (rc) return fail("ecwam_hip_implsch: unsupported spectral size for the LDS tiling");
@@ -559,7 +555,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
 
 int ecwam_hip_set_implsch_generation(ecwam_hip_ctx* c, int gen) {
   if (!c) return fail("null context");
-  if (gen != 0 && gen != 2 && gen != 3 && gen != 4) return fail("ecwam_hip_set_implsch_generation: 0 (automatic), 2, 3 or 4");
+  if (gen != 0 && gen != 1 && gen != 2 && gen != 4) return fail("ecwam_hip_set_implsch_generation: 0 (automatic), 1, 2 or 4");
   c->implsch_gen = gen;
   return 0;
 }
@@ -573,39 +569,6 @@ int ecwam_hip_outbs(ecwam_hip_ctx* c, int kijs, int kijl, const void* fl1, doubl
   DISPATCH(rc = launch_outbs<float>(c->dtab, kijs, kijl, fl1, zmiss, out, c->NANG, c->NFRE, s),
            rc = launch_outbs<double>(c->dtab, kijs, kijl, fl1, zmiss, out, c->NANG, c->NFRE, s));
   if (rc) return fail("ecwam_hip_outbs: unsupported spectral size");
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-
-int ecwam_hip_snonlin3(ecwam_hip_ctx* c, int n, const void* fl1, const void* depth, const void* akmean, void* sl, void* fld, int mode,
-                       void* stream) {
-  if (!c) return fail("null context");
-  if (n < 0 || (n > 0 && (!fl1 || !depth || !akmean || !sl || !fld))) return fail("ecwam_hip_snonlin3: bad arguments");
-  if (c->real_bytes != 4 || c->p.isnonlin != 0) return fail("ecwam_hip_snonlin3: single precision, ISNONLIN = 0 only");
-  if (launch_snonlin3(c->dtab, c->NANG, c->NFRE, c->implsch_variant == 2, n, fl1, depth, akmean, sl, fld, mode, (hipStream_t)stream))
-    return fail("ecwam_hip_snonlin3: needs NANG = 36 and interaction tables with the rotation structure");
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-
-int ecwam_hip_sinput3(ecwam_hip_ctx* c, int n, const void* fl1, const void* wvprpt, const void* pt, void* fld, void* spos, void* xllws,
-                      void* xys, int mode, void* stream) {
-  if (!c) return fail("null context");
-  if (n < 0 || (n > 0 && (!fl1 || !wvprpt || !pt || !fld || !spos || !xllws || !xys))) return fail("ecwam_hip_sinput3: bad arguments");
-  if (c->real_bytes != 4 || c->p.iphys != 1 || c->p.llnormagam || c->p.tauwshelter == 0.0)
-    return fail("ecwam_hip_sinput3: single precision, IPHYS = 1, LLNORMAGAM = F, TAUWSHELTER /= 0 only");
-  if (launch_sinput3(c->dtab, c->NANG, c->NFRE, n, fl1, wvprpt, pt, fld, spos, xllws, xys, mode, (hipStream_t)stream))
-    return fail("ecwam_hip_sinput3: needs NANG = 36");
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-
-int ecwam_hip_sdissip3(ecwam_hip_ctx* c, int n, const void* fl1, const void* wvprpt, const void* pt, void* fld, int mode, void* stream) {
-  if (!c) return fail("null context");
-  if (n < 0 || (n > 0 && (!fl1 || !wvprpt || !pt || !fld))) return fail("ecwam_hip_sdissip3: bad arguments");
-  if (c->real_bytes != 4 || c->p.iphys != 1) return fail("ecwam_hip_sdissip3: single precision, IPHYS = 1 only");
-  if (launch_sdissip3(c->dtab, c->NANG, c->NFRE, 2 * c->p.nsdsnth + 1, n, fl1, wvprpt, pt, fld, mode, (hipStream_t)stream))
-    return fail("ecwam_hip_sdissip3: needs NANG = 36 and at most 17 taps");
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -1,8 +1,8 @@
-// Launcher of the IMPLSCH kernel generations 1-3 (implsch_v1.h: lane = direction, three tiles; implsch_v2.h: two tiles, fused sweep;
-// implsch_v3.h: three points per wavefront).  The fourth generation lives in implsch4.hip.
+// Launcher of the one-point-per-wavefront IMPLSCH kernels (implsch_v1.h: lane = direction, three tiles -- interaction tables without the
+// rotation structure; implsch_v2.h: two tiles, fused sweep -- every configuration).  The several-points-per-wavefront kernel of flag
+// set A lives in implsch4.hip.
 #include "implsch_v1.h"
 #include "implsch_v2.h"
-#include "implsch_v3.h"
 
 template <typename T>
 int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws,
@@ -10,32 +10,9 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
   const int n = kijl - kijs;
   if (n <= 0) return 0;
   const bool norma = (variant & 16) != 0;  // LLNORMAGAM, packed by capi.hip
-  const bool v3ok = (variant & 64) != 0;   // the configuration fits the three-points-per-wavefront kernel (capi.hip)
   const bool rare = (variant & 32) != 0;   // any of LLGCBZ0 / LCIWA2 / LCIWA3 / LCISCAL / LWNEMOCOU: the build that carries those branches
   variant &= 15;
   const bool variant2 = (variant == 2);
-  if constexpr (sizeof(T) == 4) {
-    // third kernel generation (three points per wavefront, implsch_v3.h): flag set A without the optional branches, 36 directions.
-    // ECWAM_HIP_IMPLSCH_V3=0 falls back to k_implsch2 (diagnostics, and the parity test that keeps both generations checked)
-    const char* e3 = getenv("ECWAM_HIP_IMPLSCH_V3");
-    if (!(e3 && atoi(e3) == 0) && v3ok && variant2 && !norma && !rare && NANG == 2 * V3G && !w2n && !dbg) {
-      const size_t per3 = (size_t)((V3P * (NANG * NFRE + V3_NFAC * NFRE + 4 * NFRE) + V3P * NSC + 3) & ~3) * sizeof(float);
-      int wpb3 = 1;
-      { const char* ew = getenv("ECWAM_HIP_V3_WPB"); if (ew) wpb3 = atoi(ew); }   // diagnostics
-#define LAUNCH3(W)                                                                                                             \
-  do {                                                                                                                         \
-    const size_t shmem = per3 * W;                                                                                             \
-    if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_implsch3<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-    hipLaunchKernelGGL((k_implsch3<W>), dim3((n + V3P * W - 1) / (V3P * W)), dim3(64 * W), shmem, s, (const DevTab<float>*)tab, kijs, \
-                       kijl, (float*)fl1, (const float*)wvprpt, (float*)ff, (float*)intf, mij, (float*)xllws);                 \
-  } while (0)
-      if (wpb3 == 4) LAUNCH3(4);
-      else if (wpb3 == 2) LAUNCH3(2);
-      else LAUNCH3(1);
-#undef LAUNCH3
-      return 0;
-    }
-  }
   const int ntile = (variant == 2) ? 2 : 3;
   const int NAP = variant2 ? NANG : (NANG | 1);
   const int nscr = variant2 ? 0 : 64;
@@ -56,9 +33,11 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
     if (waves > best) { best = waves; wpb = cand; }
   }
   if (best == 0) return 1;
-  { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_WPB"); if (e_ && variant == 2) { const int w = atoi(e_); if (w == 3 || w == 1) wpb = w; } }
   size_t shmem = per_wave * wpb;
-  { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_PADLDS"); if (e_) shmem += (size_t)atoi(e_); }  // diagnostics: lower the residency
+#ifdef ECWAM_HIP_DIAGNOSTICS   // timing builds only (tools/build_diag.sh)
+  { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_WPB"); if (e_ && variant == 2) { const int w = atoi(e_); if (w == 3 || w == 1) { wpb = w; shmem = per_wave * wpb; } } }
+  { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_PADLDS"); if (e_) { const int pad = atoi(e_); if (pad > 0 && shmem + (size_t)pad <= 160 * 1024) shmem += (size_t)pad; } }
+#endif
   const int blocks = (n + wpb - 1) / wpb;
 #define LAUNCHK(KFN)                                                                                                         \
   do {                                                                                                                       \

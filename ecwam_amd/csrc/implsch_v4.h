@@ -2,7 +2,7 @@
 // G = NANG/2 lanes per point, lane j of a point owns the ADJACENT direction pair (K = 2j, 2j+1).  Single and double precision,
 // NANG = 36 / 24 / 12 (PP = 3 / 5 / 10), NFRE = 36.
 //
-// What changed against implsch_v3.h, and why (tools/ubench_valu.hip, profiles/r02_ubench_valu.txt, MI355X):
+// What changed against the round-1 three-points-per-wavefront kernel (k_implsch3: pairs (K, K+18), ds_bpermute rotations), and why (tools/ubench_valu.hip, profiles/r02_ubench_valu.txt, MI355X):
 //   * ds_bpermute_b32 costs 6 cycles of the CU's single LDS pipe per wave instruction, ds_read_b32 / ds_read_b64 cost 2: the 53
 //     bpermutes per interaction frequency of k_implsch3 kept the LDS pipe ~70 % busy during the sweep.  Here every rotation in K
 //     is a ds_read_b64 of an LDS row at a per-lane wrapped address (the lane's pair shifted by an even number of directions;

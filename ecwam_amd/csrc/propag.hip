@@ -1194,7 +1194,9 @@ void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, 
       (const T*)sinph, klon, klat, kcor, (const T*)wlat, (const T*)wcor, (const T*)cg, (const T*)cosphm1, order, kijs, kijl, m0, \
       m1, copy_rest, ntiles, (const T*)obs, mlf, (T)delpro_lf, in_k, (T*)gout, gout_k
   int vw = W;
-  { const char* e_ = getenv("ECWAM_HIP_OTF_VW"); if (e_) vw = atoi(e_); }  // diagnostics
+#ifdef ECWAM_HIP_DIAGNOSTICS
+  { const char* e_ = getenv("ECWAM_HIP_OTF_VW"); if (e_) vw = atoi(e_); }
+#endif
   if (gout && (gout_k % W != 0 || (uintptr_t)gout % 16 != 0)) gout = nullptr;   // checked by the caller; never taken
   const bool vec = vw >= W && aligned && NFRE % W == 0 && in_k % W == 0;   // a range boundary inside a vector is handled by the kernel
   if (obs) {  // LSUBGRID
@@ -1250,7 +1252,9 @@ void launch_propags2_gen(const void* tab, int irefra, const void* f1, void* f3, 
   // 8 bytes per lane is the fastest width here (measured at O320 sp: 7.9 ms, against 9.2 ms at 16 bytes and 9.0 ms scalar):
   // the VW sets of 21 weights a thread keeps live cost more occupancy than the wider accesses save
   int vw = 2;
-  { const char* e_ = getenv("ECWAM_HIP_GEN_VW"); if (e_) vw = atoi(e_); }  // diagnostics
+#ifdef ECWAM_HIP_DIAGNOSTICS
+  { const char* e_ = getenv("ECWAM_HIP_GEN_VW"); if (e_) vw = atoi(e_); }
+#endif
   const bool v4 = vw >= W && aligned && NFRE % W == 0 && NR % W == 0 && m0 % W == 0 && m1 % W == 0;
   const bool v2 = vw >= 2 && aligned && NFRE % 2 == 0 && NR % 2 == 0 && m0 % 2 == 0 && m1 % 2 == 0;
   if (!f1)

@@ -250,10 +250,10 @@ int ecwam_hip_propags2_refra(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n
 int ecwam_hip_implsch(ecwam_hip_ctx *ctx, int kijs, int kijl, void *fl1, const void *wvprpt, void *ff, void *intf, int *mij,
                       void *xllws, double *wam2nemo, void *dbg, void *stream);
 /*
- * IMPLSCH exists in several kernel generations with identical results up to rounding (csrc/implsch_v2.h: one point per wavefront,
- * every configuration; implsch_v3.h / implsch_v4.h: several points per wavefront, flag set A).  ecwam_hip_implsch launches the
- * fastest one that covers the context's configuration; gen = 2, 3 or 4 caps the choice at that generation (parity tests that keep
- * the generations checked against each other), gen = 0 restores the automatic choice.
+ * IMPLSCH exists in several kernel generations with identical results up to rounding (csrc/implsch_v1.h / implsch_v2.h: one point per
+ * wavefront, every configuration; implsch_v4.h: several points per wavefront, flag set A).  ecwam_hip_implsch launches the fastest
+ * one that covers the context's configuration; gen = 1, 2 or 4 caps the choice at that generation (parity tests that keep the
+ * generations checked against each other), gen = 0 restores the automatic choice.
  */
 int ecwam_hip_set_implsch_generation(ecwam_hip_ctx *ctx, int gen);
 
@@ -266,29 +266,6 @@ int ecwam_hip_set_implsch_generation(ecwam_hip_ctx *ctx, int gen);
  */
 int ecwam_hip_outbs(ecwam_hip_ctx *ctx, int kijs, int kijl, const void *fl1, double zmiss, void *out, void *stream);
 int ecwam_hip_outwnorm(ecwam_hip_ctx *ctx, const void *field, int stride, int n, double zmiss, double *result, void *stream);
-
-/*
- * SNONLIN alone (snonlin.F90:10-13, 100-330: the discrete interaction approximation; ISNONLIN = 0, single precision,
- * NANG = 36) in the three-points-per-wavefront lane layout planned for the next IMPLSCH kernel: a
- * diagnostic seam to validate and time that layout, not used by ecwam_hip_implsch.  fl1: device float FL1[n][NANG][NFRE];
- * depth, akmean: device float [n] (WVENVI%DEPTH, AKMEAN of FKMEAN); sl, fld: device float [n][NFRE][18][2], the
- * contributions SNONLIN adds to SL and FLD (starting from zero), direction K = j + 18 h at [..][j][h].
- * mode 0: the DIA; mode 1: load / store only (SL = F, FLD = 0: the timing baseline).  Returns non-zero for other configurations.
- */
-int ecwam_hip_snonlin3(ecwam_hip_ctx *ctx, int n, const void *fl1, const void *depth, const void *akmean, void *sl, void *fld,
-                       int mode, void *stream);
-/*
- * SINPUT_ARD alone (sinput_ard.F90:10-14, 153-520) in the same lane layout: the second SINFLX call (NGST = 2, LLSNEG = T), sheltering
- * on (TAUWSHELTER /= 0), LLNORMAGAM = F, single precision, NANG = 36.  pt: device float [n][12] = UFRIC, Z0M, RAORW, SIG_N, TEMP2,
- * PTURB, AIRD_PVISC (the swell-damping set-up of sinput_ard.F90:213-258), SIN(WDWAVE), COS(WDWAVE), 3 spare; wvprpt as for
- * ecwam_hip_implsch.  Out: fld (FLD), spos (SPOS), xllws [n][NFRE][18][2] as above; xys [n][NFRE][4] = SUM_K SPOS*SINTH,
- * SUM_K SPOS*COSTH, SUM_K SPOS, 0 (what STRESSO integrates).  mode as above.
- */
-int ecwam_hip_sinput3(ecwam_hip_ctx *ctx, int n, const void *fl1, const void *wvprpt, const void *pt, void *fld, void *spos,
-                      void *xllws, void *xys, int mode, void *stream);
-/* SDISSIP_ARD alone (sdissip_ard.F90:10-12, 117-314; SSDSC3 = 0) in the same layout: fld [n][NFRE][18][2] = the dissipation
- * coefficient D (SL = D*F); pt as for ecwam_hip_sinput3 (UFRIC, RAORW, SIN / COS of WDWAVE are read). */
-int ecwam_hip_sdissip3(ecwam_hip_ctx *ctx, int n, const void *fl1, const void *wvprpt, const void *pt, void *fld, int mode, void *stream);
 
 /* NEWWIND forcing hand-over (newwind.F90:126-161): FF <- FF_NEXT members + TAUW cap.  ecwam_hip_newwind takes ICODE_WND = ICODE
  * of the parameters; a coupled host (LWCOU) passes ICODE_CPL through ecwam_hip_newwind_icode (newwind.F90:120-124). */

@@ -289,12 +289,18 @@ class Oracle:
         mij = np.zeros(n, np.int32)
         self.lib.ora_set_ibrmem(None)
         steps, t0 = 0, time.perf_counter()
+        self.t_propags2 = self.t_implsch = 0.0      # seconds inside each of the two C calls (separate rates)
         while True:
+            ta = time.perf_counter()
             self.lib.ora_propags2(C.c_int(0), C.c_int(n), self._p(f1), self._p(f3), self._p(g["klon"]), self._p(g["klat"]),
                                   self._p(g["kcor"]), self._p(w["SUMWN"]), self._p(w["WLONN"]), self._p(w["WLATN"]), self._p(w["WCORN"]),
                                   self._p(w["WKPMN"]), C.c_int(1), C.c_int(self.NFRE_RED))
+            tb = time.perf_counter()
             rc = self.lib.ora_implsch_w2n(C.c_int(n), self._p(f3), *(self._p(x) for x in a), self._p(env), self._p(ff), self._p(intf),
                                           self._p(mij), self._p(xllws), None, None)
+            tc = time.perf_counter()
+            self.t_propags2 += tb - ta
+            self.t_implsch += tc - tb
             if rc:
                 raise RuntimeError(f"ora_implsch abort branch rc={rc}")
             f1, f3 = f3, f1          # the land row of both buffers is zero

@@ -250,7 +250,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
   WSYNC();
 }
 
-// One wavefront advances PP sea points.  Lanes beyond PP G shadow lanes of point 0 and the points of a short last wave shadow its
+// One wavefront advances PP sea points.  Lanes beyond PP G shadow other lanes and the points of a short last wave shadow its
 // last point: shadows run the same instructions on the same data, so their LDS and global stores repeat their original's values
 // at the same addresses -- no store is predicated.
 template <typename T, int NANG, int PP, int R1, int R2, int NH>
@@ -277,9 +277,15 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   L.lane = threadIdx.x & 63;
   const int lane = L.lane;
   {
-    const int pl = lane / G;
-    L.p = pl < PP ? pl : 0;                        // spare lanes shadow point 0
-    L.j = lane - pl * G;
+    // spare lanes (64 - PP G of them) shadow a lane of their own half-wave (a 64-bit LDS access is served in two groups of 32
+    // lanes; equal addresses inside a group are one broadcast access): no bank conflicts from the shadows
+    int src = lane;
+    if (lane >= PP * G) {
+      if (PP * G > 32) src = lane >= 32 ? 32 : 0;
+      else { src = lane >= 32 ? lane - 32 : 0; if (src >= PP * G) src = 0; }
+    }
+    L.p = src / G;
+    L.j = src - L.p * G;
   }
   const int p = L.p, j = L.j;
   const int ij0 = kijs + blockIdx.x * PP;

@@ -25,7 +25,8 @@ struct ecwam_hip_ctx {
   int real_bytes;
   int device;
   int NANG, NFRE, NFRE_RED;
-  void* dtab;  // DevTab<T> in device memory
+  void* dtab = nullptr;  // DevTab<T> in device memory
+  double* norm_scratch = nullptr;   // ecwam_hip_outwnorm: per-context reduction scratch (4 + 4 x 256 doubles)
   int implsch_variant;  // 2: two-tile fused-sweep kernel (needs the DIA rotation structure), 1: three-tile kernel
   // fourth kernel generation (implsch_v4.h): DIA rotations K1 = K -+ r1, K2 = K +- r2, NSDSNTH = nh; ok = the tables have that structure
   int v4_ok = 0, v4_r1 = 0, v4_r2 = 0, v4_nh = 0;
@@ -304,26 +305,40 @@ int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int r
     return fail("ecwam_hip_create: only IPHYS=0/1, ISNONLIN=0/1/2, IREFRA=0..3, ICODE=1..3 are on the hot path (SURVEY.md 8a)");
   if (p->lciwa1 && (!t->cideac || p->nict < 2 || p->nich < 2 || p->nict * p->nich > 36 * 16))
     return fail("ecwam_hip_create: LCIWA1 (SDICE1) needs the CIDEAC table (tables.cideac, NICT*NICH <= 576)");
+  {   // every table the kernels read must be there (the optional ones: cideac, checked above)
+    const void* need[] = {t->fr, t->dfim, t->dfimofr, t->dfimfr, t->dfim_sim, t->rhowg_dfim, t->zpifr, t->fr5, t->cofrm4, t->flmax, t->th, t->costh,
+                          t->sinth, t->wtauhf, t->swellft, t->ikp, t->ikp1, t->ikm, t->ikm1, t->af11, t->k1w, t->k2w, t->k11w, t->k21w, t->inlcoef,
+                          t->rnlcoef, t->indicessat, t->satweights, t->kpm, t->jxo, t->jyo, t->kcr};
+    for (const void* q : need) if (!q) return fail("ecwam_hip_create: a required table pointer is NULL");
+    if (p->nwav_gc > 0 && (!t->xk_gc || !t->xkm_gc || !t->omega_gc || !t->omxkm3_gc || !t->cm_gc || !t->c2osqrtvg_gc || !t->xkmsqrtvgoc2_gc ||
+                           !t->om3gmkm_gc || !t->delkcc_gc_ns || !t->delkcc_omxkm3_gc)) return fail("ecwam_hip_create: a gravity-capillary table pointer is NULL");
+  }
   HIPCHK(hipSetDevice(device));
   ecwam_hip_ctx* c = new ecwam_hip_ctx();
   c->real_bytes = real_bytes; c->device = device; c->NANG = p->nang; c->NFRE = p->nfre; c->NFRE_RED = p->nfre_red; c->p = *p;
+#define HIPCHK_CTX(x)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (x);                                                                           \
+    if (e_ != hipSuccess) { if (c->dtab) (void)hipFree(c->dtab); delete c; return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } \
+  } while (0)
   if (real_bytes == 4) {
     std::vector<DevTab<float>> h(1);
     build_tab<float>(p, t, h.data());
     c->implsch_variant = h[0].DIA_PULL ? 2 : 1;
     v4_probe<float>(h[0], c);
     if ((p->llgcbz0 || p->lciwa1 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou || p->lwnemocouwrs || p->lwnemocoustrn || p->isnonlin || p->iphys == 0 || p->icode != 3 || !p->lwvflx_snl) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
-    HIPCHK(hipMalloc(&c->dtab, sizeof(DevTab<float>)));
-    HIPCHK(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<float>), hipMemcpyHostToDevice));
+    HIPCHK_CTX(hipMalloc(&c->dtab, sizeof(DevTab<float>)));
+    HIPCHK_CTX(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<float>), hipMemcpyHostToDevice));
   } else {
     std::vector<DevTab<double>> h(1);
     build_tab<double>(p, t, h.data());
     c->implsch_variant = h[0].DIA_PULL ? 2 : 1;
     v4_probe<double>(h[0], c);
     if ((p->llgcbz0 || p->lciwa1 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou || p->lwnemocouwrs || p->lwnemocoustrn || p->isnonlin || p->iphys == 0 || p->icode != 3 || !p->lwvflx_snl) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
-    HIPCHK(hipMalloc(&c->dtab, sizeof(DevTab<double>)));
-    HIPCHK(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<double>), hipMemcpyHostToDevice));
+    HIPCHK_CTX(hipMalloc(&c->dtab, sizeof(DevTab<double>)));
+    HIPCHK_CTX(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<double>), hipMemcpyHostToDevice));
   }
+#undef HIPCHK_CTX
   *out = c;
   return 0;
 }
@@ -331,6 +346,7 @@ int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int r
 int ecwam_hip_destroy(ecwam_hip_ctx* c) {
   if (!c) return 0;
   if (c->dtab) (void)hipFree(c->dtab);
+  if (c->norm_scratch) (void)hipFree(c->norm_scratch);
   halo_release(c);
   delete c;
   return 0;
@@ -578,14 +594,13 @@ int ecwam_hip_outwnorm(ecwam_hip_ctx* c, const void* field, int stride, int n, d
   if (n < 0 || stride < 1 || !result || (n > 0 && !field)) return fail("ecwam_hip_outwnorm: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const int nb = 256;
-  double* scratch = nullptr;
-  HIPCHK(hipMalloc(&scratch, (size_t)(4 + 4 * nb) * sizeof(double)));
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->norm_scratch) HIPCHK(hipMalloc(&c->norm_scratch, (size_t)(4 + 4 * nb) * sizeof(double)));
+  double* scratch = c->norm_scratch;
   DISPATCH(launch_norm<float>(field, stride, n, zmiss, scratch, nb, s), launch_norm<double>(field, stride, n, zmiss, scratch, nb, s));
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(result, scratch, 4 * sizeof(double), hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(scratch);
-  HIPCHK(e);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(result, scratch, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
   return 0;
 }
 

@@ -1138,6 +1138,11 @@ __global__ void k_pack_rows(const T* __restrict__ fl, const int* __restrict__ id
 }
 
 // ---- host launchers (called from capi.hip) ---------------------------------------------------------
+// dynamic LDS beyond the default 64 KB limit (double precision, 48 frequencies, obstructions: 80 KB of the CU's 160 KB)
+template <typename K>
+static inline void allow_lds(K kfn, size_t shmem) {
+  if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+}
 static inline int grid_for(long long total, int block = 256) {
   long long b = (total + block - 1) / block;
   const long long cap = 256LL * 16;  // 256 CUs x 16 blocks, grid-stride beyond (guide G11)
@@ -1200,14 +1205,14 @@ void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, 
   if (gout && (gout_k % W != 0 || (uintptr_t)gout % 16 != 0)) gout = nullptr;   // checked by the caller; never taken
   const bool vec = vw >= W && aligned && NFRE % W == 0 && in_k % W == 0;   // a range boundary inside a vector is handled by the kernel
   if (obs) {  // LSUBGRID
-    if (vec) hipLaunchKernelGGL((k_propags2_otf<T, W, true>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
-    else hipLaunchKernelGGL((k_propags2_otf<T, 1, true>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
+    if (vec) { allow_lds(k_propags2_otf<T, W, true>, shmem); hipLaunchKernelGGL((k_propags2_otf<T, W, true>), dim3(grid), dim3(256), shmem, s, OTF_ARGS); }
+    else { allow_lds(k_propags2_otf<T, 1, true>, shmem); hipLaunchKernelGGL((k_propags2_otf<T, 1, true>), dim3(grid), dim3(256), shmem, s, OTF_ARGS); }
   } else if (vec)
-    hipLaunchKernelGGL((k_propags2_otf<T, W, false>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
+    { allow_lds(k_propags2_otf<T, W, false>, shmem); hipLaunchKernelGGL((k_propags2_otf<T, W, false>), dim3(grid), dim3(256), shmem, s, OTF_ARGS); }
   else if (vw >= 2 && aligned && NFRE % 2 == 0 && in_k % 2 == 0)
-    hipLaunchKernelGGL((k_propags2_otf<T, 2, false>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
+    { allow_lds(k_propags2_otf<T, 2, false>, shmem); hipLaunchKernelGGL((k_propags2_otf<T, 2, false>), dim3(grid), dim3(256), shmem, s, OTF_ARGS); }
   else
-    hipLaunchKernelGGL((k_propags2_otf<T, 1, false>), dim3(grid), dim3(256), shmem, s, OTF_ARGS);
+    { allow_lds(k_propags2_otf<T, 1, false>, shmem); hipLaunchKernelGGL((k_propags2_otf<T, 1, false>), dim3(grid), dim3(256), shmem, s, OTF_ARGS); }
 #undef OTF_ARGS
 }
 template <typename T>
@@ -1258,16 +1263,16 @@ void launch_propags2_gen(const void* tab, int irefra, const void* f1, void* f3, 
   const bool v4 = vw >= W && aligned && NFRE % W == 0 && NR % W == 0 && m0 % W == 0 && m1 % W == 0;
   const bool v2 = vw >= 2 && aligned && NFRE % 2 == 0 && NR % 2 == 0 && m0 % 2 == 0 && m1 % 2 == 0;
   if (!f1)
-    hipLaunchKernelGGL((k_propags2_gen<T, 1, true, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
+    { allow_lds(k_propags2_gen<T, 1, true, false>, shmem); hipLaunchKernelGGL((k_propags2_gen<T, 1, true, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS); }
   else if (obs) {
-    if (v2) hipLaunchKernelGGL((k_propags2_gen<T, 2, false, true>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
-    else hipLaunchKernelGGL((k_propags2_gen<T, 1, false, true>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
+    if (v2) { allow_lds(k_propags2_gen<T, 2, false, true>, shmem); hipLaunchKernelGGL((k_propags2_gen<T, 2, false, true>), dim3(grid), dim3(256), shmem, s, GEN_ARGS); }
+    else { allow_lds(k_propags2_gen<T, 1, false, true>, shmem); hipLaunchKernelGGL((k_propags2_gen<T, 1, false, true>), dim3(grid), dim3(256), shmem, s, GEN_ARGS); }
   } else if (v4)
-    hipLaunchKernelGGL((k_propags2_gen<T, W, false, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
+    { allow_lds(k_propags2_gen<T, W, false, false>, shmem); hipLaunchKernelGGL((k_propags2_gen<T, W, false, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS); }
   else if (v2)
-    hipLaunchKernelGGL((k_propags2_gen<T, 2, false, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
+    { allow_lds(k_propags2_gen<T, 2, false, false>, shmem); hipLaunchKernelGGL((k_propags2_gen<T, 2, false, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS); }
   else
-    hipLaunchKernelGGL((k_propags2_gen<T, 1, false, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
+    { allow_lds(k_propags2_gen<T, 1, false, false>, shmem); hipLaunchKernelGGL((k_propags2_gen<T, 1, false, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS); }
 #undef GEN_ARGS
 }
 template <typename T>

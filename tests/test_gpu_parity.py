@@ -836,3 +836,34 @@ def test_implsch_kernel_generations_agree(api):
         assert np.max(np.abs(a["FF"].astype(float) - b["FF"].astype(float)) / ffs) < 5e-5, gen
         st = H.compare_implsch(a, b, case["tables"])
         assert st["intf_max_rel_all"] < 5e-3, (gen, st)
+
+
+@pytest.mark.parametrize("prec", ["sp", "dp"])
+def test_restart_record_round_trip_through_the_device(api, prec, tmp_path):
+    """writefl.F90:110-118 / getspec: the device spectra written as one unformatted record (((FL(IJ,K,M),IJ),K),M) and read back into
+    a second model reproduce the state bit for bit, and the restarted model takes the same next step; the file read with
+    scipy.io.FortranFile (an independent reader of Fortran sequential records) holds FL(IJ,K,M) in the reference's index order."""
+    from scipy.io import FortranFile
+
+    from ecwam_amd import grid as G
+    from ecwam_amd.wamintgr import Wamintgr
+
+    cfg = Config(nang=12, nfre=36, nfre_red=25, idelt=900, idelpro=900)
+    g = G.build_grid(16, mask="continents")
+    a = Wamintgr(cfg, g, prec)
+    a.init_synthetic(seed=3)
+    a.step()
+    f = str(tmp_path / "BLS_restart")
+    a.write_restart(f)
+    rec = FortranFile(f, "r").read_reals(dtype=a.npdt)
+    fl_host = a.fl1[: g.nsea].cpu().numpy()
+    assert rec.size == fl_host.size and np.array_equal(rec.reshape((cfg.nfre, cfg.nang, g.nsea)).transpose(2, 1, 0), fl_host)
+    b = Wamintgr(cfg, g, prec)
+    b.init_synthetic(seed=3)
+    b.ff.copy_(a.ff); b.intf.copy_(a.intf)          # the restart file of the reference carries the spectra only (writefl.F90)
+    b.read_restart(f)
+    assert torch.equal(a.fl1[: g.nsea], b.fl1[: g.nsea])
+    a.step(); b.step()
+    torch.cuda.synchronize()
+    assert torch.equal(a.fl1[: g.nsea], b.fl1[: g.nsea]) and torch.equal(a.mij, b.mij) and torch.equal(a.xllws, b.xllws)
+    a.ctx.close(); b.ctx.close()

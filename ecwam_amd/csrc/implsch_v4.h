@@ -52,24 +52,83 @@ __device__ __forceinline__ V2<T> v4_same(V2<T> v, int addr) {
   r.y = v4_bp(addr, v.y);
   return r;
 }
-// all-reduce over the G lanes of a point: G = 18: rotations by 9, then 3 and 6, then 1 and 2; G = 12: 6, 3, then 1 and 2; G = 6: 3, then
-// 1 and 2 (byte addresses of the source lanes)
-struct V4Rot { int a0, a1, a2, a3, a4; };
-template <int G, typename T>
-__device__ __forceinline__ V2<T> v4_allsum(V2<T> v, const V4Rot& r) {
-  v = v + v4_same<T>(v, r.a0);
-  if (G == 18) v = v + (v4_same<T>(v, r.a1) + v4_same<T>(v, r.a2));
-  if (G == 12) v = v + v4_same<T>(v, r.a1);
-  v = v + (v4_same<T>(v, r.a3) + v4_same<T>(v, r.a4));
+// all-reduce over the G lanes of a point.
+//   G = 18 (36 directions, three points per wave): lanes 0..47 hold pairs 0..15 of the three points, one point per DPP row of 16
+//   lanes; lanes 48..53 hold pairs 16, 17 ("extras", two lanes per point).  A reduction folds the extras into lanes 0, 1 of the row
+//   (one ds_bpermute: a0 = the extra of lanes 0, 1, the lane itself elsewhere, fold = 1 / 0), rotates inside the row (v_*_dpp
+//   row_ror 8, 4, 2, 1: no LDS) and hands the total to the extras and the shadows (one ds_bpermute: a1 = lane 0 of the row for
+//   them, the lane itself in rows 0..2).  ds_bpermute costs 6 cycles of the CU's LDS pipe: 2 per quantity instead of 5.
+//   G = 12 / 6: rotations by 6, 3, then 1 and 2 / by 3, then 1 and 2 (byte addresses of the source lanes).
+template <typename T>
+struct V4Rot { int a0, a1, a2, a3, a4; T fold; };
+template <int CTRL>
+__device__ __forceinline__ float v4_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double v4_dpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+#define V4_ROW_ROR(n) (0x120 + (n))
+template <typename T>
+__device__ __forceinline__ V2<T> v4_rowsum(V2<T> v) {
+  T x = v.x, y = v.y;   // component-wise: v_add_f32_dpp takes the rotated operand directly, a packed add would need two v_mov_dpp first
+  x += v4_dpp<V4_ROW_ROR(8)>(x); y += v4_dpp<V4_ROW_ROR(8)>(y);
+  x += v4_dpp<V4_ROW_ROR(4)>(x); y += v4_dpp<V4_ROW_ROR(4)>(y);
+  x += v4_dpp<V4_ROW_ROR(2)>(x); y += v4_dpp<V4_ROW_ROR(2)>(y);
+  x += v4_dpp<V4_ROW_ROR(1)>(x); y += v4_dpp<V4_ROW_ROR(1)>(y);
+  return V2<T>{x, y};
+}
+template <typename T>
+__device__ __forceinline__ T v4_rowmax(T v) {
+  v = m_max(v, v4_dpp<V4_ROW_ROR(8)>(v));
+  v = m_max(v, v4_dpp<V4_ROW_ROR(4)>(v));
+  v = m_max(v, v4_dpp<V4_ROW_ROR(2)>(v));
+  v = m_max(v, v4_dpp<V4_ROW_ROR(1)>(v));
+  return v;
+}
+// single precision: v_max_f32_dpp directly (the compiler keeps v_mov_dpp + a canonicalising v_max + v_max per step); the s_nop covers
+// the two wait states between a VALU write of a register and its use as a DPP operand
+template <>
+__device__ __forceinline__ float v4_rowmax<float>(float v) {
+  asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+               : "+v"(v));
   return v;
 }
 template <int G, typename T>
-__device__ __forceinline__ T v4_allmax(T v, const V4Rot& r) {
-  v = m_max(v, v4_bp(r.a0, v));
-  if (G == 18) v = m_max(v, m_max(v4_bp(r.a1, v), v4_bp(r.a2, v)));
-  if (G == 12) v = m_max(v, v4_bp(r.a1, v));
-  v = m_max(v, m_max(v4_bp(r.a3, v), v4_bp(r.a4, v)));
-  return v;
+__device__ __forceinline__ V2<T> v4_allsum(V2<T> v, const V4Rot<T>& r) {
+  if constexpr (G == 18) {
+    v = v + r.fold * v4_same<T>(v, r.a0);
+    v = v4_rowsum<T>(v);
+    return v4_same<T>(v, r.a1);
+  } else {
+    v = v + v4_same<T>(v, r.a0);
+    if (G == 12) v = v + v4_same<T>(v, r.a1);
+    v = v + (v4_same<T>(v, r.a3) + v4_same<T>(v, r.a4));
+    return v;
+  }
+}
+// one quantity (the other half of a pair would be wasted exchanges)
+template <int G, typename T>
+__device__ __forceinline__ T v4_allsum1(T v, const V4Rot<T>& r) {
+  if constexpr (G == 18) {
+    v = v + r.fold * v4_bp(r.a0, v);
+    v = v + v4_dpp<V4_ROW_ROR(8)>(v);
+    v = v + v4_dpp<V4_ROW_ROR(4)>(v);
+    v = v + v4_dpp<V4_ROW_ROR(2)>(v);
+    v = v + v4_dpp<V4_ROW_ROR(1)>(v);
+    return v4_bp(r.a1, v);
+  } else {
+    v = v + v4_bp(r.a0, v);
+    if (G == 12) v = v + v4_bp(r.a1, v);
+    v = v + (v4_bp(r.a3, v) + v4_bp(r.a4, v));
+    return v;
+  }
 }
 
 // the pair (X(2j+r), X(2j+r+1)) of an LDS row; sh[i] = index of element (2j + 2(i-NSH)) mod NANG of the lane's point in a row
@@ -104,10 +163,10 @@ struct V4Ctx {
   T* sq;          // [M] SQRT(WAVNUM)
   T* zcn;         // [M] LOG(WAVNUM Z0M) of the current SINFLX call
   T* c;           // scalars of the point [NSC]
-  V4Rot rot;
+  V4Rot<T> rot;
   V2<T> sinth, costh;
   // module tables per frequency, lane m holds M = m+1: broadcast with v_readlane inside the M loops
-  T rDFIM, rDFIMOFR, rDFIMFR, rZPIFR, rRHOWG, rCOFRM4, rFLMAX, rC5;   // rC5 = -SWELLF5 2 SQRT(2 NU_AIR SIG) (sinput_ard.F90:343)
+  T rDFIM, rDFIMOFR, rDFIMFR, rZPIFR, rRHOWG, rCOFRM4, rFLMAX, rC5, rT1;   // rC5 = -SWELLF5 2 SQRT(2 NU_AIR SIG), rT1 = -SWELLF 16 SIG**2 / G (sinput_ard.F90:343-347)
 };
 enum { Q4_BSC = 0, Q4_SBO, Q4_CINV, Q4_WAVNUM };   // Q4_BSC = WAVNUM XK2CG / 2 pi
 
@@ -120,14 +179,13 @@ __device__ __forceinline__ int v4_opaque_zero() {
 }
 
 // SINPUT_ARD (sinput_ard.F90:153-520) for one SINFLX call.  Outputs: XLLWS masks of the two directions of the lane (bit m), the row
-// integrals X, Y, S of the frequencies the lane owns (m = s G + j), the FEMEANWS integrands (wse: x = SUM DFIM F, y = SUM DFIMOFR F
+// integrals X, Y of the frequencies the lane owns (m = s G + j), the FEMEANWS integrands (wse: x = SUM DFIM F, y = SUM DFIMOFR F
 // over the windsea bins; wslast = windsea part of the last row), apl (negative wind input per direction) and -- LLSNEG -- the
 // wind-input coefficient of every row into gfl (the point's XLLWS block, [M][K]).
 template <typename T, int NANG, int PP, int NGST, bool LLSNEG>
 __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UFRIC, T Z0M, T RAORW, T SIG_N, T TEMP2, T PTURB, T AIRD_PVISC,
-                          T sinwd, T coswd, T* __restrict__ gfl, unsigned long long& xm0, unsigned long long& xm1, V2<T>& wse,
-                          V2<T>& wslast, V2<T>& apl, T (&rX)[V4_NFRE / (NANG / 2)], T (&rY)[V4_NFRE / (NANG / 2)],
-                          T (&rS)[V4_NFRE / (NANG / 2)]) {
+                          T sinwd, T coswd, T* __restrict__ gfl, T* __restrict__ gsp, unsigned long long& xm0, unsigned long long& xm1, V2<T>& wse,
+                          V2<T>& wslast, V2<T>& apl, T (&rX)[V4_NFRE / (NANG / 2)], T (&rY)[V4_NFRE / (NANG / 2)]) {
   constexpr int G = NANG / 2, NFRE = V4_NFRE, RS = PP * NANG, NS = NFRE / G;
   const T CONST1 = tb.BETAMAXOXKAPPA2, ABS_TAUWSHELTER = m_abs(tb.TAUWSHELTER);
   const T FU = m_abs(tb.SWELLF3), FUD = tb.SWELLF2, ROGOROAIR = tb.G / RAORW;
@@ -148,7 +206,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
   const V2<T> z2 = {T(0), T(0)};
   wse = z2; wslast = z2; apl = z2;
 #pragma unroll
-  for (int s = 0; s < NS; s++) { rX[s] = T(0); rY[s] = T(0); rS[s] = T(0); }
+  for (int s = 0; s < NS; s++) { rX[s] = T(0); rY[s] = T(0); }
   const T* tF = L.tile + L.own;
   // operands of the next row are read one row ahead (the row itself, CINV / WAVNUM, LOG(WAVNUM Z0M))
   V2<T> f_n = *reinterpret_cast<const V2<T>*>(tF);
@@ -167,7 +225,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
     const T CONSTF = ROGOROAIR * cinv_m * lane_get(L.rDFIM, m);
     const T DSTAB1 = LLSNEG ? (lane_get(L.rC5, m) * AIRD_PVISC) * cw.y : T(0);
     const T CNSN = (SIGm * CONST1) * RAORW;
-    const T TEMP1 = LLSNEG ? (-tb.SWELLF * T(16) * (SIGm * SIGm) / tb.G) * RAORW : T(0);
+    const T TEMP1 = LLSNEG ? lane_get(L.rT1, m) * RAORW : T(0);
     V2<T> SLP[2], FLP[2];
     bool xl0 = false, xl1 = false;
 #pragma unroll
@@ -212,7 +270,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
     sp = AVG * sp;
     fl = AVG * fl;
     const bool anygrow = __builtin_amdgcn_ballot_w64(xl0 || xl1) != 0ull;
-    T xrow = T(0), yrow = T(0), srow = T(0);
+    T xrow = T(0), yrow = T(0);
     if (anygrow) {
 #pragma unroll
       for (int ig = 0; ig < NGST; ig++) {
@@ -223,7 +281,6 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
         xrow += xs.x;
         yrow += xs.y;
       }
-      if (LLSNEG) srow = v4_allsum<G, T>(V2<T>{sp.x + sp.y, T(0)}, L.rot).x;
       xrow = AVG * xrow; yrow = AVG * yrow;
     }
     {  // the lane that owns frequency m keeps its row integrals
@@ -234,12 +291,13 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
         const bool w = mine && (ms == s);
         rX[s] = w ? xrow : rX[s];
         rY[s] = w ? yrow : rY[s];
-        rS[s] = w ? srow : rS[s];
       }
     }
     if (LLSNEG) {
       apl = apl + (fl * f - sp) * lane_get(L.rRHOWG, m);
       *reinterpret_cast<V2<T>*>(gfl + (size_t)m * NANG) = fl;
+      // the lane's share of the row's positive input: summed below the cut-off once MIJ is known (stresso.F90:160-168), no all-reduce here
+      gsp[(size_t)m * NANG] = sp.x + sp.y;
     }
     if (xl0) xm0 |= (1ull << m);
     if (xl1) xm1 |= (1ull << m);
@@ -279,13 +337,20 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   {
     // spare lanes (64 - PP G of them) shadow a lane of their own half-wave (a 64-bit LDS access is served in two groups of 32
     // lanes; equal addresses inside a group are one broadcast access): no bank conflicts from the shadows
-    int src = lane;
-    if (lane >= PP * G) {
-      if (PP * G > 32) src = lane >= 32 ? 32 : 0;
-      else { src = lane >= 32 ? lane - 32 : 0; if (src >= PP * G) src = 0; }
+    if constexpr (G == 18) {
+      static_assert(G != 18 || PP == 3, "36 directions: one point per DPP row + two extra lanes per point");
+      if (lane < 48) { L.p = lane >> 4; L.j = lane & 15; }
+      else if (lane < 54) { L.p = (lane - 48) >> 1; L.j = 16 + ((lane - 48) & 1); }
+      else { L.p = 2; L.j = 0; }                       // shadows of lane 32
+    } else {
+      int src = lane;
+      if (lane >= PP * G) {
+        if (PP * G > 32) src = lane >= 32 ? 32 : 0;
+        else { src = lane >= 32 ? lane - 32 : 0; if (src >= PP * G) src = 0; }
+      }
+      L.p = src / G;
+      L.j = src - L.p * G;
     }
-    L.p = src / G;
-    L.j = src - L.p * G;
   }
   const int p = L.p, j = L.j;
   const int ij0 = kijs + blockIdx.x * PP;
@@ -301,13 +366,19 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     k = k < 0 ? k + NANG : (k >= NANG ? k - NANG : k);
     sh[i] = p * NANG + k;
   }
-  {
+  if constexpr (G == 18) {
+    const bool low = lane < 48 && j < 2;
+    L.rot.a0 = 4 * (low ? 48 + 2 * p + j : lane);
+    L.rot.a1 = 4 * (lane < 48 ? lane : 16 * p);
+    L.rot.a2 = L.rot.a3 = L.rot.a4 = 0;
+    L.rot.fold = low ? T(1) : T(0);
+  } else {
     const int base = p * G;
 #define V4_ROT(r) (4 * (base + ((j + (r)) >= G ? j + (r) - G : j + (r))))
-    if (G == 18) { L.rot.a0 = V4_ROT(9); L.rot.a1 = V4_ROT(3); L.rot.a2 = V4_ROT(6); }
     if (G == 12) { L.rot.a0 = V4_ROT(6); L.rot.a1 = V4_ROT(3); L.rot.a2 = 0; }
     if (G == 6) { L.rot.a0 = V4_ROT(3); L.rot.a1 = 0; L.rot.a2 = 0; }
     L.rot.a3 = V4_ROT(1); L.rot.a4 = V4_ROT(2);
+    L.rot.fold = T(0);
 #undef V4_ROT
   }
   {
@@ -315,6 +386,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     L.rDFIM = tb.DFIM[mi]; L.rDFIMOFR = tb.DFIMOFR[mi]; L.rDFIMFR = tb.DFIMFR[mi]; L.rZPIFR = tb.ZPIFR[mi]; L.rRHOWG = tb.RHOWG_DFIM[mi];
     L.rCOFRM4 = tb.COFRM4[mi]; L.rFLMAX = tb.FLMAX[mi];
     L.rC5 = -tb.SWELLF5 * T(2) * m_sqrt(T(2) * tb.RNU * tb.ZPIFR[mi]);
+    L.rT1 = -tb.SWELLF * T(16) * (tb.ZPIFR[mi] * tb.ZPIFR[mi]) / tb.G;
   }
   L.sinth = V2<T>{tb.SINTH[2 * j], tb.SINTH[2 * j + 1]};
   L.costh = V2<T>{tb.COSTH[2 * j], tb.COSTH[2 * j + 1]};
@@ -465,7 +537,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
 
   auto femws_finish = [&](V2<T> wse, V2<T> wslast, T& FM, T& EMW) {
     const V2<T> s = v4_allsum<G, T>(wse, L.rot);
-    const T t2 = v4_allsum<G, T>(V2<T>{wslast.x + wslast.y, T(0)}, L.rot).x;
+    const T t2 = v4_allsum1<G, T>(wslast.x + wslast.y, L.rot);
     const T em = tb.EPSMIN + s.x + DELT25 * t2;
     const T fm = tb.EPSMIN + s.y + (tb.FRTAIL * tb.DELTH) * t2;
     FM = em / fm;
@@ -490,7 +562,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     }
     return r;
   };
-  T rX[NS], rY[NS], rS[NS];
+  T rX[NS], rY[NS];
+  T* gsp = fl1 + (size_t)ij * N + 2 * j;   // the point's FL1 block is dead until the final store: the second SINPUT parks its positive input there
   // stress sums below the cut-off and the F(:,MIJ) integrals of TAU_PHI_HF (stresso.F90:148-173, tau_phi_hf.F90:170-196)
   auto post_stress = [&](int MIJ, V2<T> apl, bool phiwa) {
     V2<T> s = z2;
@@ -501,11 +574,18 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       const T w = rrh(m, MIJ);
       const T wx = w * L.fac4[m * 4 + Q4_CINV];
       s = s + V2<T>{wx * rX[q], wx * rY[q]};
-      sp += w * rS[q];
+    }
+    if (phiwa) {
+#pragma unroll 6
+      for (int m = 0; m < NFRE; m++) {
+        T w = lane_get(L.rRHOWG, m);
+        if (m + 1 == MIJ && MIJ != NFRE) w = T(0.5) * w;
+        sp += (m + 1 <= MIJ ? w : T(0)) * gsp[(size_t)m * NANG];
+      }
     }
     s = v4_allsum<G, T>(s, L.rot);
     T PH = T(0);
-    if (phiwa) PH = v4_allsum<G, T>(V2<T>{apl.x + apl.y + sp, T(0)}, L.rot).x;
+    if (phiwa) PH = v4_allsum1<G, T>(apl.x + apl.y + sp, L.rot);
     const V2<T> fm = *reinterpret_cast<const V2<T>*>(tF + (MIJ - 1) * RS);
     const V2<T> fc2 = fm * cpos * cpos, fc3 = fc2 * cpos;
     const V2<T> h = v4_allsum<G, T>(V2<T>{fc3.x + fc3.y, fc2.x + fc2.y}, L.rot);
@@ -520,7 +600,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   unsigned long long xm0, xm1;
   V2<T> wse, wslast, apl;
   T FMEANWS, EMW;
-  v4_sinput<T, NANG, PP, 1, false>(tb, L, UFRIC, Z0M, RAORW, T(0), T(0), T(0), T(0), sinwd, coswd, nullptr, xm0, xm1, wse, wslast, apl, rX, rY, rS);
+  v4_sinput<T, NANG, PP, 1, false>(tb, L, UFRIC, Z0M, RAORW, T(0), T(0), T(0), T(0), sinwd, coswd, nullptr, nullptr, xm0, xm1, wse, wslast, apl, rX, rY);
   femws_finish(wse, wslast, FMEANWS, EMW);
   int MIJ = frcutindex4(FMEANWS, UFRIC);
   post_stress(MIJ, apl, false);
@@ -544,8 +624,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   V4_PHASE_EXIT(204);
   // ---- second SINFLX call: wind-input coefficient (parked in the point's XLLWS block, [M][K]), XLLWS, MIJ, wave stress, PHIWA
   T* gx = xllws + (size_t)ij * N + 2 * j;   // this lane's pair in row 0 of the block
-  v4_sinput<T, NANG, PP, 2, true>(tb, L, UFRIC, Z0M, RAORW, c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], sinwd, coswd, gx, xm0, xm1, wse,
-                                  wslast, apl, rX, rY, rS);
+  v4_sinput<T, NANG, PP, 2, true>(tb, L, UFRIC, Z0M, RAORW, c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], sinwd, coswd, gx, gsp, xm0, xm1, wse,
+                                  wslast, apl, rX, rY);
   femws_finish(wse, wslast, FMEANWS, EMW);
   MIJ = frcutindex4(FMEANWS, UFRIC);
   post_stress(MIJ, apl, true);
@@ -631,7 +711,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         V2<T> Dcur;
         const V2<T> fcur = f_p;
         {
-          const T bm = m_max(bm_p, m_max(e3_p, e4_p));
+          const T bm = (G == 18) ? e3_p : m_max(bm_p, m_max(e3_p, e4_p));
           const T d0 = m_max(T(0), bm * TMP03 - SSDSC4);
           const V2<T> t1 = bs_p * TMP03 - SSDSC4;
           const V2<T> d1 = {m_max(T(0), t1.x), m_max(T(0), t1.y)};
@@ -696,16 +776,15 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
             D2 = v4_at<T, NSH, -R2>(st1, sh); D2s = v4_at<T, NSH, -(R2 + 1)>(st1, sh);
             P1 = (R1 == 0) ? DELAP : v4_at<T, NSH, R1>(st2, sh); P1s = v4_at<T, NSH, R1 + 1>(st2, sh);
             bm1 = m_max(bm1, e0);
-            if (G == 18) { e1 = v4_bp(L.rot.a1, bm1); e2 = v4_bp(L.rot.a2, bm1); }
+            if constexpr (G == 18) { bm1 = v4_rowmax<T>(bm1); e3 = v4_bp(L.rot.a1, bm1); }   // extras folded in, row maximum, back to the extras
             if (G == 12) e1 = v4_bp(L.rot.a1, bm1);
           } else {
             A2 = v4_at<T, NSH, R2>(st0, sh); A2s = v4_at<T, NSH, R2 + 1>(st0, sh);
             A1 = (R1 == 0) ? AD : v4_at<T, NSH, -R1>(st0, sh); A1s = v4_at<T, NSH, -(R1 + 1)>(st0, sh);
             D2 = v4_at<T, NSH, R2>(st1, sh); D2s = v4_at<T, NSH, R2 + 1>(st1, sh);
             P1 = (R1 == 0) ? DELAP : v4_at<T, NSH, -R1>(st2, sh); P1s = v4_at<T, NSH, -(R1 + 1)>(st2, sh);
-            if (G == 18) bm1 = m_max(bm1, m_max(e1, e2));
             if (G == 12) bm1 = m_max(bm1, e1);
-            e3 = v4_bp(L.rot.a3, bm1); e4 = v4_bp(L.rot.a4, bm1);
+            if constexpr (G != 18) { e3 = v4_bp(L.rot.a3, bm1); e4 = v4_bp(L.rot.a4, bm1); }
           }
           V4SYNC();
           // (one fused multiply-add per term: the reference adds the two terms of a row one after the other as well)
@@ -772,7 +851,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   if (tb.LCFLX) {
     const V2<T> sx = a_x * L.sinth, sy = a_x * L.costh;
     const V2<T> r0 = v4_allsum<G, T>(V2<T>{a_t.x + a_t.y, sx.x + sx.y}, L.rot);
-    const T YSTRESS = v4_allsum<G, T>(V2<T>{sy.x + sy.y, T(0)}, L.rot).x;
+    const T YSTRESS = v4_allsum1<G, T>(sy.x + sy.y, L.rot);
     const T PHILF = r0.x, XSTRESS = r0.y;
     const T EPSUS3 = tb.EPSUS * m_sqrt(tb.EPSUS);
     T OOVAL = T(1), USTAR = UFRIC;

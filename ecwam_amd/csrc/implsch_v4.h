@@ -664,7 +664,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     const T USFM = UFRIC * m_max(FMEANWS, FMEAN);
     const bool flux_snl = tb.LCFLX && tb.LWVFLX_SNL;
     const int NRED = tb.NFRE_RED, MLST = tb.MLSTHG;
-    T* st0 = sStg;            // staging rows: up / AD(kh=1), vp / DELAM(1), um / DELAP(1), vm / AD(2), DELAM(2), DELAP(2)
+    T* st0 = sStg;            // staging rows: up / AD(kh=1), vp / DELAM(1), um / DELAP(1), vm / AD(2), row MC-4 / DELAM(2), DELAP(2)
     T* st1 = sStg + RS;
     T* st2 = sStg + 2 * RS;
     T* st3 = sStg + 3 * RS;
@@ -678,10 +678,27 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     V2<T> wiq[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) wiq[i] = *reinterpret_cast<const V2<T>*>(gx + (size_t)i * NANG);   // rows 0..3, first used by MC = 5..8
-    auto clampr = [&](int r) { return r < 0 ? 0 : (r > NFRE - 1 ? NFRE - 1 : r); };
+    // scalar clamps (a two-sided integer clamp of a uniform value is selected as v_med3_i32 and drags the address arithmetic into
+    // the vector unit: signed maximum, then unsigned minimum)
+    auto lo0 = [&](int r) { return r < 0 ? 0 : r; };
+    auto hi35 = [&](int r) { return (int)((unsigned)r < (unsigned)(NFRE - 1) ? (unsigned)r : (unsigned)(NFRE - 1)); };
+    // the un-updated tile rows MC-5 .. MC+2 (clamped to 0 .. NFRE-1: INLCOEF by formula, checked by ecwam_hip_create) stay in a register
+    // ring, slot = row & 7: one LDS read per interaction (row MC+3, at the end of interaction MC into the slot of row MC-5) instead
+    // of five.  Rows are updated in place behind the ring (row MC-5 at the end of interaction MC).
+    V2<T> fR[8];
+    {
+      const V2<T> r0 = *reinterpret_cast<const V2<T>*>(tF);
+      fR[4] = r0; fR[5] = r0; fR[6] = r0; fR[7] = r0; fR[0] = r0;
+      fR[1] = *reinterpret_cast<const V2<T>*>(tF + RS);
+      fR[2] = *reinterpret_cast<const V2<T>*>(tF + 2 * RS);
+      fR[3] = *reinterpret_cast<const V2<T>*>(tF + 3 * RS);
+    }
+    // RHOWGDFTH(M) = RHOWG_DFIM(M) w(M), w = 1 below the cut-off MIJ, 1/2 at MIJ (1 if MIJ = NFRE), 0 above (frcutindex.F90:98-107):
+    // w = clamp(MIJ + 1/2 - M, 0, 1); MIJ differs between the points of the wave
+    const T MIJh = (T)MIJ + (MIJ == NFRE ? T(1) : T(0.5));
     // carried from one interaction to the next: saturation spectrum of row MC-4 with its directional maximum (last exchange in
-    // flight), that row's frequency and un-updated values
-    V2<T> bs_p = z2, f_p = z2;
+    // flight) and that row's frequency
+    V2<T> bs_p = z2;
     T bm_p = T(0), e3_p = T(0), e4_p = T(0), sig_p = T(0);
     for (int MCb = 0; MCb < MLST; MCb += 8) {
 #pragma unroll
@@ -689,27 +706,15 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         const int MC = MCb + 1 + jj;
         const int c0 = (1 + jj) & 7, cm = (1 + jj + 4) & 7, cm1 = (1 + jj + 5) & 7, cp = (1 + jj + 2) & 7, cp1 = (1 + jj + 3) & 7;
         const int m = MC - 5;   // row that is complete after this interaction
-        // ---- stage 1: LDS reads: the five rows interaction MC gathers from (INLCOEF by formula, checked by ecwam_hip_create), the row
-        //      the dissipation is evaluated for (MC-4: one interaction ahead of its update) and the factors of row MC-5
-        const int IC = clampr(MC - 1), IP = clampr(MC + 1), IP1 = clampr(MC + 2), IM = clampr(MC - 5), IM1 = clampr(MC - 4);
-        const V2<T> fIC = *reinterpret_cast<const V2<T>*>(tF + IC * RS);
-        const V2<T> fIP = *reinterpret_cast<const V2<T>*>(tF + IP * RS), fIP1 = *reinterpret_cast<const V2<T>*>(tF + IP1 * RS);
-        const V2<T> fIM = *reinterpret_cast<const V2<T>*>(tF + IM * RS), fIM1 = *reinterpret_cast<const V2<T>*>(tF + IM1 * RS);
-        T el[4 * NSH + 2];                // row MC-4: element e = F(2j - 2 NSH + e)
-        {
-          const T* row = sT + IM1 * RS;
-#pragma unroll
-          for (int i = 0; i <= 2 * NSH; i++) {
-            const V2<T> v = *reinterpret_cast<const V2<T>*>(row + sh[i]);
-            el[2 * i] = v.x; el[2 * i + 1] = v.y;
-          }
-        }
+        // ---- stage 1: the factors of rows MC-5 (update) and MC-4 (saturation spectrum)
+        const V2<T> fIC = fR[jj & 7], fIP = fR[(jj + 2) & 7], fIM = fR[(jj + 4) & 7], fIM1 = fR[(jj + 5) & 7];
+        const int IM = lo0(MC - 5), IM1 = hi35(lo0(MC - 4));
         const T bscn = L.fac4[IM1 * 4 + Q4_BSC];
         const V2<T> qf0 = *reinterpret_cast<const V2<T>*>(L.fac4 + IM * 4), qf1 = *reinterpret_cast<const V2<T>*>(L.fac4 + IM * 4 + 2);
         // meanwhile: the dissipation coefficient of row m (sdissip_ard.F90:117-314) from the saturation spectrum and the maximum the
         // previous interaction left in flight
         V2<T> Dcur;
-        const V2<T> fcur = f_p;
+        const V2<T> fcur = fIM;
         {
           const T bm = (G == 18) ? e3_p : m_max(bm_p, m_max(e3_p, e4_p));
           const T d0 = m_max(T(0), bm * TMP03 - SSDSC4);
@@ -720,20 +725,23 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         // ---- coefficient record of the interaction (wave-uniform)
         const T* cg = tb.DIACF[MC - 1];
         const T* cs = cg + 12;
-        const T FTAIL = cg[0], GW1 = cg[1], GW2 = cg[2], GW3 = cg[3], GW4 = cg[4], GW5 = cg[5], GW6 = cg[6], GW7 = cg[7], GW8 = cg[8];
+        const T GW1 = cg[1], GW2 = cg[2], GW3 = cg[3], GW4 = cg[4], GW5 = cg[5], GW6 = cg[6], GW7 = cg[7], GW8 = cg[8];
         const T FTEMP = cg[9] * ENHFR;
         const T FKLAMPA = cs[0], FKLAMPB = cs[1], FKLAMP2 = cs[2], FKLAMP1 = cs[3];
         const T FKLAPA2 = cs[4], FKLAPB2 = cs[5], FKLAP12 = cs[6], FKLAP22 = cs[7];
         const T FKLAMMA = cs[8], FKLAMMB = cs[9], FKLAMM2 = cs[10], FKLAMM1 = cs[11];
         const T FKLAMA2 = cs[12], FKLAMB2 = cs[13], FKLAM12 = cs[14], FKLAM22 = cs[15];
         const bool mid = (MC > MFR1STFR && MC < MFRLSTFR);
-        // ---- stage 2: frequency-interpolated rows of the + and - legs (snonlin.F90:236-262) -> staging rows, rotated reads;
+        const T FTAIL = mid ? T(1) : cg[0];   // x 1 is exact: no select on the vector side
+        // ---- stage 2: frequency-interpolated rows of the + and - legs (snonlin.F90:236-262) and row MC-4 -> staging rows, rotated reads;
         //      saturation spectrum of row MC-4 (SATWEIGHTS symmetric about the centre tap) and the first exchange of its maximum
-        const V2<T> FIJ = mid ? fIC : fIC * FTAIL;
+        const V2<T> FIJ = fIC * FTAIL;
+        const V2<T> fIP1 = fR[(jj + 3) & 7];
         const V2<T> up = GW1 * fIP + GW3 * fIP1, vp = GW2 * fIP + GW4 * fIP1;
         const V2<T> um = GW5 * fIM + GW7 * fIM1, vm = GW6 * fIM + GW8 * fIM1;
         *reinterpret_cast<V2<T>*>(st0 + L.own) = up; *reinterpret_cast<V2<T>*>(st1 + L.own) = vp;
         *reinterpret_cast<V2<T>*>(st2 + L.own) = um; *reinterpret_cast<V2<T>*>(st3 + L.own) = vm;
+        *reinterpret_cast<V2<T>*>(st4 + L.own) = fIM1;
         V4SYNC();
         // kh = 1: K1 = K - R1, K11 = K - R1 - 1, K2 = K + R2, K21 = K + R2 + 1; kh = 2 mirrored
         V2<T> SAPk[2], SAMk[2];
@@ -741,6 +749,12 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         SAMk[0] = v4_at<T, NSH, R2>(st2, sh) + v4_at<T, NSH, R2 + 1>(st3, sh);
         SAPk[1] = (R1 == 0 ? up : v4_at<T, NSH, R1>(st0, sh)) + v4_at<T, NSH, R1 + 1>(st1, sh);
         SAMk[1] = v4_at<T, NSH, -R2>(st2, sh) + v4_at<T, NSH, -(R2 + 1)>(st3, sh);
+        T el[4 * NSH + 2];                // row MC-4: element e = F(2j - 2 NSH + e), read back from its staging row at fixed addresses
+#pragma unroll
+        for (int i = 0; i <= 2 * NSH; i++) {
+          const V2<T> v = (i == NSH) ? fIM1 : *reinterpret_cast<const V2<T>*>(st4 + sh[i]);
+          el[2 * i] = v.x; el[2 * i + 1] = v.y;
+        }
         V2<T> bsat = {wt[NH] * el[2 * NSH], wt[NH] * el[2 * NSH + 1]};
 #pragma unroll
         for (int d = 1; d <= NH; d++) {
@@ -755,49 +769,65 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         const V2<T> FCEN = FTEMP * FIJ;
         T e1 = T(0), e2 = T(0), e3 = T(0), e4 = T(0);
         // (the always-true test splits the basic block: scheduled as one block, the eight unrolled interactions need 340 VGPRs)
-        if (MC <= MLST)
+        // The two mirror images go through separate staging rows (0..2 and 3..5) so that the reads of the first are in flight while
+        // the products of the second are formed, and the reads of the second while the increments of the first are added.
+        if (MC <= MLST) {
+          V2<T> ADk[2], DELADk[2];
+          V2<T> A2[2], A2s[2], A1[2], A1s[2], D2[2], D2s[2], P1[2], P1s[2];
 #pragma unroll
-        for (int kh = 0; kh < 2; kh++) {
-          const V2<T> SAP = SAPk[kh], SAM = SAMk[kh];
-          V2<T> FAD1 = FIJ * (SAP + SAM);
-          const V2<T> FAD2 = FAD1 - T(2) * SAP * SAM;
-          FAD1 = FAD1 + FAD2;
-          const V2<T> AD = FAD2 * FCEN;
-          const V2<T> DELAD = FAD1 * FTEMP;
-          const V2<T> DELAP = (FIJ - T(2) * SAM) * DAL1 * FCEN;
-          const V2<T> DELAM = (FIJ - T(2) * SAP) * DAL2 * FCEN;
-          *reinterpret_cast<V2<T>*>(st0 + L.own) = AD; *reinterpret_cast<V2<T>*>(st1 + L.own) = DELAM;
-          *reinterpret_cast<V2<T>*>(st2 + L.own) = DELAP;
-          V4SYNC();
-          V2<T> A2, A2s, A1, A1s, D2, D2s, P1, P1s;
-          if (kh == 0) {
-            A2 = v4_at<T, NSH, -R2>(st0, sh); A2s = v4_at<T, NSH, -(R2 + 1)>(st0, sh);
-            A1 = (R1 == 0) ? AD : v4_at<T, NSH, R1>(st0, sh); A1s = v4_at<T, NSH, R1 + 1>(st0, sh);
-            D2 = v4_at<T, NSH, -R2>(st1, sh); D2s = v4_at<T, NSH, -(R2 + 1)>(st1, sh);
-            P1 = (R1 == 0) ? DELAP : v4_at<T, NSH, R1>(st2, sh); P1s = v4_at<T, NSH, R1 + 1>(st2, sh);
-            bm1 = m_max(bm1, e0);
-            if constexpr (G == 18) { bm1 = v4_rowmax<T>(bm1); e3 = v4_bp(L.rot.a1, bm1); }   // extras folded in, row maximum, back to the extras
-            if (G == 12) e1 = v4_bp(L.rot.a1, bm1);
-          } else {
-            A2 = v4_at<T, NSH, R2>(st0, sh); A2s = v4_at<T, NSH, R2 + 1>(st0, sh);
-            A1 = (R1 == 0) ? AD : v4_at<T, NSH, -R1>(st0, sh); A1s = v4_at<T, NSH, -(R1 + 1)>(st0, sh);
-            D2 = v4_at<T, NSH, R2>(st1, sh); D2s = v4_at<T, NSH, R2 + 1>(st1, sh);
-            P1 = (R1 == 0) ? DELAP : v4_at<T, NSH, -R1>(st2, sh); P1s = v4_at<T, NSH, -(R1 + 1)>(st2, sh);
-            if (G == 12) bm1 = m_max(bm1, e1);
-            if constexpr (G != 18) { e3 = v4_bp(L.rot.a3, bm1); e4 = v4_bp(L.rot.a4, bm1); }
+          for (int kh = 0; kh < 2; kh++) {
+            const V2<T> SAP = SAPk[kh], SAM = SAMk[kh];
+            V2<T> FAD1 = FIJ * (SAP + SAM);
+            const V2<T> FAD2 = FAD1 - T(2) * SAP * SAM;
+            FAD1 = FAD1 + FAD2;
+            const V2<T> AD = FAD2 * FCEN;
+            ADk[kh] = AD;
+            DELADk[kh] = FAD1 * FTEMP;
+            const V2<T> DELAP = (FIJ - T(2) * SAM) * DAL1 * FCEN;
+            const V2<T> DELAM = (FIJ - T(2) * SAP) * DAL2 * FCEN;
+            T* sa = kh == 0 ? st0 : st3;
+            T* sm = kh == 0 ? st1 : st4;
+            T* sp = kh == 0 ? st2 : st5;
+            *reinterpret_cast<V2<T>*>(sa + L.own) = AD; *reinterpret_cast<V2<T>*>(sm + L.own) = DELAM;
+            *reinterpret_cast<V2<T>*>(sp + L.own) = DELAP;
+            V4SYNC();
+            if (kh == 0) {
+              A2[0] = v4_at<T, NSH, -R2>(sa, sh); A2s[0] = v4_at<T, NSH, -(R2 + 1)>(sa, sh);
+              A1[0] = (R1 == 0) ? AD : v4_at<T, NSH, R1>(sa, sh); A1s[0] = v4_at<T, NSH, R1 + 1>(sa, sh);
+              D2[0] = v4_at<T, NSH, -R2>(sm, sh); D2s[0] = v4_at<T, NSH, -(R2 + 1)>(sm, sh);
+              P1[0] = (R1 == 0) ? DELAP : v4_at<T, NSH, R1>(sp, sh); P1s[0] = v4_at<T, NSH, R1 + 1>(sp, sh);
+              bm1 = m_max(bm1, e0);
+              if constexpr (G == 18) { bm1 = v4_rowmax<T>(bm1); e3 = v4_bp(L.rot.a1, bm1); }   // extras folded in, row maximum, back to the extras
+              if (G == 12) e1 = v4_bp(L.rot.a1, bm1);
+            } else {
+              A2[1] = v4_at<T, NSH, R2>(sa, sh); A2s[1] = v4_at<T, NSH, R2 + 1>(sa, sh);
+              A1[1] = (R1 == 0) ? AD : v4_at<T, NSH, -R1>(sa, sh); A1s[1] = v4_at<T, NSH, -(R1 + 1)>(sa, sh);
+              D2[1] = v4_at<T, NSH, R2>(sm, sh); D2s[1] = v4_at<T, NSH, R2 + 1>(sm, sh);
+              P1[1] = (R1 == 0) ? DELAP : v4_at<T, NSH, -R1>(sp, sh); P1s[1] = v4_at<T, NSH, -(R1 + 1)>(sp, sh);
+              if (G == 12) bm1 = m_max(bm1, e1);
+              if constexpr (G != 18) { e3 = v4_bp(L.rot.a3, bm1); e4 = v4_bp(L.rot.a4, bm1); }
+            }
           }
           V4SYNC();
-          // (one fused multiply-add per term: the reference adds the two terms of a row one after the other as well)
-          aS[c0] -= T(2) * AD;
-          aF[c0] -= T(2) * DELAD;
-          aS[cm] += A2 * FKLAMM1; aS[cm] += A2s * FKLAMM2;
-          aF[cm] += D2 * FKLAM12; aF[cm] += D2s * FKLAM22;
-          aS[cm1] += A2 * FKLAMMA; aS[cm1] += A2s * FKLAMMB;
-          aF[cm1] += D2 * FKLAMA2; aF[cm1] += D2s * FKLAMB2;
-          aS[cp] += A1 * FKLAMP1; aS[cp] += A1s * FKLAMP2;
-          aF[cp] += P1 * FKLAP12; aF[cp] += P1s * FKLAP22;
-          aS[cp1] += A1 * FKLAMPA; aS[cp1] += A1s * FKLAMPB;
-          aF[cp1] += P1 * FKLAPA2; aF[cp1] += P1s * FKLAPB2;
+#pragma unroll
+          for (int kh = 0; kh < 2; kh++) {
+            // (one fused multiply-add per term: the reference adds the two terms of a row one after the other as well)
+            aS[c0] -= T(2) * ADk[kh];
+            aF[c0] -= T(2) * DELADk[kh];
+            aS[cm] += A2[kh] * FKLAMM1; aS[cm] += A2s[kh] * FKLAMM2;
+            aF[cm] += D2[kh] * FKLAM12; aF[cm] += D2s[kh] * FKLAM22;
+            aS[cm1] += A2[kh] * FKLAMMA; aS[cm1] += A2s[kh] * FKLAMMB;
+            aF[cm1] += D2[kh] * FKLAMA2; aF[cm1] += D2s[kh] * FKLAMB2;
+            aS[cp] += A1[kh] * FKLAMP1; aS[cp] += A1s[kh] * FKLAMP2;
+            aF[cp] += P1[kh] * FKLAP12; aF[cp] += P1s[kh] * FKLAP22;
+            if (kh == 0) {   // first contribution to the row that entered the ring (0 + x = x: no zeroing of the slot)
+              aS[cp1] = A1[kh] * FKLAMPA; aF[cp1] = P1[kh] * FKLAPA2;
+            } else {
+              aS[cp1] += A1[kh] * FKLAMPA; aF[cp1] += P1[kh] * FKLAPA2;
+            }
+            aS[cp1] += A1s[kh] * FKLAMPB;
+            aF[cp1] += P1s[kh] * FKLAPB2;
+          }
         }
         // ---- row m = MC-5 is complete: no later interaction reads or feeds it
         if (m >= 0) {
@@ -826,18 +856,16 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
           ss.y = ss.y + DELTM * m_min(flmax - fn.y, T(0));
           fn.x = m_min(fn.x, flmax); fn.y = m_min(fn.y, flmax);
           *reinterpret_cast<V2<T>*>(tFw + m * RS) = fn;
-          T rh = T(0);   // RHOWGDFTH(M) (frcutindex.F90:98-107); MIJ differs between the points of the wave
-          if (m + 1 <= MIJ) { rh = rhowg; if (m + 1 == MIJ && MIJ != NFRE) rh = T(0.5) * rh; }
+          const T rh = rhowg * m_min(m_max(MIJh - (T)(m + 1), T(0)), T(1));
           a_t = a_t + rh * ss;
           a_x = a_x + (qf1.x * rh) * ss;
         }
-        aS[cm] = z2;
-        aF[cm] = z2;
         {
           const int mn = m + 4;
           if (mn >= 4 && mn < NFRE) wiq[jj & 3] = *reinterpret_cast<const V2<T>*>(gx + (size_t)mn * NANG);
         }
-        bs_p = bsat; f_p = V2<T>{el[2 * NSH], el[2 * NSH + 1]}; bm_p = bm1; e3_p = e3; e4_p = e4; sig_p = lane_get(L.rZPIFR, clampr(m + 1));
+        fR[(jj + 4) & 7] = *reinterpret_cast<const V2<T>*>(tF + hi35(MC + 3) * RS);
+        bs_p = bsat; bm_p = bm1; e3_p = e3; e4_p = e4; sig_p = lane_get(L.rZPIFR, hi35(lo0(m + 1)));
         V4SYNC();
       }
     }

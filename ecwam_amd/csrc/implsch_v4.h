@@ -697,31 +697,65 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     // w = clamp(MIJ + 1/2 - M, 0, 1); MIJ differs between the points of the wave
     const T MIJh = (T)MIJ + (MIJ == NFRE ? T(1) : T(0.5));
     // carried from one interaction to the next: saturation spectrum of row MC-4 with its directional maximum (last exchange in
-    // flight) and that row's frequency
+    // flight) and that row's frequency; the record of the row the previous interaction completed (its update fills the wait for
+    // the coefficient record and the first LDS round trip of this interaction)
     V2<T> bs_p = z2;
     T bm_p = T(0), e3_p = T(0), e4_p = T(0), sig_p = T(0);
-    for (int MCb = 0; MCb < MLST; MCb += 8) {
+    V2<T> u_f = z2, u_D = z2;
+    T u_sbo = T(0), u_cinv = T(0), u_wn = T(0);
+    // new spectrum, limiter and fluxes of row m (implsch.F90:300-392) from the finished ring slot and the parked wind input
+    auto update_row = [&](int m, V2<T>& accS, V2<T>& accF, V2<T>& wslot) {
+      const V2<T> f = u_f;
+      const T cofr = lane_get(L.rCOFRM4, m), flmax = lane_get(L.rFLMAX, m), rhowg = lane_get(L.rRHOWG, m);
+      V2<T> D = u_D;
+      if (turb) D = D - (lane_get(L.rZPIFR, m) * u_wn * FACTURB) * coswdif;
+      const V2<T> fldw = D + wslot;
+      V2<T> sl = fldw * f + accS;
+      V2<T> fld = fldw + accF;
+      V2<T> ss = z2;
+      if (flux_snl) {
+        const V2<T> den = {m_max(T(1) - DELT5 * fld.x, T(1)), m_max(T(1) - DELT5 * fld.y, T(1))};
+        ss = V2<T>{f_div(sl.x, den.x), f_div(sl.y, den.y)};
+      }
+      if (shallow_brk && m < NRED) { sl = sl - SDS * f; fld = fld - SDS; }
+      if (m < NRED) { sl = sl + u_sbo * f; fld = fld + u_sbo; }
+      const T lim = USFM * (cofr * DELT);
+      V2<T> fn;
+      {
+        const T G0 = f_div(DELT * sl.x, m_max(T(1) - DELT5 * fld.x, T(1))), G1 = f_div(DELT * sl.y, m_max(T(1) - DELT5 * fld.y, T(1)));
+        fn.x = m_max(f.x + m_sign(m_min(m_abs(G0), lim), G0), FLM.x);
+        fn.y = m_max(f.y + m_sign(m_min(m_abs(G1), lim), G1), FLM.y);
+      }
+      ss.x = ss.x + DELTM * m_min(flmax - fn.x, T(0));
+      ss.y = ss.y + DELTM * m_min(flmax - fn.y, T(0));
+      fn.x = m_min(fn.x, flmax); fn.y = m_min(fn.y, flmax);
+      *reinterpret_cast<V2<T>*>(tFw + m * RS) = fn;
+      const T rh = rhowg * m_min(m_max(MIJh - (T)(m + 1), T(0)), T(1));
+      a_t = a_t + rh * ss;
+      a_x = a_x + (u_cinv * rh) * ss;
+      const int mn = m + 4;   // the slot of the wind-input ring is free: row m+4
+      if (mn < NFRE) wslot = *reinterpret_cast<const V2<T>*>(gx + (size_t)mn * NANG);
+    };
+    *reinterpret_cast<V2<T>*>(st4 + L.own) = fR[5];   // row MC-4 of the first interaction
+    V4SYNC();
+    int MCb = 0;
+    for (; MCb < MLST; MCb += 8) {
 #pragma unroll
       for (int jj = 0; jj < 8; jj++) {
         const int MC = MCb + 1 + jj;
         const int c0 = (1 + jj) & 7, cm = (1 + jj + 4) & 7, cm1 = (1 + jj + 5) & 7, cp = (1 + jj + 2) & 7, cp1 = (1 + jj + 3) & 7;
-        const int m = MC - 5;   // row that is complete after this interaction
-        // ---- stage 1: the factors of rows MC-5 (update) and MC-4 (saturation spectrum)
+        const int m = MC - 5;   // row that is complete after this interaction (updated at the top of the next one)
+        // ---- stage 1: row MC-4 back from its staging row (rotated reads at fixed addresses), the factors of rows MC-5 and MC-4
         const V2<T> fIC = fR[jj & 7], fIP = fR[(jj + 2) & 7], fIM = fR[(jj + 4) & 7], fIM1 = fR[(jj + 5) & 7];
+        T el[4 * NSH + 2];                // row MC-4: element e = F(2j - 2 NSH + e)
+#pragma unroll
+        for (int i = 0; i <= 2 * NSH; i++) {
+          const V2<T> v = (i == NSH) ? fIM1 : *reinterpret_cast<const V2<T>*>(st4 + sh[i]);
+          el[2 * i] = v.x; el[2 * i + 1] = v.y;
+        }
         const int IM = lo0(MC - 5), IM1 = hi35(lo0(MC - 4));
         const T bscn = L.fac4[IM1 * 4 + Q4_BSC];
         const V2<T> qf0 = *reinterpret_cast<const V2<T>*>(L.fac4 + IM * 4), qf1 = *reinterpret_cast<const V2<T>*>(L.fac4 + IM * 4 + 2);
-        // meanwhile: the dissipation coefficient of row m (sdissip_ard.F90:117-314) from the saturation spectrum and the maximum the
-        // previous interaction left in flight
-        V2<T> Dcur;
-        const V2<T> fcur = fIM;
-        {
-          const T bm = (G == 18) ? e3_p : m_max(bm_p, m_max(e3_p, e4_p));
-          const T d0 = m_max(T(0), bm * TMP03 - SSDSC4);
-          const V2<T> t1 = bs_p * TMP03 - SSDSC4;
-          const V2<T> d1 = {m_max(T(0), t1.x), m_max(T(0), t1.y)};
-          Dcur = (c2 * sig_p) * (d0 * d0) + (c2m1 * sig_p) * (d1 * d1);
-        }
         // ---- coefficient record of the interaction (wave-uniform)
         const T* cg = tb.DIACF[MC - 1];
         const T* cs = cg + 12;
@@ -733,15 +767,26 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         const T FKLAMA2 = cs[12], FKLAMB2 = cs[13], FKLAM12 = cs[14], FKLAM22 = cs[15];
         const bool mid = (MC > MFR1STFR && MC < MFRLSTFR);
         const T FTAIL = mid ? T(1) : cg[0];   // x 1 is exact: no select on the vector side
-        // ---- stage 2: frequency-interpolated rows of the + and - legs (snonlin.F90:236-262) and row MC-4 -> staging rows, rotated reads;
-        //      saturation spectrum of row MC-4 (SATWEIGHTS symmetric about the centre tap) and the first exchange of its maximum
+        // ---- meanwhile: the row the previous interaction completed
+        if (m - 1 >= 0 && m - 1 < NFRE) update_row(m - 1, aS[(jj + 4) & 7], aF[(jj + 4) & 7], wiq[(jj + 3) & 3]);
+        // the dissipation coefficient of row m (sdissip_ard.F90:117-314) from the saturation spectrum and the maximum the previous
+        // interaction left in flight
+        {
+          const T bm = (G == 18) ? e3_p : m_max(bm_p, m_max(e3_p, e4_p));
+          const T d0 = m_max(T(0), bm * TMP03 - SSDSC4);
+          const V2<T> t1 = bs_p * TMP03 - SSDSC4;
+          const V2<T> d1 = {m_max(T(0), t1.x), m_max(T(0), t1.y)};
+          u_D = (c2 * sig_p) * (d0 * d0) + (c2m1 * sig_p) * (d1 * d1);
+          u_f = fIM; u_sbo = qf0.y; u_cinv = qf1.x; u_wn = qf1.y;
+        }
+        // ---- stage 2: frequency-interpolated rows of the + and - legs (snonlin.F90:236-262) -> staging rows, rotated reads; meanwhile
+        //      the saturation spectrum of row MC-4 (SATWEIGHTS symmetric about the centre tap) and the first exchange of its maximum
         const V2<T> FIJ = fIC * FTAIL;
         const V2<T> fIP1 = fR[(jj + 3) & 7];
         const V2<T> up = GW1 * fIP + GW3 * fIP1, vp = GW2 * fIP + GW4 * fIP1;
         const V2<T> um = GW5 * fIM + GW7 * fIM1, vm = GW6 * fIM + GW8 * fIM1;
         *reinterpret_cast<V2<T>*>(st0 + L.own) = up; *reinterpret_cast<V2<T>*>(st1 + L.own) = vp;
         *reinterpret_cast<V2<T>*>(st2 + L.own) = um; *reinterpret_cast<V2<T>*>(st3 + L.own) = vm;
-        *reinterpret_cast<V2<T>*>(st4 + L.own) = fIM1;
         V4SYNC();
         // kh = 1: K1 = K - R1, K11 = K - R1 - 1, K2 = K + R2, K21 = K + R2 + 1; kh = 2 mirrored
         V2<T> SAPk[2], SAMk[2];
@@ -749,12 +794,6 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         SAMk[0] = v4_at<T, NSH, R2>(st2, sh) + v4_at<T, NSH, R2 + 1>(st3, sh);
         SAPk[1] = (R1 == 0 ? up : v4_at<T, NSH, R1>(st0, sh)) + v4_at<T, NSH, R1 + 1>(st1, sh);
         SAMk[1] = v4_at<T, NSH, -R2>(st2, sh) + v4_at<T, NSH, -(R2 + 1)>(st3, sh);
-        T el[4 * NSH + 2];                // row MC-4: element e = F(2j - 2 NSH + e), read back from its staging row at fixed addresses
-#pragma unroll
-        for (int i = 0; i <= 2 * NSH; i++) {
-          const V2<T> v = (i == NSH) ? fIM1 : *reinterpret_cast<const V2<T>*>(st4 + sh[i]);
-          el[2 * i] = v.x; el[2 * i + 1] = v.y;
-        }
         V2<T> bsat = {wt[NH] * el[2 * NSH], wt[NH] * el[2 * NSH + 1]};
 #pragma unroll
         for (int d = 1; d <= NH; d++) {
@@ -765,7 +804,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         T bm1 = m_max(bsat.x, bsat.y);
         const T e0 = v4_bp(L.rot.a0, bm1);
         V4SYNC();
-        // ---- stage 3: the DIA products of the two mirror images (snonlin.F90:264-306), one after the other through staging rows 0..2
+        // ---- stage 3: the DIA products of the two mirror images (snonlin.F90:264-306)
         const V2<T> FCEN = FTEMP * FIJ;
         T e1 = T(0), e2 = T(0), e3 = T(0), e4 = T(0);
         // (the always-true test splits the basic block: scheduled as one block, the eight unrolled interactions need 340 VGPRs)
@@ -796,16 +835,22 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
               A1[0] = (R1 == 0) ? AD : v4_at<T, NSH, R1>(sa, sh); A1s[0] = v4_at<T, NSH, R1 + 1>(sa, sh);
               D2[0] = v4_at<T, NSH, -R2>(sm, sh); D2s[0] = v4_at<T, NSH, -(R2 + 1)>(sm, sh);
               P1[0] = (R1 == 0) ? DELAP : v4_at<T, NSH, R1>(sp, sh); P1s[0] = v4_at<T, NSH, R1 + 1>(sp, sh);
-              bm1 = m_max(bm1, e0);
-              if constexpr (G == 18) { bm1 = v4_rowmax<T>(bm1); e3 = v4_bp(L.rot.a1, bm1); }   // extras folded in, row maximum, back to the extras
-              if (G == 12) e1 = v4_bp(L.rot.a1, bm1);
+              if constexpr (G != 18) {
+                bm1 = m_max(bm1, e0);
+                if (G == 12) e1 = v4_bp(L.rot.a1, bm1);
+              }
             } else {
               A2[1] = v4_at<T, NSH, R2>(sa, sh); A2s[1] = v4_at<T, NSH, R2 + 1>(sa, sh);
               A1[1] = (R1 == 0) ? AD : v4_at<T, NSH, -R1>(sa, sh); A1s[1] = v4_at<T, NSH, -(R1 + 1)>(sa, sh);
               D2[1] = v4_at<T, NSH, R2>(sm, sh); D2s[1] = v4_at<T, NSH, R2 + 1>(sm, sh);
               P1[1] = (R1 == 0) ? DELAP : v4_at<T, NSH, -R1>(sp, sh); P1s[1] = v4_at<T, NSH, -(R1 + 1)>(sp, sh);
-              if (G == 12) bm1 = m_max(bm1, e1);
-              if constexpr (G != 18) { e3 = v4_bp(L.rot.a3, bm1); e4 = v4_bp(L.rot.a4, bm1); }
+              if constexpr (G == 18) {   // extras folded in, row maximum (no LDS), back to the extras: read by the next interaction
+                bm1 = v4_rowmax<T>(m_max(bm1, e0));
+                e3 = v4_bp(L.rot.a1, bm1);
+              } else {
+                if (G == 12) bm1 = m_max(bm1, e1);
+                e3 = v4_bp(L.rot.a3, bm1); e4 = v4_bp(L.rot.a4, bm1);
+              }
             }
           }
           V4SYNC();
@@ -829,46 +874,15 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
             aF[cp1] += P1s[kh] * FKLAPB2;
           }
         }
-        // ---- row m = MC-5 is complete: no later interaction reads or feeds it
-        if (m >= 0) {
-          const V2<T> f = fcur;
-          const T cofr = lane_get(L.rCOFRM4, m), flmax = lane_get(L.rFLMAX, m), rhowg = lane_get(L.rRHOWG, m);
-          const V2<T> wi = wiq[jj & 3];   // wind input of the second SINFLX call
-          if (turb) Dcur = Dcur - (lane_get(L.rZPIFR, m) * qf1.y * FACTURB) * coswdif;
-          const V2<T> fldw = Dcur + wi;
-          V2<T> sl = fldw * f + aS[cm];
-          V2<T> fld = fldw + aF[cm];
-          V2<T> ss = z2;
-          if (flux_snl) {
-            const V2<T> den = {m_max(T(1) - DELT5 * fld.x, T(1)), m_max(T(1) - DELT5 * fld.y, T(1))};
-            ss = V2<T>{f_div(sl.x, den.x), f_div(sl.y, den.y)};
-          }
-          if (shallow_brk && m < NRED) { sl = sl - SDS * f; fld = fld - SDS; }
-          if (m < NRED) { const T sbo = qf0.y; sl = sl + sbo * f; fld = fld + sbo; }
-          const T lim = USFM * (cofr * DELT);
-          V2<T> fn;
-          {
-            const T G0 = f_div(DELT * sl.x, m_max(T(1) - DELT5 * fld.x, T(1))), G1 = f_div(DELT * sl.y, m_max(T(1) - DELT5 * fld.y, T(1)));
-            fn.x = m_max(f.x + m_sign(m_min(m_abs(G0), lim), G0), FLM.x);
-            fn.y = m_max(f.y + m_sign(m_min(m_abs(G1), lim), G1), FLM.y);
-          }
-          ss.x = ss.x + DELTM * m_min(flmax - fn.x, T(0));
-          ss.y = ss.y + DELTM * m_min(flmax - fn.y, T(0));
-          fn.x = m_min(fn.x, flmax); fn.y = m_min(fn.y, flmax);
-          *reinterpret_cast<V2<T>*>(tFw + m * RS) = fn;
-          const T rh = rhowg * m_min(m_max(MIJh - (T)(m + 1), T(0)), T(1));
-          a_t = a_t + rh * ss;
-          a_x = a_x + (qf1.x * rh) * ss;
-        }
-        {
-          const int mn = m + 4;
-          if (mn >= 4 && mn < NFRE) wiq[jj & 3] = *reinterpret_cast<const V2<T>*>(gx + (size_t)mn * NANG);
-        }
+        // ---- row MC-3 (the saturation row of the next interaction) -> its staging row; row MC+3 enters the ring in the slot of row MC-5
+        *reinterpret_cast<V2<T>*>(st4 + L.own) = fR[(jj + 6) & 7];
         fR[(jj + 4) & 7] = *reinterpret_cast<const V2<T>*>(tF + hi35(MC + 3) * RS);
         bs_p = bsat; bm_p = bm1; e3_p = e3; e4_p = e4; sig_p = lane_get(L.rZPIFR, hi35(lo0(m + 1)));
         V4SYNC();
       }
     }
+    // the row the last interaction completed (MCb is a multiple of 8 here: static ring slots)
+    if (MCb - 5 >= 0 && MCb - 5 < NFRE) update_row(MCb - 5, aS[4], aF[4], wiq[3]);
   }
   V4SYNC();
   V4_PHASE_EXIT(207);

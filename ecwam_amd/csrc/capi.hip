@@ -403,20 +403,22 @@ int ecwam_hip_propags2_otf_split(ecwam_hip_ctx* c, const void* f1, void* f3, int
                                  const void* cosphm1_ext, const int* order, int kijs, int kijl, int nd3s, int nd3e, int copy_rest,
                                  void* stream) {
   if (!c) return fail("null context");
-  if (kijl < kijs || kijs < 0 || kijl > n || nd3s < 1 || nd3e > c->NFRE_RED || nd3e < nd3s - 1 || ifrelfmax < 0 || ifrelfmax > c->NFRE_RED)
+  // with a processing order kijs..kijl index its entries (entries < 0 are padding and skipped: the order may be longer than n)
+  if (kijl < kijs || kijs < 0 || (!order && kijl > n) || nd3s < 1 || nd3e > c->NFRE_RED || nd3e < nd3s - 1 || ifrelfmax < 0 || ifrelfmax > c->NFRE_RED)
     return fail("ecwam_hip_propags2_otf: bad range");
+  if ((copy_rest & 4) && !order) return fail("ecwam_hip_propags2_otf: 2-D tiles need a processing order");
   if (in_nfre == 0) in_nfre = c->NFRE;
   if (gout && (gout_nfre < 1 || gout_nfre > c->NFRE || gout_nfre % (16 / c->real_bytes) != 0 || gout == f1 || ((uintptr_t)gout % 16) != 0))
     return fail("ecwam_hip_propags2_otf: the compact output buffer must be 16-byte aligned, distinct from F1, and hold a multiple of 16 bytes per direction");
-  if (in_nfre != c->NFRE && (in_nfre < nd3e || in_nfre > c->NFRE || copy_rest))
+  if (in_nfre != c->NFRE && (in_nfre < nd3e || in_nfre > c->NFRE || (copy_rest & 1)))
     return fail("ecwam_hip_propags2_otf: a compact input buffer must hold every advected frequency and cannot be combined with copy_rest");
   if (kijl > kijs && (!f1 || !f3 || !kxlt || !zdello || !cosph || !sinph || !klon || !klat || !kcor || !wlat || !wcor || !cgroup_ext || !cosphm1_ext))
     return fail("ecwam_hip_propags2_otf: null pointer");
   if (f1 == f3) return fail("ecwam_hip_propags2_otf: F1 and F3 must not alias");
-  if (c->obs && kijl > c->n_obs) return fail("ecwam_hip_propags2_otf: more points than the obstruction table holds");
+  if (c->obs && (order ? n : kijl) > c->n_obs) return fail("ecwam_hip_propags2_otf: more points than the obstruction table holds");
   hipStream_t s = (hipStream_t)stream;
   const int N = (c->NANG << 16) | (c->NFRE << 8) | c->NFRE_RED;
-  copy_rest = copy_rest ? 1 : 0;
+  copy_rest = (copy_rest & 1) | (copy_rest & 4);   // bit 0: carry the other frequencies over; bit 2: the order describes 2-D tiles
 #ifdef ECWAM_HIP_DIAGNOSTICS
   { const char* e_ = getenv("ECWAM_HIP_OTF_WALK"); if (e_ && atoi(e_) == 0) copy_rest |= 2; }  // plain grid-stride tile walk
 #endif

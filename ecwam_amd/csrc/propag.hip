@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
   // XCD-aware tile walk: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own 4 MiB L2.  XCD x
   // walks the contiguous tile range [x*tpx, (x+1)*tpx) so that a spectrum fetched as somebody's neighbour is still in that
   // L2 when its own tile (or the next neighbour) comes up; gridDim.x is a multiple of 8 (launch_propags2_otf).
-  const bool xwalk = copy_rest < 2;  // copy_rest & 2: plain grid-stride walk (diagnostics)
+  const bool xwalk = !(copy_rest & 2);  // copy_rest & 2: plain grid-stride walk (diagnostics)
   const int tpx = xwalk ? (ntiles + 7) / 8 : ntiles;
   const int xcd = xwalk ? (blockIdx.x & 7) : 0;
   const int tend = min((xcd + 1) * tpx, ntiles);
@@ -435,18 +435,20 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
     if (threadIdx.x < np) {
       const int t = threadIdx.x;
       const int ij = order ? order[p0 + t] : p0 + t;
-      sP[t] = ctu_point(ij, ngy, kxlt, zdello, xdella, cosph, sinph, wlat, wcor, cosphm1);
       int* q = sI + t * 16;
-      q[0] = ij;
-      q[1] = klon[ij * 2 + 0]; q[2] = klon[ij * 2 + 1];
-      for (int i = 0; i < 4; i++) q[3 + i] = klat[ij * 4 + i];
-      for (int i = 0; i < 8; i++) q[7 + i] = kcor[ij * 8 + i];
+      q[0] = ij;   // < 0: padding entry of a 2-D tile (skipped)
+      if (ij >= 0) {
+        sP[t] = ctu_point(ij, ngy, kxlt, zdello, xdella, cosph, sinph, wlat, wcor, cosphm1);
+        q[1] = klon[ij * 2 + 0]; q[2] = klon[ij * 2 + 1];
+        for (int i = 0; i < 4; i++) q[3 + i] = klat[ij * 4 + i];
+        for (int i = 0; i < 8; i++) q[7 + i] = kcor[ij * 8 + i];
+      }
     }
     __syncthreads();
     for (int it = threadIdx.x; it < np * NFRE; it += blockDim.x) {
       const int t = it / NFRE, m = it - t * NFRE;
       const int* q = sI + t * 16;
-      if (m >= (m0 / VW) * VW && m < ((m1 + VW - 1) / VW) * VW) {   // whole vectors around the range (their spare lanes are computed, not stored)
+      if (q[0] >= 0 && m >= (m0 / VW) * VW && m < ((m1 + VW - 1) / VW) * VW) {   // whole vectors around the range (their spare lanes are computed, not stored)
         T cgl[2], cgy0[2], cgy1[2];
         for (int ic = 0; ic < 2; ic++) {
           cgl[ic] = cg[(size_t)q[1 + ic] * NFRE + m];
@@ -463,20 +465,19 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
       }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < np * NV; e += blockDim.x) {
-      const int t = e / NV, ev = e - t * NV;
+    typedef VecIO<T, VW> IO;
+    auto element = [&](const int t, const int ev) {
       const int k = ev / FV, m = (ev - k * FV) * VW;
       const int* q = sI + t * 16;
       const size_t own = (size_t)q[0] * N, own_in = (size_t)q[0] * NIN;
       const int el = k * NFRE + m, el_in = k * in_k + m;
-      typedef VecIO<T, VW> IO;
       if (m + VW <= m0 || m >= m1) {   // no element of this vector is advected
         if (copy_rest & 1) {
           T v[VW];
           IO::ld(f1 + own_in + el_in, v);
           IO::st(f3 + own + el, v);
         }
-        continue;
+        return;
       }
       const bool partial = (VW > 1) && (m < m0 || m + VW > m1);   // the range boundary cuts this vector
       const CtuPoint<T>& p = sP[t];
@@ -546,6 +547,23 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
       }
       IO::st_stream(f3 + own + el, r);
       if (gout && m < gout_k) IO::st(gout + ((size_t)q[0] * NANG + k) * gout_k + m, r);
+    };
+    if (copy_rest & 4) {
+      // 2-D tiles (decomp.tile2d_order: tile entry t = 4 g + w is the g-th point of a segment of latitude row w of a group of four
+      // rows): wave w walks the points of row w, the four waves work on the same 1 KB chunk of (K, M) of four latitude neighbours at
+      // the same time, chunk by chunk over the whole tile, so that a chunk fetched as a neighbour is served by the CU's L1 / the XCD's
+      // L2 when its owner (or the next neighbour) asks for it a few hundred cycles later
+      const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      for (int c = 0; c < NV; c += 64)
+        for (int g = 0; g < OTF_TP / 4; g++) {
+          const int t = 4 * g + w, ev = c + lane;
+          if (t < np && sI[t * 16] >= 0 && ev < NV) element(t, ev);
+        }
+    } else {
+      for (int e = threadIdx.x; e < np * NV; e += blockDim.x) {
+        const int t = e / NV;
+        if (sI[t * 16] >= 0) element(t, e - t * NV);
+      }
     }
   }
 }
@@ -1191,6 +1209,9 @@ void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, 
   const size_t shmem = OTF_TP * (sizeof(CtuPoint<T>) + 16 * sizeof(int)) +
                        ((size_t)OTF_TP * (obs ? 13 : 5) * NFRE + 6 * NANG) * sizeof(T) + 8 * NANG * sizeof(int) + 16;
   int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
+#ifdef ECWAM_HIP_DIAGNOSTICS
+  { const char* e_ = getenv("ECWAM_HIP_OTF_GRID"); if (e_ && atoi(e_) > 0 && atoi(e_) < grid) grid = atoi(e_); }
+#endif
   grid = (grid + 7) & ~7;  // whole rounds of the 8 XCDs
   constexpr int W = VecOf<T>::W;
   const bool aligned = ((uintptr_t)f1 % 16 == 0) && ((uintptr_t)f3 % 16 == 0);

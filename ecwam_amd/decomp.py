@@ -126,3 +126,32 @@ def strip_order(grid, dom, width: int = 256) -> np.ndarray:
     strip = np.minimum((lon * nstrip).astype(np.int64), nstrip - 1)
     key = (strip * (int(ky.max()) + 1) + ky) * (nmax + 1) + ix
     return np.argsort(key, kind="stable").astype(np.int32)
+
+
+def tile2d_order(grid, dom, rows: int = 4, tile: int = 16) -> np.ndarray:
+    """Processing order of the owned points as 2-D tiles for k_propags2_otf: groups of `rows` consecutive latitude rows are cut
+    into longitude segments of at most tile/rows points per row; a tile lists its points as entry t = rows*g + w = the g-th point
+    of the segment of row w, padded with -1 (skipped by the kernel) where a row of the group is shorter.  The four wavefronts of
+    a workgroup then work on latitude neighbours at the same time (see the kernel).  Pure work ordering, like strip_order."""
+    per = tile // rows
+    ix = np.asarray(grid.ixlg[dom.lo:dom.hi], dtype=np.int64)
+    ky = np.asarray(grid.kxlt[dom.lo:dom.hi], dtype=np.int64)
+    out = []
+    urows = np.unique(ky)
+    for r0 in range(0, len(urows), rows):
+        grp = urows[r0:r0 + rows]
+        idx = []
+        for r in grp:
+            sel = np.nonzero(ky == r)[0]
+            idx.append(sel[np.argsort(ix[sel], kind="stable")])
+        nmax = max(len(a) for a in idx)
+        nbins = -(-nmax // per)
+        t = np.full((nbins, per, rows), -1, dtype=np.int64)
+        for w, a in enumerate(idx):
+            n = len(a)
+            edges = (np.arange(nbins + 1) * n) // nbins         # <= per points per bin since n <= nmax <= per*nbins
+            b = np.searchsorted(edges, np.arange(n), side="right") - 1
+            g = np.arange(n) - edges[b]
+            t[b, g, w] = a
+        out.append(t.reshape(-1))
+    return np.concatenate(out).astype(np.int32)

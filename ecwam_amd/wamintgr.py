@@ -132,8 +132,12 @@ class Wamintgr:
         # optional processing order of the advection (longitude strips); measured neutral on MI355X (the 256 MB Infinity Cache
         # already serves the latitude neighbours), kept as an option
         self.order = None
+        self.tiles2d = False
         if strip_width > 0 and self.n > 4 * strip_width:
             self.order = torch.from_numpy(decomp.strip_order(grid, self.dom, strip_width)).to(self.dev)
+        elif strip_width < 0:      # 2-D tiles of four latitude rows x four longitudes
+            self.order = torch.from_numpy(decomp.tile2d_order(grid, self.dom)).to(self.dev)
+            self.tiles2d = True
         self.wvprpt = torch.zeros((self.n, api.NWPR, NFRE), **z)
         self.ff = torch.zeros((self.n, api.NFF), **z)
         self.ff_next = None
@@ -269,8 +273,11 @@ class Wamintgr:
         def advect_rows(k0, k1, m1, m2, delpro, copy_rest, split=0, src=None):
             if k1 <= k0:
                 return
+            tiled = self.tiles2d and (k0, k1) == (0, self.n)
+            if tiled:                                        # the range indexes the entries of the (padded) tile order
+                k1 = int(self.order.shape[0])
             if src is not None and src is not self.fl1:      # compact fast-wave rows -> fast-wave slots of FL3
-                self.ctx.propags2_otf(src, self.fl3, g, self.cgroup_ext, delpro, k0, k1, m1, m2, copy_rest=False, order=self.order)
+                self.ctx.propags2_otf(src, self.fl3, g, self.cgroup_ext, delpro, k0, k1, m1, m2, copy_rest=False, order=self.order, tiles2d=tiled)
                 return
             if self.irefra:
                 self.ctx.propags2_refra(self.fl1, self.fl3, g, self.cgroup_ext, self.omosnh2kd_ext, self.wavnum_ext, self.refr, delpro, k0,
@@ -279,7 +286,7 @@ class Wamintgr:
                 self.ctx.propags2(self.fl1, self.fl3, g["klon"], g["klat"], g["kcor"], self.w, k0, k1, m1, m2, copy_rest=copy_rest)
             else:
                 self.ctx.propags2_otf(self.fl1, self.fl3, g, self.cgroup_ext, delpro, k0, k1, m1, m2, copy_rest=copy_rest,
-                                      order=self.order, ifrelfmax=split, delpro_lf=self.delpro_lf if split else None,
+                                      order=self.order, tiles2d=tiled, ifrelfmax=split, delpro_lf=self.delpro_lf if split else None,
                                       gout=self.g1 if split else None)   # the fast waves also into the compact buffer
 
         def advect(m1, m2, delpro, copy_rest, split=0, rows=None, src=None):

@@ -169,8 +169,13 @@ int ecwam_hip_ctuw(ecwam_hip_ctx *ctx, int n, int nland, int ngy, double delpro,
  * wlat/wcor as LEFT BY ecwam_hip_ctuw, i.e. after the CTUWINI land snapping) plus those of ecwam_hip_propags2; the
  * result is bit-identical to ecwam_hip_ctuw followed by ecwam_hip_propags2 with the same delpro.  ecwam_hip_ctuw with
  * w == NULL performs the CTUWINI snapping and the CFL / weight-range checks without storing the weights.
- *   order  optional int[>=kijl]: rows are processed in the order order[kijs..kijl) (a permutation of [kijs,kijl) chosen by
- *          the host for cache locality, e.g. longitude strips); NULL = natural order.  Results do not depend on it.
+ *   order  optional int[>=kijl]: the rows order[kijs..kijl) are processed, in that sequence (chosen by the host for cache
+ *          locality, e.g. longitude strips); entries < 0 are padding and skipped, so the list may be longer than n; NULL =
+ *          natural order.  Results do not depend on it.
+ *   copy_rest  bit 0: the frequencies outside nd3s..nd3e are copied from f1; bit 2 (value 4, needs order): the list describes
+ *          2-D tiles of 16 entries, entry 4 g + w = g-th point of a longitude segment of the w-th of four adjacent latitude
+ *          rows; the four wavefronts of a workgroup then work on latitude neighbours at the same time (40 % less fabric
+ *          read traffic at O320, same time: DESIGN.md section 3).
  */
 int ecwam_hip_propags2_otf(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n, int ngy, double delpro, const int *kxlt,
                            const void *zdello, double xdella, const void *cosph, const void *sinph, const int *klon,

@@ -867,3 +867,28 @@ def test_restart_record_round_trip_through_the_device(api, prec, tmp_path):
     torch.cuda.synchronize()
     assert torch.equal(a.fl1[: g.nsea], b.fl1[: g.nsea]) and torch.equal(a.mij, b.mij) and torch.equal(a.xllws, b.xllws)
     a.ctx.close(); b.ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,lf", [("sp", 0), ("sp", 4), ("dp", 0)])
+def test_advection_work_orders_are_bit_identical(api, prec, lf):
+    """PROPAG_WAM in natural order, in longitude strips (decomp.strip_order) and in the 2-D tiles of decomp.tile2d_order (padded with
+    skipped entries, one wavefront per latitude row of a tile): pure work orderings, the advected spectra must not change by a bit
+    (two steps, continents mask so that land neighbours occur, lf > 0: fast-wave sub-steps through the compact buffer)."""
+    from ecwam_amd import grid as G
+    from ecwam_amd.wamintgr import Wamintgr
+
+    cfg = Config(nang=12, nfre=36, nfre_red=32, idelt=900, idelpro=900)
+    g = G.build_grid(24, mask="continents")
+    out = []
+    for strip in (0, 16, -1):
+        m = Wamintgr(cfg, g, prec, strip_width=strip, **(dict(ifrelfmax=lf, delpro_lf=450.0) if lf else {}))
+        m.init_synthetic(seed=5)
+        assert (m.order is None) == (strip == 0) and m.tiles2d == (strip < 0)
+        for _ in range(2):
+            m.propag()
+        torch.cuda.synchronize()
+        out.append(m.fl1[: m.n].cpu().numpy())
+        m.close() if hasattr(m, "close") else None
+    assert np.isfinite(out[0]).all() and out[0].max() > 0
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])

@@ -258,6 +258,13 @@ def test_oracle_optional_branches_invariants():
     d = decomp.local_domain(g, 0, 1)
     order = decomp.strip_order(g, d, 32)
     assert sorted(order.tolist()) == list(range(d.n))
+    # 2-D tile order: every point once, padded to whole tiles, a tile spans at most four latitude rows
+    t2 = decomp.tile2d_order(g, d)
+    assert t2.shape[0] % 16 == 0 and sorted(t2[t2 >= 0].tolist()) == list(range(d.n))
+    ky = np.asarray(g.kxlt)[d.lo:d.hi]
+    for tile in t2.reshape(-1, 16):
+        rows = ky[tile[tile >= 0]]
+        assert rows.size and rows.max() - rows.min() <= 3
 
 
 GLOO_WORKER = r'''

@@ -205,6 +205,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
   xm0 = 0ull; xm1 = 0ull;
   const V2<T> z2 = {T(0), T(0)};
   wse = z2; wslast = z2; apl = z2;
+  T sp_even = T(0);
 #pragma unroll
   for (int s = 0; s < NS; s++) { rX[s] = T(0); rY[s] = T(0); }
   const T* tF = L.tile + L.own;
@@ -296,8 +297,10 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
     if (LLSNEG) {
       apl = apl + (fl * f - sp) * lane_get(L.rRHOWG, m);
       *reinterpret_cast<V2<T>*>(gfl + (size_t)m * NANG) = fl;
-      // the lane's share of the row's positive input: summed below the cut-off once MIJ is known (stresso.F90:160-168), no all-reduce here
-      gsp[(size_t)m * NANG] = sp.x + sp.y;
+      // the lane's share of the row's positive input: summed below the cut-off once MIJ is known (stresso.F90:160-168), no all-reduce
+      // here; two rows per 8-byte store so that the point's lanes write whole, contiguous lines
+      if (m & 1) *reinterpret_cast<V2<T>*>(gsp + (size_t)(m >> 1) * NANG) = V2<T>{sp_even, sp.x + sp.y};
+      else sp_even = sp.x + sp.y;
     }
     if (xl0) xm0 |= (1ull << m);
     if (xl1) xm1 |= (1ull << m);
@@ -577,10 +580,13 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     }
     if (phiwa) {
 #pragma unroll 6
-      for (int m = 0; m < NFRE; m++) {
-        T w = lane_get(L.rRHOWG, m);
-        if (m + 1 == MIJ && MIJ != NFRE) w = T(0.5) * w;
-        sp += (m + 1 <= MIJ ? w : T(0)) * gsp[(size_t)m * NANG];
+      for (int m = 0; m < NFRE; m += 2) {
+        const V2<T> v = *reinterpret_cast<const V2<T>*>(gsp + (size_t)(m >> 1) * NANG);   // rows m, m+1
+        T w0 = lane_get(L.rRHOWG, m), w1 = lane_get(L.rRHOWG, m + 1);
+        if (m + 1 == MIJ && MIJ != NFRE) w0 = T(0.5) * w0;
+        if (m + 2 == MIJ && MIJ != NFRE) w1 = T(0.5) * w1;
+        sp += (m + 1 <= MIJ ? w0 : T(0)) * v.x;
+        sp += (m + 2 <= MIJ ? w1 : T(0)) * v.y;
       }
     }
     s = v4_allsum<G, T>(s, L.rot);

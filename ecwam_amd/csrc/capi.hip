@@ -29,7 +29,7 @@ struct ecwam_hip_ctx {
   double* norm_scratch = nullptr;   // ecwam_hip_outwnorm: per-context reduction scratch (4 + 4 x 256 doubles)
   int implsch_variant;  // 2: two-tile fused-sweep kernel (needs the DIA rotation structure), 1: three-tile kernel
   // fourth kernel generation (implsch_v4.h): DIA rotations K1 = K -+ r1, K2 = K +- r2, NSDSNTH = nh; ok = the tables have that structure
-  int v4_ok = 0, v4_r1 = 0, v4_r2 = 0, v4_nh = 0;
+  int v4_ok = 0, v4_r1 = 0, v4_r2 = 0, v4_nh = 0, v4_shelter = 0;
   int implsch_gen = 0;  // 0: the fastest kernel generation that covers the configuration; 1 / 2 / 4: at most that generation (tests)
   // advection halo exchange (MPEXCHNG): peers, the owned rows each of them needs (concatenated in peer order) and where their rows
   // land; RCCL communicator + a stream of its own so that the exchange runs beside the interior stencil
@@ -64,7 +64,7 @@ template <typename T> void launch_c2p(const void*, void*, int, int, int, int, in
 template <typename T> void launch_p2c(const void*, void*, int, int, int, int, int, hipStream_t);
 template <typename T> void launch_pack(const void*, const int*, int, int, void*, hipStream_t);
 template <typename T> int launch_implsch(const void*, int, int, void*, const void*, void*, void*, int*, void*, double*, void*, int, int, int, hipStream_t);
-template <typename T> int launch_implsch4(const void*, int, int, void*, const void*, void*, void*, int*, void*, int, int, int, int, int, hipStream_t);
+template <typename T> int launch_implsch4(const void*, int, int, void*, const void*, void*, void*, int*, void*, int, int, int, int, int, int, hipStream_t);
 
 // Does the fourth kernel generation cover these tables?  It needs the pull-form DIA structure with K1W = K -+ r1, K11W = K1W -+ 1,
 // K2W = K +- r2, K21W = K2W +- 1 (kh = 1 / 2) and saturation weights that depend on the tap only (init_sdiss_ardh.F90:88-94: they
@@ -88,7 +88,7 @@ static void v4_probe(const DevTab<T>& h, ecwam_hip_ctx* c) {
       if ((e < 0 ? -e : e) > T(16) * eps * wmax) return;
       if (h.INDICESSAT[t][k] != ((k - h.NSDSNTH + t) % NANG + NANG) % NANG) return;
     }
-  c->v4_r1 = r1; c->v4_r2 = r2; c->v4_nh = h.NSDSNTH; c->v4_ok = 1;
+  c->v4_r1 = r1; c->v4_r2 = r2; c->v4_nh = h.NSDSNTH; c->v4_shelter = (h.TAUWSHELTER != T(0)); c->v4_ok = 1;
 }
 
 template <typename T>
@@ -557,11 +557,16 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   int rc, variant = c->implsch_variant;
   if (c->implsch_gen == 1) variant = 1;   // tests: the three-tile kernel (its own case: interaction tables without the rotation structure)
   if (c->p.llnormagam) variant |= 16;
-  if (c->p.llgcbz0 || c->p.lciwa1 || c->p.lciwa2 || c->p.lciwa3 || c->p.lciscal || c->p.lwnemocou || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin || c->p.iphys == 0 || c->p.icode != 3 || !c->p.lwvflx_snl) variant |= 32;
-  // fourth kernel generation (implsch_v4.h): flag set A without the optional branches, single and double precision
-  if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !(variant & (16 | 32)) && (variant & 15) == 2 && !wam2nemo && !dbg) {
-    DISPATCH(rc = launch_implsch4<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, s),
-             rc = launch_implsch4<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, s));
+  const bool rare = c->p.lciwa1 || c->p.lciwa2 || c->p.lciwa3 || c->p.lciscal || c->p.lwnemocou || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin ||
+                    c->p.iphys == 0 || c->p.icode != 3 || !c->p.lwvflx_snl;
+  if (c->p.llgcbz0 || rare) variant |= 32;
+  // fourth kernel generation (implsch_v4.h): flag sets A and B (LLGCBZ0, LLNORMAGAM) without the other optional branches, single and
+  // double precision.  The sheltered growth needs TAUWSHELTER /= 0, the normalised one TAUWSHELTER = 0 (setwavphys.F90:150-190).
+  const int ext = (c->p.llnormagam || c->p.llgcbz0) ? 1 : 0;
+  if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !rare && (variant & 15) == 2 && !wam2nemo && !dbg &&
+      (c->p.llnormagam ? c->v4_shelter == 0 : c->v4_shelter != 0)) {
+    DISPATCH(rc = launch_implsch4<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s),
+             rc = launch_implsch4<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s));
     if (rc == 0) { HIPCHK(hipGetLastError()); return 0; }
   }
   DISPATCH(rc = launch_implsch<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s),

@@ -311,10 +311,123 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
   WSYNC();
 }
 
+// SINPUT_ARD with the normalised growth rate (LLNORMAGAM = T, sinput_ard.F90:380-437; TAUWSHELTER = 0 in that physics: no sheltering
+// recurrence, the growth direction is the wind direction).  Per row and gust state one all-reduce for SUMF / SUMFSIN2, one for the row
+// integrals.  xng: plane [M] of CONSTN RNFAC / RAORW XK2CG(M) (filled here, in the plane SQRT(WAVNUM) leaves free between the two FKMEAN).
+template <typename T, int NANG, int PP, int NGST, bool LLSNEG>
+__device__ void v4_sinput_n(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, const T* __restrict__ xk2cg, T UFRIC, T Z0M, T RAORW, T RNFAC,
+                            T SIG_N, T TEMP2, T PTURB, T AIRD_PVISC, V2<T> coswdif, V2<T> sinwdif2, T* __restrict__ gfl, T* __restrict__ gsp,
+                            unsigned long long& xm0, unsigned long long& xm1, V2<T>& wse, V2<T>& wslast, V2<T>& apl,
+                            T (&rX)[V4_NFRE / (NANG / 2)], T (&rY)[V4_NFRE / (NANG / 2)]) {
+  constexpr int G = NANG / 2, NFRE = V4_NFRE, RS = PP * NANG, NS = NFRE / G;
+  const T CONST1 = tb.BETAMAXOXKAPPA2;
+  const T CSTRNFAC = (tb.DELTH / (tb.XKAPPA * tb.ZPI)) * RNFAC / RAORW;
+  const T FU = m_abs(tb.SWELLF3), FUD = tb.SWELLF2;
+  const T AVG = T(1) / T(NGST);
+  T* xng = L.sq;
+  for (int m = L.j; m < NFRE; m += G) {
+    L.zcn[m] = m_log(L.fac4[m * 4 + Q4_WAVNUM] * Z0M);
+    xng[m] = CSTRNFAC * xk2cg[m];
+  }
+  WSYNC();
+  const T XKAPPA = tb.XKAPPA, ZALP = tb.ZALP;
+  T USTP[2], USTPM1[2];
+  if (NGST == 1) USTP[0] = UFRIC;
+  else { USTP[0] = UFRIC * (T(1) + SIG_N); USTP[1] = UFRIC * (T(1) - SIG_N); }
+#pragma unroll
+  for (int ig = 0; ig < NGST; ig++) USTPM1[ig] = T(1) / m_max(USTP[ig], tb.EPSUS);
+  xm0 = 0ull; xm1 = 0ull;
+  const V2<T> z2 = {T(0), T(0)};
+  wse = z2; wslast = z2; apl = z2;
+  T sp_even = T(0);
+#pragma unroll
+  for (int s = 0; s < NS; s++) { rX[s] = T(0); rY[s] = T(0); }
+  const bool c0 = coswdif.x > T(0.01), c1 = coswdif.y > T(0.01);
+  const V2<T> rcos = {f_rcp(coswdif.x), f_rcp(coswdif.y)};
+  T GAMNORMA[2] = {T(1), T(1)};
+  const T* tF = L.tile + L.own;
+  for (int m = 0; m < NFRE; m++) {
+    const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
+    const V2<T> cw = *reinterpret_cast<const V2<T>*>(L.fac4 + m * 4 + Q4_CINV);
+    const T ZCN = L.zcn[m], cinv_m = cw.x, XNGAMCONST = xng[m];
+    const T SIGm = lane_get(L.rZPIFR, m);
+    const T DSTAB1 = LLSNEG ? (lane_get(L.rC5, m) * AIRD_PVISC) * cw.y : T(0);
+    const T CNSN = (SIGm * CONST1) * RAORW;
+    const T TEMP1 = LLSNEG ? lane_get(L.rT1, m) * RAORW : T(0);
+    V2<T> SLP[2], FLP[2];
+    bool xl0 = false, xl1 = false;
+#pragma unroll
+    for (int ig = 0; ig < NGST; ig++) {
+      const T UCN = USTP[ig] * cinv_m;
+      const T UCNZALPD = XKAPPA * f_rcp(UCN + ZALP);
+      V2<T> gam0 = z2;
+      const T Z0 = ZCN + UCNZALPD * rcos.x, Z1 = ZCN + UCNZALPD * rcos.y;
+      const bool n0 = c0 && (Z0 < T(0)), n1 = c1 && (Z1 < T(0));
+      if (__builtin_amdgcn_ballot_w64(n0 || n1) != 0ull) {
+        const V2<T> ZL = {Z0, Z1};
+        const V2<T> Z2X = ZL * ZL * (coswdif * UCN);
+        const V2<T> ex = {f_exp(Z0), f_exp(Z1)};
+        const V2<T> g = ex * Z2X * Z2X * CNSN;
+        gam0.x = n0 ? g.x : T(0);
+        gam0.y = n1 ? g.y : T(0);
+        xl0 = xl0 || n0;
+        xl1 = xl1 || n1;
+        const V2<T> a = gam0 * f, as2 = a * sinwdif2;
+        const V2<T> sm = v4_allsum<G, T>(V2<T>{a.x + a.y, as2.x + as2.y}, L.rot);   // SUMF, SUMFSIN2
+        const T ZNZ = XNGAMCONST * USTPM1[ig];
+        GAMNORMA[ig] = (T(1) + ZNZ * sm.y) / (T(1) + ZNZ * sm.x);
+      }
+      V2<T> dstab = z2;
+      if (LLSNEG) {
+        const V2<T> DSTAB2 = TEMP1 * (TEMP2 + (FU + FUD * coswdif) * USTP[ig]);
+        dstab = DSTAB1 + PTURB * DSTAB2;
+      }
+      const V2<T> gn = gam0 * GAMNORMA[ig];
+      FLP[ig] = gn + dstab;
+      SLP[ig] = gn * f;
+    }
+    V2<T> sp = SLP[0], fl = FLP[0];
+    if (NGST == 2) { sp = sp + SLP[1]; fl = fl + FLP[1]; }
+    sp = AVG * sp;
+    fl = AVG * fl;
+    const bool anygrow = __builtin_amdgcn_ballot_w64(xl0 || xl1) != 0ull;
+    T xrow = T(0), yrow = T(0);
+    if (anygrow) {
+      const V2<T> sx = sp * L.sinth, sy = sp * L.costh;
+      const V2<T> xs = v4_allsum<G, T>(V2<T>{sx.x + sx.y, sy.x + sy.y}, L.rot);
+      xrow = xs.x; yrow = xs.y;
+    }
+    {  // the lane that owns frequency m keeps its row integrals
+      const int ms = m / G, mj = m - ms * G;
+      const bool mine = (L.j == mj);
+#pragma unroll
+      for (int s = 0; s < NS; s++) {
+        const bool w = mine && (ms == s);
+        rX[s] = w ? xrow : rX[s];
+        rY[s] = w ? yrow : rY[s];
+      }
+    }
+    if (LLSNEG) {
+      apl = apl + (fl * f - sp) * lane_get(L.rRHOWG, m);
+      *reinterpret_cast<V2<T>*>(gfl + (size_t)m * NANG) = fl;
+      if (m & 1) *reinterpret_cast<V2<T>*>(gsp + (size_t)(m >> 1) * NANG) = V2<T>{sp_even, sp.x + sp.y};
+      else sp_even = sp.x + sp.y;
+    }
+    if (xl0) xm0 |= (1ull << m);
+    if (xl1) xm1 |= (1ull << m);
+    const V2<T> x = {xl0 ? f.x : T(0), xl1 ? f.y : T(0)};
+    wse = wse + V2<T>{lane_get(L.rDFIM, m), lane_get(L.rDFIMOFR, m)} * (x.x + x.y);
+    wslast = x;
+  }
+  WSYNC();
+}
+
 // One wavefront advances PP sea points.  Lanes beyond PP G shadow other lanes and the points of a short last wave shadow its
 // last point: shadows run the same instructions on the same data, so their LDS and global stores repeat their original's values
 // at the same addresses -- no store is predicated.
-template <typename T, int NANG, int PP, int R1, int R2, int NH>
+// EXT: the build that also carries LLGCBZ0 (gravity-capillary roughness: HALPHAP, TAUT_Z0 with STRESS_GC per point across the wave)
+// and LLNORMAGAM (normalised growth rate) -- the cy49r1 / cy50r1 physics; the flag-set-A build has none of that code.
+template <typename T, int NANG, int PP, int R1, int R2, int NH, bool EXT>
 // single precision: two waves per SIMD (LDS: 8 waves per CU), at most 256 VGPRs; double precision: the LDS holds one wave per SIMD
 // (40 KB per wave) and the kernel may use the whole register file (340 registers: no scratch)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(V4_WPE_MIN(T), 2)))
@@ -436,9 +549,12 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     q[C_TAUW] = ff[8]; q[C_TAUWDIR] = ff[9];
     q[C_RAORW] = m_max(AIRD, T(1)) * tb.ROWATERM1; q[C_EMAXDPT] = ff[14]; q[C_DEPTH] = ff[15];
     q[C_SINWD] = m_sin(WDWAVE); q[C_COSWD] = m_cos(WDWAVE);
-    q[C_RNFAC] = T(1);
+    T RNFAC = T(1);   // sinflx.F90:116-120
+    if (EXT && tb.LLNORMAGAM && tb.LLCAPCHNK) RNFAC = T(1) + tb.DTHRN_A * (T(1) + m_tanh(WSWAVE - tb.DTHRN_U));
+    q[C_RNFAC] = RNFAC;
     T UFRIC = ff[7], Z0M = ff[10], Z0B = ff[11], CHRNCK = ff[12];
-    taut_z0_a(tb, 0, WSWAVE, WDWAVE, ff[8], ff[9], UFRIC, Z0M, Z0B, CHRNCK);
+    if (EXT && tb.LLGCBZ0) q[C_TWCOS] = m_cos(WDWAVE - ff[9]);   // COSDIFF of the first TAUT_Z0, which runs per point across the wave below
+    else taut_z0_a(tb, 0, WSWAVE, WDWAVE, ff[8], ff[9], UFRIC, Z0M, Z0B, CHRNCK);
     q[C_UFRIC] = UFRIC; q[C_Z0M] = Z0M; q[C_Z0B] = Z0B; q[C_CHRNCK] = CHRNCK;
     q[C_SPARE] = ff[2];   // CICOVER
   }
@@ -536,7 +652,60 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   }
   WSYNC();
   V4_PHASE_EXIT(202);
+  const bool gcb = EXT && tb.LLGCBZ0, norma = EXT && tb.LLNORMAGAM;
+  V2<T> sinwdif2 = z2;
+  if (norma) {
+    const V2<T> sd = L.sinth * coswd - L.costh * sinwd;   // SIN(TH - WDWAVE)
+    sinwdif2 = sd * sd;
+  }
+  // gravity-capillary TAUT_Z0 of every point of the wave, one after the other: STRESS_GC's wavenumber sum runs across the 64 lanes
+  auto taut_z0_gc = [&](int iusfg) {
+    for (int q = 0; q < PP; q++) {
+      T* cq = sSC + q * NSC;
+      T UF = cq[C_UFRIC], Z0 = cq[C_Z0M], Z0Bv = cq[C_Z0B], CH = cq[C_CHRNCK];
+      const T cosd = iusfg ? cq[C_COSWD] * cq[C_TWCOS] + cq[C_SINWD] * cq[C_TWSIN] : cq[C_TWCOS];
+      taut_z0_b_w(tb, lane, iusfg, cq[C_HALP], cq[C_WSWAVE], cosd, cq[C_TAUW], cq[C_RNFAC], UF, Z0, Z0Bv, CH);
+      T sgn = T(0);
+      if (iusfg) sgn = wsigstar(tb, cq[C_WSWAVE], UF, Z0, cq[C_WSTAR]);
+      WSYNC();
+      if (lane == 0) {
+        cq[C_UFRIC] = UF; cq[C_Z0M] = Z0; cq[C_Z0B] = Z0Bv; cq[C_CHRNCK] = CH;
+        if (iusfg) cq[C_SIGN] = sgn;
+      }
+      WSYNC();
+    }
+  };
+  if (gcb) {
+    // HALPHAP (halphap.F90:68-112, meansqs_lf.F90:80-100, femean.F90:84-121): Phillips parameter of the wind-sea half plane
+    const V2<T> wd = {__builtin_signbit(coswdif.x) ? T(0) : T(1), __builtin_signbit(coswdif.y) ? T(0) : T(1)};
+    V2<T> sa = z2, sb = z2;   // (XMSS, EM), (FM, last row of MAX(F WD, EPSMIN))
+    T f1d = T(0);
+    for (int m = 0; m < NFRE; m++) {
+      const V2<T> v = *reinterpret_cast<const V2<T>*>(tF + m * RS) * wd;
+      const T t1 = v.x + v.y, t2 = m_max(v.x, tb.EPSMIN) + m_max(v.y, tb.EPSMIN);
+      const T dfm = lane_get(L.rDFIM, m), wn = L.fac4[m * 4 + Q4_WAVNUM];
+      sa = sa + V2<T>{(dfm * wn * wn) * t1, dfm * t2};
+      sb.x = sb.x + lane_get(L.rDFIMOFR, m) * t2;
+      if (m == NFRE - 1) { sb.y = t2; f1d = t1; }
+    }
+    sa = v4_allsum<G, T>(sa, L.rot); sb = v4_allsum<G, T>(sb, L.rot);
+    const T F1D = tb.DELTH * v4_allsum1<G, T>(f1d, L.rot);
+    const T XMSS = sa.x;
+    const T EM = sa.y + tb.WETAIL * frl * tb.DELTH * sb.y;
+    T FM = sb.x + tb.FRTAIL * tb.DELTH * sb.y;
+    FM = m_max(EM / FM, tb.FR[0]);
+    const T ATAIL = tb.ZPI4GM2 * tb.FR5[NFRE - 1] * F1D;
+    T ALPHAP;
+    if (EM > T(0) && FM < tb.FR[NFRE - 3]) {
+      ALPHAP = XMSS / (m_log(tb.FR[NFRE - 1]) - m_log(FM));
+      if (ALPHAP > tb.ALPHAPMAX) ALPHAP = ATAIL;
+    } else ALPHAP = ATAIL;
+    if (j == 0) c[C_HALP] = T(0.5) * m_min(ALPHAP, tb.ALPHAPMAX);
+    WSYNC();
+    taut_z0_gc(0);
+  }
   T UFRIC = c[C_UFRIC], Z0M = c[C_Z0M];
+  const T RNFAC = c[C_RNFAC];
 
   auto femws_finish = [&](V2<T> wse, V2<T> wslast, T& FM, T& EMW) {
     const V2<T> s = v4_allsum<G, T>(wse, L.rot);
@@ -595,8 +764,13 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     const V2<T> fm = *reinterpret_cast<const V2<T>*>(tF + (MIJ - 1) * RS);
     const V2<T> fc2 = fm * cpos * cpos, fc3 = fc2 * cpos;
     const V2<T> h = v4_allsum<G, T>(V2<T>{fc3.x + fc3.y, fc2.x + fc2.y}, L.rot);
+    V2<T> hn = z2;   // F1DSIN2, F1D of the normalised growth rate (tau_phi_hf.F90:187-196)
+    if (norma) {
+      const V2<T> fs = fm * sinwdif2;
+      hn = v4_allsum<G, T>(V2<T>{fs.x + fs.y, fm.x + fm.y}, L.rot);
+    }
     if (j == 0) {
-      c[C_XS] = s.x; c[C_YS] = s.y; c[C_F1DCOS3] = tb.DELTH * h.x; c[C_F1DCOS2] = tb.DELTH * h.y; c[C_F1DSIN2] = T(0); c[C_F1D] = T(0);
+      c[C_XS] = s.x; c[C_YS] = s.y; c[C_F1DCOS3] = tb.DELTH * h.x; c[C_F1DCOS2] = tb.DELTH * h.y; c[C_F1DSIN2] = tb.DELTH * hn.x; c[C_F1D] = tb.DELTH * hn.y;
       c[C_MIJ] = (T)MIJ;
       if (phiwa) c[C_PHIWA] = PH;
     }
@@ -606,21 +780,26 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   unsigned long long xm0, xm1;
   V2<T> wse, wslast, apl;
   T FMEANWS, EMW;
-  v4_sinput<T, NANG, PP, 1, false>(tb, L, UFRIC, Z0M, RAORW, T(0), T(0), T(0), T(0), sinwd, coswd, nullptr, nullptr, xm0, xm1, wse, wslast, apl, rX, rY);
+  if (norma) v4_sinput_n<T, NANG, PP, 1, false>(tb, L, wp + 3 * NFRE, UFRIC, Z0M, RAORW, RNFAC, T(0), T(0), T(0), T(0), coswdif, sinwdif2, nullptr, nullptr,
+                                               xm0, xm1, wse, wslast, apl, rX, rY);
+  else v4_sinput<T, NANG, PP, 1, false>(tb, L, UFRIC, Z0M, RAORW, T(0), T(0), T(0), T(0), sinwd, coswd, nullptr, nullptr, xm0, xm1, wse, wslast, apl, rX, rY);
   femws_finish(wse, wslast, FMEANWS, EMW);
   int MIJ = frcutindex4(FMEANWS, UFRIC);
   post_stress(MIJ, apl, false);
   WSYNC();
   V4_PHASE_EXIT(203);
   // ---- stage 2: STRESSO scalars, second TAUT_Z0, WSIGSTAR, swell set-up, SDIWBK
-  v4_stresso<T, PP, false>(tb, sSC, lane, false);
+  v4_stresso<T, PP, EXT>(tb, sSC, lane, false);
   WSYNC();
+  if (gcb) taut_z0_gc(1);   // (with WSIGSTAR)
   if (lane < PP) {
     T* q = sSC + lane * NSC;
-    T UF = q[C_UFRIC], Z0 = q[C_Z0M], Z0Bv = q[C_Z0B], CH = q[C_CHRNCK];
-    taut_z0_c(tb, 1, q[C_WSWAVE], q[C_COSWD] * q[C_TWCOS] + q[C_SINWD] * q[C_TWSIN], q[C_TAUW], UF, Z0, Z0Bv, CH);
-    q[C_UFRIC] = UF; q[C_Z0M] = Z0; q[C_Z0B] = Z0Bv; q[C_CHRNCK] = CH;
-    q[C_SIGN] = wsigstar(tb, q[C_WSWAVE], UF, Z0, q[C_WSTAR]);
+    if (!gcb) {
+      T UF = q[C_UFRIC], Z0 = q[C_Z0M], Z0Bv = q[C_Z0B], CH = q[C_CHRNCK];
+      taut_z0_c(tb, 1, q[C_WSWAVE], q[C_COSWD] * q[C_TWCOS] + q[C_SINWD] * q[C_TWSIN], q[C_TAUW], UF, Z0, Z0Bv, CH);
+      q[C_UFRIC] = UF; q[C_Z0M] = Z0; q[C_Z0B] = Z0Bv; q[C_CHRNCK] = CH;
+      q[C_SIGN] = wsigstar(tb, q[C_WSWAVE], UF, Z0, q[C_WSTAR]);
+    }
     swell_setup_pt(tb, q);
     q[C_SDS] = sdiwbk_pt(tb, q[C_EMAXDPT], q[C_EMEAN], q[C_F1MEAN], q[C_DEPTH]);
   }
@@ -630,15 +809,17 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   V4_PHASE_EXIT(204);
   // ---- second SINFLX call: wind-input coefficient (parked in the point's XLLWS block, [M][K]), XLLWS, MIJ, wave stress, PHIWA
   T* gx = xllws + (size_t)ij * N + 2 * j;   // this lane's pair in row 0 of the block
-  v4_sinput<T, NANG, PP, 2, true>(tb, L, UFRIC, Z0M, RAORW, c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], sinwd, coswd, gx, gsp, xm0, xm1, wse,
-                                  wslast, apl, rX, rY);
+  if (norma) v4_sinput_n<T, NANG, PP, 2, true>(tb, L, wp + 3 * NFRE, UFRIC, Z0M, RAORW, RNFAC, c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], coswdif,
+                                              sinwdif2, gx, gsp, xm0, xm1, wse, wslast, apl, rX, rY);
+  else v4_sinput<T, NANG, PP, 2, true>(tb, L, UFRIC, Z0M, RAORW, c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], sinwd, coswd, gx, gsp, xm0, xm1, wse,
+                                       wslast, apl, rX, rY);
   femws_finish(wse, wslast, FMEANWS, EMW);
   MIJ = frcutindex4(FMEANWS, UFRIC);
   post_stress(MIJ, apl, true);
   WSYNC();
   V4_PHASE_EXIT(205);
   // ---- stage 3: STRESSO of the second call (TAUW, TAUWDIR, PHIWA)
-  v4_stresso<T, PP, false>(tb, sSC, lane, true);
+  v4_stresso<T, PP, EXT>(tb, sSC, lane, true);
   WSYNC();
   V4_PHASE_EXIT(206);
 

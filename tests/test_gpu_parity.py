@@ -97,21 +97,47 @@ def _implsch_parity(api, nang, nred, prec, llnormagam, gen=0):
     ctx.close()
 
 
-@pytest.mark.parametrize("nang,nred", [(36, 36), (24, 29)])
+@pytest.mark.parametrize("nang,nred", [(36, 36), (24, 29), (12, 25)])
 @pytest.mark.parametrize("prec", ["dp", "sp"])
-def test_implsch_parity_flag_set_b(api, nang, nred, prec):
+@pytest.mark.parametrize("gen", [0, 2])
+def test_implsch_parity_flag_set_b(api, nang, nred, prec, gen):
     """Flag set B of SURVEY.md 8(d) (cy49r1): LLGCBZ0=T (HALPHAP, gravity-capillary TAUT_Z0 with STRESS_GC, OMEGAGC limit of
-    the TAUHF quadrature) + LLNORMAGAM=T."""
+    the TAUHF quadrature) + LLNORMAGAM=T.  gen 0: the EXT build of k_implsch4 (several points per wavefront), gen 2: k_implsch2."""
     cfg = Config(nang=nang, nfre=36, nfre_red=nred, llgcbz0=True, llnormagam=True)
-    case = H.make_point_case(1536, cfg, prec, spectra="mixed")
+    n = 1537   # a short last wavefront in every layout
+    case = H.make_point_case(n, cfg, prec, spectra="mixed")
     ref = H.oracle_implsch(case, _oracle(cfg, prec))
     ctx = api.HipContext(case["tables"])
+    ctx.set_implsch_generation(gen)
     got = H.gpu_implsch(case, ctx)
     st = H.compare_implsch(ref, got, case["tables"])
     ctx.close()
-    n = 1536
     assert np.isfinite(got["FL1"]).all() and np.isfinite(got["FF"]).all() and np.isfinite(got["INTF"]).all()
     _assert_implsch_stats(st, n, prec)
+
+
+@pytest.mark.parametrize("flags", [dict(llgcbz0=True), dict(llnormagam=True), dict(llgcbz0=True, llnormagam=True, llcapchnk=False)],
+                         ids=["gcbz0", "normagam", "b_nocapchnk"])
+def test_implsch_flag_set_b_generations_agree(api, flags):
+    """The EXT build of k_implsch4 against k_implsch2 on LLGCBZ0 alone (sheltered growth + gravity-capillary roughness), LLNORMAGAM
+    alone and both: MIJ and XLLWS identical, spectra within 2e-5 of the point's peak, forcing outputs within 5e-5 of their scale."""
+    cfg = Config(nang=36, nfre=36, nfre_red=36, **flags)
+    n = 2 * 1024 + 1
+    case = H.make_point_case(n, cfg, "sp", spectra="mixed", seed=99)
+    out = {}
+    ctx = api.HipContext(case["tables"])
+    for gen in (2, 4):
+        ctx.set_implsch_generation(gen)
+        out[gen] = H.gpu_implsch(case, ctx)
+    ctx.close()
+    a, b = out[2], out[4]
+    assert np.array_equal(a["MIJ"], b["MIJ"]) and np.array_equal(a["XLLWS"], b["XLLWS"])
+    peak = np.abs(a["FL1"]).max(axis=(1, 2), keepdims=True).astype(float)
+    assert np.max(np.abs(a["FL1"].astype(float) - b["FL1"].astype(float)) / peak) < 2e-5
+    ffs = np.abs(a["FF"]).max(axis=0, keepdims=True).astype(float) + 1e-30
+    assert np.max(np.abs(a["FF"].astype(float) - b["FF"].astype(float)) / ffs) < 5e-5
+    st = H.compare_implsch(a, b, case["tables"])
+    assert st["intf_max_rel_all"] < 5e-3, st
 
 
 @pytest.mark.parametrize("prec", ["dp", "sp"])

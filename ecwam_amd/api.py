@@ -220,7 +220,7 @@ class HipContext:
         self._chk(self.lib.ecwam_hip_implsch(self._h, kijs, kijl, *a, pw, pd, _stream_ptr()))
 
     def set_implsch_generation(self, gen: int) -> None:
-        """Cap the IMPLSCH kernel generation (2, 3, 4; 0 = automatic): include/ecwam_hip.h ecwam_hip_set_implsch_generation."""
+        """Cap the IMPLSCH kernel generation (2 or 4; 0 = automatic): include/ecwam_hip.h ecwam_hip_set_implsch_generation."""
         self._chk(self.lib.ecwam_hip_set_implsch_generation(self._h, int(gen)))
 
     # -- OUTBS subset (outblock.F90 parameters 1-3) and OUTWNORM statistics, on the device

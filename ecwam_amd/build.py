@@ -19,7 +19,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 
 
 INCLUDE = os.path.join(HERE, "..", "include", "ecwam_hip.h")
-DEPS = {"capi.hip": ["dev.h"], "propag.hip": ["dev.h"], "implsch.hip": ["dev.h", "implsch_v1.h", "implsch_v2.h"], "implsch4.hip": ["dev.h", "implsch_v1.h", "implsch_v2.h", "implsch_v4.h"], "outbs.hip": ["dev.h"]}
+DEPS = {"capi.hip": ["dev.h"], "propag.hip": ["dev.h"], "implsch.hip": ["dev.h", "implsch_common.h", "implsch_v2.h"], "implsch4.hip": ["dev.h", "implsch_common.h", "implsch_v2.h", "implsch_v4.h"], "outbs.hip": ["dev.h"]}
 
 
 def _obj_stale(src: str, obj: str) -> bool:

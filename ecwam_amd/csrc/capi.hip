@@ -27,10 +27,9 @@ struct ecwam_hip_ctx {
   int NANG, NFRE, NFRE_RED;
   void* dtab = nullptr;  // DevTab<T> in device memory
   double* norm_scratch = nullptr;   // ecwam_hip_outwnorm: per-context reduction scratch (4 + 4 x 256 doubles)
-  int implsch_variant;  // 2: two-tile fused-sweep kernel (needs the DIA rotation structure), 1: three-tile kernel
   // fourth kernel generation (implsch_v4.h): DIA rotations K1 = K -+ r1, K2 = K +- r2, NSDSNTH = nh; ok = the tables have that structure
   int v4_ok = 0, v4_r1 = 0, v4_r2 = 0, v4_nh = 0, v4_shelter = 0;
-  int implsch_gen = 0;  // 0: the fastest kernel generation that covers the configuration; 1 / 2 / 4: at most that generation (tests)
+  int implsch_gen = 0;  // 0: the fastest kernel generation that covers the configuration; 2 / 4: at most that generation (tests)
   // advection halo exchange (MPEXCHNG): peers, the owned rows each of them needs (concatenated in peer order) and where their rows
   // land; RCCL communicator + a stream of its own so that the exchange runs beside the interior stencil
   int rank = 0, nranks = 1;
@@ -324,17 +323,15 @@ int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int r
   if (real_bytes == 4) {
     std::vector<DevTab<float>> h(1);
     build_tab<float>(p, t, h.data());
-    c->implsch_variant = h[0].DIA_PULL ? 2 : 1;
+    if (!h[0].DIA_PULL) { delete c; return fail("ecwam_hip_create: the interaction tables do not have the rotation structure of INISNONLIN (K1W = K -+ r1, K2W = K +- r2, INLCOEF = MC, MC+2, MC+3, MC-4, MC-3; KFRH = 8, MFRSTLW = -3): not supported"); }
     v4_probe<float>(h[0], c);
-    if ((p->llgcbz0 || p->lciwa1 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou || p->lwnemocouwrs || p->lwnemocoustrn || p->isnonlin || p->iphys == 0 || p->icode != 3 || !p->lwvflx_snl) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
     HIPCHK_CTX(hipMalloc(&c->dtab, sizeof(DevTab<float>)));
     HIPCHK_CTX(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<float>), hipMemcpyHostToDevice));
   } else {
     std::vector<DevTab<double>> h(1);
     build_tab<double>(p, t, h.data());
-    c->implsch_variant = h[0].DIA_PULL ? 2 : 1;
+    if (!h[0].DIA_PULL) { delete c; return fail("ecwam_hip_create: the interaction tables do not have the rotation structure of INISNONLIN (K1W = K -+ r1, K2W = K +- r2, INLCOEF = MC, MC+2, MC+3, MC-4, MC-3; KFRH = 8, MFRSTLW = -3): not supported"); }
     v4_probe<double>(h[0], c);
-    if ((p->llgcbz0 || p->lciwa1 || p->lciwa2 || p->lciwa3 || p->lciscal || p->lwnemocou || p->lwnemocouwrs || p->lwnemocoustrn || p->isnonlin || p->iphys == 0 || p->icode != 3 || !p->lwvflx_snl) && c->implsch_variant != 2) { delete c; return fail("ecwam_hip_create: LLGCBZ0=T / SDICE need the rotation-structured DIA tables (IMPLSCH variant 2)"); }
     HIPCHK_CTX(hipMalloc(&c->dtab, sizeof(DevTab<double>)));
     HIPCHK_CTX(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<double>), hipMemcpyHostToDevice));
   }
@@ -554,8 +551,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   if (kijl > kijs && c->p.lwnemocou && !wam2nemo) return fail("ecwam_hip_implsch: LWNEMOCOU needs the WAVE2OCEAN buffer");
   if (!c->p.lwnemocou) wam2nemo = nullptr;
   hipStream_t s = (hipStream_t)stream;
-  int rc, variant = c->implsch_variant;
-  if (c->implsch_gen == 1) variant = 1;   // tests: the three-tile kernel (its own case: interaction tables without the rotation structure)
+  int rc, variant = 0;
   if (c->p.llnormagam) variant |= 16;
   const bool rare = c->p.lciwa1 || c->p.lciwa2 || c->p.lciwa3 || c->p.lciscal || c->p.lwnemocou || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin ||
                     c->p.iphys == 0 || c->p.icode != 3 || !c->p.lwvflx_snl;
@@ -563,7 +559,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   // fourth kernel generation (implsch_v4.h): flag sets A and B (LLGCBZ0, LLNORMAGAM) without the other optional branches, single and
   // double precision.  The sheltered growth needs TAUWSHELTER /= 0, the normalised one TAUWSHELTER = 0 (setwavphys.F90:150-190).
   const int ext = (c->p.llnormagam || c->p.llgcbz0) ? 1 : 0;
-  if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !rare && (variant & 15) == 2 && !wam2nemo && !dbg &&
+  if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !rare && !wam2nemo && !dbg &&
       (c->p.llnormagam ? c->v4_shelter == 0 : c->v4_shelter != 0)) {
     DISPATCH(rc = launch_implsch4<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s),
              rc = launch_implsch4<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s));
@@ -578,7 +574,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
 
 int ecwam_hip_set_implsch_generation(ecwam_hip_ctx* c, int gen) {
   if (!c) return fail("null context");
-  if (gen != 0 && gen != 1 && gen != 2 && gen != 4) return fail("ecwam_hip_set_implsch_generation: 0 (automatic), 1, 2 or 4");
+  if (gen != 0 && gen != 2 && gen != 4) return fail("ecwam_hip_set_implsch_generation: 0 (automatic), 2 or 4");
   c->implsch_gen = gen;
   return 0;
 }

@@ -1,7 +1,6 @@
-// Launcher of the one-point-per-wavefront IMPLSCH kernels (implsch_v1.h: lane = direction, three tiles -- interaction tables without the
-// rotation structure; implsch_v2.h: two tiles, fused sweep -- every configuration).  The several-points-per-wavefront kernel of flag
-// set A lives in implsch4.hip.
-#include "implsch_v1.h"
+// Launcher of the one-point-per-wavefront IMPLSCH kernel (implsch_v2.h: lane = direction, two LDS tiles, fused sweep -- every
+// configuration).  The several-points-per-wavefront kernel of flag sets A and B lives in implsch4.hip.
+#include "implsch_common.h"
 #include "implsch_v2.h"
 
 template <typename T>
@@ -11,19 +10,13 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
   if (n <= 0) return 0;
   const bool norma = (variant & 16) != 0;  // LLNORMAGAM, packed by capi.hip
   const bool rare = (variant & 32) != 0;   // any of LLGCBZ0 / LCIWA2 / LCIWA3 / LCISCAL / LWNEMOCOU: the build that carries those branches
-  variant &= 15;
-  const bool variant2 = (variant == 2);
-  const int ntile = (variant == 2) ? 2 : 3;
-  const int NAP = variant2 ? NANG : (NANG | 1);
-  const int nscr = variant2 ? 0 : 64;
-  const size_t per_wave = (size_t)(ntile * NFRE * NAP + nscr) * sizeof(T) + (variant == 2 ? NSC * sizeof(T) : 0);
+  const size_t per_wave = (size_t)(2 * NFRE * NANG + NSC) * sizeof(T);
   // waves (= points) per block: the choice that fits the most waves into the 160 KiB of LDS of a CU; ties go to the larger
-  // block, which amortises the lane-per-point scalar stages of variant 2 over more points
-  static const int cands3[] = {4, 2, 1}, cands2[] = {3, 1, 1};
-  const int* cands = (variant == 2) ? cands2 : cands3;
-  const int ncand = 3;
-  // register-limited residency: variant 2 is compiled for 3 (sp) / 2 (dp) waves per SIMD, variant 1 uses 151 / 256 VGPRs
-  const int capw = 4 * ((sizeof(T) == 4) ? (variant == 2 ? 4 : 3) : 2);
+  // block, which amortises the lane-per-point scalar stages over more points
+  static const int cands[] = {3, 1};
+  const int ncand = 2;
+  // register-limited residency: compiled for 3 (sp) / 2 (dp) waves per SIMD
+  const int capw = 4 * ((sizeof(T) == 4) ? 4 : 2);
   int wpb = 1, best = 0;
   for (int i = 0; i < ncand; i++) {
     const int cand = cands[i];
@@ -35,7 +28,7 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
   if (best == 0) return 1;
   size_t shmem = per_wave * wpb;
 #ifdef ECWAM_HIP_DIAGNOSTICS   // timing builds only (tools/build_diag.sh)
-  { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_WPB"); if (e_ && variant == 2) { const int w = atoi(e_); if (w == 3 || w == 1) { wpb = w; shmem = per_wave * wpb; } } }
+  { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_WPB"); if (e_) { const int w = atoi(e_); if (w == 3 || w == 1) { wpb = w; shmem = per_wave * wpb; } } }
   { const char* e_ = getenv("ECWAM_HIP_IMPLSCH_PADLDS"); if (e_) { const int pad = atoi(e_); if (pad > 0 && shmem + (size_t)pad <= 160 * 1024) shmem += (size_t)pad; } }
 #endif
   const int blocks = (n + wpb - 1) / wpb;
@@ -45,8 +38,6 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
     hipLaunchKernelGGL(KFN, dim3(blocks), dim3(64 * wpb), shmem, s, (const DevTab<T>*)tab, kijs, kijl, (T*)fl1,              \
                        (const T*)wvprpt, (T*)ff, (T*)intf, mij, (T*)xllws, w2n, (T*)dbg);                                         \
   } while (0)
-#define LAUNCH(K, W) LAUNCHK((K<T, W>))
-  if (variant2) {
 #define LAUNCH2(W)                                                                                                           \
   do {                                                                                                                       \
     if (norma && rare) LAUNCHK((k_implsch2<T, W, true, true>));                                                              \
@@ -54,15 +45,9 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
     else if (rare) LAUNCHK((k_implsch2<T, W, false, true>));                                                                 \
     else LAUNCHK((k_implsch2<T, W, false, false>));                                                                          \
   } while (0)
-    if (wpb == 3) LAUNCH2(3);
-    else LAUNCH2(1);
+  if (wpb == 3) LAUNCH2(3);
+  else LAUNCH2(1);
 #undef LAUNCH2
-  } else {
-    if (wpb == 4) LAUNCH(k_implsch, 4);
-    else if (wpb == 2) LAUNCH(k_implsch, 2);
-    else LAUNCH(k_implsch, 1);
-  }
-#undef LAUNCH
 #undef LAUNCHK
   return 0;
 }

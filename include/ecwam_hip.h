@@ -255,10 +255,10 @@ int ecwam_hip_propags2_refra(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n
 int ecwam_hip_implsch(ecwam_hip_ctx *ctx, int kijs, int kijl, void *fl1, const void *wvprpt, void *ff, void *intf, int *mij,
                       void *xllws, double *wam2nemo, void *dbg, void *stream);
 /*
- * IMPLSCH exists in several kernel generations with identical results up to rounding (csrc/implsch_v1.h / implsch_v2.h: one point per
- * wavefront, every configuration; implsch_v4.h: several points per wavefront, flag set A).  ecwam_hip_implsch launches the fastest
- * one that covers the context's configuration; gen = 1, 2 or 4 caps the choice at that generation (parity tests that keep the
- * generations checked against each other), gen = 0 restores the automatic choice.
+ * IMPLSCH exists in two kernel generations with identical results up to rounding (csrc/implsch_v2.h: one point per wavefront, every
+ * configuration; implsch_v4.h: several points per wavefront, flag sets A and B).  ecwam_hip_implsch launches the fastest one that
+ * covers the context's configuration; gen = 2 or 4 caps the choice at that generation (parity tests that keep the generations
+ * checked against each other), gen = 0 restores the automatic choice.
  */
 int ecwam_hip_set_implsch_generation(ecwam_hip_ctx *ctx, int gen);
 

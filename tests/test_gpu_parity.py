@@ -803,23 +803,16 @@ def test_long_run_single_precision_tracks_oracle(api):
     m.ctx.close()
 
 
-@pytest.mark.parametrize("prec", ["dp", "sp"])
-def test_implsch_three_tile_fallback_kernel(api, prec):
-    """The three-tile kernel (generation 1) that serves DIA tables without the rotation structure stays correct: selected through
-    ecwam_hip_set_implsch_generation on a configuration that normally takes a later generation."""
-    cfg = Config(nang=24, nfre=36, nfre_red=29)
-    n = 515
-    case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=41)
-    ref = H.oracle_implsch(case, _oracle(cfg, prec))
-    ctx = api.HipContext(case["tables"])
-    ctx.set_implsch_generation(1)
-    got = H.gpu_implsch(case, ctx)
-    st = H.compare_implsch(ref, got, case["tables"])
-    ctx.close()
-    if prec == "dp":
-        assert st["mij_flips"] == 0 and st["fl1_max_rel_peak_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
-    else:
-        assert st["mij_flips"] <= 3 and st["fl1_max_rel_peak_clean"] < 3e-5 and st["swh_max_rel"] < 2e-6, st
+def test_tables_without_the_rotation_structure_are_refused(api):
+    """The kernels rely on the structure INISNONLIN gives the interaction tables (K1W = K -+ r1 ..., INLCOEF by formula): a context
+    whose tables break it must fail at creation, loudly, not compute something else."""
+    import copy
+    t = Tables(Config(nang=24, nfre=36, nfre_red=29), np.float32)
+    t2 = copy.copy(t)
+    t2.K1W = np.array(t.K1W, copy=True)
+    t2.K1W[3, 0] = t2.K1W[3, 0] % 24 + 1          # another (valid, 1-based) direction
+    with pytest.raises(api.EcwamHipError, match="rotation structure"):
+        api.HipContext(t2)
 
 
 @pytest.mark.parametrize("prec", ["dp", "sp"])
@@ -840,20 +833,20 @@ def test_implsch_parity_48_directions(api, prec):
 
 
 def test_implsch_kernel_generations_agree(api):
-    """k_implsch4 (the default on flag set A) against k_implsch2 and k_implsch on the same inputs, with a point count that leaves a
-    short last wavefront in either layout: MIJ and XLLWS identical, spectra within 2e-5 of the point's spectral peak (observed
-    8e-6), forcing outputs within 5e-5 of their scale (all three sum in wavefront order, in different groupings)."""
+    """k_implsch4 (the default on flag set A) against k_implsch2 on the same inputs, with a point count that leaves a short last
+    wavefront in either layout: MIJ and XLLWS identical, spectra within 2e-5 of the point's spectral peak (observed 8e-6), forcing
+    outputs within 5e-5 of their scale (both sum in wavefront order, in different groupings)."""
     cfg = Config(nang=36, nfre=36, nfre_red=36)
     n = 4 * 1024 + 1
     case = H.make_point_case(n, cfg, "sp", spectra="mixed", seed=2024)
     out = {}
     ctx = api.HipContext(case["tables"])
-    for gen in (1, 2, 4):
+    for gen in (2, 4):
         ctx.set_implsch_generation(gen)
         out[gen] = H.gpu_implsch(case, ctx)
     ctx.close()
     b = out[4]
-    for gen in (1, 2):
+    for gen in (2,):
         a = out[gen]
         assert np.array_equal(a["MIJ"], b["MIJ"]) and np.array_equal(a["XLLWS"], b["XLLWS"]), gen
         peak = np.abs(a["FL1"]).max(axis=(1, 2), keepdims=True).astype(float)

@@ -82,15 +82,22 @@ def cpu_baseline(nang: int, nfre: int, prec: str, target_s: float = 15.0) -> dic
     cg_ext[:n] = pr["CGROUP"]
     cg_ext[n] = syn.depth_props(np.array([998.999]), t, dt)["CGROUP"][0]
     w = o.ctu_weights(g, cg_ext, float(cfg.idelpro))
-    steps, el = o.timed_steps(g, fl, w, pr, env, ff, intf, max_steps=200, target_s=target_s)   # C calls only, arrays prepared once
+    # IMPLSCH through the NPROMA-blocked variant (SINPUT_ARD / SDISSIP_ARD / SNONLIN with the point index innermost, vector libm,
+    # flush-to-zero: what the reference's loop order and production flags give a compiler), then a short run of the point-by-point
+    # restatement for comparison; C calls only, arrays prepared once
+    steps, el = o.timed_steps(g, fl.copy(), w, pr, env, ff.copy(), intf.copy(), max_steps=200, target_s=0.75 * target_s)
+    kind, t_impl, t_prop = o.implsch_kind, o.t_implsch, o.t_propags2
+    s2, _ = o.timed_steps(g, fl, w, pr, env, ff, intf, max_steps=200, target_s=0.25 * target_s, blocked=False)
     return {"value": n * steps / el, "unit": "grid-point spectral steps/s", "cores": cores, "kind": "port",
-            "implsch_only": n * steps / o.t_implsch, "propags2_only": n * steps / o.t_propags2,
-            "note": "the C restatement integrates one sea point at a time (scalar inner loops over K and M; the reference blocks NPROMA "
-                    "points innermost and vectorises over them, implsch.F90:152-170), unpinned against the reference (DESIGN.md section 4): "
-                    "a lower bound of what the reference's OpenMP path does on these cores, not a measurement of it",
+            "implsch_only": n * steps / t_impl, "propags2_only": n * steps / t_prop, "implsch_variant": kind,
+            "implsch_only_point_by_point": n * s2 / o.t_implsch,
+            "note": "IMPLSCH runs the NPROMA-blocked C restatement (oracle/ora_implsch_blk.inc: SINPUT_ARD, SDISSIP_ARD and SNONLIN with "
+                    "the sea-point index innermost as in implsch.F90:152-170, omp simd + libmvec, flush-to-zero; the scalar chains TAUT_Z0 / "
+                    "STRESSO / FKMEAN point by point), checked against the point-by-point oracle; unpinned against the reference "
+                    "(DESIGN.md section 4): an estimate of what the reference's OpenMP path does on these cores, not a measurement of it",
             "sample": f"O48 all-ocean grid ({n} sea points), {nang}x{nfre} spectrum, {prec}, {steps} full steps "
-                      f"(PROPAGS2 + IMPLSCH), oracle/ C restatement (speed build: gcc -O3 -march=x86-64-v3) with OpenMP over points, {cores} threads "
-                      f"(host reports {os.cpu_count()} logical CPUs)"}
+                      f"(PROPAGS2 + IMPLSCH), oracle/ C restatement (speed build: gcc -O3 -march=x86-64-v3) with OpenMP over blocks of 32 points, "
+                      f"{cores} threads (host reports {os.cpu_count()} logical CPUs)"}
 
 
 def main() -> None:

@@ -1437,44 +1437,19 @@ static real cimsstrn(const real *FL1, const real *WAVNUM, real DEPTH, real CITHI
   return STRN;
 }
 
-static int implsch_point(real *FL1, real *XLLWS, point_t *p, real *dbg) {
+/* implsch.F90:288-462: everything after SNONLIN (SSOURCE of the flux diagnostics, SDIWBK, sea-ice attenuation, SBOTTOM, the limited
+ * update, WNFLUXES, the second FKMEAN / FEMEANWS, IMPHFTAIL, SETICE, STOKESDRIFT).  Shared by the point-by-point path and the
+ * NPROMA-blocked timing variant (ora_implsch_blk.inc). */
+static void implsch_tail(real *FL1, const real *XLLWS, point_t *p, real *FLD, real *SL, real *SSOURCE, real *SLICE, const real *FLM,
+                         const real *COSWDIF, const real *RHOWGDFTH, real EMEAN, real FMEAN, real F1MEAN, real FMEANWS_IN, real PHIWA) {
   const int NANG = S.NANG, NFRE = S.NFRE;
-  static __thread real FLD[NA * NF], SL[NA * NF], SPOS[NA * NF], SSOURCE[NA * NF], SLICE[NA * NF];
-  real DELT, DELTM, DELT5, GTEMP1, GTEMP2, FLHAB, RAORW, EMEAN, FMEAN, HALP = 0, EMEANWS, FMEANWS, USFM;
-  real F1MEAN, AKMEAN, XKMEAN, PHIWA;
-  real FLM[NA], COSWDIF[NA], SINWDIF2[NA], TEMP[NF], RHOWGDFTH[NF], DELFL[NF];
+  real DELT, DELTM, DELT5, GTEMP1, GTEMP2, FLHAB, EMEANWS, FMEANWS = FMEANWS_IN, USFM, AKMEAN, XKMEAN;
+  real TEMP[NF], DELFL[NF];
   int LCFLX;
-  if (S.c.isnonlin < 0 || S.c.isnonlin > 2) return 2;
-  if (S.c.lciwa1 && S.NICT == 0) return 2; /* SDICE1 needs ora_set_cideac */
-
   DELT = (real)S.c.idelt;
   DELTM = C_(1.0) / DELT;
   DELT5 = (real)S.c.ximp * DELT;
   LCFLX = S.c.lwflux || S.c.lwfluxout || S.c.lwnemocou;
-  RAORW = RMAX(p->AIRD, C_(1.0)) * S.ROWATERM1;
-  for (int K = 0; K < NANG; K++) {
-    COSWDIF[K] = COS(S.TH[K] - p->WDWAVE);
-    real s = SIN(S.TH[K] - p->WDWAVE);
-    SINWDIF2[K] = s * s;
-  }
-  if (S.c.lwnemocouwrs) /* implsch.F90:205-213 (the SDICEn overwrite it when active) */
-    for (int i = 0; i < NANG * NFRE; i++) SLICE[i] = C_(0.0);
-  if (S.c.lbiwbk) sdepthlim(p->EMAXDPT, FL1);
-  fkmean(FL1, p->WAVNUM, &EMEAN, &FMEAN, &F1MEAN, &AKMEAN, &XKMEAN);
-  for (int K = 0; K < NANG; K++) {
-    real c = RMAX(C_(0.0), COSWDIF[K]);
-    FLM[K] = (C_(1.) - C_(0.9) * RMIN(p->CICOVER, C_(0.99))) * S.FLMIN * (c * c);
-  }
-  for (int ICALL = 1; ICALL <= 2; ICALL++) {
-    if (sinflx(ICALL, 2, 1, FL1, p, RAORW, COSWDIF, SINWDIF2, FMEAN, &HALP, &FMEANWS, FLM, &PHIWA, FLD, SL, SPOS, RHOWGDFTH,
-               XLLWS)) return 1;
-  }
-  if (dbg) { dbg[0] = EMEAN; dbg[1] = FMEAN; dbg[2] = F1MEAN; dbg[3] = AKMEAN; dbg[4] = XKMEAN; dbg[5] = FMEANWS; dbg[6] = PHIWA; }
-  if (S.c.iphys == 0) sdissip_jan(FL1, FLD, SL, p->WAVNUM, EMEAN, F1MEAN, XKMEAN); /* sdissip.F90:76-83 */
-  else sdissip_ard(FL1, FLD, SL, p->WAVNUM, p->XK2CG, p->UFRIC, COSWDIF, RAORW);
-  if (LCFLX && !S.c.lwvflx_snl)
-    for (int i = 0; i < NANG * NFRE; i++) SSOURCE[i] = SL[i];
-  snonlin(FL1, FLD, SL, p->DEPTH, AKMEAN, p->WAVNUM);
   if (LCFLX && S.c.lwvflx_snl)
     for (int i = 0; i < NANG * NFRE; i++) {
       GTEMP1 = RMAX((C_(1.0) - DELT5 * FLD[i]), C_(1.0));
@@ -1528,6 +1503,47 @@ static int implsch_point(real *FL1, real *XLLWS, point_t *p, real *dbg) {
     else { p->NEMOUSTOKES = 0.0; p->NEMOVSTOKES = 0.0; }
     if (S.c.lwnemocoustrn) p->NEMOSTRN = p->STRNMS;
   }
+}
+
+static int implsch_point(real *FL1, real *XLLWS, point_t *p, real *dbg) {
+  const int NANG = S.NANG, NFRE = S.NFRE;
+  static __thread real FLD[NA * NF], SL[NA * NF], SPOS[NA * NF], SSOURCE[NA * NF], SLICE[NA * NF];
+  real DELT, DELTM, DELT5, GTEMP1, GTEMP2, FLHAB, RAORW, EMEAN, FMEAN, HALP = 0, EMEANWS, FMEANWS, USFM;
+  real F1MEAN, AKMEAN, XKMEAN, PHIWA;
+  real FLM[NA], COSWDIF[NA], SINWDIF2[NA], TEMP[NF], RHOWGDFTH[NF], DELFL[NF];
+  int LCFLX;
+  if (S.c.isnonlin < 0 || S.c.isnonlin > 2) return 2;
+  if (S.c.lciwa1 && S.NICT == 0) return 2; /* SDICE1 needs ora_set_cideac */
+
+  DELT = (real)S.c.idelt;
+  DELTM = C_(1.0) / DELT;
+  DELT5 = (real)S.c.ximp * DELT;
+  LCFLX = S.c.lwflux || S.c.lwfluxout || S.c.lwnemocou;
+  RAORW = RMAX(p->AIRD, C_(1.0)) * S.ROWATERM1;
+  for (int K = 0; K < NANG; K++) {
+    COSWDIF[K] = COS(S.TH[K] - p->WDWAVE);
+    real s = SIN(S.TH[K] - p->WDWAVE);
+    SINWDIF2[K] = s * s;
+  }
+  if (S.c.lwnemocouwrs) /* implsch.F90:205-213 (the SDICEn overwrite it when active) */
+    for (int i = 0; i < NANG * NFRE; i++) SLICE[i] = C_(0.0);
+  if (S.c.lbiwbk) sdepthlim(p->EMAXDPT, FL1);
+  fkmean(FL1, p->WAVNUM, &EMEAN, &FMEAN, &F1MEAN, &AKMEAN, &XKMEAN);
+  for (int K = 0; K < NANG; K++) {
+    real c = RMAX(C_(0.0), COSWDIF[K]);
+    FLM[K] = (C_(1.) - C_(0.9) * RMIN(p->CICOVER, C_(0.99))) * S.FLMIN * (c * c);
+  }
+  for (int ICALL = 1; ICALL <= 2; ICALL++) {
+    if (sinflx(ICALL, 2, 1, FL1, p, RAORW, COSWDIF, SINWDIF2, FMEAN, &HALP, &FMEANWS, FLM, &PHIWA, FLD, SL, SPOS, RHOWGDFTH,
+               XLLWS)) return 1;
+  }
+  if (dbg) { dbg[0] = EMEAN; dbg[1] = FMEAN; dbg[2] = F1MEAN; dbg[3] = AKMEAN; dbg[4] = XKMEAN; dbg[5] = FMEANWS; dbg[6] = PHIWA; }
+  if (S.c.iphys == 0) sdissip_jan(FL1, FLD, SL, p->WAVNUM, EMEAN, F1MEAN, XKMEAN); /* sdissip.F90:76-83 */
+  else sdissip_ard(FL1, FLD, SL, p->WAVNUM, p->XK2CG, p->UFRIC, COSWDIF, RAORW);
+  if (LCFLX && !S.c.lwvflx_snl)
+    for (int i = 0; i < NANG * NFRE; i++) SSOURCE[i] = SL[i];
+  snonlin(FL1, FLD, SL, p->DEPTH, AKMEAN, p->WAVNUM);
+  implsch_tail(FL1, XLLWS, p, FLD, SL, SSOURCE, SLICE, FLM, COSWDIF, RHOWGDFTH, EMEAN, FMEAN, F1MEAN, FMEANWS, PHIWA);
   return 0;
 }
 
@@ -1747,3 +1763,5 @@ void ora_taut_z0(real U10, real UDIR, real TAUW, real TAUWDIR, real HALP, real R
   taut_z0(0, HALP, U10, UDIR, TAUW, TAUWDIR, RNFAC, &US, &Z0, &Z0B, &CH);
   out[0] = US; out[1] = Z0; out[2] = Z0B; out[3] = CH;
 }
+
+#include "ora_implsch_blk.inc"

@@ -132,6 +132,26 @@ class Oracle:
             out["DBG"] = dbg
         return out
 
+    def implsch_blocked(self, fl1, wavnum, cgroup, cinv, xk2cg, stokfac, env, ff, intf):
+        """The NPROMA-blocked variant (ora_implsch_blk.inc: SINPUT_ARD / SDISSIP_ARD / SNONLIN with the point index innermost and
+        vector libm): the CPU timing baseline.  Same arguments and result as implsch(); None when the configuration is outside
+        what the blocked routines restate."""
+        n = fl1.shape[0]
+        T = self.dtype
+        fl1 = np.array(fl1, dtype=T, order="C")
+        ff = np.array(ff, dtype=T, order="C")
+        intf = np.array(intf, dtype=T, order="C")
+        xllws = np.zeros_like(fl1)
+        mij = np.zeros(n, dtype=np.int32)
+        a = [np.ascontiguousarray(x, dtype=T) for x in (wavnum, cgroup, cinv, xk2cg, stokfac, env)]
+        rc = self.lib.ora_implsch_blk(C.c_int(n), self._p(fl1), *(self._p(x) for x in a[:5]), self._p(a[5]), self._p(ff), self._p(intf),
+                                      self._p(mij), self._p(xllws))
+        if rc == -1:
+            return None
+        if rc:
+            raise RuntimeError(f"ora_implsch_blk abort branch rc={rc}")
+        return dict(FL1=fl1, XLLWS=xllws, MIJ=mij, FF=ff, INTF=intf)
+
     def outbs(self, fl1, zmiss=-999.0):
         """OUTBLOCK parameters 1-3 and 6: returns [n][5] = SWH, MWD [deg], MWP (or zmiss), EM, PP1D (or zmiss)."""
         fl1 = np.ascontiguousarray(fl1, dtype=self.dtype)
@@ -271,9 +291,10 @@ class Oracle:
                                   self._p(w["WMPMN"]), C.c_int(nd3s), C.c_int(nd3e))
         return f3
 
-    def timed_steps(self, grid, fl, w, props, env, ff, intf, max_steps=50, target_s=15.0):
+    def timed_steps(self, grid, fl, w, props, env, ff, intf, max_steps=50, target_s=15.0, blocked=True):
         """bench.py's cpu_baseline leg: full steps (PROPAGS2 + IMPLSCH) in place on prepared arrays; returns (steps, seconds)
-        of the C calls alone (no Python-side copies inside the timed region)."""
+        of the C calls alone (no Python-side copies inside the timed region).  blocked: IMPLSCH through the NPROMA-blocked
+        variant (ora_implsch_blk) where it covers the configuration (self.implsch_kind says which ran)."""
         import time
 
         T = self.dtype
@@ -296,8 +317,14 @@ class Oracle:
                                   self._p(g["kcor"]), self._p(w["SUMWN"]), self._p(w["WLONN"]), self._p(w["WLATN"]), self._p(w["WCORN"]),
                                   self._p(w["WKPMN"]), C.c_int(1), C.c_int(self.NFRE_RED))
             tb = time.perf_counter()
-            rc = self.lib.ora_implsch_w2n(C.c_int(n), self._p(f3), *(self._p(x) for x in a), self._p(env), self._p(ff), self._p(intf),
-                                          self._p(mij), self._p(xllws), None, None)
+            rc = -1
+            if blocked:
+                rc = self.lib.ora_implsch_blk(C.c_int(n), self._p(f3), *(self._p(x) for x in a), self._p(env), self._p(ff), self._p(intf),
+                                              self._p(mij), self._p(xllws))
+            self.implsch_kind = "nproma-blocked" if rc != -1 else "point by point"
+            if rc == -1:
+                rc = self.lib.ora_implsch_w2n(C.c_int(n), self._p(f3), *(self._p(x) for x in a), self._p(env), self._p(ff), self._p(intf),
+                                              self._p(mij), self._p(xllws), None, None)
             tc = time.perf_counter()
             self.t_propags2 += tb - ta
             self.t_implsch += tc - tb

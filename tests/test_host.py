@@ -391,3 +391,28 @@ def test_oracle_regression_vectors():
             assert np.array_equal(a, b), k
         else:
             assert np.max(np.abs(a - b)) <= 1e-9 * max(np.max(np.abs(a)), 1e-300), k
+
+
+@pytest.mark.parametrize("prec", ["sp", "dp"])
+@pytest.mark.parametrize("flags", [{}, dict(llgcbz0=True, llnormagam=True)], ids=["set_a", "set_b"])
+def test_nproma_blocked_cpu_variant_agrees_with_the_oracle(prec, flags):
+    """bench.py times IMPLSCH on the CPU through the NPROMA-blocked variant (oracle/ora_implsch_blk.inc: the three hot routines with the
+    point index innermost, vector libm, flush-to-zero in the speed build).  It is a timing baseline, not the parity oracle -- but it must
+    compute the same thing: MIJ and XLLWS identical, spectra / forcing / fluxes within vector-libm rounding of the point-by-point oracle,
+    in the exact and in the speed build, with a ragged last block; configurations it does not restate are declined."""
+    from oracle.oracle import Oracle
+    cfg = Config(nang=24, nfre=36, nfre_red=29, **flags)
+    n = 3 * 32 + 7
+    case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=17)
+    pr = case["props"]
+    args = (case["FL1"], pr["WAVNUM"], pr["CGROUP"], pr["CINV"], pr["XK2CG"], pr["STOKFAC"], case["ENV"], case["FF"], case["INTF"])
+    for fast in (False, True):
+        o = Oracle(cfg, prec, fast=fast)
+        ref, blk = o.implsch(*args), o.implsch_blocked(*args)
+        assert blk is not None
+        st = H.compare_implsch(ref, blk, case["tables"])
+        assert st["mij_flips"] == 0 and st["xllws_bins_diff"] == 0, st
+        tol = (2e-5, 1e-4) if prec == "sp" else (1e-12, 1e-10)
+        assert st["fl1_max_rel_peak_all"] < tol[0] and st["ff_max_rel_all"] < tol[0] and st["intf_max_rel_all"] < tol[1], st
+    o = Oracle(Config(nang=24, nfre=36, nfre_red=29, iphys=0), prec)
+    assert o.implsch_blocked(*args) is None

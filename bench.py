@@ -93,7 +93,8 @@ def cpu_baseline(nang: int, nfre: int, prec: str, target_s: float = 15.0) -> dic
             "implsch_only_point_by_point": n * s2 / o.t_implsch,
             "note": "IMPLSCH runs the NPROMA-blocked C restatement (oracle/ora_implsch_blk.inc: SINPUT_ARD, SDISSIP_ARD and SNONLIN with "
                     "the sea-point index innermost as in implsch.F90:152-170, omp simd + libmvec, flush-to-zero; the scalar chains TAUT_Z0 / "
-                    "STRESSO / FKMEAN point by point), checked against the point-by-point oracle; unpinned against the reference "
+                    "STRESSO / FKMEAN point by point), PROPAGS2 its eight weights packed as contiguous streams (ora_propags2_w8, bit-identical); "
+                    "both checked against the point-by-point oracle; unpinned against the reference "
                     "(DESIGN.md section 4): an estimate of what the reference's OpenMP path does on these cores, not a measurement of it",
             "sample": f"O48 all-ocean grid ({n} sea points), {nang}x{nfre} spectrum, {prec}, {steps} full steps "
                       f"(PROPAGS2 + IMPLSCH), oracle/ C restatement (speed build: gcc -O3 -march=x86-64-v3) with OpenMP over blocks of 32 points, "

@@ -193,6 +193,52 @@ void ora_propags2(int KIJS, int KIJL, const real *F1, real *F3, const int *KLON,
 #undef FF1
 }
 
+/* Timing variant of PROPAGS2 for bench.py's cpu_baseline: the reference keeps its weight arrays with IJ fastest, so the eight
+ * weights the stencil reads are eight contiguous streams for its compiler; the [ij][k][m][..] layout of this restatement makes them
+ * strided and drags the ten unused weights per element through the caches.  ora_pack_w8 packs the eight once as W8[ij][8][K][M]
+ * (order: 1-SUMWN, WLONN(JXO), WLATN(JYO,1:2), WCORN(KCR,1:2), WKPMN(-1), WKPMN(+1)); ora_propags2_w8 is the same sum, same order of
+ * the terms, with unit-stride vectorisable loops over M.  Same results as ora_propags2 bit for bit (tests/test_host.py). */
+void ora_pack_w8(int n, const real *SUMWN, const real *WLONN, const real *WLATN, const real *WCORN, const real *WKPMN, real *W8) {
+  const int NANG = S.NANG, NR = S.NFRE_RED;
+#pragma omp parallel for schedule(static)
+  for (int IJ = 0; IJ < n; IJ++)
+    for (int K = 0; K < NANG; K++) {
+      const int jx = S.JXO[K][0] - 1, jy = S.JYO[K][0] - 1, kc = S.KCR[K][0] - 1;
+      for (int M = 0; M < NR; M++) {
+        const size_t b = ((size_t)IJ * NANG + K) * NR + M;
+        real *w = W8 + (((size_t)IJ * 8) * NANG + K) * NR + M;
+        const size_t pl = (size_t)NANG * NR;
+        w[0] = C_(1.0) - SUMWN[b];
+        w[pl] = WLONN[b * 2 + jx];
+        w[2 * pl] = WLATN[(b * 2 + jy) * 2 + 0]; w[3 * pl] = WLATN[(b * 2 + jy) * 2 + 1];
+        w[4 * pl] = WCORN[(b * 4 + 0) * 2 + 0]; w[5 * pl] = WCORN[(b * 4 + 0) * 2 + 1];   /* WCORN(..,1,1:2): the corner KCR(K,1) */
+        w[6 * pl] = WKPMN[b * 3 + 0]; w[7 * pl] = WKPMN[b * 3 + 2];
+      }
+    }
+}
+void ora_propags2_w8(int KIJS, int KIJL, const real *F1, real *F3, const int *KLON, const int *KLAT, const int *KCOR, const real *W8,
+                     int ND3S, int ND3E) {
+  const int NANG = S.NANG, NFRE = S.NFRE, NR = S.NFRE_RED;
+  const size_t pl = (size_t)NANG * NR;
+#pragma omp parallel for schedule(static)
+  for (int IJ = KIJS; IJ < KIJL; IJ++) {
+    for (int K = 0; K < NANG; K++) {
+      const int jx = S.JXO[K][0] - 1, jy = S.JYO[K][0] - 1, kc = S.KCR[K][0] - 1;
+      const int km = S.KPM[K][0] - 1, kp = S.KPM[K][2] - 1;
+      const real *fo = F1 + ((size_t)IJ * NANG + K) * NFRE, *flon = F1 + ((size_t)KLON[IJ * 2 + jx] * NANG + K) * NFRE;
+      const real *fl1 = F1 + ((size_t)KLAT[(IJ * 2 + jy) * 2 + 0] * NANG + K) * NFRE, *fl2 = F1 + ((size_t)KLAT[(IJ * 2 + jy) * 2 + 1] * NANG + K) * NFRE;
+      const real *fc1 = F1 + ((size_t)KCOR[(IJ * 4 + kc) * 2 + 0] * NANG + K) * NFRE, *fc2 = F1 + ((size_t)KCOR[(IJ * 4 + kc) * 2 + 1] * NANG + K) * NFRE;
+      const real *fkm = F1 + ((size_t)IJ * NANG + km) * NFRE, *fkp = F1 + ((size_t)IJ * NANG + kp) * NFRE;
+      const real *w = W8 + (((size_t)IJ * 8) * NANG + K) * NR;
+      real *o = F3 + ((size_t)IJ * NANG + K) * NFRE;
+#pragma omp simd
+      for (int M = ND3S - 1; M < ND3E; M++)
+        o[M] = w[M] * fo[M] + w[pl + M] * flon[M] + w[2 * pl + M] * fl1[M] + w[3 * pl + M] * fl2[M] + w[4 * pl + M] * fc1[M] +
+               w[5 * pl + M] * fc2[M] + w[6 * pl + M] * fkm[M] + w[7 * pl + M] * fkp[M];
+    }
+  }
+}
+
 /* ======================================================================================================================
  * IREFRA = 1 (depth refraction), 2 (current refraction), 3 (depth + current refraction)
  * ====================================================================================================================== */

@@ -291,6 +291,23 @@ class Oracle:
                                   self._p(w["WMPMN"]), C.c_int(nd3s), C.c_int(nd3e))
         return f3
 
+    def pack_w8(self, n, w):
+        """W8[ij][8][NANG][NFRE_RED]: the eight weights PROPAGS2 reads (ora_pack_w8), for ora_propags2_w8."""
+        w8 = np.zeros((n, 8, self.NANG, self.NFRE_RED), self.dtype)
+        self.lib.ora_pack_w8(C.c_int(n), self._p(w["SUMWN"]), self._p(w["WLONN"]), self._p(w["WLATN"]), self._p(w["WCORN"]),
+                             self._p(w["WKPMN"]), self._p(w8))
+        return w8
+
+    def propags2_w8(self, grid, f1, w8, nd3s=1, nd3e=None):
+        """PROPAGS2 through the packed weights: same result as propags2()."""
+        g = self._grid_arrays(grid)
+        n = grid.nsea
+        f1 = np.ascontiguousarray(f1, dtype=self.dtype)
+        f3 = np.zeros_like(f1)
+        self.lib.ora_propags2_w8(C.c_int(0), C.c_int(n), self._p(f1), self._p(f3), self._p(g["klon"]), self._p(g["klat"]), self._p(g["kcor"]),
+                                 self._p(w8), C.c_int(nd3s), C.c_int(self.NFRE_RED if nd3e is None else nd3e))
+        return f3
+
     def timed_steps(self, grid, fl, w, props, env, ff, intf, max_steps=50, target_s=15.0, blocked=True):
         """bench.py's cpu_baseline leg: full steps (PROPAGS2 + IMPLSCH) in place on prepared arrays; returns (steps, seconds)
         of the C calls alone (no Python-side copies inside the timed region).  blocked: IMPLSCH through the NPROMA-blocked
@@ -309,13 +326,20 @@ class Oracle:
         xllws = np.zeros((n, self.NANG, self.NFRE), T)
         mij = np.zeros(n, np.int32)
         self.lib.ora_set_ibrmem(None)
+        w8 = None
+        if blocked:        # the eight weights the stencil reads as contiguous streams (the reference's arrays have IJ fastest); set-up, untimed
+            w8 = self.pack_w8(n, w)
         steps, t0 = 0, time.perf_counter()
         self.t_propags2 = self.t_implsch = 0.0      # seconds inside each of the two C calls (separate rates)
         while True:
             ta = time.perf_counter()
-            self.lib.ora_propags2(C.c_int(0), C.c_int(n), self._p(f1), self._p(f3), self._p(g["klon"]), self._p(g["klat"]),
-                                  self._p(g["kcor"]), self._p(w["SUMWN"]), self._p(w["WLONN"]), self._p(w["WLATN"]), self._p(w["WCORN"]),
-                                  self._p(w["WKPMN"]), C.c_int(1), C.c_int(self.NFRE_RED))
+            if w8 is not None:
+                self.lib.ora_propags2_w8(C.c_int(0), C.c_int(n), self._p(f1), self._p(f3), self._p(g["klon"]), self._p(g["klat"]),
+                                         self._p(g["kcor"]), self._p(w8), C.c_int(1), C.c_int(self.NFRE_RED))
+            else:
+                self.lib.ora_propags2(C.c_int(0), C.c_int(n), self._p(f1), self._p(f3), self._p(g["klon"]), self._p(g["klat"]),
+                                      self._p(g["kcor"]), self._p(w["SUMWN"]), self._p(w["WLONN"]), self._p(w["WLATN"]), self._p(w["WCORN"]),
+                                      self._p(w["WKPMN"]), C.c_int(1), C.c_int(self.NFRE_RED))
             tb = time.perf_counter()
             rc = -1
             if blocked:

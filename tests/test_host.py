@@ -416,3 +416,29 @@ def test_nproma_blocked_cpu_variant_agrees_with_the_oracle(prec, flags):
         assert st["fl1_max_rel_peak_all"] < tol[0] and st["ff_max_rel_all"] < tol[0] and st["intf_max_rel_all"] < tol[1], st
     o = Oracle(Config(nang=24, nfre=36, nfre_red=29, iphys=0), prec)
     assert o.implsch_blocked(*args) is None
+
+
+def test_packed_weight_cpu_advection_is_bit_identical():
+    """ora_propags2_w8 (bench.py's CPU timing variant of PROPAGS2: the eight weights packed as contiguous streams, unit-stride loops
+    over M) returns the bits of ora_propags2, in the exact and in the speed build of the oracle (continents mask: land neighbours)."""
+    from ecwam_amd import synthetic as syn
+    from oracle.oracle import Oracle
+    cfg = Config(nang=12, nfre=36, nfre_red=30, idelt=900, idelpro=900)
+    g = G.build_grid(16, mask="continents")
+    t = Tables(cfg, np.float64)
+    rng = np.random.default_rng(8)
+    for prec, fast in (("dp", False), ("sp", False), ("sp", True)):
+        o = Oracle(cfg, prec, fast=fast)
+        dt = H.np_dtype(prec)
+        n = g.nsea
+        depth = rng.uniform(20.0, 3000.0, n)
+        pr = syn.depth_props(depth, Tables(cfg, dt), dt)
+        cg = np.zeros((n + 1, 36), dt)
+        cg[:n] = pr["CGROUP"]
+        cg[n] = syn.depth_props(np.array([998.999]), Tables(cfg, dt), dt)["CGROUP"][0]
+        w = o.ctu_weights(g, cg, 900.0)
+        f1 = np.zeros((n + 1, 12, 36), dt)
+        f1[:n] = rng.uniform(0.0, 1.0, (n, 12, 36))
+        ref = o.propags2(g, f1, w)
+        got = o.propags2_w8(g, f1, o.pack_w8(n, w))
+        assert np.array_equal(ref, got), (prec, fast)

@@ -842,5 +842,28 @@ int ecwam_hip_sync(ecwam_hip_ctx* c, void* stream) {
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }
+int ecwam_hip_queue_create(ecwam_hip_ctx* c, void** queue) {
+  if (!c || !queue) return fail("ecwam_hip_queue_create: null argument");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s;
+  HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *queue = (void*)s;
+  return 0;
+}
+int ecwam_hip_queue_destroy(ecwam_hip_ctx* c, void* queue) {
+  if (!c) return fail("null context");
+  if (queue) HIPCHK(hipStreamDestroy((hipStream_t)queue));
+  return 0;
+}
+int ecwam_hip_queue_wait_for(ecwam_hip_ctx* c, void* waiter, void* waited) {
+  if (!c) return fail("null context");
+  if (waiter == waited) return 0;
+  hipEvent_t e;
+  HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(e, (hipStream_t)waited));
+  HIPCHK(hipStreamWaitEvent((hipStream_t)waiter, e, 0));
+  HIPCHK(hipEventDestroy(e));   // released once the recorded work has completed
+  return 0;
+}
 
 }  // extern "C"

@@ -332,6 +332,13 @@ int ecwam_hip_memcpy_h2d(ecwam_hip_ctx *ctx, void *dst_dev, const void *src_host
 int ecwam_hip_memcpy_d2h(ecwam_hip_ctx *ctx, void *dst_host, const void *src_dev, unsigned long long bytes, void *stream);
 int ecwam_hip_memset(ecwam_hip_ctx *ctx, void *dst_dev, int value, unsigned long long bytes, void *stream);
 int ecwam_hip_sync(ecwam_hip_ctx *ctx, void *stream);
+/* Asynchronous queues (FIELD_API's QUEUE= of SYNC_HOST_* / SYNC_DEVICE_*, WAIT_FOR_ASYNC_QUEUE: field_async_module; the OpenACC
+ * build's async(1..6), wamintgr_loki_gpu.F90:100-200): a queue is a non-blocking HIP stream, usable as the `stream` of every entry
+ * point.  ecwam_hip_queue_wait_for makes work enqueued on `waiter` from now on start after everything enqueued on `waited` so far
+ * (either may be NULL = the default stream); ecwam_hip_sync(ctx, queue) is WAIT_FOR_ASYNC_QUEUE. */
+int ecwam_hip_queue_create(ecwam_hip_ctx *ctx, void **queue);
+int ecwam_hip_queue_destroy(ecwam_hip_ctx *ctx, void *queue);
+int ecwam_hip_queue_wait_for(ecwam_hip_ctx *ctx, void *waiter, void *waited);
 /* Page-lock host arrays the host keeps copying to / from (the reference pins its fields when WAM_HAVE_CUDA, wvalloc.F90:49-52) */
 int ecwam_hip_host_register(ecwam_hip_ctx *ctx, void *host, unsigned long long bytes);
 int ecwam_hip_host_unregister(ecwam_hip_ctx *ctx, void *host);

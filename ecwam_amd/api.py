@@ -252,11 +252,12 @@ class HipContext:
             self._chk(self.lib.ecwam_hip_newwind_icode(*a, int(icode_wnd), _stream_ptr()))
 
     def nosource(self, kijs, kijl, fl1, mij, xllws):
-        """LLSOURCE = F (wamintgr.F90:152-160): FL1 = MAX(FL1, EPSMIN), MIJ = NFRE, XLLWS = 0 on rows [kijs, kijl)."""
-        nrow = fl1.shape[0]
+        """LLSOURCE = F (wamintgr.F90:152-160): FL1 = MAX(FL1, EPSMIN), MIJ = NFRE, XLLWS = 0 on rows [kijs, kijl).
+        fl1 = None: a call before the next source-term date (wamintgr.F90:178-186): MIJ and XLLWS only."""
+        nrow = xllws.shape[0] if fl1 is None else fl1.shape[0]
         if not (0 <= kijs <= kijl <= min(nrow, mij.shape[0], xllws.shape[0])):
             raise ValueError("NOSOURCE: KIJS/KIJL outside the operands")
-        self._chk(self.lib.ecwam_hip_nosource(self._h, kijs, kijl, self._real(fl1, (nrow, self.NANG, self.NFRE), "FL1"),
+        self._chk(self.lib.ecwam_hip_nosource(self._h, kijs, kijl, None if fl1 is None else self._real(fl1, (nrow, self.NANG, self.NFRE), "FL1"),
                                               self._int(mij, (mij.shape[0],), "MIJ"),
                                               self._real(xllws, (xllws.shape[0], self.NANG, self.NFRE), "XLLWS"), _stream_ptr()))
 

@@ -624,7 +624,7 @@ int ecwam_hip_newwind(ecwam_hip_ctx* c, int n, void* ff, const void* ff_next, vo
 int ecwam_hip_nosource(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, int* mij, void* xllws, void* stream) {
   if (!c) return fail("null context");
   if (kijs < 0 || kijl < kijs) return fail("ecwam_hip_nosource: bad range");
-  if (kijl > kijs && (!fl1 || !mij || !xllws)) return fail("ecwam_hip_nosource: null pointer");
+  if (kijl > kijs && (!mij || !xllws)) return fail("ecwam_hip_nosource: null pointer");
   hipStream_t s = (hipStream_t)stream;
   DISPATCH(launch_nosource<float>(c->dtab, kijs, kijl, c->NANG * c->NFRE, fl1, xllws, mij, s),
            launch_nosource<double>(c->dtab, kijs, kijl, c->NANG * c->NFRE, fl1, xllws, mij, s));

@@ -1307,7 +1307,7 @@ __global__ void k_nosource(const DevTab<T>* __restrict__ tab, long long e0, long
                            int kijl, int* __restrict__ mij) {
   const T eps = tab->EPSMIN;
   for (long long g = e0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; g < e1; g += (long long)gridDim.x * blockDim.x) {
-    fl1[g] = m_max(fl1[g], eps);
+    if (fl1) fl1[g] = m_max(fl1[g], eps);   // fl1 == nullptr: the call before the source-term date (no clamp)
     xllws[g] = T(0);
   }
   for (int ij = kijs + blockIdx.x * blockDim.x + threadIdx.x; ij < kijl; ij += gridDim.x * blockDim.x) mij[ij] = tab->NFRE;

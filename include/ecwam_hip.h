@@ -277,7 +277,7 @@ int ecwam_hip_outwnorm(ecwam_hip_ctx *ctx, const void *field, int stride, int n,
 int ecwam_hip_newwind(ecwam_hip_ctx *ctx, int n, void *ff, const void *ff_next, void *stream);
 int ecwam_hip_newwind_icode(ecwam_hip_ctx *ctx, int n, void *ff, const void *ff_next, int icode_wnd, void *stream);
 /* The LLSOURCE = F branch of WAMINTGR (wamintgr.F90:152-160) on device rows [kijs, kijl): FL1 = MAX(FL1, EPSMIN), MIJ = NFRE,
- * XLLWS = 0. */
+ * XLLWS = 0.  fl1 == NULL: the branch of a call before the next source-term date (wamintgr.F90:178-186): MIJ = NFRE, XLLWS = 0 only. */
 int ecwam_hip_nosource(ecwam_hip_ctx *ctx, int kijs, int kijl, void *fl1, int *mij, void *xllws, void *stream);
 
 /*

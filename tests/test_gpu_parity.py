@@ -911,3 +911,30 @@ def test_advection_work_orders_are_bit_identical(api, prec, lf):
         m.close() if hasattr(m, "close") else None
     assert np.isfinite(out[0]).all() and out[0].max() > 0
     assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
+
+
+@pytest.mark.parametrize("prec", ["sp", "dp"])
+def test_no_source_branches_of_wamintgr(api, prec):
+    """wamintgr.F90:152-160 (LLSOURCE = F at a source-term date: FL1 = MAX(FL1, EPSMIN), MIJ = NFRE, XLLWS = 0) and :178-186 (a call
+    before the next source-term date: MIJ and XLLWS only, the advected spectra untouched), on a sub-range of the device rows."""
+    cfg = Config(nang=12, nfre=36, nfre_red=30)
+    t = Tables(cfg, H.np_dtype(prec))
+    ctx = api.HipContext(t)
+    dev = ctx.device
+    n = 301
+    rng = np.random.default_rng(4)
+    fl0 = torch.from_numpy(rng.uniform(-1.0, 1.0, (n, 12, 36)).astype(H.np_dtype(prec))).to(dev)
+    for clamp in (False, True):
+        fl = fl0.clone()
+        mij = torch.full((n,), 7, dtype=torch.int32, device=dev)
+        xl = torch.ones_like(fl)
+        ctx.nosource(5, n - 3, fl if clamp else None, mij, xl)
+        torch.cuda.synchronize()
+        inside = slice(5, n - 3)
+        assert (mij[inside] == 36).all() and (mij[:5] == 7).all() and (mij[n - 3:] == 7).all()
+        assert (xl[inside] == 0).all() and (xl[:5] == 1).all() and (xl[n - 3:] == 1).all()
+        want = fl0.clone()
+        if clamp:
+            want[inside] = torch.clamp(want[inside], min=float(t.EPSMIN))
+        assert torch.equal(fl, want)
+    ctx.close()

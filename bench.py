@@ -143,8 +143,9 @@ def main() -> None:
         if a.share_gpu:
             dist.init_process_group("gloo")
         else:
-            # "cpu:gloo,cuda:nccl": the host-staged halo moves CPU tensors, everything else goes over RCCL
-            dist.init_process_group("cpu:gloo,cuda:nccl" if a.halo == "host" else "nccl", device_id=torch.device("cuda", local_rank))
+            # "cpu:gloo,cuda:nccl": the host-staged halo (chosen, or the fallback of the self-check below) moves CPU tensors,
+            # everything else goes over RCCL
+            dist.init_process_group("cpu:gloo,cuda:nccl", device_id=torch.device("cuda", local_rank))
 
     ng = a.grid or {1: 320, 2: 453, 4: 640, 8: 1280}.get(world, int(round(320 * math.sqrt(world))))
     # time step: 450 s at O320 (the 900 s of the reference's 24-direction O320 yml violates the CTU stability criterion
@@ -159,6 +160,36 @@ def main() -> None:
     nfail = m.build_weights()
     if nfail:
         raise SystemExit(f"CFL violated at {nfail} points")
+
+    # ---- N > 1: check the halo exchange once before anything is timed -- every rank fills its owned rows with the global point
+    #      index, exchanges, and compares its halo rows with the indices its neighbours own.  A transport that raises or delivers
+    #      something else on ANY rank (first run on a new node: RCCL point-to-point set-up) is replaced by the host-staged one on
+    #      all ranks, and the JSON line says so.
+    halo_used = a.halo
+    if world > 1:
+        from ecwam_amd.wamintgr import HaloExchange
+
+        def halo_ok() -> bool:
+            try:
+                t = torch.zeros((m.dom.nrows, 1, 4), dtype=m.fl1.dtype, device=m.fl1.device)
+                t[: m.n, 0, 0] = torch.arange(m.dom.lo, m.dom.hi, dtype=torch.float64, device=t.device).to(t.dtype) % 65536.0
+                m.halo(t)
+                torch.cuda.synchronize()
+                want = torch.from_numpy(np.asarray(m.dom.halo_global, dtype=np.float64) % 65536.0).to(t.dtype)
+                return bool(torch.equal(t[m.n: m.n + m.dom.nh, 0, 0].cpu(), want))
+            except Exception as e:          # noqa: BLE001 -- any failure of the transport means: use the other one
+                print(f"[bench] rank {rank}: halo transport '{a.halo}' failed its self-check: {e!r}", file=sys.stderr, flush=True)
+                return False
+
+        flag = torch.tensor([1 if halo_ok() else 0], dtype=torch.int32)          # CPU tensor: reduced over gloo
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and a.halo != "host":
+            m.halo = HaloExchange(m.dom, m.dev, m.ctx, transport="host")
+            halo_used = f"host (fallback: '{a.halo}' failed the self-check)"
+            flag = torch.tensor([1 if halo_ok() else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            raise SystemExit("halo exchange self-check failed")
 
     def sync():
         torch.cuda.synchronize()
@@ -256,7 +287,7 @@ def main() -> None:
                                    + (f", {a.adv_per_source} advection steps per source step" if a.adv_per_source != 1 else "")
                                    + (f", fast waves M<={a.ifrelfmax} in two sub-steps" if a.ifrelfmax else ""),
                        "points_per_gpu": m.n, "halo_points": m.dom.nh, "parallelism": f"sea-point block x{world}",
-                       "halo": a.halo if world > 1 else None},
+                       "halo": halo_used if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "committed_pmc: profiles/r02_hbm_traffic_pmc.json" if traffic is not None else None},

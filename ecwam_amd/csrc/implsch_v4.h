@@ -193,15 +193,11 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
   for (int m = L.j; m < NFRE; m += G) L.zcn[m] = m_log(L.fac4[m * 4 + Q4_WAVNUM] * Z0M);
   WSYNC();
   const T XKAPPA = tb.XKAPPA, ZALP = tb.ZALP;
-  T USTP[2], XSTRESS[2] = {T(0), T(0)}, YSTRESS[2] = {T(0), T(0)}, TAUX[2], TAUY[2];
-  if (NGST == 1) USTP[0] = UFRIC;
-  else { USTP[0] = UFRIC * (T(1) + SIG_N); USTP[1] = UFRIC * (T(1) - SIG_N); }
-#pragma unroll
-  for (int ig = 0; ig < NGST; ig++) {
-    const T USG2 = USTP[ig] * USTP[ig];
-    TAUX[ig] = USG2 * sinwd;
-    TAUY[ig] = USG2 * coswd;
-  }
+  // the two gust states as the halves of a pair (NGST = 1: both halves the same state): the wave-uniform chain of a row -- sheltered
+  // stress, its direction and magnitude, U*/c -- is packed arithmetic on them
+  V2<T> vUSTP = (NGST == 1) ? V2<T>{UFRIC, UFRIC} : V2<T>{UFRIC * (T(1) + SIG_N), UFRIC * (T(1) - SIG_N)};
+  V2<T> vXS = {T(0), T(0)}, vYS = {T(0), T(0)};
+  const V2<T> vTAUX = (vUSTP * vUSTP) * sinwd, vTAUY = (vUSTP * vUSTP) * coswd;
   xm0 = 0ull; xm1 = 0ull;
   const V2<T> z2 = {T(0), T(0)};
   wse = z2; wslast = z2; apl = z2;
@@ -229,18 +225,24 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
     const T TEMP1 = LLSNEG ? lane_get(L.rT1, m) * RAORW : T(0);
     V2<T> SLP[2], FLP[2];
     bool xl0 = false, xl1 = false;
+    const V2<T> vTPX = vTAUX - ABS_TAUWSHELTER * vXS, vTPY = vTAUY - ABS_TAUWSHELTER * vYS;
+    const V2<T> vh2 = vTPX * vTPX + vTPY * vTPY;
+    V2<T> vrh = {f_rsq(vh2.x), (NGST == 2) ? f_rsq(vh2.y) : T(0)};
+    if (NGST == 1) vrh.y = vrh.x;
+    const bool zr0 = !(vh2.x > T(0)), zr1 = !(vh2.y > T(0));
+    V2<T> vh = vh2 * vrh, vCOSU = vTPY * vrh, vSINU = vTPX * vrh;
+    vh.x = zr0 ? T(0) : vh.x; vCOSU.x = zr0 ? T(1) : vCOSU.x; vSINU.x = zr0 ? T(0) : vSINU.x;
+    if (NGST == 2) { vh.y = zr1 ? T(0) : vh.y; vCOSU.y = zr1 ? T(1) : vCOSU.y; vSINU.y = zr1 ? T(0) : vSINU.y; }
+    vUSTP = V2<T>{f_sqrt(vh.x), (NGST == 2) ? f_sqrt(vh.y) : T(0)};
+    if (NGST == 1) vUSTP.y = vUSTP.x;
+    const V2<T> vUCN = vUSTP * cinv_m;
+    const V2<T> vden = vUCN + ZALP;
+    const V2<T> vUZ = XKAPPA * V2<T>{f_rcp(vden.x), (NGST == 2) ? f_rcp(vden.y) : T(0)};
 #pragma unroll
     for (int ig = 0; ig < NGST; ig++) {
-      const T TAUPX = TAUX[ig] - ABS_TAUWSHELTER * XSTRESS[ig];
-      const T TAUPY = TAUY[ig] - ABS_TAUWSHELTER * YSTRESS[ig];
-      const T h2 = TAUPX * TAUPX + TAUPY * TAUPY;
-      const bool zero = !(h2 > T(0));
-      const T rh = f_rsq(h2);
-      const T h = zero ? T(0) : h2 * rh;
-      const T COSU = zero ? T(1) : TAUPY * rh, SINU = zero ? T(0) : TAUPX * rh;
-      USTP[ig] = f_sqrt(h);
-      const T UCN = USTP[ig] * cinv_m;
-      const T UCNZALPD = XKAPPA * f_rcp(UCN + ZALP);
+      const T COSU = ig ? vCOSU.y : vCOSU.x, SINU = ig ? vSINU.y : vSINU.x;
+      const T UCN = ig ? vUCN.y : vUCN.x, UCNZALPD = ig ? vUZ.y : vUZ.x;
+      const T USTPg = ig ? vUSTP.y : vUSTP.x;
       const V2<T> coslp = L.costh * COSU + L.sinth * SINU;
       V2<T> gam0 = z2;
       {
@@ -260,7 +262,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
       }
       V2<T> dstab = z2;
       if (LLSNEG) {
-        const V2<T> DSTAB2 = TEMP1 * (TEMP2 + (FU + FUD * coslp) * USTP[ig]);
+        const V2<T> DSTAB2 = TEMP1 * (TEMP2 + (FU + FUD * coslp) * USTPg);
         dstab = DSTAB1 + PTURB * DSTAB2;
       }
       FLP[ig] = gam0 + dstab;
@@ -277,8 +279,8 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
       for (int ig = 0; ig < NGST; ig++) {
         const V2<T> sx = SLP[ig] * L.sinth, sy = SLP[ig] * L.costh;
         const V2<T> xs = v4_allsum<G, T>(V2<T>{sx.x + sx.y, sy.x + sy.y}, L.rot);
-        XSTRESS[ig] = XSTRESS[ig] + CONSTF * xs.x;
-        YSTRESS[ig] = YSTRESS[ig] + CONSTF * xs.y;
+        if (ig == 0) { vXS.x = vXS.x + CONSTF * xs.x; vYS.x = vYS.x + CONSTF * xs.y; }
+        else { vXS.y = vXS.y + CONSTF * xs.x; vYS.y = vYS.y + CONSTF * xs.y; }
         xrow += xs.x;
         yrow += xs.y;
       }

@@ -600,19 +600,6 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     XK = tb.EPSMIN + s2.x + COEFX * tl;
     XK = (XK / EM) * (XK / EM);
   };
-  auto fkmean4 = [&](T& EM, T& FM1, T& F1, T& AK, T& XK) {
-    V2<T> s0 = z2, s1 = z2, s2 = z2;   // (EM, FM), (F1, AK), (XK, last row)
-    for (int m = 0; m < NFRE; m++) {
-      const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
-      const T t = f.x + f.y;
-      const T dfm = lane_get(L.rDFIM, m), sqm = L.sq[m];
-      s0 = s0 + V2<T>{dfm, lane_get(L.rDFIMOFR, m)} * t;
-      s1 = s1 + V2<T>{lane_get(L.rDFIMFR, m), dfm / sqm} * t;
-      s2.x = s2.x + (sqm * dfm) * t;
-      if (m == NFRE - 1) s2.y = t;
-    }
-    fkmean_finish(s0, s1, s2, EM, FM1, F1, AK, XK);
-  };
 
   // ---- SDEPTHLIM (sdepthlim.F90:64-78, semean.F90:82-120), FKMEAN, the tail of sinflx.F90:124-128 and the orbital integrals of the
   //      swell damping (sinput_ard.F90:213-222) in two passes over the tile
@@ -1110,19 +1097,33 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     PHIAW = OOVAL * PHIWA / XN + (T(1) - OOVAL) * T(3.75);
   }
 
-  // ---- second FKMEAN / FEMEANWS, IMPHFTAIL, SETICE, STOKESDRIFT (implsch.F90:422-462); the SQRT(WAVNUM) plane was a staging row
-  for (int m = j; m < NFRE; m += G) L.sq[m] = m_sqrt(L.fac4[m * 4 + Q4_WAVNUM]);
-  WSYNC();
-  fkmean4(EMEAN, FMEAN, F1MEAN, AKMEAN, XKMEAN);
-  T EMEANWS;
+  // ---- second FKMEAN / FEMEANWS, IMPHFTAIL, SETICE, STOKESDRIFT (implsch.F90:422-462); the SQRT(WAVNUM) plane was a staging row.
+  //      The Stokes-drift weights STOKFAC(M) DFIM_SIM(M) of the point go to the other plane now: read inside the row loop below
+  //      they were one exposed global-memory round trip per frequency.
   {
-    V2<T> we = z2, wl = z2;
+    const T* stk = wp + 4 * NFRE;   // STOKFAC(M) of the point
+    for (int m = j; m < NFRE; m += G) {
+      L.sq[m] = m_sqrt(L.fac4[m * 4 + Q4_WAVNUM]);
+      L.zcn[m] = (m < tb.NFRE_ODD) ? stk[m] * tb.DFIM_SIM[m] : T(0);
+    }
+  }
+  WSYNC();
+  T EMEANWS;
+  {  // FKMEAN and FEMEANWS in one pass over the rows (fkmean.F90:94-150, femeanws.F90:84-123)
+    V2<T> s0 = z2, s1 = z2, s2 = z2, we = z2, wl = z2;   // (EM, FM), (F1, AK), (XK, last row), windsea (EM, FM), windsea last row
     for (int m = 0; m < NFRE; m++) {
       const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
+      const T t = f.x + f.y;
+      const T dfm = lane_get(L.rDFIM, m), dfo = lane_get(L.rDFIMOFR, m), sqm = L.sq[m];
+      s0 = s0 + V2<T>{dfm, dfo} * t;
+      s1 = s1 + V2<T>{lane_get(L.rDFIMFR, m), dfm / sqm} * t;
+      s2.x = s2.x + (sqm * dfm) * t;
+      if (m == NFRE - 1) s2.y = t;
       const V2<T> x = {((xm0 >> m) & 1ull) ? f.x : T(0), ((xm1 >> m) & 1ull) ? f.y : T(0)};
-      we = we + V2<T>{lane_get(L.rDFIM, m), lane_get(L.rDFIMOFR, m)} * (x.x + x.y);
+      we = we + V2<T>{dfm, dfo} * (x.x + x.y);
       wl = x;
     }
+    fkmean_finish(s0, s1, s2, EMEAN, FMEAN, F1MEAN, AKMEAN, XKMEAN);
     femws_finish(we, wl, FMEANWS, EMEANWS);
   }
   {  // imphftail.F90: TEMP2(M) / TEMP1 = (XK2CG WAVNUM)(MIJ) / (XK2CG WAVNUM)(M)
@@ -1145,9 +1146,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     const int MO = tb.NFRE_ODD;
     const T fo = tb.FR[MO - 1];
     const T CONST = T(2) * tb.DELTH * (tb.ZPI * tb.ZPI * tb.ZPI) / tb.G * m_pow4(fo);
-    const T* stk = wp + 4 * NFRE;   // STOKFAC(M) of the point (same address in its G lanes)
     V2<T> a = z2;
-    for (int m = 0; m < MO; m++) a = a + (stk[m] * tb.DFIM_SIM[m]) * *reinterpret_cast<const V2<T>*>(tF + m * RS);
+    for (int m = 0; m < MO; m++) a = a + L.zcn[m] * *reinterpret_cast<const V2<T>*>(tF + m * RS);
     a = a + CONST * *reinterpret_cast<const V2<T>*>(tF + (MO - 1) * RS);
     const V2<T> ax = a * L.sinth, ay = a * L.costh;
     const V2<T> s = v4_allsum<G, T>(V2<T>{ax.x + ax.y, ay.x + ay.y}, L.rot);

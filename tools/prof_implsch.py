@@ -21,14 +21,14 @@ if len(sys.argv) > 3:
     ctx.set_implsch_generation(int(sys.argv[3]))
 dev = ctx.device
 wv, ff, intf = H.pack_device_inputs(case)
-rep = n // 4096
-fl0 = torch.from_numpy(case["FL1"]).to(dev).repeat(rep, 1, 1)
-twv = torch.from_numpy(wv).to(dev).repeat(rep, 1, 1)
-tff0 = torch.from_numpy(ff).to(dev).repeat(rep, 1)
-tin = torch.from_numpy(intf).to(dev).repeat(rep, 1)
+rep = (n + 4095) // 4096
+fl0 = torch.from_numpy(case["FL1"]).to(dev).repeat(rep, 1, 1)[:n].contiguous()
+twv = torch.from_numpy(wv).to(dev).repeat(rep, 1, 1)[:n].contiguous()
+tff0 = torch.from_numpy(ff).to(dev).repeat(rep, 1)[:n].contiguous()
+tin = torch.from_numpy(intf).to(dev).repeat(rep, 1)[:n].contiguous()
 mij = torch.zeros(n, dtype=torch.int32, device=dev)
 xl = torch.zeros_like(fl0)
-for it in range(3):
+for it in range(5):
     fl = fl0.clone()
     tff = tff0.clone()
     torch.cuda.synchronize()

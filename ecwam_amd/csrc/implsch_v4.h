@@ -170,14 +170,6 @@ struct V4Ctx {
 };
 enum { Q4_BSC = 0, Q4_SBO, Q4_CINV, Q4_WAVNUM };   // Q4_BSC = WAVNUM XK2CG / 2 pi
 
-// a VGPR that holds zero without the compiler knowing: added to a wave-uniform address it turns the load into a vector load
-// (vmcnt, registers usable as VALU operands) instead of a scalar load (lgkmcnt shared with the LDS, out of order)
-__device__ __forceinline__ int v4_opaque_zero() {
-  int z;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-  return z;
-}
-
 // SINPUT_ARD (sinput_ard.F90:153-520) for one SINFLX call.  Outputs: XLLWS masks of the two directions of the lane (bit m), the row
 // integrals X, Y of the frequencies the lane owns (m = s G + j), the FEMEANWS integrands (wse: x = SUM DFIM F, y = SUM DFIMOFR F
 // over the windsea bins; wslast = windsea part of the last row), apl (negative wind input per direction) and -- LLSNEG -- the

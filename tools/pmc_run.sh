@@ -1,5 +1,5 @@
 #!/bin/bash
-# diagnostics: arbitrary PMC sets on the IMPLSCH profiling driver.  usage: PMC="A B C" [N=32768] [PREC=sp] [GEN=0|2|3|4] bash tools/pmc_run.sh
+# diagnostics: arbitrary PMC sets on the IMPLSCH profiling driver.  usage: PMC="A B C" [N=32768] [PREC=sp] [GEN=0|2|4] bash tools/pmc_run.sh
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 N=${N:-32768}; PREC=${PREC:-sp}; TAG=${TAG:-x}; GEN=${GEN:-0}
 rm -rf gpurun_out/pmc_$TAG

@@ -7,9 +7,9 @@ rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d gpurun_out/pmc_$TAG -
 python3 - <<PY
 import csv,glob,collections
 f=glob.glob('gpurun_out/pmc_$TAG/*/*counter_collection.csv')[0]
-agg=collections.defaultdict(float)
+agg=collections.defaultdict(float); launches=set()
 for r in csv.DictReader(open(f)):
     if 'implsch' in r['Kernel_Name']:
-        agg[r['Counter_Name']]+=float(r['Counter_Value'])
-print({k:round(v/3/$N,1) for k,v in agg.items()})
+        agg[r['Counter_Name']]+=float(r['Counter_Value']); launches.add(r['Dispatch_Id'])
+print({k:round(v/len(launches)/$N,1) for k,v in agg.items()})   # per launch and sea point
 PY

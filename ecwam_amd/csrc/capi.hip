@@ -30,6 +30,8 @@ struct ecwam_hip_ctx {
   // fourth kernel generation (implsch_v4.h): DIA rotations K1 = K -+ r1, K2 = K +- r2, NSDSNTH = nh; ok = the tables have that structure
   int v4_ok = 0, v4_r1 = 0, v4_r2 = 0, v4_nh = 0, v4_shelter = 0;
   int implsch_gen = 0;  // 0: the fastest kernel generation that covers the configuration; 2 / 4: at most that generation (tests)
+  void* fin = nullptr;  // rows of scalars k_implsch4 hands to its finishing kernel, indexed by the point number; grown on demand
+  size_t fin_bytes = 0;
   // advection halo exchange (MPEXCHNG): peers, the owned rows each of them needs (concatenated in peer order) and where their rows
   // land; RCCL communicator + a stream of its own so that the exchange runs beside the interior stencil
   int rank = 0, nranks = 1;
@@ -63,7 +65,8 @@ template <typename T> void launch_c2p(const void*, void*, int, int, int, int, in
 template <typename T> void launch_p2c(const void*, void*, int, int, int, int, int, hipStream_t);
 template <typename T> void launch_pack(const void*, const int*, int, int, void*, hipStream_t);
 template <typename T> int launch_implsch(const void*, int, int, void*, const void*, void*, void*, int*, void*, double*, void*, int, int, int, hipStream_t);
-template <typename T> int launch_implsch4(const void*, int, int, void*, const void*, void*, void*, int*, void*, int, int, int, int, int, int, hipStream_t);
+template <typename T> int launch_implsch4(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, int, int, int, int, int, int, hipStream_t);
+int implsch4_fin_row();
 
 // Does the fourth kernel generation cover these tables?  It needs the pull-form DIA structure with K1W = K -+ r1, K11W = K1W -+ 1,
 // K2W = K +- r2, K21W = K2W +- 1 (kh = 1 / 2) and saturation weights that depend on the tap only (init_sdiss_ardh.F90:88-94: they
@@ -344,6 +347,7 @@ int ecwam_hip_destroy(ecwam_hip_ctx* c) {
   if (!c) return 0;
   if (c->dtab) (void)hipFree(c->dtab);
   if (c->norm_scratch) (void)hipFree(c->norm_scratch);
+  if (c->fin) (void)hipFree(c->fin);
   halo_release(c);
   delete c;
   return 0;
@@ -561,8 +565,15 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   const int ext = (c->p.llnormagam || c->p.llgcbz0) ? 1 : 0;
   if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !rare && !wam2nemo && !dbg &&
       (c->p.llnormagam ? c->v4_shelter == 0 : c->v4_shelter != 0)) {
-    DISPATCH(rc = launch_implsch4<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s),
-             rc = launch_implsch4<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s));
+    const size_t need = (size_t)(kijl > 0 ? kijl : 0) * implsch4_fin_row() * c->real_bytes;
+    if (need > c->fin_bytes) {   // first call, or a longer block than any before: hipFree waits for the kernels still reading the old rows
+      if (c->fin) HIPCHK(hipFree(c->fin));
+      c->fin = nullptr; c->fin_bytes = 0;
+      HIPCHK(hipMalloc(&c->fin, need));
+      c->fin_bytes = need;
+    }
+    DISPATCH(rc = launch_implsch4<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s),
+             rc = launch_implsch4<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s));
     if (rc == 0) { HIPCHK(hipGetLastError()); return 0; }
   }
   DISPATCH(rc = launch_implsch<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s),

@@ -239,9 +239,9 @@ __device__ __forceinline__ void stresso_node(const DevTab<T>& tb, const T* c, in
   const T CM1 = (Y * c[C_SQRTGZ0]) * tb.GM1;
   nY = Y; nCM1 = CM1; nLC = c[C_XLOGGZ0] + T(2) * m_log(CM1);
 }
-template <typename T, bool RARE>
-// nY/nCM1/nLC: node values held by lane nbase+J (pulled through the LDS crossbar; every lane of the wave runs this)
-__device__ void stresso_tail_pt(const DevTab<T>& tb, T* c, T nY, T nCM1, T nLC, T pY, T pCM1, T pLC, int nbase, bool store, bool LLPHIWA) {
+// nodeN / nodeP (J, Y, CM1, LC): the J-th quadrature node of the momentum / of the energy flux integral
+template <typename T, bool RARE, typename FN, typename FP>
+__device__ __forceinline__ void stresso_tail_core(const DevTab<T>& tb, T* c, FN nodeN, FP nodeP, bool store, bool LLPHIWA) {
   const T AIRD = c[C_AIRD], UFRIC = c[C_UFRIC], Z0M = c[C_Z0M], RNFAC = c[C_RNFAC];
   const T F1DCOS3 = c[C_F1DCOS3], F1DCOS2 = c[C_F1DCOS2];
   const int MIJ = (int)c[C_MIJ];
@@ -264,7 +264,8 @@ __device__ void stresso_tail_pt(const DevTab<T>& tb, T* c, T nY, T nCM1, T nLC, 
   T DELZ = m_max((c[C_ZSUP] - ZINF) / T(JTOT - 1), T(0));
   T TAUHF = T(0), acc = T(0);
   for (int J = 0; J < JTOT; J++) {
-    const T Y = lane_pull(nY, nbase + J), CM1 = lane_pull(nCM1, nbase + J), LC = lane_pull(nLC, nbase + J);
+    T Y, CM1, LC;
+    nodeN(J, Y, CM1, LC);
     const T ZARG = tb.XKAPPA * f_rcp(UST * CM1 + tb.ZALP);
     const T ZLOG = m_min(LC + ZARG, T(0));
     const T ZBETA = m_pow4(ZLOG) * f_exp(ZLOG);
@@ -286,7 +287,8 @@ __device__ void stresso_tail_pt(const DevTab<T>& tb, T* c, T nY, T nCM1, T nLC, 
     DELZ = m_max((T(0) - ZINF) / T(JTOT - 1), T(0));  // ZSUP = ZSUPMAX = 0 for the energy flux (tau_phi_hf.F90:246-248)
     const T CONSTPHI = AIRD * tb.ZPI4GM1 * fr5;
     for (int J = 0; J < JTOT; J++) {
-      const T Y = lane_pull(pY, nbase + J), CM1 = lane_pull(pCM1, nbase + J), LC = lane_pull(pLC, nbase + J);
+      T Y, CM1, LC;
+      nodeP(J, Y, CM1, LC);
       const T ZARG = tb.XKAPPA * f_rcp(USTPH * CM1 + tb.ZALP);
       const T ZLOG = m_min(LC + ZARG, T(0));
       const T ZBETA = m_pow4(ZLOG) * f_exp(ZLOG);
@@ -320,6 +322,22 @@ __device__ void stresso_tail_pt(const DevTab<T>& tb, T* c, T nY, T nCM1, T nLC, 
       c[C_PHIWA] = c[C_PHIWA] + PHIHF;
     }
   }
+}
+// nY/nCM1/nLC: node values held by lane nbase+J (pulled through the LDS crossbar; every lane of the wave runs this)
+template <typename T, bool RARE>
+__device__ void stresso_tail_pt(const DevTab<T>& tb, T* c, T nY, T nCM1, T nLC, T pY, T pCM1, T pLC, int nbase, bool store, bool LLPHIWA) {
+  stresso_tail_core<T, RARE>(
+      tb, c, [&](int J, T& Y, T& CM1, T& LC) { Y = lane_pull(nY, nbase + J); CM1 = lane_pull(nCM1, nbase + J); LC = lane_pull(nLC, nbase + J); },
+      [&](int J, T& Y, T& CM1, T& LC) { Y = lane_pull(pY, nbase + J); CM1 = lane_pull(pCM1, nbase + J); LC = lane_pull(pLC, nbase + J); }, store, LLPHIWA);
+}
+// the whole of STRESSO's scalar half for one point on one lane (no lane exchange): the finishing kernel of the fourth generation
+template <typename T, bool RARE>
+__device__ __forceinline__ void stresso_point(const DevTab<T>& tb, T* c, bool LLPHIWA) {
+  stresso_head_pt<T, RARE>(tb, c);
+  const T ZSUP = c[C_ZSUP];
+  stresso_tail_core<T, RARE>(
+      tb, c, [&](int J, T& Y, T& CM1, T& LC) { stresso_node(tb, c, J, ZSUP, Y, CM1, LC); },
+      [&](int J, T& Y, T& CM1, T& LC) { stresso_node(tb, c, J, (RARE && tb.LLGCBZ0) ? T(0) : ZSUP, Y, CM1, LC); }, true, LLPHIWA);
 }
 // the three steps on the stage's wave: lanes < WPB own a point, lanes < WPB*JTOT a node
 template <typename T, int WPB, bool RARE>

@@ -39,6 +39,10 @@
 template <typename T>
 using V2 = T __attribute__((ext_vector_type(2)));
 
+// the row of scalars per sea point that k_implsch4_pre hands to k_implsch4 and k_implsch4 to k_implsch4_fin
+enum { FIN_AIRD = 0, FIN_UFRIC, FIN_Z0M, FIN_MIJ, FIN_XS, FIN_YS, FIN_F1DCOS3, FIN_F1DCOS2, FIN_F1DSIN2, FIN_F1D, FIN_RNFAC, FIN_PHIWA,
+       FIN_SINWD, FIN_COSWD, FIN_WSWAVE, FIN_CICOVER, FIN_PHILF, FIN_XSTRESS, FIN_YSTRESS, FIN_Z0B, FIN_CHRNCK, FIN_COSDIFF, V4_NFIN = 24 };
+
 __device__ __forceinline__ float v4_bp(int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); }
 __device__ __forceinline__ double v4_bp(int addr, double v) {
   const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
@@ -426,7 +430,7 @@ template <typename T, int NANG, int PP, int R1, int R2, int NH, bool EXT>
 // (40 KB per wave) and the kernel may use the whole register file (340 registers: no scratch)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(V4_WPE_MIN(T), 2)))
 k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__ fl1, const T* __restrict__ wvprpt, T* __restrict__ ffa,
-           T* __restrict__ intfa, int* __restrict__ mij_out, T* __restrict__ xllws) {
+           T* __restrict__ intfa, int* __restrict__ mij_out, T* __restrict__ xllws, T* __restrict__ fin) {
   constexpr int G = NANG / 2, NFRE = V4_NFRE, N = NANG * NFRE, RS = PP * NANG, NS = NFRE / G;
   constexpr int NSH = (NH + 1) / 2;          // even shifts -2 NSH .. 2 NSH cover the taps -NH .. NH+1 and the DIA rotations
   constexpr int NTAP = 2 * NH + 1;
@@ -542,14 +546,11 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     q[C_AIRD] = AIRD; q[C_WDWAVE] = WDWAVE; q[C_WSWAVE] = WSWAVE; q[C_WSTAR] = ff[4];
     q[C_TAUW] = ff[8]; q[C_TAUWDIR] = ff[9];
     q[C_RAORW] = m_max(AIRD, T(1)) * tb.ROWATERM1; q[C_EMAXDPT] = ff[14]; q[C_DEPTH] = ff[15];
-    q[C_SINWD] = m_sin(WDWAVE); q[C_COSWD] = m_cos(WDWAVE);
-    T RNFAC = T(1);   // sinflx.F90:116-120
-    if (EXT && tb.LLNORMAGAM && tb.LLCAPCHNK) RNFAC = T(1) + tb.DTHRN_A * (T(1) + m_tanh(WSWAVE - tb.DTHRN_U));
-    q[C_RNFAC] = RNFAC;
-    T UFRIC = ff[7], Z0M = ff[10], Z0B = ff[11], CHRNCK = ff[12];
-    if (EXT && tb.LLGCBZ0) q[C_TWCOS] = m_cos(WDWAVE - ff[9]);   // COSDIFF of the first TAUT_Z0, which runs per point across the wave below
-    else taut_z0_a(tb, 0, WSWAVE, WDWAVE, ff[8], ff[9], UFRIC, Z0M, Z0B, CHRNCK);
-    q[C_UFRIC] = UFRIC; q[C_Z0M] = Z0M; q[C_Z0B] = Z0B; q[C_CHRNCK] = CHRNCK;
+    // SIN / COS(WDWAVE), RNFAC and the first TAUT_Z0 (LLGCBZ0: its COSDIFF; it runs per point across the wave below): k_implsch4_pre
+    const T* fr = fin + (size_t)pid * V4_NFIN;
+    q[C_SINWD] = fr[FIN_SINWD]; q[C_COSWD] = fr[FIN_COSWD]; q[C_RNFAC] = fr[FIN_RNFAC];
+    if (EXT && tb.LLGCBZ0) q[C_TWCOS] = fr[FIN_COSDIFF];
+    q[C_UFRIC] = fr[FIN_UFRIC]; q[C_Z0M] = fr[FIN_Z0M]; q[C_Z0B] = fr[FIN_Z0B]; q[C_CHRNCK] = fr[FIN_CHRNCK];
     q[C_SPARE] = ff[2];   // CICOVER
   }
   // ---- per-frequency factors of the point: lane j fills M = j+1, j+1+G, ...
@@ -799,9 +800,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   post_stress(MIJ, apl, true);
   WSYNC();
   V4_PHASE_EXIT(205);
-  // ---- stage 3: STRESSO of the second call (TAUW, TAUWDIR, PHIWA)
-  v4_stresso<T, PP, EXT>(tb, sSC, lane, true);
-  WSYNC();
+  // ---- STRESSO of the second call (TAUW, TAUWDIR, PHIWA) and the scalar half of WNFLUXES: nothing below needs them, and on this
+  //      kernel's waves they are a long dependent chain on PP lanes.  k_implsch4_fin runs them afterwards, one point per lane.
   V4_PHASE_EXIT(206);
 
   // ---- SDISSIP + SNONLIN + update sweep (implsch.F90:262-392), software-pipelined over the interaction frequencies MC = 1 .. MLSTHG:
@@ -1054,39 +1054,15 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   }
   V4SYNC();
   V4_PHASE_EXIT(207);
-  const T TAUW = c[C_TAUW], TAUWDIR = c[C_TAUWDIR], PHIWA = c[C_PHIWA], Z0B = c[C_Z0B], CHRNCK = c[C_CHRNCK];
+  const T Z0B = c[C_Z0B], CHRNCK = c[C_CHRNCK];
 
-  // ---- WNFLUXES (wnfluxes.F90:147-330), LWNEMOCOU = F
-  T TAUXD = T(0), TAUYD = T(0), TAUOCXD = T(0), TAUOCYD = T(0), TAUOC = T(0), PHIOCD = T(0), PHIEPS = T(0), PHIAW = T(0);
+  // ---- WNFLUXES (wnfluxes.F90:147-190): the directional sums of the flux accumulators; the rest of it in k_implsch4_fin
+  T PHILF = T(0), XSTRESS = T(0), YSTRESS = T(0);
   if (tb.LCFLX) {
     const V2<T> sx = a_x * L.sinth, sy = a_x * L.costh;
     const V2<T> r0 = v4_allsum<G, T>(V2<T>{a_t.x + a_t.y, sx.x + sx.y}, L.rot);
-    const T YSTRESS = v4_allsum1<G, T>(sy.x + sy.y, L.rot);
-    const T PHILF = r0.x, XSTRESS = r0.y;
-    const T EPSUS3 = tb.EPSUS * m_sqrt(tb.EPSUS);
-    T OOVAL = T(1), USTAR = UFRIC;
-    if (tb.LICERUN && tb.LWAMRSETCI && CICOVER > tb.CIBLOCK) {
-      OOVAL = m_exp(-m_min(m_pow4(CICOVER * (T(1) / m_max(tb.CITHRSH, T(0.01)))), T(10)));
-      const T U10P = m_max(WSWAVE, tb.EPSU10);
-      const T CD_BULK = m_min((T(1.03E-3) + T(0.04E-3) * m_pow(U10P, T(1.48))) * m_pow(U10P, T(-0.21)), T(0.003));
-      const T CD_WAVE = (UFRIC / U10P) * (UFRIC / U10P);
-      const T CD_ICE = OOVAL * CD_WAVE + (T(1) - OOVAL) * CD_BULK;
-      USTAR = m_max(m_sqrt(CD_ICE) * U10P, tb.EPSUS);
-    }
-    const T TAU = AIRD * m_max(USTAR * USTAR, tb.EPSUS);
-    TAUXD = TAU * sinwd;
-    TAUYD = TAU * coswd;
-    TAUOCXD = TAUXD - OOVAL * XSTRESS;
-    TAUOCYD = TAUYD - OOVAL * YSTRESS;
-    const T TAUO = m_sqrt(TAUOCXD * TAUOCXD + TAUOCYD * TAUOCYD);
-    TAUOC = m_min(m_max(TAUO / TAU, tb.TAUOCMIN), tb.TAUOCMAX);
-    const T USTRA = ffa[(size_t)ij * ECWAM_HIP_NFF + 5], VSTRA = ffa[(size_t)ij * ECWAM_HIP_NFF + 6];
-    if (tb.LWCOUAST && (USTRA != T(0) || VSTRA != T(0))) { TAUXD = USTRA; TAUOCXD = USTRA * TAUOC; TAUYD = VSTRA; TAUOCYD = VSTRA * TAUOC; }
-    const T XN = AIRD * m_max(USTAR * USTAR * USTAR, EPSUS3);
-    PHIOCD = OOVAL * (PHILF - PHIWA) + (T(1) - OOVAL) * T(-3.75) * XN;
-    PHIEPS = m_min(m_max(PHIOCD / XN, tb.PHIEPSMIN), tb.PHIEPSMAX);
-    PHIOCD = PHIEPS * XN;
-    PHIAW = OOVAL * PHIWA / XN + (T(1) - OOVAL) * T(3.75);
+    YSTRESS = v4_allsum1<G, T>(sy.x + sy.y, L.rot);
+    PHILF = r0.x; XSTRESS = r0.y;
   }
 
   // ---- second FKMEAN / FEMEANWS, IMPHFTAIL, SETICE, STOKESDRIFT (implsch.F90:422-462); the SQRT(WAVNUM) plane was a staging row.
@@ -1191,17 +1167,90 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   }
   if (j == 0) {
     T* fo = ffa + (size_t)ij * ECWAM_HIP_NFF;
-    fo[7] = UFRIC; fo[8] = TAUW; fo[9] = TAUWDIR; fo[10] = Z0M; fo[11] = Z0B; fo[12] = CHRNCK;
+    fo[7] = UFRIC; fo[10] = Z0M; fo[11] = Z0B; fo[12] = CHRNCK;   // TAUW, TAUWDIR: k_implsch4_fin
     T* io = intfa + (size_t)ij * ECWAM_HIP_NINTF;
     io[2] = USTOKES; io[3] = VSTOKES;
-    if (tb.LCFLX) {
-      io[5] = TAUXD; io[6] = TAUYD; io[7] = TAUOCXD; io[8] = TAUOCYD; io[9] = TAUOC; io[10] = T(0); io[11] = T(0);
-      io[12] = PHIOCD; io[13] = PHIEPS; io[14] = PHIAW;
-    }
+    T* fr = fin + (size_t)ij * V4_NFIN;
+    fr[FIN_AIRD] = AIRD; fr[FIN_UFRIC] = UFRIC; fr[FIN_Z0M] = Z0M; fr[FIN_MIJ] = c[C_MIJ];
+    fr[FIN_XS] = c[C_XS]; fr[FIN_YS] = c[C_YS]; fr[FIN_F1DCOS3] = c[C_F1DCOS3]; fr[FIN_F1DCOS2] = c[C_F1DCOS2];
+    fr[FIN_F1DSIN2] = c[C_F1DSIN2]; fr[FIN_F1D] = c[C_F1D]; fr[FIN_RNFAC] = c[C_RNFAC]; fr[FIN_PHIWA] = c[C_PHIWA];
+    fr[FIN_SINWD] = sinwd; fr[FIN_COSWD] = coswd; fr[FIN_WSWAVE] = WSWAVE; fr[FIN_CICOVER] = CICOVER;
+    fr[FIN_PHILF] = PHILF; fr[FIN_XSTRESS] = XSTRESS; fr[FIN_YSTRESS] = YSTRESS;
     if (tb.LWFLUX) {
       io[0] = (EMEANWS < tb.WSEMEAN_MIN) ? tb.WSEMEAN_MIN : EMEANWS;
       io[1] = (EMEANWS < tb.WSEMEAN_MIN) ? T(2) * tb.FR[NFRE - 1] : FMEANWS;
     }
     mij_out[ij] = MIJ;
+  }
+}
+
+// The scalar start of the time step, one sea point per lane (sinflx.F90:105-122): direction of the wind, RNFAC, the first TAUT_Z0
+// (taut_z0.F90:288-340; with LLGCBZ0 only its COSDIFF -- the gravity-capillary iteration needs the spectrum and stays in k_implsch4).
+template <typename T, bool EXT>
+__global__ void __launch_bounds__(64) k_implsch4_pre(const DevTab<T>* __restrict__ tp, int kijs, int kijl, const T* __restrict__ ffa,
+                                                     T* __restrict__ fin) {
+  const DevTab<T>& tb = *tp;
+  const int ij = kijs + blockIdx.x * 64 + threadIdx.x;
+  if (ij >= kijl) return;
+  const T* ff = ffa + (size_t)ij * ECWAM_HIP_NFF;
+  T* fr = fin + (size_t)ij * V4_NFIN;
+  const T WDWAVE = ff[1], WSWAVE = ff[3];
+  fr[FIN_SINWD] = m_sin(WDWAVE); fr[FIN_COSWD] = m_cos(WDWAVE);
+  T RNFAC = T(1);   // sinflx.F90:116-120
+  if (EXT && tb.LLNORMAGAM && tb.LLCAPCHNK) RNFAC = T(1) + tb.DTHRN_A * (T(1) + m_tanh(WSWAVE - tb.DTHRN_U));
+  fr[FIN_RNFAC] = RNFAC;
+  T UFRIC = ff[7], Z0M = ff[10], Z0B = ff[11], CHRNCK = ff[12];
+  if (EXT && tb.LLGCBZ0) fr[FIN_COSDIFF] = m_cos(WDWAVE - ff[9]);
+  else taut_z0_a(tb, 0, WSWAVE, WDWAVE, ff[8], ff[9], UFRIC, Z0M, Z0B, CHRNCK);
+  fr[FIN_UFRIC] = UFRIC; fr[FIN_Z0M] = Z0M; fr[FIN_Z0B] = Z0B; fr[FIN_CHRNCK] = CHRNCK;
+}
+
+// The scalar end of the time step, one sea point per lane: STRESSO's second call (stresso.F90:180-229 with tau_phi_hf.F90:125-301:
+// TAUW, TAUWDIR, PHIWA) and WNFLUXES' point-wise part (wnfluxes.F90:190-330, LWNEMOCOU = F) from the row of scalars k_implsch4 left
+// in fin(:, IJ).  On k_implsch4's waves these two dependent chains kept PP lanes busy; here every lane has a point.
+template <typename T, bool EXT>
+__global__ void __launch_bounds__(64) k_implsch4_fin(const DevTab<T>* __restrict__ tp, int kijs, int kijl, const T* __restrict__ fin,
+                                                     T* __restrict__ ffa, T* __restrict__ intfa) {
+  const DevTab<T>& tb = *tp;
+  const int ij = kijs + blockIdx.x * 64 + threadIdx.x;
+  if (ij >= kijl) return;
+  const T* fr = fin + (size_t)ij * V4_NFIN;
+  T c[NSC];
+  c[C_AIRD] = fr[FIN_AIRD]; c[C_UFRIC] = fr[FIN_UFRIC]; c[C_Z0M] = fr[FIN_Z0M]; c[C_MIJ] = fr[FIN_MIJ];
+  c[C_XS] = fr[FIN_XS]; c[C_YS] = fr[FIN_YS]; c[C_F1DCOS3] = fr[FIN_F1DCOS3]; c[C_F1DCOS2] = fr[FIN_F1DCOS2];
+  c[C_F1DSIN2] = fr[FIN_F1DSIN2]; c[C_F1D] = fr[FIN_F1D]; c[C_RNFAC] = fr[FIN_RNFAC]; c[C_PHIWA] = fr[FIN_PHIWA];
+  c[C_SINWD] = fr[FIN_SINWD]; c[C_COSWD] = fr[FIN_COSWD];
+  const T AIRD = c[C_AIRD], UFRIC = c[C_UFRIC], sinwd = c[C_SINWD], coswd = c[C_COSWD];
+  const T WSWAVE = fr[FIN_WSWAVE], CICOVER = fr[FIN_CICOVER], PHILF = fr[FIN_PHILF], XSTRESS = fr[FIN_XSTRESS], YSTRESS = fr[FIN_YSTRESS];
+  stresso_point<T, EXT>(tb, c, true);
+  const T PHIWA = c[C_PHIWA];
+  T* fo = ffa + (size_t)ij * ECWAM_HIP_NFF;
+  fo[8] = c[C_TAUW]; fo[9] = c[C_TAUWDIR];
+  if (tb.LCFLX) {
+    const T EPSUS3 = tb.EPSUS * m_sqrt(tb.EPSUS);
+    T OOVAL = T(1), USTAR = UFRIC;
+    if (tb.LICERUN && tb.LWAMRSETCI && CICOVER > tb.CIBLOCK) {
+      OOVAL = m_exp(-m_min(m_pow4(CICOVER * (T(1) / m_max(tb.CITHRSH, T(0.01)))), T(10)));
+      const T U10P = m_max(WSWAVE, tb.EPSU10);
+      const T CD_BULK = m_min((T(1.03E-3) + T(0.04E-3) * m_pow(U10P, T(1.48))) * m_pow(U10P, T(-0.21)), T(0.003));
+      const T CD_WAVE = (UFRIC / U10P) * (UFRIC / U10P);
+      const T CD_ICE = OOVAL * CD_WAVE + (T(1) - OOVAL) * CD_BULK;
+      USTAR = m_max(m_sqrt(CD_ICE) * U10P, tb.EPSUS);
+    }
+    const T TAU = AIRD * m_max(USTAR * USTAR, tb.EPSUS);
+    T TAUXD = TAU * sinwd, TAUYD = TAU * coswd;
+    T TAUOCXD = TAUXD - OOVAL * XSTRESS, TAUOCYD = TAUYD - OOVAL * YSTRESS;
+    const T TAUO = m_sqrt(TAUOCXD * TAUOCXD + TAUOCYD * TAUOCYD);
+    const T TAUOC = m_min(m_max(TAUO / TAU, tb.TAUOCMIN), tb.TAUOCMAX);
+    const T USTRA = fo[5], VSTRA = fo[6];
+    if (tb.LWCOUAST && (USTRA != T(0) || VSTRA != T(0))) { TAUXD = USTRA; TAUOCXD = USTRA * TAUOC; TAUYD = VSTRA; TAUOCYD = VSTRA * TAUOC; }
+    const T XN = AIRD * m_max(USTAR * USTAR * USTAR, EPSUS3);
+    T PHIOCD = OOVAL * (PHILF - PHIWA) + (T(1) - OOVAL) * T(-3.75) * XN;
+    const T PHIEPS = m_min(m_max(PHIOCD / XN, tb.PHIEPSMIN), tb.PHIEPSMAX);
+    PHIOCD = PHIEPS * XN;
+    const T PHIAW = OOVAL * PHIWA / XN + (T(1) - OOVAL) * T(3.75);
+    T* io = intfa + (size_t)ij * ECWAM_HIP_NINTF;
+    io[5] = TAUXD; io[6] = TAUYD; io[7] = TAUOCXD; io[8] = TAUOCYD; io[9] = TAUOC; io[10] = T(0); io[11] = T(0);
+    io[12] = PHIOCD; io[13] = PHIEPS; io[14] = PHIAW;
   }
 }

@@ -88,12 +88,17 @@ def cpu_baseline(nang: int, nfre: int, prec: str, target_s: float = 15.0) -> dic
     steps, el = o.timed_steps(g, fl.copy(), w, pr, env, ff.copy(), intf.copy(), max_steps=200, target_s=0.75 * target_s)
     kind, t_impl, t_prop = o.implsch_kind, o.t_implsch, o.t_propags2
     s2, _ = o.timed_steps(g, fl, w, pr, env, ff, intf, max_steps=200, target_s=0.25 * target_s, blocked=False)
-    return {"value": n * steps / el, "unit": "grid-point spectral steps/s", "cores": cores, "kind": "port",
-            "implsch_only": n * steps / t_impl, "propags2_only": n * steps / t_prop, "implsch_variant": kind,
-            "implsch_only_point_by_point": n * s2 / o.t_implsch,
-            "note": "IMPLSCH runs the NPROMA-blocked C restatement (oracle/ora_implsch_blk.inc: SINPUT_ARD, SDISSIP_ARD and SNONLIN with "
-                    "the sea-point index innermost as in implsch.F90:152-170, omp simd + libmvec, flush-to-zero; the scalar chains TAUT_Z0 / "
-                    "STRESSO / FKMEAN point by point), PROPAGS2 its eight weights packed as contiguous streams (ora_propags2_w8, bit-identical); "
+    # which of the two is faster depends on the host (vector width, threads per core): the baseline is the step with the faster one
+    per_blk, per_pt = t_impl / steps, o.t_implsch / s2
+    per_step = el / steps - per_blk + min(per_blk, per_pt)
+    if per_pt < per_blk:
+        kind = "point-by-point"
+    return {"value": n / per_step, "unit": "grid-point spectral steps/s", "cores": cores, "kind": "port",
+            "implsch_only": n / min(per_blk, per_pt), "propags2_only": n * steps / t_prop, "implsch_variant": kind,
+            "implsch_only_nproma_blocked": n / per_blk, "implsch_only_point_by_point": n / per_pt,
+            "note": "IMPLSCH is timed in two C restatements and the faster one on this host counts: NPROMA-blocked (oracle/ora_implsch_blk.inc: "
+                    "SINPUT_ARD, SDISSIP_ARD and SNONLIN with the sea-point index innermost as in implsch.F90:152-170, omp simd + libmvec, "
+                    "flush-to-zero; the scalar chains TAUT_Z0 / STRESSO / FKMEAN point by point) and point by point; PROPAGS2 its eight weights packed as contiguous streams (ora_propags2_w8, bit-identical); "
                     "both checked against the point-by-point oracle; unpinned against the reference "
                     "(DESIGN.md section 4): an estimate of what the reference's OpenMP path does on these cores, not a measurement of it",
             "sample": f"O48 all-ocean grid ({n} sea points), {nang}x{nfre} spectrum, {prec}, {steps} full steps "

@@ -570,6 +570,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
       if (c->fin) HIPCHK(hipFree(c->fin));
       c->fin = nullptr; c->fin_bytes = 0;
       HIPCHK(hipMalloc(&c->fin, need));
+      HIPCHK(hipMemset(c->fin, 0, need));
       c->fin_bytes = need;
     }
     DISPATCH(rc = launch_implsch4<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s),

@@ -1216,7 +1216,8 @@ __global__ void __launch_bounds__(64) k_implsch4_fin(const DevTab<T>* __restrict
   if (ij >= kijl) return;
   const T* fr = fin + (size_t)ij * V4_NFIN;
   T c[NSC];
-  c[C_AIRD] = fr[FIN_AIRD]; c[C_UFRIC] = fr[FIN_UFRIC]; c[C_Z0M] = fr[FIN_Z0M]; c[C_MIJ] = fr[FIN_MIJ];
+  c[C_AIRD] = fr[FIN_AIRD]; c[C_UFRIC] = fr[FIN_UFRIC]; c[C_Z0M] = fr[FIN_Z0M];
+  c[C_MIJ] = m_min(m_max(fr[FIN_MIJ], T(1)), T(V4_NFRE));   // a table index: whatever the row holds, stay inside FR(1:NFRE)
   c[C_XS] = fr[FIN_XS]; c[C_YS] = fr[FIN_YS]; c[C_F1DCOS3] = fr[FIN_F1DCOS3]; c[C_F1DCOS2] = fr[FIN_F1DCOS2];
   c[C_F1DSIN2] = fr[FIN_F1DSIN2]; c[C_F1D] = fr[FIN_F1D]; c[C_RNFAC] = fr[FIN_RNFAC]; c[C_PHIWA] = fr[FIN_PHIWA];
   c[C_SINWD] = fr[FIN_SINWD]; c[C_COSWD] = fr[FIN_COSWD];

@@ -858,6 +858,39 @@ def test_implsch_kernel_generations_agree(api):
 
 
 @pytest.mark.parametrize("prec", ["sp", "dp"])
+def test_implsch_in_blocks_is_bit_identical(api, prec):
+    """ecwam_hip_implsch on sub-ranges KIJS..KIJL of the arrays (the reference's NPROMA chunks: implsch.F90:10, wamintgr.F90:120-149), in
+    growing and in ragged blocks, on two streams, against one call over all points: every output bit-identical.  k_implsch4 hands
+    scalars to its finishing kernel through rows of a context-owned buffer indexed by the point number, which grows with KIJL."""
+    import torch
+
+    cfg = Config(nang=36, nfre=36, nfre_red=36)
+    n = 3001
+    case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=31)
+    ctx = api.HipContext(case["tables"])
+    whole = H.gpu_implsch(case, ctx)
+    ctx.close()
+    ctx = api.HipContext(case["tables"])      # a fresh context: its buffer starts empty and grows block by block
+    dev = ctx.device
+    wv, ff, intf = H.pack_device_inputs(case)
+    fl1 = torch.from_numpy(case["FL1"].copy()).to(dev)
+    twv, tff, tintf = (torch.from_numpy(a).to(dev) for a in (wv, ff, intf))
+    mij = torch.zeros(n, dtype=torch.int32, device=dev)
+    xllws = torch.zeros_like(fl1)
+    bounds = [0, 7, 64, 65, 1000, 1001, 2048, n]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(bounds[:-1], bounds[1:])):
+        with torch.cuda.stream(streams[i & 1]):
+            ctx.implsch(a, b, fl1, twv, tff, tintf, mij, xllws)
+    torch.cuda.synchronize()
+    got = dict(FL1=fl1.cpu().numpy(), XLLWS=xllws.cpu().numpy(), MIJ=mij.cpu().numpy(), FF=tff.cpu().numpy()[:, :14], INTF=tintf.cpu().numpy()[:, :15])
+    ctx.close()
+    for k in ("FL1", "XLLWS", "MIJ", "FF", "INTF"):
+        assert np.array_equal(whole[k], got[k]), k
+
+
+@pytest.mark.parametrize("prec", ["sp", "dp"])
 def test_restart_record_round_trip_through_the_device(api, prec, tmp_path):
     """writefl.F90:110-118 / getspec: the device spectra written as one unformatted record (((FL(IJ,K,M),IJ),K),M) and read back into
     a second model reproduce the state bit for bit, and the restarted model takes the same next step; the file read with

@@ -16,7 +16,8 @@ for f in glob.glob("gpurun_out/traf_*/*/*counter_collection.csv"):
         n=r["Kernel_Name"]
         k="implsch" if "implsch" in n else ("propags2" if "propags2" in n else None)
         if not k: continue
-        agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[k].add(r["Dispatch_Id"])
+        agg[k][r["Counter_Name"]]+=float(r["Counter_Value"])
+        if "implsch4_pre" not in n and "implsch4_fin" not in n: cnt[k].add(r["Dispatch_Id"])   # one IMPLSCH call = three kernels
     for k in agg:
         for c,v in agg[k].items(): out[k][c]=v/len(cnt[k])
 print(json.dumps(out,indent=1))

@@ -219,6 +219,10 @@ class HipContext:
             pw = wam2nemo.data_ptr()
         self._chk(self.lib.ecwam_hip_implsch(self._h, kijs, kijl, *a, pw, pd, _stream_ptr()))
 
+    def implsch_reserve(self, npts: int) -> None:
+        """Size the per-point scalar rows of the IMPLSCH kernels once, outside the time loop: ecwam_hip_implsch_reserve."""
+        self._chk(self.lib.ecwam_hip_implsch_reserve(self._h, int(npts)))
+
     def set_implsch_generation(self, gen: int) -> None:
         """Cap the IMPLSCH kernel generation (2 or 4; 0 = automatic): include/ecwam_hip.h ecwam_hip_set_implsch_generation."""
         self._chk(self.lib.ecwam_hip_set_implsch_generation(self._h, int(gen)))

@@ -565,14 +565,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   const int ext = (c->p.llnormagam || c->p.llgcbz0) ? 1 : 0;
   if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !rare && !wam2nemo && !dbg &&
       (c->p.llnormagam ? c->v4_shelter == 0 : c->v4_shelter != 0)) {
-    const size_t need = (size_t)(kijl > 0 ? kijl : 0) * implsch4_fin_row() * c->real_bytes;
-    if (need > c->fin_bytes) {   // first call, or a longer block than any before: hipFree waits for the kernels still reading the old rows
-      if (c->fin) HIPCHK(hipFree(c->fin));
-      c->fin = nullptr; c->fin_bytes = 0;
-      HIPCHK(hipMalloc(&c->fin, need));
-      HIPCHK(hipMemset(c->fin, 0, need));
-      c->fin_bytes = need;
-    }
+    if (int rc2 = ecwam_hip_implsch_reserve(c, kijl)) return rc2;   // no-op once the buffer covers kijl
     DISPATCH(rc = launch_implsch4<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s),
              rc = launch_implsch4<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s));
     if (rc == 0) { HIPCHK(hipGetLastError()); return 0; }
@@ -581,6 +574,20 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
            rc = launch_implsch<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s));
   if (rc) return fail("ecwam_hip_implsch: unsupported spectral size for the LDS tiling");
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ecwam_hip_implsch_reserve(ecwam_hip_ctx* c, int npts) {
+  if (!c) return fail("ecwam_hip_implsch_reserve: null context");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t need = (size_t)(npts > 0 ? npts : 0) * implsch4_fin_row() * c->real_bytes;
+  if (need > c->fin_bytes) {   // hipFree waits for the kernels still reading the old rows
+    if (c->fin) HIPCHK(hipFree(c->fin));
+    c->fin = nullptr; c->fin_bytes = 0;
+    HIPCHK(hipMalloc(&c->fin, need));
+    HIPCHK(hipMemset(c->fin, 0, need));
+    c->fin_bytes = need;
+  }
   return 0;
 }
 

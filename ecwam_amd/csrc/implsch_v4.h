@@ -1094,6 +1094,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     fkmean_finish(s0, s1, s2, EMEAN, FMEAN, F1MEAN, AKMEAN, XKMEAN);
     femws_finish(we, wl, FMEANWS, EMEANWS);
   }
+  V4_PHASE_EXIT(208);
   {  // imphftail.F90: TEMP2(M) / TEMP1 = (XK2CG WAVNUM)(MIJ) / (XK2CG WAVNUM)(M)
     const T B1 = L.fac4[(MIJ - 1) * 4 + Q4_BSC];
     const V2<T> tf = *reinterpret_cast<const V2<T>*>(tF + (MIJ - 1) * RS);
@@ -1128,6 +1129,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     VSTOKES = m_min(m_max(VSTOKES, T(-1.5)), T(1.5));
   }
   WSYNC();
+  V4_PHASE_EXIT(209);
   // ---- store FL1 (16-byte chunks gathered from VEC rows of the tile), XLLWS(K,M) from the bit masks, per-point scalars
   {
     constexpr int NV = N / VEC, NIT = (NV + 63) / 64;
@@ -1151,6 +1153,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       if (r >= NC) { r -= NC; k += 1; }
     }
   }
+  V4_PHASE_EXIT(210);
   {   // every wind-input row parked in this block has been read by now
     T* x0 = xllws + (size_t)ij * N + (size_t)(2 * j) * NFRE;   // rows K = 2j and 2j+1 are contiguous
 #pragma unroll 1
@@ -1165,6 +1168,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       }
     }
   }
+  V4_PHASE_EXIT(211);
   if (j == 0) {
     T* fo = ffa + (size_t)ij * ECWAM_HIP_NFF;
     fo[7] = UFRIC; fo[10] = Z0M; fo[11] = Z0B; fo[12] = CHRNCK;   // TAUW, TAUWDIR: k_implsch4_fin

@@ -144,6 +144,7 @@ class Wamintgr:
         self.intf = torch.zeros((self.n, api.NINTF), **z)
         self.mij = torch.zeros(self.n, dtype=torch.int32, device=self.dev)
         self.xllws = torch.zeros((self.n, NANG, NFRE), **z)
+        self.ctx.implsch_reserve(self.n)        # no allocation inside the time loop
         self.cflfail = torch.zeros(self.n, dtype=torch.int32, device=self.dev)
         self.ifrelfmax = ifrelfmax
         self.delpro_lf = delpro_lf

@@ -261,6 +261,14 @@ int ecwam_hip_implsch(ecwam_hip_ctx *ctx, int kijs, int kijl, void *fl1, const v
  * checked against each other), gen = 0 restores the automatic choice.
  */
 int ecwam_hip_set_implsch_generation(ecwam_hip_ctx *ctx, int gen);
+/*
+ * k_implsch4 is bracketed by two one-point-per-lane kernels (first TAUT_Z0 before, second STRESSO and WNFLUXES after it) that exchange
+ * 24 scalars per sea point through a context-owned device buffer indexed by the point number.  ecwam_hip_implsch grows that buffer when
+ * kijl exceeds what it holds -- a device allocation and a device-wide wait inside an otherwise stream-ordered call.  A host that wants
+ * none of that in its time loop (or captures the step into a hipGraph) sizes it once: npts = the largest kijl it will pass.  Calls on
+ * several streams may share the buffer as long as their [kijs,kijl) do not overlap.
+ */
+int ecwam_hip_implsch_reserve(ecwam_hip_ctx *ctx, int npts);
 
 /*
  * Integrated output parameters without a spectrum copy-back (the device-side part of OUTBS: outblock.F90:204,223-243,

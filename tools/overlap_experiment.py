@@ -1,5 +1,5 @@
 """Diagnostics: WAMINTGR at O320 with the advection of block c+1 running beside the source terms of block c on a second stream.
-usage: python3 tools/overlap_experiment.py [nchunks ...]"""
+usage: python3 tools/overlap_experiment.py sp|dp [nchunks ...]"""
 import os
 import sys
 import time
@@ -14,7 +14,8 @@ from ecwam_amd.wamintgr import Wamintgr  # noqa: E402
 
 cfg = Config(nang=36, nfre=36, nfre_red=36, idelt=450, idelpro=450)
 g = G.build_grid(320)
-w = Wamintgr(cfg, g, "sp")
+prec = sys.argv[1] if len(sys.argv) > 1 else "sp"
+w = Wamintgr(cfg, g, prec)
 w.init_synthetic()
 w.build_weights()
 n = w.n
@@ -59,7 +60,7 @@ def timeit(f, *a, reps=10):
 
 
 print("serial ms", timeit(step_serial), flush=True)
-for nch in [int(a) for a in sys.argv[1:]] or [2, 4, 8, 16, 32]:
+for nch in [int(a) for a in sys.argv[2:]] or [2, 4, 8, 16, 32]:
     print("pipelined", nch, "ms", timeit(step_pipelined, nch), flush=True)
 print("serial ms", timeit(step_serial), flush=True)
 print("norm", w.swh_norm())

@@ -181,7 +181,7 @@ enum { Q4_BSC = 0, Q4_SBO, Q4_CINV, Q4_WAVNUM };   // Q4_BSC = WAVNUM XK2CG / 2 
 template <typename T, int NANG, int PP, int NGST, bool LLSNEG>
 __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UFRIC, T Z0M, T RAORW, T SIG_N, T TEMP2, T PTURB, T AIRD_PVISC,
                           T sinwd, T coswd, T* __restrict__ gfl, T* __restrict__ gsp, unsigned long long& xm0, unsigned long long& xm1, V2<T>& wse,
-                          V2<T>& wslast, V2<T>& apl, T (&rX)[V4_NFRE / (NANG / 2)], T (&rY)[V4_NFRE / (NANG / 2)]) {
+                          V2<T>& wslast, V2<T>& apl, T (&rX)[V4_NFRE / (NANG / 2)], T (&rY)[V4_NFRE / (NANG / 2)], T* __restrict__ sXY) {
   constexpr int G = NANG / 2, NFRE = V4_NFRE, RS = PP * NANG, NS = NFRE / G;
   const T CONST1 = tb.BETAMAXOXKAPPA2, ABS_TAUWSHELTER = m_abs(tb.TAUWSHELTER);
   const T FU = m_abs(tb.SWELLF3), FUD = tb.SWELLF2, ROGOROAIR = tb.G / RAORW;
@@ -282,7 +282,11 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
       }
       xrow = AVG * xrow; yrow = AVG * yrow;
     }
-    {  // the lane that owns frequency m keeps its row integrals
+    if constexpr (G == 18) {
+      // the row integrals into the (idle) staging rows: the symmetric rotations of the all-reduce leave the same bits on every lane of
+      // the point, so all of them store
+      *reinterpret_cast<V2<T>*>(sXY + 2 * m) = V2<T>{xrow, yrow};
+    } else {  // (sums of three rotated terms differ in the last bit between lanes) the lane that owns frequency m keeps its row integrals
       const int ms = m / G, mj = m - ms * G;
       const bool mine = (L.j == mj);
 #pragma unroll
@@ -316,7 +320,7 @@ template <typename T, int NANG, int PP, int NGST, bool LLSNEG>
 __device__ void v4_sinput_n(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, const T* __restrict__ xk2cg, T UFRIC, T Z0M, T RAORW, T RNFAC,
                             T SIG_N, T TEMP2, T PTURB, T AIRD_PVISC, V2<T> coswdif, V2<T> sinwdif2, T* __restrict__ gfl, T* __restrict__ gsp,
                             unsigned long long& xm0, unsigned long long& xm1, V2<T>& wse, V2<T>& wslast, V2<T>& apl,
-                            T (&rX)[V4_NFRE / (NANG / 2)], T (&rY)[V4_NFRE / (NANG / 2)]) {
+                            T (&rX)[V4_NFRE / (NANG / 2)], T (&rY)[V4_NFRE / (NANG / 2)], T* __restrict__ sXY) {
   constexpr int G = NANG / 2, NFRE = V4_NFRE, RS = PP * NANG, NS = NFRE / G;
   const T CONST1 = tb.BETAMAXOXKAPPA2;
   const T CSTRNFAC = (tb.DELTH / (tb.XKAPPA * tb.ZPI)) * RNFAC / RAORW;
@@ -395,7 +399,11 @@ __device__ void v4_sinput_n(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, co
       const V2<T> xs = v4_allsum<G, T>(V2<T>{sx.x + sx.y, sy.x + sy.y}, L.rot);
       xrow = xs.x; yrow = xs.y;
     }
-    {  // the lane that owns frequency m keeps its row integrals
+    if constexpr (G == 18) {
+      // the row integrals into the (idle) staging rows: the symmetric rotations of the all-reduce leave the same bits on every lane of
+      // the point, so all of them store
+      *reinterpret_cast<V2<T>*>(sXY + 2 * m) = V2<T>{xrow, yrow};
+    } else {  // (sums of three rotated terms differ in the last bit between lanes) the lane that owns frequency m keeps its row integrals
       const int ms = m / G, mj = m - ms * G;
       const bool mine = (L.j == mj);
 #pragma unroll
@@ -717,6 +725,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     return r;
   };
   T rX[NS], rY[NS];
+  T* sXY = sStg + p * NFRE * 2;   // 36 directions: [M][2] row integrals X, Y of the point (the staging rows are idle outside the sweep)
   T* gsp = fl1 + (size_t)ij * N + 2 * j;   // the point's FL1 block is dead until the final store: the second SINPUT parks its positive input there
   // stress sums below the cut-off and the F(:,MIJ) integrals of TAU_PHI_HF (stresso.F90:148-173, tau_phi_hf.F90:170-196)
   auto post_stress = [&](int MIJ, V2<T> apl, bool phiwa) {
@@ -727,7 +736,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       const int m = q * G + j;
       const T w = rrh(m, MIJ);
       const T wx = w * L.fac4[m * 4 + Q4_CINV];
-      s = s + V2<T>{wx * rX[q], wx * rY[q]};
+      if constexpr (G == 18) s = s + wx * *reinterpret_cast<const V2<T>*>(sXY + 2 * m);
+      else s = s + V2<T>{wx * rX[q], wx * rY[q]};
     }
     if (phiwa) {
 #pragma unroll 6
@@ -763,8 +773,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   V2<T> wse, wslast, apl;
   T FMEANWS, EMW;
   if (norma) v4_sinput_n<T, NANG, PP, 1, false>(tb, L, wp + 3 * NFRE, UFRIC, Z0M, RAORW, RNFAC, T(0), T(0), T(0), T(0), coswdif, sinwdif2, nullptr, nullptr,
-                                               xm0, xm1, wse, wslast, apl, rX, rY);
-  else v4_sinput<T, NANG, PP, 1, false>(tb, L, UFRIC, Z0M, RAORW, T(0), T(0), T(0), T(0), sinwd, coswd, nullptr, nullptr, xm0, xm1, wse, wslast, apl, rX, rY);
+                                               xm0, xm1, wse, wslast, apl, rX, rY, sXY);
+  else v4_sinput<T, NANG, PP, 1, false>(tb, L, UFRIC, Z0M, RAORW, T(0), T(0), T(0), T(0), sinwd, coswd, nullptr, nullptr, xm0, xm1, wse, wslast, apl, rX, rY, sXY);
   femws_finish(wse, wslast, FMEANWS, EMW);
   int MIJ = frcutindex4(FMEANWS, UFRIC);
   post_stress(MIJ, apl, false);
@@ -792,9 +802,9 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   // ---- second SINFLX call: wind-input coefficient (parked in the point's XLLWS block, [M][K]), XLLWS, MIJ, wave stress, PHIWA
   T* gx = xllws + (size_t)ij * N + 2 * j;   // this lane's pair in row 0 of the block
   if (norma) v4_sinput_n<T, NANG, PP, 2, true>(tb, L, wp + 3 * NFRE, UFRIC, Z0M, RAORW, RNFAC, c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], coswdif,
-                                              sinwdif2, gx, gsp, xm0, xm1, wse, wslast, apl, rX, rY);
+                                              sinwdif2, gx, gsp, xm0, xm1, wse, wslast, apl, rX, rY, sXY);
   else v4_sinput<T, NANG, PP, 2, true>(tb, L, UFRIC, Z0M, RAORW, c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], sinwd, coswd, gx, gsp, xm0, xm1, wse,
-                                       wslast, apl, rX, rY);
+                                       wslast, apl, rX, rY, sXY);
   femws_finish(wse, wslast, FMEANWS, EMW);
   MIJ = frcutindex4(FMEANWS, UFRIC);
   post_stress(MIJ, apl, true);

@@ -1,4 +1,5 @@
 // C ABI of libecwam_hip.so (include/ecwam_hip.h): context management and kernel launch entry points.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -186,8 +187,18 @@ static int build_tab(const ecwam_hip_params* p, const ecwam_hip_tables* t, DevTa
     for (int j = 0; j < 8; j++) { d->DIACF[i][12 + j] = d->RNLCOEF[i][5 + j]; d->DIACF[i][20 + j] = d->RNLCOEF[i][17 + j]; }
     const int MC = i + 1;
     auto cl = [&](int r) { return (r < 1 ? 1 : (r > NFRE ? NFRE : r)) - 1; };
+    d->DIACF[i][10] = d->ZPIFR[cl(MC - 3)];
+    const int mu = cl(MC - 5);
+    d->DIACF[i][28] = d->COFRM4[mu]; d->DIACF[i][29] = d->FLMAX[mu]; d->DIACF[i][30] = d->RHOWG_DFIM[mu]; d->DIACF[i][11] = d->ZPIFR[mu];
     const int want[5] = {cl(MC), cl(MC + 2), cl(MC + 3), cl(MC - 4), cl(MC - 3)};
     for (int j = 0; j < 5; j++) if (d->INLCOEF[i][j] != want[j]) d->V4_ROWS = 0;
+  }
+  for (int m = 0; m < NFRE; m++) {
+    T* r = d->SINROW[m];
+    r[0] = d->ZPIFR[m]; r[1] = d->DFIM[m];
+    r[2] = -d->SWELLF5 * T(2) * std::sqrt(T(2) * d->RNU * d->ZPIFR[m]);
+    r[3] = -d->SWELLF * T(16) * (d->ZPIFR[m] * d->ZPIFR[m]) / d->G;
+    r[4] = d->RHOWG_DFIM[m]; r[5] = d->DFIMOFR[m]; r[6] = T(0); r[7] = T(0);
   }
   const int ntap = 2 * p->nsdsnth + 1;
   for (int k = 0; k < NANG; k++)

@@ -170,7 +170,7 @@ struct V4Ctx {
   V4Rot<T> rot;
   V2<T> sinth, costh;
   // module tables per frequency, lane m holds M = m+1: broadcast with v_readlane inside the M loops
-  T rDFIM, rDFIMOFR, rDFIMFR, rZPIFR, rRHOWG, rCOFRM4, rFLMAX, rC5, rT1;   // rC5 = -SWELLF5 2 SQRT(2 NU_AIR SIG), rT1 = -SWELLF 16 SIG**2 / G (sinput_ard.F90:343-347)
+  T rDFIM, rDFIMOFR, rDFIMFR, rZPIFR, rRHOWG, rCOFRM4, rFLMAX;
 };
 enum { Q4_BSC = 0, Q4_SBO, Q4_CINV, Q4_WAVNUM };   // Q4_BSC = WAVNUM XK2CG / 2 pi
 
@@ -214,11 +214,12 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
       cw_n = *reinterpret_cast<const V2<T>*>(L.fac4 + mn * 4 + Q4_CINV);
       zcn_n = L.zcn[mn];
     }
-    const T SIGm = lane_get(L.rZPIFR, m);
-    const T CONSTF = ROGOROAIR * cinv_m * lane_get(L.rDFIM, m);
-    const T DSTAB1 = LLSNEG ? (lane_get(L.rC5, m) * AIRD_PVISC) * cw.y : T(0);
+    const T* row = tb.SINROW[m];   // one scalar load: ZPIFR, DFIM, C5, T1, RHOWG_DFIM, DFIMOFR of the row
+    const T SIGm = row[0], DFIMm = row[1];
+    const T CONSTF = ROGOROAIR * cinv_m * DFIMm;
+    const T DSTAB1 = LLSNEG ? (row[2] * AIRD_PVISC) * cw.y : T(0);
     const T CNSN = (SIGm * CONST1) * RAORW;
-    const T TEMP1 = LLSNEG ? lane_get(L.rT1, m) * RAORW : T(0);
+    const T TEMP1 = LLSNEG ? row[3] * RAORW : T(0);
     V2<T> SLP[2], FLP[2];
     bool xl0 = false, xl1 = false;
     const V2<T> vTPX = vTAUX - ABS_TAUWSHELTER * vXS, vTPY = vTAUY - ABS_TAUWSHELTER * vYS;
@@ -297,7 +298,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
       }
     }
     if (LLSNEG) {
-      apl = apl + (fl * f - sp) * lane_get(L.rRHOWG, m);
+      apl = apl + (fl * f - sp) * row[4];
       *reinterpret_cast<V2<T>*>(gfl + (size_t)m * NANG) = fl;
       // the lane's share of the row's positive input: summed below the cut-off once MIJ is known (stresso.F90:160-168), no all-reduce
       // here; two rows per 8-byte store so that the point's lanes write whole, contiguous lines
@@ -307,7 +308,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
     if (xl0) xm0 |= (1ull << m);
     if (xl1) xm1 |= (1ull << m);
     const V2<T> x = {xl0 ? f.x : T(0), xl1 ? f.y : T(0)};
-    wse = wse + V2<T>{lane_get(L.rDFIM, m), lane_get(L.rDFIMOFR, m)} * (x.x + x.y);
+    wse = wse + V2<T>{DFIMm, row[5]} * (x.x + x.y);
     wslast = x;
   }
   WSYNC();
@@ -352,10 +353,11 @@ __device__ void v4_sinput_n(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, co
     const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
     const V2<T> cw = *reinterpret_cast<const V2<T>*>(L.fac4 + m * 4 + Q4_CINV);
     const T ZCN = L.zcn[m], cinv_m = cw.x, XNGAMCONST = xng[m];
-    const T SIGm = lane_get(L.rZPIFR, m);
-    const T DSTAB1 = LLSNEG ? (lane_get(L.rC5, m) * AIRD_PVISC) * cw.y : T(0);
+    const T* row = tb.SINROW[m];   // one scalar load: ZPIFR, DFIM, C5, T1, RHOWG_DFIM, DFIMOFR of the row
+    const T SIGm = row[0], DFIMm = row[1];
+    const T DSTAB1 = LLSNEG ? (row[2] * AIRD_PVISC) * cw.y : T(0);
     const T CNSN = (SIGm * CONST1) * RAORW;
-    const T TEMP1 = LLSNEG ? lane_get(L.rT1, m) * RAORW : T(0);
+    const T TEMP1 = LLSNEG ? row[3] * RAORW : T(0);
     V2<T> SLP[2], FLP[2];
     bool xl0 = false, xl1 = false;
 #pragma unroll
@@ -414,7 +416,7 @@ __device__ void v4_sinput_n(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, co
       }
     }
     if (LLSNEG) {
-      apl = apl + (fl * f - sp) * lane_get(L.rRHOWG, m);
+      apl = apl + (fl * f - sp) * row[4];
       *reinterpret_cast<V2<T>*>(gfl + (size_t)m * NANG) = fl;
       if (m & 1) *reinterpret_cast<V2<T>*>(gsp + (size_t)(m >> 1) * NANG) = V2<T>{sp_even, sp.x + sp.y};
       else sp_even = sp.x + sp.y;
@@ -422,7 +424,7 @@ __device__ void v4_sinput_n(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, co
     if (xl0) xm0 |= (1ull << m);
     if (xl1) xm1 |= (1ull << m);
     const V2<T> x = {xl0 ? f.x : T(0), xl1 ? f.y : T(0)};
-    wse = wse + V2<T>{lane_get(L.rDFIM, m), lane_get(L.rDFIMOFR, m)} * (x.x + x.y);
+    wse = wse + V2<T>{DFIMm, row[5]} * (x.x + x.y);
     wslast = x;
   }
   WSYNC();
@@ -507,8 +509,6 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     const int mi = lane < NFRE ? lane : 0;
     L.rDFIM = tb.DFIM[mi]; L.rDFIMOFR = tb.DFIMOFR[mi]; L.rDFIMFR = tb.DFIMFR[mi]; L.rZPIFR = tb.ZPIFR[mi]; L.rRHOWG = tb.RHOWG_DFIM[mi];
     L.rCOFRM4 = tb.COFRM4[mi]; L.rFLMAX = tb.FLMAX[mi];
-    L.rC5 = -tb.SWELLF5 * T(2) * m_sqrt(T(2) * tb.RNU * tb.ZPIFR[mi]);
-    L.rT1 = -tb.SWELLF * T(16) * (tb.ZPIFR[mi] * tb.ZPIFR[mi]) / tb.G;
   }
   L.sinth = V2<T>{tb.SINTH[2 * j], tb.SINTH[2 * j + 1]};
   L.costh = V2<T>{tb.COSTH[2 * j], tb.COSTH[2 * j + 1]};
@@ -882,11 +882,10 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     V2<T> u_f = z2, u_D = z2;
     T u_sbo = T(0), u_cinv = T(0), u_wn = T(0);
     // new spectrum, limiter and fluxes of row m (implsch.F90:300-392) from the finished ring slot and the parked wind input
-    auto update_row = [&](int m, V2<T>& accS, V2<T>& accF, V2<T>& wslot) {
+    auto update_row = [&](int m, V2<T>& accS, V2<T>& accF, V2<T>& wslot, T cofr, T flmax, T rhowg, T sig) {
       const V2<T> f = u_f;
-      const T cofr = lane_get(L.rCOFRM4, m), flmax = lane_get(L.rFLMAX, m), rhowg = lane_get(L.rRHOWG, m);
       V2<T> D = u_D;
-      if (turb) D = D - (lane_get(L.rZPIFR, m) * u_wn * FACTURB) * coswdif;
+      if (turb) D = D - (sig * u_wn * FACTURB) * coswdif;
       const V2<T> fldw = D + wslot;
       V2<T> sl = fldw * f + accS;
       V2<T> fld = fldw + accF;
@@ -946,7 +945,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         const bool mid = (MC > MFR1STFR && MC < MFRLSTFR);
         const T FTAIL = mid ? T(1) : cg[0];   // x 1 is exact: no select on the vector side
         // ---- meanwhile: the row the previous interaction completed
-        if (m - 1 >= 0 && m - 1 < NFRE) update_row(m - 1, aS[(jj + 4) & 7], aF[(jj + 4) & 7], wiq[(jj + 3) & 3]);
+        if (m - 1 >= 0 && m - 1 < NFRE) update_row(m - 1, aS[(jj + 4) & 7], aF[(jj + 4) & 7], wiq[(jj + 3) & 3], cg[28], cg[29], cg[30], cg[11]);
         // the dissipation coefficient of row m (sdissip_ard.F90:117-314) from the saturation spectrum and the maximum the previous
         // interaction left in flight
         {
@@ -1055,12 +1054,13 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         // ---- row MC-3 (the saturation row of the next interaction) -> its staging row; row MC+3 enters the ring in the slot of row MC-5
         *reinterpret_cast<V2<T>*>(st4 + L.own) = fR[(jj + 6) & 7];
         fR[(jj + 4) & 7] = *reinterpret_cast<const V2<T>*>(tF + hi35(MC + 3) * RS);
-        bs_p = bsat; bm_p = bm1; e3_p = e3; e4_p = e4; sig_p = lane_get(L.rZPIFR, hi35(lo0(m + 1)));
+        bs_p = bsat; bm_p = bm1; e3_p = e3; e4_p = e4; sig_p = cg[10];
         V4SYNC();
       }
     }
     // the row the last interaction completed (MCb is a multiple of 8 here: static ring slots)
-    if (MCb - 5 >= 0 && MCb - 5 < NFRE) update_row(MCb - 5, aS[4], aF[4], wiq[3]);
+    if (MCb - 5 >= 0 && MCb - 5 < NFRE)
+      update_row(MCb - 5, aS[4], aF[4], wiq[3], lane_get(L.rCOFRM4, MCb - 5), lane_get(L.rFLMAX, MCb - 5), lane_get(L.rRHOWG, MCb - 5), lane_get(L.rZPIFR, MCb - 5));
   }
   V4SYNC();
   V4_PHASE_EXIT(207);

@@ -223,6 +223,10 @@ class HipContext:
         """Size the per-point scalar rows of the IMPLSCH kernels once, outside the time loop: ecwam_hip_implsch_reserve."""
         self._chk(self.lib.ecwam_hip_implsch_reserve(self._h, int(npts)))
 
+    def implsch_generation_used(self) -> int:
+        """Kernel generation the last implsch() call launched (2 or 4)."""
+        return int(self.lib.ecwam_hip_implsch_generation_used(self._h))
+
     def set_implsch_generation(self, gen: int) -> None:
         """Cap the IMPLSCH kernel generation (2 or 4; 0 = automatic): include/ecwam_hip.h ecwam_hip_set_implsch_generation."""
         self._chk(self.lib.ecwam_hip_set_implsch_generation(self._h, int(gen)))

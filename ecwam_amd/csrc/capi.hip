@@ -31,6 +31,7 @@ struct ecwam_hip_ctx {
   // fourth kernel generation (implsch_v4.h): DIA rotations K1 = K -+ r1, K2 = K +- r2, NSDSNTH = nh; ok = the tables have that structure
   int v4_ok = 0, v4_r1 = 0, v4_r2 = 0, v4_nh = 0, v4_shelter = 0;
   int implsch_gen = 0;  // 0: the fastest kernel generation that covers the configuration; 2 / 4: at most that generation (tests)
+  int implsch_last = 0; // generation the last ecwam_hip_implsch call launched (2 / 4)
   void* fin = nullptr;  // rows of scalars k_implsch4 hands to its finishing kernel, indexed by the point number; grown on demand
   size_t fin_bytes = 0;
   // advection halo exchange (MPEXCHNG): peers, the owned rows each of them needs (concatenated in peer order) and where their rows
@@ -571,16 +572,20 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   const bool rare = c->p.lciwa1 || c->p.lciwa2 || c->p.lciwa3 || c->p.lciscal || c->p.lwnemocou || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin ||
                     c->p.iphys == 0 || c->p.icode != 3 || !c->p.lwvflx_snl;
   if (c->p.llgcbz0 || rare) variant |= 32;
-  // fourth kernel generation (implsch_v4.h): flag sets A and B (LLGCBZ0, LLNORMAGAM) without the other optional branches, single and
-  // double precision.  The sheltered growth needs TAUWSHELTER /= 0, the normalised one TAUWSHELTER = 0 (setwavphys.F90:150-190).
+  // fourth kernel generation (implsch_v4.h): flag sets A and B (LLGCBZ0, LLNORMAGAM), with or without the sea-ice damping rates that
+  // depend on the frequency only (LCIWA1, LCIWA3, LCISCAL), without the other optional branches, single and double precision.  The
+  // sheltered growth needs TAUWSHELTER /= 0, the normalised one TAUWSHELTER = 0 (setwavphys.F90:150-190).
   const int ext = (c->p.llnormagam || c->p.llgcbz0) ? 1 : 0;
-  if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !rare && !wam2nemo && !dbg &&
+  const bool rare4 = c->p.lciwa2 || c->p.lwnemocouibr || c->p.lwnemocou || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin || c->p.iphys == 0 || c->p.icode != 3 ||
+                     !c->p.lwvflx_snl;
+  if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !rare4 && !wam2nemo && !dbg &&
       (c->p.llnormagam ? c->v4_shelter == 0 : c->v4_shelter != 0)) {
     if (int rc2 = ecwam_hip_implsch_reserve(c, kijl)) return rc2;   // no-op once the buffer covers kijl
     DISPATCH(rc = launch_implsch4<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s),
              rc = launch_implsch4<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s));
-    if (rc == 0) { HIPCHK(hipGetLastError()); return 0; }
+    if (rc == 0) { HIPCHK(hipGetLastError()); c->implsch_last = 4; return 0; }
   }
+  c->implsch_last = 2;
   DISPATCH(rc = launch_implsch<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s),
            rc = launch_implsch<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s));
   if (rc) return fail("ecwam_hip_implsch: unsupported spectral size for the LDS tiling");
@@ -601,6 +606,8 @@ int ecwam_hip_implsch_reserve(ecwam_hip_ctx* c, int npts) {
   }
   return 0;
 }
+
+int ecwam_hip_implsch_generation_used(ecwam_hip_ctx* c) { return c ? c->implsch_last : 0; }
 
 int ecwam_hip_set_implsch_generation(ecwam_hip_ctx* c, int gen) {
   if (!c) return fail("null context");

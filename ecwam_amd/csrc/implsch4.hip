@@ -1,6 +1,6 @@
 // Launcher of the fourth IMPLSCH kernel generation (implsch_v4.h): PP sea points per wavefront on adjacent direction pairs, every
 // rotation in K through LDS rows.  implsch.F90:10-468 on flag set A (LLGCBZ0 = F, LLNORMAGAM = F) and, in the EXT build of the
-// kernel, flag set B (either or both of them T: cy49r1 / cy50r1); no sea-ice attenuation, no NEMO coupling, IPHYS = 1, ISNONLIN = 0,
+// kernel, flag set B (either or both of them T: cy49r1 / cy50r1); sea-ice damping LCIWA1 / LCIWA3 / LCISCAL, no LCIWA2, no NEMO coupling, IPHYS = 1, ISNONLIN = 0,
 // ICODE = 3, NFRE = 36, NANG = 36 / 24 / 12, single and double precision.  Everything else runs k_implsch2 (implsch.hip).
 #include "implsch_common.h"
 #include "implsch_v2.h"

@@ -565,12 +565,68 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   const T* wp = wvprpt + (size_t)ij * ECWAM_HIP_NWPR * NFRE;
   {
     const T DEPTHv = ffa[(size_t)ij * ECWAM_HIP_NFF + 15];
+    // sea-ice attenuation (implsch.F90:312-339): SDICE1 (scattering, sdice1.F90:104-181) and SDICE3 (viscous friction, sdice3.F90:110-160)
+    // are, like SBOTTOM, a damping rate per (point, frequency): FLD += c, SL += c F.  The three rates share one slot of the table (the
+    // reference adds them one after the other: the sums differ in rounding only).  SDICE2 depends on F itself and the NEMO coupling
+    // needs SLICE on its own: k_implsch2.
+    const bool ice1 = tb.LICERUN && tb.LCIWA1, ice3 = tb.LICERUN && tb.LCIWA3;
+    T CICOVERv = T(0), CITHICKv = T(0), DINV = T(0);
+    if (ice1 || ice3) {
+      CICOVERv = ffa[(size_t)ij * ECWAM_HIP_NFF + 2];
+      CITHICKv = ffa[(size_t)ij * ECWAM_HIP_NFF + 13];
+    }
+    if (ice1) {   // mean floe diameter of the fragmentation cascade
+      const T CIFRGL = T(0.955), CIDMIN = T(20.0), CIFRGMT = T(2.0), A = T(200.0), C = T(300.0);
+      const int MAXICM = (int)(m_log(A / CIDMIN) / m_log(CIFRGMT));
+      DINV = CIDMIN;
+      if (CITHICKv > T(0)) {
+        const T CIDMAX = A + C * CICOVERv;
+        int ICM = (int)(m_log(CIDMAX / CIDMIN) / m_log(CIFRGMT));
+        if (ICM > MAXICM) ICM = MAXICM;
+        T SN = T(0), SD = T(0), X = T(1), FI = T(1);
+        for (int I = 0; I <= ICM; I++) {   // X = (CIFRGMT**2*CIFRGL)**I, FI = CIFRGMT**I
+          SN = SN + X * CIDMAX / FI;
+          SD = SD + X;
+          X = X * (CIFRGMT * CIFRGMT * CIFRGL);
+          FI = FI * CIFRGMT;
+        }
+        DINV = T(1) / (SN / SD);
+      }
+    }
     for (int m = j; m < NFRE; m += G) {
       T* f = L.fac4 + m * 4;
       const T WAVNUM = wp[m], XK2CG = wp[3 * NFRE + m];
       f[Q4_WAVNUM] = WAVNUM; f[Q4_CINV] = wp[2 * NFRE + m]; f[Q4_BSC] = WAVNUM * (T(1) / tb.ZPI) * XK2CG; L.sq[m] = m_sqrt(WAVNUM);
       T sbo = T(0);   // sbottom.F90:79-89
       if (m < tb.NFRE_RED && DEPTHv < tb.BATHYMAX) sbo = (-T(2) * T(0.038) * tb.GM1) * WAVNUM / m_sinh(m_min(T(2) * DEPTHv * WAVNUM, T(50)));
+      if (ice1 || ice3) {
+        const T CGROUP = wp[NFRE + m];
+        T dmp = T(0);
+        if (ice1 && CITHICKv > T(0)) {   // CIDEAC(period, thickness), bilinear (sdice1.F90:135-163)
+          const int NICT = tb.NICT, NICH = tb.NICH;
+          const T TW = T(1) / tb.FR[m];
+          int IT = (int)m_floor((TW - tb.TICMIN) / tb.DTIC + T(1));
+          IT = IT < 1 ? 1 : (IT > NICT ? NICT : IT);
+          const int IT1 = IT + 1 > NICT ? NICT : IT + 1;
+          const T WT1 = m_max(m_min(T(1), (TW - (tb.TICMIN + T(IT - 1) * tb.DTIC)) / tb.DTIC), T(0));
+          const T WT = T(1) - WT1;
+          int IH = (int)m_floor((CITHICKv - tb.HICMIN) / tb.DHIC + T(1));
+          IH = IH < 1 ? 1 : (IH > NICH ? NICH : IH);
+          const int IH1 = IH + 1 > NICH ? NICH : IH + 1;
+          const T WH1 = m_max(m_min(T(1), (CITHICKv - (tb.HICMIN + T(IH - 1) * tb.DHIC)) / tb.DHIC), T(0));
+          const T WH = T(1) - WH1;
+          const T* cd = tb.CIDEAC;
+          const T CI = WT * (WH * cd[(IH - 1) * NICT + IT - 1] + WH1 * cd[(IH1 - 1) * NICT + IT - 1]) +
+                       WT1 * (WH * cd[(IH - 1) * NICT + IT1 - 1] + WH1 * cd[(IH1 - 1) * NICT + IT1 - 1]);
+          dmp = CICOVERv * (-(m_exp(CI) * DINV * tb.ZALPFACB) * CGROUP);
+        }
+        if (ice3) {
+          const T CDICE = T(0.1274) * m_pow(tb.ZPI / m_sqrt(tb.G), T(4.5));
+          const T ALP = (T(2) * CDICE * m_pow(CITHICKv, T(1.25)) * m_pow(tb.FR[m], T(4.5))) * tb.ZALPFACX;
+          dmp = dmp + (-CICOVERv * ALP * CGROUP);
+        }
+        sbo = dmp + sbo;
+      }
       f[Q4_SBO] = sbo;
     }
   }
@@ -841,6 +897,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     const bool shallow_brk = tb.LBIWBK && (DEPTH < T(50));
     const T USFM = UFRIC * m_max(FMEANWS, FMEAN);
     const bool flux_snl = tb.LCFLX && tb.LWVFLX_SNL;
+    const T BETA = (tb.LICERUN && tb.LCISCAL) ? T(1) - CICOVER : T(1);
     const int NRED = tb.NFRE_RED, MLST = tb.MLSTHG;
     T* st0 = sStg;            // staging rows: up / AD(kh=1), vp / DELAM(1), um / DELAP(1), vm / AD(2), row MC-4 / DELAM(2), DELAP(2)
     T* st1 = sStg + RS;
@@ -895,7 +952,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         ss = V2<T>{f_div(sl.x, den.x), f_div(sl.y, den.y)};
       }
       if (shallow_brk && m < NRED) { sl = sl - SDS * f; fld = fld - SDS; }
-      if (m < NRED) { sl = sl + u_sbo * f; fld = fld + u_sbo; }
+      sl = BETA * sl; fld = BETA * fld;                     // LCISCAL (implsch.F90:316-321); BETA = 1 without it: exact
+      sl = sl + u_sbo * f; fld = fld + u_sbo;               // SBOTTOM (zero at M > NFRE_RED) + SDICE1 + SDICE3: the table slot
       const T lim = USFM * (cofr * DELT);
       V2<T> fn;
       {
@@ -1243,9 +1301,14 @@ __global__ void __launch_bounds__(64) k_implsch4_fin(const DevTab<T>* __restrict
   fo[8] = c[C_TAUW]; fo[9] = c[C_TAUWDIR];
   if (tb.LCFLX) {
     const T EPSUS3 = tb.EPSUS * m_sqrt(tb.EPSUS);
+    // with an explicit ice attenuation term the blending with the ice-covered fluxes starts at CICOVER = 0 (wnfluxes.F90:206-214)
+    const bool sdice_on = tb.LCIWA1 || tb.LCIWA2 || tb.LCIWA3;
+    const T ZCITHRS = sdice_on ? T(0) : tb.CIBLOCK;
+    const T CITHRSH_INV = sdice_on ? T(50) : T(1) / m_max(tb.CITHRSH, T(0.01));
+    const T ZMAXEXP = sdice_on ? T(20) : T(10);
     T OOVAL = T(1), USTAR = UFRIC;
-    if (tb.LICERUN && tb.LWAMRSETCI && CICOVER > tb.CIBLOCK) {
-      OOVAL = m_exp(-m_min(m_pow4(CICOVER * (T(1) / m_max(tb.CITHRSH, T(0.01)))), T(10)));
+    if (tb.LICERUN && tb.LWAMRSETCI && CICOVER > ZCITHRS) {
+      OOVAL = m_exp(-m_min(m_pow4(CICOVER * CITHRSH_INV), ZMAXEXP));
       const T U10P = m_max(WSWAVE, tb.EPSU10);
       const T CD_BULK = m_min((T(1.03E-3) + T(0.04E-3) * m_pow(U10P, T(1.48))) * m_pow(U10P, T(-0.21)), T(0.003));
       const T CD_WAVE = (UFRIC / U10P) * (UFRIC / U10P);

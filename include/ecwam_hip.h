@@ -261,6 +261,9 @@ int ecwam_hip_implsch(ecwam_hip_ctx *ctx, int kijs, int kijl, void *fl1, const v
  * checked against each other), gen = 0 restores the automatic choice.
  */
 int ecwam_hip_set_implsch_generation(ecwam_hip_ctx *ctx, int gen);
+/* The generation the last ecwam_hip_implsch call of this context launched (2 or 4; 0 before the first call): lets a test assert that a
+ * configuration runs on the kernel it is meant to run on. */
+int ecwam_hip_implsch_generation_used(ecwam_hip_ctx *ctx);
 /*
  * k_implsch4 is bracketed by two one-point-per-lane kernels (first TAUT_Z0 before, second STRESSO and WNFLUXES after it) that exchange
  * 24 scalars per sea point through a context-owned device buffer indexed by the point number.  ecwam_hip_implsch grows that buffer when

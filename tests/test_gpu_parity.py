@@ -168,6 +168,30 @@ def test_implsch_parity_sea_ice_attenuation(api, prec, flags):
     assert np.max(np.abs(ref0["FL1"] - ref["FL1"])) > 0
 
 
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+@pytest.mark.parametrize("nang,nred", [(36, 36), (24, 29), (12, 25)])
+@pytest.mark.parametrize("flags", [dict(lciwa1=True), dict(lciwa1=True, lciwa3=True, lciscal=True)])
+def test_implsch_sea_ice_damping_on_the_fast_kernel(api, prec, nang, nred, flags):
+    """SDICE1 (the code default LCIWA1 = T, mpuserin.F90:772) / SDICE3 / LCISCAL are damping rates per (point, frequency): k_implsch4
+    carries them in the table slot of the bottom friction.  Against the oracle, against k_implsch2, and the call must really have
+    launched the fourth generation."""
+    cfg = Config(nang=nang, nfre=36, nfre_red=nred, **flags)
+    case = _ice_case(cfg, prec, n=1025)
+    ref = H.oracle_implsch(case, _oracle(cfg, prec))
+    ctx = api.HipContext(case["tables"])
+    got = H.gpu_implsch(case, ctx)
+    assert ctx.implsch_generation_used() == 4
+    ctx.set_implsch_generation(2)
+    old = H.gpu_implsch(case, ctx)
+    assert ctx.implsch_generation_used() == 2
+    ctx.close()
+    assert np.isfinite(got["FL1"]).all() and np.isfinite(got["INTF"]).all()
+    _assert_implsch_stats(H.compare_implsch(ref, got, case["tables"]), case["n"], prec)
+    assert np.array_equal(old["MIJ"], got["MIJ"]) and np.array_equal(old["XLLWS"], got["XLLWS"])
+    peak = np.abs(old["FL1"]).max(axis=(1, 2), keepdims=True).astype(float)
+    assert np.max(np.abs(old["FL1"].astype(float) - got["FL1"].astype(float)) / peak) < (2e-5 if prec == "sp" else 1e-12)
+
+
 def _ice_case(cfg, prec, n=1024, seed=21):
     case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=seed)
     rng = np.random.default_rng(5)

@@ -41,7 +41,7 @@ using V2 = T __attribute__((ext_vector_type(2)));
 
 // the row of scalars per sea point that k_implsch4_pre hands to k_implsch4 and k_implsch4 to k_implsch4_fin
 enum { FIN_AIRD = 0, FIN_UFRIC, FIN_Z0M, FIN_MIJ, FIN_XS, FIN_YS, FIN_F1DCOS3, FIN_F1DCOS2, FIN_F1DSIN2, FIN_F1D, FIN_RNFAC, FIN_PHIWA,
-       FIN_SINWD, FIN_COSWD, FIN_WSWAVE, FIN_CICOVER, FIN_PHILF, FIN_XSTRESS, FIN_YSTRESS, FIN_Z0B, FIN_CHRNCK, FIN_COSDIFF, V4_NFIN = 24 };
+       FIN_SINWD, FIN_COSWD, FIN_WSWAVE, FIN_CICOVER, FIN_PHILF, FIN_XSTRESS, FIN_YSTRESS, FIN_Z0B, FIN_CHRNCK, FIN_COSDIFF, FIN_EMEAN, FIN_F1MEAN, V4_NFIN = 24 };
 
 __device__ __forceinline__ float v4_bp(int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); }
 __device__ __forceinline__ double v4_bp(int addr, double v) {
@@ -1248,6 +1248,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     fr[FIN_F1DSIN2] = c[C_F1DSIN2]; fr[FIN_F1D] = c[C_F1D]; fr[FIN_RNFAC] = c[C_RNFAC]; fr[FIN_PHIWA] = c[C_PHIWA];
     fr[FIN_SINWD] = sinwd; fr[FIN_COSWD] = coswd; fr[FIN_WSWAVE] = WSWAVE; fr[FIN_CICOVER] = CICOVER;
     fr[FIN_PHILF] = PHILF; fr[FIN_XSTRESS] = XSTRESS; fr[FIN_YSTRESS] = YSTRESS;
+    fr[FIN_EMEAN] = c[C_EMEAN]; fr[FIN_F1MEAN] = c[C_F1MEAN];   // of the spectrum before the update (implsch.F90:396-414)
     if (tb.LWFLUX) {
       io[0] = (EMEANWS < tb.WSEMEAN_MIN) ? tb.WSEMEAN_MIN : EMEANWS;
       io[1] = (EMEANWS < tb.WSEMEAN_MIN) ? T(2) * tb.FR[NFRE - 1] : FMEANWS;
@@ -1282,7 +1283,7 @@ __global__ void __launch_bounds__(64) k_implsch4_pre(const DevTab<T>* __restrict
 // in fin(:, IJ).  On k_implsch4's waves these two dependent chains kept PP lanes busy; here every lane has a point.
 template <typename T, bool EXT>
 __global__ void __launch_bounds__(64) k_implsch4_fin(const DevTab<T>* __restrict__ tp, int kijs, int kijl, const T* __restrict__ fin,
-                                                     T* __restrict__ ffa, T* __restrict__ intfa) {
+                                                     T* __restrict__ ffa, T* __restrict__ intfa, double* __restrict__ w2n) {
   const DevTab<T>& tb = *tp;
   const int ij = kijs + blockIdx.x * 64 + threadIdx.x;
   if (ij >= kijl) return;
@@ -1307,6 +1308,7 @@ __global__ void __launch_bounds__(64) k_implsch4_fin(const DevTab<T>* __restrict
     const T CITHRSH_INV = sdice_on ? T(50) : T(1) / m_max(tb.CITHRSH, T(0.01));
     const T ZMAXEXP = sdice_on ? T(20) : T(10);
     T OOVAL = T(1), USTAR = UFRIC;
+    T EM_OC = fr[FIN_EMEAN], F1_OC = fr[FIN_F1MEAN];
     if (tb.LICERUN && tb.LWAMRSETCI && CICOVER > ZCITHRS) {
       OOVAL = m_exp(-m_min(m_pow4(CICOVER * CITHRSH_INV), ZMAXEXP));
       const T U10P = m_max(WSWAVE, tb.EPSU10);
@@ -1314,6 +1316,15 @@ __global__ void __launch_bounds__(64) k_implsch4_fin(const DevTab<T>* __restrict
       const T CD_WAVE = (UFRIC / U10P) * (UFRIC / U10P);
       const T CD_ICE = OOVAL * CD_WAVE + (T(1) - OOVAL) * CD_BULK;
       USTAR = m_max(m_sqrt(CD_ICE) * U10P, tb.EPSUS);
+      if (tb.LWNEMOCOU) {  // fully developed sea under ice for the NEMO wave height / period (wnfluxes.F90:236-246)
+        const T EFD_FAC = T(4) * tb.EGRCRV / (tb.G * tb.G);
+        const T FFD_FAC = m_pow(tb.EGRCRV / tb.AFCRV, T(1) / tb.BFCRV) * tb.G;
+        const T EFD = m_min(EFD_FAC * m_pow4(USTAR), T(6.25));
+        EM_OC = m_max(OOVAL * EM_OC + (T(1) - OOVAL) * EFD, T(0.0625));
+        const T FFD = FFD_FAC / USTAR;
+        F1_OC = OOVAL * F1_OC + (T(1) - OOVAL) * FFD;
+        F1_OC = m_min(m_max(F1_OC, tb.FR[1]), tb.FR[tb.NFRE - 1]);
+      }
     }
     const T TAU = AIRD * m_max(USTAR * USTAR, tb.EPSUS);
     T TAUXD = TAU * sinwd, TAUYD = TAU * coswd;
@@ -1330,5 +1341,21 @@ __global__ void __launch_bounds__(64) k_implsch4_fin(const DevTab<T>* __restrict
     T* io = intfa + (size_t)ij * ECWAM_HIP_NINTF;
     io[5] = TAUXD; io[6] = TAUYD; io[7] = TAUOCXD; io[8] = TAUOCYD; io[9] = TAUOC; io[10] = T(0); io[11] = T(0);
     io[12] = PHIOCD; io[13] = PHIEPS; io[14] = PHIAW;
+    if (tb.LWNEMOCOU && w2n) {  // wnfluxes.F90:304-328 (LNUPD = T; no ice stress without LWNEMOCOUWRS: that configuration runs k_implsch2)
+      double* q = w2n + (size_t)ij * 13;
+      q[3] = (double)PHIEPS; q[4] = (double)TAUOC;
+      q[5] = (EM_OC != T(0)) ? 4.0 * (double)m_sqrt(EM_OC) : 0.0;
+      q[6] = (F1_OC != T(0)) ? 1.0 / (double)F1_OC : 0.0;
+      if (tb.LWNEMOTAUOC) { q[7] += (double)TAUOCXD; q[8] += (double)TAUOCYD; }
+      else { q[7] += (double)TAUXD; q[8] += (double)TAUYD; }
+      q[11] += (double)WSWAVE; q[12] += (double)PHIOCD;
+    }
+  }
+  // stokestrn.F90:75-88 (LWNEMOCOUSTRN = F): the Stokes drift k_implsch4 left in INTFLDS
+  if (tb.LWNEMOCOU && w2n && ((tb.LWNEMOCOUSEND && tb.LWCOU) || !tb.LWCOU)) {
+    const T* io = intfa + (size_t)ij * ECWAM_HIP_NINTF;
+    double* q = w2n + (size_t)ij * 13;
+    q[0] = tb.LWNEMOCOUSTK ? (double)io[2] : 0.0;
+    q[1] = tb.LWNEMOCOUSTK ? (double)io[3] : 0.0;
   }
 }

@@ -381,9 +381,11 @@ def test_implsch_fluxes_without_the_nonlinear_transfer(api, prec):
 
 @pytest.mark.parametrize("prec", ["dp", "sp"])
 @pytest.mark.parametrize("tauoc", [True, False])
-def test_implsch_wam2nemo_outputs(api, prec, tauoc):
+@pytest.mark.parametrize("gen", [0, 2])
+def test_implsch_wam2nemo_outputs(api, prec, tauoc, gen):
     """LWNEMOCOU: the 13 WAVE2OCEAN members (always double) -- instantaneous NPHIEPS/NTAUOC/NSWH/NMWP/NEMO*STOKES and the
-    accumulating NEMOTAUX/Y, NEMOWSWAVE, NEMOPHIF (wnfluxes.F90:304-328, stokestrn.F90:75-88) -- over two consecutive calls."""
+    accumulating NEMOTAUX/Y, NEMOWSWAVE, NEMOPHIF (wnfluxes.F90:304-328, stokestrn.F90:75-88) -- over two consecutive calls.
+    gen 0: k_implsch4, whose finishing kernel writes them; gen 2: k_implsch2."""
     cfg = Config(nang=24, nfre=36, nfre_red=29, lwnemocou=True, lwnemotauoc=tauoc)
     n = 768
     case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=31)
@@ -406,9 +408,11 @@ def test_implsch_wam2nemo_outputs(api, prec, tauoc):
     w = torch.from_numpy(w0.copy()).to(dev)
     with pytest.raises(api.EcwamHipError):
         ctx.implsch(0, n, fl1, twv, tff, tintf, mij, xllws)          # LWNEMOCOU without the buffer is an error
+    ctx.set_implsch_generation(gen)
     for _ in range(2):
         ctx.implsch(0, n, fl1, twv, tff, tintf, mij, xllws, wam2nemo=w)
     torch.cuda.synchronize()
+    assert ctx.implsch_generation_used() == (4 if gen == 0 else 2)
     got, want = w.cpu().numpy(), r2["W2N"]
     ctx.close()
     assert np.array_equal(got[:, [2, 9, 10]], want[:, [2, 9, 10]])    # NEMOSTRN, NEMOTAUICX/Y: carried through untouched

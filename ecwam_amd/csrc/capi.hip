@@ -576,7 +576,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   // depend on the frequency only (LCIWA1, LCIWA3, LCISCAL), without the other optional branches, single and double precision.  The
   // sheltered growth needs TAUWSHELTER /= 0, the normalised one TAUWSHELTER = 0 (setwavphys.F90:150-190).
   const int ext = (c->p.llnormagam || c->p.llgcbz0) ? 1 : 0;
-  const bool rare4 = c->p.lciwa2 || c->p.lwnemocouibr || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin || c->p.iphys == 0 || c->p.icode != 3 ||
+  const bool rare4 = c->p.lciwa2 || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin || c->p.iphys == 0 || c->p.icode != 3 ||
                      !c->p.lwvflx_snl;
   if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !rare4 && !dbg &&
       (c->p.llnormagam ? c->v4_shelter == 0 : c->v4_shelter != 0)) {

@@ -570,10 +570,12 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     // reference adds them one after the other: the sums differ in rounding only).  SDICE2 depends on F itself and the NEMO coupling
     // needs SLICE on its own: k_implsch2.
     const bool ice1 = tb.LICERUN && tb.LCIWA1, ice3 = tb.LICERUN && tb.LCIWA3;
-    T CICOVERv = T(0), CITHICKv = T(0), DINV = T(0);
+    T CICOVERv = T(0), CITHICKv = T(0), DINV = T(0), ALPFAC = tb.ZALPFACX;
     if (ice1 || ice3) {
       CICOVERv = ffa[(size_t)ij * ECWAM_HIP_NFF + 2];
       CITHICKv = ffa[(size_t)ij * ECWAM_HIP_NFF + 13];
+      // broken ice attenuates less (icebreak_modify_attenuation.F90:82-93); IBRMEM is the input slot 15 of INTFLDS
+      if (tb.LWNEMOCOUIBR && intfa[(size_t)ij * ECWAM_HIP_NINTF + 15] <= tb.ZIBRW_THRSH) ALPFAC = T(1) / tb.ZALPFACX;
     }
     if (ice1) {   // mean floe diameter of the fragmentation cascade
       const T CIFRGL = T(0.955), CIDMIN = T(20.0), CIFRGMT = T(2.0), A = T(200.0), C = T(300.0);
@@ -622,7 +624,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         }
         if (ice3) {
           const T CDICE = T(0.1274) * m_pow(tb.ZPI / m_sqrt(tb.G), T(4.5));
-          const T ALP = (T(2) * CDICE * m_pow(CITHICKv, T(1.25)) * m_pow(tb.FR[m], T(4.5))) * tb.ZALPFACX;
+          const T ALP = (T(2) * CDICE * m_pow(CITHICKv, T(1.25)) * m_pow(tb.FR[m], T(4.5))) * ALPFAC;
           dmp = dmp + (-CICOVERv * ALP * CGROUP);
         }
         sbo = dmp + sbo;

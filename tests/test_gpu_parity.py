@@ -216,6 +216,7 @@ def test_implsch_parity_sdice1_and_ice_breakup(api, prec, flags):
     ref = H.oracle_implsch(case, _oracle(cfg, prec))
     ctx = api.HipContext(case["tables"])
     got = H.gpu_implsch(case, ctx)
+    assert ctx.implsch_generation_used() == 4      # both option sets are damping rates per (point, frequency): the fast kernel
     st = H.compare_implsch(ref, got, case["tables"])
     ctx.close()
     assert np.isfinite(got["FL1"]).all() and np.isfinite(got["INTF"]).all()

@@ -205,6 +205,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
   V2<T> f_n = *reinterpret_cast<const V2<T>*>(tF);
   V2<T> cw_n = *reinterpret_cast<const V2<T>*>(L.fac4 + Q4_CINV);
   T zcn_n = L.zcn[0];
+#pragma unroll 2
   for (int m = 0; m < NFRE; m++) {
     const V2<T> f = f_n, cw = cw_n;
     const T ZCN = zcn_n, cinv_m = cw.x;
@@ -246,7 +247,9 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
         const bool c0 = coslp.x > T(0.01), c1 = coslp.y > T(0.01);
         const T Z0 = ZCN + UCNZALPD * f_rcp(coslp.x), Z1 = ZCN + UCNZALPD * f_rcp(coslp.y);
         const bool n0 = c0 && (Z0 < T(0)), n1 = c1 && (Z1 < T(0));
-        if (__builtin_amdgcn_ballot_w64(n0 || n1) != 0ull) {
+        // single precision: no test for "no lane grows" -- a uniform branch here costs more than the two v_exp_f32 it would skip;
+        // the double-precision exponentials are long instruction sequences worth skipping
+        if (sizeof(T) == 4 || __builtin_amdgcn_ballot_w64(n0 || n1) != 0ull) {
           const V2<T> ZL = {Z0, Z1};
           const V2<T> Z2X = ZL * ZL * (coslp * UCN);
           const V2<T> ex = {f_exp(Z0), f_exp(Z1)};
@@ -269,9 +272,8 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
     if (NGST == 2) { sp = sp + SLP[1]; fl = fl + FLP[1]; }
     sp = AVG * sp;
     fl = AVG * fl;
-    const bool anygrow = __builtin_amdgcn_ballot_w64(xl0 || xl1) != 0ull;
     T xrow = T(0), yrow = T(0);
-    if (anygrow) {
+    if (sizeof(T) == 4 || __builtin_amdgcn_ballot_w64(xl0 || xl1) != 0ull) {
 #pragma unroll
       for (int ig = 0; ig < NGST; ig++) {
         const V2<T> sx = SLP[ig] * L.sinth, sy = SLP[ig] * L.costh;
@@ -349,6 +351,7 @@ __device__ void v4_sinput_n(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, co
   const V2<T> rcos = {f_rcp(coswdif.x), f_rcp(coswdif.y)};
   T GAMNORMA[2] = {T(1), T(1)};
   const T* tF = L.tile + L.own;
+#pragma unroll 2
   for (int m = 0; m < NFRE; m++) {
     const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
     const V2<T> cw = *reinterpret_cast<const V2<T>*>(L.fac4 + m * 4 + Q4_CINV);
@@ -898,7 +901,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     const T DELT = (T)tb.IDELT, DELTM = T(1) / DELT, DELT5 = tb.XIMP * DELT;
     const bool shallow_brk = tb.LBIWBK && (DEPTH < T(50));
     const T USFM = UFRIC * m_max(FMEANWS, FMEAN);
-    const bool flux_snl = tb.LCFLX && tb.LWVFLX_SNL;
+    const T FSNL = (tb.LCFLX && tb.LWVFLX_SNL) ? T(1) : T(0);
+    const T SDSL = shallow_brk ? SDS : T(0);
     const T BETA = (tb.LICERUN && tb.LCISCAL) ? T(1) - CICOVER : T(1);
     const int NRED = tb.NFRE_RED, MLST = tb.MLSTHG;
     T* st0 = sStg;            // staging rows: up / AD(kh=1), vp / DELAM(1), um / DELAP(1), vm / AD(2), row MC-4 / DELAM(2), DELAP(2)
@@ -944,16 +948,19 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     auto update_row = [&](int m, V2<T>& accS, V2<T>& accF, V2<T>& wslot, T cofr, T flmax, T rhowg, T sig) {
       const V2<T> f = u_f;
       V2<T> D = u_D;
-      if (turb) D = D - (sig * u_wn * FACTURB) * coswdif;
+      D = D - (sig * u_wn * FACTURB) * coswdif;   // (FACTURB = 0 without the turbulence term: exact, and cheaper than a uniform branch)
       const V2<T> fldw = D + wslot;
       V2<T> sl = fldw * f + accS;
       V2<T> fld = fldw + accF;
-      V2<T> ss = z2;
-      if (flux_snl) {
+      V2<T> ss;
+      {
         const V2<T> den = {m_max(T(1) - DELT5 * fld.x, T(1)), m_max(T(1) - DELT5 * fld.y, T(1))};
-        ss = V2<T>{f_div(sl.x, den.x), f_div(sl.y, den.y)};
+        ss = V2<T>{f_div(sl.x, den.x), f_div(sl.y, den.y)} * FSNL;   // FSNL = 1 / 0: LCFLX and LWVFLX_SNL
       }
-      if (shallow_brk && m < NRED) { sl = sl - SDS * f; fld = fld - SDS; }
+      {
+        const T sd = (m < NRED) ? SDSL : T(0);                        // SDIWBK where the point is shallow (SDSL = 0 elsewhere: exact)
+        sl = sl - sd * f; fld = fld - sd;
+      }
       sl = BETA * sl; fld = BETA * fld;                     // LCISCAL (implsch.F90:316-321); BETA = 1 without it: exact
       sl = sl + u_sbo * f; fld = fld + u_sbo;               // SBOTTOM (zero at M > NFRE_RED) + SDICE1 + SDICE3: the table slot
       const T lim = USFM * (cofr * DELT);

@@ -256,7 +256,8 @@ int ecwam_hip_implsch(ecwam_hip_ctx *ctx, int kijs, int kijl, void *fl1, const v
                       void *xllws, double *wam2nemo, void *dbg, void *stream);
 /*
  * IMPLSCH exists in two kernel generations with identical results up to rounding (csrc/implsch_v2.h: one point per wavefront, every
- * configuration; implsch_v4.h: several points per wavefront, flag sets A and B).  ecwam_hip_implsch launches the fastest one that
+ * configuration; implsch_v4.h: several points per wavefront, flag sets A and B with or without the sea-ice damping LCIWA1 / LCIWA3 / LCISCAL and the
+ * NEMO coupling outputs of LWNEMOCOU).  ecwam_hip_implsch launches the fastest one that
  * covers the context's configuration; gen = 2 or 4 caps the choice at that generation (parity tests that keep the generations
  * checked against each other), gen = 0 restores the automatic choice.
  */

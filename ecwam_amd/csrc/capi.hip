@@ -199,7 +199,7 @@ static int build_tab(const ecwam_hip_params* p, const ecwam_hip_tables* t, DevTa
     r[0] = d->ZPIFR[m]; r[1] = d->DFIM[m];
     r[2] = -d->SWELLF5 * T(2) * std::sqrt(T(2) * d->RNU * d->ZPIFR[m]);
     r[3] = -d->SWELLF * T(16) * (d->ZPIFR[m] * d->ZPIFR[m]) / d->G;
-    r[4] = d->RHOWG_DFIM[m]; r[5] = d->DFIMOFR[m]; r[6] = T(0); r[7] = T(0);
+    r[4] = d->RHOWG_DFIM[m]; r[5] = d->DFIMOFR[m]; r[6] = d->DFIMFR[m]; r[7] = T(0);
   }
   const int ntap = 2 * p->nsdsnth + 1;
   for (int k = 0; k < NANG; k++)

@@ -66,7 +66,7 @@ struct DevTab {
   // words 10, 11, 28..30 of the record of interaction MC: ZPIFR of the (clamped) row MC-3 and COFRM4, FLMAX, RHOWG_DFIM, ZPIFR of row
   // MC-5, which that interaction updates -- the record is one scalar load, a lane table costs a v_readlane per value
   // SINPUT_ARD's per-frequency constants as one 8-word record per row: ZPIFR, DFIM, -SWELLF5 2 SQRT(2 NU_AIR SIG), -SWELLF 16 SIG**2 / G
-  // (sinput_ard.F90:343-347), RHOWG_DFIM, DFIMOFR, 2 spare
+  // (sinput_ard.F90:343-347), RHOWG_DFIM, DFIMOFR, DFIMFR, 1 spare
   alignas(32) T SINROW[MAXF][8];
   int V4_ROWS;
   // saturation filter: [k2][k] so that lanes (k) read consecutive words

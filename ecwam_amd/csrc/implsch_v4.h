@@ -672,31 +672,39 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       V2<T> s = z2;
       for (int m = 0; m < NFRE; m++) {
         const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
-        const T t = f.x + f.y;
-        s.x = s.x + lane_get(L.rDFIM, m) * t;
-        if (m == NFRE - 1) s.y = t;
+        s.x = s.x + tb.SINROW[m][1] * (f.x + f.y);
+      }
+      {
+        const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + (NFRE - 1) * RS);
+        s.y = f.x + f.y;
       }
       s = v4_allsum<G, T>(s, L.rot);
       const T EM = tb.EPSMIN + s.x + DELT25 * s.y;
       sc = m_min(EMAXDPT / EM, T(1));
     }
     V2<T> s0 = z2, s1 = z2, s2 = z2, so = z2;
-    for (int m = 0; m < NFRE; m++) {
-      V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
-      if (tb.LBIWBK) { f = f * sc; f.x = m_max(f.x, tb.EPSMIN); f.y = m_max(f.y, tb.EPSMIN); }
+    // branch-free rows: without LBIWBK the scale is 1 and the floor -infinity (both exact), the row is stored back unchanged; the
+    // last row (raised to the noise floor for the orbital integrals only) is peeled off
+    const T flo = tb.LBIWBK ? tb.EPSMIN : -std::numeric_limits<T>::infinity();
+    auto row202 = [&](int m, bool last) {
+      V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS) * sc;
+      f.x = m_max(f.x, flo); f.y = m_max(f.y, flo);
       const T t = f.x + f.y;
-      const T dfm = lane_get(L.rDFIM, m), sqm = L.sq[m], sig = lane_get(L.rZPIFR, m);
-      s0 = s0 + V2<T>{dfm, lane_get(L.rDFIMOFR, m)} * t;
-      s1 = s1 + V2<T>{lane_get(L.rDFIMFR, m), dfm / sqm} * t;
+      const T* row = tb.SINROW[m];
+      const T dfm = row[1], sqm = L.sq[m], sig = row[0];
+      s0 = s0 + V2<T>{dfm, row[5]} * t;
+      s1 = s1 + V2<T>{row[6], dfm / sqm} * t;
       s2.x = s2.x + (sqm * dfm) * t;
-      if (m == NFRE - 1) {
+      if (last) {
         s2.y = t;
         f.x = m_max(f.x, FLM.x); f.y = m_max(f.y, FLM.y);   // the orbital integrals see the raised tail
       }
       const T to = f.x + f.y;
       so = so + V2<T>{dfm * (sig * sig), dfm} * to;
-      if (tb.LBIWBK || m == NFRE - 1) *reinterpret_cast<V2<T>*>(tFw + m * RS) = f;
-    }
+      *reinterpret_cast<V2<T>*>(tFw + m * RS) = f;
+    };
+    for (int m = 0; m < NFRE - 1; m++) row202(m, false);
+    row202(NFRE - 1, true);
     fkmean_finish(s0, s1, s2, EMEAN, FMEAN, F1MEAN, AKMEAN, XKMEAN);
     so = v4_allsum<G, T>(so, L.rot);
     if (j == 0) { c[C_UORBT] = tb.EPSMIN + so.x; c[C_AORB] = tb.EPSMIN + so.y; c[C_EMEAN] = EMEAN; c[C_F1MEAN] = F1MEAN; }
@@ -1156,18 +1164,21 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   T EMEANWS;
   {  // FKMEAN and FEMEANWS in one pass over the rows (fkmean.F90:94-150, femeanws.F90:84-123)
     V2<T> s0 = z2, s1 = z2, s2 = z2, we = z2, wl = z2;   // (EM, FM), (F1, AK), (XK, last row), windsea (EM, FM), windsea last row
+    T tlast = T(0);
     for (int m = 0; m < NFRE; m++) {
       const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
       const T t = f.x + f.y;
-      const T dfm = lane_get(L.rDFIM, m), dfo = lane_get(L.rDFIMOFR, m), sqm = L.sq[m];
+      const T* row = tb.SINROW[m];
+      const T dfm = row[1], dfo = row[5], sqm = L.sq[m];
       s0 = s0 + V2<T>{dfm, dfo} * t;
-      s1 = s1 + V2<T>{lane_get(L.rDFIMFR, m), dfm / sqm} * t;
+      s1 = s1 + V2<T>{row[6], dfm / sqm} * t;
       s2.x = s2.x + (sqm * dfm) * t;
-      if (m == NFRE - 1) s2.y = t;
+      tlast = t;
       const V2<T> x = {((xm0 >> m) & 1ull) ? f.x : T(0), ((xm1 >> m) & 1ull) ? f.y : T(0)};
       we = we + V2<T>{dfm, dfo} * (x.x + x.y);
       wl = x;
     }
+    s2.y = tlast;
     fkmean_finish(s0, s1, s2, EMEAN, FMEAN, F1MEAN, AKMEAN, XKMEAN);
     femws_finish(we, wl, FMEANWS, EMEANWS);
   }

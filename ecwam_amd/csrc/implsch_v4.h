@@ -9,18 +9,22 @@
 //     odd shifts take one half from each of two even shifts): the DIA gathers read four staged rows (the frequency-interpolated
 //     spectra), the DIA increments are staged in three rows and pulled back rotated, the 2 NSDSNTH + 1 taps of the saturation
 //     filter are NSDSNTH + 1 reads of the row itself.  No half swaps (v_cndmask), no per-tap address registers.
-//   * v_pk_fma_f32 issues at 4.4 cycles per wave instruction against 2.6 for v_fma_f32 when two waves share a SIMD: packing halves
-//     the instruction count but buys 15 % of issue time, so nothing here depends on it (the code is plain scalar arithmetic on the
-//     two halves of a pair and compiles for double precision as it stands).
+//   * the arithmetic is written on pairs (ext_vector_type(2): the two directions of a lane, or the two gust states of a row) and
+//     compiles to v_pk_* in single precision; v_pk_fma_f32 issues at 4.4 cycles per wave instruction against 2.6 for v_fma_f32 when
+//     two waves share a SIMD, so packing pays through the instruction count (the same source is plain arithmetic in double precision).
 //   * the tile is [M][point][K] (K fastest, natural order): the coalesced load / store are 16-byte global accesses with the
 //     (K, M) transposition done by four 4-byte LDS accesses at immediate offsets -- 5 instead of 45 vector instructions per element.
-//   * the row integrals of SINPUT live in registers of the lane that owns the frequency (no LDS table); the planes SQRT(WAVNUM) and
-//     LOG(WAVNUM Z0M) of the factor table double as staging rows during the sweep: 20 424 B of LDS per wave (sp, NANG = 36), 8 waves
-//     per CU as before -- the limit: 24 sea points per CU is what 160 KB hold.
+//   * the planes SQRT(WAVNUM) and LOG(WAVNUM Z0M) of the factor table double as staging rows during the sweep, the staging rows hold
+//     SINPUT's row integrals outside it: 20 424 B of LDS per wave (sp, NANG = 36), 8 waves per CU as before -- the limit: 24 sea
+//     points per CU is what 160 KB hold.
 //   * with two waves per SIMD a wave issues one instruction per ~5.3 cycles whatever its kind, and a third of its life was spent in
-//     s_waitcnt: the sweep is software-pipelined (three LDS round trips per interaction frequency instead of eight, see there),
-//     scalar loads are gone from it (their lgkmcnt is shared with the LDS and returns out of order), no store is predicated.
-// The lane-per-point scalar stages (TAUT_Z0, STRESSO / TAU_PHI_HF, WSIGSTAR, swell set-up, SDIWBK) are those of implsch_v2.h.
+//     s_waitcnt: the sweep is software-pipelined (three LDS round trips per interaction frequency instead of eight, see there), no
+//     store is predicated, and the row loops are straight-line code: a uniform branch per row costs more than most of the work such
+//     branches skip.  Constants per frequency come as ONE scalar-loaded record per row (DevTab::SINROW, DIACF).
+//   * the dependent scalar chains that need no spectrum on either side run one sea point per lane in k_implsch4_pre (first TAUT_Z0)
+//     and k_implsch4_fin (second STRESSO / TAU_PHI_HF, WNFLUXES, NEMO coupling outputs) around the main kernel.
+// The lane-per-point scalar stages between the vector stages (STRESSO of the first call, second TAUT_Z0, WSIGSTAR, swell set-up,
+// SDIWBK) are those of implsch_v2.h.
 #pragma once
 
 #define V4_NFRE 36

@@ -188,6 +188,10 @@ static int build_tab(const ecwam_hip_params* p, const ecwam_hip_tables* t, DevTa
     for (int j = 0; j < 8; j++) { d->DIACF[i][12 + j] = d->RNLCOEF[i][5 + j]; d->DIACF[i][20 + j] = d->RNLCOEF[i][17 + j]; }
     const int MC = i + 1;
     auto cl = [&](int r) { return (r < 1 ? 1 : (r > NFRE ? NFRE : r)) - 1; };
+    {  // snonlin.F90:236-240: the tail factor applies outside MFR1STFR < MC < MFRLSTFR
+      const int MFR1STFR = -p->mfrstlw + 1, MFRLSTFR = NFRE - p->kfrh + MFR1STFR;
+      d->DIACF[i][31] = (MC > MFR1STFR && MC < MFRLSTFR) ? T(1) : d->RNLCOEF[i][0];
+    }
     d->DIACF[i][10] = d->ZPIFR[cl(MC - 3)];
     const int mu = cl(MC - 5);
     d->DIACF[i][28] = d->COFRM4[mu]; d->DIACF[i][29] = d->FLMAX[mu]; d->DIACF[i][30] = d->RHOWG_DFIM[mu]; d->DIACF[i][11] = d->ZPIFR[mu];

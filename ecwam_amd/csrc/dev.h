@@ -63,7 +63,7 @@ struct DevTab {
   // AF11, 2 spare), words 12..27 the scatter set (RNLCOEF(6:13), RNLCOEF(18:25)); V4_ROWS = 1 when INLCOEF equals the clamped
   // MC, MC+2, MC+3, MC-4, MC-3
   alignas(16) T DIACF[MAXMC][32];
-  // words 10, 11, 28..30 of the record of interaction MC: ZPIFR of the (clamped) row MC-3 and COFRM4, FLMAX, RHOWG_DFIM, ZPIFR of row
+  // word 31: FTAIL as the sweep applies it (1 between MFR1STFR and MFRLSTFR); words 10, 11, 28..30 of the record of interaction MC: ZPIFR of the (clamped) row MC-3 and COFRM4, FLMAX, RHOWG_DFIM, ZPIFR of row
   // MC-5, which that interaction updates -- the record is one scalar load, a lane table costs a v_readlane per value
   // SINPUT_ARD's per-frequency constants as one 8-word record per row: ZPIFR, DFIM, -SWELLF5 2 SQRT(2 NU_AIR SIG), -SWELLF 16 SIG**2 / G
   // (sinput_ard.F90:343-347), RHOWG_DFIM, DFIMOFR, DFIMFR, 1 spare

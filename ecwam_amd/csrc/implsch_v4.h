@@ -900,8 +900,6 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   {
     T ENHFR = m_max(T(0.75) * DEPTH * AKMEAN, T(0.5));
     ENHFR = T(1) + (T(5.5) / ENHFR) * (T(1) - T(0.833) * ENHFR) * m_exp(-T(1.25) * ENHFR);
-    const int MFR1STFR = -tb.MFRSTLW + 1;
-    const int MFRLSTFR = NFRE - tb.KFRH + MFR1STFR;
     const T DAL1 = tb.DAL1, DAL2 = tb.DAL2;
     T wt[NH + 1];   // SATWEIGHTS depend on the tap only and are symmetric (checked by ecwam_hip_create): wave-uniform, taps -NH .. 0
 #pragma unroll
@@ -989,8 +987,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       const T rh = rhowg * m_min(m_max(MIJh - (T)(m + 1), T(0)), T(1));
       a_t = a_t + rh * ss;
       a_x = a_x + (u_cinv * rh) * ss;
-      const int mn = m + 4;   // the slot of the wind-input ring is free: row m+4
-      if (mn < NFRE) wslot = *reinterpret_cast<const V2<T>*>(gx + (size_t)mn * NANG);
+      // the slot of the wind-input ring is free: row m+4 (beyond the last row the last one again, never used: no branch)
+      wslot = *reinterpret_cast<const V2<T>*>(gx + (size_t)hi35(m + 4) * NANG);
     };
     *reinterpret_cast<V2<T>*>(st4 + L.own) = fR[5];   // row MC-4 of the first interaction
     V4SYNC();
@@ -1021,8 +1019,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         const T FKLAPA2 = cs[4], FKLAPB2 = cs[5], FKLAP12 = cs[6], FKLAP22 = cs[7];
         const T FKLAMMA = cs[8], FKLAMMB = cs[9], FKLAMM2 = cs[10], FKLAMM1 = cs[11];
         const T FKLAMA2 = cs[12], FKLAMB2 = cs[13], FKLAM12 = cs[14], FKLAM22 = cs[15];
-        const bool mid = (MC > MFR1STFR && MC < MFRLSTFR);
-        const T FTAIL = mid ? T(1) : cg[0];   // x 1 is exact: no select on the vector side
+        const T FTAIL = cg[31];   // the tail factor RNLCOEF(1), or 1 between MFR1STFR and MFRLSTFR where the reference skips it (x 1 is exact)
         // ---- meanwhile: the row the previous interaction completed
         if (m - 1 >= 0 && m - 1 < NFRE) update_row(m - 1, aS[(jj + 4) & 7], aF[(jj + 4) & 7], wiq[(jj + 3) & 3], cg[28], cg[29], cg[30], cg[11]);
         // the dissipation coefficient of row m (sdissip_ard.F90:117-314) from the saturation spectrum and the maximum the previous

@@ -886,6 +886,37 @@ def test_implsch_kernel_generations_agree(api):
         assert st["intf_max_rel_all"] < 5e-3, (gen, st)
 
 
+def test_two_steps_replay_from_a_hip_graph(api):
+    """The time loop makes no allocation and no host synchronisation (ecwam_hip_implsch_reserve at set-up): two WAMINTGR steps -- the
+    ping-pong spectra are back in place after an even number -- are captured into a hipGraph and replayed; bit-identical to the
+    same steps launched one by one."""
+    from ecwam_amd import grid as G
+    from ecwam_amd.wamintgr import Wamintgr
+
+    cfg = Config(nang=36, nfre=36, nfre_red=36, idelt=450, idelpro=450)
+    g = G.build_grid(48)
+    a = Wamintgr(cfg, g, "sp")
+    b = Wamintgr(cfg, g, "sp")
+    for w in (a, b):
+        w.init_synthetic()
+        assert w.build_weights() == 0
+    for _ in range(6):
+        a.step()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        b.step()
+        b.step()                               # outside the capture: whatever a first call sets up
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):    # captured, not run
+        b.step()
+        b.step()
+    graph.replay()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(a.fl1[: a.n], b.fl1[: b.n]) and torch.equal(a.ff, b.ff) and torch.equal(a.mij, b.mij)
+
+
 @pytest.mark.parametrize("prec", ["sp", "dp"])
 def test_implsch_in_blocks_is_bit_identical(api, prec):
     """ecwam_hip_implsch on sub-ranges KIJS..KIJL of the arrays (the reference's NPROMA chunks: implsch.F90:10, wamintgr.F90:120-149), in

@@ -114,7 +114,7 @@ __device__ __forceinline__ int m_nint(float x) { return (int)lroundf(x); }
 __device__ __forceinline__ int m_nint(double x) { return (int)lround(x); }
 // ---- IMPLSCH hot-loop math: single precision goes straight to the hardware transcendental unit (v_rcp/v_sqrt/v_exp/
 // v_log, <= 1 ulp each, no range fix-up code: the arguments on these paths are bounded, see the call sites);
-// double precision keeps the library routines.  f_exp(x) = 2^(x*log2e): relative error <= |x|*1.2e-7.
+// double precision keeps the library routines for EXP / LOG / SQRT.  f_exp(x) = 2^(x*log2e): relative error <= |x|*1.2e-7.
 __device__ __forceinline__ float f_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 // double precision: hardware seed (v_rcp_f64 / v_rsq_f64, ~2^-26) + two Newton steps in FMA form: < 2 ulp, no IEEE
 // special-case sequence (div_scale/div_fmas/div_fixup).  Arguments on these paths are finite, non-zero and normal.
@@ -134,7 +134,12 @@ __device__ __forceinline__ double f_rcp(double b) {
 __device__ __forceinline__ float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ double f_sqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ float f_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ __forceinline__ double f_rsq(double x) { return 1.0 / sqrt(x); }
+__device__ __forceinline__ double f_rsq(double x) {   // x > 0 (the callers discard the result of x = 0)
+  double y = __builtin_amdgcn_rsq(x);
+  y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
+  y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
+  return y;
+}
 __device__ __forceinline__ float f_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 __device__ __forceinline__ double f_exp(double x) { return exp(x); }
 __device__ __forceinline__ float f_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }

@@ -114,7 +114,7 @@ __device__ __forceinline__ int m_nint(float x) { return (int)lroundf(x); }
 __device__ __forceinline__ int m_nint(double x) { return (int)lround(x); }
 // ---- IMPLSCH hot-loop math: single precision goes straight to the hardware transcendental unit (v_rcp/v_sqrt/v_exp/
 // v_log, <= 1 ulp each, no range fix-up code: the arguments on these paths are bounded, see the call sites);
-// double precision keeps the library routines for EXP / LOG / SQRT.  f_exp(x) = 2^(x*log2e): relative error <= |x|*1.2e-7.
+// double precision keeps the library routines for EXP / LOG.  f_exp(x) = 2^(x*log2e): relative error <= |x|*1.2e-7.
 __device__ __forceinline__ float f_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 // double precision: hardware seed (v_rcp_f64 / v_rsq_f64, ~2^-26) + two Newton steps in FMA form: < 2 ulp, no IEEE
 // special-case sequence (div_scale/div_fmas/div_fixup).  Arguments on these paths are finite, non-zero and normal.
@@ -132,7 +132,15 @@ __device__ __forceinline__ double f_rcp(double b) {
   return r;
 }
 __device__ __forceinline__ float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ double f_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ double f_sqrt(double x) {   // x >= 0, finite: seed, one coupled Newton step for SQRT and 1/(2 SQRT), one correction
+  const double y = __builtin_amdgcn_rsq(x);
+  double s = x * y, h = 0.5 * y;
+  const double r = fma(-h, s, 0.5);
+  s = fma(s, r, s);
+  h = fma(h, r, h);
+  s = fma(fma(-s, s, x), h, s);
+  return x == 0.0 ? 0.0 : s;
+}
 __device__ __forceinline__ float f_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ double f_rsq(double x) {   // x > 0 (the callers discard the result of x = 0)
   double y = __builtin_amdgcn_rsq(x);

@@ -697,7 +697,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       const T* row = tb.SINROW[m];
       const T dfm = row[1], sqm = L.sq[m], sig = row[0];
       s0 = s0 + V2<T>{dfm, row[5]} * t;
-      s1 = s1 + V2<T>{row[6], dfm / sqm} * t;
+      s1 = s1 + V2<T>{row[6], f_div(dfm, sqm)} * t;
       s2.x = s2.x + (sqm * dfm) * t;
       if (last) {
         s2.y = t;
@@ -1172,7 +1172,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       const T* row = tb.SINROW[m];
       const T dfm = row[1], dfo = row[5], sqm = L.sq[m];
       s0 = s0 + V2<T>{dfm, dfo} * t;
-      s1 = s1 + V2<T>{row[6], dfm / sqm} * t;
+      s1 = s1 + V2<T>{row[6], f_div(dfm, sqm)} * t;
       s2.x = s2.x + (sqm * dfm) * t;
       tlast = t;
       const V2<T> x = {((xm0 >> m) & 1ull) ? f.x : T(0), ((xm1 >> m) & 1ull) ? f.y : T(0)};

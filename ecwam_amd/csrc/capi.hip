@@ -249,6 +249,19 @@ __global__ void k_selftest(int* nbad) {
   bad += (lane_get(q[0], 5) != v[0][5]);
   bad += (lane_pull(q[1], (lane + 9) & 63) != v[1][(lane + 9) & 63]);
   bad += (rot_up(q[2], lane, 36) != ((lane < 36) ? v[2][(lane + 35) % 36] : (lane == 36 ? v[2][35] : T(0))));
+  // the hot-loop replacements of the library's EXP / SQRT / 1 / SQRT (dev.h) against the library over their argument ranges
+  for (int i = 0; i < 256; i++) {
+    const T u = T(lane * 256 + i) / T(16384);                      // 0 .. 1
+    const T xe = T(-700) * u * u + T(3) * (T(1) - u) - T(1.5);     // EXP: -701.5 .. 1.5, dense near zero
+    const T tol = sizeof(T) == 8 ? T(1e-15) : T(1e-4);             // sp: v_exp_f32 of x log2(e), |x| 1.2e-7 relative
+    const T ee = m_exp(xe), eg = f_exp(xe);
+    bad += !(m_abs(eg - ee) <= tol * ee + (sizeof(T) == 8 ? T(1e-320) : T(1e-37)));
+    const T xs = m_exp(T(sizeof(T) == 8 ? 600 : 80) * (T(2) * u - T(1)));   // SQRT, 1 / SQRT: 1e-260 .. 1e260 (sp 1e-35 .. 1e35)
+    const T ts = sizeof(T) == 8 ? T(9e-16) : T(3e-7);
+    const T sr = m_sqrt(xs);
+    bad += !(m_abs(f_sqrt(xs) - sr) <= ts * sr) + !(m_abs(f_rsq(xs) * sr - T(1)) <= T(2) * ts);
+  }
+  bad += (f_sqrt(T(0)) != T(0)) + (f_exp(T(-1000)) != T(0));
   if (bad) atomicAdd(nbad, bad);
 }
 

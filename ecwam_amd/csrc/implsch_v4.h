@@ -229,12 +229,12 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
     bool xl0 = false, xl1 = false;
     const V2<T> vTPX = vTAUX - ABS_TAUWSHELTER * vXS, vTPY = vTAUY - ABS_TAUWSHELTER * vYS;
     const V2<T> vh2 = vTPX * vTPX + vTPY * vTPY;
-    V2<T> vrh = {f_rsq(vh2.x), (NGST == 2) ? f_rsq(vh2.y) : T(0)};
+    // |TAUP| = h2 / SQRT(h2) with the root of MAX(h2, tiny): a vanishing stress gives h = 0 exactly and a finite direction (0, 0) --
+    // which direction does not matter then, every term it enters carries the factor USTP = 0 -- without the selects of a zero test
+    const T TINY = sizeof(T) == 4 ? T(1e-36) : T(1e-300);
+    V2<T> vrh = {f_rsq(m_max(vh2.x, TINY)), (NGST == 2) ? f_rsq(m_max(vh2.y, TINY)) : T(0)};
     if (NGST == 1) vrh.y = vrh.x;
-    const bool zr0 = !(vh2.x > T(0)), zr1 = !(vh2.y > T(0));
-    V2<T> vh = vh2 * vrh, vCOSU = vTPY * vrh, vSINU = vTPX * vrh;
-    vh.x = zr0 ? T(0) : vh.x; vCOSU.x = zr0 ? T(1) : vCOSU.x; vSINU.x = zr0 ? T(0) : vSINU.x;
-    if (NGST == 2) { vh.y = zr1 ? T(0) : vh.y; vCOSU.y = zr1 ? T(1) : vCOSU.y; vSINU.y = zr1 ? T(0) : vSINU.y; }
+    const V2<T> vh = vh2 * vrh, vCOSU = vTPY * vrh, vSINU = vTPX * vrh;
     vUSTP = V2<T>{f_sqrt(vh.x), (NGST == 2) ? f_sqrt(vh.y) : T(0)};
     if (NGST == 1) vUSTP.y = vUSTP.x;
     const V2<T> vUCN = vUSTP * cinv_m;

@@ -178,6 +178,141 @@ struct V4Ctx {
 };
 enum { Q4_BSC = 0, Q4_SBO, Q4_CINV, Q4_WAVNUM };   // Q4_BSC = WAVNUM XK2CG / 2 pi
 
+// TAUT_Z0 with the gravity-capillary roughness model (taut_z0.F90:148-287, LLGCBZ0 = T) for FOUR sea points at once: the 16 lanes of
+// DPP row r work for one point (every argument is the value of the lane's point, the same on the lanes of a row), STRESS_GC's sum over
+// the gravity-capillary wavenumbers NS .. NWAV_GC (stress_gc.F90:80-130, at most 82 terms) runs over the lanes of the row.  The
+// iterations of a point stop by its own criterion (its lanes keep their values from then on); the wave leaves a loop when every row has.
+// taut_z0_b_w (implsch_v2.h) is the same arithmetic for one point per wave.
+template <typename T>
+__device__ T stress_gc_row(const DevTab<T>& tb, int l16, bool run, T ANG_GC, T USTAR, T Z0, T Z0MIN, T HALP, T RNFAC) {
+  const T XLAMA = T(0.25), XLAMB = T(4.0);
+  const int NS = ns_gc_d(tb, USTAR);
+  const T t = USTAR * (Z0MIN / Z0);
+  const T TAUWCG_MIN = t * t;
+  const T XLAMBDA = T(1) + XLAMA * m_tanh(XLAMB * m_pow4(USTAR));
+  const T LOGXL = m_log(XLAMBDA);
+  const T hc = HALP * tb.C2OSQRTVG_GC[NS];
+  const T ZABHRC = ANG_GC * tb.BETAMAXOXKAPPA2 * hc;
+  const T CONST = tb.LLNORMAGAM ? RNFAC * tb.BMAXOKAP * hc / m_max(USTAR, tb.EPSUS) : T(0);
+  T acc = T(0);
+  for (int I = NS + l16;; I += 16) {
+    const bool act = run && I <= tb.NWAV_GC;
+    if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
+    if (act) {
+      const T X = USTAR * tb.CM_GC[I];
+      const T XLOG = m_log(tb.XK_GC[I] * Z0) + tb.XKAPPA / (X + tb.ZALP);
+      const T ZLOG = m_min(XLOG - LOGXL, T(0));
+      const T ZLOG2X = ZLOG * ZLOG * X;
+      const T GAM_W = ZLOG2X * ZLOG2X * m_exp(XLOG) * tb.OM3GMKM_GC[I];
+      const T ZN = CONST * tb.XKMSQRTVGOC2_GC[I] * GAM_W;
+      const T GAMNORMA = (T(1) + tb.RN1_RN * ZN) / (T(1) + ZN);
+      const T wt = (I == NS) ? tb.DELKCC_GC_NS[NS] * tb.OMXKM3_GC[NS] : tb.DELKCC_OMXKM3_GC[I];
+      acc = acc + (GAM_W * wt) * GAMNORMA;
+    }
+  }
+  const T TAUWCG = v4_rowsum<T>(V2<T>{acc, T(0)}).x;
+  return m_max(ZABHRC * TAUWCG, TAUWCG_MIN);
+}
+template <typename T>
+__device__ void taut_z0_b_rows(const DevTab<T>& tb, int l16, int IUSFG, T HALP, T UTOP, T COSDIFF, T TAUW, T RNFAC, T& USTAR, T& Z0, T& Z0B,
+                               T& CHRNCK) {
+  const int NITER = 18;
+  const T PMAX = T(0.99), Z0MIN = T(0.000001);
+  const T US2TOTAUW = T(1) + tb.EPS1;
+  const T RNUKAPPAM1 = (T(0.04) * tb.RNU) / tb.XKAPPA;
+  const T PCE_GC = T(0.001) * IUSFG + (1 - IUSFG) * T(0.005);
+  const T TAUWACT = m_max(TAUW * COSDIFF, tb.EPSMIN);
+  const bool LLCOSDIFF = (COSDIFF > T(0.9));
+  T ALPHAOG = T(0);
+  if (tb.LLCAPCHNK) ALPHAOG = chnkmin(tb, UTOP) * tb.GM1;
+  const T USMAX = m_max(-T(0.21339) + T(0.093698) * UTOP - T(0.0020944) * UTOP * UTOP + T(5.5091E-5) * UTOP * UTOP * UTOP, T(0.03));
+  const T TAUWEFF = m_min(TAUWACT * US2TOTAUW, USMAX * USMAX);
+  T X, CDFG;
+  if (IUSFG == 0) {
+    const T ALPHAGM1 = tb.ALPHA * tb.GM1;
+    if (UTOP < T(1)) CDFG = T(0.002);
+    else if (LLCOSDIFF) {
+      const T um = m_max(USTAR, tb.EPSUS);
+      X = m_min(TAUWACT / (um * um), PMAX);
+      T ZCHAR = m_min(ALPHAGM1 * USTAR * USTAR / m_sqrt(T(1) - X), T(0.05) * m_exp(-T(0.05) * (UTOP - T(35.))));
+      ZCHAR = m_min(ZCHAR, tb.ALPHAMAX);
+      CDFG = tb.ACDLIN + tb.BCDLIN * m_sqrt(ZCHAR) * UTOP;
+    } else CDFG = cdm_d(UTOP);
+    USTAR = UTOP * m_sqrt(CDFG);
+  }
+  const T W1 = T(0.85) - T(0.05) * (m_tanh(T(10) * (UTOP - T(5))) + T(1));
+  const T XKUTOP = tb.XKAPPA * UTOP;
+  T USTOLD = USTAR;
+  T TAUOLD = USTOLD * USTOLD;
+  T TAUUNR = T(0);
+  bool run = true;   // the point is still iterating; true after the loop = the reference's ITER > NITER
+  for (int ITER = 1; ITER <= NITER; ITER++) {
+    if (__builtin_amdgcn_ballot_w64(run) == 0ull) break;
+    const T Z0n = m_max(tb.XNLEV / (m_exp(m_min(XKUTOP / USTOLD, T(50))) - T(1)), Z0MIN);
+    const T TAUV = RNUKAPPAM1 * USTOLD / Z0n;
+    const T ANG_GC = tb.ANG_GC_A + tb.ANG_GC_B * m_tanh(tb.ANG_GC_C * TAUOLD);
+    const T TAUUNRn = stress_gc_row(tb, l16, run, ANG_GC, USTAR, Z0n, Z0MIN, HALP, RNFAC);
+    const T TAUNEW = TAUWEFF + TAUV + TAUUNRn;
+    const T USTNEW = m_sqrt(TAUNEW);
+    const T USTARn = W1 * USTOLD + (T(1) - W1) * USTNEW;
+    if (run) {
+      Z0 = Z0n; TAUUNR = TAUUNRn; USTAR = USTARn;
+      if (m_abs(USTAR - USTOLD) < PCE_GC * USTAR) run = false;
+      else { TAUOLD = USTAR * USTAR; USTOLD = USTAR; }
+    }
+  }
+  X = TAUWEFF / TAUOLD;
+  if (run && X >= PMAX) {
+    CDFG = cdm_d(UTOP);
+    USTAR = UTOP * m_sqrt(CDFG);
+    const T Z0MINRST = USTAR * USTAR * tb.ALPHA * tb.GM1;
+    Z0 = m_max(tb.XNLEV / (m_exp(XKUTOP / USTAR) - T(1)), Z0MINRST);
+    Z0B = Z0MINRST;
+  } else {
+    Z0 = m_max(tb.XNLEV / (m_exp(XKUTOP / USTAR) - T(1)), Z0MIN);
+    Z0B = Z0 * m_sqrt(TAUUNR / TAUOLD);
+  }
+  if (X < PMAX) {   // Newton refinement: no lane exchange, every lane iterates for its point
+    const T USNRF = USTAR, Z0NRF = Z0, Z0BNRF = Z0B;
+    USTOLD = USTAR;
+    TAUOLD = m_max(USTOLD * USTOLD, TAUWEFF);
+    const T ALPOG = m_max(m_min(Z0B / TAUOLD, tb.ALPHAMAX), ALPHAOG);
+    int ITER;
+    for (ITER = 1; ITER <= NITER; ITER++) {
+      X = m_min(TAUWEFF / TAUOLD, PMAX);
+      const T USTM1 = T(1) / m_max(USTOLD, tb.EPSUS);
+      const T Z0VIS = tb.RNUM * USTM1;
+      const T HZ0VISO1MX = T(0.5) * Z0VIS / (T(1) - X);
+      Z0B = ALPOG * TAUOLD;
+      Z0 = HZ0VISO1MX + m_sqrt(HZ0VISO1MX * HZ0VISO1MX + Z0B * Z0B / (T(1) - X));
+      const T XOLOGZ0 = T(1) / m_log(tb.XNLEV / Z0 + T(1));
+      const T Fv = USTOLD - XKUTOP * XOLOGZ0;
+      const T ZZ = T(2) * USTM1 * (T(3) * Z0B * Z0B + T(0.5) * Z0VIS * Z0 - Z0 * Z0) / (T(2) * Z0 * Z0 * (T(1) - X) - Z0VIS * Z0);
+      const T DELF = T(1) - XKUTOP * XOLOGZ0 * XOLOGZ0 * ZZ;
+      if (DELF != T(0)) USTAR = USTOLD - Fv / DELF;
+      const T TAUNEW = m_max(USTAR * USTAR, TAUWEFF);
+      USTAR = m_sqrt(TAUNEW);
+      const T DEL = TAUNEW - TAUOLD;
+      if (m_abs(DEL) < PCE_GC * TAUOLD) break;
+      TAUOLD = TAUNEW;
+      USTOLD = USTAR;
+    }
+    if (ITER > NITER) {
+      USTAR = USNRF; Z0 = Z0NRF; Z0B = Z0BNRF;
+      const T USTM1 = T(1) / m_max(USTAR, tb.EPSUS);
+      const T Z0VIS = tb.RNUM * USTM1;
+      CHRNCK = m_max(tb.G * (Z0 - Z0VIS) * USTM1 * USTM1, tb.ALPHAMIN);
+    } else {
+      const T um = m_max(USTAR, tb.EPSUS);
+      CHRNCK = m_max(tb.G * (Z0B / m_sqrt(T(1) - X)) / (um * um), tb.ALPHAMIN);
+    }
+  } else {
+    const T USTM1 = T(1) / m_max(USTAR, tb.EPSUS);
+    const T Z0VIS = tb.RNUM * USTM1;
+    CHRNCK = m_max(tb.G * (Z0 - Z0VIS) * USTM1 * USTM1, tb.ALPHAMIN);
+  }
+}
+
 // SINPUT_ARD (sinput_ard.F90:153-520) for one SINFLX call.  Outputs: XLLWS masks of the two directions of the lane (bit m), the row
 // integrals X, Y of the frequencies the lane owns (m = s G + j), the FEMEANWS integrands (wse: x = SUM DFIM F, y = SUM DFIMOFR F
 // over the windsea bins; wslast = windsea part of the last row), apl (negative wind input per direction) and -- LLSNEG -- the
@@ -721,17 +856,20 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     const V2<T> sd = L.sinth * coswd - L.costh * sinwd;   // SIN(TH - WDWAVE)
     sinwdif2 = sd * sd;
   }
-  // gravity-capillary TAUT_Z0 of every point of the wave, one after the other: STRESS_GC's wavenumber sum runs across the 64 lanes
+  // gravity-capillary TAUT_Z0 of the points of the wave, four at a time: a DPP row of 16 lanes per point (rows beyond the last point
+  // shadow it: same values, same stores)
   auto taut_z0_gc = [&](int iusfg) {
-    for (int q = 0; q < PP; q++) {
-      T* cq = sSC + q * NSC;
+    for (int b = 0; b < (PP + 3) / 4; b++) {
+      const int q4 = 4 * b + (lane >> 4);
+      T* cq = sSC + (q4 < PP ? q4 : PP - 1) * NSC;
       T UF = cq[C_UFRIC], Z0 = cq[C_Z0M], Z0Bv = cq[C_Z0B], CH = cq[C_CHRNCK];
       const T cosd = iusfg ? cq[C_COSWD] * cq[C_TWCOS] + cq[C_SINWD] * cq[C_TWSIN] : cq[C_TWCOS];
-      taut_z0_b_w(tb, lane, iusfg, cq[C_HALP], cq[C_WSWAVE], cosd, cq[C_TAUW], cq[C_RNFAC], UF, Z0, Z0Bv, CH);
+      const T WSW = cq[C_WSWAVE], WST = cq[C_WSTAR];
+      taut_z0_b_rows(tb, lane & 15, iusfg, cq[C_HALP], WSW, cosd, cq[C_TAUW], cq[C_RNFAC], UF, Z0, Z0Bv, CH);
       T sgn = T(0);
-      if (iusfg) sgn = wsigstar(tb, cq[C_WSWAVE], UF, Z0, cq[C_WSTAR]);
+      if (iusfg) sgn = wsigstar(tb, WSW, UF, Z0, WST);
       WSYNC();
-      if (lane == 0) {
+      if ((lane & 15) == 0) {
         cq[C_UFRIC] = UF; cq[C_Z0M] = Z0; cq[C_Z0B] = Z0Bv; cq[C_CHRNCK] = CH;
         if (iusfg) cq[C_SIGN] = sgn;
       }

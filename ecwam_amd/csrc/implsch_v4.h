@@ -660,31 +660,19 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
 
   // ---- spectra F[ij][K][M] -> tile [M][point][K]: 16-byte global loads (chunk w of a point = direction w / NC, frequencies
   //      VEC (w % NC) ..), the VEC frequencies of a chunk go to VEC rows; all the loads are issued before the first LDS store
+  //      -- and before the loads of the point scalars and factor tables below, whose LDS stores come first: one round trip to memory
+  //      for all of them instead of one after the other
+  constexpr int NVL = N / VEC, NITL = (NVL + 63) / 64;   // chunks per point, iterations per point
+  VT val[PP][NITL];
   {
-    constexpr int NV = N / VEC, NIT = (NV + 63) / 64;   // chunks per point, iterations per point
-    VT val[PP][NIT];
 #pragma unroll
     for (int q = 0; q < PP; q++) {
       const T* g = fl1 + (size_t)(ij0 + (q < n ? q : n - 1)) * N;
 #pragma unroll
-      for (int it = 0; it < NIT; it++) {
+      for (int it = 0; it < NITL; it++) {
         const int w = lane + 64 * it;
-        if (w < NV) val[q][it] = *reinterpret_cast<const VT*>(g + (size_t)w * VEC);
+        if (w < NVL) val[q][it] = *reinterpret_cast<const VT*>(g + (size_t)w * VEC);
       }
-    }
-    int k = lane / NC, r = lane - k * NC;
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-      const int w = lane + 64 * it;
-      if (w < NV) {
-        T* d = sT + (r * VEC) * RS + k;
-#pragma unroll
-        for (int q = 0; q < PP; q++)
-#pragma unroll
-          for (int i = 0; i < VEC; i++) d[i * RS + q * NANG] = val[q][it][i];
-      }
-      k += 64 / NC; r += 64 % NC;
-      if (r >= NC) { r -= NC; k += 1; }
     }
   }
   // ---- point scalars + first TAUT_Z0, one lane per point (sinflx.F90:105-122)
@@ -772,6 +760,22 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         sbo = dmp + sbo;
       }
       f[Q4_SBO] = sbo;
+    }
+  }
+  {   // the tile: registers -> LDS
+    int k = lane / NC, r = lane - k * NC;
+#pragma unroll
+    for (int it = 0; it < NITL; it++) {
+      const int w = lane + 64 * it;
+      if (w < NVL) {
+        T* d = sT + (r * VEC) * RS + k;
+#pragma unroll
+        for (int q = 0; q < PP; q++)
+#pragma unroll
+          for (int i = 0; i < VEC; i++) d[i * RS + q * NANG] = val[q][it][i];
+      }
+      k += 64 / NC; r += 64 % NC;
+      if (r >= NC) { r -= NC; k += 1; }
     }
   }
   WSYNC();

@@ -955,7 +955,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       else s = s + V2<T>{wx * rX[q], wx * rY[q]};
     }
     if (phiwa) {
-#pragma unroll 6
+#pragma unroll   // (all 18 loads in flight at once)
       for (int m = 0; m < NFRE; m += 2) {
         const V2<T> v = *reinterpret_cast<const V2<T>*>(gsp + (size_t)(m >> 1) * NANG);   // rows m, m+1
         T w0 = lane_get(L.rRHOWG, m), w1 = lane_get(L.rRHOWG, m + 1);
@@ -1283,6 +1283,14 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   V4SYNC();
   V4_PHASE_EXIT(207);
   const T Z0B = c[C_Z0B], CHRNCK = c[C_CHRNCK];
+  // the Stokes-drift weights STOKFAC(M) DFIM_SIM(M) of the lane's frequencies: loaded here, used behind the flux sums (their
+  // round trip to memory hides behind the three all-reduces)
+  T stkw[NS];
+#pragma unroll
+  for (int q = 0; q < NS; q++) {
+    const int m = q * G + j;
+    stkw[q] = (m < tb.NFRE_ODD) ? wp[4 * NFRE + m] * tb.DFIM_SIM[m] : T(0);
+  }
 
   // ---- WNFLUXES (wnfluxes.F90:147-190): the directional sums of the flux accumulators; the rest of it in k_implsch4_fin
   T PHILF = T(0), XSTRESS = T(0), YSTRESS = T(0);
@@ -1296,12 +1304,11 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   // ---- second FKMEAN / FEMEANWS, IMPHFTAIL, SETICE, STOKESDRIFT (implsch.F90:422-462); the SQRT(WAVNUM) plane was a staging row.
   //      The Stokes-drift weights STOKFAC(M) DFIM_SIM(M) of the point go to the other plane now: read inside the row loop below
   //      they were one exposed global-memory round trip per frequency.
-  {
-    const T* stk = wp + 4 * NFRE;   // STOKFAC(M) of the point
-    for (int m = j; m < NFRE; m += G) {
-      L.sq[m] = m_sqrt(L.fac4[m * 4 + Q4_WAVNUM]);
-      L.zcn[m] = (m < tb.NFRE_ODD) ? stk[m] * tb.DFIM_SIM[m] : T(0);
-    }
+#pragma unroll
+  for (int q = 0; q < NS; q++) {
+    const int m = q * G + j;
+    L.sq[m] = m_sqrt(L.fac4[m * 4 + Q4_WAVNUM]);
+    L.zcn[m] = stkw[q];
   }
   WSYNC();
   T EMEANWS;

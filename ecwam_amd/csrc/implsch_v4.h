@@ -675,26 +675,37 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       }
     }
   }
-  // ---- point scalars + first TAUT_Z0, one lane per point (sinflx.F90:105-122)
+  // ---- point scalars (sinflx.F90:105-122; the first TAUT_Z0 ran in k_implsch4_pre), one lane per point: the loads are unconditional
+  //      (every lane, of point lane mod PP) so that they are in flight with the tile's; the same for the factor tables below
+  const int pl = lane < PP ? lane : lane % PP;
+  const int pid = ij0 + (pl < n ? pl : n - 1);
+  const T* ffp = ffa + (size_t)pid * ECWAM_HIP_NFF;
+  const T* frp = fin + (size_t)pid * V4_NFIN;
+  const T p_aird = ffp[0], p_wdwave = ffp[1], p_ci = ffp[2], p_wswave = ffp[3], p_wstar = ffp[4], p_tauw = ffp[8], p_tauwdir = ffp[9];
+  const T p_emaxdpt = ffp[14], p_depth = ffp[15];
+  const T p_sinwd = frp[FIN_SINWD], p_coswd = frp[FIN_COSWD], p_rnfac = frp[FIN_RNFAC], p_cosdiff = frp[FIN_COSDIFF];
+  const T p_ufric = frp[FIN_UFRIC], p_z0m = frp[FIN_Z0M], p_z0b = frp[FIN_Z0B], p_chrnck = frp[FIN_CHRNCK];
+  const T* wp = wvprpt + (size_t)ij * ECWAM_HIP_NWPR * NFRE;
+  T w_wn[NS], w_cg[NS], w_ci[NS], w_xk[NS];   // WAVNUM, CGROUP, CINV, XK2CG of the lane's frequencies m = s G + j
+#pragma unroll
+  for (int q = 0; q < NS; q++) {
+    const int m = q * G + j;
+    w_wn[q] = wp[m]; w_cg[q] = wp[NFRE + m]; w_ci[q] = wp[2 * NFRE + m]; w_xk[q] = wp[3 * NFRE + m];
+  }
+  const T DEPTHv = ffa[(size_t)ij * ECWAM_HIP_NFF + 15];
+  const T CICOVERi = ffa[(size_t)ij * ECWAM_HIP_NFF + 2], CITHICKi = ffa[(size_t)ij * ECWAM_HIP_NFF + 13];
   if (lane < PP) {
-    const int pid = ij0 + (lane < n ? lane : n - 1);
-    const T* ff = ffa + (size_t)pid * ECWAM_HIP_NFF;
     T* q = sSC + lane * NSC;
-    const T AIRD = ff[0], WDWAVE = ff[1], WSWAVE = ff[3];
-    q[C_AIRD] = AIRD; q[C_WDWAVE] = WDWAVE; q[C_WSWAVE] = WSWAVE; q[C_WSTAR] = ff[4];
-    q[C_TAUW] = ff[8]; q[C_TAUWDIR] = ff[9];
-    q[C_RAORW] = m_max(AIRD, T(1)) * tb.ROWATERM1; q[C_EMAXDPT] = ff[14]; q[C_DEPTH] = ff[15];
-    // SIN / COS(WDWAVE), RNFAC and the first TAUT_Z0 (LLGCBZ0: its COSDIFF; it runs per point across the wave below): k_implsch4_pre
-    const T* fr = fin + (size_t)pid * V4_NFIN;
-    q[C_SINWD] = fr[FIN_SINWD]; q[C_COSWD] = fr[FIN_COSWD]; q[C_RNFAC] = fr[FIN_RNFAC];
-    if (EXT && tb.LLGCBZ0) q[C_TWCOS] = fr[FIN_COSDIFF];
-    q[C_UFRIC] = fr[FIN_UFRIC]; q[C_Z0M] = fr[FIN_Z0M]; q[C_Z0B] = fr[FIN_Z0B]; q[C_CHRNCK] = fr[FIN_CHRNCK];
-    q[C_SPARE] = ff[2];   // CICOVER
+    q[C_AIRD] = p_aird; q[C_WDWAVE] = p_wdwave; q[C_WSWAVE] = p_wswave; q[C_WSTAR] = p_wstar;
+    q[C_TAUW] = p_tauw; q[C_TAUWDIR] = p_tauwdir;
+    q[C_RAORW] = m_max(p_aird, T(1)) * tb.ROWATERM1; q[C_EMAXDPT] = p_emaxdpt; q[C_DEPTH] = p_depth;
+    q[C_SINWD] = p_sinwd; q[C_COSWD] = p_coswd; q[C_RNFAC] = p_rnfac;
+    if (EXT && tb.LLGCBZ0) q[C_TWCOS] = p_cosdiff;
+    q[C_UFRIC] = p_ufric; q[C_Z0M] = p_z0m; q[C_Z0B] = p_z0b; q[C_CHRNCK] = p_chrnck;
+    q[C_SPARE] = p_ci;   // CICOVER
   }
   // ---- per-frequency factors of the point: lane j fills M = j+1, j+1+G, ...
-  const T* wp = wvprpt + (size_t)ij * ECWAM_HIP_NWPR * NFRE;
   {
-    const T DEPTHv = ffa[(size_t)ij * ECWAM_HIP_NFF + 15];
     // sea-ice attenuation (implsch.F90:312-339): SDICE1 (scattering, sdice1.F90:104-181) and SDICE3 (viscous friction, sdice3.F90:110-160)
     // are, like SBOTTOM, a damping rate per (point, frequency): FLD += c, SL += c F.  The three rates share one slot of the table (the
     // reference adds them one after the other: the sums differ in rounding only).  SDICE2 depends on F itself and the NEMO coupling
@@ -702,8 +713,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     const bool ice1 = tb.LICERUN && tb.LCIWA1, ice3 = tb.LICERUN && tb.LCIWA3;
     T CICOVERv = T(0), CITHICKv = T(0), DINV = T(0), ALPFAC = tb.ZALPFACX;
     if (ice1 || ice3) {
-      CICOVERv = ffa[(size_t)ij * ECWAM_HIP_NFF + 2];
-      CITHICKv = ffa[(size_t)ij * ECWAM_HIP_NFF + 13];
+      CICOVERv = CICOVERi;
+      CITHICKv = CITHICKi;
       // broken ice attenuates less (icebreak_modify_attenuation.F90:82-93); IBRMEM is the input slot 15 of INTFLDS
       if (tb.LWNEMOCOUIBR && intfa[(size_t)ij * ECWAM_HIP_NINTF + 15] <= tb.ZIBRW_THRSH) ALPFAC = T(1) / tb.ZALPFACX;
     }
@@ -725,14 +736,16 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         DINV = T(1) / (SN / SD);
       }
     }
-    for (int m = j; m < NFRE; m += G) {
+#pragma unroll
+    for (int qq = 0; qq < NS; qq++) {
+      const int m = qq * G + j;
       T* f = L.fac4 + m * 4;
-      const T WAVNUM = wp[m], XK2CG = wp[3 * NFRE + m];
-      f[Q4_WAVNUM] = WAVNUM; f[Q4_CINV] = wp[2 * NFRE + m]; f[Q4_BSC] = WAVNUM * (T(1) / tb.ZPI) * XK2CG; L.sq[m] = m_sqrt(WAVNUM);
+      const T WAVNUM = w_wn[qq], XK2CG = w_xk[qq];
+      f[Q4_WAVNUM] = WAVNUM; f[Q4_CINV] = w_ci[qq]; f[Q4_BSC] = WAVNUM * (T(1) / tb.ZPI) * XK2CG; L.sq[m] = m_sqrt(WAVNUM);
       T sbo = T(0);   // sbottom.F90:79-89
       if (m < tb.NFRE_RED && DEPTHv < tb.BATHYMAX) sbo = (-T(2) * T(0.038) * tb.GM1) * WAVNUM / m_sinh(m_min(T(2) * DEPTHv * WAVNUM, T(50)));
       if (ice1 || ice3) {
-        const T CGROUP = wp[NFRE + m];
+        const T CGROUP = w_cg[qq];
         T dmp = T(0);
         if (ice1 && CITHICKv > T(0)) {   // CIDEAC(period, thickness), bilinear (sdice1.F90:135-163)
           const int NICT = tb.NICT, NICH = tb.NICH;

@@ -968,9 +968,15 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       else s = s + V2<T>{wx * rX[q], wx * rY[q]};
     }
     if (phiwa) {
-#pragma unroll   // (all 18 loads in flight at once)
+      // all 18 loads in flight at once: left to itself the compiler reuses one register pair and makes 18 round trips to memory,
+      // load - wait - use, one after the other (the scheduling barrier keeps the uses behind the last load)
+      V2<T> pv[NFRE / 2];
+#pragma unroll
+      for (int i = 0; i < NFRE / 2; i++) pv[i] = *reinterpret_cast<const V2<T>*>(gsp + (size_t)i * NANG);   // rows 2i, 2i+1
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
       for (int m = 0; m < NFRE; m += 2) {
-        const V2<T> v = *reinterpret_cast<const V2<T>*>(gsp + (size_t)(m >> 1) * NANG);   // rows m, m+1
+        const V2<T> v = pv[m >> 1];
         T w0 = lane_get(L.rRHOWG, m), w1 = lane_get(L.rRHOWG, m + 1);
         if (m + 1 == MIJ && MIJ != NFRE) w0 = T(0.5) * w0;
         if (m + 2 == MIJ && MIJ != NFRE) w1 = T(0.5) * w1;

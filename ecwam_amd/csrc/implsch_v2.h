@@ -13,7 +13,9 @@ enum {
   C_WSWAVE = 0, C_WDWAVE, C_TAUW, C_TAUWDIR, C_UFRIC, C_Z0M, C_Z0B, C_CHRNCK, C_AIRD, C_WSTAR, C_RNFAC, C_RAORW,
   C_XS, C_YS, C_PHIWA, C_MIJ, C_F1DCOS3, C_F1DCOS2, C_F1DSIN2, C_F1D, C_UORBT, C_AORB, C_SIGN, C_TEMP2, C_PTURB, C_AIRDPVISC,
   C_EMEAN, C_F1MEAN, C_EMAXDPT, C_DEPTH, C_SDS, C_SPARE,
-  C_XSN, C_YSN, C_UST, C_SINU, C_COSU, C_XLOGGZ0, C_SQRTGZ0, C_ZINF, C_SINWD, C_COSWD, C_TWSIN, C_TWCOS, C_ZSUP, C_HALP, NSC  // NSC = 46
+  C_XSN, C_YSN, C_UST, C_SINU, C_COSU, C_XLOGGZ0, C_SQRTGZ0, C_ZINF, C_SINWD, C_COSWD, C_TWSIN, C_TWCOS, C_ZSUP, C_HALP,
+  C_ZPIFRMIJ, C_FR5MIJ,   // ZPIFR(MIJ), FR5(MIJ): filled with C_MIJ so that STRESSO's dependent chain starts from LDS, not from a table in memory
+  NSC  // NSC = 48
 };
 
 // ---- LLGCBZ0 = T (gravity-capillary roughness model, flag set B) -------------------------------------------------------
@@ -220,7 +222,7 @@ __device__ void stresso_head_pt(const DevTab<T>& tb, T* c) {
   c[C_XSN] = XSTRESS; c[C_YSN] = YSTRESS; c[C_UST] = UST;
   c[C_SINU] = SINU; c[C_COSU] = COSU;
   const T X0G = tb.X0TAUHF * tb.G;
-  const T OMEGACC = m_max(tb.ZPIFR[MIJ - 1], X0G / UST);
+  const T OMEGACC = m_max(c[C_ZPIFRMIJ], X0G / UST);
   const T SQRTZ0OG = m_sqrt(Z0M * tb.GM1);
   c[C_XLOGGZ0] = m_log(tb.G * Z0M);
   c[C_SQRTGZ0] = T(1) / SQRTZ0OG;
@@ -251,7 +253,7 @@ __device__ __forceinline__ void stresso_tail_core(const DevTab<T>& tb, T* c, FN 
   const T SQRTGZ0 = c[C_SQRTGZ0];
   const T SQRTZ0OG = m_sqrt(Z0M * tb.GM1);
   const T ZINF = c[C_ZINF];
-  const T fr5 = tb.FR5[MIJ - 1];
+  const T fr5 = c[C_FR5MIJ];
   const T CONSTTAU = tb.ZPI4GM2 * fr5;
   T CONST1 = T(0), CONST2 = T(0);
   const bool NORMA = tb.LLNORMAGAM != 0;
@@ -1428,7 +1430,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(s
       F1DSIN2 = tb.DELTH * usum(fm * sinwdif2);
       F1D = tb.DELTH * usum(fm);
     }
-    if (L.lane == 0) { c[C_F1DCOS3] = F1DCOS3; c[C_F1DCOS2] = F1DCOS2; c[C_F1DSIN2] = F1DSIN2; c[C_F1D] = F1D; c[C_MIJ] = T(MIJ); }
+    if (L.lane == 0) { c[C_F1DCOS3] = F1DCOS3; c[C_F1DCOS2] = F1DCOS2; c[C_F1DSIN2] = F1DSIN2; c[C_F1D] = F1D; c[C_MIJ] = T(MIJ); c[C_ZPIFRMIJ] = tb.ZPIFR[MIJ - 1]; c[C_FR5MIJ] = tb.FR5[MIJ - 1]; }
   };
   // FRCUTINDEX (frcutindex.F90:84-108)
   auto frcutindex = [&](T FMEANWS, T UFRICv, T& rRH) -> int {

@@ -945,18 +945,17 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     return MIJ;
   };
   auto rrh = [&](int m, int MIJ) -> T {   // RHOWGDFTH(M), zero above MIJ, halved at MIJ (frcutindex.F90:98-107)
-    T r = T(0);
-    if (m + 1 <= MIJ) {
-      r = tb.RHOWG_DFIM[m];
-      if (m + 1 == MIJ && MIJ != NFRE) r = T(0.5) * r;
-    }
-    return r;
+    // RHOWG_DFIM(M) from the lane table (lane m holds it): an exchange through the LDS crossbar instead of a round trip to the table in memory
+    T r = v4_bp(4 * m, L.rRHOWG);
+    if (m + 1 == MIJ && MIJ != NFRE) r = T(0.5) * r;
+    return (m + 1 <= MIJ) ? r : T(0);
   };
   T rX[NS], rY[NS];
   T* sXY = sStg + p * NFRE * 2;   // 36 directions: [M][2] row integrals X, Y of the point (the staging rows are idle outside the sweep)
   T* gsp = fl1 + (size_t)ij * N + 2 * j;   // the point's FL1 block is dead until the final store: the second SINPUT parks its positive input there
   // stress sums below the cut-off and the F(:,MIJ) integrals of TAU_PHI_HF (stresso.F90:148-173, tau_phi_hf.F90:170-196)
   auto post_stress = [&](int MIJ, V2<T> apl, bool phiwa) {
+    const T zpm = tb.ZPIFR[MIJ - 1], f5m = tb.FR5[MIJ - 1];   // for STRESSO: in flight behind the sums below
     V2<T> s = z2;
     T sp = T(0);
 #pragma unroll
@@ -997,7 +996,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     }
     if (j == 0) {
       c[C_XS] = s.x; c[C_YS] = s.y; c[C_F1DCOS3] = tb.DELTH * h.x; c[C_F1DCOS2] = tb.DELTH * h.y; c[C_F1DSIN2] = tb.DELTH * hn.x; c[C_F1D] = tb.DELTH * hn.y;
-      c[C_MIJ] = (T)MIJ;
+      c[C_MIJ] = (T)MIJ; c[C_ZPIFRMIJ] = zpm; c[C_FR5MIJ] = f5m;
       if (phiwa) c[C_PHIWA] = PH;
     }
   };
@@ -1480,6 +1479,7 @@ __global__ void __launch_bounds__(64) k_implsch4_fin(const DevTab<T>* __restrict
   T c[NSC];
   c[C_AIRD] = fr[FIN_AIRD]; c[C_UFRIC] = fr[FIN_UFRIC]; c[C_Z0M] = fr[FIN_Z0M];
   c[C_MIJ] = m_min(m_max(fr[FIN_MIJ], T(1)), T(V4_NFRE));   // a table index: whatever the row holds, stay inside FR(1:NFRE)
+  c[C_ZPIFRMIJ] = tb.ZPIFR[(int)c[C_MIJ] - 1]; c[C_FR5MIJ] = tb.FR5[(int)c[C_MIJ] - 1];
   c[C_XS] = fr[FIN_XS]; c[C_YS] = fr[FIN_YS]; c[C_F1DCOS3] = fr[FIN_F1DCOS3]; c[C_F1DCOS2] = fr[FIN_F1DCOS2];
   c[C_F1DSIN2] = fr[FIN_F1DSIN2]; c[C_F1D] = fr[FIN_F1D]; c[C_RNFAC] = fr[FIN_RNFAC]; c[C_PHIWA] = fr[FIN_PHIWA];
   c[C_SINWD] = fr[FIN_SINWD]; c[C_COSWD] = fr[FIN_COSWD];

@@ -1303,12 +1303,14 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   const T Z0B = c[C_Z0B], CHRNCK = c[C_CHRNCK];
   // the Stokes-drift weights STOKFAC(M) DFIM_SIM(M) of the lane's frequencies: loaded here, used behind the flux sums (their
   // round trip to memory hides behind the three all-reduces)
-  T stkw[NS];
+  T stkw[NS], stkd[NS];
 #pragma unroll
-  for (int q = 0; q < NS; q++) {
+  for (int q = 0; q < NS; q++) {   // unconditional loads, pinned here (a conditional one is sunk into a branch behind the sums: load, wait, twice)
     const int m = q * G + j;
-    stkw[q] = (m < tb.NFRE_ODD) ? wp[4 * NFRE + m] * tb.DFIM_SIM[m] : T(0);
+    stkw[q] = wp[4 * NFRE + m];
+    stkd[q] = tb.DFIM_SIM[m];
   }
+  __builtin_amdgcn_sched_barrier(0);
 
   // ---- WNFLUXES (wnfluxes.F90:147-190): the directional sums of the flux accumulators; the rest of it in k_implsch4_fin
   T PHILF = T(0), XSTRESS = T(0), YSTRESS = T(0);
@@ -1326,7 +1328,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   for (int q = 0; q < NS; q++) {
     const int m = q * G + j;
     L.sq[m] = m_sqrt(L.fac4[m * 4 + Q4_WAVNUM]);
-    L.zcn[m] = stkw[q];
+    L.zcn[m] = (m < tb.NFRE_ODD) ? stkw[q] * stkd[q] : T(0);
   }
   WSYNC();
   T EMEANWS;

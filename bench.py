@@ -26,10 +26,6 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from ecwam_amd import grid as G  # noqa: E402
-from ecwam_amd.tables import Config  # noqa: E402
-from ecwam_amd.wamintgr import Wamintgr  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
@@ -56,9 +52,33 @@ def usable_cores() -> int:
     return n
 
 
+def self_launch(a, argv) -> None:
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks as a CHILD process -- one
+    torch.distributed.run with N workers, rendezvous on 127.0.0.1 -- before this process has made any GPU call (never an exec
+    after one), let its output through (rank 0 prints the JSON line) and exit with its code.  Fewer than N visible devices is an
+    error, not a silent one-GPU run (torch.cuda.device_count() does not initialise the GPU)."""
+    import socket
+    import subprocess
+
+    ndev = torch.cuda.device_count()
+    if not a.share_gpu and ndev < a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but only {ndev} GPU(s) visible (use --share-gpu to rehearse the N>1 code on one GPU)")
+    if a.share_gpu and ndev < 1:
+        raise SystemExit("bench.py: --share-gpu needs one GPU")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    print(f"[bench] no launcher (WORLD_SIZE unset): starting {a.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.run(cmd).returncode)
+
+
 def cpu_baseline(nang: int, nfre: int, prec: str, target_s: float = 15.0) -> dict:
     """Oracle (plain-C restatement, OpenMP over points) timed on this host on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ecwam_amd import grid as G
+    from ecwam_amd.tables import Config
     cores = int(os.environ.get("ECWAM_BENCH_CPU_THREADS", "0")) or usable_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)     # read by libgomp when the oracle library is loaded below
     from ecwam_amd import synthetic as syn
@@ -123,8 +143,9 @@ def main() -> None:
                     help="advection steps per source-term step (1: the O320 configuration; 2: O1280's native 450 s / 900 s ratio)")
     ap.add_argument("--ifrelfmax", type=int, default=0,
                     help="fast waves: frequencies 1..IFRELFMAX advected with two sub-steps of half the time step (O1280: 5)")
-    ap.add_argument("--halo", default="torch", choices=["torch", "lib", "host"],
-                    help="halo exchange: torch.distributed P2P (RCCL), the library's own RCCL exchange (ecwam_hip_halo_start/_finish), "
+    ap.add_argument("--halo", default="lib", choices=["lib", "torch", "host"],
+                    help="halo exchange (N > 1): the library's own MPEXCHNG (ecwam_hip_halo_start/_finish: grouped RCCL send/recv on the "
+                         "library's stream -- what WAMINTGR_HIP calls; the default), torch.distributed P2P on packed buffers (RCCL), "
                          "or host staged through the CPU backend")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal of the N>1 code on ONE GPU: every rank uses device 0, process group on gloo, host-staged halo")
@@ -133,11 +154,18 @@ def main() -> None:
                     help="refraction: 0 none (BASELINE configurations), 1 depth, 2 currents, 3 both (synthetic current field)")
     a = ap.parse_args()
 
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a, sys.argv[1:])          # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    from ecwam_amd import grid as G
+    from ecwam_amd.tables import Config
+    from ecwam_amd.wamintgr import Wamintgr
     if a.share_gpu:
         local_rank, a.halo = 0, "host"
     torch.cuda.set_device(local_rank)
@@ -158,21 +186,27 @@ def main() -> None:
     dt = 450 if ng <= 320 else max(15, int(450 * 320 / ng) // 15 * 15)
     cfg = Config(nang=a.nang, nfre=a.nfre, nfre_red=a.nfre, idelt=dt, idelpro=dt, irefra=a.irefra)
     grid = G.build_grid(ng)
+    # N > 1: the model starts on the host-staged transport (no RCCL involved: it cannot fail to set up), then moves to the asked one
     m = Wamintgr(cfg, grid, a.prec, device=local_rank, rank=rank, nranks=world, weights=a.weights, strip_width=a.strip,
-                 ifrelfmax=a.ifrelfmax, delpro_lf=(dt / 2.0 if a.ifrelfmax else None), halo_transport=a.halo)
+                 ifrelfmax=a.ifrelfmax, delpro_lf=(dt / 2.0 if a.ifrelfmax else None), halo_transport="host" if world > 1 else "torch")
     m.init_synthetic()
     m.ff_next = m.ff.clone()      # NEWWIND hands the (unchanged synthetic) forcing over every step: k_newwind is part of the step
     nfail = m.build_weights()
     if nfail:
         raise SystemExit(f"CFL violated at {nfail} points")
 
-    # ---- N > 1: check the halo exchange once before anything is timed -- every rank fills its owned rows with the global point
-    #      index, exchanges, and compares its halo rows with the indices its neighbours own.  A transport that raises or delivers
-    #      something else on ANY rank (first run on a new node: RCCL point-to-point set-up) is replaced by the host-staged one on
-    #      all ranks, and the JSON line says so.
-    halo_used = a.halo
+    # ---- N > 1: set the asked halo transport up and check it once before anything is timed -- every rank fills its owned rows with
+    #      the global point index, exchanges, and compares its halo rows with the indices its neighbours own.  A transport that
+    #      raises or delivers something else on ANY rank (first run on a new node: RCCL communicator / point-to-point set-up) is
+    #      replaced by the host-staged one on all ranks, and the JSON line says so.
+    halo_used, halo_ranks = a.halo, None
     if world > 1:
         from ecwam_amd.wamintgr import HaloExchange
+
+        def all_ok(ok: bool) -> bool:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)          # CPU tensor: reduced over gloo
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(int(flag.item()))
 
         def halo_ok() -> bool:
             try:
@@ -183,18 +217,25 @@ def main() -> None:
                 want = torch.from_numpy(np.asarray(m.dom.halo_global, dtype=np.float64) % 65536.0).to(t.dtype)
                 return bool(torch.equal(t[m.n: m.n + m.dom.nh, 0, 0].cpu(), want))
             except Exception as e:          # noqa: BLE001 -- any failure of the transport means: use the other one
-                print(f"[bench] rank {rank}: halo transport '{a.halo}' failed its self-check: {e!r}", file=sys.stderr, flush=True)
+                print(f"[bench] rank {rank}: halo transport '{m.halo.transport}' failed its self-check: {e!r}", file=sys.stderr, flush=True)
                 return False
 
-        flag = torch.tensor([1 if halo_ok() else 0], dtype=torch.int32)          # CPU tensor: reduced over gloo
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0 and a.halo != "host":
-            m.halo = HaloExchange(m.dom, m.dev, m.ctx, transport="host")
-            halo_used = f"host (fallback: '{a.halo}' failed the self-check)"
-            flag = torch.tensor([1 if halo_ok() else 0], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
+        host_halo = m.halo
+        if a.halo != "host":
+            try:
+                m.halo = HaloExchange(m.dom, m.dev, m.ctx, transport=a.halo)      # "lib": ncclCommInitRank inside the library
+                ok = True
+            except Exception as e:          # noqa: BLE001
+                print(f"[bench] rank {rank}: halo transport '{a.halo}' could not be set up: {e!r}", file=sys.stderr, flush=True)
+                ok = False
+            if not all_ok(ok) or not all_ok(halo_ok()):
+                m.halo = host_halo
+                m.ctx.halo_setup(m.dom)
+                halo_used = f"host (fallback: '{a.halo}' failed its set-up or self-check)"
+        if isinstance(halo_used, str) and halo_used.startswith("host") and not all_ok(halo_ok()):
             raise SystemExit("halo exchange self-check failed")
+        if m.halo.transport == "lib":
+            halo_ranks = m.ctx.comm_count()       # what RCCL itself says (ncclCommCount)
 
     def sync():
         torch.cuda.synchronize()
@@ -292,7 +333,8 @@ def main() -> None:
                                    + (f", {a.adv_per_source} advection steps per source step" if a.adv_per_source != 1 else "")
                                    + (f", fast waves M<={a.ifrelfmax} in two sub-steps" if a.ifrelfmax else ""),
                        "points_per_gpu": m.n, "halo_points": m.dom.nh, "parallelism": f"sea-point block x{world}",
-                       "halo": halo_used if world > 1 else None},
+                       "halo": halo_used if world > 1 else None, "halo_rccl_ranks": halo_ranks,
+                       "ranks": world, "share_gpu": bool(a.share_gpu)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "committed_pmc: profiles/r02_hbm_traffic_pmc.json" if traffic is not None else None},

@@ -328,6 +328,12 @@ class HipContext:
             raise ValueError("RCCL unique id: 128 bytes")
         self._chk(self.lib.ecwam_hip_comm_init(self._h, uid))
 
+    def comm_count(self) -> int:
+        """Ranks of the library's RCCL communicator as RCCL reports them (0: none)."""
+        k = C.c_int(0)
+        self._chk(self.lib.ecwam_hip_comm_count(self._h, C.byref(k)))
+        return int(k.value)
+
     def _rows(self, fl):
         if not (fl.is_cuda and fl.is_contiguous() and fl.dtype == self.dtype and fl.dim() == 3):
             raise ValueError("halo: expected a contiguous device tensor [rows][NANG][M] of the context's precision")

@@ -45,6 +45,7 @@ struct ecwam_hip_ctx {
   ncclComm_t comm = nullptr;
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_packed = nullptr, ev_done = nullptr;
+  bool halo_inflight = false;   // an exchange has been posted whose ev_done no later halo_start has waited for
   ecwam_hip_params p;
   const void* obs = nullptr;  // LSUBGRID: device OBS[n_obs][8][NFRE] (ecwam_hip_set_obstructions), read by CTUW / PROPAGS2
   int n_obs = 0;
@@ -272,6 +273,7 @@ struct RcclApi {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclSend) Send = nullptr;
@@ -285,7 +287,7 @@ static int rccl_load() {
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!h) return fail(std::string("RCCL not found (dlopen librccl.so.1): ") + dlerror());
 #define SYM_(f) g_rccl.f = (decltype(g_rccl.f))dlsym(h, "nccl" #f); if (!g_rccl.f) return fail("librccl: symbol nccl" #f " missing")
-  SYM_(GetUniqueId); SYM_(CommInitRank); SYM_(CommDestroy); SYM_(GroupStart); SYM_(GroupEnd); SYM_(Send); SYM_(Recv); SYM_(GetErrorString);
+  SYM_(GetUniqueId); SYM_(CommInitRank); SYM_(CommDestroy); SYM_(CommCount); SYM_(GroupStart); SYM_(GroupEnd); SYM_(Send); SYM_(Recv); SYM_(GetErrorString);
 #undef SYM_
   g_rccl.h = h;
   return 0;
@@ -785,9 +787,22 @@ int ecwam_hip_comm_init(ecwam_hip_ctx* c, const void* id128) {
   if (c->nranks < 2) return 0;
   if (rccl_load()) return 1;
   HIPCHK(hipSetDevice(c->device));
+  if (c->comm) {   // a second initialisation replaces the communicator: let the posted exchange finish, then release the old one
+    if (c->comm_stream) HIPCHK(hipStreamSynchronize(c->comm_stream));
+    (void)g_rccl.CommDestroy(c->comm);
+    c->comm = nullptr; c->halo_inflight = false;
+  }
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
   NCCLCHK(g_rccl.CommInitRank(&c->comm, c->nranks, id, c->rank));
+  return 0;
+}
+
+int ecwam_hip_comm_count(ecwam_hip_ctx* c, int* nranks) {
+  if (!c || !nranks) return fail("ecwam_hip_comm_count: null argument");
+  *nranks = 0;
+  if (!c->comm) return 0;
+  NCCLCHK(g_rccl.CommCount(c->comm, nranks));
   return 0;
 }
 
@@ -814,6 +829,9 @@ int ecwam_hip_halo_start(ecwam_hip_ctx* c, void* fl, int rowlen, void* stream) {
   if (!c->comm) return fail("ecwam_hip_halo_start: no communicator (ecwam_hip_comm_init)");
   hipStream_t s = (hipStream_t)stream;
   HIPCHK(hipSetDevice(c->device));
+  // the send buffer is reused: the sends of the previous exchange must have read it before this pack overwrites it (a caller
+  // that skipped ecwam_hip_halo_finish, e.g. on an error path, would otherwise race with them)
+  if (c->halo_inflight) HIPCHK(hipStreamWaitEvent(s, c->ev_done, 0));
   if (halo_pack(c, fl, rowlen, s)) return 1;
   HIPCHK(hipEventRecord(c->ev_packed, s));                     // everything enqueued on `stream` so far, the pack included
   HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
@@ -827,6 +845,7 @@ int ecwam_hip_halo_start(ecwam_hip_ctx* c, void* fl, int rowlen, void* stream) {
   }
   NCCLCHK(g_rccl.GroupEnd());
   HIPCHK(hipEventRecord(c->ev_done, c->comm_stream));
+  c->halo_inflight = true;
   return 0;
 }
 

@@ -43,10 +43,13 @@ class HaloExchange:
                 uid = torch.zeros(128, dtype=torch.uint8)
                 if dom.rank == 0:
                     uid = torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8).clone()
-                on_gpu = dist.get_backend() == "nccl"
-                t = uid.to(device) if on_gpu else uid
-                dist.broadcast(t, src=0)
-                ctx.comm_init(bytes(t.cpu().numpy().tobytes()))
+                try:                          # a CPU tensor where the group has a CPU backend (gloo, or "cpu:gloo,cuda:nccl") ...
+                    dist.broadcast(uid, src=0)
+                except RuntimeError:          # ... a device tensor in a pure RCCL group (the same on every rank)
+                    t = uid.to(device)
+                    dist.broadcast(t, src=0)
+                    uid = t.cpu()
+                ctx.comm_init(bytes(uid.numpy().tobytes()))
 
     def start(self, fl: torch.Tensor) -> list:
         """Pack the rows the neighbours need and post every send / receive; returns the pending requests.  Until `finish`

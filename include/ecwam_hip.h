@@ -39,7 +39,7 @@ extern "C" {
 #define ECWAM_HIP_MAXANG 48
 /* bumped whenever ecwam_hip_params / ecwam_hip_tables or an entry point changes: 2 = refraction entry points, SDICE1 table and
  * ice break-up parameters added.  ecwam_hip_abi_version() returns the value the library was built with. */
-#define ECWAM_HIP_ABI_VERSION 2
+#define ECWAM_HIP_ABI_VERSION 3
 #define ECWAM_HIP_MAXFRE 48
 #define ECWAM_HIP_MAXMC 56     /* MLSTHG = NFRE - ISM <= 48 + 8 */
 #define ECWAM_HIP_MAXTAP 47    /* 2*NSDSNTH+1, NSDSNTH <= NANG/2-1 */
@@ -331,6 +331,7 @@ int ecwam_hip_halo_setup(ecwam_hip_ctx *ctx, int rank, int nranks, int npeers, c
 int ecwam_hip_halo_counts(ecwam_hip_ctx *ctx, int *n_send, int *n_recv);
 int ecwam_hip_comm_unique_id(void *id128);
 int ecwam_hip_comm_init(ecwam_hip_ctx *ctx, const void *id128);
+int ecwam_hip_comm_count(ecwam_hip_ctx *ctx, int *nranks);   /* ranks of the RCCL communicator (ncclCommCount); 0 without one */
 int ecwam_hip_halo_start(ecwam_hip_ctx *ctx, void *fl, int rowlen, void *stream);
 int ecwam_hip_halo_finish(ecwam_hip_ctx *ctx, void *stream);
 int ecwam_hip_halo_pack_host(ecwam_hip_ctx *ctx, const void *fl, int rowlen, void *host_send, void *stream);

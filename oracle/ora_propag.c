@@ -193,6 +193,42 @@ void ora_propags2(int KIJS, int KIJL, const real *F1, real *F3, const int *KLON,
 #undef FF1
 }
 
+/* propag_wam.F90:247-313, IPROPAGS = 2 without refraction: the PROPAG_WAM advection sequence on ONE domain (MPEXCHNG returns at once
+ * when NPROC <= 1, mpexchng.F90:106-109).  The weights are the ones CTUWUPDT leaves behind (ctuwupdt.F90:220-256): with IFRELFMAX > 0
+ * DELPRO_LF for M <= IFRELFMAX and IDELPRO above, i.e. two ora_ctuw calls into the same arrays.
+ *   :247-254  PROPAGS2(FL1_EXT, FL3_EXT, ..., ND3SF1=1, ND3EF1=NFRE_RED, ND3S=1, ND3E=NFRE_RED)
+ *   :257-259  NSTEP_LF = NINT(REAL(IDELPRO)/DELPRO_LF); ISUBST = 2
+ *   :261-264  ND3SF1 = 1, ND3EF1 = IFRELFMAX+1, ND3S = 1, ND3E = IFRELFMAX
+ *   :266-311  DO WHILE (ISUBST <= NSTEP_LF): FL1_EXT(IJ,K,ND3S:ND3E) = FL3_EXT(IJ,K,ND3S:ND3E) for the owned points; MPEXCHNG; PROPAGS2
+ *   :373-386  FL1(IJ,K,M,ICHNK) = FL3_EXT(..) for M <= NFRE_RED (block -> chunk; M > NFRE_RED is not touched).
+ * FL1_EXT: [(n+1)][NANG][NFRE] in/out, row n = the land slot (zero, propag_wam.F90:146); FL3_EXT: scratch of the same shape.
+ * Returns NSTEP_LF (1 when the fast waves are not sub-stepped). */
+int ora_propag_wam(int n, real *FL1_EXT, real *FL3_EXT, const int *KLON, const int *KLAT, const int *KCOR, const real *SUMWN,
+                   const real *WLONN, const real *WLATN, const real *WCORN, const real *WKPMN, int IFRELFMAX, int IDELPRO,
+                   real DELPRO_LF) {
+  const int NANG = S.NANG, NFRE = S.NFRE, NR = S.NFRE_RED;
+  int NSTEP_LF = 1;
+  for (size_t i = 0; i < (size_t)NANG * NFRE; i++) FL1_EXT[(size_t)n * NANG * NFRE + i] = C_(0.0);
+  ora_propags2(0, n, FL1_EXT, FL3_EXT, KLON, KLAT, KCOR, SUMWN, WLONN, WLATN, WCORN, WKPMN, 1, NR);
+  if (IFRELFMAX > 0 && IFRELFMAX < NR) {
+    NSTEP_LF = NINT((real)IDELPRO / DELPRO_LF);
+    int ISUBST = 2;
+    const int ND3S = 1, ND3E = IFRELFMAX;
+    while (ISUBST <= NSTEP_LF) {
+      for (int IJ = 0; IJ < n; IJ++)
+        for (int K = 0; K < NANG; K++)
+          for (int M = ND3S - 1; M < ND3E; M++)
+            FL1_EXT[((size_t)IJ * NANG + K) * NFRE + M] = FL3_EXT[((size_t)IJ * NANG + K) * NFRE + M];
+      ora_propags2(0, n, FL1_EXT, FL3_EXT, KLON, KLAT, KCOR, SUMWN, WLONN, WLATN, WCORN, WKPMN, ND3S, ND3E);
+      ISUBST++;
+    }
+  }
+  for (int IJ = 0; IJ < n; IJ++)
+    for (int K = 0; K < NANG; K++)
+      for (int M = 0; M < NR; M++) FL1_EXT[((size_t)IJ * NANG + K) * NFRE + M] = FL3_EXT[((size_t)IJ * NANG + K) * NFRE + M];
+  return NSTEP_LF;
+}
+
 /* Timing variant of PROPAGS2 for bench.py's cpu_baseline: the reference keeps its weight arrays with IJ fastest, so the eight
  * weights the stencil reads are eight contiguous streams for its compiler; the [ij][k][m][..] layout of this restatement makes them
  * strided and drags the ten unused weights per element through the caches.  ora_pack_w8 packs the eight once as W8[ij][8][K][M]

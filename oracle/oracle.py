@@ -172,10 +172,11 @@ class Oracle:
         self._obs = None if obs is None else np.ascontiguousarray(obs, dtype=self.dtype)
         self.lib.ora_set_obstructions(None if self._obs is None else self._p(self._obs))
 
-    def ctu_weights(self, grid, cgroup_ext, delpro, mstart=1, mend=None):
+    def ctu_weights(self, grid, cgroup_ext, delpro, mstart=1, mend=None, into=None):
         """CTUWINI + CTUW for all owned points of `grid` (a ecwam_amd.grid.Grid-like object).
         cgroup_ext: [(npts+1)][NFRE] incl. land row.  Returns dict of reference-shaped weight arrays and
-        the (mutated) WLAT/WCOR."""
+        the (mutated) WLAT/WCOR.  into: the result of an earlier call whose arrays receive the range mstart..mend (the
+        second CTUWDRV call of ctuwupdt.F90:241-254); its failure flags are kept."""
         T = self.dtype
         n, nland = grid.nsea, grid.nland
         NANG, NR = self.NANG, self.NFRE_RED
@@ -196,11 +197,14 @@ class Oracle:
         dp = np.zeros((n, 2), T)
         self.lib.ora_ctuwini(C.c_int(n), C.c_int(nland), C.c_int(grid.ngy), self._p(kxlt), self._p(cosph), self._p(cosphm1),
                              self._p(klat), self._p(kcor), self._p(wlat), self._p(wcor), self._p(wlatm1), self._p(wcorm1), self._p(dp))
-        sumwn = np.zeros((n, NANG, NR), T)
-        wlonn = np.zeros((n, NANG, NR, 2), T)
-        wlatn = np.zeros((n, NANG, NR, 2, 2), T)
-        wcorn = np.zeros((n, NANG, NR, 4, 2), T)
-        wkpmn = np.zeros((n, NANG, NR, 3), T)
+        if into is not None:
+            sumwn, wlonn, wlatn, wcorn, wkpmn = (into[k] for k in ("SUMWN", "WLONN", "WLATN", "WCORN", "WKPMN"))
+        else:
+            sumwn = np.zeros((n, NANG, NR), T)
+            wlonn = np.zeros((n, NANG, NR, 2), T)
+            wlatn = np.zeros((n, NANG, NR, 2, 2), T)
+            wcorn = np.zeros((n, NANG, NR, 4, 2), T)
+            wkpmn = np.zeros((n, NANG, NR, 3), T)
         fail = np.zeros(n, np.int32)
         creal = C.c_float if T == np.float32 else C.c_double
         self.lib.ora_ctuw.restype = C.c_int
@@ -209,7 +213,37 @@ class Oracle:
                                   self._p(wlat), self._p(wcor), self._p(wlatm1), self._p(wcorm1), self._p(dp), self._p(cg),
                                   self._p(cosphm1), self._p(sumwn), self._p(wlonn), self._p(wlatn), self._p(wcorn), self._p(wkpmn),
                                   self._p(fail))
+        if into is not None:
+            fail |= into["FAIL"]
+            nfail = int(fail.sum())
         return dict(SUMWN=sumwn, WLONN=wlonn, WLATN=wlatn, WCORN=wcorn, WKPMN=wkpmn, WLAT=wlat, WCOR=wcor, NFAIL=nfail, FAIL=fail)
+
+    def ctu_weights_wam(self, grid, cgroup_ext, idelpro, ifrelfmax=0, delpro_lf=None):
+        """CTUWUPDT's weight set (ctuwupdt.F90:220-256): one CTUWDRV call over all frequencies, or -- IFRELFMAX > 0 -- DELPRO_LF for
+        the fast waves M <= IFRELFMAX and IDELPRO for the rest."""
+        if ifrelfmax <= 0:
+            return self.ctu_weights(grid, cgroup_ext, float(idelpro))
+        w = self.ctu_weights(grid, cgroup_ext, float(delpro_lf), 1, ifrelfmax)
+        if ifrelfmax < self.NFRE_RED:
+            w = self.ctu_weights(grid, cgroup_ext, float(idelpro), ifrelfmax + 1, self.NFRE_RED, into=w)
+        return w
+
+    def propag_wam(self, grid, fl1_ext, w, idelpro, ifrelfmax=0, delpro_lf=None):
+        """PROPAG_WAM's advection sequence on one domain (propag_wam.F90:247-313 + the block -> chunk copy :373-386): PROPAGS2 on all
+        frequencies, then NSTEP_LF-1 sub-steps on the fast waves.  fl1_ext: [(npts+1)][NANG][NFRE], land row last.  Returns the new
+        FL1_EXT (M > NFRE_RED unchanged) and NSTEP_LF."""
+        T = self.dtype
+        f1 = np.array(fl1_ext, dtype=T, order="C")
+        assert f1.shape[0] == grid.nsea + 1
+        f3 = np.zeros_like(f1)
+        g = self._grid_arrays(grid)
+        creal = C.c_float if T == np.float32 else C.c_double
+        self.lib.ora_propag_wam.restype = C.c_int
+        nstep = self.lib.ora_propag_wam(C.c_int(grid.nsea), self._p(f1), self._p(f3), self._p(g["klon"]), self._p(g["klat"]),
+                                        self._p(g["kcor"]), self._p(w["SUMWN"]), self._p(w["WLONN"]), self._p(w["WLATN"]),
+                                        self._p(w["WCORN"]), self._p(w["WKPMN"]), C.c_int(int(ifrelfmax)), C.c_int(int(idelpro)),
+                                        creal(float(delpro_lf) if delpro_lf else 0.0))
+        return f1, nstep
 
     def propags2(self, grid, f1, w, nd3s=1, nd3e=None):
         """f1: [(npts+1)][NANG][NFRE] (land row zero). Returns F3 with the same shape (rows >= nsea untouched = 0)."""

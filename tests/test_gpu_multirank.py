@@ -23,18 +23,37 @@ def _run(cmd, env):
     return json.loads(line)
 
 
-@pytest.mark.parametrize("nranks", [2, 3])
-def test_bench_two_ranks_on_one_gpu_match_single_rank(tmp_path, nranks):
+@pytest.mark.parametrize("nranks,launcher", [(2, "self"), (3, "torchrun")])
+def test_bench_two_ranks_on_one_gpu_match_single_rank(tmp_path, nranks, launcher):
+    """launcher "self": the driver's command shape, `python bench.py --gpus N ...` with WORLD_SIZE unset -- bench.py starts its own N
+    ranks as a child process; "torchrun": started under torch.distributed.run as the contract's N > 1 command does."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
     common = ["--grid", "48", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
     one = _run([sys.executable, "bench.py", "--gpus", "1", "--dump", str(tmp_path / "one")] + common, env)
-    port = 29500 + (os.getpid() % 2000) + nranks
-    many = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}", "--master-addr", "127.0.0.1",
-                 "--master-port", str(port), "bench.py", "--gpus", str(nranks), "--share-gpu", "--dump", str(tmp_path / "many")] + common, env)
-    assert many["n_gpus"] == nranks and many["config"]["halo"] == "host" and many["finite"] and one["finite"]
+    tail = ["bench.py", "--gpus", str(nranks), "--share-gpu", "--dump", str(tmp_path / "many")] + common
+    if launcher == "self":
+        many = _run([sys.executable] + tail, env)
+    else:
+        port = 29500 + (os.getpid() % 2000) + nranks
+        many = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}", "--master-addr", "127.0.0.1",
+                     "--master-port", str(port)] + tail, env)
+    assert many["n_gpus"] == nranks and many["config"]["ranks"] == nranks and many["config"]["halo"] == "host" and many["finite"] and one["finite"]
     a = np.load(str(tmp_path / "one") + ".0.npy")
     b = np.concatenate([np.load(str(tmp_path / "many") + f".{r}.npy") for r in range(nranks)])
     assert a.shape == b.shape and np.array_equal(a, b)
     assert many["value"] > 0 and abs(many["swh_norm_rank0"]["max"]) < 50
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`bench.py --gpus N` on a node with fewer than N devices must fail loudly, not run one rank (a one-GPU figure in an N-GPU record)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and "visible" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

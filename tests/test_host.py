@@ -25,7 +25,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
     for name in declared:
         assert getattr(h, name) is not None
-    assert h.ecwam_hip_abi_version() == int(re.search(r"#define ECWAM_HIP_ABI_VERSION (\d+)", hdr).group(1)) == 2
+    assert h.ecwam_hip_abi_version() == int(re.search(r"#define ECWAM_HIP_ABI_VERSION (\d+)", hdr).group(1)) == 3
     # the parameter struct seen from Python has the size the C compiler gives it
     src = '#include "ecwam_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu", sizeof(ecwam_hip_params), sizeof(ecwam_hip_tables));return 0;}'
     import tempfile
@@ -179,6 +179,68 @@ def test_oracle_decomposed_advection_equals_global():
         wl = o.ctu_weights(lg, cg[ext], 900.0)
         f3l = o.propags2(lg, f1[ext], wl)
         assert np.array_equal(f3l[: d.n], f3[d.lo:d.hi])
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+def test_oracle_propag_wam_is_the_reference_call_sequence(prec):
+    """ora_propag_wam (propag_wam.F90:247-313) against the same sequence written out call by call with an independent numpy
+    stencil of propags2.F90:107-116 fed with the oracle's weight arrays: the two time steps meet in one weight set
+    (ctuwupdt.F90:220-256), the fast waves are advected NSTEP_LF times with DELPRO_LF, the slow waves once with IDELPRO."""
+    from oracle.oracle import Oracle
+
+    cfg = Config(nang=12, nfre=36, nfre_red=25, idelpro=900)
+    g = G.build_grid(12, mask="continents")
+    o = Oracle(cfg, prec)
+    dt = np.float32 if prec == "sp" else np.float64
+    t = Tables(cfg, dt)
+    rng = np.random.default_rng(3)
+    n, NANG, NR, lf, dlf = g.nsea, 12, 25, 6, 300.0
+    cg = rng.uniform(3, 12, (n + 1, 36)).astype(dt)
+    f1 = np.zeros((n + 1, NANG, 36), dt)
+    f1[:n] = rng.uniform(0, 1, (n, NANG, 36))
+    w = o.ctu_weights_wam(g, cg, cfg.idelpro, lf, dlf)
+    wf = o.ctu_weights(g, cg, dlf)            # every frequency with the fast-wave step
+    ws = o.ctu_weights(g, cg, 900.0)          # every frequency with the full step
+    for k in ("SUMWN", "WLONN", "WLATN", "WCORN", "WKPMN"):
+        assert np.array_equal(w[k][:, :, :lf], wf[k][:, :, :lf]) and np.array_equal(w[k][:, :, lf:], ws[k][:, :, lf:])
+    assert w["NFAIL"] == 0
+
+    jxo, jyo, kcr = np.asarray(t.JXO)[:, 0] - 1, np.asarray(t.JYO)[:, 0] - 1, np.asarray(t.KCR)[:, 0] - 1
+    K = np.arange(NANG)
+    km, kp = (K - 1) % NANG, (K + 1) % NANG
+
+    def stencil(f, m0, m1):
+        """F3(IJ,K,M) of propags2.F90:107-116 for M in [m0, m1), terms in the reference's order."""
+        out = np.zeros((n, NANG, m1 - m0), dt)
+        for k in range(NANG):
+            sl = (slice(0, n), k, slice(m0, m1))
+            fo = f[:n, k, m0:m1]
+            acc = (dt(1.0) - w["SUMWN"][sl]) * fo
+            acc = acc + w["WLONN"][sl + (jxo[k],)] * f[g.klon[:, jxo[k]], k, m0:m1]
+            for icl in range(2):
+                acc = acc + w["WLATN"][sl + (jyo[k], icl)] * f[g.klat[:, jyo[k], icl], k, m0:m1]
+            for icl in range(2):
+                acc = acc + w["WCORN"][sl + (0, icl)] * f[g.kcor[:, kcr[k], icl], k, m0:m1]
+            acc = acc + w["WKPMN"][sl + (0,)] * f[:n, km[k], m0:m1]
+            acc = acc + w["WKPMN"][sl + (2,)] * f[:n, kp[k], m0:m1]
+            out[:, k] = acc
+        return out
+
+    f3 = f1.copy()
+    f3[:n, :, :NR] = stencil(f1, 0, NR)
+    ext = f1.copy()
+    for _ in range(2, 4):                      # NSTEP_LF = NINT(900 / 300) = 3: sub-steps 2 and 3
+        ext[:n, :, :lf] = f3[:n, :, :lf]
+        f3[:n, :, :lf] = stencil(ext, 0, lf)
+    got, nstep = o.propag_wam(g, f1, w, cfg.idelpro, lf, dlf)
+    assert nstep == 3
+    assert np.array_equal(got[:n, :, NR:], f1[:n, :, NR:]) and not got[n].any()
+    eps = np.finfo(dt).eps
+    assert np.abs(got[:n, :, :NR].astype(float) - f3[:n, :, :NR].astype(float)).max() <= 4 * eps      # numpy may fuse nothing: same order
+    # without sub-steps the composed call is PROPAGS2 itself
+    one, nstep = o.propag_wam(g, f1, ws, cfg.idelpro, 0, None)
+    ref = o.propags2(g, f1, ws)
+    assert nstep == 1 and np.array_equal(one[:n, :, :NR], ref[:n, :, :NR])
 
 
 def test_oracle_physics_invariants():

@@ -1,7 +1,9 @@
 """Build libecwam_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
 from __future__ import annotations
 
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -14,49 +16,92 @@ SOURCES = ["capi.hip", "propag.hip", "implsch.hip", "implsch4.hip", "outbs.hip"]
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # IMPLSCH is VALU-issue bound: single-precision divide/sqrt by the hardware reciprocal / square root plus one
 # refinement (<= 2.5 ulp) instead of the correctly rounded sequences; double precision is unaffected.
-EXTRA = {"implsch.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt"], "implsch4.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]}
+FAST_DIV = ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
-
+IMPLSCH_SOURCES = ("implsch.hip", "implsch4.hip")
+# Build variants of the IMPLSCH translation units (the single-precision error attribution):
+#   ""         the product build: hardware reciprocal / square root / exp2 / log2 in single precision, FMA contraction on
+#   "strict1"  ECWAM_HIP_STRICT=1: divisions and square roots correctly rounded
+#   "strict2"  ECWAM_HIP_STRICT=2: EXP / LOG with an exact argument reduction (error of the hardware exp2 / log2 only)
+#   "strict3"  both
+#   "strict7"  both + floating-point contraction off (no FMA the source does not spell out)
+# A variant is written to libecwam_hip_<variant>.so next to the product library; ECWAM_HIP_LIB=<path> makes lib.load() use it.
+VARIANTS = {"": FAST_DIV, "strict1": ["-DECWAM_HIP_STRICT=1"], "strict2": FAST_DIV + ["-DECWAM_HIP_STRICT=2"],
+            "strict3": ["-DECWAM_HIP_STRICT=3"], "strict7": ["-DECWAM_HIP_STRICT=3", "-ffp-contract=off"]}
 
 INCLUDE = os.path.join(HERE, "..", "include", "ecwam_hip.h")
-DEPS = {"capi.hip": ["dev.h"], "propag.hip": ["dev.h"], "implsch.hip": ["dev.h", "implsch_common.h", "implsch_v2.h"], "implsch4.hip": ["dev.h", "implsch_common.h", "implsch_v2.h", "implsch_v4.h"], "outbs.hip": ["dev.h"]}
 
 
-def _obj_stale(src: str, obj: str) -> bool:
-    if not os.path.exists(obj):
-        return True
-    t = os.path.getmtime(obj)
-    deps = [os.path.join(CSRC, src), INCLUDE, os.path.abspath(__file__)] + [os.path.join(CSRC, d) for d in DEPS.get(src, [])]
-    return any(os.path.getmtime(d) > t for d in deps)
+def lib_path(variant: str = "") -> str:
+    return LIB if not variant else os.path.join(LIBDIR, f"libecwam_hip_{variant}.so")
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the objects whose source (or a header it includes) changed, then link."""
+def _closure(path: str, seen: dict) -> None:
+    """The file and every header it includes with quotes, recursively (system headers come with the toolchain)."""
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return
+    with open(path, "rb") as fh:
+        data = fh.read()
+    seen[path] = data
+    for m in re.finditer(rb'^[ \t]*#[ \t]*include[ \t]*"([^"]+)"', data, re.M):
+        _closure(os.path.join(os.path.dirname(path), m.group(1).decode()), seen)
+
+
+def _stamp(src: str, flags: list) -> str:
+    """Content hash of everything an object depends on: the command line, the source and the closure of its quoted includes.
+    (mtime comparisons reuse stale objects that travelled with a snapshot, and miss a header that is not in a hand-kept list.)"""
+    seen: dict = {}
+    _closure(os.path.join(CSRC, src), seen)
+    h = hashlib.sha256(" ".join([HIPCC, *flags]).encode())
+    for k in sorted(seen):
+        h.update(os.path.relpath(k, HERE).encode())
+        h.update(seen[k])
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
+    """Compile the objects whose command line, source or included headers changed (content hashes in <obj>.stamp), then link."""
+    if variant not in VARIANTS:
+        raise ValueError(f"unknown build variant {variant!r}: {sorted(VARIANTS)}")
     os.makedirs(LIBDIR, exist_ok=True)
-    objs = []
-    procs = []
+    lib = lib_path(variant)
+    objs, procs, stamps = [], [], {}
     for src in SOURCES:
-        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        special = bool(variant) and src in IMPLSCH_SOURCES
+        obj = os.path.join(LIBDIR, src.replace(".hip", f".{variant}.o" if special else ".o"))
+        flags = FLAGS + ((VARIANTS[variant] if special else FAST_DIV) if src in IMPLSCH_SOURCES else [])
         objs.append(obj)
-        if not force and not _obj_stale(src, obj):
+        st = _stamp(src, flags)
+        old = ""
+        if os.path.exists(obj) and os.path.exists(obj + ".stamp"):
+            with open(obj + ".stamp") as fh:
+                old = fh.read().strip()
+        if not force and old == st:
             continue
-        cmd = [HIPCC, *FLAGS, *EXTRA.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        stamps[obj] = st
+        cmd = [HIPCC, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for src, p in procs:
+        procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, obj, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{out}")
+        with open(obj + ".stamp", "w") as fh:
+            fh.write(stamps[obj])
         if verbose and out.strip():
             print(out)
-    if not procs and os.path.exists(LIB) and all(os.path.getmtime(o) <= os.path.getmtime(LIB) for o in objs):
-        return LIB
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    link_stamp = hashlib.sha256("".join(open(o + ".stamp").read() for o in objs).encode()).hexdigest()
+    if not procs and os.path.exists(lib) and os.path.exists(lib + ".stamp") and open(lib + ".stamp").read().strip() == link_stamp:
+        return lib
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
-    return LIB
+    with open(lib + ".stamp", "w") as fh:
+        fh.write(link_stamp)
+    return lib
 
 
 FLANG = shutil.which("amdflang") or "/opt/rocm/lib/llvm/bin/flang"
@@ -98,5 +143,8 @@ def build_fortran(force: bool = False) -> list:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
-    print(build_fortran(force="--force" in sys.argv))
+    vs = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--variant=")]
+    for v in vs or [""]:
+        print(build(force="--force" in sys.argv, verbose=True, variant=v))
+    if not vs:
+        print(build_fortran(force="--force" in sys.argv))

@@ -115,7 +115,16 @@ __device__ __forceinline__ int m_nint(double x) { return (int)lround(x); }
 // ---- IMPLSCH hot-loop math: single precision goes straight to the hardware transcendental unit (v_rcp/v_sqrt/v_exp/
 // v_log, <= 1 ulp each, no range fix-up code: the arguments on these paths are bounded, see the call sites);
 // double precision keeps the library routines for EXP / LOG (a Taylor EXP without special cases measured the same).  f_exp(x) = 2^(x*log2e): relative error <= |x|*1.2e-7.
+// ECWAM_HIP_STRICT (build variants of ecwam_amd/build.py): bit 0 -- single-precision divisions, reciprocals and
+// square roots correctly rounded; bit 1 -- single-precision EXP / LOG through the library routines (<= 1 ulp).  0 in the product build.
+#ifndef ECWAM_HIP_STRICT
+#define ECWAM_HIP_STRICT 0
+#endif
+#if ECWAM_HIP_STRICT & 1
+__device__ __forceinline__ float f_div(float a, float b) { return a / b; }
+#else
 __device__ __forceinline__ float f_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#endif
 // double precision: hardware seed (v_rcp_f64 / v_rsq_f64, ~2^-26) + two Newton steps in FMA form: < 2 ulp, no IEEE
 // special-case sequence (div_scale/div_fmas/div_fixup).  Arguments on these paths are finite, non-zero and normal.
 __device__ __forceinline__ double f_rcp(double b);
@@ -124,14 +133,22 @@ __device__ __forceinline__ double f_div(double a, double b) {
   const double q = a * r;
   return fma(fma(-b, q, a), r, q);
 }
+#if ECWAM_HIP_STRICT & 1
+__device__ __forceinline__ float f_rcp(float b) { return 1.0f / b; }
+#else
 __device__ __forceinline__ float f_rcp(float b) { return __builtin_amdgcn_rcpf(b); }
+#endif
 __device__ __forceinline__ double f_rcp(double b) {
   double r = __builtin_amdgcn_rcp(b);
   r = fma(fma(-b, r, 1.0), r, r);
   r = fma(fma(-b, r, 1.0), r, r);
   return r;
 }
+#if ECWAM_HIP_STRICT & 1
+__device__ __forceinline__ float f_sqrt(float x) { return sqrtf(x); }
+#else
 __device__ __forceinline__ float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#endif
 __device__ __forceinline__ double f_sqrt(double x) {   // x >= 0, finite: seed, one coupled Newton step for SQRT and 1/(2 SQRT), one correction
   const double y = __builtin_amdgcn_rsq(x);
   double s = x * y, h = 0.5 * y;
@@ -141,16 +158,28 @@ __device__ __forceinline__ double f_sqrt(double x) {   // x >= 0, finite: seed, 
   s = fma(fma(-s, s, x), h, s);
   return x == 0.0 ? 0.0 : s;
 }
+#if ECWAM_HIP_STRICT & 1
+__device__ __forceinline__ float f_rsq(float x) { return 1.0f / sqrtf(x); }
+#else
 __device__ __forceinline__ float f_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+#endif
 __device__ __forceinline__ double f_rsq(double x) {   // x > 0 (the callers discard the result of x = 0)
   double y = __builtin_amdgcn_rsq(x);
   y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
   y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
   return y;
 }
+#if ECWAM_HIP_STRICT & 2
+__device__ __forceinline__ float f_exp(float x) { return expf(x); }
+#else
 __device__ __forceinline__ float f_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+#endif
 __device__ __forceinline__ double f_exp(double x) { return exp(x); }
+#if ECWAM_HIP_STRICT & 2
+__device__ __forceinline__ float f_log(float x) { return logf(x); }
+#else
 __device__ __forceinline__ float f_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
+#endif
 __device__ __forceinline__ double f_log(double x) { return log(x); }
 template <typename T>
 __device__ __forceinline__ T m_pow4(T x) {

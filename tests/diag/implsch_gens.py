@@ -1,5 +1,5 @@
 """IMPLSCH kernel generations side by side (diagnostics, not a test): time per launch and parity statistics against the oracle.
-python tools/implsch_gens.py [npoints] [prec,...] [nang,...] [A|B|N|G: flag set A, B (LLGCBZ0 + LLNORMAGAM), LLNORMAGAM only, LLGCBZ0 only]"""
+python tests/diag/implsch_gens.py [npoints] [prec,...] [nang,...] [A|B|N|G: flag set A, B (LLGCBZ0 + LLNORMAGAM), LLNORMAGAM only, LLGCBZ0 only]"""
 import json
 import os
 import sys
@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import harness as H  # noqa: E402

@@ -437,10 +437,10 @@ def test_speed_build_of_the_oracle_agrees_with_the_strict_build():
 
 
 def test_oracle_regression_vectors():
-    """tests/golden/oracle_regression_dp.npz (tools/make_oracle_regression.py): frozen outputs of this repository's own oracle
+    """tests/golden/oracle_regression_dp.npz (tests/diag/make_oracle_regression.py): frozen outputs of this repository's own oracle
     for small seeded cases.  Regression only -- they say nothing about the reference.  Tolerance 1e-9 of each array's scale: libm
     may differ between the machine that wrote them and the one that checks them."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "diag"))
     import make_oracle_regression as M
 
     want = np.load(os.path.join(ROOT, "tests", "golden", "oracle_regression_dp.npz"))

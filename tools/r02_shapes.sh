@@ -8,4 +8,4 @@ for cfg in "640 sp" "1280 sp" "640 dp" "1280 dp"; do
 done
 timeout -k 10 250 python3 bench.py --grid 1280 --ifrelfmax 5 --adv-per-source 2 --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_O1280_sp_native.json 2> $O/bench_O1280_sp_native.err || echo "native failed"
 timeout -k 10 120 python3 bench.py --irefra 2 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_O320_sp_irefra2.json 2> $O/bench_O320_sp_irefra2.err || echo "irefra failed"
-for f in A B; do timeout -k 10 300 python3 tools/implsch_gens.py 131072 sp,dp 36,24,12 $f > $O/gens_$f.txt 2>&1 || echo "gens $f failed"; grep -h "ms" $O/gens_$f.txt | head -20; done
+for f in A B; do timeout -k 10 300 python3 tests/diag/implsch_gens.py 131072 sp,dp 36,24,12 $f > $O/gens_$f.txt 2>&1 || echo "gens $f failed"; grep -h "ms" $O/gens_$f.txt | head -20; done

@@ -141,6 +141,10 @@ class Wamintgr:
         elif strip_width < 0:      # 2-D tiles of four latitude rows x four longitudes
             self.order = torch.from_numpy(decomp.tile2d_order(grid, self.dom)).to(self.dev)
             self.tiles2d = True
+        if self.order is not None and (int(cfg.irefra) or weights == "stored"):
+            # the refraction and stored-weight kernels walk the rows in their natural order: a work order (whose padded length would
+            # otherwise replace the row range handed to them) does not apply
+            self.order, self.tiles2d = None, False
         self.wvprpt = torch.zeros((self.n, api.NWPR, NFRE), **z)
         self.ff = torch.zeros((self.n, api.NFF), **z)
         self.ff_next = None

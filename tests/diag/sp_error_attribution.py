@@ -18,6 +18,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+ORACLE_ROW = "--oracle-row" in sys.argv
+
+
 def worker() -> None:
     import numpy as np
     import torch
@@ -34,10 +37,24 @@ def worker() -> None:
         cfg = Config(nang=36, nfre=36, nfre_red=36, idelt=idelt, idelpro=idelt)
         case = H.make_point_case(1536, cfg, prec, spectra="mixed", seed=777)
         ref = H.oracle_implsch(case, Oracle(cfg, prec))
+        # the same single-precision inputs through the double-precision oracle: what single precision itself loses
+        cd = dict(case, prec="dp", FL1=case["FL1"].astype(np.float64), FF=case["FF"].astype(np.float64), INTF=case["INTF"].astype(np.float64),
+                  ENV=case["ENV"].astype(np.float64), props={k: v.astype(np.float64) for k, v in case["props"].items()})
+        truth = H.oracle_implsch(cd, Oracle(cfg, "dp"))
+        keys = ("mij_flips", "xllws_pts_diff", "fl1_max_rel_peak_clean", "swh_max_rel", "ff_max_rel_clean", "intf_max_rel_clean",
+                "fl1_frac_sig_bins_gt_1e-5")
+        if ORACLE_ROW:
+            st = H.compare_implsch(truth, ref, case["tables"])
+            out[f"idelt{idelt}"] = {k: st[k] for k in keys}
+            out[f"idelt{idelt}_vs_dp"] = out[f"idelt{idelt}"]
+            out["ms_131072"] = float("nan")
+            continue
         ctx = api.HipContext(case["tables"])
-        st = H.compare_implsch(ref, H.gpu_implsch(case, ctx), case["tables"])
-        out[f"idelt{idelt}"] = {k: st[k] for k in ("mij_flips", "xllws_pts_diff", "fl1_max_rel_peak_clean", "swh_max_rel", "ff_max_rel_clean",
-                                                  "intf_max_rel_clean", "fl1_frac_sig_bins_gt_1e-5")}
+        got = H.gpu_implsch(case, ctx)
+        st = H.compare_implsch(ref, got, case["tables"])
+        out[f"idelt{idelt}"] = {k: st[k] for k in keys}
+        st2 = H.compare_implsch(truth, got, case["tables"])
+        out[f"idelt{idelt}_vs_dp"] = {k: st2[k] for k in keys}
         if idelt == 900:      # launch time on 131 072 points
             n, nc = 131072, 1536
             dev = ctx.device
@@ -61,6 +78,10 @@ def worker() -> None:
                 ts.append(e0.elapsed_time(e1))
             out["ms_131072"] = min(ts[1:])
         ctx.close()
+    if ORACLE_ROW:
+        out["steps12"] = {"swh_pt_max": float("nan"), "swh_pt_p99": float("nan"), "swh_avg": float("nan"), "swh_max": float("nan")}
+        print("RESULT " + json.dumps(out), flush=True)
+        return
     # twelve full steps, per-point swh and the global norms
     cfg = Config(nang=24, nfre=36, nfre_red=29)
     g = G.build_grid(16, mask="continents")
@@ -92,28 +113,33 @@ def worker() -> None:
 def main() -> None:
     from ecwam_amd import build as B
 
-    variants = sys.argv[1:] or list(B.VARIANTS)
+    variants = [a for a in sys.argv[1:] if not a.startswith("--")] or list(B.VARIANTS)
     rows = []
-    for v in variants:
+    for v in ["oracle-sp"] + variants:
         v = "" if v in ("default", "product") else v
-        lib = B.lib_path(v)
-        if not os.path.exists(lib):
-            B.build(variant=v)
-        env = dict(os.environ, ECWAM_HIP_LIB=lib)
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        env = dict(os.environ)
+        if v != "oracle-sp":
+            lib = B.lib_path(v)
+            if not os.path.exists(lib):
+                B.build(variant=v)
+            env["ECWAM_HIP_LIB"] = lib
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker"] + (["--oracle-row"] if v == "oracle-sp" else []), env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
         if r.returncode != 0 or not line:
             print(f"variant {v or 'product'}: FAILED\n{r.stdout[-1500:]}\n{r.stderr[-3000:]}", flush=True)
             continue
         d = json.loads(line[-1][7:])
-        rows.append((v or "product", " ".join(B.VARIANTS[v]), d))
+        rows.append((v or "product", "the sp oracle against the dp oracle on the same sp inputs" if v == "oracle-sp" else " ".join(B.VARIANTS[v]), d))
         print(f"{v or 'product'}: {json.dumps(d)}", flush=True)
     print()
-    print("variant  | flags | ms/131072 pts | IDELT=900: bins/peak  swh  forcing  fluxes  MIJ flips | IDELT=450: bins/peak  swh | 12 steps: swh point max / p99  norm avg  norm max")
+    print("variant  | flags | ms/131072 pts | IDELT=900 vs sp oracle: bins/peak  swh  forcing  fluxes  MIJ flips | IDELT=900 vs DP oracle: bins/peak  swh  forcing | "
+          "IDELT=450 vs sp oracle: bins/peak  swh | 12 steps vs sp oracle: swh point max / p99  norm avg  norm max")
     for name, flags, d in rows:
-        a, b, s = d["idelt900"], d["idelt450"], d["steps12"]
-        print(f"{name:8s} | {flags} | {d['ms_131072']:.3f} | {a['fl1_max_rel_peak_clean']:.2e} {a['swh_max_rel']:.2e} {a['ff_max_rel_clean']:.2e} "
-              f"{a['intf_max_rel_clean']:.2e} {a['mij_flips']} | {b['fl1_max_rel_peak_clean']:.2e} {b['swh_max_rel']:.2e} | "
+        a, b, s, t = d["idelt900"], d["idelt450"], d["steps12"], d["idelt900_vs_dp"]
+        print(f"{name:9s} | {flags} | {d['ms_131072']:.3f} | {a['fl1_max_rel_peak_clean']:.2e} {a['swh_max_rel']:.2e} {a['ff_max_rel_clean']:.2e} "
+              f"{a['intf_max_rel_clean']:.2e} {a['mij_flips']} | {t['fl1_max_rel_peak_clean']:.2e} {t['swh_max_rel']:.2e} {t['ff_max_rel_clean']:.2e} | "
+              f"{b['fl1_max_rel_peak_clean']:.2e} {b['swh_max_rel']:.2e} | "
               f"{s['swh_pt_max']:.2e} {s['swh_pt_p99']:.2e} {s['swh_avg']:.2e} {s['swh_max']:.2e}")
 
 

@@ -15,7 +15,19 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-def _write_case(path, m, cfg, grid, nproma, nstep, obs=None, nosource=False):
+class _LocalGrid:
+    """The Grid-shaped view of one rank's band (decomp.LocalDomain): local numbering, halo rows after the owned ones, land last."""
+
+    def __init__(self, g, d):
+        self.nsea, self.ngy, self.xdella = d.n, g.ngy, g.xdella
+        self.kxlt, self.klon, self.klat, self.kcor = d.kxlt, d.klon, d.klat, d.kcor
+        self.wlat, self.wcor = g.wlat[d.lo:d.hi], g.wcor[d.lo:d.hi]
+        self.cosph, self.sinph, self.zdello, self.cosphm1_ext = g.cosph, g.sinph, g.zdello, d.cosphm1_ext
+
+
+def _write_case(path, m, cfg, grid, nproma, nstep, obs=None, nosource=False, dom=None):
+    """dom: the rank's decomp.LocalDomain for a multi-rank case (grid = its _LocalGrid): the header carries rank / ranks / halo size /
+    interior range, the lists of ECWAM_HIP_SET_DECOMPOSITION (1-based, the reference's NTOPE / IJTOPE / NIJSTART) end the file."""
     from ecwam_amd import lib as L, synthetic as syn
 
     t = m.t
@@ -24,11 +36,15 @@ def _write_case(path, m, cfg, grid, nproma, nstep, obs=None, nosource=False):
     nchnk = (n + nproma - 1) // nproma
     params = L.make_params(t)
     tp, keep = L.make_tables(t)
+    peers = sorted(set(dom.send) | set(dom.recv)) if dom is not None else []
+    ia, ib = dom.interior() if dom is not None else (0, n)
     with open(path, "wb") as f:
         hdr = np.array([cfg.nang, cfg.nfre, cfg.nfre_red, nproma, nchnk, n, grid.ngy, cfg.idelt, cfg.idelpro,
                         np.dtype(dt).itemsize, nstep, ctypes.sizeof(params), len(keep), int(m.ifrelfmax),
                         int(m.delpro_lf or 0), int(cfg.irefra != 0), int(bool(getattr(m, 'llcflcuroff', False))),
-                        int(obs is not None), int(nosource)], dtype=np.int32)
+                        int(obs is not None), int(nosource),
+                        dom.nranks if dom is not None else 1, dom.rank if dom is not None else 0, dom.nh if dom is not None else 0,
+                        len(peers), ia + 1, ib, 0], dtype=np.int32)
         f.write(hdr.tobytes())
         f.write(bytes(params))
         for a in keep:
@@ -62,14 +78,44 @@ def _write_case(path, m, cfg, grid, nproma, nstep, obs=None, nosource=False):
         if obs is not None:   # OBS[n][8][NFRE] -> OBSLAT(N,NFRE_RED,2), OBSLON(N,NFRE_RED,2), OBSCOR(N,NFRE_RED,4)
             o = np.moveaxis(np.asarray(obs)[:, :, :cfg.nfre_red], 1, 2)
             f.write(F(o[:, :, 0:2], dt) + F(o[:, :, 2:4], dt) + F(o[:, :, 4:8], dt))
+        if dom is not None:
+            sc = np.array([len(dom.send.get(p_, ())) for p_ in peers], np.int32)
+            f.write(np.array(peers, np.int32).tobytes() + sc.tobytes())
+            f.write(np.array([dom.recv.get(p_, (0, 0))[0] + 1 for p_ in peers], np.int32).tobytes())
+            f.write(np.array([dom.recv.get(p_, (0, 0))[1] for p_ in peers], np.int32).tobytes())
+            f.write(np.concatenate([np.asarray(dom.send[p_], np.int32) + 1 for p_ in peers if p_ in dom.send]).tobytes())
     return nchnk
+
+
+def _read_out(path, dt, nproma, nchnk, nang, nfre, n):
+    """The harness' output file -> point-major arrays of the n owned points."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    nsp = nproma * nang * nfre * nchnk
+    isz = np.dtype(dt).itemsize
+    off = 0
+    fl_f = np.frombuffer(raw, dtype=dt, count=nsp, offset=off).reshape((nproma, nang, nfre, nchnk), order="F"); off += nsp * isz
+    xl_f = np.frombuffer(raw, dtype=dt, count=nsp, offset=off).reshape((nproma, nang, nfre, nchnk), order="F"); off += nsp * isz
+    mij_f = np.frombuffer(raw, dtype=np.int32, count=nproma * nchnk, offset=off).reshape((nproma, nchnk), order="F"); off += 4 * nproma * nchnk
+    ff_f = np.frombuffer(raw, dtype=dt, count=14 * nproma * nchnk, offset=off).reshape((nproma, nchnk, 14), order="F"); off += 14 * nproma * nchnk * isz
+    in_f = np.frombuffer(raw, dtype=dt, count=15 * nproma * nchnk, offset=off).reshape((nproma, nchnk, 15), order="F"); off += 15 * nproma * nchnk * isz
+    ij = np.arange(n)
+    out = dict(FL1=fl_f[ij % nproma, :, :, ij // nproma], XLLWS=xl_f[ij % nproma, :, :, ij // nproma], MIJ=mij_f[ij % nproma, ij // nproma],
+               FF=ff_f[ij % nproma, ij // nproma, :], INTF=in_f[ij % nproma, ij // nproma, :], raw_fl=fl_f)
+    if off < raw.size:      # LWNEMOCOU: NEMONTAU and the 13 WAVE2OCEAN members (double), in the order of the device rows
+        out["NEMONTAU"] = int(np.frombuffer(raw, dtype=np.int32, count=1, offset=off)[0]); off += 4
+        w = np.frombuffer(raw, dtype=np.float64, count=13 * nproma * nchnk, offset=off).reshape((nproma, nchnk, 13), order="F")
+        out["W2N"] = w[ij % nproma, ij // nproma, :]
+    return out
 
 
 @pytest.mark.parametrize("prec,lf,irefra,subgrid,nosource", [("sp", 0, 0, False, False), ("dp", 0, 0, False, False), ("sp", 5, 0, False, False),
                                                              ("sp", 0, 2, False, False), ("dp", 0, 3, False, False), ("sp", 0, 0, True, False),
-                                                             ("sp", 0, 2, True, False), ("sp", 0, 0, False, True), ("dp", 5, 0, False, True)])
+                                                             ("sp", 0, 2, True, False), ("sp", 0, 0, False, True), ("dp", 5, 0, False, True),
+                                                             ("sp", 5, 2, False, False), ("dp", 4, 3, False, False)])
 def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec, lf, irefra, subgrid, nosource):
-    """nosource: YOWSTAT's LLSOURCE = F -- the branch of wamintgr.F90:152-160 (FL1 = MAX(FL1, EPSMIN), MIJ = NFRE, XLLWS = 0) runs on the
+    """lf > 0 together with irefra > 0: fast-wave sub-steps with refraction (propag_wam.F90:175-212 + :247-313), the reference's call
+    sequence on the full rows with one CURMASK per frequency range.
+    nosource: YOWSTAT's LLSOURCE = F -- the branch of wamintgr.F90:152-160 (FL1 = MAX(FL1, EPSMIN), MIJ = NFRE, XLLWS = 0) runs on the
     device copies (ecwam_hip_nosource); the advected spectra still hold exact zeros from the land neighbours before the clamp."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -104,27 +150,71 @@ def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec, lf, irefra, su
         assert float(m.fl1[: g.nsea].min()) >= epsmin and int(m.mij.min()) == cfg.nfre == int(m.mij.max()) and float(m.xllws.abs().max()) == 0.0
     dt = m.npdt
     n = g.nsea
-    raw = np.fromfile(out, dtype=np.uint8)
-    nsp = nproma * cfg.nang * cfg.nfre * nchnk
-    isz = np.dtype(dt).itemsize
-    off = 0
-    fl_f = np.frombuffer(raw, dtype=dt, count=nsp, offset=off).reshape((nproma, cfg.nang, cfg.nfre, nchnk), order="F"); off += nsp * isz
-    xl_f = np.frombuffer(raw, dtype=dt, count=nsp, offset=off).reshape((nproma, cfg.nang, cfg.nfre, nchnk), order="F"); off += nsp * isz
-    mij_f = np.frombuffer(raw, dtype=np.int32, count=nproma * nchnk, offset=off).reshape((nproma, nchnk), order="F"); off += 4 * nproma * nchnk
-    ff_f = np.frombuffer(raw, dtype=dt, count=14 * nproma * nchnk, offset=off).reshape((nproma, nchnk, 14), order="F"); off += 14 * nproma * nchnk * isz
-    in_f = np.frombuffer(raw, dtype=dt, count=15 * nproma * nchnk, offset=off).reshape((nproma, nchnk, 15), order="F")
-    ij = np.arange(n)
-    fl_pts = fl_f[ij % nproma, :, :, ij // nproma]
-    xl_pts = xl_f[ij % nproma, :, :, ij // nproma]
-    assert np.array_equal(fl_pts, m.fl1.cpu().numpy()[:n])
-    assert np.array_equal(xl_pts, m.xllws.cpu().numpy())
-    assert np.array_equal(mij_f[ij % nproma, ij // nproma], m.mij.cpu().numpy())
-    assert np.array_equal(ff_f[ij % nproma, ij // nproma, :], m.ff.cpu().numpy()[:, :14])
+    o = _read_out(out, dt, nproma, nchnk, cfg.nang, cfg.nfre, n)
+    fl_f = o["raw_fl"]
+    assert np.array_equal(o["FL1"], m.fl1.cpu().numpy()[:n])
+    assert np.array_equal(o["XLLWS"], m.xllws.cpu().numpy())
+    assert np.array_equal(o["MIJ"], m.mij.cpu().numpy())
+    assert np.array_equal(o["FF"], m.ff.cpu().numpy()[:, :14])
     # INTGT_PARAM_FIELDS members written in the order of synthetic.INTF_NAMES
-    assert np.array_equal(in_f[ij % nproma, ij // nproma, :][:, [2, 3, 5, 6, 7, 8, 9, 12, 13, 14]],
-                          m.intf.cpu().numpy()[:, [2, 3, 5, 6, 7, 8, 9, 12, 13, 14]])
+    assert np.array_equal(o["INTF"][:, [2, 3, 5, 6, 7, 8, 9, 12, 13, 14]], m.intf.cpu().numpy()[:, [2, 3, 5, 6, 7, 8, 9, 12, 13, 14]])
     # pad lanes of the ragged last chunk replicate its lane 1 (propag_wam.F90:388-398)
     kl = n - (nchnk - 1) * nproma
     if kl < nproma:
         assert np.array_equal(fl_f[kl:, :, :, -1], np.repeat(fl_f[:1, :, :, -1], nproma - kl, axis=0))
+    m.ctx.close()
+
+
+@pytest.mark.parametrize("prec,lf", [("sp", 0), ("dp", 5)])
+def test_fortran_two_processes_on_one_gpu_match_single_domain(tmp_path, prec, lf):
+    """The multi-rank path of the Fortran layer, executed: two processes of the harness share the GPU, each owns one band of the sea
+    points (ECWAM_HIP_SET_DECOMPOSITION with the reference's 1-based NTOPE / IJTOPE / NIJSTART-style lists -> 0-based device rows,
+    halo rows and land slot behind the owned rows, interior range), the halo travels host-staged (ecwam_hip_halo_pack_host ->
+    the harness' exchange through files, where ecWAM would call MPI -> ecwam_hip_halo_unpack_host), fast-wave sub-steps exchange the
+    compact rows.  Both bands together must equal the single-domain Python host bit for bit.  Also LWNEMOCOU: the WAVE2OCEAN sums and
+    the accumulation count NEMONTAU (wamintgr.F90:150) after two source steps."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ecwam_amd import build, decomp, grid as G
+    from ecwam_amd.wamintgr import Wamintgr
+
+    exe = build.fortran_exe(prec)
+    if not os.path.exists(exe):
+        build.build_fortran()
+    cfg = Config(nang=12, nfre=36, nfre_red=25, idelt=900, idelpro=900, lwnemocou=True)
+    g = G.build_grid(16, mask="continents")
+    kw = dict(ifrelfmax=lf, delpro_lf=450.0 if lf else None)
+    nranks, nproma, nstep = 2, 24, 2
+    xdir = tmp_path / "xchg"
+    xdir.mkdir()
+    procs, meta = [], []
+    for r in range(nranks):
+        mr = Wamintgr(cfg, g, prec, rank=r, nranks=nranks, halo_transport="host", **kw)
+        mr.init_synthetic(seed=21)
+        case, out = str(tmp_path / f"case{r}.bin"), str(tmp_path / f"out{r}.bin")
+        nchnk = _write_case(case, mr, cfg, _LocalGrid(g, mr.dom), nproma, nstep, dom=mr.dom)
+        meta.append((out, nchnk, mr.dom.n))
+        mr.ctx.close()
+        procs.append(subprocess.Popen([exe, case, out, "run", str(xdir)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        o, _ = p.communicate(timeout=600)
+        assert p.returncode == 0 and "ok" in o, o
+    m = Wamintgr(cfg, g, prec, **kw)
+    m.init_synthetic(seed=21)
+    w2n = torch.zeros((g.nsea, 13), dtype=torch.float64, device=m.dev)
+    for _ in range(nstep):
+        m.propag()
+        m.newwind()
+        m.ctx.implsch(0, m.n, m.fl1, m.wvprpt, m.ff, m.intf, m.mij, m.xllws, wam2nemo=w2n)
+    torch.cuda.synchronize()
+    outs = [_read_out(o, m.npdt, nproma, nc, cfg.nang, cfg.nfre, n) for o, nc, n in meta]
+    n = g.nsea
+    cat = lambda k: np.concatenate([o[k] for o in outs])
+    assert np.array_equal(cat("FL1"), m.fl1.cpu().numpy()[:n])
+    assert np.array_equal(cat("XLLWS"), m.xllws.cpu().numpy())
+    assert np.array_equal(cat("MIJ"), m.mij.cpu().numpy())
+    assert np.array_equal(cat("FF"), m.ff.cpu().numpy()[:, :14])
+    assert all(o["NEMONTAU"] == nstep for o in outs)
+    got, want = cat("W2N"), w2n.cpu().numpy()
+    assert np.array_equal(got, want) and np.abs(want[:, 7]).max() > 0        # NEMOTAUX accumulated over the two steps
     m.ctx.close()

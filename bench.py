@@ -74,8 +74,11 @@ def self_launch(a, argv) -> None:
     raise SystemExit(subprocess.run(cmd).returncode)
 
 
-def cpu_baseline(nang: int, nfre: int, prec: str, target_s: float = 15.0) -> dict:
-    """Oracle (plain-C restatement, OpenMP over points) timed on this host on a bounded sample of the same workload."""
+def cpu_baseline(nang: int, nfre: int, prec: str, target_s: float = 9.0, ng: int = 96) -> dict:
+    """Oracle (plain-C restatement, OpenMP over points) timed on this host on a bounded sample of the same workload: the O96 all-ocean
+    grid (40 280 sea points: 209 MB of spectra per copy in single precision, 1.7 GB of packed CTU weights -- beyond the last-level cache
+    share of the cores used, so that the advection rate is a memory rate as it is at O320), the bench's precision first, then the
+    other one on a shorter run."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from ecwam_amd import grid as G
     from ecwam_amd.tables import Config
@@ -85,45 +88,55 @@ def cpu_baseline(nang: int, nfre: int, prec: str, target_s: float = 15.0) -> dic
     from ecwam_amd.tables import Tables
     from oracle.oracle import Oracle
 
-    cfg = Config(nang=nang, nfre=nfre, nfre_red=nfre, idelt=450, idelpro=450)
-    dt = np.float32 if prec == "sp" else np.float64
-    t = Tables(cfg, dt)
-    o = Oracle(cfg, prec, fast=True)     # same sources, built -O3 -march=x86-64-v3 (oracle/Makefile): timing only
-    g = G.build_grid(48)
+    g = G.build_grid(ng)
     n = g.nsea
-    p = syn.point_params(n)
-    pr = syn.depth_props(p["DEPTH"], t, dt)
-    fl = np.zeros((n + 1, nang, nfre), dt)
-    fl[:n] = syn.jonswap_spectra(t.FR, t.TH, p["FP"], p["THETAQ"], dt)
-    ff = syn.forcing(p, slice(0, n), t, dt)
-    intf = np.zeros((n, syn.NINTF), dt)
-    env = np.stack([pr["EMAXDPT"], p["DEPTH"].astype(dt)], 1)
-    cg_ext = np.zeros((n + 1, nfre), dt)
-    cg_ext[:n] = pr["CGROUP"]
-    cg_ext[n] = syn.depth_props(np.array([998.999]), t, dt)["CGROUP"][0]
-    w = o.ctu_weights(g, cg_ext, float(cfg.idelpro))
-    # IMPLSCH through the NPROMA-blocked variant (SINPUT_ARD / SDISSIP_ARD / SNONLIN with the point index innermost, vector libm,
-    # flush-to-zero: what the reference's loop order and production flags give a compiler), then a short run of the point-by-point
-    # restatement for comparison; C calls only, arrays prepared once
-    steps, el = o.timed_steps(g, fl.copy(), w, pr, env, ff.copy(), intf.copy(), max_steps=200, target_s=0.75 * target_s)
-    kind, t_impl, t_prop = o.implsch_kind, o.t_implsch, o.t_propags2
-    s2, _ = o.timed_steps(g, fl, w, pr, env, ff, intf, max_steps=200, target_s=0.25 * target_s, blocked=False)
-    # which of the two is faster depends on the host (vector width, threads per core): the baseline is the step with the faster one
-    per_blk, per_pt = t_impl / steps, o.t_implsch / s2
-    per_step = el / steps - per_blk + min(per_blk, per_pt)
-    if per_pt < per_blk:
-        kind = "point-by-point"
-    return {"value": n / per_step, "unit": "grid-point spectral steps/s", "cores": cores, "kind": "port",
-            "implsch_only": n / min(per_blk, per_pt), "propags2_only": n * steps / t_prop, "implsch_variant": kind,
-            "implsch_only_nproma_blocked": n / per_blk, "implsch_only_point_by_point": n / per_pt,
-            "note": "IMPLSCH is timed in two C restatements and the faster one on this host counts: NPROMA-blocked (oracle/ora_implsch_blk.inc: "
-                    "SINPUT_ARD, SDISSIP_ARD and SNONLIN with the sea-point index innermost as in implsch.F90:152-170, omp simd + libmvec, "
-                    "flush-to-zero; the scalar chains TAUT_Z0 / STRESSO / FKMEAN point by point) and point by point; PROPAGS2 its eight weights packed as contiguous streams (ora_propags2_w8, bit-identical); "
-                    "both checked against the point-by-point oracle; unpinned against the reference "
-                    "(DESIGN.md section 4): an estimate of what the reference's OpenMP path does on these cores, not a measurement of it",
-            "sample": f"O48 all-ocean grid ({n} sea points), {nang}x{nfre} spectrum, {prec}, {steps} full steps "
-                      f"(PROPAGS2 + IMPLSCH), oracle/ C restatement (speed build: gcc -O3 -march=x86-64-v3) with OpenMP over blocks of 32 points, "
-                      f"{cores} threads (host reports {os.cpu_count()} logical CPUs)"}
+
+    def leg(pr_: str, budget: float) -> dict:
+        cfg = Config(nang=nang, nfre=nfre, nfre_red=nfre, idelt=450, idelpro=450)
+        dt = np.float32 if pr_ == "sp" else np.float64
+        t = Tables(cfg, dt)
+        o = Oracle(cfg, pr_, fast=True)     # same sources, built -O3 -march=x86-64-v3 (oracle/Makefile): timing only
+        p = syn.point_params(n)
+        pr = syn.depth_props(p["DEPTH"], t, dt)
+        fl = np.zeros((n + 1, nang, nfre), dt)
+        fl[:n] = syn.jonswap_spectra(t.FR, t.TH, p["FP"], p["THETAQ"], dt)
+        ff = syn.forcing(p, slice(0, n), t, dt)
+        intf = np.zeros((n, syn.NINTF), dt)
+        env = np.stack([pr["EMAXDPT"], p["DEPTH"].astype(dt)], 1)
+        cg_ext = np.zeros((n + 1, nfre), dt)
+        cg_ext[:n] = pr["CGROUP"]
+        cg_ext[n] = syn.depth_props(np.array([998.999]), t, dt)["CGROUP"][0]
+        w = o.ctu_weights(g, cg_ext, float(cfg.idelpro))
+        # IMPLSCH through the NPROMA-blocked variant (SINPUT_ARD / SDISSIP_ARD / SNONLIN with the point index innermost, vector libm,
+        # flush-to-zero: what the reference's loop order and production flags give a compiler), then a short run of the point-by-point
+        # restatement for comparison; C calls only, arrays prepared once
+        steps, el = o.timed_steps(g, fl.copy(), w, pr, env, ff.copy(), intf.copy(), max_steps=200, target_s=0.75 * budget)
+        kind, t_impl, t_prop = o.implsch_kind, o.t_implsch, o.t_propags2
+        s2, _ = o.timed_steps(g, fl, w, pr, env, ff, intf, max_steps=200, target_s=0.25 * budget, blocked=False)
+        # which of the two is faster depends on the host (vector width, threads per core): the baseline is the step with the faster one
+        per_blk, per_pt = t_impl / steps, o.t_implsch / s2
+        per_step = el / steps - per_blk + min(per_blk, per_pt)
+        if per_pt < per_blk:
+            kind = "point-by-point"
+        return {"value": n / per_step, "implsch_only": n / min(per_blk, per_pt), "propags2_only": n * steps / t_prop, "implsch_variant": kind,
+                "implsch_only_nproma_blocked": n / per_blk, "implsch_only_point_by_point": n / per_pt, "steps": steps}
+
+    main_leg = leg(prec, target_s)
+    other = "dp" if prec == "sp" else "sp"
+    other_leg = leg(other, 0.4 * target_s)
+    steps = main_leg.pop("steps")
+    out = {"value": main_leg.pop("value"), "unit": "grid-point spectral steps/s", "cores": cores, "kind": "port", **main_leg,
+           other: {k: v for k, v in other_leg.items()},
+           "note": "IMPLSCH is timed in two C restatements and the faster one on this host counts: NPROMA-blocked (oracle/ora_implsch_blk.inc: "
+                   "SINPUT_ARD, SDISSIP_ARD and SNONLIN with the sea-point index innermost as in implsch.F90:152-170, omp simd + libmvec, "
+                   "flush-to-zero; the scalar chains TAUT_Z0 / STRESSO / FKMEAN point by point) and point by point; PROPAGS2 its eight weights packed as contiguous streams (ora_propags2_w8, bit-identical); "
+                   "both checked against the point-by-point oracle; unpinned against the reference "
+                   "(DESIGN.md section 4): an estimate of what the reference's OpenMP path does on these cores, not a measurement of it",
+           "sample": f"O{ng} all-ocean grid ({n} sea points, {n * nang * nfre * (4 if prec == 'sp' else 8) / 1e6:.0f} MB of spectra per copy: beyond the cores' cache), "
+                     f"{nang}x{nfre} spectrum, {prec}, {steps} full steps "
+                     f"(PROPAGS2 + IMPLSCH), oracle/ C restatement (speed build: gcc -O3 -march=x86-64-v3) with OpenMP over blocks of 32 points, "
+                     f"{cores} threads (host reports {os.cpu_count()} logical CPUs); the other precision ('{other}') on the same sample, half the time"}
+    return out
 
 
 def main() -> None:

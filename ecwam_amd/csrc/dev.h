@@ -181,6 +181,27 @@ __device__ __forceinline__ float f_log(float x) { return logf(x); }
 __device__ __forceinline__ float f_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
 #endif
 __device__ __forceinline__ double f_log(double x) { return log(x); }
+// a / b for the implicit update (implsch.F90:384-386: GTEMP2 = DELT SL / MAX(1 - DELT5 FLD, 1)).  Where the dissipation is stiff, F + GTEMP2
+// = F / GTEMP1 is a difference of nearly equal numbers: a relative error e of the quotient comes out as e GTEMP1 in the new spectrum
+// (GTEMP1 reaches 10^2..10^3 in the tail), and the 1 ulp of the bare reciprocal doubled the distance of the significant wave height to the
+// double-precision answer (1.7e-6 against 7e-7 for correctly rounded arithmetic, profiles/r03_sp_error_attribution.txt).  One Newton
+// step on the quotient: within half an ulp + 2^-46 relative of a / b, two fused multiply-adds.
+__device__ __forceinline__ float f_div_r(float a, float b) {
+  const float r = __builtin_amdgcn_rcpf(b);
+  const float q = a * r;
+  return __builtin_fmaf(__builtin_fmaf(-q, b, a), r, q);
+}
+__device__ __forceinline__ double f_div_r(double a, double b) { return f_div(a, b); }
+// site-selective exactness for the error attribution (tests/diag/sp_error_attribution.py): bit SITE of ECWAM_HIP_STRICT makes the
+// operation at the call sites tagged SITE correctly rounded (the variant builds drop -fno-hip-fp32-correctly-rounded-divide-sqrt)
+template <int SITE> __device__ __forceinline__ float fs_rcp(float x) { if constexpr ((ECWAM_HIP_STRICT & SITE) != 0) return 1.0f / x; else return f_rcp(x); }
+template <int SITE> __device__ __forceinline__ double fs_rcp(double x) { return f_rcp(x); }
+template <int SITE> __device__ __forceinline__ float fs_div(float a, float b) { if constexpr ((ECWAM_HIP_STRICT & SITE) != 0) return a / b; else return f_div(a, b); }
+template <int SITE> __device__ __forceinline__ double fs_div(double a, double b) { return f_div(a, b); }
+template <int SITE> __device__ __forceinline__ float fs_rsq(float x) { if constexpr ((ECWAM_HIP_STRICT & SITE) != 0) return 1.0f / sqrtf(x); else return f_rsq(x); }
+template <int SITE> __device__ __forceinline__ double fs_rsq(double x) { return f_rsq(x); }
+template <int SITE> __device__ __forceinline__ float fs_sqrt(float x) { if constexpr ((ECWAM_HIP_STRICT & SITE) != 0) return sqrtf(x); else return f_sqrt(x); }
+template <int SITE> __device__ __forceinline__ double fs_sqrt(double x) { return f_sqrt(x); }
 template <typename T>
 __device__ __forceinline__ T m_pow4(T x) {
   T x2 = x * x;

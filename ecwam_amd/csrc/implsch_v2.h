@@ -1258,7 +1258,7 @@ __device__ void source_sweep(const DevTab<T>& tb, T* sF, const T* sFLD, const La
           const T sbo = lane_get(rSBO, m);
           if (m < tb.NFRE_RED) { sl = sl + sbo * f; fld = fld + sbo; }
           const T GTEMP1 = m_max(T(1) - DELT5 * fld, T(1));
-          const T GTEMP2 = f_div(DELT * sl, GTEMP1);
+          const T GTEMP2 = f_div_r(DELT * sl, GTEMP1);   // (refined: see f_div_r)
           const T FLHAB = m_min(m_abs(GTEMP2), lane_get(rLIM, m));
           T fn = f + m_sign(FLHAB, GTEMP2);
           fn = m_max(fn, FLM);

@@ -367,14 +367,14 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
     // |TAUP| = h2 / SQRT(h2) with the root of MAX(h2, tiny): a vanishing stress gives h = 0 exactly and a finite direction (0, 0) --
     // which direction does not matter then, every term it enters carries the factor USTP = 0 -- without the selects of a zero test
     const T TINY = sizeof(T) == 4 ? T(1e-36) : T(1e-300);
-    V2<T> vrh = {f_rsq(m_max(vh2.x, TINY)), (NGST == 2) ? f_rsq(m_max(vh2.y, TINY)) : T(0)};
+    V2<T> vrh = {fs_rsq<8>(m_max(vh2.x, TINY)), (NGST == 2) ? fs_rsq<8>(m_max(vh2.y, TINY)) : T(0)};
     if (NGST == 1) vrh.y = vrh.x;
     const V2<T> vh = vh2 * vrh, vCOSU = vTPY * vrh, vSINU = vTPX * vrh;
-    vUSTP = V2<T>{f_sqrt(vh.x), (NGST == 2) ? f_sqrt(vh.y) : T(0)};
+    vUSTP = V2<T>{fs_sqrt<8>(vh.x), (NGST == 2) ? fs_sqrt<8>(vh.y) : T(0)};
     if (NGST == 1) vUSTP.y = vUSTP.x;
     const V2<T> vUCN = vUSTP * cinv_m;
     const V2<T> vden = vUCN + ZALP;
-    const V2<T> vUZ = XKAPPA * V2<T>{f_rcp(vden.x), (NGST == 2) ? f_rcp(vden.y) : T(0)};
+    const V2<T> vUZ = XKAPPA * V2<T>{fs_rcp<8>(vden.x), (NGST == 2) ? fs_rcp<8>(vden.y) : T(0)};
 #pragma unroll
     for (int ig = 0; ig < NGST; ig++) {
       const T COSU = ig ? vCOSU.y : vCOSU.x, SINU = ig ? vSINU.y : vSINU.x;
@@ -384,7 +384,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
       V2<T> gam0 = z2;
       {
         const bool c0 = coslp.x > T(0.01), c1 = coslp.y > T(0.01);
-        const T Z0 = ZCN + UCNZALPD * f_rcp(coslp.x), Z1 = ZCN + UCNZALPD * f_rcp(coslp.y);
+        const T Z0 = ZCN + UCNZALPD * fs_rcp<4>(coslp.x), Z1 = ZCN + UCNZALPD * fs_rcp<4>(coslp.y);
         const bool n0 = c0 && (Z0 < T(0)), n1 = c1 && (Z1 < T(0));
         // single precision: no test for "no lane grows" -- a uniform branch here costs more than the two v_exp_f32 it would skip;
         // the double-precision exponentials are long instruction sequences worth skipping
@@ -849,7 +849,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       const T* row = tb.SINROW[m];
       const T dfm = row[1], sqm = L.sq[m], sig = row[0];
       s0 = s0 + V2<T>{dfm, row[5]} * t;
-      s1 = s1 + V2<T>{row[6], f_div(dfm, sqm)} * t;
+      s1 = s1 + V2<T>{row[6], fs_div<32>(dfm, sqm)} * t;
       s2.x = s2.x + (sqm * dfm) * t;
       if (last) {
         s2.y = t;
@@ -1136,7 +1136,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       const T lim = USFM * (cofr * DELT);
       V2<T> fn;
       {
-        const T G0 = f_div(DELT * sl.x, m_max(T(1) - DELT5 * fld.x, T(1))), G1 = f_div(DELT * sl.y, m_max(T(1) - DELT5 * fld.y, T(1)));
+        const T G0 = f_div_r(DELT * sl.x, m_max(T(1) - DELT5 * fld.x, T(1))), G1 = f_div_r(DELT * sl.y, m_max(T(1) - DELT5 * fld.y, T(1)));   // (refined: see f_div_r)
         fn.x = m_max(f.x + m_sign(m_min(m_abs(G0), lim), G0), FLM.x);
         fn.y = m_max(f.y + m_sign(m_min(m_abs(G1), lim), G1), FLM.y);
       }
@@ -1341,7 +1341,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       const T* row = tb.SINROW[m];
       const T dfm = row[1], dfo = row[5], sqm = L.sq[m];
       s0 = s0 + V2<T>{dfm, dfo} * t;
-      s1 = s1 + V2<T>{row[6], f_div(dfm, sqm)} * t;
+      s1 = s1 + V2<T>{row[6], fs_div<32>(dfm, sqm)} * t;
       s2.x = s2.x + (sqm * dfm) * t;
       tlast = t;
       const V2<T> x = {((xm0 >> m) & 1ull) ? f.x : T(0), ((xm1 >> m) & 1ull) ? f.y : T(0)};

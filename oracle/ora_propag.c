@@ -78,10 +78,13 @@ int ora_ctuw(int n, int nland, real DELPRO, int MSTART, int MEND, const int *KXL
   (void)nland;
   real CMTODEG = C_(360.0) / S.CIRC;
   for (int IJ = 0; IJ < n; IJ++) LCFLFAIL[IJ] = 0;
-  for (int M = MSTART; M <= MEND; M++) {
+  /* (the reference loops M, K, IJ with IJ innermost over arrays that have IJ fastest; here IJ is the slowest index of the arrays:
+   *  IJ outermost -- the elements are independent of each other, the interchange is exact) */
+#pragma omp parallel for schedule(static)
+  for (int IJ = 0; IJ < n; IJ++) {
     for (int K = 1; K <= NANG; K++) {
       const int *jx = S.JXO[K - 1], *jy = S.JYO[K - 1], *kc = S.KCR[K - 1];
-      for (int IJ = 0; IJ < n; IJ++) {
+      for (int M = MSTART; M <= MEND; M++) {
         real CGX[3], CGY[3], ADXP[3], ADYP[3], DXUP[3], DXDW[3], DYUP[3], DYDW[3], WEIGHT[5];
         real CG0 = CGROUP_EXT[(size_t)IJ * NFRE + (M - 1)];
         int KY = KXLT[IJ];
@@ -128,12 +131,13 @@ int ora_ctuw(int n, int nland, real DELPRO, int MSTART, int MEND, const int *KXL
   }
   /* refraction terms, ctuw.F90:407-484 */
   real DELTH0 = (real)(0.25 * DELPRO) / S.DELTH; /* 0.25 is a default-kind literal, ctuw.F90:407 */
-  for (int K = 1; K <= NANG; K++) {
-    int KP1 = K + 1; if (KP1 > NANG) KP1 = 1;
-    int KM1 = K - 1; if (KM1 < 1) KM1 = NANG;
-    real SP = DELTH0 * (S.SINTH[K - 1] + S.SINTH[KP1 - 1]) / S.R;
-    real SM = DELTH0 * (S.SINTH[K - 1] + S.SINTH[KM1 - 1]) / S.R;
-    for (int IJ = 0; IJ < n; IJ++) {
+#pragma omp parallel for schedule(static)
+  for (int IJ = 0; IJ < n; IJ++) {
+    for (int K = 1; K <= NANG; K++) {
+      int KP1 = K + 1; if (KP1 > NANG) KP1 = 1;
+      int KM1 = K - 1; if (KM1 < 1) KM1 = NANG;
+      real SP = DELTH0 * (S.SINTH[K - 1] + S.SINTH[KP1 - 1]) / S.R;
+      real SM = DELTH0 * (S.SINTH[K - 1] + S.SINTH[KM1 - 1]) / S.R;
       int JH = KXLT[IJ];
       real TANPH = SINPH[JH] / COSPH[JH];
       real DRGP = TANPH * SP, DRGM = TANPH * SM;
@@ -149,9 +153,10 @@ int ora_ctuw(int n, int nland, real DELPRO, int MSTART, int MEND, const int *KXL
     }
   }
   /* checks + SUMWN accumulation, ctuw.F90:536-687 */
-  for (int K = 1; K <= NANG; K++)
-    for (int M = MSTART; M <= MEND; M++)
-      for (int IJ = 0; IJ < n; IJ++) {
+#pragma omp parallel for schedule(static)
+  for (int IJ = 0; IJ < n; IJ++)
+    for (int K = 1; K <= NANG; K++)
+      for (int M = MSTART; M <= MEND; M++) {
         size_t b = ((size_t)IJ * NANG + (K - 1)) * NR + (M - 1);
         for (int i = 0; i < 4; i++) if (WLATN[b * 4 + i] > C_(1.0) || WLATN[b * 4 + i] < C_(0.0)) LCFLFAIL[IJ] = 1;
         for (int i = 0; i < 2; i++) if (WLONN[b * 2 + i] > C_(1.0) || WLONN[b * 2 + i] < C_(0.0)) LCFLFAIL[IJ] = 1;

@@ -443,7 +443,7 @@ def test_implsch_edge_cases(api, prec):
     got = H.gpu_implsch(case, ctx)
     st = H.compare_implsch(ref, got, case["tables"])
     assert np.isfinite(got["FL1"]).all()
-    tol = 1e-10 if prec == "dp" else 5e-5
+    tol = 1e-10 if prec == "dp" else 5e-6        # observed 5.5e-7
     print(f"edge cases {prec}: bins {st['fl1_max_rel_peak_clean']:.2e} of the peak, MIJ flips {st['mij_flips']}")
     assert st["fl1_max_rel_peak_clean"] < tol and st["mij_flips"] <= 1, st
     # empty range and single point must be accepted
@@ -827,7 +827,7 @@ def test_long_run_single_precision_tracks_oracle(api):
     assert np.isfinite(got).all()
     rel = np.abs(got - want) / np.maximum(want, 0.05)
     print("long-run swh: p99 rel diff", np.percentile(rel, 99), "max", rel.max())
-    assert np.percentile(rel, 99) < 2.5e-6 and rel.max() < 1.2e-5, (np.percentile(rel, 99), rel.max())   # observed 2.5e-7 / 1.1e-6: gates at 10 x
+    assert np.percentile(rel, 99) < 2.5e-6 and rel.max() < 5e-6, (np.percentile(rel, 99), rel.max())   # observed 2.7e-7 / 4.8e-7 (round 2: 2.5e-7 / 1.1e-6): gates at <= 10 x
     uf = m.ff.cpu().numpy()[:, 7].astype(float)
     assert np.max(np.abs(uf - ff[:, 7]) / np.maximum(ff[:, 7], 1e-3)) < 5e-2
     m.ctx.close()

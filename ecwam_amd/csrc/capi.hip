@@ -69,6 +69,7 @@ template <typename T> void launch_p2c(const void*, void*, int, int, int, int, in
 template <typename T> void launch_pack(const void*, const int*, int, int, void*, hipStream_t);
 template <typename T> int launch_implsch(const void*, int, int, void*, const void*, void*, void*, int*, void*, double*, void*, int, int, int, hipStream_t);
 template <typename T> int launch_implsch4(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, int, int, int, int, int, int, hipStream_t);
+template <typename T> int launch_implsch4x(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, int, int, int, int, int, int, hipStream_t);
 int implsch4_fin_row();
 
 // Does the fourth kernel generation cover these tables?  It needs the pull-form DIA structure with K1W = K -+ r1, K11W = K1W -+ 1,
@@ -595,13 +596,20 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   // depend on the frequency only (LCIWA1, LCIWA3, LCISCAL), without the other optional branches, single and double precision.  The
   // sheltered growth needs TAUWSHELTER /= 0, the normalised one TAUWSHELTER = 0 (setwavphys.F90:150-190).
   const int ext = (c->p.llnormagam || c->p.llgcbz0) ? 1 : 0;
-  const bool rare4 = c->p.lciwa2 || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin || c->p.iphys == 0 || c->p.icode != 3 ||
-                     !c->p.lwvflx_snl;
-  if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !rare4 && !dbg &&
-      (c->p.llnormagam ? c->v4_shelter == 0 : c->v4_shelter != 0)) {
+  const bool rare4 = c->p.lciwa2 || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin > 1 || c->p.icode != 3 || !c->p.lwvflx_snl;
+  // the alternate physics the registered configurations select, on flag set A only: 1 = IPHYS 0 (sinput_jan + sdissip_jan; its
+  // TAUWSHELTER is 0), 2 = ISNONLIN 1 (TRANSF per interaction frequency); both at once: k_implsch2
+  const int alt = (c->p.iphys == 0 ? 1 : 0) | (c->p.isnonlin == 1 ? 2 : 0);
+  const bool alt_ok = alt == 0 || (!ext && alt != 3);
+  const bool shelter_ok = alt == 1 ? true : (c->p.llnormagam ? c->v4_shelter == 0 : c->v4_shelter != 0);
+  if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !rare4 && alt_ok && !dbg && shelter_ok) {
     if (int rc2 = ecwam_hip_implsch_reserve(c, kijl)) return rc2;   // no-op once the buffer covers kijl
-    DISPATCH(rc = launch_implsch4<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s),
-             rc = launch_implsch4<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s));
+    if (alt)
+      DISPATCH(rc = launch_implsch4x<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, alt, s),
+               rc = launch_implsch4x<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, alt, s));
+    else
+      DISPATCH(rc = launch_implsch4<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s),
+               rc = launch_implsch4<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s));
     if (rc == 0) { HIPCHK(hipGetLastError()); c->implsch_last = 4; return 0; }
   }
   c->implsch_last = 2;

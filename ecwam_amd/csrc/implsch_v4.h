@@ -572,12 +572,109 @@ __device__ void v4_sinput_n(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, co
   WSYNC();
 }
 
+// SINPUT_JAN (sinput_jan.F90:171-396, IPHYS = 0; LLNORMAGAM = F): Janssen's wind input with gustiness and the swell damping of IDAMPING.
+// No sheltering: the rows do not depend on each other (the row integrals of the stress are still reduced row by row, but nothing
+// waits for them).  Same outputs as v4_sinput.  coswdif: COS(TH - WDWAVE) of the lane's pair.
+template <typename T, int NANG, int PP, int NGST, bool LLSNEG>
+__device__ void v4_sinput_jan(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UFRIC, T Z0M, T RAORW, T SIG_N, V2<T> coswdif,
+                              T* __restrict__ gfl, T* __restrict__ gsp, unsigned long long& xm0, unsigned long long& xm1, V2<T>& wse,
+                              V2<T>& wslast, V2<T>& apl, T (&rX)[V4_NFRE / (NANG / 2)], T (&rY)[V4_NFRE / (NANG / 2)], T* __restrict__ sXY) {
+  constexpr int G = NANG / 2, NFRE = V4_NFRE, RS = PP * NANG, NS = NFRE / G;
+  const T CONST1 = tb.BETAMAXOXKAPPA2;
+  const T CONST3 = T(tb.IDAMPING) * (T(2) * tb.XKAPPA / CONST1);
+  const T XKAPPAD = T(1) / tb.XKAPPA;
+  for (int m = L.j; m < NFRE; m += G) L.zcn[m] = m_log(L.fac4[m * 4 + Q4_WAVNUM] * Z0M);
+  WSYNC();
+  // gust states (sinput_jan.F90:200-246): US = UFRIC (1 -+ SIG_N), weights 1/2 each
+  const T WS = T(1) / T(NGST);
+  const V2<T> vUS = (NGST == 1) ? V2<T>{UFRIC, UFRIC} : V2<T>{UFRIC * (T(1) - SIG_N), UFRIC * (T(1) + SIG_N)};
+  const bool c0 = coswdif.x > T(0.01), c1 = coswdif.y > T(0.01);
+  const V2<T> xkoc = {tb.XKAPPA * f_rcp(coswdif.x), tb.XKAPPA * f_rcp(coswdif.y)};
+  xm0 = 0ull; xm1 = 0ull;
+  const V2<T> z2 = {T(0), T(0)};
+  wse = z2; wslast = z2; apl = z2;
+  T sp_even = T(0);
+#pragma unroll
+  for (int s = 0; s < NS; s++) { rX[s] = T(0); rY[s] = T(0); }
+  const T* tF = L.tile + L.own;
+#pragma unroll 2
+  for (int m = 0; m < NFRE; m++) {
+    const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
+    const V2<T> cw = *reinterpret_cast<const V2<T>*>(L.fac4 + m * 4 + Q4_CINV);   // CINV, WAVNUM
+    const T ZCN = L.zcn[m], cinv_m = cw.x;
+    const T* row = tb.SINROW[m];   // ZPIFR, DFIM, -, -, RHOWG_DFIM, DFIMOFR of the row
+    const T SIGm = row[0], DFIMm = row[1];
+    const T ZTANHKD = (SIGm * SIGm) * f_rcp(tb.G * cw.y);
+    const T CNSN = (SIGm * CONST1) * ZTANHKD * RAORW;
+    const V2<T> vUCN = vUS * cinv_m + tb.ZALP;
+    const V2<T> vUCND = {f_rcp(vUCN.x), (NGST == 2) ? f_rcp(vUCN.y) : T(0)};
+    V2<T> ufac1 = z2, ufac2 = z2;
+    bool xl0 = false, xl1 = false;
+#pragma unroll
+    for (int ig = 0; ig < NGST; ig++) {
+      const T UCN = ig ? vUCN.y : vUCN.x, UCND = ig ? vUCND.y : vUCND.x, US = ig ? vUS.y : vUS.x;
+      const T Z0 = ZCN + xkoc.x * UCND, Z1 = ZCN + xkoc.y * UCND;
+      const bool n0 = c0 && (Z0 < T(0)), n1 = c1 && (Z1 < T(0));
+      if (sizeof(T) == 4 || __builtin_amdgcn_ballot_w64(n0 || n1) != 0ull) {
+        const V2<T> ZL = {Z0, Z1};
+        const V2<T> Z2X = ZL * ZL * (coswdif * UCN);
+        const V2<T> ex = {f_exp(Z0), f_exp(Z1)};
+        const V2<T> g = ex * Z2X * Z2X * CNSN;
+        ufac1.x += n0 ? WS * g.x : T(0);
+        ufac1.y += n1 ? WS * g.y : T(0);
+        xl0 = xl0 || n0;
+        xl1 = xl1 || n1;
+      }
+      if (LLSNEG) {   // swell damping (sinput_jan.F90:368-381)
+        const T C3 = CONST3 * (UCN * UCN);
+        const T XVD = f_rcp(-US * XKAPPAD * ZCN * cinv_m);
+        ufac2 = ufac2 + (WS * C3) * (coswdif - XVD);
+      }
+    }
+    const V2<T> fl = ufac1 + ufac2 * CNSN;
+    const V2<T> sp = ufac1 * f;
+    T xrow = T(0), yrow = T(0);
+    if (sizeof(T) == 4 || __builtin_amdgcn_ballot_w64(xl0 || xl1) != 0ull) {
+      const V2<T> sx = sp * L.sinth, sy = sp * L.costh;
+      const V2<T> xs = v4_allsum<G, T>(V2<T>{sx.x + sx.y, sy.x + sy.y}, L.rot);
+      xrow = xs.x; yrow = xs.y;
+    }
+    if constexpr (G == 18) {
+      *reinterpret_cast<V2<T>*>(sXY + 2 * m) = V2<T>{xrow, yrow};
+    } else {
+      const int ms = m / G, mj = m - ms * G;
+      const bool mine = (L.j == mj);
+#pragma unroll
+      for (int s = 0; s < NS; s++) {
+        const bool w = mine && (ms == s);
+        rX[s] = w ? xrow : rX[s];
+        rY[s] = w ? yrow : rY[s];
+      }
+    }
+    if (LLSNEG) {
+      apl = apl + (fl * f - sp) * row[4];
+      *reinterpret_cast<V2<T>*>(gfl + (size_t)m * NANG) = fl;
+      if (m & 1) *reinterpret_cast<V2<T>*>(gsp + (size_t)(m >> 1) * NANG) = V2<T>{sp_even, sp.x + sp.y};
+      else sp_even = sp.x + sp.y;
+    }
+    if (xl0) xm0 |= (1ull << m);
+    if (xl1) xm1 |= (1ull << m);
+    const V2<T> x = {xl0 ? f.x : T(0), xl1 ? f.y : T(0)};
+    wse = wse + V2<T>{DFIMm, row[5]} * (x.x + x.y);
+    wslast = x;
+  }
+  WSYNC();
+}
+
 // One wavefront advances PP sea points.  Lanes beyond PP G shadow other lanes and the points of a short last wave shadow its
 // last point: shadows run the same instructions on the same data, so their LDS and global stores repeat their original's values
 // at the same addresses -- no store is predicated.
 // EXT: the build that also carries LLGCBZ0 (gravity-capillary roughness: HALPHAP, TAUT_Z0 with STRESS_GC per point across the wave)
 // and LLNORMAGAM (normalised growth rate) -- the cy49r1 / cy50r1 physics; the flag-set-A build has none of that code.
-template <typename T, int NANG, int PP, int R1, int R2, int NH, bool EXT>
+// JAN: IPHYS = 0 (sinput_jan.F90 + sdissip_jan.F90: the dissipation is a rate per (point, frequency) in the saturation slot of the
+// factor table; no saturation filter, no sheltering recurrence).  ENHMC: ISNONLIN = 1 (the DIA scaled per interaction frequency by
+// TRANSF(k(MC), DEPTH), snonlin.F90:138-150).  Both without EXT.
+template <typename T, int NANG, int PP, int R1, int R2, int NH, bool EXT, bool JAN = false, bool ENHMC = false>
 // single precision: two waves per SIMD (LDS: 8 waves per CU), at most 256 VGPRs; double precision: the LDS holds one wave per SIMD
 // (40 KB per wave) and the kernel may use the whole register file (340 registers: no scratch)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(V4_WPE_MIN(T), 2)))
@@ -589,6 +686,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   constexpr int VEC = 16 / (int)sizeof(T);   // elements per 16-byte global access
   constexpr int NC = NFRE / VEC;             // 16-byte chunks per direction
   static_assert(PP * G <= 64 && NFRE % G == 0 && NFRE % VEC == 0 && R2 + 2 <= 2 * NSH + 1 && PP * NFRE >= RS, "layout");
+  static_assert(!(EXT && (JAN || ENHMC)), "IPHYS = 0 and ISNONLIN = 1 are built without LLGCBZ0 / LLNORMAGAM");
   typedef T VT __attribute__((ext_vector_type(VEC)));
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const DevTab<T>& tb = *tp;
@@ -865,6 +963,19 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     so = v4_allsum<G, T>(so, L.rot);
     if (j == 0) { c[C_UORBT] = tb.EPSMIN + so.x; c[C_AORB] = tb.EPSMIN + so.y; c[C_EMEAN] = EMEAN; c[C_F1MEAN] = F1MEAN; }
   }
+  if constexpr (JAN) {
+    // SDISSIP_JAN (sdissip_jan.F90:92-128) is a rate per (point, frequency): TEMP1(M) goes to the slot of the saturation scale, which
+    // nothing reads before IMPHFTAIL (restored behind the sweep)
+    const T SDSJ = (tb.CDIS * tb.ZPI) * F1MEAN * (EMEAN * EMEAN) * m_pow4(XKMEAN);
+    const T CVIS = tb.RNU * tb.CDISVIS;
+#pragma unroll
+    for (int q = 0; q < NS; q++) {
+      const int m = q * G + j;
+      const T wn = L.fac4[m * 4 + Q4_WAVNUM];
+      const T X = wn / XKMEAN;
+      L.fac4[m * 4 + Q4_BSC] = SDSJ * X * ((T(1) - tb.DELTA_SDIS) + tb.DELTA_SDIS * X) + CVIS * (wn * wn);
+    }
+  }
   WSYNC();
   V4_PHASE_EXIT(202);
   const bool gcb = EXT && tb.LLGCBZ0, norma = EXT && tb.LLNORMAGAM;
@@ -1007,6 +1118,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   T FMEANWS, EMW;
   if (norma) v4_sinput_n<T, NANG, PP, 1, false>(tb, L, wp + 3 * NFRE, UFRIC, Z0M, RAORW, RNFAC, T(0), T(0), T(0), T(0), coswdif, sinwdif2, nullptr, nullptr,
                                                xm0, xm1, wse, wslast, apl, rX, rY, sXY);
+  else if constexpr (JAN) v4_sinput_jan<T, NANG, PP, 1, false>(tb, L, UFRIC, Z0M, RAORW, T(0), coswdif, nullptr, nullptr, xm0, xm1, wse, wslast, apl, rX, rY, sXY);
   else v4_sinput<T, NANG, PP, 1, false>(tb, L, UFRIC, Z0M, RAORW, T(0), T(0), T(0), T(0), sinwd, coswd, nullptr, nullptr, xm0, xm1, wse, wslast, apl, rX, rY, sXY);
   femws_finish(wse, wslast, FMEANWS, EMW);
   int MIJ = frcutindex4(FMEANWS, UFRIC);
@@ -1036,6 +1148,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   T* gx = xllws + (size_t)ij * N + 2 * j;   // this lane's pair in row 0 of the block
   if (norma) v4_sinput_n<T, NANG, PP, 2, true>(tb, L, wp + 3 * NFRE, UFRIC, Z0M, RAORW, RNFAC, c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], coswdif,
                                               sinwdif2, gx, gsp, xm0, xm1, wse, wslast, apl, rX, rY, sXY);
+  else if constexpr (JAN) v4_sinput_jan<T, NANG, PP, 2, true>(tb, L, UFRIC, Z0M, RAORW, c[C_SIGN], coswdif, gx, gsp, xm0, xm1, wse, wslast, apl, rX, rY, sXY);
   else v4_sinput<T, NANG, PP, 2, true>(tb, L, UFRIC, Z0M, RAORW, c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], sinwd, coswd, gx, gsp, xm0, xm1, wse,
                                        wslast, apl, rX, rY, sXY);
   femws_finish(wse, wslast, FMEANWS, EMW);
@@ -1060,13 +1173,47 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   {
     T ENHFR = m_max(T(0.75) * DEPTH * AKMEAN, T(0.5));
     ENHFR = T(1) + (T(5.5) / ENHFR) * (T(1) - T(0.833) * ENHFR) * m_exp(-T(1.25) * ENHFR);
+    // ISNONLIN = 1 (snonlin.F90:138-150): ENH(MC) = MAX(MIN(ENH_MAX, TRANSF(k(MC), DEPTH)), ENH_MIN) per interaction frequency; lane j of
+    // the point evaluates MC = q G + j + 1 (the wavenumber of the point's own table up to NFRE, the deep-water one beyond) and hands
+    // it to the point's lanes with one lane exchange per interaction
+    constexpr int NQE = ENHMC ? (V4_NFRE + 4 + G - 1) / G : 1;
+    T rENH[NQE];
+    int enh_lane0 = 0, enh_ext0 = 0;   // byte addresses of the point's lanes for pair 0 and for pair 16 (36 directions: the extras)
+    if constexpr (ENHMC) {
+#pragma unroll
+      for (int q = 0; q < NQE; q++) {
+        const int mc = q * G + j;   // MC - 1
+        T XK;
+        if (mc < NFRE) XK = L.fac4[mc * 4 + Q4_WAVNUM];
+        else {
+          T fr = T(1);
+          for (int i = 0; i < mc + 1 - NFRE; i++) fr = fr * tb.FRATIO;
+          const T w = tb.ZPIFR[NFRE - 1] * fr;
+          XK = tb.GM1 * (w * w);
+        }
+        rENH[q] = m_max(m_min(T(10), transf_d(tb, XK, DEPTH)), T(0.1));
+      }
+      if constexpr (G == 18) { enh_lane0 = 4 * (16 * p); enh_ext0 = 4 * (48 + 2 * p - 16); }
+      else { enh_lane0 = 4 * (p * G); enh_ext0 = enh_lane0; }
+    }
+    auto enh_of = [&](int MC) -> T {   // MC wave-uniform
+      if constexpr (!ENHMC) return ENHFR;
+      else {
+        const int q = (MC - 1) / G, jl = (MC - 1) - q * G;
+        T v = rENH[0];
+#pragma unroll
+        for (int i = 1; i < NQE; i++) v = (q == i) ? rENH[i] : v;
+        const int base = (G == 18 && jl >= 16) ? enh_ext0 : enh_lane0;
+        return v4_bp(base + 4 * jl, v);
+      }
+    };
     const T DAL1 = tb.DAL1, DAL2 = tb.DAL2;
     T wt[NH + 1];   // SATWEIGHTS depend on the tap only and are symmetric (checked by ecwam_hip_create): wave-uniform, taps -NH .. 0
 #pragma unroll
     for (int t = 0; t <= NH; t++) wt[t] = tb.SATWEIGHTS[t][NANG / 2];
     const T TMP03 = T(1) / (tb.SDSBR * tb.MICHE), SSDSC4 = tb.SSDSC4;
     const T c2 = tb.SSDSC2 * tb.SSDSC6, c2m1 = tb.SSDSC2 * (T(1) - tb.SSDSC6);
-    const bool turb = tb.SSDSC5 != T(0);
+    const bool turb = !JAN && tb.SSDSC5 != T(0);
     const T FACTURB = turb ? (T(2) * tb.SSDSC5 / tb.G) * RAORW * UFRIC * UFRIC : T(0);
     const T DELT = (T)tb.IDELT, DELTM = T(1) / DELT, DELT5 = tb.XIMP * DELT;
     const bool shallow_brk = tb.LBIWBK && (DEPTH < T(50));
@@ -1150,7 +1297,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       // the slot of the wind-input ring is free: row m+4 (beyond the last row the last one again, never used: no branch)
       wslot = *reinterpret_cast<const V2<T>*>(gx + (size_t)hi35(m + 4) * NANG);
     };
-    *reinterpret_cast<V2<T>*>(st4 + L.own) = fR[5];   // row MC-4 of the first interaction
+    if constexpr (!JAN) *reinterpret_cast<V2<T>*>(st4 + L.own) = fR[5];   // row MC-4 of the first interaction
     V4SYNC();
     int MCb = 0;
     for (; MCb < MLST; MCb += 8) {
@@ -1162,19 +1309,22 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         // ---- stage 1: row MC-4 back from its staging row (rotated reads at fixed addresses), the factors of rows MC-5 and MC-4
         const V2<T> fIC = fR[jj & 7], fIP = fR[(jj + 2) & 7], fIM = fR[(jj + 4) & 7], fIM1 = fR[(jj + 5) & 7];
         T el[4 * NSH + 2];                // row MC-4: element e = F(2j - 2 NSH + e)
-#pragma unroll
-        for (int i = 0; i <= 2 * NSH; i++) {
-          const V2<T> v = (i == NSH) ? fIM1 : *reinterpret_cast<const V2<T>*>(st4 + sh[i]);
-          el[2 * i] = v.x; el[2 * i + 1] = v.y;
-        }
         const int IM = lo0(MC - 5), IM1 = hi35(lo0(MC - 4));
-        const T bscn = L.fac4[IM1 * 4 + Q4_BSC];
+        T bscn = T(0);
+        if constexpr (!JAN) {
+#pragma unroll
+          for (int i = 0; i <= 2 * NSH; i++) {
+            const V2<T> v = (i == NSH) ? fIM1 : *reinterpret_cast<const V2<T>*>(st4 + sh[i]);
+            el[2 * i] = v.x; el[2 * i + 1] = v.y;
+          }
+          bscn = L.fac4[IM1 * 4 + Q4_BSC];
+        }
         const V2<T> qf0 = *reinterpret_cast<const V2<T>*>(L.fac4 + IM * 4), qf1 = *reinterpret_cast<const V2<T>*>(L.fac4 + IM * 4 + 2);
         // ---- coefficient record of the interaction (wave-uniform)
         const T* cg = tb.DIACF[MC - 1];
         const T* cs = cg + 12;
         const T GW1 = cg[1], GW2 = cg[2], GW3 = cg[3], GW4 = cg[4], GW5 = cg[5], GW6 = cg[6], GW7 = cg[7], GW8 = cg[8];
-        const T FTEMP = cg[9] * ENHFR;
+        const T FTEMP = cg[9] * enh_of(MC <= MLST ? MC : MLST);
         const T FKLAMPA = cs[0], FKLAMPB = cs[1], FKLAMP2 = cs[2], FKLAMP1 = cs[3];
         const T FKLAPA2 = cs[4], FKLAPB2 = cs[5], FKLAP12 = cs[6], FKLAP22 = cs[7];
         const T FKLAMMA = cs[8], FKLAMMB = cs[9], FKLAMM2 = cs[10], FKLAMM1 = cs[11];
@@ -1184,7 +1334,10 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         if (m - 1 >= 0 && m - 1 < NFRE) update_row(m - 1, aS[(jj + 4) & 7], aF[(jj + 4) & 7], wiq[(jj + 3) & 3], cg[28], cg[29], cg[30], cg[11]);
         // the dissipation coefficient of row m (sdissip_ard.F90:117-314) from the saturation spectrum and the maximum the previous
         // interaction left in flight
-        {
+        if constexpr (JAN) {   // SDISSIP_JAN: the rate of row m sits in the saturation slot of the factor table
+          u_D = V2<T>{qf0.x, qf0.x};
+          u_f = fIM; u_sbo = qf0.y; u_cinv = qf1.x; u_wn = qf1.y;
+        } else {
           const T bm = (G == 18) ? e3_p : m_max(bm_p, m_max(e3_p, e4_p));
           const T d0 = m_max(T(0), bm * TMP03 - SSDSC4);
           const V2<T> t1 = bs_p * TMP03 - SSDSC4;
@@ -1207,15 +1360,19 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         SAMk[0] = v4_at<T, NSH, R2>(st2, sh) + v4_at<T, NSH, R2 + 1>(st3, sh);
         SAPk[1] = (R1 == 0 ? up : v4_at<T, NSH, R1>(st0, sh)) + v4_at<T, NSH, R1 + 1>(st1, sh);
         SAMk[1] = v4_at<T, NSH, -R2>(st2, sh) + v4_at<T, NSH, -(R2 + 1)>(st3, sh);
-        V2<T> bsat = {wt[NH] * el[2 * NSH], wt[NH] * el[2 * NSH + 1]};
+        V2<T> bsat = z2;
+        T bm1 = T(0), e0 = T(0);
+        if constexpr (!JAN) {
+          bsat = V2<T>{wt[NH] * el[2 * NSH], wt[NH] * el[2 * NSH + 1]};
 #pragma unroll
-        for (int d = 1; d <= NH; d++) {
-          bsat.x += wt[NH - d] * (el[2 * NSH - d] + el[2 * NSH + d]);
-          bsat.y += wt[NH - d] * (el[2 * NSH + 1 - d] + el[2 * NSH + 1 + d]);
+          for (int d = 1; d <= NH; d++) {
+            bsat.x += wt[NH - d] * (el[2 * NSH - d] + el[2 * NSH + d]);
+            bsat.y += wt[NH - d] * (el[2 * NSH + 1 - d] + el[2 * NSH + 1 + d]);
+          }
+          bsat = bsat * bscn;
+          bm1 = m_max(bsat.x, bsat.y);
+          e0 = v4_bp(L.rot.a0, bm1);
         }
-        bsat = bsat * bscn;
-        T bm1 = m_max(bsat.x, bsat.y);
-        const T e0 = v4_bp(L.rot.a0, bm1);
         V4SYNC();
         // ---- stage 3: the DIA products of the two mirror images (snonlin.F90:264-306)
         const V2<T> FCEN = FTEMP * FIJ;
@@ -1248,7 +1405,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
               A1[0] = (R1 == 0) ? AD : v4_at<T, NSH, R1>(sa, sh); A1s[0] = v4_at<T, NSH, R1 + 1>(sa, sh);
               D2[0] = v4_at<T, NSH, -R2>(sm, sh); D2s[0] = v4_at<T, NSH, -(R2 + 1)>(sm, sh);
               P1[0] = (R1 == 0) ? DELAP : v4_at<T, NSH, R1>(sp, sh); P1s[0] = v4_at<T, NSH, R1 + 1>(sp, sh);
-              if constexpr (G != 18) {
+              if constexpr (G != 18 && !JAN) {
                 bm1 = m_max(bm1, e0);
                 if (G == 12) e1 = v4_bp(L.rot.a1, bm1);
               }
@@ -1257,7 +1414,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
               A1[1] = (R1 == 0) ? AD : v4_at<T, NSH, -R1>(sa, sh); A1s[1] = v4_at<T, NSH, -(R1 + 1)>(sa, sh);
               D2[1] = v4_at<T, NSH, R2>(sm, sh); D2s[1] = v4_at<T, NSH, R2 + 1>(sm, sh);
               P1[1] = (R1 == 0) ? DELAP : v4_at<T, NSH, -R1>(sp, sh); P1s[1] = v4_at<T, NSH, -(R1 + 1)>(sp, sh);
-              if constexpr (G == 18) {   // extras folded in, row maximum (no LDS), back to the extras: read by the next interaction
+              if constexpr (JAN) {
+              } else if constexpr (G == 18) {   // extras folded in, row maximum (no LDS), back to the extras: read by the next interaction
                 bm1 = v4_rowmax<T>(m_max(bm1, e0));
                 e3 = v4_bp(L.rot.a1, bm1);
               } else {
@@ -1288,7 +1446,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
           }
         }
         // ---- row MC-3 (the saturation row of the next interaction) -> its staging row; row MC+3 enters the ring in the slot of row MC-5
-        *reinterpret_cast<V2<T>*>(st4 + L.own) = fR[(jj + 6) & 7];
+        if constexpr (!JAN) *reinterpret_cast<V2<T>*>(st4 + L.own) = fR[(jj + 6) & 7];
         fR[(jj + 4) & 7] = *reinterpret_cast<const V2<T>*>(tF + hi35(MC + 3) * RS);
         bs_p = bsat; bm_p = bm1; e3_p = e3; e4_p = e4; sig_p = cg[10];
         V4SYNC();
@@ -1304,11 +1462,13 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   // the Stokes-drift weights STOKFAC(M) DFIM_SIM(M) of the lane's frequencies: loaded here, used behind the flux sums (their
   // round trip to memory hides behind the three all-reduces)
   T stkw[NS], stkd[NS];
+  T xk2r[JAN ? NS : 1];
 #pragma unroll
   for (int q = 0; q < NS; q++) {   // unconditional loads, pinned here (a conditional one is sunk into a branch behind the sums: load, wait, twice)
     const int m = q * G + j;
     stkw[q] = wp[4 * NFRE + m];
     stkd[q] = tb.DFIM_SIM[m];
+    if constexpr (JAN) xk2r[q] = wp[3 * NFRE + m];   // XK2CG again: the saturation scale WAVNUM XK2CG / 2 pi back into its slot for IMPHFTAIL
   }
   __builtin_amdgcn_sched_barrier(0);
 
@@ -1329,6 +1489,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     const int m = q * G + j;
     L.sq[m] = m_sqrt(L.fac4[m * 4 + Q4_WAVNUM]);
     L.zcn[m] = (m < tb.NFRE_ODD) ? stkw[q] * stkd[q] : T(0);
+    if constexpr (JAN) L.fac4[m * 4 + Q4_BSC] = L.fac4[m * 4 + Q4_WAVNUM] * (T(1) / tb.ZPI) * xk2r[q];
   }
   WSYNC();
   T EMEANWS;

@@ -278,7 +278,17 @@ def test_implsch_parity_iphys_0(api, prec, llnormagam):
     ref = H.oracle_implsch(case, _oracle(cfg, prec))
     ctx = api.HipContext(case["tables"])
     got = H.gpu_implsch(case, ctx)
+    gen = ctx.implsch_generation_used()
     st = H.compare_implsch(ref, got, case["tables"])
+    # the registered configuration (LLNORMAGAM = F) runs the fast kernel (k_implsch4 with SINPUT_JAN / SDISSIP_JAN); the two kernel
+    # generations agree with each other as they do on flag set A
+    assert gen == (2 if llnormagam else 4)
+    if not llnormagam:
+        ctx.set_implsch_generation(2)
+        got2 = H.gpu_implsch(case, ctx)
+        assert ctx.implsch_generation_used() == 2
+        st2 = H.compare_implsch(got2, got, case["tables"])
+        assert st2["mij_flips"] == 0 and st2["xllws_bins_diff"] == 0 and st2["fl1_max_rel_peak_all"] < (1e-12 if prec == "dp" else 2e-5), st2
     ctx.close()
     assert np.isfinite(got["FL1"]).all() and np.isfinite(got["FF"]).all() and np.isfinite(got["INTF"]).all()
     if prec == "dp":
@@ -310,6 +320,7 @@ def test_implsch_parity_isnonlin_1_2(api, prec, isnonlin):
     ref = H.oracle_implsch(case, o)
     ctx = api.HipContext(case["tables"])
     got = H.gpu_implsch(case, ctx)
+    assert ctx.implsch_generation_used() == (4 if isnonlin == 1 else 2)      # ISNONLIN = 1 is a build of the fast kernel
     st = H.compare_implsch(ref, got, case["tables"])
     ctx.close()
     if prec == "dp":
@@ -320,6 +331,42 @@ def test_implsch_parity_isnonlin_1_2(api, prec, isnonlin):
     c0 = dict(case); c0["cfg"] = cfg0; c0["tables"] = Tables(cfg0, dt)
     r0 = H.oracle_implsch(c0, _oracle(cfg0, prec))
     assert np.max(np.abs(r0["FL1"] - ref["FL1"])) > 0                             # the option acts
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+@pytest.mark.parametrize("nang,nred,flags", [(36, 36, dict(iphys=0)), (24, 29, dict(iphys=0)), (36, 36, dict(isnonlin=1)), (12, 25, dict(isnonlin=1)),
+                                             (24, 29, dict(iphys=0, lciwa3=True, lciscal=True)), (36, 36, dict(iphys=0, isnonlin=1))])
+def test_alternate_physics_on_the_fast_kernel(api, prec, nang, nred, flags):
+    """Every build of k_implsch4 for IPHYS = 0 (sinput_jan.F90, sdissip_jan.F90) and ISNONLIN = 1 (snonlin.F90:138-150) -- 36 / 24 / 12
+    directions, both precisions -- against the oracle and against k_implsch2, on a case with shallow and intermediate depths (TRANSF
+    and the depth-dependent dispersion act).  Both options at once stay on k_implsch2."""
+    cfg = Config(nang=nang, nfre=36, nfre_red=nred, **flags)
+    n = 700
+    case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=23)
+    dt = H.np_dtype(prec)
+    rng = np.random.default_rng(8)
+    from ecwam_amd import synthetic as syn
+    case["ENV"][:, 1] = (10.0 ** rng.uniform(0.6, 2.9, n)).astype(dt)            # 4 m .. 800 m
+    pr = syn.depth_props(case["ENV"][:, 1], case["tables"], dt)
+    case["props"] = pr
+    case["ENV"][:, 0] = pr["EMAXDPT"]
+    if flags.get("lciwa3"):
+        case["FF"][:, 2] = rng.uniform(0.0, 0.9, n).astype(dt) * (rng.uniform(0, 1, n) < 0.4)      # CICOVER
+        case["FF"][:, 13] = rng.uniform(0.1, 3.0, n).astype(dt)                                      # CITHICK
+    ref = H.oracle_implsch(case, _oracle(cfg, prec))
+    ctx = api.HipContext(case["tables"])
+    got = H.gpu_implsch(case, ctx)
+    both = "iphys" in flags and "isnonlin" in flags
+    assert ctx.implsch_generation_used() == (2 if both else 4)
+    st = H.compare_implsch(ref, got, case["tables"])
+    _assert_implsch_stats(st, n, prec)
+    if not both:
+        ctx.set_implsch_generation(2)
+        got2 = H.gpu_implsch(case, ctx)
+        assert ctx.implsch_generation_used() == 2
+        st2 = H.compare_implsch(got2, got, case["tables"])
+        assert st2["mij_flips"] == 0 and st2["xllws_bins_diff"] == 0 and st2["fl1_max_rel_peak_all"] < (1e-12 if prec == "dp" else 2e-5), st2
+    ctx.close()
 
 
 _SWEEP = [dict(llcapchnk=False), dict(lbiwbk=False), dict(licerun=False), dict(lmaskice=False), dict(lwamrsetci=False),

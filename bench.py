@@ -202,7 +202,7 @@ def main() -> None:
     # N > 1: the model starts on the host-staged transport (no RCCL involved: it cannot fail to set up), then moves to the asked one
     m = Wamintgr(cfg, grid, a.prec, device=local_rank, rank=rank, nranks=world, weights=a.weights, strip_width=a.strip,
                  ifrelfmax=a.ifrelfmax, delpro_lf=(dt / 2.0 if a.ifrelfmax else None), halo_transport="host" if world > 1 else "torch")
-    m.init_synthetic()
+    m.init_synthetic(env_on_device=bool(a.irefra) and world > 1)      # refraction on N > 1 ranks: PROENVHALO on the device, halo rows through the transport
     m.ff_next = m.ff.clone()      # NEWWIND hands the (unchanged synthetic) forcing over every step: k_newwind is part of the step
     nfail = m.build_weights()
     if nfail:

@@ -345,6 +345,16 @@ class HipContext:
     def halo_finish(self) -> None:
         self._chk(self.lib.ecwam_hip_halo_finish(self._h, _stream_ptr()))
 
+    # -- PROENVHALO on the device (proenvhalo.F90:63-107)
+    def proenvhalo_pack(self, n, wvprpt, omosnh2kd, depth, ucur, vcur, buffer_ext) -> None:
+        self._chk(self.lib.ecwam_hip_proenvhalo_pack(self._h, int(n), wvprpt.data_ptr(), omosnh2kd.data_ptr(), depth.data_ptr(), ucur.data_ptr(),
+                                                     vcur.data_ptr(), buffer_ext.data_ptr(), _stream_ptr()))
+
+    def proenvhalo_unpack(self, nrows, buffer_ext, land, wavnum_ext, cgroup_ext, omosnh2kd_ext, depth_ext, u_ext, v_ext) -> None:
+        self._chk(self.lib.ecwam_hip_proenvhalo_unpack(self._h, int(nrows), buffer_ext.data_ptr(), land.data_ptr(), wavnum_ext.data_ptr(),
+                                                       cgroup_ext.data_ptr(), omosnh2kd_ext.data_ptr(), depth_ext.data_ptr(), u_ext.data_ptr(),
+                                                       v_ext.data_ptr(), _stream_ptr()))
+
     def halo_pack_host(self, fl, host_send) -> None:
         self._chk(self.lib.ecwam_hip_halo_pack_host(self._h, fl.data_ptr(), self._rows(fl), host_send.data_ptr(), _stream_ptr()))
 

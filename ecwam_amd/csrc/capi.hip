@@ -67,6 +67,8 @@ template <typename T> void launch_nosource(const void*, int, int, int, void*, vo
 template <typename T> void launch_c2p(const void*, void*, int, int, int, int, int, hipStream_t);
 template <typename T> void launch_p2c(const void*, void*, int, int, int, int, int, hipStream_t);
 template <typename T> void launch_pack(const void*, const int*, int, int, void*, hipStream_t);
+template <typename T> void launch_proenv_pack(int, int, const void*, const void*, const void*, const void*, const void*, void*, hipStream_t);
+template <typename T> void launch_proenv_unpack(int, int, const void*, const void*, void*, void*, void*, void*, void*, void*, hipStream_t);
 template <typename T> int launch_implsch(const void*, int, int, void*, const void*, void*, void*, int*, void*, double*, void*, int, int, int, hipStream_t);
 template <typename T> int launch_implsch4(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, int, int, int, int, int, int, hipStream_t);
 template <typename T> int launch_implsch4x(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, int, int, int, int, int, int, hipStream_t);
@@ -773,6 +775,27 @@ int ecwam_hip_halo_setup(ecwam_hip_ctx* c, int rank, int nranks, int npeers, con
     HIPCHK(hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
   }
+  return 0;
+}
+
+int ecwam_hip_proenvhalo_pack(ecwam_hip_ctx* c, int n, const void* wvprpt, const void* omosnh2kd, const void* depth, const void* ucur, const void* vcur,
+                              void* buffer_ext, void* stream) {
+  if (!c) return fail("null context");
+  if (n < 0 || (n > 0 && (!wvprpt || !omosnh2kd || !depth || !ucur || !vcur || !buffer_ext))) return fail("ecwam_hip_proenvhalo_pack: bad arguments");
+  DISPATCH(launch_proenv_pack<float>(n, c->NFRE, wvprpt, omosnh2kd, depth, ucur, vcur, buffer_ext, (hipStream_t)stream),
+           launch_proenv_pack<double>(n, c->NFRE, wvprpt, omosnh2kd, depth, ucur, vcur, buffer_ext, (hipStream_t)stream));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ecwam_hip_proenvhalo_unpack(ecwam_hip_ctx* c, int nrows, const void* buffer_ext, const void* land, void* wavnum_ext, void* cgroup_ext,
+                                void* omosnh2kd_ext, void* depth_ext, void* u_ext, void* v_ext, void* stream) {
+  if (!c) return fail("null context");
+  if (nrows < 0 || !buffer_ext || !land || !wavnum_ext || !cgroup_ext || !omosnh2kd_ext || !depth_ext || !u_ext || !v_ext)
+    return fail("ecwam_hip_proenvhalo_unpack: bad arguments");
+  DISPATCH(launch_proenv_unpack<float>(nrows, c->NFRE, buffer_ext, land, wavnum_ext, cgroup_ext, omosnh2kd_ext, depth_ext, u_ext, v_ext, (hipStream_t)stream),
+           launch_proenv_unpack<double>(nrows, c->NFRE, buffer_ext, land, wavnum_ext, cgroup_ext, omosnh2kd_ext, depth_ext, u_ext, v_ext, (hipStream_t)stream));
+  HIPCHK(hipGetLastError());
   return 0;
 }
 

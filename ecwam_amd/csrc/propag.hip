@@ -1155,6 +1155,43 @@ __global__ void k_pack_rows(const T* __restrict__ fl, const int* __restrict__ id
   }
 }
 
+// PROENVHALO (proenvhalo.F90:69-107) on the device.  BUFFER_EXT[row][3 NFRE + 3]: WAVNUM(1:NFRE), CGROUP, OMOSNH2KD, DEPTH, UCUR, VCUR
+// of every local row (DELLAM1 / COSPHM1 of the reference's buffer are static geometry the context already holds per row).
+// k_proenv_pack fills the owned rows from the device-resident fields; the halo rows arrive through the library's MPEXCHNG on rows of
+// 3 NFRE + 3 reals; k_proenv_unpack spreads all rows over the extended arrays the advection kernels read and fills the land slot
+// (WVPRPT_LAND, BATHYMAX, U = V = 0: proenvhalo.F90:99-106).
+template <typename T>
+__global__ void k_proenv_pack(int n, int NFRE, const T* __restrict__ wvprpt, const T* __restrict__ omosnh2kd, const T* __restrict__ depth,
+                              const T* __restrict__ ucur, const T* __restrict__ vcur, T* __restrict__ buf) {
+  const int RL = 3 * NFRE + 3;
+  const long long total = (long long)n * RL;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const int ij = (int)(g / RL), e = (int)(g - (long long)ij * RL);
+    T v;
+    if (e < 2 * NFRE) v = wvprpt[(size_t)ij * ECWAM_HIP_NWPR * NFRE + e];     // WAVNUM and CGROUP are members 0 and 1 of the WVPRPT row
+    else if (e < 3 * NFRE) v = omosnh2kd[(size_t)ij * NFRE + (e - 2 * NFRE)];
+    else v = (e == 3 * NFRE) ? depth[ij] : (e == 3 * NFRE + 1 ? ucur[ij] : vcur[ij]);
+    buf[g] = v;
+  }
+}
+template <typename T>
+__global__ void k_proenv_unpack(int nrows, int NFRE, const T* __restrict__ buf, const T* __restrict__ land, T* __restrict__ wavnum_ext,
+                                T* __restrict__ cgroup_ext, T* __restrict__ omosnh2kd_ext, T* __restrict__ depth_ext, T* __restrict__ u_ext,
+                                T* __restrict__ v_ext) {
+  const int RL = 3 * NFRE + 3;
+  const long long total = (long long)(nrows + 1) * RL;      // + the land slot, row index nrows
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const int ij = (int)(g / RL), e = (int)(g - (long long)ij * RL);
+    const T v = ij < nrows ? buf[g] : land[e];
+    if (e < NFRE) wavnum_ext[(size_t)ij * NFRE + e] = v;
+    else if (e < 2 * NFRE) cgroup_ext[(size_t)ij * NFRE + (e - NFRE)] = v;
+    else if (e < 3 * NFRE) omosnh2kd_ext[(size_t)ij * NFRE + (e - 2 * NFRE)] = v;
+    else if (e == 3 * NFRE) depth_ext[ij] = v;
+    else if (e == 3 * NFRE + 1) u_ext[ij] = v;
+    else v_ext[ij] = v;
+  }
+}
+
 // ---- host launchers (called from capi.hip) ---------------------------------------------------------
 // dynamic LDS beyond the default 64 KB limit (double precision, 48 frequencies, obstructions: 80 KB of the CU's 160 KB)
 template <typename K>
@@ -1344,7 +1381,23 @@ void launch_pack(const void* fl, const int* idx, int n, int rowlen, void* buf, h
   hipLaunchKernelGGL(k_pack_rows<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)fl, idx, n, rowlen, (T*)buf);
 }
 
+template <typename T>
+void launch_proenv_pack(int n, int NFRE, const void* wvprpt, const void* om, const void* depth, const void* u, const void* v, void* buf, hipStream_t s) {
+  const long long total = (long long)n * (3 * NFRE + 3);
+  if (total <= 0) return;
+  hipLaunchKernelGGL(k_proenv_pack<T>, dim3(grid_for(total)), dim3(256), 0, s, n, NFRE, (const T*)wvprpt, (const T*)om, (const T*)depth, (const T*)u,
+                     (const T*)v, (T*)buf);
+}
+template <typename T>
+void launch_proenv_unpack(int nrows, int NFRE, const void* buf, const void* land, void* wn, void* cg, void* om, void* dep, void* u, void* v, hipStream_t s) {
+  const long long total = (long long)(nrows + 1) * (3 * NFRE + 3);
+  hipLaunchKernelGGL(k_proenv_unpack<T>, dim3(grid_for(total)), dim3(256), 0, s, nrows, NFRE, (const T*)buf, (const T*)land, (T*)wn, (T*)cg, (T*)om,
+                     (T*)dep, (T*)u, (T*)v);
+}
+
 #define INST(T)                                                                                                                   \
+  template void launch_proenv_pack<T>(int, int, const void*, const void*, const void*, const void*, const void*, void*, hipStream_t); \
+  template void launch_proenv_unpack<T>(int, int, const void*, const void*, void*, void*, void*, void*, void*, void*, hipStream_t); \
   template void launch_propags2<T>(const void*, const void*, void*, const int*, const int*, const int*, const void*, int, int,   \
                                    int, int, int, int, hipStream_t);                                                              \
   template void launch_ctuw<T>(const void*, int, int, int, double, int, int, const int*, const void*, double, const void*,       \

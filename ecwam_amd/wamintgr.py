@@ -177,7 +177,9 @@ class Wamintgr:
             self.wavnum_ext = torch.zeros((self.nrows, NFRE), **z)
 
     # ---- synthetic initial state; identical for every decomposition
-    def init_synthetic(self, seed: int = 12345, chunk: int = 65536, currents: bool | None = None) -> None:
+    def init_synthetic(self, seed: int = 12345, chunk: int = 65536, currents: bool | None = None, env_on_device: bool = False) -> None:
+        """env_on_device (refraction on a decomposed grid): the extended DEPTH / UCUR / VCUR / OMOSNH2KD / WAVNUM / CGROUP rows are not
+        assembled on the host from the global fields but by PROENVHALO on the device -- owned rows + one halo exchange (proenvhalo())."""
         g, d, t = self.grid, self.dom, self.t
         p = syn.point_params(g.nsea, seed=seed)
         self.params = p
@@ -220,7 +222,11 @@ class Wamintgr:
                 ug, vg = syn.currents(g)
                 u[: ext.size] = ug[ext]
                 v[: ext.size] = vg[ext]
-            self.set_environment(dep, u, v, om_ext, wn_ext)
+            if env_on_device:
+                n = self.n
+                self.proenvhalo(dep[:n], u[:n], v[:n], om_ext[:n])
+            else:
+                self.set_environment(dep, u, v, om_ext, wn_ext)
         self.fl1[self.dom.nland].zero_()
         self.fl3[self.dom.nland].zero_()
 
@@ -242,6 +248,34 @@ class Wamintgr:
                          (self.wavnum_ext, wavnum_ext)):
             dst.copy_(torch.as_tensor(np.ascontiguousarray(src, dtype=self.npdt)))
         self.weights_ready = False
+
+    # ---- PROENVHALO (proenvhalo.F90:63-107) on the device
+    def proenvhalo_pack(self, depth, ucur, vcur, omosnh2kd) -> torch.Tensor:
+        """Owned DEPTH / UCUR / VCUR [n] and OMOSNH2KD [n][NFRE] (device tensors or arrays) + the WAVNUM / CGROUP of the device-resident
+        WVPRPT rows -> the owned rows of BUFFER_EXT [nrows][1][3 NFRE + 3]; its halo rows are to be exchanged like spectra."""
+        if not self.irefra:
+            raise ValueError("PROENVHALO serves the refraction set-up (IREFRA = 1, 2, 3)")
+        NFRE = self.cfg.nfre
+        if getattr(self, "env_buf", None) is None:
+            self.env_buf = torch.zeros((self.nrows - 1, 1, 3 * NFRE + 3), dtype=self.dtype, device=self.dev)
+            land = syn.depth_props(np.array([float(self.t.BATHYMAX)]), self.t, self.npdt)      # WVPRPT_LAND (initdpthflds.F90:85-88)
+            row = np.concatenate([land["WAVNUM"][0], land["CGROUP"][0], land["OMOSNH2KD"][0], [float(self.t.BATHYMAX), 0.0, 0.0]]).astype(self.npdt)
+            self.env_land = torch.from_numpy(row).to(self.dev)
+        a = [torch.as_tensor(np.ascontiguousarray(x, dtype=self.npdt)).to(self.dev) if not torch.is_tensor(x) else x.to(self.dev, self.dtype).contiguous()
+             for x in (depth, ucur, vcur, omosnh2kd)]
+        assert a[0].shape[0] == self.n and tuple(a[3].shape) == (self.n, NFRE)
+        self.ctx.proenvhalo_pack(self.n, self.wvprpt, a[3], a[0], a[1], a[2], self.env_buf)
+        return self.env_buf
+
+    def proenvhalo_unpack(self) -> None:
+        self.ctx.proenvhalo_unpack(self.nrows - 1, self.env_buf, self.env_land, self.wavnum_ext, self.cgroup_ext, self.omosnh2kd_ext,
+                                   self.depth_ext, self.u_ext, self.v_ext)
+        self.weights_ready = False      # LLUPDTTD / LUPDTWGHT (propag_wam.F90:175-236)
+
+    def proenvhalo(self, depth, ucur, vcur, omosnh2kd) -> None:
+        """New depth / currents on a decomposed grid without a host round trip: pack, MPEXCHNG(BUFFER_EXT, 3*NFRE_RED+5, 1, 1), unpack."""
+        self.halo(self.proenvhalo_pack(depth, ucur, vcur, omosnh2kd))
+        self.proenvhalo_unpack()
 
     # ---- CTUWUPDT (ctuwupdt.F90:220-256): weights for the (sub-)step structure
     def build_weights(self) -> int:

@@ -337,6 +337,22 @@ int ecwam_hip_halo_finish(ecwam_hip_ctx *ctx, void *stream);
 int ecwam_hip_halo_pack_host(ecwam_hip_ctx *ctx, const void *fl, int rowlen, void *host_send, void *stream);
 int ecwam_hip_halo_unpack_host(ecwam_hip_ctx *ctx, void *fl, int rowlen, const void *host_recv, void *stream);
 
+/*
+ * PROENVHALO (proenvhalo.F90:63-107) on the device: the extended (own + halo + land) rows of the fields the weights and the refraction
+ * terms are built from, assembled without a round trip through the host when the currents (or the depth) change on a decomposed grid.
+ *   buffer_ext: device real [nrows][3*NFRE + 3] -- per local row WAVNUM(1:NFRE), CGROUP(1:NFRE), OMOSNH2KD(1:NFRE), DEPTH, UCUR, VCUR (the
+ *     reference's BUFFER_EXT without DELLAM1 / COSPHM1, which the geometry arrays of the set-up hold).
+ *   ecwam_hip_proenvhalo_pack fills the n owned rows from the device-resident WVPRPT rows (members 0, 1), OMOSNH2KD[n][NFRE] and the
+ *     per-point DEPTH / UCUR / VCUR;  the halo rows [n, nrows) are then exchanged like the spectra: ecwam_hip_halo_start(ctx, buffer_ext,
+ *     3*NFRE + 3, stream) + ecwam_hip_halo_finish (or the host-staged pair) = MPEXCHNG(BUFFER_EXT, 3*NFRE_RED+5, 1, 1);
+ *   ecwam_hip_proenvhalo_unpack spreads the nrows rows over the extended arrays [nrows + 1][..] the advection entry points read and fills
+ *     the land slot (row nrows) from land[3*NFRE + 3] = (WVPRPT_LAND%WAVNUM, %CGROUP, %OMOSNH2KD, BATHYMAX, 0, 0).
+ */
+int ecwam_hip_proenvhalo_pack(ecwam_hip_ctx *ctx, int n, const void *wvprpt, const void *omosnh2kd, const void *depth,
+                              const void *ucur, const void *vcur, void *buffer_ext, void *stream);
+int ecwam_hip_proenvhalo_unpack(ecwam_hip_ctx *ctx, int nrows, const void *buffer_ext, const void *land, void *wavnum_ext,
+                                void *cgroup_ext, void *omosnh2kd_ext, void *depth_ext, void *u_ext, void *v_ext, void *stream);
+
 /* Device-memory helpers for hosts without their own HIP binding (the Fortran layer): the counterpart of FIELD_API's
  * device allocation / GET_DEVICE_DATA / SYNC_HOST copies (drvtype_mod.fypp:116-480).  `stream` may be NULL. */
 int ecwam_hip_malloc(ecwam_hip_ctx *ctx, unsigned long long bytes, void **dptr);

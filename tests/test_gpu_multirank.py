@@ -23,8 +23,8 @@ def _run(cmd, env):
     return json.loads(line)
 
 
-@pytest.mark.parametrize("nranks,launcher", [(2, "self"), (3, "torchrun")])
-def test_bench_two_ranks_on_one_gpu_match_single_rank(tmp_path, nranks, launcher):
+@pytest.mark.parametrize("nranks,launcher,extra", [(2, "self", []), (3, "torchrun", []), (2, "self", ["--irefra", "2"])])
+def test_bench_two_ranks_on_one_gpu_match_single_rank(tmp_path, nranks, launcher, extra):
     """launcher "self": the driver's command shape, `python bench.py --gpus N ...` with WORLD_SIZE unset -- bench.py starts its own N
     ranks as a child process; "torchrun": started under torch.distributed.run as the contract's N > 1 command does."""
     if not torch.cuda.is_available():
@@ -32,7 +32,9 @@ def test_bench_two_ranks_on_one_gpu_match_single_rank(tmp_path, nranks, launcher
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    common = ["--grid", "48", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    # extra = --irefra 2: currents; on N > 1 ranks the extended environment rows come from PROENVHALO on the device (owned rows + one
+    # exchange of 3 NFRE + 3 reals per halo row through the same transport), on one rank from the host assembly: same bits
+    common = ["--grid", "48", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra
     one = _run([sys.executable, "bench.py", "--gpus", "1", "--dump", str(tmp_path / "one")] + common, env)
     tail = ["bench.py", "--gpus", str(nranks), "--share-gpu", "--dump", str(tmp_path / "many")] + common
     if launcher == "self":

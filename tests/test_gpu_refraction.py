@@ -235,6 +235,47 @@ def test_decomposed_step_with_overlapped_exchange_is_bit_identical(api, irefra, 
         m.ctx.close()
 
 
+@pytest.mark.parametrize("prec", ["sp", "dp"])
+def test_proenvhalo_on_the_device_equals_the_host_assembly(api, prec):
+    """PROENVHALO (proenvhalo.F90:63-107) on the device: owned rows packed from the device-resident fields, halo rows exchanged as rows of
+    3 NFRE + 3 reals (here: copied from the owners' packed rows, what MPEXCHNG delivers), land slot from WVPRPT_LAND -- the extended DEPTH /
+    UCUR / VCUR / OMOSNH2KD / WAVNUM / CGROUP arrays of every rank equal those assembled on the host from the global fields bit for bit, and
+    so do the dot terms and CFL flags built from them."""
+    from ecwam_amd import grid as G
+    from ecwam_amd.wamintgr import Wamintgr
+
+    cfg = Config(nang=12, nfre=36, nfre_red=28, idelt=600, idelpro=600, irefra=3)
+    g = G.build_grid(20, mask="continents")
+    nr = 3
+    host = [Wamintgr(cfg, g, prec, rank=r, nranks=nr) for r in range(nr)]
+    dev = [Wamintgr(cfg, g, prec, rank=r, nranks=nr) for r in range(nr)]
+    for m in host + dev:
+        m.init_synthetic(seed=11)                       # extended rows assembled on the host from the global synthetic fields
+    names = ("depth_ext", "u_ext", "v_ext", "omosnh2kd_ext", "wavnum_ext", "cgroup_ext")
+    packed = []
+    for m, h in zip(dev, host):
+        n = m.n
+        own = [getattr(h, k)[:n].clone() for k in names[:4]]
+        for k in names:                                  # poison what PROENVHALO has to rebuild
+            getattr(m, k).fill_(float("nan"))
+        packed.append(m.proenvhalo_pack(*own))
+    owned = torch.cat([b[: m.n] for b, m in zip(packed, dev)])            # rows of all ranks in global point order
+    for m, b in zip(dev, packed):
+        hg = torch.from_numpy(np.asarray(m.dom.halo_global, dtype=np.int64)).to(owned.device)
+        b[m.n: m.n + m.dom.nh] = owned[hg]                                 # MPEXCHNG(BUFFER_EXT, 3*NFRE_RED+5, 1, 1)
+        m.proenvhalo_unpack()
+    torch.cuda.synchronize()
+    for m, h in zip(dev, host):
+        for k in names:
+            assert torch.equal(getattr(m, k), getattr(h, k)), k
+        assert m.weights_ready is False
+        assert m.build_weights() == h.build_weights()
+        assert torch.equal(m.refr, h.refr) and torch.equal(m.cflfail, h.cflfail)
+    assert float(host[1].u_ext.abs().max()) > 0.1 and host[1].dom.nh > 0
+    for m in host + dev:
+        m.ctx.close()
+
+
 @pytest.mark.parametrize("prec", ["dp", "sp"])
 @pytest.mark.parametrize("irefra", [0, 2])
 def test_subgrid_obstructions(api, prec, irefra):

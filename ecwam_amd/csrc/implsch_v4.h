@@ -139,6 +139,25 @@ __device__ __forceinline__ T v4_allsum1(T v, const V4Rot<T>& r) {
   }
 }
 
+// The positive wind input of a row summed over the directions of the point -> the point's row table in LDS (SINPUT's second call;
+// weighted below the cut-off once MIJ is known, stresso.F90:160-168).  36 directions: the extras are folded into lanes 0, 1 of the point's
+// DPP row, four row rotations, every lane of the row holds the total and stores it (the same value at the same address); the extras'
+// own row of 16 lanes sums a mixture nobody reads: their store goes to a private slot (spw).  No trip through global memory (rounds 1
+// and 2 parked the per-lane shares in the point's FL1 block: 1.1 GB written and read back per O320 launch).
+template <int G, typename T>
+__device__ __forceinline__ void v4_row_total_to_lds(T v, const V4Rot<T>& r, T* spw, int m) {
+  if constexpr (G == 18) {
+    v = v + r.fold * v4_bp(r.a0, v);
+    v = v + v4_dpp<V4_ROW_ROR(8)>(v);
+    v = v + v4_dpp<V4_ROW_ROR(4)>(v);
+    v = v + v4_dpp<V4_ROW_ROR(2)>(v);
+    v = v + v4_dpp<V4_ROW_ROR(1)>(v);
+  } else {
+    v = v4_allsum1<G, T>(v, r);
+  }
+  spw[m] = v;
+}
+
 // the pair (X(2j+r), X(2j+r+1)) of an LDS row; sh[i] = index of element (2j + 2(i-NSH)) mod NANG of the lane's point in a row
 template <typename T, int NSH, int r>
 __device__ __forceinline__ V2<T> v4_at(const T* row, const int (&sh)[2 * NSH + 1]) {
@@ -336,7 +355,6 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
   xm0 = 0ull; xm1 = 0ull;
   const V2<T> z2 = {T(0), T(0)};
   wse = z2; wslast = z2; apl = z2;
-  T sp_even = T(0);
 #pragma unroll
   for (int s = 0; s < NS; s++) { rX[s] = T(0); rY[s] = T(0); }
   const T* tF = L.tile + L.own;
@@ -441,10 +459,8 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
     if (LLSNEG) {
       apl = apl + (fl * f - sp) * row[4];
       *reinterpret_cast<V2<T>*>(gfl + (size_t)m * NANG) = fl;
-      // the lane's share of the row's positive input: summed below the cut-off once MIJ is known (stresso.F90:160-168), no all-reduce
-      // here; two rows per 8-byte store so that the point's lanes write whole, contiguous lines
-      if (m & 1) *reinterpret_cast<V2<T>*>(gsp + (size_t)(m >> 1) * NANG) = V2<T>{sp_even, sp.x + sp.y};
-      else sp_even = sp.x + sp.y;
+      // the row's positive input summed over the directions -> the point's row table (weighted below the cut-off once MIJ is known)
+      v4_row_total_to_lds<G, T>(sp.x + sp.y, L.rot, gsp, m);
     }
     if (xl0) xm0 |= (1ull << m);
     if (xl1) xm1 |= (1ull << m);
@@ -483,7 +499,6 @@ __device__ void v4_sinput_n(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, co
   xm0 = 0ull; xm1 = 0ull;
   const V2<T> z2 = {T(0), T(0)};
   wse = z2; wslast = z2; apl = z2;
-  T sp_even = T(0);
 #pragma unroll
   for (int s = 0; s < NS; s++) { rX[s] = T(0); rY[s] = T(0); }
   const bool c0 = coswdif.x > T(0.01), c1 = coswdif.y > T(0.01);
@@ -560,8 +575,7 @@ __device__ void v4_sinput_n(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, co
     if (LLSNEG) {
       apl = apl + (fl * f - sp) * row[4];
       *reinterpret_cast<V2<T>*>(gfl + (size_t)m * NANG) = fl;
-      if (m & 1) *reinterpret_cast<V2<T>*>(gsp + (size_t)(m >> 1) * NANG) = V2<T>{sp_even, sp.x + sp.y};
-      else sp_even = sp.x + sp.y;
+      v4_row_total_to_lds<G, T>(sp.x + sp.y, L.rot, gsp, m);
     }
     if (xl0) xm0 |= (1ull << m);
     if (xl1) xm1 |= (1ull << m);
@@ -593,7 +607,6 @@ __device__ void v4_sinput_jan(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, 
   xm0 = 0ull; xm1 = 0ull;
   const V2<T> z2 = {T(0), T(0)};
   wse = z2; wslast = z2; apl = z2;
-  T sp_even = T(0);
 #pragma unroll
   for (int s = 0; s < NS; s++) { rX[s] = T(0); rY[s] = T(0); }
   const T* tF = L.tile + L.own;
@@ -654,8 +667,7 @@ __device__ void v4_sinput_jan(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, 
     if (LLSNEG) {
       apl = apl + (fl * f - sp) * row[4];
       *reinterpret_cast<V2<T>*>(gfl + (size_t)m * NANG) = fl;
-      if (m & 1) *reinterpret_cast<V2<T>*>(gsp + (size_t)(m >> 1) * NANG) = V2<T>{sp_even, sp.x + sp.y};
-      else sp_even = sp.x + sp.y;
+      v4_row_total_to_lds<G, T>(sp.x + sp.y, L.rot, gsp, m);
     }
     if (xl0) xm0 |= (1ull << m);
     if (xl1) xm1 |= (1ull << m);
@@ -1063,12 +1075,17 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   };
   T rX[NS], rY[NS];
   T* sXY = sStg + p * NFRE * 2;   // 36 directions: [M][2] row integrals X, Y of the point (the staging rows are idle outside the sweep)
-  T* gsp = fl1 + (size_t)ij * N + 2 * j;   // the point's FL1 block is dead until the final store: the second SINPUT parks its positive input there
+  // row table [M] of the point for the positive input of SINPUT's second call (staging rows 2, 3 are idle outside the sweep); lanes that
+  // hold no row total of their own (the extras of the 36-direction layout and their shadows) store to a private slot behind it
+  constexpr int SPOFF = (G == 18) ? 2 * RS : 0;   // (36 directions: rows 0, 1 hold the row integrals X, Y of the stress)
+  static_assert(SPOFF + PP * V4_NFRE <= (G == 18 ? 3 : 4) * RS, "the row tables fit the staging rows");
+  T* gsp = (G == 18 && lane >= 48) ? sStg + 3 * RS + lane : sStg + SPOFF + p * NFRE;
   // stress sums below the cut-off and the F(:,MIJ) integrals of TAU_PHI_HF (stresso.F90:148-173, tau_phi_hf.F90:170-196)
   auto post_stress = [&](int MIJ, V2<T> apl, bool phiwa) {
     const T zpm = tb.ZPIFR[MIJ - 1], f5m = tb.FR5[MIJ - 1];   // for STRESSO: in flight behind the sums below
     V2<T> s = z2;
     T sp = T(0);
+    const T* spt = sStg + SPOFF + p * NFRE;
 #pragma unroll
     for (int q = 0; q < NS; q++) {
       const int m = q * G + j;
@@ -1076,23 +1093,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       const T wx = w * L.fac4[m * 4 + Q4_CINV];
       if constexpr (G == 18) s = s + wx * *reinterpret_cast<const V2<T>*>(sXY + 2 * m);
       else s = s + V2<T>{wx * rX[q], wx * rY[q]};
-    }
-    if (phiwa) {
-      // all 18 loads in flight at once: left to itself the compiler reuses one register pair and makes 18 round trips to memory,
-      // load - wait - use, one after the other (the scheduling barrier keeps the uses behind the last load)
-      V2<T> pv[NFRE / 2];
-#pragma unroll
-      for (int i = 0; i < NFRE / 2; i++) pv[i] = *reinterpret_cast<const V2<T>*>(gsp + (size_t)i * NANG);   // rows 2i, 2i+1
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < NFRE; m += 2) {
-        const V2<T> v = pv[m >> 1];
-        T w0 = lane_get(L.rRHOWG, m), w1 = lane_get(L.rRHOWG, m + 1);
-        if (m + 1 == MIJ && MIJ != NFRE) w0 = T(0.5) * w0;
-        if (m + 2 == MIJ && MIJ != NFRE) w1 = T(0.5) * w1;
-        sp += (m + 1 <= MIJ ? w0 : T(0)) * v.x;
-        sp += (m + 2 <= MIJ ? w1 : T(0)) * v.y;
-      }
+      if (phiwa) sp += w * spt[m];   // the lane weighs the row totals of the positive input it owns (m = q G + j): the all-reduce below adds the lanes up
     }
     s = v4_allsum<G, T>(s, L.rot);
     T PH = T(0);

@@ -1,5 +1,5 @@
 """IMPLSCH kernel generations side by side (diagnostics, not a test): time per launch and parity statistics against the oracle.
-python tests/diag/implsch_gens.py [npoints] [prec,...] [nang,...] [A|B|N|G: flag set A, B (LLGCBZ0 + LLNORMAGAM), LLNORMAGAM only, LLGCBZ0 only]"""
+python tests/diag/implsch_gens.py [npoints] [prec,...] [nang,...] [A|B|N|G|J|E: flag set A, B (LLGCBZ0 + LLNORMAGAM), LLNORMAGAM only, LLGCBZ0 only, IPHYS = 0, ISNONLIN = 1]"""
 import json
 import os
 import sys
@@ -19,7 +19,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 precs = sys.argv[2].split(",") if len(sys.argv) > 2 else ["sp", "dp"]
 nangs = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [36, 24, 12]
 NRED = {36: 36, 24: 29, 12: 25}
-FLAGS = {"A": {}, "B": dict(llgcbz0=True, llnormagam=True), "N": dict(llnormagam=True), "G": dict(llgcbz0=True)}[sys.argv[4] if len(sys.argv) > 4 else "A"]
+FLAGS = {"A": {}, "B": dict(llgcbz0=True, llnormagam=True), "N": dict(llnormagam=True), "G": dict(llgcbz0=True), "J": dict(iphys=0),
+         "E": dict(isnonlin=1)}[sys.argv[4] if len(sys.argv) > 4 else "A"]
 for nang in nangs:
     for prec in precs:
         cfg = Config(nang=nang, nfre=36, nfre_red=NRED[nang], idelt=450, idelpro=450, **FLAGS)

@@ -24,15 +24,16 @@ IMPLSCH_SOURCES = ("implsch.hip", "implsch4.hip", "implsch4x.hip")
 #   "exactdiv" every `/` and SQRT the source spells out is correctly rounded (the scalar chains per sea point: TAUT_Z0, STRESSO, FKMEAN,
 #              FRCUTINDEX ...); the per-bin sites of the row loops, which call f_div / f_rcp / f_rsq / f_sqrt, keep the hardware approximations
 #   "strict1"  ECWAM_HIP_STRICT=1: those per-bin divisions and square roots correctly rounded as well
-#   "site4/8/16/32"  exactdiv + ONE group of per-bin sites exact: 4 the reciprocal of COS(TH - wind stress direction) in SINPUT_ARD's ZLOG,
-#              8 the row-uniform chain of the sheltering (1 / |TAU|, SQRT, 1 / (U*/c + ZALP)), 16 the divisions of the implicit update,
-#              32 DFIM / SQRT(WAVNUM) of FKMEAN
+#   "site4/8/32"  exactdiv + ONE group of per-bin sites exact: 4 the reciprocal of COS(TH - wind stress direction) in SINPUT_ARD's ZLOG,
+#              8 the row-uniform chain of the sheltering (1 / |TAU|, SQRT, 1 / (U*/c + ZALP)), 32 DFIM / SQRT(WAVNUM) of FKMEAN.  (The
+#              experiment's fourth group, 16 = the divisions of the implicit update, was the one that mattered and became the product's
+#              refined quotient dev.h::f_div_r: profiles/r03_sp_error_attribution.txt.)
 #   "strict2"  ECWAM_HIP_STRICT=2: EXP / LOG with an exact argument reduction (error of the hardware exp2 / log2 only)
 #   "strict3"  both
 #   "strict7"  both + floating-point contraction off (no FMA the source does not spell out)
 # A variant is written to libecwam_hip_<variant>.so next to the product library; ECWAM_HIP_LIB=<path> makes lib.load() use it.
 VARIANTS = {"": FAST_DIV, "exactdiv": ["-DECWAM_HIP_STRICT=0"], "strict1": ["-DECWAM_HIP_STRICT=1"], "strict2": FAST_DIV + ["-DECWAM_HIP_STRICT=2"],
-            "site4": ["-DECWAM_HIP_STRICT=4"], "site8": ["-DECWAM_HIP_STRICT=8"], "site16": ["-DECWAM_HIP_STRICT=16"], "site32": ["-DECWAM_HIP_STRICT=32"],
+            "site4": ["-DECWAM_HIP_STRICT=4"], "site8": ["-DECWAM_HIP_STRICT=8"], "site32": ["-DECWAM_HIP_STRICT=32"],
             "strict3": ["-DECWAM_HIP_STRICT=3"], "strict7": ["-DECWAM_HIP_STRICT=3", "-ffp-contract=off"]}
 
 INCLUDE = os.path.join(HERE, "..", "include", "ecwam_hip.h")

@@ -376,8 +376,9 @@ template <typename T> struct VecIO<T, 1> {
   static __device__ __forceinline__ void st(T* p, const T* o) { p[0] = o[0]; }
   static __device__ __forceinline__ void st_stream(T* p, const T* o) { __builtin_nontemporal_store(o[0], p); }
 };
+// (single precision without obstructions -- the benchmark's build -- needs its four waves per SIMD to hide the gathers' latency: 128 VGPRs)
 template <typename T, int VW, bool OBS>
-__global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restrict__ tab, const T* __restrict__ f1, T* __restrict__ f3,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && !OBS) ? 4 : 1))) k_propags2_otf(const DevTab<T>* __restrict__ tab, const T* __restrict__ f1, T* __restrict__ f3,
                                                       int n_geom, int ngy, T delpro, const int* __restrict__ kxlt,
                                                       const T* __restrict__ zdello, T xdella, const T* __restrict__ cosph,
                                                       const T* __restrict__ sinph, const int* __restrict__ klon,
@@ -423,6 +424,11 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
   // XCD-aware tile walk: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own 4 MiB L2.  XCD x
   // walks the contiguous tile range [x*tpx, (x+1)*tpx) so that a spectrum fetched as somebody's neighbour is still in that
   // L2 when its own tile (or the next neighbour) comes up; gridDim.x is a multiple of 8 (launch_propags2_otf).
+  // natural work order: element e = threadIdx.x + i blockDim.x of a tile is (point t, direction k, vector mv) with e = (t NANG + k) FV + mv
+  const int step_q = (int)blockDim.x / FV, step_r = (int)blockDim.x - step_q * FV;   // blockDim.x vectors = step_q directions + step_r vectors
+  const int step_wrap = (step_q + 1 + NANG - 1) / NANG;                              // directions wrap into the next point at most this often per step
+  const int t_first = (int)threadIdx.x / NV, k_first = ((int)threadIdx.x - t_first * NV) / FV,
+            mv_first = (int)threadIdx.x - t_first * NV - k_first * FV;
   const bool xwalk = !(copy_rest & 2);  // copy_rest & 2: plain grid-stride walk (diagnostics)
   const int tpx = xwalk ? (ntiles + 7) / 8 : ntiles;
   const int xcd = xwalk ? (blockIdx.x & 7) : 0;
@@ -466,8 +472,8 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
     }
     __syncthreads();
     typedef VecIO<T, VW> IO;
-    auto element = [&](const int t, const int ev) {
-      const int k = ev / FV, m = (ev - k * FV) * VW;
+    auto element = [&](const int t, const int k, const int mv) {   // direction k, vector mv of the NFRE / VW of a direction
+      const int m = mv * VW;
       const int* q = sI + t * 16;
       const size_t own = (size_t)q[0] * N, own_in = (size_t)q[0] * NIN;
       const int el = k * NFRE + m, el_in = k * in_k + m;
@@ -554,15 +560,23 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
       // the same time, chunk by chunk over the whole tile, so that a chunk fetched as a neighbour is served by the CU's L1 / the XCD's
       // L2 when its owner (or the next neighbour) asks for it a few hundred cycles later
       const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-      for (int c = 0; c < NV; c += 64)
+      for (int c = 0; c < NV; c += 64) {
+        const int ev = c + lane, k = ev / FV, mv = ev - k * FV;
         for (int g = 0; g < OTF_TP / 4; g++) {
-          const int t = 4 * g + w, ev = c + lane;
-          if (t < np && sI[t * 16] >= 0 && ev < NV) element(t, ev);
+          const int t = 4 * g + w;
+          if (t < np && sI[t * 16] >= 0 && ev < NV) element(t, k, mv);
         }
+      }
     } else {
+      // (point, direction, vector) of the thread's element advance by blockDim.x vectors per iteration: kept incrementally -- two
+      // divisions by run-time values per element (~ 55 of the ~ 330 instructions of an iteration) were the alternative
+      int t = t_first, k = k_first, mv = mv_first;
       for (int e = threadIdx.x; e < np * NV; e += blockDim.x) {
-        const int t = e / NV;
-        if (sI[t * 16] >= 0) element(t, e - t * NV);
+        if (sI[t * 16] >= 0) element(t, k, mv);
+        mv += step_r; k += step_q;
+        if (mv >= FV) { mv -= FV; k += 1; }
+        for (int i = 0; i < step_wrap; i++)
+          if (k >= NANG) { k -= NANG; t += 1; }
       }
     }
   }

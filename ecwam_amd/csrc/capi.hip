@@ -286,8 +286,10 @@ struct RcclApi {
 static RcclApi g_rccl;
 static int rccl_load() {
   if (g_rccl.h) return 0;
-  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  // By SONAME: in a process that has already mapped an RCCL (PyTorch-ROCm links its bundled librccl.so.1) this returns THAT copy, so that
+  // one RCCL and one HIP runtime serve the process; RTLD_LOCAL: a second copy must never interpose its symbols on the first.
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
   if (!h) return fail(std::string("RCCL not found (dlopen librccl.so.1): ") + dlerror());
 #define SYM_(f) g_rccl.f = (decltype(g_rccl.f))dlsym(h, "nccl" #f); if (!g_rccl.f) return fail("librccl: symbol nccl" #f " missing")
   SYM_(GetUniqueId); SYM_(CommInitRank); SYM_(CommDestroy); SYM_(CommCount); SYM_(GroupStart); SYM_(GroupEnd); SYM_(Send); SYM_(Recv); SYM_(GetErrorString);

@@ -763,7 +763,9 @@ int ecwam_hip_halo_setup(ecwam_hip_ctx* c, int rank, int nranks, int npeers, con
   c->send_off.resize(npeers);
   c->n_send = 0; c->n_recv = 0;
   for (int i = 0; i < npeers; i++) {
-    if (peer[i] < 0 || peer[i] >= nranks || peer[i] == rank || send_count[i] < 0 || recv_count[i] < 0 || recv_dst0[i] < 0)
+    // (peer[i] == rank is accepted: an exchange of a rank with itself -- rows that are their owner's own halo, e.g. a band that wraps
+    //  around; RCCL pairs a send and a receive of the same rank inside one group)
+    if (peer[i] < 0 || peer[i] >= nranks || send_count[i] < 0 || recv_count[i] < 0 || recv_dst0[i] < 0)
       return fail("ecwam_hip_halo_setup: bad peer entry");
     c->send_off[i] = c->n_send; c->n_send += send_count[i]; c->n_recv += recv_count[i];
   }
@@ -817,7 +819,7 @@ int ecwam_hip_comm_unique_id(void* id128) {
 
 int ecwam_hip_comm_init(ecwam_hip_ctx* c, const void* id128) {
   if (!c || !id128) return fail("ecwam_hip_comm_init: null argument");
-  if (c->nranks < 2) return 0;
+  if (c->peer.empty()) return 0;   // nothing to exchange (one rank without a self exchange): no communicator
   if (rccl_load()) return 1;
   HIPCHK(hipSetDevice(c->device));
   if (c->comm) {   // a second initialisation replaces the communicator: let the posted exchange finish, then release the old one
@@ -857,7 +859,7 @@ static int halo_pack(ecwam_hip_ctx* c, const void* fl, int rowlen, hipStream_t s
 
 int ecwam_hip_halo_start(ecwam_hip_ctx* c, void* fl, int rowlen, void* stream) {
   if (!c) return fail("null context");
-  if (c->nranks < 2 || c->peer.empty()) return 0;
+  if (c->peer.empty()) return 0;
   if (!fl || rowlen < 1) return fail("ecwam_hip_halo_start: bad arguments");
   if (!c->comm) return fail("ecwam_hip_halo_start: no communicator (ecwam_hip_comm_init)");
   hipStream_t s = (hipStream_t)stream;
@@ -884,7 +886,7 @@ int ecwam_hip_halo_start(ecwam_hip_ctx* c, void* fl, int rowlen, void* stream) {
 
 int ecwam_hip_halo_finish(ecwam_hip_ctx* c, void* stream) {
   if (!c) return fail("null context");
-  if (c->nranks < 2 || c->peer.empty()) return 0;
+  if (c->peer.empty() || !c->halo_inflight) return 0;
   HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->ev_done, 0));
   return 0;
 }

@@ -59,3 +59,45 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode != 0 and "visible" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_library_rccl_exchange_loopback_on_one_gpu(tmp_path):
+    """The library's own MPEXCHNG transport executed on hardware with the one GPU there is: a communicator of ONE rank (RCCL refuses two
+    ranks on one device) whose halo segment is fed by the rank itself -- dlopen of librccl, ncclGetUniqueId / ncclCommInitRank /
+    ncclCommCount, the pack kernel on the caller's stream, the grouped ncclSend + ncclRecv on the library's stream behind an event, the
+    receive landing in the halo rows, the caller's stream waiting at halo_finish, twice in a row without a host synchronisation (the
+    second exchange reuses the send buffer behind the first one's event), on full rows and on compact fast-wave rows.  In a child
+    process under a timeout: a transport that hangs must fail the test, not the session."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    code = r"""
+import sys, types, numpy as np, torch
+sys.path.insert(0, %r)
+from ecwam_amd import api
+from ecwam_amd.tables import Config, Tables
+t = Tables(Config(nang=12, nfre=36, nfre_red=25), np.float32)
+ctx = api.HipContext(t)
+n, nh = 700, 60
+rng = np.random.default_rng(3)
+send = np.sort(rng.choice(n, nh, replace=False)).astype(np.int32)
+dom = types.SimpleNamespace(rank=0, nranks=1, send={0: send}, recv={0: (n, nh)})
+ctx.halo_setup(dom)
+ctx.comm_init(ctx.comm_unique_id())
+assert ctx.comm_count() == 1
+for rowshape in ((12, 36), (12, 8)):
+    fl = torch.zeros((n + nh + 1,) + rowshape, dtype=torch.float32, device=ctx.device)
+    for it in range(2):
+        fl[:n] = torch.from_numpy(rng.uniform(0, 1, (n,) + rowshape).astype(np.float32)).to(ctx.device)
+        fl[n:n + nh] = -1.0
+        ctx.halo_start(fl)
+        fl[0:5] += 0.0                      # work on the caller's stream between start and finish
+        ctx.halo_finish()
+        got = fl[n:n + nh].clone()          # ordered behind the exchange on the caller's stream
+        torch.cuda.synchronize()
+        assert torch.equal(got, fl[torch.from_numpy(send).long().to(ctx.device)]), (rowshape, it)
+        assert float(fl[n + nh].abs().max()) == 0.0
+ctx.close()
+print("loopback ok")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert r.returncode == 0 and "loopback ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -25,7 +25,7 @@ class _LocalGrid:
         self.cosph, self.sinph, self.zdello, self.cosphm1_ext = g.cosph, g.sinph, g.zdello, d.cosphm1_ext
 
 
-def _write_case(path, m, cfg, grid, nproma, nstep, obs=None, nosource=False, dom=None):
+def _write_case(path, m, cfg, grid, nproma, nstep, obs=None, nosource=False, dom=None, proenvhalo=False):
     """dom: the rank's decomp.LocalDomain for a multi-rank case (grid = its _LocalGrid): the header carries rank / ranks / halo size /
     interior range, the lists of ECWAM_HIP_SET_DECOMPOSITION (1-based, the reference's NTOPE / IJTOPE / NIJSTART) end the file."""
     from ecwam_amd import lib as L, synthetic as syn
@@ -44,7 +44,7 @@ def _write_case(path, m, cfg, grid, nproma, nstep, obs=None, nosource=False, dom
                         int(m.delpro_lf or 0), int(cfg.irefra != 0), int(bool(getattr(m, 'llcflcuroff', False))),
                         int(obs is not None), int(nosource),
                         dom.nranks if dom is not None else 1, dom.rank if dom is not None else 0, dom.nh if dom is not None else 0,
-                        len(peers), ia + 1, ib, 0], dtype=np.int32)
+                        len(peers), ia + 1, ib, int(proenvhalo)], dtype=np.int32)
         f.write(hdr.tobytes())
         f.write(bytes(params))
         for a in keep:
@@ -72,9 +72,13 @@ def _write_case(path, m, cfg, grid, nproma, nstep, obs=None, nosource=False, dom
         ff = m.ff.cpu().numpy()
         for i in range(16):
             f.write(F(chunk(ff[:, i]), dt))
-        if cfg.irefra:
+        if cfg.irefra and not proenvhalo:
             for a in (m.depth_ext, m.u_ext, m.v_ext, m.omosnh2kd_ext, m.wavnum_ext):
                 f.write(F(a.cpu().numpy(), dt))
+        elif cfg.irefra:       # this rank's own OMOSNH2KD / UCUR / VCUR (chunked) and the land row: ECWAM_HIP_PROENVHALO assembles the rest
+            f.write(F(chunk(m.omosnh2kd_ext.cpu().numpy()[:n]), dt) + F(chunk(m.u_ext.cpu().numpy()[:n]), dt) + F(chunk(m.v_ext.cpu().numpy()[:n]), dt))
+            land = syn.depth_props(np.array([float(t.BATHYMAX)]), t, dt)
+            f.write(np.concatenate([land["WAVNUM"][0], land["CGROUP"][0], land["OMOSNH2KD"][0], [float(t.BATHYMAX), 0.0, 0.0]]).astype(dt).tobytes())
         if obs is not None:   # OBS[n][8][NFRE] -> OBSLAT(N,NFRE_RED,2), OBSLON(N,NFRE_RED,2), OBSCOR(N,NFRE_RED,4)
             o = np.moveaxis(np.asarray(obs)[:, :, :cfg.nfre_red], 1, 2)
             f.write(F(o[:, :, 0:2], dt) + F(o[:, :, 2:4], dt) + F(o[:, :, 4:8], dt))
@@ -165,14 +169,16 @@ def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec, lf, irefra, su
     m.ctx.close()
 
 
-@pytest.mark.parametrize("prec,lf", [("sp", 0), ("dp", 5)])
-def test_fortran_two_processes_on_one_gpu_match_single_domain(tmp_path, prec, lf):
+@pytest.mark.parametrize("prec,lf,irefra", [("sp", 0, 0), ("dp", 5, 0), ("sp", 0, 2), ("dp", 4, 3)])
+def test_fortran_two_processes_on_one_gpu_match_single_domain(tmp_path, prec, lf, irefra):
     """The multi-rank path of the Fortran layer, executed: two processes of the harness share the GPU, each owns one band of the sea
     points (ECWAM_HIP_SET_DECOMPOSITION with the reference's 1-based NTOPE / IJTOPE / NIJSTART-style lists -> 0-based device rows,
     halo rows and land slot behind the owned rows, interior range), the halo travels host-staged (ecwam_hip_halo_pack_host ->
     the harness' exchange through files, where ecWAM would call MPI -> ecwam_hip_halo_unpack_host), fast-wave sub-steps exchange the
     compact rows.  Both bands together must equal the single-domain Python host bit for bit.  Also LWNEMOCOU: the WAVE2OCEAN sums and
-    the accumulation count NEMONTAU (wamintgr.F90:150) after two source steps."""
+    the accumulation count NEMONTAU (wamintgr.F90:150) after two source steps.  irefra > 0: refraction on two ranks -- each process hands
+    ECWAM_HIP_PROENVHALO its own DEPTH / UCUR / VCUR / OMOSNH2KD, the halo rows of the environment travel through the same exchange as rows
+    of 3 NFRE + 3 reals, every PROPAGS2 call of the (sub-stepped) sequence runs behind its own exchange of the spectra."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from ecwam_amd import build, decomp, grid as G
@@ -181,7 +187,7 @@ def test_fortran_two_processes_on_one_gpu_match_single_domain(tmp_path, prec, lf
     exe = build.fortran_exe(prec)
     if not os.path.exists(exe):
         build.build_fortran()
-    cfg = Config(nang=12, nfre=36, nfre_red=25, idelt=900, idelpro=900, lwnemocou=True)
+    cfg = Config(nang=12, nfre=36, nfre_red=25, idelt=900, idelpro=900, lwnemocou=True, irefra=irefra)
     g = G.build_grid(16, mask="continents")
     kw = dict(ifrelfmax=lf, delpro_lf=450.0 if lf else None)
     nranks, nproma, nstep = 2, 24, 2
@@ -192,7 +198,8 @@ def test_fortran_two_processes_on_one_gpu_match_single_domain(tmp_path, prec, lf
         mr = Wamintgr(cfg, g, prec, rank=r, nranks=nranks, halo_transport="host", **kw)
         mr.init_synthetic(seed=21)
         case, out = str(tmp_path / f"case{r}.bin"), str(tmp_path / f"out{r}.bin")
-        nchnk = _write_case(case, mr, cfg, _LocalGrid(g, mr.dom), nproma, nstep, dom=mr.dom)
+        mr.llcflcuroff = irefra != 3
+        nchnk = _write_case(case, mr, cfg, _LocalGrid(g, mr.dom), nproma, nstep, dom=mr.dom, proenvhalo=bool(irefra))
         meta.append((out, nchnk, mr.dom.n))
         mr.ctx.close()
         procs.append(subprocess.Popen([exe, case, out, "run", str(xdir)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -201,6 +208,7 @@ def test_fortran_two_processes_on_one_gpu_match_single_domain(tmp_path, prec, lf
         assert p.returncode == 0 and "ok" in o, o
     m = Wamintgr(cfg, g, prec, **kw)
     m.init_synthetic(seed=21)
+    m.llcflcuroff = irefra != 3
     w2n = torch.zeros((g.nsea, 13), dtype=torch.float64, device=m.dev)
     for _ in range(nstep):
         m.propag()

@@ -205,6 +205,10 @@ def main() -> None:
     m.init_synthetic(env_on_device=bool(a.irefra) and world > 1)      # refraction on N > 1 ranks: PROENVHALO on the device, halo rows through the transport
     m.ff_next = m.ff.clone()      # NEWWIND hands the (unchanged synthetic) forcing over every step: k_newwind is part of the step
     nfail = m.build_weights()
+    if dist is not None:      # every rank leaves together (the reference aborts the whole run, ctuwdrv.F90:124-146): nobody waits in a collective
+        tot = torch.tensor([nfail], dtype=torch.int64)
+        dist.all_reduce(tot)
+        nfail = int(tot.item())
     if nfail:
         raise SystemExit(f"CFL violated at {nfail} points")
 

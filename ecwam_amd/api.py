@@ -116,9 +116,11 @@ class HipContext:
 
     # -- PROPAGS2 with on-the-fly CTU weights (no W array): same result as ctuw() + propags2()
     def propags2_otf(self, f1, f3, grid_dev: dict, cgroup_ext, delpro: float, kijs, kijl, nd3s=1, nd3e=None, copy_rest=True,
-                     order=None, ifrelfmax: int = 0, delpro_lf: float | None = None, gout=None, tiles2d: bool = False):
+                     order=None, ifrelfmax: int = 0, delpro_lf: float | None = None, gout=None, tiles2d: bool = False, gin=None):
         """ifrelfmax > 0: frequencies 1..ifrelfmax advance with delpro_lf, the others with delpro, in the same pass.
-        gout: optional compact buffer [nrow][NANG][w] that also receives the first w advected frequencies."""
+        gout: optional compact buffer [nrow][NANG][w] that also receives the first w advected frequencies.
+        gin: optional compact buffer [nrow][NANG][w] the first w frequencies are READ from (with full rows f1).
+        f1 and / or f3 may themselves be compact buffers [nrow][NANG][w] (a fast-wave sub-step)."""
         nd3e = self.NR if nd3e is None else nd3e
         g = grid_dev
         n, nland, ngy = g["n"], g["nland"], g["ngy"]
@@ -132,15 +134,18 @@ class HipContext:
             raise ValueError("PROPAGS2: 2-D tiles need the order of decomp.tile2d_order")
         dlf = float(delpro if delpro_lf is None else delpro_lf)
         in_nfre = int(f1.shape[2])          # NFRE, or the width of a compact fast-wave buffer [nrow][NANG][in_nfre]
-        args = [self._real(f1, (nrow, self.NANG, in_nfre), "F1"), self._real(f3, (f3.shape[0], self.NANG, self.NFRE), "F3"), n, ngy,
+        out_nfre = int(f3.shape[2])
+        args = [self._real(f1, (nrow, self.NANG, in_nfre), "F1"), self._real(f3, (f3.shape[0], self.NANG, out_nfre), "F3"), n, ngy,
                 float(delpro), dlf, int(ifrelfmax), 0 if in_nfre == self.NFRE else in_nfre,
+                None if gin is None else self._real(gin, (gin.shape[0], self.NANG, gin.shape[2]), "GIN"),
+                0 if gin is None else int(gin.shape[2]), 0 if out_nfre == self.NFRE else out_nfre,
                 None if gout is None else self._real(gout, (gout.shape[0], self.NANG, gout.shape[2]), "GOUT"),
                 0 if gout is None else int(gout.shape[2]), self._int(g["kxlt"], (n,), "KXLT"), self._real(g["zdello"], (ngy,), "ZDELLO"),
                 float(g["xdella"]), self._real(g["cosph"], (ngy,), "COSPH"), self._real(g["sinph"], (ngy,), "SINPH"),
                 self._int(g["klon"], (n, 2), "KLON"), self._int(g["klat"], (n, 2, 2), "KLAT"), self._int(g["kcor"], (n, 4, 2), "KCOR"),
                 self._real(g["wlat"], (n, 2), "WLAT"), self._real(g["wcor"], (n, 4), "WCOR"),
                 self._real(cgroup_ext, (nrow, self.NFRE), "CGROUP_EXT"), self._real(g["cosphm1_ext"], (nrow,), "COSPHM1_EXT"), po]
-        self._chk(self.lib.ecwam_hip_propags2_otf_split(self._h, *args, kijs, kijl, nd3s, nd3e, int(bool(copy_rest)) | (4 if tiles2d else 0), _stream_ptr()))
+        self._chk(self.lib.ecwam_hip_propags2_otf_fast(self._h, *args, kijs, kijl, nd3s, nd3e, int(bool(copy_rest)) | (4 if tiles2d else 0), _stream_ptr()))
 
     # -- FL1_EXT(:,:,M1:M2) <- FL3_EXT between the fast-wave sub-steps (propag_wam.F90:287-291)
     def copy_freq_range(self, src, dst, n, m_first, m_last):

@@ -58,7 +58,7 @@ template <typename T> void launch_ctuwini_only(int, int, const int*, const int*,
 template <typename T> void launch_propdot(const void*, int, int, int, const int*, const void*, double, const void*, const int*, const int*, const void*, const void*, const void*, const void*, const void*, void*, hipStream_t);
 template <typename T> void launch_curmask(int, int, int, const int*, void*, hipStream_t);
 template <typename T> void launch_propags2_gen(const void*, int, const void*, void*, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const void*, const void*, const void*, int*, int, int, int, int, int, int, int, const void*, hipStream_t);
-template <typename T> void launch_propags2_otf(const void*, const void*, void*, int, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const int*, int, int, int, int, int, int, const void*, int, double, int, void*, int, hipStream_t);
+template <typename T> void launch_propags2_otf(const void*, const void*, void*, int, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const int*, int, int, int, int, int, int, const void*, int, double, int, void*, int, const void*, int, int, hipStream_t);
 template <typename T> void launch_copy_freq_range(const void*, void*, int, int, int, int, int, int, hipStream_t);
 template <typename T> int launch_outbs(const void*, int, int, const void*, double, void*, int, int, hipStream_t);
 template <typename T> void launch_norm(const void*, int, int, double, double*, int, hipStream_t);
@@ -439,7 +439,21 @@ int ecwam_hip_propags2_otf_split(ecwam_hip_ctx* c, const void* f1, void* f3, int
                                  const int* klat, const int* kcor, const void* wlat, const void* wcor, const void* cgroup_ext,
                                  const void* cosphm1_ext, const int* order, int kijs, int kijl, int nd3s, int nd3e, int copy_rest,
                                  void* stream) {
+  return ecwam_hip_propags2_otf_fast(c, f1, f3, n, ngy, delpro, delpro_lf, ifrelfmax, in_nfre, nullptr, 0, 0, gout, gout_nfre, kxlt, zdello, xdella, cosph,
+                                     sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s, nd3e, copy_rest, stream);
+}
+
+int ecwam_hip_propags2_otf_fast(ecwam_hip_ctx* c, const void* f1, void* f3, int n, int ngy, double delpro, double delpro_lf, int ifrelfmax,
+                                int in_nfre, const void* gin, int gin_nfre, int out_nfre, void* gout, int gout_nfre, const int* kxlt,
+                                const void* zdello, double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat,
+                                const int* kcor, const void* wlat, const void* wcor, const void* cgroup_ext, const void* cosphm1_ext,
+                                const int* order, int kijs, int kijl, int nd3s, int nd3e, int copy_rest, void* stream) {
   if (!c) return fail("null context");
+  if (out_nfre == 0) out_nfre = c->NFRE;
+  if (out_nfre != c->NFRE && (out_nfre < nd3e || out_nfre > c->NFRE || gout))
+    return fail("ecwam_hip_propags2_otf_fast: a compact output buffer must hold every advected frequency and excludes a second compact copy");
+  if (gin && (in_nfre != 0 && in_nfre != c->NFRE)) return fail("ecwam_hip_propags2_otf_fast: the compact fast-wave input goes with full input rows");
+  if (gin && (gin_nfre < 1 || gin_nfre > c->NFRE || gin == f3 || gin == gout)) return fail("ecwam_hip_propags2_otf_fast: bad compact input buffer");
   // with a processing order kijs..kijl index its entries (entries < 0 are padding and skipped: the order may be longer than n)
   if (kijl < kijs || kijs < 0 || (!order && kijl > n) || nd3s < 1 || nd3e > c->NFRE_RED || nd3e < nd3s - 1 || ifrelfmax < 0 || ifrelfmax > c->NFRE_RED)
     return fail("ecwam_hip_propags2_otf: bad range");
@@ -447,8 +461,8 @@ int ecwam_hip_propags2_otf_split(ecwam_hip_ctx* c, const void* f1, void* f3, int
   if (in_nfre == 0) in_nfre = c->NFRE;
   if (gout && (gout_nfre < 1 || gout_nfre > c->NFRE || gout_nfre % (16 / c->real_bytes) != 0 || gout == f1 || ((uintptr_t)gout % 16) != 0))
     return fail("ecwam_hip_propags2_otf: the compact output buffer must be 16-byte aligned, distinct from F1, and hold a multiple of 16 bytes per direction");
-  if (in_nfre != c->NFRE && (in_nfre < nd3e || in_nfre > c->NFRE || (copy_rest & 1)))
-    return fail("ecwam_hip_propags2_otf: a compact input buffer must hold every advected frequency and cannot be combined with copy_rest");
+  if (in_nfre != c->NFRE && (in_nfre < nd3e || in_nfre > c->NFRE || ((copy_rest & 1) && out_nfre != in_nfre)))
+    return fail("ecwam_hip_propags2_otf: a compact input buffer must hold every advected frequency; copy_rest only into a compact output of the same width");
   if (kijl > kijs && (!f1 || !f3 || !kxlt || !zdello || !cosph || !sinph || !klon || !klat || !kcor || !wlat || !wcor || !cgroup_ext || !cosphm1_ext))
     return fail("ecwam_hip_propags2_otf: null pointer");
   if (f1 == f3) return fail("ecwam_hip_propags2_otf: F1 and F3 must not alias");
@@ -459,8 +473,8 @@ int ecwam_hip_propags2_otf_split(ecwam_hip_ctx* c, const void* f1, void* f3, int
 #ifdef ECWAM_HIP_DIAGNOSTICS
   { const char* e_ = getenv("ECWAM_HIP_OTF_WALK"); if (e_ && atoi(e_) == 0) copy_rest |= 2; }  // plain grid-stride tile walk
 #endif
-  DISPATCH(launch_propags2_otf<float>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, c->obs, ifrelfmax, delpro_lf, in_nfre, gout, gout_nfre, s),
-           launch_propags2_otf<double>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, c->obs, ifrelfmax, delpro_lf, in_nfre, gout, gout_nfre, s));
+  DISPATCH(launch_propags2_otf<float>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, c->obs, ifrelfmax, delpro_lf, in_nfre, gout, gout_nfre, gin, gin_nfre, out_nfre, s),
+           launch_propags2_otf<double>(c->dtab, f1, f3, n, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, cosphm1_ext, order, kijs, kijl, nd3s - 1, nd3e, copy_rest, N, c->obs, ifrelfmax, delpro_lf, in_nfre, gout, gout_nfre, gin, gin_nfre, out_nfre, s));
   HIPCHK(hipGetLastError());
   return 0;
 }

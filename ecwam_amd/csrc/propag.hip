@@ -378,7 +378,7 @@ template <typename T> struct VecIO<T, 1> {
 };
 // (single precision without obstructions -- the benchmark's build -- needs its four waves per SIMD to hide the gathers' latency: 128 VGPRs)
 template <typename T, int VW, bool OBS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && !OBS) ? 4 : 1))) k_propags2_otf(const DevTab<T>* __restrict__ tab, const T* __restrict__ f1, T* __restrict__ f3,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && !OBS) ? 4 : 1))) k_propags2_otf(const DevTab<T>* __restrict__ tab, const T* __restrict__ f1_rows, T* __restrict__ f3,
                                                       int n_geom, int ngy, T delpro, const int* __restrict__ kxlt,
                                                       const T* __restrict__ zdello, T xdella, const T* __restrict__ cosph,
                                                       const T* __restrict__ sinph, const int* __restrict__ klon,
@@ -387,7 +387,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeo
                                                       const T* __restrict__ cg, const T* __restrict__ cosphm1,
                                                       const int* __restrict__ order, int kijs, int kijl, int m0, int m1,
                                                       int copy_rest, int ntiles, const T* __restrict__ obs, int mlf, T delpro_lf, int in_k,
-                                                      T* __restrict__ gout, int gout_k) {
+                                                      T* __restrict__ gout, int gout_k, const T* __restrict__ gin, int gin_k, int out_k) {
+  // gin (optional, with full input rows only): the first gin_k frequencies of every direction are READ from the compact buffer
+  // gin[ij][K][gin_k] instead of the input rows -- the fast waves after their sub-steps on compact rows; the other frequencies come from f1.
+  // out_k: frequencies per direction in the OUTPUT rows (NFRE, or the width of a compact buffer: a fast-wave sub-step compact -> compact).
   // gout (optional): the first gout_k frequencies of every advected direction are ALSO written to the compact buffer
   // gout[ij][K][gout_k] (the fast waves the next sub-step starts from: saves extracting them from the FL3 rows afterwards)
   // in_k: frequencies per direction in the INPUT rows (NFRE, or the width of a compact fast-wave buffer [ij][K][in_k]);
@@ -396,7 +399,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeo
   // (propag_wam.F90:247-283 calls PROPAGS2 once per range)
   extern __shared__ __align__(16) unsigned char otf_smem[];
   const int NANG = tab->NANG, NFRE = tab->NFRE;
-  const int N = NANG * NFRE, NIN = NANG * in_k, FV = in_k / VW, NV = NANG * FV;
+  const int N = NANG * NFRE, FV = in_k / VW, NV = NANG * FV;
+  if (out_k <= 0) out_k = NFRE;
+  const int NOUT = NANG * out_k;
   const T CMTODEG = T(360.0) / tab->CIRC;
   const T DELTH0 = T(0.25) * delpro / tab->DELTH;
   const T DELTH0_LF = T(0.25) * delpro_lf / tab->DELTH;
@@ -475,8 +480,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeo
     auto element = [&](const int t, const int k, const int mv) {   // direction k, vector mv of the NFRE / VW of a direction
       const int m = mv * VW;
       const int* q = sI + t * 16;
-      const size_t own = (size_t)q[0] * N, own_in = (size_t)q[0] * NIN;
-      const int el = k * NFRE + m, el_in = k * in_k + m;
+      const bool fromg = gin && m < gin_k;                 // this vector's inputs (own and neighbours) live in the compact buffer
+      const T* __restrict__ f1 = fromg ? gin : f1_rows;
+      const int ik = fromg ? gin_k : in_k;
+      const int NIN = NANG * ik;
+      const size_t own = (size_t)q[0] * NOUT, own_in = (size_t)q[0] * NIN;
+      const int el = k * out_k + m, el_in = k * ik + m;
       if (m + VW <= m0 || m >= m1) {   // no element of this vector is advected
         if (copy_rest & 1) {
           T v[VW];
@@ -506,8 +515,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeo
       IO::ld(f1 + (size_t)q[4 + 2 * jy0] * NIN + el_in, fla2);
       IO::ld(f1 + (size_t)q[7 + 2 * kc] * NIN + el_in, fco1);
       IO::ld(f1 + (size_t)q[8 + 2 * kc] * NIN + el_in, fco2);
-      IO::ld(f1 + own_in + km * in_k + m, fkm);
-      IO::ld(f1 + own_in + kp * in_k + m, fkp);
+      IO::ld(f1 + own_in + km * ik + m, fkm);
+      IO::ld(f1 + own_in + kp * ik + m, fkp);
       const T* bb = sB + (size_t)t * 5 * NFRE + m;
       T bh0[VW], bh1[VW], by0[VW], by1[VW], bc0[VW];
       IO::ld(bb, bh0); IO::ld(bb + NFRE, bh1); IO::ld(bb + 2 * NFRE, by0); IO::ld(bb + 3 * NFRE, by1); IO::ld(bb + 4 * NFRE, bc0);
@@ -1251,7 +1260,7 @@ void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, 
                          const void* zdello, double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat,
                          const int* kcor, const void* wlat, const void* wcor, const void* cg, const void* cosphm1, const int* order,
                          int kijs, int kijl, int m0, int m1, int copy_rest, int dims, const void* obs, int mlf, double delpro_lf, int in_k,
-                         void* gout, int gout_k, hipStream_t s) {
+                         void* gout, int gout_k, const void* gin, int gin_k, int out_k, hipStream_t s) {
   const int NANG = dims >> 16, NFRE = (dims >> 8) & 0xFF;
   if (in_k <= 0) in_k = NFRE;
   const int n = kijl - kijs;
@@ -1269,19 +1278,20 @@ void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, 
 #define OTF_ARGS                                                                                                              \
   (const DevTab<T>*)tab, (const T*)f1, (T*)f3, n_geom, ngy, (T)delpro, kxlt, (const T*)zdello, (T)xdella, (const T*)cosph,     \
       (const T*)sinph, klon, klat, kcor, (const T*)wlat, (const T*)wcor, (const T*)cg, (const T*)cosphm1, order, kijs, kijl, m0, \
-      m1, copy_rest, ntiles, (const T*)obs, mlf, (T)delpro_lf, in_k, (T*)gout, gout_k
+      m1, copy_rest, ntiles, (const T*)obs, mlf, (T)delpro_lf, in_k, (T*)gout, gout_k, (const T*)gin, gin_k, out_k
   int vw = W;
 #ifdef ECWAM_HIP_DIAGNOSTICS
   { const char* e_ = getenv("ECWAM_HIP_OTF_VW"); if (e_) vw = atoi(e_); }
 #endif
   if (gout && (gout_k % W != 0 || (uintptr_t)gout % 16 != 0)) gout = nullptr;   // checked by the caller; never taken
-  const bool vec = vw >= W && aligned && NFRE % W == 0 && in_k % W == 0;   // a range boundary inside a vector is handled by the kernel
+  if (out_k <= 0) out_k = NFRE;
+  const bool vec = vw >= W && aligned && NFRE % W == 0 && in_k % W == 0 && out_k % W == 0 && (!gin || (gin_k % W == 0 && (uintptr_t)gin % 16 == 0));   // a range boundary inside a vector is handled by the kernel
   if (obs) {  // LSUBGRID
     if (vec) { allow_lds(k_propags2_otf<T, W, true>, shmem); hipLaunchKernelGGL((k_propags2_otf<T, W, true>), dim3(grid), dim3(256), shmem, s, OTF_ARGS); }
     else { allow_lds(k_propags2_otf<T, 1, true>, shmem); hipLaunchKernelGGL((k_propags2_otf<T, 1, true>), dim3(grid), dim3(256), shmem, s, OTF_ARGS); }
   } else if (vec)
     { allow_lds(k_propags2_otf<T, W, false>, shmem); hipLaunchKernelGGL((k_propags2_otf<T, W, false>), dim3(grid), dim3(256), shmem, s, OTF_ARGS); }
-  else if (vw >= 2 && aligned && NFRE % 2 == 0 && in_k % 2 == 0)
+  else if (vw >= 2 && aligned && NFRE % 2 == 0 && in_k % 2 == 0 && out_k % 2 == 0 && (!gin || gin_k % 2 == 0))
     { allow_lds(k_propags2_otf<T, 2, false>, shmem); hipLaunchKernelGGL((k_propags2_otf<T, 2, false>), dim3(grid), dim3(256), shmem, s, OTF_ARGS); }
   else
     { allow_lds(k_propags2_otf<T, 1, false>, shmem); hipLaunchKernelGGL((k_propags2_otf<T, 1, false>), dim3(grid), dim3(256), shmem, s, OTF_ARGS); }
@@ -1430,7 +1440,7 @@ void launch_proenv_unpack(int nrows, int NFRE, const void* buf, const void* land
   template void launch_propags2_otf<T>(const void*, const void*, void*, int, int, double, const int*, const void*, double,        \
                                        const void*, const void*, const int*, const int*, const int*, const void*, const void*,   \
                                        const void*, const void*, const int*, int, int, int, int, int, int, const void*, int, double,   \
-                                       int, void*, int, hipStream_t);                                                                              \
+                                       int, void*, int, const void*, int, int, hipStream_t);                                                                              \
   template void launch_c2p<T>(const void*, void*, int, int, int, int, int, hipStream_t);                                          \
   template void launch_p2c<T>(const void*, void*, int, int, int, int, int, hipStream_t);                                          \
   template void launch_copy_freq_range<T>(const void*, void*, int, int, int, int, int, int, hipStream_t);                             \

@@ -157,10 +157,16 @@ class Wamintgr:
         self.delpro_lf = delpro_lf
         # fast waves between the sub-steps: compact rows [ij][K][LFP] (a frequency sub-range of the full rows would touch every
         # cache line of the spectra; these are 36/LFP times smaller, for the stencil and for the halo exchange)
-        self.g1 = None
+        self.g1 = self.g2 = None
+        self.gfast_valid = False        # g1 holds the first LFP frequencies of the current FL1 (fast waves + the slow ones that fill its last vector)
+        # "compact": sub-steps 1 .. NSTEP_LF-1 compact -> compact BEFORE the full pass, which reads the fast waves' last state from the
+        # compact buffer and writes complete rows (round 3); "rows": the full pass first, the further sub-steps write the fast-wave slots
+        # of the FL3 rows (round 2; every line of FL3 touched once more per sub-step).  Same bits.
+        self.fast_mode = "compact"
         if 0 < ifrelfmax < cfg.nfre_red and weights == "otf" and not int(cfg.irefra):
             lfp = min(cfg.nfre, (ifrelfmax + 3) // 4 * 4)
             self.g1 = torch.zeros((self.nrows, NANG, lfp), **z)
+            self.g2 = torch.zeros((self.nrows, NANG, lfp), **z)
         self.weights_ready = False
         # refraction (IREFRA = 1 depth, 2 currents, 3 both): per-point THD/S0/U/V/OMDD/CURMASK instead of the reference's
         # THDD/THDC/SDOT and 21 weight arrays; PROPAGS2 rebuilds every weight on the fly
@@ -356,6 +362,9 @@ class Wamintgr:
                 advect(*a, rows=(ib, self.n), src=src)
 
         otf_plain = self.weights == "otf" and not self.irefra
+        if lf and otf_plain and self.g1 is not None and self.fast_mode == "compact" and self.order is None:
+            self._propag_fast_compact(advect_rows)
+            return
         if self.weights == "stored" or self.ifrelfmax <= 0:
             exchange_and_advect([(1, c.nfre_red, float(c.idelpro), True)])      # stored W already carries the per-range time steps
         elif otf_plain:
@@ -379,16 +388,54 @@ class Wamintgr:
                     exchange_and_advect([(1, self.ifrelfmax, float(self.delpro_lf), False)])
         self.fl1, self.fl3 = self.fl3, self.fl1
 
+    def _propag_fast_compact(self, advect_rows) -> None:
+        """PROPAG_WAM with fast-wave sub-steps (propag_wam.F90:247-313) in the order that writes no frequency sub-range into full rows:
+        the fast waves do not depend on the slow ones, so their sub-steps 1 .. NSTEP_LF-1 run first, compact -> compact (rows 4.5 x
+        shorter at IFRELFMAX = 5, for the stencil and for MPEXCHNG), and the one full pass takes their last state as the input of the last
+        sub-step next to the slow waves of FL1 and writes complete FL3 rows (+ the compact copy the next advection step starts from)."""
+        c, g = self.cfg, self.gd
+        lfm, dlf = self.ifrelfmax, float(self.delpro_lf)
+        nstep_lf = int(round(float(c.idelpro) / dlf))
+        lfp = int(self.g1.shape[2])
+        if not self.gfast_valid:      # (after IMPLSCH or a new initial state) FL1's first LFP frequencies -> compact rows
+            self.ctx.copy_freq_range(self.fl1, self.g1, self.n, 1, lfp)
+        ga, gb = self.g1, self.g2
+        overlap = self.dom.nranks > 1
+        ia, ib = self.interior if overlap else (0, self.n)
+
+        def run(passes, exchanges):
+            """post the exchanges, advect the rows that read no halo row, wait, advect the two ends of the band"""
+            reqs = [self.halo.start(x) for x in exchanges] if self.dom.nranks > 1 else []
+            passes(ia, ib)
+            for r in reqs:
+                self.halo.finish(r)
+            if overlap:
+                passes(0, ia)
+                passes(ib, self.n)
+
+        for _ in range(nstep_lf - 1):
+            src, dst = ga, gb
+            run(lambda k0, k1: k1 > k0 and self.ctx.propags2_otf(src, dst, g, self.cgroup_ext, dlf, k0, k1, 1, lfm, copy_rest=True), [src])
+            ga, gb = gb, ga
+        # the full pass: slow waves from FL1 with IDELPRO, the fast waves' last sub-step from the compact rows with DELPRO_LF
+        run(lambda k0, k1: k1 > k0 and self.ctx.propags2_otf(self.fl1, self.fl3, g, self.cgroup_ext, float(c.idelpro), k0, k1, 1, c.nfre_red, copy_rest=True,
+                                                            ifrelfmax=lfm, delpro_lf=dlf, gin=ga, gout=gb), [self.fl1, ga])
+        self.g1, self.g2 = gb, ga
+        self.gfast_valid = True
+        self.fl1, self.fl3 = self.fl3, self.fl1
+
     def newwind(self) -> None:
         if self.ff_next is not None:
             self.ctx.newwind(self.ff, self.ff_next)
 
     def implsch(self) -> None:
         self.ctx.implsch(0, self.n, self.fl1, self.wvprpt, self.ff, self.intf, self.mij, self.xllws)
+        self.gfast_valid = False
 
     def nosource(self) -> None:
         """NO SOURCE TERM CONTRIBUTION (wamintgr.F90:152-160, LLSOURCE = F)."""
         self.ctx.nosource(0, self.n, self.fl1, self.mij, self.xllws)
+        self.gfast_valid = False
 
     def step(self, advect: bool = True, source: bool = True, llsource: bool = True) -> None:
         if advect:
@@ -409,6 +456,7 @@ class Wamintgr:
         from . import restart
         a = restart.read_fl(path, self.n, self.cfg.nang, self.cfg.nfre, self.npdt)
         self.fl1[: self.n] = torch.from_numpy(a).to(self.dev)
+        self.gfast_valid = False
 
     # ---- OUTBS subset on the device: [n][5] = swh, mean direction, mean period, EM, peak period; norms = OUTWNORM (avg, min, max, count)
     def outbs(self) -> torch.Tensor:

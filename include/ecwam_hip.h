@@ -198,6 +198,22 @@ int ecwam_hip_propags2_otf_split(ecwam_hip_ctx *ctx, const void *f1, void *f3, i
                                  const void *sinph, const int *klon, const int *klat, const int *kcor, const void *wlat,
                                  const void *wcor, const void *cgroup_ext, const void *cosphm1_ext, const int *order, int kijs,
                                  int kijl, int nd3s, int nd3e, int copy_rest, void *stream);
+/*
+ * The same with the two further row formats of the fast-wave sub-steps (round 3): the sub-steps 1 .. NSTEP_LF-1 of the fast waves run
+ * compact -> compact BEFORE the full pass (the fast waves do not depend on the slow ones: the same arithmetic in another order, hence
+ * the same bits as propag_wam.F90:247-313), and the full pass takes their last state as the input of the last sub-step and writes
+ * complete rows -- no pass writes a frequency sub-range into full rows (which touches every line of them).
+ *   gin / gin_nfre (may be NULL / 0; needs full input rows, in_nfre = 0): the first gin_nfre frequencies of every direction are read
+ *     from the compact buffer gin[npts+1][NANG][gin_nfre] (own point and neighbours alike) instead of f1.
+ *   out_nfre: 0 (f3 has the FL layout) or the width of a compact OUTPUT buffer f3[npts+1][NANG][out_nfre] (then gout must be NULL; with a
+ *     compact input of the same width copy_rest carries the frequencies beyond nd3e over, so that whole 16-byte vectors stay valid).
+ */
+int ecwam_hip_propags2_otf_fast(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n, int ngy, double delpro, double delpro_lf,
+                                int ifrelfmax, int in_nfre, const void *gin, int gin_nfre, int out_nfre, void *gout, int gout_nfre,
+                                const int *kxlt, const void *zdello, double xdella, const void *cosph, const void *sinph,
+                                const int *klon, const int *klat, const int *kcor, const void *wlat, const void *wcor,
+                                const void *cgroup_ext, const void *cosphm1_ext, const int *order, int kijs, int kijl, int nd3s,
+                                int nd3e, int copy_rest, void *stream);
 /* dst[ij][K][m_first-1 .. m_last-1] = src[...] for rows [0,n): FL1_EXT(:,:,1:IFRELFMAX) = FL3_EXT(...) between the fast-wave
  * sub-steps (propag_wam.F90:287-291).  dst_nfre: 0 (dst has the FL layout) or the width of a compact buffer dst[..][NANG][dst_nfre] */
 int ecwam_hip_copy_freq_range(ecwam_hip_ctx *ctx, const void *src, void *dst, int n, int m_first, int m_last, int dst_nfre,

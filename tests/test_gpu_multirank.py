@@ -23,7 +23,8 @@ def _run(cmd, env):
     return json.loads(line)
 
 
-@pytest.mark.parametrize("nranks,launcher,extra", [(2, "self", []), (3, "torchrun", []), (2, "self", ["--irefra", "2"])])
+@pytest.mark.parametrize("nranks,launcher,extra", [(2, "self", []), (3, "torchrun", []), (2, "self", ["--irefra", "2"]),
+                                                   (3, "self", ["--ifrelfmax", "5", "--adv-per-source", "2"])])
 def test_bench_two_ranks_on_one_gpu_match_single_rank(tmp_path, nranks, launcher, extra):
     """launcher "self": the driver's command shape, `python bench.py --gpus N ...` with WORLD_SIZE unset -- bench.py starts its own N
     ranks as a child process; "torchrun": started under torch.distributed.run as the contract's N > 1 command does."""
@@ -32,6 +33,8 @@ def test_bench_two_ranks_on_one_gpu_match_single_rank(tmp_path, nranks, launcher
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
+    # extra = --ifrelfmax 5 --adv-per-source 2: the O1280 structure -- fast-wave sub-steps on compact rows (their own, smaller halo exchange),
+    # the compact copy handed from the first advection step to the second.
     # extra = --irefra 2: currents; on N > 1 ranks the extended environment rows come from PROENVHALO on the device (owned rows + one
     # exchange of 3 NFRE + 3 reals per halo row through the same transport), on one rank from the host assembly: same bits
     common = ["--grid", "48", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra

@@ -102,6 +102,36 @@ def test_propag_wam_fast_wave_substeps_match_oracle(api, prec, nang, nred, lf, d
     m.ctx.close()
 
 
+@pytest.mark.parametrize("prec,lf,dlf", [("sp", 5, 225.0), ("dp", 4, 150.0)])
+def test_fast_wave_sub_step_orders_are_bit_identical(api, prec, lf, dlf):
+    """The two orders of the sub-stepped advection -- the reference's (full pass first, the further sub-steps into the fast-wave slots of the
+    full rows: fast_mode "rows") and the one that writes no frequency sub-range into full rows (the sub-steps first, compact -> compact, the
+    full pass last with the compact rows as the fast waves' input: fast_mode "compact", the default) -- are the same arithmetic per element:
+    same bits after two 2 : 1 cycles with source terms in between (the compact copy is refreshed after IMPLSCH and handed from one
+    advection step to the next)."""
+    from ecwam_amd import grid as G
+    from ecwam_amd.wamintgr import Wamintgr
+
+    cfg = Config(nang=36, nfre=36, nfre_red=29, idelpro=450, idelt=900)
+    g = G.build_grid(16, mask="continents")
+    res = {}
+    for mode in ("rows", "compact"):
+        m = Wamintgr(cfg, g, prec, ifrelfmax=lf, delpro_lf=dlf)
+        m.fast_mode = mode
+        m.init_synthetic(seed=5)
+        _add_swell(m, g.nsea)
+        for _ in range(2):
+            m.step(advect=True, source=False)
+            assert m.gfast_valid == (mode == "compact")
+            m.step(advect=True, source=True)
+            assert not m.gfast_valid
+        torch.cuda.synchronize()
+        res[mode] = (m.fl1.cpu().numpy().copy(), m.mij.cpu().numpy().copy())
+        m.ctx.close()
+    assert np.array_equal(res["rows"][0], res["compact"][0]) and np.array_equal(res["rows"][1], res["compact"][1])
+    assert np.isfinite(res["compact"][0]).all()
+
+
 @pytest.mark.parametrize("prec", ["sp", "dp"])
 def test_native_2to1_cycle_with_fast_waves_matches_oracle(api, prec):
     """The O1280 structure end to end: two advection steps of 450 s (each with a fast-wave sub-step of 225 s, M <= 5) per source

@@ -32,3 +32,14 @@ print("copy M=1..5            :", t(lambda: m.ctx.copy_freq_range(m.fl3, m.fl1, 
 print("fast waves only (1..5) :", t(lambda: m.ctx.propags2_otf(m.fl1, m.fl3, g, m.cgroup_ext, dt / 2.0, 0, m.n, 1, 5, copy_rest=False)))
 print("fast waves only (1..4) :", t(lambda: m.ctx.propags2_otf(m.fl1, m.fl3, g, m.cgroup_ext, dt / 2.0, 0, m.n, 1, 4, copy_rest=False)))
 print("whole propag()         :", t(m.propag))
+# round 3: the pieces of the compact-first order
+print("fused pass + gout      :", t(lambda: m.ctx.propags2_otf(m.fl1, m.fl3, g, m.cgroup_ext, float(dt), 0, m.n, 1, 36, ifrelfmax=5, delpro_lf=dt / 2.0, gout=m.g1)))
+print("sub-step compact->rows :", t(lambda: m.ctx.propags2_otf(m.g1, m.fl3, g, m.cgroup_ext, dt / 2.0, 0, m.n, 1, 5, copy_rest=False)))
+print("extract M=1..8 compact :", t(lambda: m.ctx.copy_freq_range(m.fl1, m.g1, m.n, 1, 8)))
+print("sub-step compact->comp :", t(lambda: m.ctx.propags2_otf(m.g1, m.g2, g, m.cgroup_ext, dt / 2.0, 0, m.n, 1, 5, copy_rest=True)))
+print("full pass gin + gout   :", t(lambda: m.ctx.propags2_otf(m.fl1, m.fl3, g, m.cgroup_ext, float(dt), 0, m.n, 1, 36, ifrelfmax=5, delpro_lf=dt / 2.0, gin=m.g1, gout=m.g2)))
+print("full pass gin          :", t(lambda: m.ctx.propags2_otf(m.fl1, m.fl3, g, m.cgroup_ext, float(dt), 0, m.n, 1, 36, ifrelfmax=5, delpro_lf=dt / 2.0, gin=m.g1)))
+for mode in ("rows", "compact"):
+    m.fast_mode = mode
+    m.gfast_valid = False
+    print(f"whole propag() {mode:8s}:", t(m.propag))

@@ -147,6 +147,13 @@ class HipContext:
                 self._real(cgroup_ext, (nrow, self.NFRE), "CGROUP_EXT"), self._real(g["cosphm1_ext"], (nrow,), "COSPHM1_EXT"), po]
         self._chk(self.lib.ecwam_hip_propags2_otf_fast(self._h, *args, kijs, kijl, nd3s, nd3e, int(bool(copy_rest)) | (4 if tiles2d else 0), _stream_ptr()))
 
+    def set_fastwave_copy(self, g) -> None:
+        """g: compact rows [nrow][NANG][w] IMPLSCH / NOSOURCE also write the first w frequencies of their result to (None: off)."""
+        if g is None:
+            self._chk(self.lib.ecwam_hip_set_fastwave_copy(self._h, None, 0))
+        else:
+            self._chk(self.lib.ecwam_hip_set_fastwave_copy(self._h, self._real(g, (g.shape[0], self.NANG, g.shape[2]), "G"), int(g.shape[2])))
+
     # -- FL1_EXT(:,:,M1:M2) <- FL3_EXT between the fast-wave sub-steps (propag_wam.F90:287-291)
     def copy_freq_range(self, src, dst, n, m_first, m_last):
         """dst may be a compact buffer [nrow][NANG][w] with w >= m_last."""

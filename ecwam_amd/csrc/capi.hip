@@ -47,6 +47,8 @@ struct ecwam_hip_ctx {
   hipEvent_t ev_packed = nullptr, ev_done = nullptr;
   bool halo_inflight = false;   // an exchange has been posted whose ev_done no later halo_start has waited for
   ecwam_hip_params p;
+  void* fast_g = nullptr;     // ecwam_hip_set_fastwave_copy: compact rows [ij][K][fast_gk] IMPLSCH / NOSOURCE also leave the new fast waves in
+  int fast_gk = 0;
   const void* obs = nullptr;  // LSUBGRID: device OBS[n_obs][8][NFRE] (ecwam_hip_set_obstructions), read by CTUW / PROPAGS2
   int n_obs = 0;
 };
@@ -70,8 +72,8 @@ template <typename T> void launch_pack(const void*, const int*, int, int, void*,
 template <typename T> void launch_proenv_pack(int, int, const void*, const void*, const void*, const void*, const void*, void*, hipStream_t);
 template <typename T> void launch_proenv_unpack(int, int, const void*, const void*, void*, void*, void*, void*, void*, void*, hipStream_t);
 template <typename T> int launch_implsch(const void*, int, int, void*, const void*, void*, void*, int*, void*, double*, void*, int, int, int, hipStream_t);
-template <typename T> int launch_implsch4(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, int, int, int, int, int, int, hipStream_t);
-template <typename T> int launch_implsch4x(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, int, int, int, int, int, int, hipStream_t);
+template <typename T> int launch_implsch4(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, int, int, int, int, int, int, hipStream_t);
+template <typename T> int launch_implsch4x(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, int, int, int, int, int, int, hipStream_t);
 int implsch4_fin_row();
 
 // Does the fourth kernel generation cover these tables?  It needs the pull-form DIA structure with K1W = K -+ r1, K11W = K1W -+ 1,
@@ -311,6 +313,16 @@ static void halo_release(ecwam_hip_ctx* c) {
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   c->comm = nullptr; c->d_send_idx = nullptr; c->d_send_buf = nullptr; c->ev_packed = c->ev_done = nullptr; c->comm_stream = nullptr;
+}
+
+// the first fast_gk frequencies of rows [kijs, kijl) of FL1 -> the compact rows of ecwam_hip_set_fastwave_copy (the kernels that do not
+// write them from their tile)
+static void fastwave_copy(ecwam_hip_ctx* c, const void* fl1, int kijs, int kijl, hipStream_t s) {
+  const size_t rb = (size_t)c->real_bytes;
+  const char* src = (const char*)fl1 + (size_t)kijs * c->NANG * c->NFRE * rb;
+  char* dst = (char*)c->fast_g + (size_t)kijs * c->NANG * c->fast_gk * rb;
+  if (c->real_bytes == 4) launch_copy_freq_range<float>(src, dst, kijl - kijs, c->NANG, c->NFRE, 0, c->fast_gk, c->fast_gk, s);
+  else launch_copy_freq_range<double>(src, dst, kijl - kijs, c->NANG, c->NFRE, 0, c->fast_gk, c->fast_gk, s);
 }
 
 extern "C" {
@@ -623,11 +635,11 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !rare4 && alt_ok && !dbg && shelter_ok) {
     if (int rc2 = ecwam_hip_implsch_reserve(c, kijl)) return rc2;   // no-op once the buffer covers kijl
     if (alt)
-      DISPATCH(rc = launch_implsch4x<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, alt, s),
-               rc = launch_implsch4x<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, alt, s));
+      DISPATCH(rc = launch_implsch4x<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, alt, s),
+               rc = launch_implsch4x<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, alt, s));
     else
-      DISPATCH(rc = launch_implsch4<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s),
-               rc = launch_implsch4<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s));
+      DISPATCH(rc = launch_implsch4<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s),
+               rc = launch_implsch4<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s));
     if (rc == 0) { HIPCHK(hipGetLastError()); c->implsch_last = 4; return 0; }
   }
   c->implsch_last = 2;
@@ -635,6 +647,15 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
            rc = launch_implsch<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s));
   if (rc) return fail("ecwam_hip_implsch: unsupported spectral size for the LDS tiling");
   HIPCHK(hipGetLastError());
+  if (c->fast_g) fastwave_copy(c, fl1, kijs, kijl, s);   // (k_implsch4 writes the compact rows from its tile)
+  return 0;
+}
+
+int ecwam_hip_set_fastwave_copy(ecwam_hip_ctx* c, void* g, int g_nfre) {
+  if (!c) return fail("null context");
+  if (g && (g_nfre < 1 || g_nfre > c->NFRE || g_nfre % (16 / c->real_bytes) != 0 || ((uintptr_t)g % 16) != 0))
+    return fail("ecwam_hip_set_fastwave_copy: the compact rows must be 16-byte aligned and hold a multiple of 16 bytes per direction");
+  c->fast_g = g; c->fast_gk = g ? g_nfre : 0;
   return 0;
 }
 
@@ -711,6 +732,7 @@ int ecwam_hip_nosource(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, int* mij
   DISPATCH(launch_nosource<float>(c->dtab, kijs, kijl, c->NANG * c->NFRE, fl1, xllws, mij, s),
            launch_nosource<double>(c->dtab, kijs, kijl, c->NANG * c->NFRE, fl1, xllws, mij, s));
   HIPCHK(hipGetLastError());
+  if (c->fast_g && fl1 && kijl > kijs) { fastwave_copy(c, fl1, kijs, kijl, s); HIPCHK(hipGetLastError()); }
   return 0;
 }
 

@@ -691,7 +691,9 @@ template <typename T, int NANG, int PP, int R1, int R2, int NH, bool EXT, bool J
 // (40 KB per wave) and the kernel may use the whole register file (340 registers: no scratch)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(V4_WPE_MIN(T), 2)))
 k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__ fl1, const T* __restrict__ wvprpt, T* __restrict__ ffa,
-           T* __restrict__ intfa, int* __restrict__ mij_out, T* __restrict__ xllws, T* __restrict__ fin) {
+           T* __restrict__ intfa, int* __restrict__ mij_out, T* __restrict__ xllws, T* __restrict__ fin, T* __restrict__ gfast, int gk) {
+  // gfast (optional): compact rows gfast[ij][K][gk] that also receive the first gk frequencies of the new spectrum -- what the next
+  // advection step's fast-wave sub-steps start from (ecwam_hip_set_fastwave_copy): written from the tile, no second pass over FL1
   constexpr int G = NANG / 2, NFRE = V4_NFRE, N = NANG * NFRE, RS = PP * NANG, NS = NFRE / G;
   constexpr int NSH = (NH + 1) / 2;          // even shifts -2 NSH .. 2 NSH cover the taps -NH .. NH+1 and the DIA rotations
   constexpr int NTAP = 2 * NH + 1;
@@ -1566,6 +1568,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
 #pragma unroll
             for (int i = 0; i < VEC; i++) val[i] = d[i * RS + q * NANG];
             *reinterpret_cast<VT*>(fl1 + (size_t)(ij0 + q) * N + (size_t)w * VEC) = val;
+            if (gfast && r * VEC < gk) *reinterpret_cast<VT*>(gfast + ((size_t)(ij0 + q) * NANG + k) * gk + r * VEC) = val;
           }
         }
       }

@@ -428,14 +428,22 @@ class Wamintgr:
         if self.ff_next is not None:
             self.ctx.newwind(self.ff, self.ff_next)
 
+    def _fast_sink(self) -> bool:
+        """IMPLSCH / NOSOURCE leave the fast waves of their result in the compact rows the next advection step starts from."""
+        on = self.g1 is not None and self.fast_mode == "compact" and self.order is None
+        self.ctx.set_fastwave_copy(self.g1 if on else None)
+        return on
+
     def implsch(self) -> None:
+        on = self._fast_sink()
         self.ctx.implsch(0, self.n, self.fl1, self.wvprpt, self.ff, self.intf, self.mij, self.xllws)
-        self.gfast_valid = False
+        self.gfast_valid = on
 
     def nosource(self) -> None:
         """NO SOURCE TERM CONTRIBUTION (wamintgr.F90:152-160, LLSOURCE = F)."""
+        on = self._fast_sink()
         self.ctx.nosource(0, self.n, self.fl1, self.mij, self.xllws)
-        self.gfast_valid = False
+        self.gfast_valid = on
 
     def step(self, advect: bool = True, source: bool = True, llsource: bool = True) -> None:
         if advect:

@@ -214,6 +214,10 @@ int ecwam_hip_propags2_otf_fast(ecwam_hip_ctx *ctx, const void *f1, void *f3, in
                                 const int *klon, const int *klat, const int *kcor, const void *wlat, const void *wcor,
                                 const void *cgroup_ext, const void *cosphm1_ext, const int *order, int kijs, int kijl, int nd3s,
                                 int nd3e, int copy_rest, void *stream);
+/* g (may be NULL: off) = compact rows g[npts+1][NANG][g_nfre] that every later ecwam_hip_implsch / ecwam_hip_nosource call ALSO leaves the
+ * first g_nfre frequencies of the spectra it wrote in: the state the next advection step's fast-wave sub-steps start from, written from
+ * IMPLSCH's tile instead of extracted from the FL1 rows by a pass of its own (ecwam_hip_copy_freq_range).  The library keeps the pointer. */
+int ecwam_hip_set_fastwave_copy(ecwam_hip_ctx *ctx, void *g, int g_nfre);
 /* dst[ij][K][m_first-1 .. m_last-1] = src[...] for rows [0,n): FL1_EXT(:,:,1:IFRELFMAX) = FL3_EXT(...) between the fast-wave
  * sub-steps (propag_wam.F90:287-291).  dst_nfre: 0 (dst has the FL layout) or the width of a compact buffer dst[..][NANG][dst_nfre] */
 int ecwam_hip_copy_freq_range(ecwam_hip_ctx *ctx, const void *src, void *dst, int n, int m_first, int m_last, int dst_nfre,

@@ -124,7 +124,7 @@ def test_fast_wave_sub_step_orders_are_bit_identical(api, prec, lf, dlf):
             m.step(advect=True, source=False)
             assert m.gfast_valid == (mode == "compact")
             m.step(advect=True, source=True)
-            assert not m.gfast_valid
+            assert m.gfast_valid == (mode == "compact")      # IMPLSCH left the compact copy of its result
         torch.cuda.synchronize()
         res[mode] = (m.fl1.cpu().numpy().copy(), m.mij.cpu().numpy().copy())
         m.ctx.close()

@@ -434,15 +434,21 @@ class Wamintgr:
         self.ctx.set_fastwave_copy(self.g1 if on else None)
         return on
 
-    def implsch(self) -> None:
+    def implsch(self, wam2nemo=None) -> None:
+        """(Whoever writes FL1 by another route -- a direct ctx.implsch, a tensor assignment -- resets `gfast_valid`: the compact
+        fast-wave rows then no longer describe FL1 and the next propag() extracts them again.)"""
         on = self._fast_sink()
-        self.ctx.implsch(0, self.n, self.fl1, self.wvprpt, self.ff, self.intf, self.mij, self.xllws)
+        self.ctx.implsch(0, self.n, self.fl1, self.wvprpt, self.ff, self.intf, self.mij, self.xllws, wam2nemo=wam2nemo)
+        if on:
+            self.ctx.set_fastwave_copy(None)      # the library keeps no pointer into a buffer this object may swap or free
         self.gfast_valid = on
 
     def nosource(self) -> None:
         """NO SOURCE TERM CONTRIBUTION (wamintgr.F90:152-160, LLSOURCE = F)."""
         on = self._fast_sink()
         self.ctx.nosource(0, self.n, self.fl1, self.mij, self.xllws)
+        if on:
+            self.ctx.set_fastwave_copy(None)
         self.gfast_valid = on
 
     def step(self, advect: bool = True, source: bool = True, llsource: bool = True) -> None:

@@ -213,7 +213,7 @@ def test_fortran_two_processes_on_one_gpu_match_single_domain(tmp_path, prec, lf
     for _ in range(nstep):
         m.propag()
         m.newwind()
-        m.ctx.implsch(0, m.n, m.fl1, m.wvprpt, m.ff, m.intf, m.mij, m.xllws, wam2nemo=w2n)
+        m.implsch(wam2nemo=w2n)
     torch.cuda.synchronize()
     outs = [_read_out(o, m.npdt, nproma, nc, cfg.nang, cfg.nfre, n) for o, nc, n in meta]
     n = g.nsea

@@ -1379,6 +1379,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         V4SYNC();
         // ---- stage 3: the DIA products of the two mirror images (snonlin.F90:264-306)
         const V2<T> FCEN = FTEMP * FIJ;
+        const V2<T> FCD1 = DAL1 * FCEN, FCD2 = DAL2 * FCEN;   // shared by the two mirror images
         T e1 = T(0), e2 = T(0), e3 = T(0), e4 = T(0);
         // (the always-true test splits the basic block: scheduled as one block, the eight unrolled interactions need 340 VGPRs)
         // The two mirror images go through separate staging rows (0..2 and 3..5) so that the reads of the first are in flight while
@@ -1395,8 +1396,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
             const V2<T> AD = FAD2 * FCEN;
             ADk[kh] = AD;
             DELADk[kh] = FAD1 * FTEMP;
-            const V2<T> DELAP = (FIJ - T(2) * SAM) * DAL1 * FCEN;
-            const V2<T> DELAM = (FIJ - T(2) * SAP) * DAL2 * FCEN;
+            const V2<T> DELAP = (FIJ - T(2) * SAM) * FCD1;
+            const V2<T> DELAM = (FIJ - T(2) * SAP) * FCD2;
             T* sa = kh == 0 ? st0 : st3;
             T* sm = kh == 0 ? st1 : st4;
             T* sp = kh == 0 ? st2 : st5;
@@ -1428,24 +1429,24 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
             }
           }
           V4SYNC();
-#pragma unroll
-          for (int kh = 0; kh < 2; kh++) {
-            // (one fused multiply-add per term: the reference adds the two terms of a row one after the other as well)
-            aS[c0] -= T(2) * ADk[kh];
-            aF[c0] -= T(2) * DELADk[kh];
-            aS[cm] += A2[kh] * FKLAMM1; aS[cm] += A2s[kh] * FKLAMM2;
-            aF[cm] += D2[kh] * FKLAM12; aF[cm] += D2s[kh] * FKLAM22;
-            aS[cm1] += A2[kh] * FKLAMMA; aS[cm1] += A2s[kh] * FKLAMMB;
-            aF[cm1] += D2[kh] * FKLAMA2; aF[cm1] += D2s[kh] * FKLAMB2;
-            aS[cp] += A1[kh] * FKLAMP1; aS[cp] += A1s[kh] * FKLAMP2;
-            aF[cp] += P1[kh] * FKLAP12; aF[cp] += P1s[kh] * FKLAP22;
-            if (kh == 0) {   // first contribution to the row that entered the ring (0 + x = x: no zeroing of the slot)
-              aS[cp1] = A1[kh] * FKLAMPA; aF[cp1] = P1[kh] * FKLAPA2;
-            } else {
-              aS[cp1] += A1[kh] * FKLAMPA; aF[cp1] += P1[kh] * FKLAPA2;
-            }
-            aS[cp1] += A1s[kh] * FKLAMPB;
-            aF[cp1] += P1s[kh] * FKLAPB2;
+          {
+            // the two mirror images carry the same coefficients: their products are added first, then one fused multiply-add per
+            // coefficient (the reference adds the terms of KH = 1 and KH = 2 one after the other: the same sum in another order)
+            const V2<T> ADt = ADk[0] + ADk[1], DELADt = DELADk[0] + DELADk[1];
+            const V2<T> A2t = A2[0] + A2[1], A2st = A2s[0] + A2s[1], A1t = A1[0] + A1[1], A1st = A1s[0] + A1s[1];
+            const V2<T> D2t = D2[0] + D2[1], D2st = D2s[0] + D2s[1], P1t = P1[0] + P1[1], P1st = P1s[0] + P1s[1];
+            aS[c0] -= T(2) * ADt;
+            aF[c0] -= T(2) * DELADt;
+            aS[cm] += A2t * FKLAMM1; aS[cm] += A2st * FKLAMM2;
+            aF[cm] += D2t * FKLAM12; aF[cm] += D2st * FKLAM22;
+            aS[cm1] += A2t * FKLAMMA; aS[cm1] += A2st * FKLAMMB;
+            aF[cm1] += D2t * FKLAMA2; aF[cm1] += D2st * FKLAMB2;
+            aS[cp] += A1t * FKLAMP1; aS[cp] += A1st * FKLAMP2;
+            aF[cp] += P1t * FKLAP12; aF[cp] += P1st * FKLAP22;
+            // first contribution to the row that entered the ring (0 + x = x: no zeroing of the slot)
+            aS[cp1] = A1t * FKLAMPA; aF[cp1] = P1t * FKLAPA2;
+            aS[cp1] += A1st * FKLAMPB;
+            aF[cp1] += P1st * FKLAPB2;
           }
         }
         // ---- row MC-3 (the saturation row of the next interaction) -> its staging row; row MC+3 enters the ring in the slot of row MC-5

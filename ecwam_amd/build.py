@@ -34,7 +34,8 @@ IMPLSCH_SOURCES = ("implsch.hip", "implsch4.hip", "implsch4x.hip")
 # A variant is written to libecwam_hip_<variant>.so next to the product library; ECWAM_HIP_LIB=<path> makes lib.load() use it.
 VARIANTS = {"": FAST_DIV, "exactdiv": ["-DECWAM_HIP_STRICT=0"], "strict1": ["-DECWAM_HIP_STRICT=1"], "strict2": FAST_DIV + ["-DECWAM_HIP_STRICT=2"],
             "site4": ["-DECWAM_HIP_STRICT=4"], "site8": ["-DECWAM_HIP_STRICT=8"], "site32": ["-DECWAM_HIP_STRICT=32"],
-            "strict3": ["-DECWAM_HIP_STRICT=3"], "strict7": ["-DECWAM_HIP_STRICT=3", "-ffp-contract=off"]}
+            "strict3": ["-DECWAM_HIP_STRICT=3"], "strict7": ["-DECWAM_HIP_STRICT=3", "-ffp-contract=off"],
+            "noieee": FAST_DIV + ["-mno-amdgpu-ieee", "-fno-honor-nans"]}
 
 INCLUDE = os.path.join(HERE, "..", "include", "ecwam_hip.h")
 

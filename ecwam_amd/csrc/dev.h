@@ -110,6 +110,9 @@ __device__ __forceinline__ float m_floor(float x) { return floorf(x); }
 __device__ __forceinline__ double m_floor(double x) { return floor(x); }
 __device__ __forceinline__ float m_sign(float a, float b) { return copysignf(a, b); }
 __device__ __forceinline__ double m_sign(double a, double b) { return copysign(a, b); }
+// SIGN(MIN(ABS(g), lim), g) for lim >= 0 (the limiter of implsch.F90:386-388) = g clamped to [-lim, lim]: one v_med3_f32
+__device__ __forceinline__ float m_clamp_sym(float g, float lim) { return __builtin_amdgcn_fmed3f(g, -lim, lim); }
+__device__ __forceinline__ double m_clamp_sym(double g, double lim) { return copysign(fmin(fabs(g), lim), g); }
 __device__ __forceinline__ int m_nint(float x) { return (int)lroundf(x); }
 __device__ __forceinline__ int m_nint(double x) { return (int)lround(x); }
 // ---- IMPLSCH hot-loop math: single precision goes straight to the hardware transcendental unit (v_rcp/v_sqrt/v_exp/

@@ -1287,12 +1287,15 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       V2<T> fn;
       {
         const T G0 = f_div_r(DELT * sl.x, m_max(T(1) - DELT5 * fld.x, T(1))), G1 = f_div_r(DELT * sl.y, m_max(T(1) - DELT5 * fld.y, T(1)));   // (refined: see f_div_r)
-        fn.x = m_max(f.x + m_sign(m_min(m_abs(G0), lim), G0), FLM.x);
-        fn.y = m_max(f.y + m_sign(m_min(m_abs(G1), lim), G1), FLM.y);
+        fn.x = m_max(f.x + m_clamp_sym(G0, lim), FLM.x);
+        fn.y = m_max(f.y + m_clamp_sym(G1, lim), FLM.y);
       }
-      ss.x = ss.x + DELTM * m_min(flmax - fn.x, T(0));
-      ss.y = ss.y + DELTM * m_min(flmax - fn.y, T(0));
-      fn.x = m_min(fn.x, flmax); fn.y = m_min(fn.y, flmax);
+      {
+        // MIN(FLMAX - FL1, 0) is the capped value minus the uncapped one (the same subtraction where the cap bites, an exact zero elsewhere)
+        const V2<T> fc = {m_min(fn.x, flmax), m_min(fn.y, flmax)};
+        ss = ss + DELTM * (fc - fn);
+        fn = fc;
+      }
       *reinterpret_cast<V2<T>*>(tFw + m * RS) = fn;
       const T rh = rhowg * m_min(m_max(MIJh - (T)(m + 1), T(0)), T(1));
       a_t = a_t + rh * ss;
@@ -1395,7 +1398,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
             FAD1 = FAD1 + FAD2;
             const V2<T> AD = FAD2 * FCEN;
             ADk[kh] = AD;
-            DELADk[kh] = FAD1 * FTEMP;
+            DELADk[kh] = FAD1;      // (times FTEMP below, on the sum of the two mirror images)
             const V2<T> DELAP = (FIJ - T(2) * SAM) * FCD1;
             const V2<T> DELAM = (FIJ - T(2) * SAP) * FCD2;
             T* sa = kh == 0 ? st0 : st3;
@@ -1436,7 +1439,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
             const V2<T> A2t = A2[0] + A2[1], A2st = A2s[0] + A2s[1], A1t = A1[0] + A1[1], A1st = A1s[0] + A1s[1];
             const V2<T> D2t = D2[0] + D2[1], D2st = D2s[0] + D2s[1], P1t = P1[0] + P1[1], P1st = P1s[0] + P1s[1];
             aS[c0] -= T(2) * ADt;
-            aF[c0] -= T(2) * DELADt;
+            aF[c0] -= (T(2) * FTEMP) * DELADt;
             aS[cm] += A2t * FKLAMM1; aS[cm] += A2st * FKLAMM2;
             aF[cm] += D2t * FKLAM12; aF[cm] += D2st * FKLAM22;
             aS[cm1] += A2t * FKLAMMA; aS[cm1] += A2st * FKLAMMB;

@@ -68,7 +68,8 @@ def main() -> None:
     want = [a for a in args if not a.endswith(".hip")] or ["k_implsch4IfLi36ELi3ELi1ELi3ELi8ELb0E", "k_implsch4_preIfLb0E", "k_implsch4_finIfLb0E"]
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
-        flags = B.FLAGS + (B.FAST_DIV if src in B.IMPLSCH_SOURCES else [])
+        variant = os.environ.get("ISA_VARIANT", "")      # a key of ecwam_amd.build.VARIANTS
+        flags = B.FLAGS + (B.VARIANTS[variant] if src in B.IMPLSCH_SOURCES else [])
         cmd = [B.HIPCC, *[f for f in flags if f != "-fPIC"], "-S", "--cuda-device-only", "-o", out, os.path.join(B.CSRC, src)]
         subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         text = open(out).read().split("\n")

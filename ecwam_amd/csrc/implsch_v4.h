@@ -164,9 +164,9 @@ __device__ __forceinline__ V2<T> v4_at(const T* row, const int (&sh)[2 * NSH + 1
   if constexpr ((r & 1) == 0) {
     return *reinterpret_cast<const V2<T>*>(row + sh[r / 2 + NSH]);
   } else {
-    const V2<T> a = *reinterpret_cast<const V2<T>*>(row + sh[(r - 1) / 2 + NSH]);
-    const V2<T> b = *reinterpret_cast<const V2<T>*>(row + sh[(r + 1) / 2 + NSH]);
-    return V2<T>{a.y, b.x};
+    // two 4-byte reads straight into the halves of the pair (two 8-byte reads need a v_pk_mov_b32 to assemble it: 4.4 issue cycles,
+    // the cost of a packed multiply-add)
+    return V2<T>{row[sh[(r - 1) / 2 + NSH] + 1], row[sh[(r + 1) / 2 + NSH]]};
   }
 }
 

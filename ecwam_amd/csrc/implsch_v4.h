@@ -1488,36 +1488,28 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     PHILF = r0.x; XSTRESS = r0.y;
   }
 
-  // ---- second FKMEAN / FEMEANWS, IMPHFTAIL, SETICE, STOKESDRIFT (implsch.F90:422-462); the SQRT(WAVNUM) plane was a staging row.
-  //      The Stokes-drift weights STOKFAC(M) DFIM_SIM(M) of the point go to the other plane now: read inside the row loop below
+  // ---- second FEMEANWS, IMPHFTAIL, SETICE, STOKESDRIFT (implsch.F90:422-462).  The second FKMEAN (implsch.F90:422) has no reader: its
+  //      five means are locals of IMPLSCH that nothing uses after it (WNFLUXES ran before it on the means of the old spectrum, MIJ is
+  //      not recomputed); FEMEANWS of the new spectrum is read by the LWFLUX block only (implsch.F90:435-445).
+  //      The Stokes-drift weights STOKFAC(M) DFIM_SIM(M) of the point go to the LOG plane now: read inside the row loop below
   //      they were one exposed global-memory round trip per frequency.
 #pragma unroll
   for (int q = 0; q < NS; q++) {
     const int m = q * G + j;
-    L.sq[m] = m_sqrt(L.fac4[m * 4 + Q4_WAVNUM]);
     L.zcn[m] = (m < tb.NFRE_ODD) ? stkw[q] * stkd[q] : T(0);
     if constexpr (JAN) L.fac4[m * 4 + Q4_BSC] = L.fac4[m * 4 + Q4_WAVNUM] * (T(1) / tb.ZPI) * xk2r[q];
   }
   WSYNC();
-  T EMEANWS;
-  {  // FKMEAN and FEMEANWS in one pass over the rows (fkmean.F90:94-150, femeanws.F90:84-123)
-    V2<T> s0 = z2, s1 = z2, s2 = z2, we = z2, wl = z2;   // (EM, FM), (F1, AK), (XK, last row), windsea (EM, FM), windsea last row
-    T tlast = T(0);
+  T EMEANWS = T(0);
+  if (tb.LWFLUX) {  // femeanws.F90:84-123 on the new spectrum, before the tail is replaced
+    V2<T> we = z2, wl = z2;   // windsea (EM, FM), windsea part of the last row
     for (int m = 0; m < NFRE; m++) {
       const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
-      const T t = f.x + f.y;
       const T* row = tb.SINROW[m];
-      const T dfm = row[1], dfo = row[5], sqm = L.sq[m];
-      s0 = s0 + V2<T>{dfm, dfo} * t;
-      s1 = s1 + V2<T>{row[6], fs_div<32>(dfm, sqm)} * t;
-      s2.x = s2.x + (sqm * dfm) * t;
-      tlast = t;
       const V2<T> x = {((xm0 >> m) & 1ull) ? f.x : T(0), ((xm1 >> m) & 1ull) ? f.y : T(0)};
-      we = we + V2<T>{dfm, dfo} * (x.x + x.y);
+      we = we + V2<T>{row[1], row[5]} * (x.x + x.y);
       wl = x;
     }
-    s2.y = tlast;
-    fkmean_finish(s0, s1, s2, EMEAN, FMEAN, F1MEAN, AKMEAN, XKMEAN);
     femws_finish(we, wl, FMEANWS, EMEANWS);
   }
   V4_PHASE_EXIT(208);

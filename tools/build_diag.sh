@@ -6,4 +6,4 @@ hipcc $F -c ../csrc/capi.hip -o /tmp/capi_diag.o &
 hipcc $F -fno-hip-fp32-correctly-rounded-divide-sqrt -c ../csrc/implsch4.hip -o /tmp/implsch4_diag.o &
 hipcc $F -c ../csrc/propag.hip -o /tmp/propag_diag.o &
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -o libecwam_hip_diag.so /tmp/capi_diag.o /tmp/propag_diag.o implsch.o /tmp/implsch4_diag.o outbs.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o libecwam_hip_diag.so /tmp/capi_diag.o /tmp/propag_diag.o implsch.o /tmp/implsch4_diag.o implsch4x.o outbs.o

@@ -329,7 +329,7 @@ def main() -> None:
         # instruction), 2.6 cycles per wave64 VALU instruction with >= 2 waves per SIMD as measured by tools/ubench_valu.hip
         # (profiles/r02_ubench_valu.txt; the guide's figure is 2, a wave alone issues one per 5.3 cycles).  The counters of the kernel
         # itself say 4.2 cycles of VALU activity per instruction (its mix is two thirds packed fp32 at 4.4 cycles): the VALU of a SIMD is
-        # busy 76 % of the time, which is the headroom that is left -- valu_busy_fraction_pmc is the figure to read.
+        # busy 74 % of the time, which is the headroom that is left -- valu_busy_fraction_pmc is the figure to read.
         valu = None
         pf = os.path.join(prof, "r03_implsch_pmc.json")
         if default_wl and os.path.exists(pf):

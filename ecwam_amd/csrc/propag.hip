@@ -376,9 +376,10 @@ template <typename T> struct VecIO<T, 1> {
   static __device__ __forceinline__ void st(T* p, const T* o) { p[0] = o[0]; }
   static __device__ __forceinline__ void st_stream(T* p, const T* o) { __builtin_nontemporal_store(o[0], p); }
 };
-// (single precision without obstructions -- the benchmark's build -- needs its four waves per SIMD to hide the gathers' latency: 128 VGPRs)
+// (single precision without obstructions -- the benchmark's build -- needs its four waves per SIMD to hide the gathers' latency: it
+// compiles to 128 VGPRs as it is; pinned to four waves with amdgpu_waves_per_eu the 2-D tile order lost a quarter of its speed)
 template <typename T, int VW, bool OBS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && !OBS) ? 4 : 1))) k_propags2_otf(const DevTab<T>* __restrict__ tab, const T* __restrict__ f1_rows, T* __restrict__ f3,
+__global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restrict__ tab, const T* __restrict__ f1_rows, T* __restrict__ f3,
                                                       int n_geom, int ngy, T delpro, const int* __restrict__ kxlt,
                                                       const T* __restrict__ zdello, T xdella, const T* __restrict__ cosph,
                                                       const T* __restrict__ sinph, const int* __restrict__ klon,

@@ -466,6 +466,13 @@ int ecwam_hip_propags2_otf_fast(ecwam_hip_ctx* c, const void* f1, void* f3, int 
     return fail("ecwam_hip_propags2_otf_fast: a compact output buffer must hold every advected frequency and excludes a second compact copy");
   if (gin && (in_nfre != 0 && in_nfre != c->NFRE)) return fail("ecwam_hip_propags2_otf_fast: the compact fast-wave input goes with full input rows");
   if (gin && (gin_nfre < 1 || gin_nfre > c->NFRE || gin == f3 || gin == gout)) return fail("ecwam_hip_propags2_otf_fast: bad compact input buffer");
+  {
+    // every compact row format is read and written with 16-byte accesses along the frequencies
+    const int vec = 16 / c->real_bytes;
+    if ((gin && (gin_nfre % vec != 0 || ((uintptr_t)gin % 16) != 0)) || (out_nfre != c->NFRE && (out_nfre % vec != 0 || ((uintptr_t)f3 % 16) != 0)) ||
+        (in_nfre != 0 && in_nfre != c->NFRE && (in_nfre % vec != 0 || ((uintptr_t)f1 % 16) != 0)))
+      return fail("ecwam_hip_propags2_otf_fast: compact rows must be 16-byte aligned and hold a multiple of 16 bytes per direction");
+  }
   // with a processing order kijs..kijl index its entries (entries < 0 are padding and skipped: the order may be longer than n)
   if (kijl < kijs || kijs < 0 || (!order && kijl > n) || nd3s < 1 || nd3e > c->NFRE_RED || nd3e < nd3s - 1 || ifrelfmax < 0 || ifrelfmax > c->NFRE_RED)
     return fail("ecwam_hip_propags2_otf: bad range");

@@ -323,3 +323,32 @@ def test_reference_length_run_with_changing_winds(api, prec):
     assert np.percentile(rel, 99) < (1e-11 if prec == "dp" else 3e-6)
     assert abs(hs.mean() - 4 * np.sqrt(1e-12)) > 0.1 and hs.max() > 1.0
     m.ctx.close()
+
+
+def test_compact_row_formats_are_validated_before_any_launch(api):
+    """The compact fast-wave rows are read and written with 16-byte accesses: a width that is not a multiple of 16 bytes per direction, a
+    compact input next to a compact second input, or a compact output with a second compact copy is refused by the entry point (an error
+    code and a message, no kernel launched) instead of faulting on the device."""
+    from ecwam_amd import grid as G
+    from ecwam_amd.wamintgr import Wamintgr
+
+    cfg = Config(nang=36, nfre=36, nfre_red=29, idelpro=450, idelt=900)
+    g = G.build_grid(12)
+    m = Wamintgr(cfg, g, "sp", ifrelfmax=5, delpro_lf=225.0)
+    m.init_synthetic(seed=3)
+    z = dict(dtype=m.fl1.dtype, device=m.fl1.device)
+    bad = torch.zeros((m.nrows, 36, 6), **z)      # 24 bytes per direction
+    call = lambda **kw: m.ctx.propags2_otf(kw.pop("f1", m.fl1), kw.pop("f3", m.fl3), m.gd, m.cgroup_ext, 450.0, 0, m.n, 1, 29, ifrelfmax=5, delpro_lf=225.0, **kw)
+    with pytest.raises(api.EcwamHipError, match="16"):
+        call(gin=bad)
+    with pytest.raises(api.EcwamHipError, match="16"):
+        call(gout=bad)
+    with pytest.raises(api.EcwamHipError):
+        m.ctx.propags2_otf(bad, m.g2, m.gd, m.cgroup_ext, 225.0, 0, m.n, 1, 5)      # compact input of a bad width
+    with pytest.raises(api.EcwamHipError):
+        m.ctx.propags2_otf(m.g1, m.g2, m.gd, m.cgroup_ext, 225.0, 0, m.n, 1, 5, gin=m.g1)      # compact input rows with a second compact input
+    with pytest.raises(api.EcwamHipError):
+        m.ctx.propags2_otf(m.g1, m.g2, m.gd, m.cgroup_ext, 225.0, 0, m.n, 1, 5, gout=m.g1)     # compact output with a second compact copy
+    call(gin=m.g1, gout=m.g2)      # the product's own call shape still goes through
+    torch.cuda.synchronize()
+    m.ctx.close()

@@ -1305,8 +1305,24 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     };
     if constexpr (!JAN) *reinterpret_cast<V2<T>*>(st4 + L.own) = fR[5];   // row MC-4 of the first interaction
     V4SYNC();
+    // Rows above the cut-off MIJ need no source terms: IMPHFTAIL replaces them by the tail of row MIJ (imphftail.F90:77-88), their flux
+    // weights RHOWGDFTH are zero (frcutindex.F90:100-107), and the only other reader of the updated rows before the tail goes in --
+    // FEMEANWS of implsch.F90:427 -- feeds nothing but the LWFLUX block (:435-445).  Without LWFLUX the sweep therefore ends with the
+    // highest cut-off of the wave's points: interaction MC adds to the rows MC-4 .. MC+3, so the last one needed is MIJ + 4, and the last
+    // row updated is row MIJ.  (Exact: the same bits in every output.  On sea states whose cut-off lies in the middle of the frequency
+    // range that is a third of the interactions; under sea ice and in light winds MIJ = NFRE and nothing is skipped.)
+    int mijmax = 0;
+#pragma unroll
+    for (int q = 0; q < PP; q++) {
+      const int mq = __builtin_amdgcn_readlane(MIJ, G == 18 ? 16 * q : q * G);
+      mijmax = mq > mijmax ? mq : mijmax;
+    }
+    const bool whole = tb.LWFLUX != 0;
+    const int UPD_LIM = whole ? NFRE : mijmax;                                      // rows m < UPD_LIM (0-based) are updated
+    const int DIA_LIM = whole ? MLST : (mijmax + 4 < MLST ? mijmax + 4 : MLST);     // interactions MC <= DIA_LIM contribute to them
+    const int MC_END = whole ? MLST : (mijmax + 5 < MLST ? mijmax + 5 : MLST);      // row MIJ is updated at the top of interaction MIJ + 5
     int MCb = 0;
-    for (; MCb < MLST; MCb += 8) {
+    for (; MCb < MC_END; MCb += 8) {
 #pragma unroll
       for (int jj = 0; jj < 8; jj++) {
         const int MC = MCb + 1 + jj;
@@ -1337,7 +1353,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         const T FKLAMA2 = cs[12], FKLAMB2 = cs[13], FKLAM12 = cs[14], FKLAM22 = cs[15];
         const T FTAIL = cg[31];   // the tail factor RNLCOEF(1), or 1 between MFR1STFR and MFRLSTFR where the reference skips it (x 1 is exact)
         // ---- meanwhile: the row the previous interaction completed
-        if (m - 1 >= 0 && m - 1 < NFRE) update_row(m - 1, aS[(jj + 4) & 7], aF[(jj + 4) & 7], wiq[(jj + 3) & 3], cg[28], cg[29], cg[30], cg[11]);
+        if (m - 1 >= 0 && m - 1 < UPD_LIM) update_row(m - 1, aS[(jj + 4) & 7], aF[(jj + 4) & 7], wiq[(jj + 3) & 3], cg[28], cg[29], cg[30], cg[11]);
         // the dissipation coefficient of row m (sdissip_ard.F90:117-314) from the saturation spectrum and the maximum the previous
         // interaction left in flight
         if constexpr (JAN) {   // SDISSIP_JAN: the rate of row m sits in the saturation slot of the factor table
@@ -1384,10 +1400,11 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         const V2<T> FCEN = FTEMP * FIJ;
         const V2<T> FCD1 = DAL1 * FCEN, FCD2 = DAL2 * FCEN;   // shared by the two mirror images
         T e1 = T(0), e2 = T(0), e3 = T(0), e4 = T(0);
-        // (the always-true test splits the basic block: scheduled as one block, the eight unrolled interactions need 340 VGPRs)
+        // (the test -- true for every interaction when nothing is cut off -- also splits the basic block: scheduled as one block, the eight
+        // unrolled interactions need 340 VGPRs)
         // The two mirror images go through separate staging rows (0..2 and 3..5) so that the reads of the first are in flight while
         // the products of the second are formed, and the reads of the second while the increments of the first are added.
-        if (MC <= MLST) {
+        if (MC <= DIA_LIM) {
           V2<T> ADk[2], DELADk[2];
           V2<T> A2[2], A2s[2], A1[2], A1s[2], D2[2], D2s[2], P1[2], P1s[2];
 #pragma unroll
@@ -1460,7 +1477,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       }
     }
     // the row the last interaction completed (MCb is a multiple of 8 here: static ring slots)
-    if (MCb - 5 >= 0 && MCb - 5 < NFRE)
+    if (MCb - 5 >= 0 && MCb - 5 < UPD_LIM)
       update_row(MCb - 5, aS[4], aF[4], wiq[3], lane_get(L.rCOFRM4, MCb - 5), lane_get(L.rFLMAX, MCb - 5), lane_get(L.rRHOWG, MCb - 5), lane_get(L.rZPIFR, MCb - 5));
   }
   V4SYNC();

@@ -17,6 +17,7 @@ import pytest
 
 import harness as H
 from ecwam_amd.tables import Config, Tables
+from ecwam_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
 
@@ -1079,3 +1080,36 @@ def test_no_source_branches_of_wamintgr(api, prec):
             want[inside] = torch.clamp(want[inside], min=float(t.EPSMIN))
         assert torch.equal(fl, want)
     ctx.close()
+
+
+@pytest.mark.parametrize("prec,nang,nred,flags", [("sp", 36, 36, {}), ("dp", 36, 29, {}), ("sp", 24, 29, dict(llgcbz0=True, llnormagam=True)),
+                                                  ("sp", 12, 25, dict(iphys=0)), ("dp", 24, 29, dict(isnonlin=1))])
+def test_sweep_cut_at_the_cutoff_frequency_is_exact(api, prec, nang, nred, flags):
+    """Without LWFLUX nothing reads the source terms of the rows above MIJ (IMPHFTAIL replaces the rows, RHOWGDFTH is zero there), and
+    k_implsch4 ends its sweep of the interaction frequencies with the highest cut-off of a wavefront's points; with LWFLUX (FEMEANWS of
+    the new spectrum is an output then) it runs all of them.  On a state of long swell under strong winds -- cut-offs from the lower third
+    of the frequency range upwards -- both give the same bits in every output they share, and match the oracle as everywhere else."""
+    res = {}
+    for lw in (False, True):
+        cfg = Config(nang=nang, nfre=36, nfre_red=nred, lwflux=lw, **flags)
+        n = 768
+        case = H.make_point_case(n, cfg, prec, seed=33)
+        rng = np.random.default_rng(7)
+        fp = rng.uniform(0.045, 0.09, n)
+        case["FL1"] = syn.jonswap_spectra(case["tables"].FR, case["tables"].TH, fp, rng.uniform(0, 2 * np.pi, n), H.np_dtype(prec))
+        case["params"]["WSWAVE"] = rng.uniform(12.0, 35.0, n)
+        case["params"]["CICOVER"] = np.zeros(n)
+        case["FF"] = syn.forcing(case["params"], slice(0, n), case["tables"], H.np_dtype(prec))
+        ctx = api.HipContext(case["tables"])
+        got = H.gpu_implsch(case, ctx)
+        assert ctx.implsch_generation_used() == 4
+        ctx.close()
+        res[lw] = got
+        if not lw:
+            ref = H.oracle_implsch(case, _oracle(cfg, prec))
+            _assert_implsch_stats(H.compare_implsch(ref, got, case["tables"]), n, prec)
+    a, b = res[False], res[True]
+    assert a["MIJ"].min() <= 16 and (a["MIJ"] < 30).mean() > 0.5, (a["MIJ"].min(), a["MIJ"].mean())      # the cut does happen
+    for k in ("FL1", "XLLWS", "MIJ", "FF"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["INTF"][:, 2:], b["INTF"][:, 2:])      # WSEMEAN / WSFMEAN (slots 0, 1) are what LWFLUX adds

@@ -171,6 +171,11 @@ def main() -> None:
         raise SystemExit("--gpus must be >= 1")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a, sys.argv[1:])          # does not return
+    # stdout carries ONE line, the JSON line of rank 0: whatever the libraries print there on any rank (Gloo announces its connections on
+    # stdout) goes to stderr instead -- file descriptor 1 is pointed at stderr, the real stdout is kept for the result
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -364,7 +369,7 @@ def main() -> None:
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.nang, a.nfre, a.prec)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=result_out, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

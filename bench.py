@@ -144,6 +144,9 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed windows of --steps steps each, every one bracketed by barrier + synchronize; the MEDIAN window is reported "
+                         "(SURVEY.md 8d: median of 5), min / max next to it")
     ap.add_argument("--grid", type=int, default=0, help="octahedral resolution (default 320*sqrt(gpus))")
     ap.add_argument("--prec", default="sp", choices=["sp", "dp"])
     ap.add_argument("--nang", type=int, default=36)
@@ -160,6 +163,11 @@ def main() -> None:
                     help="halo exchange (N > 1): the library's own MPEXCHNG (ecwam_hip_halo_start/_finish: grouped RCCL send/recv on the "
                          "library's stream -- what WAMINTGR_HIP calls; the default), torch.distributed P2P on packed buffers (RCCL), "
                          "or host staged through the CPU backend")
+    ap.add_argument("--strict-halo", dest="strict_halo", action="store_true", default=None,
+                    help="N > 1: a halo transport that cannot be set up or fails its self-check on any rank ends the run with a non-zero exit "
+                         "instead of falling back to the host-staged transport (the default without --share-gpu: a scaling run must never "
+                         "publish a host-staged curve under the name of the RCCL one)")
+    ap.add_argument("--no-strict-halo", dest="strict_halo", action="store_false", help="allow the host-staged fallback (config.halo says so)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal of the N>1 code on ONE GPU: every rank uses device 0, process group on gloo, host-staged halo")
     ap.add_argument("--dump", default="", help="write the owned spectra of every rank to <path>.<rank>.npy after the last step")
@@ -167,8 +175,10 @@ def main() -> None:
                     help="refraction: 0 none (BASELINE configurations), 1 depth, 2 currents, 3 both (synthetic current field)")
     a = ap.parse_args()
 
-    if a.gpus < 1:
-        raise SystemExit("--gpus must be >= 1")
+    if a.gpus < 1 or a.steps < 1 or a.repeats < 1:
+        raise SystemExit("--gpus, --steps and --repeats must be >= 1")
+    if a.strict_halo is None:
+        a.strict_halo = not a.share_gpu
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a, sys.argv[1:])          # does not return
     # stdout carries ONE line, the JSON line of rank 0: whatever the libraries print there on any rank (Gloo announces its connections on
@@ -184,8 +194,10 @@ def main() -> None:
     from ecwam_amd import grid as G
     from ecwam_amd.tables import Config
     from ecwam_amd.wamintgr import Wamintgr
+    # test hook (tests/test_gpu_multirank.py): the asked transport fails its set-up without RCCL being touched
+    force_fail = bool(os.environ.get("ECWAM_BENCH_FAIL_HALO_SETUP"))
     if a.share_gpu:
-        local_rank, a.halo = 0, "host"
+        local_rank, a.halo = 0, ("lib" if force_fail else "host")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -245,12 +257,17 @@ def main() -> None:
         host_halo = m.halo
         if a.halo != "host":
             try:
+                if force_fail:
+                    raise RuntimeError("ECWAM_BENCH_FAIL_HALO_SETUP is set (test hook)")
                 m.halo = HaloExchange(m.dom, m.dev, m.ctx, transport=a.halo)      # "lib": ncclCommInitRank inside the library
                 ok = True
             except Exception as e:          # noqa: BLE001
                 print(f"[bench] rank {rank}: halo transport '{a.halo}' could not be set up: {e!r}", file=sys.stderr, flush=True)
                 ok = False
             if not all_ok(ok) or not all_ok(halo_ok()):
+                if a.strict_halo:
+                    raise SystemExit(f"bench.py: halo transport '{a.halo}' failed its set-up or its self-check on at least one rank "
+                                     f"(--strict-halo; --no-strict-halo falls back to the host-staged transport)")
                 m.halo = host_halo
                 m.ctx.halo_setup(m.dom)
                 halo_used = f"host (fallback: '{a.halo}' failed its set-up or self-check)"
@@ -273,27 +290,47 @@ def main() -> None:
 
     for _ in range(a.warmup):
         step_untimed()
-    sync()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(a.steps)]
-    t0 = time.perf_counter()
-    for s in range(a.steps):
-        e = ev[s]
-        e[0].record()
-        for _ in range(a.adv_per_source):
-            m.propag()        # halo exchange (N > 1) + PROPAGS2 (+ fast-wave sub-steps)
-        e[1].record()
-        m.newwind()
-        e[2].record()
-        m.implsch()
-        e[3].record()
-    sync()
-    el = time.perf_counter() - t0
-    t_prop = sum(e[0].elapsed_time(e[1]) for e in ev) / a.steps
-    t_impl = sum(e[2].elapsed_time(e[3]) for e in ev) / a.steps
+    # a.repeats windows of a.steps steps, each bracketed by barrier + synchronize on both sides; a window's time is the MAX over ranks,
+    # the reported one the median window.  Kernel times: HIP events on the launch stream around PROPAG_WAM and IMPLSCH of every step.
+    m.halo_events = [] if world > 1 else None      # N > 1: the compute stream's wait at the end of every exchange (Wamintgr.propag)
+    windows, kt = [], []
+    for _ in range(a.repeats):
+        sync()
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(a.steps)]
+        if m.halo_events is not None:
+            m.halo_events.clear()
+        t0 = time.perf_counter()
+        for s in range(a.steps):
+            e = ev[s]
+            e[0].record()
+            for _ in range(a.adv_per_source):
+                m.propag()        # halo exchange (N > 1) + PROPAGS2 (+ fast-wave sub-steps)
+            e[1].record()
+            m.newwind()
+            e[2].record()
+            m.implsch()
+            e[3].record()
+        sync()
+        windows.append(time.perf_counter() - t0)
+        hw = sum(x.elapsed_time(y) for x, y in m.halo_events) / a.steps if m.halo_events else 0.0
+        kt.append((sum(e[0].elapsed_time(e[1]) for e in ev) / a.steps, sum(e[2].elapsed_time(e[3]) for e in ev) / a.steps, hw))
+    m.halo_events = None
+    per_rank = None
     if dist is not None:
-        tt = torch.tensor([el, t_prop, t_impl], dtype=torch.float64, device="cpu" if a.share_gpu else "cuda")
+        dev = "cpu" if a.share_gpu else "cuda"
+        tt = torch.tensor(windows, dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el, t_prop, t_impl = (float(x) for x in tt.cpu())
+        windows = [float(x) for x in tt.cpu()]
+    order_w = sorted(range(a.repeats), key=lambda i: windows[i])
+    imed = order_w[(a.repeats - 1) // 2]        # the median window (the lower one of an even count)
+    el = windows[imed]
+    t_prop, t_impl, t_wait = kt[imed]
+    if dist is not None:
+        mine = torch.tensor([t_prop, t_impl, t_wait], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(v) for v in x.cpu()] for x in allr]
+        t_prop, t_impl = max(r_[0] for r_ in per_rank), max(r_[1] for r_ in per_rank)
     if a.dump:
         np.save(f"{a.dump}.{rank}.npy", m.fl1[: m.n].cpu().numpy())
     swh = m.swh()
@@ -349,6 +386,8 @@ def main() -> None:
             "metric": f"grid-point spectral steps/sec (whole node) at O{ng}, {a.nang}dir x {a.nfre}freq",
             "value": grid.nsea * a.steps / el, "unit": "grid-point spectral steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "repeats": a.repeats, "window_ms": {"median": el * 1e3, "min": min(windows) * 1e3, "max": max(windows) * 1e3,
+                                                "all": [w_ * 1e3 for w_ in windows]},
             "vs_baseline": None, "dtype": "f32" if a.prec == "sp" else "f64", "data": "synthetic",
             "config": {"workload": f"O{ng} all-ocean octahedral grid, {grid.nsea} sea points, {a.nang} dir x {a.nfre} freq "
                                    f"(NFRE_RED={cfg.nfre_red}), full WAMINTGR step = PROPAGS2 advection + NEWWIND + IMPLSCH, "
@@ -358,7 +397,19 @@ def main() -> None:
                                    + (f", fast waves M<={a.ifrelfmax} in two sub-steps" if a.ifrelfmax else ""),
                        "points_per_gpu": m.n, "halo_points": m.dom.nh, "parallelism": f"sea-point block x{world}",
                        "halo": halo_used if world > 1 else None, "halo_rccl_ranks": halo_ranks,
+                       "strict_halo": bool(a.strict_halo) if world > 1 else None,
+                       "grid_note": (f"O{ng} is not a BASELINE.json grid: weak scaling holds the points per GPU of O320 at N = {world}"
+                                     if ng not in (48, 320, 640, 1280) else None),
+                       "time_step_note": f"IDELT = IDELPRO = {dt} s: the reference's O320 yml runs 900 s with 24 directions "
+                                         "(tests/etopo1_oper_an_fc_O320.yml:6-9); with 36 directions 900 s fails the CTU stability check "
+                                         "near the poles of the all-ocean grid (ctuw.F90:637), 450 s passes; scaled with the grid spacing "
+                                         "beyond O320.  The work per step does not depend on the time step",
                        "ranks": world, "share_gpu": bool(a.share_gpu)},
+            # N > 1, per rank [PROPAG_WAM ms, IMPLSCH ms, of PROPAG_WAM: the compute stream waiting for the halo exchange at halo_finish]:
+            # the exchange is posted first and the rows that read no halo row (decomp.interior) are advected while it runs, so the wait
+            # is what the overlap did not hide
+            "propag_split_per_rank": ([{"rank": i, "propag_ms": r_[0], "implsch_ms": r_[1], "halo_wait_ms": r_[2], "stencil_ms": r_[0] - r_[2]}
+                                       for i, r_ in enumerate(per_rank)] if per_rank else None),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "committed_pmc: profiles/r03_hbm_traffic_pmc.json (rocprofv3 --pmc passes of this command on another run; not measured live)" if traffic is not None else None},

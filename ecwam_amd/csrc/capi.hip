@@ -40,12 +40,22 @@ struct ecwam_hip_ctx {
   std::vector<int> peer, send_cnt, send_off, recv_dst0, recv_cnt;
   int n_send = 0, n_recv = 0;
   int* d_send_idx = nullptr;
-  void* d_send_buf = nullptr;
-  size_t send_buf_bytes = 0;
+  // one send buffer + event pair per row length in use (full rows, compact fast-wave rows, PROENVHALO rows): two exchanges of
+  // different rows may be outstanding at once (propag_wam.F90:166,293) without the second pack waiting for the first one's sends
+  struct HaloSlot {
+    int rowlen = 0;
+    void* buf = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ev_packed = nullptr, ev_done = nullptr;
+    bool used = false;      // an exchange has been posted from this buffer: a later pack waits for its sends (ev_done)
+    bool pending = false;   // ... and no ecwam_hip_halo_finish has made a stream wait for it yet
+    unsigned long long age = 0;
+  };
+  static constexpr int NSLOT = 4;
+  HaloSlot slot[NSLOT];
+  unsigned long long slot_clock = 0;
   ncclComm_t comm = nullptr;
   hipStream_t comm_stream = nullptr;
-  hipEvent_t ev_packed = nullptr, ev_done = nullptr;
-  bool halo_inflight = false;   // an exchange has been posted whose ev_done no later halo_start has waited for
   ecwam_hip_params p;
   void* fast_g = nullptr;     // ecwam_hip_set_fastwave_copy: compact rows [ij][K][fast_gk] IMPLSCH / NOSOURCE also leave the new fast waves in
   int fast_gk = 0;
@@ -308,11 +318,14 @@ static int rccl_load() {
 static void halo_release(ecwam_hip_ctx* c) {
   if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
   if (c->d_send_idx) (void)hipFree(c->d_send_idx);
-  if (c->d_send_buf) (void)hipFree(c->d_send_buf);
-  if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
-  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  for (auto& q : c->slot) {
+    if (q.buf) (void)hipFree(q.buf);
+    if (q.ev_packed) (void)hipEventDestroy(q.ev_packed);
+    if (q.ev_done) (void)hipEventDestroy(q.ev_done);
+    q = ecwam_hip_ctx::HaloSlot();
+  }
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
-  c->comm = nullptr; c->d_send_idx = nullptr; c->d_send_buf = nullptr; c->ev_packed = c->ev_done = nullptr; c->comm_stream = nullptr;
+  c->comm = nullptr; c->d_send_idx = nullptr; c->comm_stream = nullptr;
 }
 
 // the first fast_gk frequencies of rows [kijs, kijl) of FL1 -> the compact rows of ecwam_hip_set_fastwave_copy (the kernels that do not
@@ -654,7 +667,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
            rc = launch_implsch<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s));
   if (rc) return fail("ecwam_hip_implsch: unsupported spectral size for the LDS tiling");
   HIPCHK(hipGetLastError());
-  if (c->fast_g) fastwave_copy(c, fl1, kijs, kijl, s);   // (k_implsch4 writes the compact rows from its tile)
+  if (c->fast_g) { fastwave_copy(c, fl1, kijs, kijl, s); HIPCHK(hipGetLastError()); }   // (k_implsch4 writes the compact rows from its tile)
   return 0;
 }
 
@@ -817,11 +830,7 @@ int ecwam_hip_halo_setup(ecwam_hip_ctx* c, int rank, int nranks, int npeers, con
     HIPCHK(hipMalloc(&c->d_send_idx, (size_t)c->n_send * sizeof(int)));
     HIPCHK(hipMemcpy(c->d_send_idx, send_idx, (size_t)c->n_send * sizeof(int), hipMemcpyHostToDevice));
   }
-  if (!c->comm_stream) {
-    HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
-  }
+  if (!c->comm_stream) HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
   return 0;
 }
 
@@ -862,13 +871,16 @@ int ecwam_hip_comm_unique_id(void* id128) {
 
 int ecwam_hip_comm_init(ecwam_hip_ctx* c, const void* id128) {
   if (!c || !id128) return fail("ecwam_hip_comm_init: null argument");
-  if (c->peer.empty()) return 0;   // nothing to exchange (one rank without a self exchange): no communicator
+  // ncclCommInitRank is collective over all nranks: a rank of a multi-rank run joins even when it has no halo peer (a band that is an
+  // enclosed basin), or the others would wait for it; only the single rank without a self exchange needs no communicator
+  if (c->nranks < 2 && c->peer.empty()) return 0;
   if (rccl_load()) return 1;
   HIPCHK(hipSetDevice(c->device));
   if (c->comm) {   // a second initialisation replaces the communicator: let the posted exchange finish, then release the old one
     if (c->comm_stream) HIPCHK(hipStreamSynchronize(c->comm_stream));
     (void)g_rccl.CommDestroy(c->comm);
-    c->comm = nullptr; c->halo_inflight = false;
+    c->comm = nullptr;
+    for (auto& q : c->slot) q.used = q.pending = false;
   }
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
@@ -884,17 +896,34 @@ int ecwam_hip_comm_count(ecwam_hip_ctx* c, int* nranks) {
   return 0;
 }
 
-static int halo_pack(ecwam_hip_ctx* c, const void* fl, int rowlen, hipStream_t s) {
+// the send buffer for rows of `rowlen` reals: the slot already serving that length, else a free one, else the least recently used
+// (whose outstanding sends the caller then waits for, as for any reuse)
+static ecwam_hip_ctx::HaloSlot* halo_slot(ecwam_hip_ctx* c, int rowlen) {
+  ecwam_hip_ctx::HaloSlot* q = nullptr;
+  for (auto& x : c->slot) if (x.rowlen == rowlen) { q = &x; break; }
+  if (!q) for (auto& x : c->slot) if (x.rowlen == 0) { q = &x; break; }
+  if (!q) { q = &c->slot[0]; for (auto& x : c->slot) if (x.age < q->age) q = &x; }
+  q->rowlen = rowlen; q->age = ++c->slot_clock;
+  return q;
+}
+
+static int halo_pack(ecwam_hip_ctx* c, ecwam_hip_ctx::HaloSlot* q, const void* fl, int rowlen, hipStream_t s) {
   const size_t need = (size_t)c->n_send * rowlen * c->real_bytes;
-  if (need > c->send_buf_bytes) {
-    if (c->d_send_buf) HIPCHK(hipFree(c->d_send_buf));
-    c->d_send_buf = nullptr; c->send_buf_bytes = 0;
-    HIPCHK(hipMalloc(&c->d_send_buf, need));
-    c->send_buf_bytes = need;
+  if (!q->ev_packed) {
+    HIPCHK(hipEventCreateWithFlags(&q->ev_packed, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&q->ev_done, hipEventDisableTiming));
+  }
+  // the buffer is reused: the sends of the exchange posted from it before must have read it before this pack overwrites it
+  if (q->used) HIPCHK(hipStreamWaitEvent(s, q->ev_done, 0));
+  if (need > q->bytes) {
+    if (q->buf) HIPCHK(hipFree(q->buf));      // (hipFree waits for the device)
+    q->buf = nullptr; q->bytes = 0;
+    HIPCHK(hipMalloc(&q->buf, need));
+    q->bytes = need;
   }
   if (c->n_send > 0) {
-    DISPATCH(launch_pack<float>(fl, c->d_send_idx, c->n_send, rowlen, c->d_send_buf, s),
-             launch_pack<double>(fl, c->d_send_idx, c->n_send, rowlen, c->d_send_buf, s));
+    DISPATCH(launch_pack<float>(fl, c->d_send_idx, c->n_send, rowlen, q->buf, s),
+             launch_pack<double>(fl, c->d_send_idx, c->n_send, rowlen, q->buf, s));
     HIPCHK(hipGetLastError());
   }
   return 0;
@@ -907,30 +936,33 @@ int ecwam_hip_halo_start(ecwam_hip_ctx* c, void* fl, int rowlen, void* stream) {
   if (!c->comm) return fail("ecwam_hip_halo_start: no communicator (ecwam_hip_comm_init)");
   hipStream_t s = (hipStream_t)stream;
   HIPCHK(hipSetDevice(c->device));
-  // the send buffer is reused: the sends of the previous exchange must have read it before this pack overwrites it (a caller
-  // that skipped ecwam_hip_halo_finish, e.g. on an error path, would otherwise race with them)
-  if (c->halo_inflight) HIPCHK(hipStreamWaitEvent(s, c->ev_done, 0));
-  if (halo_pack(c, fl, rowlen, s)) return 1;
-  HIPCHK(hipEventRecord(c->ev_packed, s));                     // everything enqueued on `stream` so far, the pack included
-  HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
+  ecwam_hip_ctx::HaloSlot* q = halo_slot(c, rowlen);
+  if (halo_pack(c, q, fl, rowlen, s)) return 1;
+  HIPCHK(hipEventRecord(q->ev_packed, s));                     // everything enqueued on `stream` so far, the pack included
+  HIPCHK(hipStreamWaitEvent(c->comm_stream, q->ev_packed, 0));
   const size_t rb = (size_t)rowlen * c->real_bytes;
   NCCLCHK(g_rccl.GroupStart());
   for (size_t i = 0; i < c->peer.size(); i++) {
     if (c->send_cnt[i] > 0)
-      NCCLCHK(g_rccl.Send((const char*)c->d_send_buf + (size_t)c->send_off[i] * rb, (size_t)c->send_cnt[i] * rb, ncclChar, c->peer[i], c->comm, c->comm_stream));
+      NCCLCHK(g_rccl.Send((const char*)q->buf + (size_t)c->send_off[i] * rb, (size_t)c->send_cnt[i] * rb, ncclChar, c->peer[i], c->comm, c->comm_stream));
     if (c->recv_cnt[i] > 0)
       NCCLCHK(g_rccl.Recv((char*)fl + (size_t)c->recv_dst0[i] * rb, (size_t)c->recv_cnt[i] * rb, ncclChar, c->peer[i], c->comm, c->comm_stream));
   }
   NCCLCHK(g_rccl.GroupEnd());
-  HIPCHK(hipEventRecord(c->ev_done, c->comm_stream));
-  c->halo_inflight = true;
+  HIPCHK(hipEventRecord(q->ev_done, c->comm_stream));
+  q->used = q->pending = true;
   return 0;
 }
 
+// every exchange posted and not yet waited for: `stream` continues behind all of them
 int ecwam_hip_halo_finish(ecwam_hip_ctx* c, void* stream) {
   if (!c) return fail("null context");
-  if (c->peer.empty() || !c->halo_inflight) return 0;
-  HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->ev_done, 0));
+  if (c->peer.empty()) return 0;
+  for (auto& q : c->slot)
+    if (q.pending) {
+      HIPCHK(hipStreamWaitEvent((hipStream_t)stream, q.ev_done, 0));
+      q.pending = false;
+    }
   return 0;
 }
 
@@ -940,8 +972,9 @@ int ecwam_hip_halo_pack_host(ecwam_hip_ctx* c, const void* fl, int rowlen, void*
   if (!fl || !host_send || rowlen < 1) return fail("ecwam_hip_halo_pack_host: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   HIPCHK(hipSetDevice(c->device));
-  if (halo_pack(c, fl, rowlen, s)) return 1;
-  HIPCHK(hipMemcpyAsync(host_send, c->d_send_buf, (size_t)c->n_send * rowlen * c->real_bytes, hipMemcpyDeviceToHost, s));
+  ecwam_hip_ctx::HaloSlot* q = halo_slot(c, rowlen);
+  if (halo_pack(c, q, fl, rowlen, s)) return 1;
+  HIPCHK(hipMemcpyAsync(host_send, q->buf, (size_t)c->n_send * rowlen * c->real_bytes, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return 0;
 }

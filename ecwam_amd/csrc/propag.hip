@@ -492,6 +492,8 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
           T v[VW];
           IO::ld(f1 + own_in + el_in, v);
           IO::st(f3 + own + el, v);
+          // (a compact copy wider than the advected range, LFP > NFRE_RED: its last vector is carried over as well)
+          if (gout && m < gout_k) IO::st(gout + ((size_t)q[0] * NANG + k) * gout_k + m, v);
         }
         return;
       }

@@ -162,12 +162,13 @@ class Wamintgr:
         # "compact": sub-steps 1 .. NSTEP_LF-1 compact -> compact BEFORE the full pass, which reads the fast waves' last state from the
         # compact buffer and writes complete rows (round 3); "rows": the full pass first, the further sub-steps write the fast-wave slots
         # of the FL3 rows (round 2; every line of FL3 touched once more per sub-step).  Same bits.
-        self.fast_mode = "compact"
+        self._fast_mode = "compact"
         if 0 < ifrelfmax < cfg.nfre_red and weights == "otf" and not int(cfg.irefra):
             lfp = min(cfg.nfre, (ifrelfmax + 3) // 4 * 4)
             self.g1 = torch.zeros((self.nrows, NANG, lfp), **z)
             self.g2 = torch.zeros((self.nrows, NANG, lfp), **z)
         self.weights_ready = False
+        self.halo_events = None         # a list: propag() appends a (before, after) event pair around every wait for a halo exchange
         # refraction (IREFRA = 1 depth, 2 currents, 3 both): per-point THD/S0/U/V/OMDD/CURMASK instead of the reference's
         # THDD/THDC/SDOT and 21 weight arrays; PROPAGS2 rebuilds every weight on the fly
         self.irefra = int(cfg.irefra)
@@ -182,11 +183,23 @@ class Wamintgr:
             self.omosnh2kd_ext = torch.zeros((self.nrows, NFRE), **z)
             self.wavnum_ext = torch.zeros((self.nrows, NFRE), **z)
 
+    @property
+    def fast_mode(self) -> str:
+        return self._fast_mode
+
+    @fast_mode.setter
+    def fast_mode(self, mode: str) -> None:
+        if mode not in ("compact", "rows"):
+            raise ValueError("fast_mode: 'compact' or 'rows'")
+        self._fast_mode = mode
+        self.gfast_valid = False      # the rows mode uses g1 as scratch: whatever it holds no longer describes FL1
+
     # ---- synthetic initial state; identical for every decomposition
     def init_synthetic(self, seed: int = 12345, chunk: int = 65536, currents: bool | None = None, env_on_device: bool = False) -> None:
         """env_on_device (refraction on a decomposed grid): the extended DEPTH / UCUR / VCUR / OMOSNH2KD / WAVNUM / CGROUP rows are not
         assembled on the host from the global fields but by PROENVHALO on the device -- owned rows + one halo exchange (proenvhalo())."""
         g, d, t = self.grid, self.dom, self.t
+        self.gfast_valid = False      # new spectra: the compact fast-wave rows are extracted again by the next propag()
         p = syn.point_params(g.nsea, seed=seed)
         self.params = p
         ext = d.ext_global()
@@ -309,6 +322,17 @@ class Wamintgr:
         self.weights_ready = True
         return int(self.cflfail.sum().item())
 
+    def _halo_finish_timed(self, reqs) -> None:
+        """halo.finish between two events on the compute stream when the caller collects them (bench.py: what the overlap did not hide)."""
+        if self.halo_events is None:
+            self.halo.finish(reqs)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.halo.finish(reqs)
+        e1.record()
+        self.halo_events.append((e0, e1))
+
     # ---- PROPAG_WAM (propag_wam.F90:166-313), IPROPAGS = 2
     def propag(self) -> None:
         if not self.weights_ready:
@@ -348,7 +372,7 @@ class Wamintgr:
             src = self.fl1 if src is None else src
             overlap = self.dom.nranks > 1 and self.order is None
             if not overlap:
-                self.halo(src)
+                self._halo_finish_timed(self.halo.start(src))
                 for a in passes:
                     advect(*a, src=src)
                 return
@@ -356,7 +380,7 @@ class Wamintgr:
             reqs = self.halo.start(src)
             for a in passes:
                 advect(*a, rows=(ia, ib), src=src)
-            self.halo.finish(reqs)
+            self._halo_finish_timed(reqs)
             for a in passes:
                 advect(*a, rows=(0, ia), src=src)
                 advect(*a, rows=(ib, self.n), src=src)
@@ -387,6 +411,7 @@ class Wamintgr:
                     self.ctx.copy_freq_range(self.fl3, self.fl1, self.n, 1, self.ifrelfmax)
                     exchange_and_advect([(1, self.ifrelfmax, float(self.delpro_lf), False)])
         self.fl1, self.fl3 = self.fl3, self.fl1
+        self.gfast_valid = False      # (the rows mode and the stored-weight / refraction paths overwrite or bypass the compact rows)
 
     def _propag_fast_compact(self, advect_rows) -> None:
         """PROPAG_WAM with fast-wave sub-steps (propag_wam.F90:247-313) in the order that writes no frequency sub-range into full rows:
@@ -408,7 +433,7 @@ class Wamintgr:
             reqs = [self.halo.start(x) for x in exchanges] if self.dom.nranks > 1 else []
             passes(ia, ib)
             for r in reqs:
-                self.halo.finish(r)
+                self._halo_finish_timed(r)
             if overlap:
                 passes(0, ia)
                 passes(ib, self.n)
@@ -419,7 +444,7 @@ class Wamintgr:
             ga, gb = gb, ga
         # the full pass: slow waves from FL1 with IDELPRO, the fast waves' last sub-step from the compact rows with DELPRO_LF
         run(lambda k0, k1: k1 > k0 and self.ctx.propags2_otf(self.fl1, self.fl3, g, self.cgroup_ext, float(c.idelpro), k0, k1, 1, c.nfre_red, copy_rest=True,
-                                                            ifrelfmax=lfm, delpro_lf=dlf, gin=ga, gout=gb), [self.fl1, ga])
+                                                            ifrelfmax=lfm, delpro_lf=dlf, gin=ga, gout=gb), [ga, self.fl1])      # the short rows first (as WAMINTGR_HIP posts them)
         self.g1, self.g2 = gb, ga
         self.gfast_valid = True
         self.fl1, self.fl3 = self.fl3, self.fl1
@@ -437,18 +462,24 @@ class Wamintgr:
     def implsch(self, wam2nemo=None) -> None:
         """(Whoever writes FL1 by another route -- a direct ctx.implsch, a tensor assignment -- resets `gfast_valid`: the compact
         fast-wave rows then no longer describe FL1 and the next propag() extracts them again.)"""
+        self.gfast_valid = False
         on = self._fast_sink()
-        self.ctx.implsch(0, self.n, self.fl1, self.wvprpt, self.ff, self.intf, self.mij, self.xllws, wam2nemo=wam2nemo)
-        if on:
-            self.ctx.set_fastwave_copy(None)      # the library keeps no pointer into a buffer this object may swap or free
+        try:
+            self.ctx.implsch(0, self.n, self.fl1, self.wvprpt, self.ff, self.intf, self.mij, self.xllws, wam2nemo=wam2nemo)
+        finally:
+            if on:
+                self.ctx.set_fastwave_copy(None)      # the library keeps no pointer into a buffer this object may swap or free
         self.gfast_valid = on
 
     def nosource(self) -> None:
         """NO SOURCE TERM CONTRIBUTION (wamintgr.F90:152-160, LLSOURCE = F)."""
+        self.gfast_valid = False
         on = self._fast_sink()
-        self.ctx.nosource(0, self.n, self.fl1, self.mij, self.xllws)
-        if on:
-            self.ctx.set_fastwave_copy(None)
+        try:
+            self.ctx.nosource(0, self.n, self.fl1, self.mij, self.xllws)
+        finally:
+            if on:
+                self.ctx.set_fastwave_copy(None)
         self.gfast_valid = on
 
     def step(self, advect: bool = True, source: bool = True, llsource: bool = True) -> None:

@@ -100,8 +100,64 @@ for rowshape in ((12, 36), (12, 8)):
         torch.cuda.synchronize()
         assert torch.equal(got, fl[torch.from_numpy(send).long().to(ctx.device)]), (rowshape, it)
         assert float(fl[n + nh].abs().max()) == 0.0
+# two exchanges of different rows outstanding at once (compact fast-wave rows posted first, then the full rows: propag_wam.F90:166,293
+# as WAMINTGR_HIP / Wamintgr._propag_fast_compact post them): each has its own send buffer and event pair, one finish waits for both
+fa = torch.zeros((n + nh + 1, 12, 8), dtype=torch.float32, device=ctx.device)
+fb = torch.zeros((n + nh + 1, 12, 36), dtype=torch.float32, device=ctx.device)
+for it in range(3):
+    fa[:n] = torch.from_numpy(rng.uniform(0, 1, (n, 12, 8)).astype(np.float32)).to(ctx.device)
+    fb[:n] = torch.from_numpy(rng.uniform(0, 1, (n, 12, 36)).astype(np.float32)).to(ctx.device)
+    fa[n:n + nh] = -1.0; fb[n:n + nh] = -1.0
+    ctx.halo_start(fa)
+    ctx.halo_start(fb)
+    ctx.halo_finish()
+    ga, gb = fa[n:n + nh].clone(), fb[n:n + nh].clone()
+    torch.cuda.synchronize()
+    ix = torch.from_numpy(send).long().to(ctx.device)
+    assert torch.equal(ga, fa[ix]) and torch.equal(gb, fb[ix]), it
 ctx.close()
 print("loopback ok")
 """ % ROOT
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
     assert r.returncode == 0 and "loopback ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_halo_transports_agree_between_two_devices(tmp_path):
+    """Runs where two GPUs are visible (skipped on the one-GPU boxes): bench.py --gpus 2 on two devices with the library's RCCL
+    exchange (ecwam_hip_halo_start / _finish over xGMI: mpexchng.F90:141-246), with torch.distributed P2P and with the host-staged
+    transport -- the same spectra bit for bit, `halo_rccl_ranks == 2` for the library transport, and no silent fallback (--strict-halo
+    is the default without --share-gpu)."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    common = ["--grid", "48", "--steps", "3", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline", "--ifrelfmax", "5", "--adv-per-source", "2"]
+    outs = {}
+    for halo in ("lib", "torch", "host"):
+        outs[halo] = _run([sys.executable, "bench.py", "--gpus", "2", "--halo", halo, "--dump", str(tmp_path / halo)] + common, env)
+        assert outs[halo]["config"]["halo"] == halo and outs[halo]["config"]["strict_halo"] is True and outs[halo]["finite"]
+        assert len(outs[halo]["propag_split_per_rank"]) == 2
+    assert outs["lib"]["config"]["halo_rccl_ranks"] == 2
+    one = _run([sys.executable, "bench.py", "--gpus", "1", "--dump", str(tmp_path / "one")] + common, env)
+    a = np.load(str(tmp_path / "one") + ".0.npy")
+    for halo in ("lib", "torch", "host"):
+        b = np.concatenate([np.load(str(tmp_path / halo) + f".{r}.npy") for r in range(2)])
+        assert np.array_equal(a, b), halo
+
+
+def test_strict_halo_is_the_default_and_fails_loudly(tmp_path):
+    """A transport that cannot be set up must end `bench.py --gpus N` with a non-zero exit and no JSON line when --strict-halo is in force
+    (forced here through bench.py's test hook ECWAM_BENCH_FAIL_HALO_SETUP); --no-strict-halo falls back and says so."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", ECWAM_BENCH_FAIL_HALO_SETUP="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    common = ["--grid", "48", "--steps", "1", "--warmup", "0", "--repeats", "1", "--no-cpu-baseline", "--share-gpu"]
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--strict-halo"] + common, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout[-1000:] + r.stderr[-2000:]
+    assert "strict-halo" in r.stderr
+    ok = _run([sys.executable, "bench.py", "--gpus", "2", "--no-strict-halo"] + common, env)
+    assert ok["config"]["halo"].startswith("host (fallback") and ok["config"]["strict_halo"] is False

@@ -114,39 +114,46 @@ def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
 
 FLANG = shutil.which("amdflang") or "/opt/rocm/lib/llvm/bin/flang"
 FSRC = os.path.join(HERE, "fortran")
-FFILES = ["ecwam_hip_mod.F90", "wamintgr_hip.F90", "smoke_wamintgr_hip.F90"]
+# the Fortran host layer: C interfaces + device state + transfer workers, the generated host types (tools/gen_yowdrvtype.py), the set-up
+# layer, the driver; then the harness programs (one executable each)
+FFILES = ["ecwam_hip_capi.F90", "yowdrvtype_hip.F90", "ecwam_hip_mod.F90", "wamintgr_hip.F90", "harness_case.F90"]
+FPROGS = {"smoke_wamintgr_hip": "smoke_wamintgr_hip.F90", "seam_sequence": "seam_sequence.F90"}
 
 
-def fortran_exe(prec: str) -> str:
-    return os.path.join(LIBDIR, f"smoke_wamintgr_hip_{prec}")
+def fortran_exe(prec: str, prog: str = "smoke_wamintgr_hip") -> str:
+    return os.path.join(LIBDIR, f"{prog}_{prec}")
 
 
 def build_fortran(force: bool = False) -> list:
-    """Fortran host layer (iso_c_binding module + WAMINTGR_HIP + harness program), sp and dp, linked against
+    """Fortran host layer (iso_c_binding module + host types + WAMINTGR_HIP) and the harness programs, sp and dp, linked against
     libecwam_hip.so with amdflang."""
     build(force=False)
     out = []
     for prec in ("sp", "dp"):
-        exe = fortran_exe(prec)
-        out.append(exe)
-        srcs = [os.path.join(FSRC, f) for f in FFILES]
-        if not force and os.path.exists(exe) and all(os.path.getmtime(s) < os.path.getmtime(exe) for s in srcs + [LIB]):
+        exes = [fortran_exe(prec, p) for p in FPROGS]
+        out += exes
+        srcs = [os.path.join(FSRC, f) for f in FFILES + list(FPROGS.values())]
+        if not force and all(os.path.exists(e) and all(os.path.getmtime(s) < os.path.getmtime(e) for s in srcs + [LIB]) for e in exes):
             continue
         moddir = os.path.join(LIBDIR, f"fmod_{prec}")
         os.makedirs(moddir, exist_ok=True)
         defs = ["-DECWAM_HIP_SINGLE"] if prec == "sp" else []
-        objs = []
-        for s in srcs:
+
+        def compile_(s):
             o = os.path.join(moddir, os.path.basename(s).replace(".F90", ".o"))
             r = subprocess.run([FLANG, "-cpp", "-O2", "-fPIC", *defs, "-module-dir", moddir, "-I", moddir, "-c", s, "-o", o],
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"flang failed for {s}:\n{r.stdout}")
-            objs.append(o)
-        r = subprocess.run([FLANG, "-o", exe, *objs, "-L", LIBDIR, "-lecwam_hip", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,$ORIGIN"],
-                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"fortran link failed:\n{r.stdout}")
+            return o
+
+        objs = [compile_(os.path.join(FSRC, f)) for f in FFILES]
+        for prog, f in FPROGS.items():
+            po = compile_(os.path.join(FSRC, f))
+            r = subprocess.run([FLANG, "-o", fortran_exe(prec, prog), po, *objs, "-L", LIBDIR, "-lecwam_hip", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,$ORIGIN"],
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"fortran link failed ({prog}):\n{r.stdout}")
     return out
 
 

@@ -338,6 +338,31 @@ static void fastwave_copy(ecwam_hip_ctx* c, const void* fl1, int kijs, int kijl,
   else launch_copy_freq_range<double>(src, dst, kijl - kijs, c->NANG, c->NFRE, 0, c->fast_gk, c->fast_gk, s);
 }
 
+// ---- one member of a FIELD_API-shaped host type <-> its slot of the library's packed per-point rows ---------------------------------
+// chunked member M(NPROMA[,NM],NCHNK) (Fortran order: element (ip, m, ich) at ((ich NM + m) NPROMA + ip)) and rows[ij][row_stride]
+// with the member's NM values at row_off; E = the element as an integer of its size (reals, doubles and int32 move alike)
+template <typename E>
+__global__ void k_member_scatter(const E* __restrict__ src, E* __restrict__ rows, int nproma, int npts, int nm, long long row_stride, long long row_off) {
+  const long long total = (long long)npts * nm;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const int ij = (int)(g / nm), m = (int)(g - (long long)ij * nm);
+    const int ich = ij / nproma, ip = ij - ich * nproma;
+    rows[(long long)ij * row_stride + row_off + m] = src[((size_t)ich * nm + m) * nproma + ip];
+  }
+}
+template <typename E>
+__global__ void k_member_gather(const E* __restrict__ rows, E* __restrict__ dst, int nproma, int nchnk, int npts, int nm, long long row_stride, long long row_off) {
+  const long long total = (long long)nchnk * nproma * nm;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const int ip = (int)(g % nproma);
+    const long long r = g / nproma;
+    const int m = (int)(r % nm), ich = (int)(r / nm);
+    int ij = ich * nproma + ip;
+    if (ij >= npts) ij = (nchnk - 1) * nproma;      // pad lanes of the ragged last chunk replicate its lane 1 (propag_wam.F90:388-398)
+    dst[g] = rows[(long long)ij * row_stride + row_off + m];
+  }
+}
+
 extern "C" {
 
 const char* ecwam_hip_last_error(void) { return g_err.c_str(); }
@@ -782,6 +807,47 @@ int ecwam_hip_points_to_chunks(ecwam_hip_ctx* c, const void* points, void* chunk
   if (nproma < 1 || nchnk < 0 || npts > nproma * nchnk || npts <= nproma * (nchnk - 1) || n2 < 1 || n3 < 1) return fail("ecwam_hip_points_to_chunks: bad shape");
   hipStream_t s = (hipStream_t)stream;
   DISPATCH(launch_p2c<float>(points, chunked, nproma, nchnk, npts, n2, n3, s), launch_p2c<double>(points, chunked, nproma, nchnk, npts, n2, n3, s));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int member_args(const char* who, int nproma, int nchnk, int npts, int nm, long long row_stride, long long row_off, int elem_bytes,
+                       const void* a, const void* b) {
+  if (nproma < 1 || nchnk < 0 || npts < 0 || npts > nproma * nchnk || (npts > 0 && npts <= nproma * (nchnk - 1)) || nm < 1 || row_off < 0 ||
+      row_off + nm > row_stride || (elem_bytes != 4 && elem_bytes != 8))
+    return fail(std::string(who) + ": bad shape");
+  if (npts > 0 && (!a || !b)) return fail(std::string(who) + ": null pointer");
+  return 0;
+}
+
+int ecwam_hip_member_scatter(ecwam_hip_ctx* c, const void* chunked, void* rows, int nproma, int nchnk, int npts, int nm, long long row_stride,
+                             long long row_off, int elem_bytes, void* stream) {
+  if (!c) return fail("null context");
+  if (member_args("ecwam_hip_member_scatter", nproma, nchnk, npts, nm, row_stride, row_off, elem_bytes, chunked, rows)) return 1;
+  if (npts == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const long long total = (long long)npts * nm;
+  const int nb = (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256);
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL(k_member_scatter<unsigned int>, dim3(nb), dim3(256), 0, s, (const unsigned int*)chunked, (unsigned int*)rows, nproma, npts, nm, row_stride, row_off);
+  else
+    hipLaunchKernelGGL(k_member_scatter<unsigned long long>, dim3(nb), dim3(256), 0, s, (const unsigned long long*)chunked, (unsigned long long*)rows, nproma, npts, nm, row_stride, row_off);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ecwam_hip_member_gather(ecwam_hip_ctx* c, const void* rows, void* chunked, int nproma, int nchnk, int npts, int nm, long long row_stride,
+                            long long row_off, int elem_bytes, void* stream) {
+  if (!c) return fail("null context");
+  if (member_args("ecwam_hip_member_gather", nproma, nchnk, npts, nm, row_stride, row_off, elem_bytes, rows, chunked)) return 1;
+  if (npts == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const long long total = (long long)nchnk * nproma * nm;
+  const int nb = (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256);
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL(k_member_gather<unsigned int>, dim3(nb), dim3(256), 0, s, (const unsigned int*)rows, (unsigned int*)chunked, nproma, nchnk, npts, nm, row_stride, row_off);
+  else
+    hipLaunchKernelGGL(k_member_gather<unsigned long long>, dim3(nb), dim3(256), 0, s, (const unsigned long long*)rows, (unsigned long long*)chunked, nproma, nchnk, npts, nm, row_stride, row_off);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -1,86 +1,14 @@
 ! smoke_wamintgr_hip.F90 -- harness program (this repository's own, not part of ecWAM): reads a case written by
-! tests/test_gpu_fortran.py, fills the YOWDRVTYPE-shaped host types, calls ECWAM_HIP_SETUP and NSTEP x WAMINTGR_HIP with
-! the reference's WAMODEL date sequence (wamodel.F90:228-312: CDTPRA=CDTPRO; CDTPRO+=IDELPRO; loop while
-! CDTIMPNEXT<=CDTPRO), and writes the resulting host arrays.  Dates are seconds counters in 14-character strings.
-MODULE SMOKE_DATES
-  USE ECWAM_HIP_MOD, ONLY : JWIM
-  IMPLICIT NONE
-CONTAINS
-  SUBROUTINE SIMPLE_INCDATE(CDATE, ISHIFT)
-    CHARACTER(LEN=*), INTENT(INOUT) :: CDATE
-    INTEGER(KIND=JWIM), INTENT(IN) :: ISHIFT
-    INTEGER(KIND=8) :: I
-    READ(CDATE, '(I14)') I
-    I = I + ISHIFT
-    WRITE(CDATE, '(I14.14)') I
-  END SUBROUTINE
-END MODULE SMOKE_DATES
-
-! Exchange of the host-staged halo segments between the processes of a multi-rank run of this harness through files in a common
-! directory (where ecWAM would call MPI_SENDRECV): per exchange number and (sender, receiver) one data file, published by a flag file
-! written after the data file is closed; the receiver waits for the flag, reads and removes both.
-MODULE SMOKE_XCHG
-  USE, INTRINSIC :: ISO_C_BINDING
-  USE ECWAM_HIP_MOD, ONLY : JWRB
-  IMPLICIT NONE
-  CHARACTER(LEN=512) :: XDIR = ' '
-  INTEGER :: MYRANK = 0, XSEQ = 0
-CONTAINS
-  FUNCTION XNAME(ISEQ, IFROM, ITO, EXT) RESULT(F)
-    INTEGER, INTENT(IN) :: ISEQ, IFROM, ITO
-    CHARACTER(LEN=*), INTENT(IN) :: EXT
-    CHARACTER(LEN=600) :: F
-    WRITE(F, '(A,A,I6.6,A,I3.3,A,I3.3,A)') TRIM(XDIR), '/x', ISEQ, '_', IFROM, '_', ITO, EXT
-  END FUNCTION
-  SUBROUTINE FILE_XCHG(NPEERS, PEER, SEND_COUNT, RECV_COUNT, ROWLEN, SENDBUF, RECVBUF)
-    INTEGER(C_INT), INTENT(IN) :: NPEERS, PEER(NPEERS), SEND_COUNT(NPEERS), RECV_COUNT(NPEERS), ROWLEN
-    REAL(KIND=JWRB), INTENT(IN) :: SENDBUF(*)
-    REAL(KIND=JWRB), INTENT(OUT) :: RECVBUF(*)
-    INTEGER :: I, IU, SO, RO, NS, NR
-    INTEGER(KIND=8) :: T0, T1, TR
-    LOGICAL :: LEX
-    XSEQ = XSEQ + 1
-    SO = 0
-    DO I = 1, NPEERS
-      NS = SEND_COUNT(I) * ROWLEN
-      IF (NS > 0) THEN
-        OPEN(NEWUNIT=IU, FILE=TRIM(XNAME(XSEQ, MYRANK, INT(PEER(I)), '.bin')), ACCESS='STREAM', FORM='UNFORMATTED', STATUS='REPLACE')
-        WRITE(IU) SENDBUF(SO+1:SO+NS)
-        CLOSE(IU)
-        OPEN(NEWUNIT=IU, FILE=TRIM(XNAME(XSEQ, MYRANK, INT(PEER(I)), '.ok')), STATUS='REPLACE')
-        CLOSE(IU)
-      ENDIF
-      SO = SO + NS
-    ENDDO
-    RO = 0
-    CALL SYSTEM_CLOCK(T0, TR)
-    DO I = 1, NPEERS
-      NR = RECV_COUNT(I) * ROWLEN
-      IF (NR > 0) THEN
-        DO
-          INQUIRE(FILE=TRIM(XNAME(XSEQ, INT(PEER(I)), MYRANK, '.ok')), EXIST=LEX)
-          IF (LEX) EXIT
-          CALL SYSTEM_CLOCK(T1)
-          IF (REAL(T1 - T0, 8) / REAL(TR, 8) > 240.0D0) ERROR STOP 'smoke_wamintgr_hip: the neighbouring rank did not deliver its halo segment'
-        ENDDO
-        OPEN(NEWUNIT=IU, FILE=TRIM(XNAME(XSEQ, INT(PEER(I)), MYRANK, '.bin')), ACCESS='STREAM', FORM='UNFORMATTED', STATUS='OLD')
-        READ(IU) RECVBUF(RO+1:RO+NR)
-        CLOSE(IU, STATUS='DELETE')
-        OPEN(NEWUNIT=IU, FILE=TRIM(XNAME(XSEQ, INT(PEER(I)), MYRANK, '.ok')), STATUS='OLD')
-        CLOSE(IU, STATUS='DELETE')
-      ENDIF
-      RO = RO + NR
-    ENDDO
-  END SUBROUTINE
-END MODULE SMOKE_XCHG
-
+! tests/test_gpu_fortran.py (harness_case.F90), calls NSTEP x WAMINTGR_HIP with the reference's WAMODEL date sequence
+! (wamodel.F90:228-312: CDTPRA=CDTPRO; CDTPRO+=IDELPRO; loop while CDTIMPNEXT<=CDTPRO), fetches the results through the
+! FIELD_API-shaped methods of the host types and writes the host arrays.  Dates are seconds counters in 14-character strings.
+! (seam_sequence.F90 is the same run inside the complete call sequence of the reference's GPU build.)
 PROGRAM SMOKE_WAMINTGR_HIP
   USE, INTRINSIC :: ISO_C_BINDING
   USE ECWAM_HIP_MOD
   USE ECWAM_HIP_DRV
   USE ECWAM_HIP_HOSTSYNC
-  USE SMOKE_DATES
-  USE SMOKE_XCHG
+  USE HARNESS_CASE
   IMPLICIT NONE
   INTERFACE
     SUBROUTINE WAMINTGR_HIP (CDTPRA, CDATE, CDATEWH, CDTIMP, CDTIMPNEXT, BLK2GLO, WVENVI, WVPRPT, FF_NOW, FF_NEXT, INTFLDS, &
@@ -99,153 +27,12 @@ PROGRAM SMOKE_WAMINTGR_HIP
       TYPE(TYPE_4D), INTENT(INOUT)            :: VARS_4D
     END SUBROUTINE
   END INTERFACE
-
-  CHARACTER(LEN=512) :: FIN, FOUT
-  INTEGER(C_INT) :: HDR(26), NANG, NFRE, NFRE_RED, NPROMA, NCHNK, NPTS, NGY, IDELT, IDELPRO, NSTEP, NTAB, NCFL
-  TYPE(ECWAM_HIP_PARAMS), TARGET :: P
-  TYPE(ECWAM_HIP_TABLES) :: T
-  INTEGER, PARAMETER :: NTABLES = 43
-  LOGICAL :: ISINT(NTABLES)   ! which members of ecwam_hip_tables are int32 (ikp..ikm1, k1w..inlcoef, indicessat, kpm..kcr)
-  TYPE RTAB
-    REAL(KIND=JWRB), ALLOCATABLE :: R(:)
-    INTEGER(C_INT), ALLOCATABLE :: I(:)
-  END TYPE
-  TYPE(RTAB), TARGET :: TB(NTABLES)
-  TYPE(C_PTR) :: TP(NTABLES)
-  INTEGER(C_INT), ALLOCATABLE :: KLON(:,:), KLAT(:,:,:), KCOR(:,:,:), KXLT(:)
-  REAL(KIND=JWRB), ALLOCATABLE :: WLAT(:,:), WCOR(:,:), ZDELLO(:), COSPH(:), SINPH(:), CGEXT(:,:), CM1EXT(:)
-  REAL(KIND=JWRB) :: XDELLA
-  REAL(KIND=JWRB), ALLOCATABLE :: OBSLAT(:,:,:), OBSLON(:,:,:), OBSCOR(:,:,:)        ! LSUBGRID
-  REAL(KIND=JWRB), ALLOCATABLE :: DEPEXT(:), UEXT(:), VEXT(:), OMEXT(:,:), WNEXT(:,:)   ! PROENVHALO rows (refraction)
-  REAL(KIND=JWRB), ALLOCATABLE :: LANDROW(:)
-  TYPE(WVGRIDGLO) :: BLK2GLO
-  TYPE(ENVIRONMENT) :: WVENVI
-  TYPE(FREQUENCY) :: WVPRPT
-  TYPE(FORCING_FIELDS) :: FF_NOW, FF_NEXT
-  TYPE(INTGT_PARAM_FIELDS) :: INTFLDS
-  TYPE(WAVE2OCEAN) :: WAM2NEMO
-  TYPE(MIJ_TYPE) :: MIJ
-  TYPE(TYPE_4D) :: VARS_4D
   CHARACTER(LEN=14) :: CDTPRA, CDATE, CDATEWH, CDTIMP, CDTIMPNEXT, CDTPRO
-  INTEGER :: IU, I, N, ISTEP, ILOOP
+  INTEGER :: ISTEP, ILOOP
   INTEGER, PARAMETER :: NWARM = 2
   INTEGER(KIND=8) :: T0, T1, TRATE
-  CHARACTER(LEN=16) :: FMODE
-  CHARACTER(C_CHAR), TARGET :: PBYTES(4096)
-  INTEGER(C_INT) :: PSIZE
-  ! multi-rank runs (HDR(20) = NRANKS > 1): this rank's band of the sea points, the lists of ECWAM_HIP_SET_DECOMPOSITION (1-based, as
-  ! the reference's NTOPE / IJTOPE / NIJSTART), the halo segments exchanged through files in the directory of the 4th argument
-  INTEGER(C_INT) :: NRANKS, IRANK, NHALO, NPEERS, NEXT
-  INTEGER(C_INT), ALLOCATABLE :: PEER(:), SEND_COUNT(:), RECV_START(:), RECV_COUNT(:), SEND_IDX(:)
-  CHARACTER(KIND=C_CHAR) :: COMM_ID(128)
-  INTEGER :: NSOURCE
 
-  ISINT = .FALSE.; ISINT(16:19) = .TRUE.; ISINT(21:25) = .TRUE.; ISINT(27) = .TRUE.; ISINT(29:32) = .TRUE.
-  CALL GET_COMMAND_ARGUMENT(1, FIN)
-  CALL GET_COMMAND_ARGUMENT(2, FOUT)
-  OPEN(NEWUNIT=IU, FILE=TRIM(FIN), ACCESS='STREAM', FORM='UNFORMATTED', STATUS='OLD')
-  READ(IU) HDR
-  NANG = HDR(1); NFRE = HDR(2); NFRE_RED = HDR(3); NPROMA = HDR(4); NCHNK = HDR(5); NPTS = HDR(6); NGY = HDR(7)
-  IDELT = HDR(8); IDELPRO = HDR(9); NSTEP = HDR(11); PSIZE = HDR(12)
-  NRANKS = MAX(1, HDR(20)); IRANK = HDR(21); NHALO = HDR(22); NPEERS = HDR(23)
-  IF (NRANKS == 1) NHALO = 0
-  NEXT = NPTS + NHALO
-  IF (HDR(10) /= STORAGE_SIZE(1.0_JWRB)/8) ERROR STOP 'precision of the case file does not match this build'
-  IF (PSIZE /= INT(C_SIZEOF(P), C_INT)) ERROR STOP 'ecwam_hip_params size mismatch'
-  IF (HDR(13) /= NTABLES) ERROR STOP 'number of tables in the case file does not match ecwam_hip_tables'
-  READ(IU) PBYTES(1:PSIZE)
-  P = TRANSFER(PBYTES(1:PSIZE), P)
-  DO I = 1, NTABLES
-    READ(IU) N
-    IF (ISINT(I)) THEN
-      ALLOCATE(TB(I)%I(N)); READ(IU) TB(I)%I; TP(I) = C_LOC(TB(I)%I)
-    ELSE
-      ALLOCATE(TB(I)%R(N)); READ(IU) TB(I)%R; TP(I) = C_LOC(TB(I)%R)
-    ENDIF
-  ENDDO
-  T%FR = TP(1); T%DFIM = TP(2); T%DFIMOFR = TP(3); T%DFIMFR = TP(4); T%DFIM_SIM = TP(5); T%RHOWG_DFIM = TP(6); T%ZPIFR = TP(7)
-  T%FR5 = TP(8); T%COFRM4 = TP(9); T%FLMAX = TP(10); T%TH = TP(11); T%COSTH = TP(12); T%SINTH = TP(13); T%WTAUHF = TP(14)
-  T%SWELLFT = TP(15); T%IKP = TP(16); T%IKP1 = TP(17); T%IKM = TP(18); T%IKM1 = TP(19); T%AF11 = TP(20); T%K1W = TP(21)
-  T%K2W = TP(22); T%K11W = TP(23); T%K21W = TP(24); T%INLCOEF = TP(25); T%RNLCOEF = TP(26); T%INDICESSAT = TP(27)
-  T%SATWEIGHTS = TP(28); T%KPM = TP(29); T%JXO = TP(30); T%JYO = TP(31); T%KCR = TP(32); T%XK_GC = TP(33); T%XKM_GC = TP(34)
-  T%OMEGA_GC = TP(35); T%OMXKM3_GC = TP(36); T%CM_GC = TP(37); T%C2OSQRTVG_GC = TP(38); T%XKMSQRTVGOC2_GC = TP(39)
-  T%OM3GMKM_GC = TP(40); T%DELKCC_GC_NS = TP(41); T%DELKCC_OMXKM3_GC = TP(42); T%CIDEAC = TP(43)
-
-  ALLOCATE(KLON(NPTS,2), KLAT(NPTS,2,2), KCOR(NPTS,4,2), KXLT(NPTS), WLAT(NPTS,2), WCOR(NPTS,4), ZDELLO(NGY), COSPH(NGY), SINPH(NGY))
-  ALLOCATE(CGEXT(NEXT+1,NFRE), CM1EXT(NEXT+1))
-  READ(IU) KLON, KLAT, KCOR, KXLT, WLAT, WCOR, ZDELLO, XDELLA, COSPH, SINPH, CGEXT, CM1EXT
-
-  ALLOCATE(VARS_4D%FL1(NPROMA,NANG,NFRE,NCHNK), VARS_4D%XLLWS(NPROMA,NANG,NFRE,NCHNK), MIJ%PTR(NPROMA,NCHNK))
-  ALLOCATE(WVPRPT%WAVNUM(NPROMA,NFRE,NCHNK), WVPRPT%CGROUP(NPROMA,NFRE,NCHNK), WVPRPT%CINV(NPROMA,NFRE,NCHNK), &
- &         WVPRPT%XK2CG(NPROMA,NFRE,NCHNK), WVPRPT%STOKFAC(NPROMA,NFRE,NCHNK))
-  CALL ALLOC_FF(FF_NOW); CALL ALLOC_FF(FF_NEXT)
-  ALLOCATE(WVENVI%EMAXDPT(NPROMA,NCHNK), WVENVI%DEPTH(NPROMA,NCHNK))
-  ALLOCATE(INTFLDS%WSEMEAN(NPROMA,NCHNK), INTFLDS%WSFMEAN(NPROMA,NCHNK), INTFLDS%USTOKES(NPROMA,NCHNK), INTFLDS%VSTOKES(NPROMA,NCHNK), &
- &         INTFLDS%STRNMS(NPROMA,NCHNK), INTFLDS%TAUXD(NPROMA,NCHNK), INTFLDS%TAUYD(NPROMA,NCHNK), INTFLDS%TAUOCXD(NPROMA,NCHNK), &
- &         INTFLDS%TAUOCYD(NPROMA,NCHNK), INTFLDS%TAUOC(NPROMA,NCHNK), INTFLDS%TAUICX(NPROMA,NCHNK), INTFLDS%TAUICY(NPROMA,NCHNK), &
- &         INTFLDS%PHIOCD(NPROMA,NCHNK), INTFLDS%PHIEPS(NPROMA,NCHNK), INTFLDS%PHIAW(NPROMA,NCHNK))
-  INTFLDS%WSEMEAN = 0; INTFLDS%WSFMEAN = 0; INTFLDS%USTOKES = 0; INTFLDS%VSTOKES = 0; INTFLDS%STRNMS = 0; INTFLDS%TAUXD = 0
-  INTFLDS%TAUYD = 0; INTFLDS%TAUOCXD = 0; INTFLDS%TAUOCYD = 0; INTFLDS%TAUOC = 0; INTFLDS%TAUICX = 0; INTFLDS%TAUICY = 0
-  INTFLDS%PHIOCD = 0; INTFLDS%PHIEPS = 0; INTFLDS%PHIAW = 0; VARS_4D%XLLWS = 0; MIJ%PTR = 0
-  READ(IU) VARS_4D%FL1, WVPRPT%WAVNUM, WVPRPT%CGROUP, WVPRPT%CINV, WVPRPT%XK2CG, WVPRPT%STOKFAC
-  READ(IU) FF_NOW%AIRD, FF_NOW%WDWAVE, FF_NOW%CICOVER, FF_NOW%WSWAVE, FF_NOW%WSTAR, FF_NOW%USTRA, FF_NOW%VSTRA, FF_NOW%UFRIC, &
- &         FF_NOW%TAUW, FF_NOW%TAUWDIR, FF_NOW%Z0M, FF_NOW%Z0B, FF_NOW%CHRNCK, FF_NOW%CITHICK, WVENVI%EMAXDPT, WVENVI%DEPTH
-  IF (HDR(16) /= 0 .AND. HDR(26) == 0) THEN   ! refraction: the extended depth / current / wave-property rows as PROENVHALO assembles them
-    ALLOCATE(DEPEXT(NPTS+1), UEXT(NPTS+1), VEXT(NPTS+1), OMEXT(NPTS+1,NFRE), WNEXT(NPTS+1,NFRE))
-    READ(IU) DEPEXT, UEXT, VEXT, OMEXT, WNEXT
-  ELSEIF (HDR(16) /= 0) THEN                  ! HDR(26) = 1: this rank's own fields, the library assembles the rows (ECWAM_HIP_PROENVHALO)
-    ALLOCATE(WVPRPT%OMOSNH2KD(NPROMA,NFRE,NCHNK), WVENVI%UCUR(NPROMA,NCHNK), WVENVI%VCUR(NPROMA,NCHNK), LANDROW(3*NFRE+3))
-    READ(IU) WVPRPT%OMOSNH2KD, WVENVI%UCUR, WVENVI%VCUR, LANDROW
-  ENDIF
-  IF (HDR(18) /= 0) THEN   ! sub-grid obstructions
-    ALLOCATE(OBSLAT(NPTS,NFRE_RED,2), OBSLON(NPTS,NFRE_RED,2), OBSCOR(NPTS,NFRE_RED,4))
-    READ(IU) OBSLAT, OBSLON, OBSCOR
-  ENDIF
-  IF (NRANKS > 1) THEN
-    ALLOCATE(PEER(NPEERS), SEND_COUNT(NPEERS), RECV_START(NPEERS), RECV_COUNT(NPEERS))
-    READ(IU) PEER, SEND_COUNT, RECV_START, RECV_COUNT
-    ALLOCATE(SEND_IDX(MAX(1, SUM(SEND_COUNT))))
-    READ(IU) SEND_IDX(1:SUM(SEND_COUNT))
-  ENDIF
-  CLOSE(IU)
-  IF (P%LWNEMOCOU /= 0) THEN
-    ALLOCATE(WAM2NEMO%NSWH(NPROMA,NCHNK), WAM2NEMO%NMWP(NPROMA,NCHNK), WAM2NEMO%NPHIEPS(NPROMA,NCHNK), WAM2NEMO%NEMOPHIF(NPROMA,NCHNK), &
- &           WAM2NEMO%NTAUOC(NPROMA,NCHNK), WAM2NEMO%NEMOTAUX(NPROMA,NCHNK), WAM2NEMO%NEMOTAUY(NPROMA,NCHNK), &
- &           WAM2NEMO%NEMOUSTOKES(NPROMA,NCHNK), WAM2NEMO%NEMOVSTOKES(NPROMA,NCHNK), WAM2NEMO%NEMOSTRN(NPROMA,NCHNK), &
- &           WAM2NEMO%NEMOWSWAVE(NPROMA,NCHNK), WAM2NEMO%NEMOTAUICX(NPROMA,NCHNK), WAM2NEMO%NEMOTAUICY(NPROMA,NCHNK))
-    WAM2NEMO%NSWH = 0; WAM2NEMO%NMWP = 0; WAM2NEMO%NPHIEPS = 0; WAM2NEMO%NEMOPHIF = 0; WAM2NEMO%NTAUOC = 0; WAM2NEMO%NEMOTAUX = 0
-    WAM2NEMO%NEMOTAUY = 0; WAM2NEMO%NEMOUSTOKES = 0; WAM2NEMO%NEMOVSTOKES = 0; WAM2NEMO%NEMOSTRN = 0; WAM2NEMO%NEMOWSWAVE = 0
-    WAM2NEMO%NEMOTAUICX = 0; WAM2NEMO%NEMOTAUICY = 0
-  ENDIF
-  IF (NRANKS > 1) THEN
-    ! the segments travel host-staged through FILE_XCHG (RCCL wants one GPU per rank; this harness also runs several ranks on one)
-    CALL GET_COMMAND_ARGUMENT(4, XDIR)
-    IF (LEN_TRIM(XDIR) == 0) ERROR STOP 'multi-rank case: the exchange directory is the 4th argument'
-    MYRANK = IRANK
-    COMM_ID = C_NULL_CHAR
-    CALL ECWAM_HIP_SET_DECOMPOSITION(IRANK, NRANKS, NHALO, NPEERS, PEER, SEND_COUNT, SEND_IDX, RECV_START, RECV_COUNT, HDR(24), HDR(25), &
- &                                   COMM_ID, HALO_XCHG=FILE_XCHG)
-  ENDIF
-
-  CALL ECWAM_HIP_SETUP(P, T, 0_C_INT, NPROMA, NCHNK, NPTS, NGY, IDELPRO, KLON, KLAT, KCOR, WLAT, WCOR, KXLT, ZDELLO, XDELLA, &
- &                     COSPH, SINPH, CGEXT, CM1EXT, NCFL)
-  IF (NCFL /= 0) ERROR STOP 'CFL criterion violated'
-  IF (HDR(18) /= 0) THEN
-    CALL ECWAM_HIP_SET_SUBGRID(OBSLAT, OBSLON, OBSCOR, NCFL)
-    IF (NCFL /= 0) ERROR STOP 'CFL criterion violated (LSUBGRID)'
-  ENDIF
-  IF (HDR(16) /= 0 .AND. HDR(26) == 0) THEN
-    CALL ECWAM_HIP_SET_ENVIRONMENT(DEPEXT, UEXT, VEXT, OMEXT, WNEXT, HDR(17) /= 0, NCFL)
-    IF (NCFL /= 0) ERROR STOP 'CFL criterion violated (refraction)'
-  ENDIF
-  IF (HDR(14) > 0) THEN   ! fast waves: IFRELFMAX, DELPRO_LF [s]
-    CALL ECWAM_HIP_SET_FASTWAVES(HDR(14), REAL(HDR(15), C_DOUBLE), NCFL)
-    IF (NCFL /= 0) ERROR STOP 'CFL criterion violated (fast waves)'
-  ENDIF
-  IF (HDR(16) /= 0 .AND. HDR(26) /= 0) THEN   ! PROENVHALO through the library: owned rows, halo rows through the exchange, land slot
-    CALL ECWAM_HIP_PROENVHALO(WVPRPT, WVENVI, LANDROW, HDR(17) /= 0, NCFL)
-    IF (NCFL /= 0) ERROR STOP 'CFL criterion violated (refraction, PROENVHALO)'
-  ENDIF
+  CALL CASE_READ_AND_SETUP()
 
   ! the steps leave everything on the device (no per-step copies); the host types are refreshed once, after the last step.
   ! HDR(19) = 1: LLSOURCE = .FALSE. (the no-source branch of WAMINTGR); a third command argument "time": print the time per step
@@ -286,37 +73,12 @@ PROGRAM SMOKE_WAMINTGR_HIP
  &                              TAUOCXD=.TRUE., TAUOCYD=.TRUE., TAUOC=.TRUE., TAUICX=.TRUE., TAUICY=.TRUE., PHIOCD=.TRUE., PHIEPS=.TRUE., &
  &                              PHIAW=.TRUE., QUEUE=5)
   CALL MIJ%SYNC_HOST_RDONLY(QUEUE=5)
+  IF (P%LWNEMOCOU /= 0) CALL WAM2NEMO%SYNC_HOST_RDONLY(QUEUE=6)
   CALL WAIT_FOR_ASYNC_QUEUE(QUEUE=4)
   CALL WAIT_FOR_ASYNC_QUEUE(QUEUE=5)
+  CALL WAIT_FOR_ASYNC_QUEUE(QUEUE=6)
 
-  OPEN(NEWUNIT=IU, FILE=TRIM(FOUT), ACCESS='STREAM', FORM='UNFORMATTED', STATUS='REPLACE')
-  WRITE(IU) VARS_4D%FL1, VARS_4D%XLLWS, MIJ%PTR
-  WRITE(IU) FF_NOW%AIRD, FF_NOW%WDWAVE, FF_NOW%CICOVER, FF_NOW%WSWAVE, FF_NOW%WSTAR, FF_NOW%USTRA, FF_NOW%VSTRA, FF_NOW%UFRIC, &
- &          FF_NOW%TAUW, FF_NOW%TAUWDIR, FF_NOW%Z0M, FF_NOW%Z0B, FF_NOW%CHRNCK, FF_NOW%CITHICK
-  WRITE(IU) INTFLDS%WSEMEAN, INTFLDS%WSFMEAN, INTFLDS%USTOKES, INTFLDS%VSTOKES, INTFLDS%STRNMS, INTFLDS%TAUXD, INTFLDS%TAUYD, &
- &          INTFLDS%TAUOCXD, INTFLDS%TAUOCYD, INTFLDS%TAUOC, INTFLDS%TAUICX, INTFLDS%TAUICY, INTFLDS%PHIOCD, INTFLDS%PHIEPS, INTFLDS%PHIAW
-  IF (P%LWNEMOCOU /= 0) THEN
-    ! YOWCOUP's accumulation count: one per source-term integration (wamintgr.F90:150); UPDNEMOSTRESS divides the sums by it
-    IF (HIP_NEMONTAU /= NSOURCE) THEN
-      WRITE(0,*) 'smoke_wamintgr_hip: NEMONTAU = ', HIP_NEMONTAU, ' after ', NSOURCE, ' source-term integrations'
-      ERROR STOP 1
-    ENDIF
-    WRITE(IU) INT(HIP_NEMONTAU, C_INT)
-    WRITE(IU) WAM2NEMO%NEMOUSTOKES, WAM2NEMO%NEMOVSTOKES, WAM2NEMO%NEMOSTRN, WAM2NEMO%NPHIEPS, WAM2NEMO%NTAUOC, WAM2NEMO%NSWH, WAM2NEMO%NMWP, &
- &            WAM2NEMO%NEMOTAUX, WAM2NEMO%NEMOTAUY, WAM2NEMO%NEMOTAUICX, WAM2NEMO%NEMOTAUICY, WAM2NEMO%NEMOWSWAVE, WAM2NEMO%NEMOPHIF
-  ELSEIF (HIP_NEMONTAU /= 0) THEN
-    ERROR STOP 'smoke_wamintgr_hip: NEMONTAU advanced without LWNEMOCOU'
-  ENDIF
-  CLOSE(IU)
+  CALL CASE_WRITE(HIP_NEMONTAU)
   CALL ECWAM_HIP_FINALIZE()
   PRINT '(A)', 'smoke_wamintgr_hip: ok'
-CONTAINS
-  SUBROUTINE ALLOC_FF(FF)
-    TYPE(FORCING_FIELDS), INTENT(INOUT) :: FF
-    ALLOCATE(FF%AIRD(NPROMA,NCHNK), FF%WDWAVE(NPROMA,NCHNK), FF%CICOVER(NPROMA,NCHNK), FF%WSWAVE(NPROMA,NCHNK), FF%WSTAR(NPROMA,NCHNK), &
- &           FF%USTRA(NPROMA,NCHNK), FF%VSTRA(NPROMA,NCHNK), FF%UFRIC(NPROMA,NCHNK), FF%TAUW(NPROMA,NCHNK), FF%TAUWDIR(NPROMA,NCHNK), &
- &           FF%Z0M(NPROMA,NCHNK), FF%Z0B(NPROMA,NCHNK), FF%CHRNCK(NPROMA,NCHNK), FF%CITHICK(NPROMA,NCHNK))
-    FF%AIRD = 1.225_JWRB; FF%WDWAVE = 0; FF%CICOVER = 0; FF%WSWAVE = 0; FF%WSTAR = 0; FF%USTRA = 0; FF%VSTRA = 0; FF%UFRIC = 0
-    FF%TAUW = 0; FF%TAUWDIR = 0; FF%Z0M = 0; FF%Z0B = 0; FF%CHRNCK = 0; FF%CITHICK = 0
-  END SUBROUTINE
 END PROGRAM SMOKE_WAMINTGR_HIP

@@ -1,9 +1,12 @@
 ! wamintgr_hip.F90 -- third variant of the reference's time-step driver next to WAMINTGR (wamintgr.F90:10-13) and
 ! WAMINTGR_LOKI_GPU (wamintgr_loki_gpu.F90:10-13): identical 14-argument interface, selected at the seam
 ! wamodel.F90:289-299.  Spectra, forcing and integrated parameters stay resident on the GPU between calls (as in the OpenACC
-! variant, GET_DEVICE_DATA_RDWR, wamintgr_loki_gpu.F90:100-105): a call uploads nothing but a new FF_NEXT when one is due and
-! downloads nothing unless the host asks -- HIP_LSYNC_FIELDS (FF_NOW, INTFLDS, MIJ: the SYNC_HOST_RDONLY of :197-200) and
-! HIP_LSYNC_SPECTRA (FL1, XLLWS: output / restart steps, wamodel.F90:376,437,460).
+! variant, GET_DEVICE_DATA_RDWR, wamintgr_loki_gpu.F90:100-105).  The host types carry FIELD_API's method surface and status tracking
+! (yowdrvtype_hip.F90): the driver makes the reference's own GET_DEVICE_DATA_* calls (wamintgr_loki_gpu.F90:100-105,121-127,141-157), which
+! copy a member to the device only when the host holds the newer copy -- the first call, a new FF_NEXT, fields the host changed and
+! said so (GET_HOST_DATA_RDWR / SYNC_DEVICE_*) -- and mark what the kernels write as newer on the device; nothing comes back unless the
+! host asks (SYNC_HOST_* / GET_HOST_DATA_*: output / restart / coupling steps, wamodel.F90:376-385,435-470,614-642), or HIP_LSYNC_EAGER
+! posts the reference's per-step SYNC_HOST_RDONLY calls (wamintgr_loki_gpu.F90:197-200).
 !
 ! Standalone build (this repository): dates and steps that the reference takes from YOWSTAT/YOWWIND are module
 ! variables of ECWAM_HIP_DRV, and INCDATE is supplied by the caller.  In-tree build: see INTEGRATION.md.
@@ -24,10 +27,14 @@ MODULE ECWAM_HIP_DRV
   INTEGER(KIND=JWIM) :: HIP_NEMONTAU = 0       ! YOWCOUP:NEMONTAU  accumulation count of the WAVE2OCEAN stresses: advanced after every IMPLSCH
                                                ! call when LWNEMOCOU (wamintgr.F90:150); UPDNEMOSTRESS divides by it and resets it (updnemostress.F90:84-123)
   INTEGER(KIND=JWIM) :: HIP_ICODE_WND = 0      ! NEWWIND's ICODE_WND: ICODE_CPL when LWCOU (newwind.F90:120-124); 0 = ICODE of the set-up
-  LOGICAL :: HIP_LSYNC_SPECTRA = .FALSE.       ! copy FL1/XLLWS back to the host arrays at the end of the call
-  LOGICAL :: HIP_LSYNC_FIELDS = .FALSE.        ! copy FF_NOW / INTFLDS / MIJ (/ WAM2NEMO) back to the host types at the end of the call
-  LOGICAL :: HIP_LFF_NOW_CHANGED = .FALSE.     ! the host has modified FF_NOW (or WVENVI%EMAXDPT / DEPTH): upload it again (reset by the call)
-  LOGICAL :: HIP_LWVPRPT_CHANGED = .FALSE.     ! the host has modified WVPRPT (new depth / currents): upload it again (reset by the call)
+  LOGICAL :: HIP_LSYNC_EAGER = .FALSE.         ! end every source-term step with the reference's asynchronous copies (wamintgr_loki_gpu.F90:197-200:
+                                               ! FL1 + FF_NOW on queue 4, WVENVI on 5, WAM2NEMO on 6): 2.2 GB per step at O320 -- off by default,
+                                               ! the host's GET_HOST_DATA_* at its output steps fetch what is missing
+  LOGICAL :: HIP_LSYNC_SPECTRA = .FALSE.       ! (shorthand) FL1 / XLLWS back in the host arrays when the call returns
+  LOGICAL :: HIP_LSYNC_FIELDS = .FALSE.        ! (shorthand) FF_NOW / INTFLDS / MIJ back in the host types when the call returns
+  LOGICAL :: HIP_LFF_NOW_CHANGED = .FALSE.     ! (shorthand for FF_NOW%GET_HOST_DATA_RDWR + the same on WVENVI) the host has modified them: the
+                                               ! host copies count, they go up again (reset by the call)
+  LOGICAL :: HIP_LWVPRPT_CHANGED = .FALSE.     ! (shorthand) the host has modified WVPRPT (new depth / currents): it goes up again (reset by the call)
   ABSTRACT INTERFACE
     SUBROUTINE INCDATE_IF(CDATE, ISHIFT)
       IMPORT :: JWIM
@@ -53,16 +60,16 @@ SUBROUTINE ECWAM_HIP_SYNC_HOST(FF_NOW, INTFLDS, MIJ, VARS_4D, LFIELDS, LSPECTRA)
   TYPE(MIJ_TYPE), INTENT(INOUT)           :: MIJ
   TYPE(TYPE_4D), INTENT(INOUT)            :: VARS_4D
   LOGICAL, INTENT(IN) :: LFIELDS, LSPECTRA
-  ! whole-type, synchronous syncs through the FIELD_API-shaped methods of the types (ecwam_hip_mod.F90); a host that wants single
-  ! members or an asynchronous queue calls those directly: CALL VARS_4D%SYNC_HOST_RDONLY(FL1=.TRUE., QUEUE=4) ...
+  ! whole-type, synchronous: GET_HOST_DATA_RDONLY copies what the device holds newer than the host and returns with the copy done.  A host
+  ! that wants single members or an asynchronous queue calls the methods itself: CALL VARS_4D%SYNC_HOST_RDONLY(FL1=.TRUE., QUEUE=4) ...
   ! CALL WAIT_FOR_ASYNC_QUEUE(QUEUE=4), as wamintgr_loki_gpu.F90:197-200 / wamodel.F90:376 do
   IF (LFIELDS) THEN
-    CALL FF_NOW%SYNC_HOST_RDONLY()
-    CALL INTFLDS%SYNC_HOST_RDONLY()
-    CALL MIJ%SYNC_HOST_RDONLY()
+    CALL FF_NOW%GET_HOST_DATA_RDONLY()
+    CALL INTFLDS%GET_HOST_DATA_RDONLY()
+    CALL MIJ%GET_HOST_DATA_RDONLY()
   ENDIF
-  IF (LSPECTRA) CALL VARS_4D%SYNC_HOST_RDONLY()
-  ! pad lanes of the last chunk keep the value of lane 1 (propag_wam.F90:388-398) -- done by POINTS_TO_CHUNKS
+  IF (LSPECTRA) CALL VARS_4D%GET_HOST_DATA_RDONLY()
+  ! pad lanes of the last chunk keep the value of lane 1 (propag_wam.F90:388-398) -- done by POINTS_TO_CHUNKS / MEMBER_GATHER
 
 END SUBROUTINE ECWAM_HIP_SYNC_HOST
 END MODULE ECWAM_HIP_HOSTSYNC
@@ -92,70 +99,38 @@ SUBROUTINE WAMINTGR_HIP (CDTPRA, CDATE, CDATEWH, CDTIMP, CDTIMPNEXT,  &
   TYPE(TYPE_4D), INTENT(INOUT)            :: VARS_4D
 
   TYPE(C_PTR) :: S0, DTMP
-  INTEGER(C_LONG_LONG) :: NSPEC
-  INTEGER :: IJ, ICH, IP, M, NP, NPROMA, NFRE, NANG, ISUB
-  INTEGER(C_INT) :: IRC, NPASS, PMS(2), PME(2), PCP(2), PRG(2)
+  INTEGER :: NP, NPROMA, NFRE, NANG, ISUB
+  INTEGER(C_INT) :: NPASS, PMS(2), PME(2), PCP(2), PRG(2)
   REAL(C_DOUBLE) :: PDEL(2)
-  REAL(KIND=JWRB), ALLOCATABLE, TARGET, SAVE :: H_WV(:,:,:)
-  LOGICAL :: LSOURCE_NOW, LFIRST
+  LOGICAL :: LSOURCE_NOW
 
   S0 = HIPST%QUEUE(0)     ! every kernel and copy of the step on the compute queue (a non-blocking stream)
   NP = HIPST%NPTS; NPROMA = HIPST%NPROMA; NFRE = HIPST%NFRE; NANG = HIPST%NANG
-  NSPEC = INT(NANG, C_LONG_LONG) * NFRE
   IF (.NOT. C_ASSOCIATED(HIPST%CTX)) THEN
     WRITE(0,*) 'WAMINTGR_HIP: ECWAM_HIP_SETUP has not been called'
     ERROR STOP 1
   ENDIF
 
-  ! ---- first call: spectra and wave properties to the device (GET_DEVICE_DATA_RDWR of the OpenACC variant,
-  !      wamintgr_loki_gpu.F90:100-105); chunked FL1(NPROMA,NANG,NFRE,NCHNK) -> FL[ij][K][M] on the device
-  LFIRST = .NOT. HIPST%LSPECTRA_ON_DEVICE
-  IF (LFIRST) THEN
-    ! page-locked host spectra (wvalloc.F90:49-52 pins them when WAM_HAVE_CUDA): once per address, released by ECWAM_HIP_FINALIZE
-    CALL HIP_REGISTER_SPECTRA(C_LOC(VARS_4D%FL1), C_LOC(VARS_4D%XLLWS), RBYTES(INT(NPROMA, C_LONG_LONG) * HIPST%NCHNK * NSPEC))
-    CALL ECWAM_HIP_CHECK(ECWAM_HIP_MEMCPY_H2D(HIPST%CTX, HIPST%D_CHUNK, C_LOC(VARS_4D%FL1), &
- &        RBYTES(INT(NPROMA, C_LONG_LONG) * HIPST%NCHNK * NSPEC), S0), 'H2D FL1')
-    CALL ECWAM_HIP_CHECK(ECWAM_HIP_CHUNKS_TO_POINTS(HIPST%CTX, HIPST%D_CHUNK, HIPST%D_FL1, NPROMA, HIPST%NCHNK, NP, NANG, NFRE, S0), &
- &        'CHUNKS_TO_POINTS')
-    HIPST%LGFAST_VALID = .FALSE.
+  ! FF_NOW works on the device rows IMPLSCH reads and writes, FF_NEXT on the rows NEWWIND reads
+  CALL ECWAM_HIP_BIND_FORCING(FF_NOW, FF_NEXT)
+  IF (HIP_LFF_NOW_CHANGED) THEN      ! the host changed them without saying so through GET_HOST_DATA_RDWR: its copies are the valid ones
+    FF_NOW%HIP%ST(:) = HIP_HOST_FRESH
+    IF (ASSOCIATED(WVENVI%HIP)) WVENVI%HIP%ST(:) = HIP_HOST_FRESH
+    HIP_LFF_NOW_CHANGED = .FALSE.
   ENDIF
-  IF (LFIRST .OR. HIP_LWVPRPT_CHANGED) THEN
-    IF (.NOT. ALLOCATED(H_WV)) ALLOCATE(H_WV(NFRE, NWPR, NP))
-    DO IJ = 1, NP
-      ICH = (IJ - 1) / NPROMA + 1; IP = IJ - (ICH - 1) * NPROMA
-      DO M = 1, NFRE
-        H_WV(M,1,IJ) = WVPRPT%WAVNUM(IP,M,ICH); H_WV(M,2,IJ) = WVPRPT%CGROUP(IP,M,ICH); H_WV(M,3,IJ) = WVPRPT%CINV(IP,M,ICH)
-        H_WV(M,4,IJ) = WVPRPT%XK2CG(IP,M,ICH); H_WV(M,5,IJ) = WVPRPT%STOKFAC(IP,M,ICH)
-      ENDDO
-    ENDDO
-    CALL ECWAM_HIP_CHECK(ECWAM_HIP_MEMCPY_H2D(HIPST%CTX, HIPST%D_WVPRPT, C_LOC(H_WV), RBYTES(INT(NP, C_LONG_LONG) * NWPR * NFRE), S0), &
- &        'H2D WVPRPT')
-    CALL ECWAM_HIP_CHECK(ECWAM_HIP_SYNC(HIPST%CTX, S0), 'SYNC')
+  IF (HIP_LWVPRPT_CHANGED) THEN
+    WVPRPT%HIP%ST(:) = HIP_HOST_FRESH
     HIP_LWVPRPT_CHANGED = .FALSE.
   ENDIF
-  IF (LFIRST) THEN
-    DO IJ = 1, NP
-      ICH = (IJ - 1) / NPROMA + 1; IP = IJ - (ICH - 1) * NPROMA
-      HIPST%H_INTF(:,IJ) = 0.0_JWRB
-      HIPST%H_INTF(1,IJ) = INTFLDS%WSEMEAN(IP,ICH); HIPST%H_INTF(2,IJ) = INTFLDS%WSFMEAN(IP,ICH)
-      HIPST%H_INTF(5,IJ) = INTFLDS%STRNMS(IP,ICH)
-      ! slot 16 of the row is an INPUT: ENVIRONMENT%IBRMEM, read by IMPLSCH when LWNEMOCOUIBR (icebreak_modify_attenuation.F90)
-      IF (ASSOCIATED(WVENVI%IBRMEM)) HIPST%H_INTF(16,IJ) = WVENVI%IBRMEM(IP,ICH)
-    ENDDO
-    CALL ECWAM_HIP_CHECK(ECWAM_HIP_MEMCPY_H2D(HIPST%CTX, HIPST%D_INTF, C_LOC(HIPST%H_INTF), RBYTES(INT(NP, C_LONG_LONG) * NINTF), S0), &
- &        'H2D INTF')
-    CALL ECWAM_HIP_CHECK(ECWAM_HIP_SYNC(HIPST%CTX, S0), 'SYNC')
-    HIPST%LSPECTRA_ON_DEVICE = .TRUE.
-  ENDIF
 
-  ! ---- forcing at the current time (FF_NOW) + the two ENVIRONMENT members IMPLSCH reads: device resident; new winds arrive through
-  !      FF_NEXT / NEWWIND below, the outputs of IMPLSCH (UFRIC, TAUW, Z0M ...) never leave the device unless asked for
-  IF (LFIRST .OR. HIP_LFF_NOW_CHANGED .OR. HIPST%LFF_NOW_STALE) THEN
-    CALL PACK_FF(FF_NOW, HIPST%H_FF)
-    CALL ECWAM_HIP_CHECK(ECWAM_HIP_MEMCPY_H2D(HIPST%CTX, HIPST%D_FF, C_LOC(HIPST%H_FF), RBYTES(INT(NP, C_LONG_LONG) * NFF), S0), 'H2D FF')
-    CALL ECWAM_HIP_CHECK(ECWAM_HIP_SYNC(HIPST%CTX, S0), 'SYNC')
-    HIP_LFF_NOW_CHANGED = .FALSE.; HIPST%LFF_NOW_STALE = .FALSE.
-  ENDIF
+  ! ---- wamintgr_loki_gpu.F90:99-105: the copies the host posted on queue 1 (wamodel.F90:209-214) have arrived; whatever the host holds
+  !      newer than the device goes up now (first call: everything; later: nothing), FL1 becomes the device's to change
+  CALL WAIT_FOR_ASYNC_QUEUE(QUEUE=1)
+  CALL VARS_4D%GET_DEVICE_DATA_RDWR(FL1=.TRUE.)
+  CALL WVPRPT%GET_DEVICE_DATA_RDONLY()
+  CALL WVENVI%GET_DEVICE_DATA_RDONLY(DEPTH=.TRUE., DELLAM1=.TRUE., COSPHM1=.TRUE., UCUR=.TRUE., VCUR=.TRUE., &
+ &                                   EMAXDPT=.TRUE., IOBND=.TRUE., IODP=.TRUE., IBRMEM=.TRUE.)
+  CALL BLK2GLO%GET_DEVICE_DATA_RDONLY()
 
   !*     PROPAGATION TIME (wamintgr.F90:94-100)
   IF (CDATE == CDTPRA) THEN
@@ -225,12 +200,16 @@ SUBROUTINE WAMINTGR_HIP (CDTPRA, CDATE, CDATEWH, CDTIMP, CDTIMPNEXT,  &
     CDATE = HIP_CDTPRO
   ENDIF
 
-  !* RETRIEVING NEW FORCING FIELDS IF NEEDED (wamintgr.F90:105, newwind.F90:107-174)
+  !* RETRIEVING NEW FORCING FIELDS IF NEEDED (wamintgr.F90:105, newwind.F90:107-174; wamintgr_loki_gpu.F90:121-131)
+  CALL WAIT_FOR_ASYNC_QUEUE(QUEUE=2)
+  CALL FF_NOW%GET_DEVICE_DATA_RDWR(AIRD=.TRUE., WDWAVE=.TRUE., CICOVER=.TRUE., WSWAVE=.TRUE.,  &
+ & WSTAR=.TRUE., UFRIC=.TRUE., TAUW=.TRUE., TAUWDIR=.TRUE., Z0M=.TRUE., Z0B=.TRUE.,  &
+ & CHRNCK=.TRUE., CITHICK=.TRUE., USTRA=.TRUE., VSTRA=.TRUE.)
+  CALL FF_NEXT%GET_DEVICE_DATA_RDONLY(AIRD=.TRUE., WDWAVE=.TRUE., CICOVER=.TRUE., WSWAVE=.TRUE.,  &
+ & WSTAR=.TRUE., UFRIC=.TRUE., TAUW=.TRUE., TAUWDIR=.TRUE., Z0M=.TRUE., Z0B=.TRUE.,  &
+ & CHRNCK=.TRUE., CITHICK=.TRUE., USTRA=.TRUE., VSTRA=.TRUE.)
   IF (CDTIMP >= CDATEWH) THEN
     IF (CDTIMP >= HIP_CDATEFL) HIP_LLNEWFILE = .TRUE.     ! newwind.F90:110-112
-    CALL PACK_FF(FF_NEXT, HIPST%H_INTF)   ! staging reuse: same (16,NPTS) shape
-    CALL ECWAM_HIP_CHECK(ECWAM_HIP_MEMCPY_H2D(HIPST%CTX, HIPST%D_FFN, C_LOC(HIPST%H_INTF), RBYTES(INT(NP, C_LONG_LONG) * NFF), S0), &
- &        'H2D FF_NEXT')
     IF (HIP_ICODE_WND /= 0) THEN
       CALL ECWAM_HIP_CHECK(ECWAM_HIP_NEWWIND_ICODE(HIPST%CTX, NP, HIPST%D_FF, HIPST%D_FFN, HIP_ICODE_WND, S0), 'ECWAM_HIP_NEWWIND')
     ELSE
@@ -242,22 +221,38 @@ SUBROUTINE WAMINTGR_HIP (CDTPRA, CDATE, CDATEWH, CDTIMP, CDTIMPNEXT,  &
   ! IT IS TIME TO INTEGRATE THE SOURCE TERMS (wamintgr.F90:110-186)
   LSOURCE_NOW = (CDATE >= CDTIMPNEXT)
   IF (LSOURCE_NOW .AND. HIP_LLSOURCE) THEN
-    IF (HIPST%LWNEMOCOU) THEN   ! the accumulating WAVE2OCEAN members go in, all 13 come back
-      CALL PACK_W2N()
-      CALL ECWAM_HIP_CHECK(ECWAM_HIP_MEMCPY_H2D(HIPST%CTX, HIPST%D_W2N, C_LOC(HIPST%H_W2N), 8_C_LONG_LONG * 13 * NP, S0), 'H2D W2N')
+    ! wamintgr_loki_gpu.F90:139-157: the accumulating WAVE2OCEAN members travel up when the host holds newer values (after UPDNEMOSTRESS
+    ! reset them, wamodel.F90:617-640), everything IMPLSCH writes becomes the device's
+    CALL WAIT_FOR_ASYNC_QUEUE(QUEUE=3)
+    IF (HIPST%LWNEMOCOU .AND. (.NOT. HIPST%LWCOU)) THEN
+      CALL WAM2NEMO%GET_DEVICE_DATA_RDWR(NEMOTAUICX=.TRUE., NEMOTAUICY=.TRUE., NEMOWSWAVE=.TRUE., NEMOPHIF=.TRUE., &
+ &      NPHIEPS=.TRUE., NTAUOC=.TRUE., NSWH=.TRUE., NMWP=.TRUE., NEMOTAUX=.TRUE., NEMOTAUY=.TRUE.)
+    ELSE
+      CALL WAM2NEMO%GET_DEVICE_DATA_WRONLY(NEMOTAUICX=.TRUE., NEMOTAUICY=.TRUE., NEMOWSWAVE=.TRUE., NEMOPHIF=.TRUE., &
+ &      NPHIEPS=.TRUE., NTAUOC=.TRUE., NSWH=.TRUE., NMWP=.TRUE., NEMOTAUX=.TRUE., NEMOTAUY=.TRUE.)
     ENDIF
+    CALL WAM2NEMO%GET_DEVICE_DATA_WRONLY(NEMOUSTOKES=.TRUE., NEMOVSTOKES=.TRUE., NEMOSTRN=.TRUE.)
+    CALL INTFLDS%GET_DEVICE_DATA_WRONLY(WSEMEAN=.TRUE., WSFMEAN=.TRUE., USTOKES=.TRUE., &
+ &    VSTOKES=.TRUE., STRNMS=.TRUE., TAUXD=.TRUE., TAUYD=.TRUE., TAUOCXD=.TRUE., &
+ &    TAUOCYD=.TRUE., TAUOC=.TRUE., PHIOCD=.TRUE., PHIEPS=.TRUE., PHIAW=.TRUE., &
+ &    TAUICX=.TRUE., TAUICY=.TRUE.)
+    CALL VARS_4D%GET_DEVICE_DATA_WRONLY(XLLWS=.TRUE.)
+    CALL MIJ%GET_DEVICE_DATA_WRONLY()
     CALL FAST_SINK(.TRUE.)      ! IMPLSCH leaves the fast waves of its result in the compact rows as well
     CALL ECWAM_HIP_CHECK(ECWAM_HIP_IMPLSCH(HIPST%CTX, 0_C_INT, NP, HIPST%D_FL1, HIPST%D_WVPRPT, HIPST%D_FF, HIPST%D_INTF, &
  &        HIPST%D_MIJ, HIPST%D_XLLWS, HIPST%D_W2N, C_NULL_PTR, S0), 'ECWAM_HIP_IMPLSCH')
     CALL FAST_SINK(.FALSE.)
-    IF (HIPST%LWNEMOCOU) THEN
-      CALL ECWAM_HIP_CHECK(ECWAM_HIP_MEMCPY_D2H(HIPST%CTX, C_LOC(HIPST%H_W2N), HIPST%D_W2N, 8_C_LONG_LONG * 13 * NP, S0), 'D2H W2N')
-      CALL ECWAM_HIP_CHECK(ECWAM_HIP_SYNC(HIPST%CTX, S0), 'SYNC')
-      CALL UNPACK_W2N()
-      HIP_NEMONTAU = HIP_NEMONTAU + 1      ! wamintgr.F90:150 / wamintgr_loki_gpu.F90:203
+    IF (HIP_LSYNC_EAGER) THEN      ! wamintgr_loki_gpu.F90:197-200
+      CALL VARS_4D%SYNC_HOST_RDONLY(FL1=.TRUE., QUEUE=4)
+      CALL FF_NOW%SYNC_HOST_RDONLY(QUEUE=4)
+      CALL WVENVI%SYNC_HOST_RDONLY(QUEUE=5)
+      IF (HIPST%LWNEMOCOU .AND. (.NOT. HIPST%LWCOU)) CALL WAM2NEMO%SYNC_HOST_RDONLY(QUEUE=6)
     ENDIF
+    IF (HIPST%LWNEMOCOU) HIP_NEMONTAU = HIP_NEMONTAU + 1      ! wamintgr.F90:150 / wamintgr_loki_gpu.F90:203
   ELSEIF (LSOURCE_NOW) THEN
     ! NO SOURCE TERM CONTRIBUTION (wamintgr.F90:152-160): MIJ = NFRE, FL1 = MAX(FL1, EPSMIN), XLLWS = 0 -- on the device copies
+    CALL VARS_4D%GET_DEVICE_DATA_WRONLY(XLLWS=.TRUE.)
+    CALL MIJ%GET_DEVICE_DATA_WRONLY()
     CALL FAST_SINK(.TRUE.)
     CALL ECWAM_HIP_CHECK(ECWAM_HIP_NOSOURCE(HIPST%CTX, 0_C_INT, NP, HIPST%D_FL1, HIPST%D_MIJ, HIPST%D_XLLWS, S0), 'ECWAM_HIP_NOSOURCE')
     CALL FAST_SINK(.FALSE.)
@@ -276,6 +271,8 @@ SUBROUTINE WAMINTGR_HIP (CDTPRA, CDATE, CDATEWH, CDTIMP, CDTIMPNEXT,  &
     IF (ASSOCIATED(HIP_INCDATE)) CALL HIP_INCDATE(CDTIMPNEXT, HIP_IDELT)
   ELSE
     ! not yet time for the source terms (wamintgr.F90:178-186): MIJ = NFRE, XLLWS = 0, the spectra as advected
+    CALL VARS_4D%GET_DEVICE_DATA_WRONLY(XLLWS=.TRUE.)
+    CALL MIJ%GET_DEVICE_DATA_WRONLY()
     CALL ECWAM_HIP_CHECK(ECWAM_HIP_NOSOURCE(HIPST%CTX, 0_C_INT, NP, C_NULL_PTR, HIPST%D_MIJ, HIPST%D_XLLWS, S0), 'ECWAM_HIP_NOSOURCE')
   ENDIF
 
@@ -344,42 +341,5 @@ CONTAINS
         CALL ADVECT_REFRA(PDEL(I), PMS(I), PME(I), PCP(I), PRG(I), HIPST%KIJL_INT, NP)
       ENDDO
     ENDIF
-  END SUBROUTINE
-  SUBROUTINE PACK_W2N()
-    INTEGER :: JJ, JC, JP
-    DO JJ = 1, NP
-      JC = (JJ - 1) / NPROMA + 1; JP = JJ - (JC - 1) * NPROMA
-      HIPST%H_W2N(1,JJ) = WAM2NEMO%NEMOUSTOKES(JP,JC); HIPST%H_W2N(2,JJ) = WAM2NEMO%NEMOVSTOKES(JP,JC)
-      HIPST%H_W2N(3,JJ) = WAM2NEMO%NEMOSTRN(JP,JC); HIPST%H_W2N(4,JJ) = WAM2NEMO%NPHIEPS(JP,JC)
-      HIPST%H_W2N(5,JJ) = WAM2NEMO%NTAUOC(JP,JC); HIPST%H_W2N(6,JJ) = WAM2NEMO%NSWH(JP,JC); HIPST%H_W2N(7,JJ) = WAM2NEMO%NMWP(JP,JC)
-      HIPST%H_W2N(8,JJ) = WAM2NEMO%NEMOTAUX(JP,JC); HIPST%H_W2N(9,JJ) = WAM2NEMO%NEMOTAUY(JP,JC)
-      HIPST%H_W2N(10,JJ) = WAM2NEMO%NEMOTAUICX(JP,JC); HIPST%H_W2N(11,JJ) = WAM2NEMO%NEMOTAUICY(JP,JC)
-      HIPST%H_W2N(12,JJ) = WAM2NEMO%NEMOWSWAVE(JP,JC); HIPST%H_W2N(13,JJ) = WAM2NEMO%NEMOPHIF(JP,JC)
-    ENDDO
-  END SUBROUTINE
-  SUBROUTINE UNPACK_W2N()
-    INTEGER :: JJ, JC, JP
-    DO JJ = 1, NP
-      JC = (JJ - 1) / NPROMA + 1; JP = JJ - (JC - 1) * NPROMA
-      WAM2NEMO%NEMOUSTOKES(JP,JC) = HIPST%H_W2N(1,JJ); WAM2NEMO%NEMOVSTOKES(JP,JC) = HIPST%H_W2N(2,JJ)
-      WAM2NEMO%NEMOSTRN(JP,JC) = HIPST%H_W2N(3,JJ); WAM2NEMO%NPHIEPS(JP,JC) = HIPST%H_W2N(4,JJ)
-      WAM2NEMO%NTAUOC(JP,JC) = HIPST%H_W2N(5,JJ); WAM2NEMO%NSWH(JP,JC) = HIPST%H_W2N(6,JJ); WAM2NEMO%NMWP(JP,JC) = HIPST%H_W2N(7,JJ)
-      WAM2NEMO%NEMOTAUX(JP,JC) = HIPST%H_W2N(8,JJ); WAM2NEMO%NEMOTAUY(JP,JC) = HIPST%H_W2N(9,JJ)
-      WAM2NEMO%NEMOTAUICX(JP,JC) = HIPST%H_W2N(10,JJ); WAM2NEMO%NEMOTAUICY(JP,JC) = HIPST%H_W2N(11,JJ)
-      WAM2NEMO%NEMOWSWAVE(JP,JC) = HIPST%H_W2N(12,JJ); WAM2NEMO%NEMOPHIF(JP,JC) = HIPST%H_W2N(13,JJ)
-    ENDDO
-  END SUBROUTINE
-  SUBROUTINE PACK_FF(FF, H)
-    TYPE(FORCING_FIELDS), INTENT(IN) :: FF
-    REAL(KIND=JWRB), INTENT(OUT) :: H(:,:)
-    INTEGER :: JJ, JC, JP
-    DO JJ = 1, NP
-      JC = (JJ - 1) / NPROMA + 1; JP = JJ - (JC - 1) * NPROMA
-      H(1,JJ) = FF%AIRD(JP,JC); H(2,JJ) = FF%WDWAVE(JP,JC); H(3,JJ) = FF%CICOVER(JP,JC); H(4,JJ) = FF%WSWAVE(JP,JC)
-      H(5,JJ) = FF%WSTAR(JP,JC); H(6,JJ) = FF%USTRA(JP,JC); H(7,JJ) = FF%VSTRA(JP,JC); H(8,JJ) = FF%UFRIC(JP,JC)
-      H(9,JJ) = FF%TAUW(JP,JC); H(10,JJ) = FF%TAUWDIR(JP,JC); H(11,JJ) = FF%Z0M(JP,JC); H(12,JJ) = FF%Z0B(JP,JC)
-      H(13,JJ) = FF%CHRNCK(JP,JC); H(14,JJ) = FF%CITHICK(JP,JC)
-      H(15,JJ) = WVENVI%EMAXDPT(JP,JC); H(16,JJ) = WVENVI%DEPTH(JP,JC)
-    ENDDO
   END SUBROUTINE
 END SUBROUTINE WAMINTGR_HIP

@@ -39,7 +39,7 @@ extern "C" {
 #define ECWAM_HIP_MAXANG 48
 /* bumped whenever ecwam_hip_params / ecwam_hip_tables or an entry point changes: 2 = refraction entry points, SDICE1 table and
  * ice break-up parameters added.  ecwam_hip_abi_version() returns the value the library was built with. */
-#define ECWAM_HIP_ABI_VERSION 3
+#define ECWAM_HIP_ABI_VERSION 4
 #define ECWAM_HIP_MAXFRE 48
 #define ECWAM_HIP_MAXMC 56     /* MLSTHG = NFRE - ISM <= 48 + 8 */
 #define ECWAM_HIP_MAXTAP 47    /* 2*NSDSNTH+1, NSDSNTH <= NANG/2-1 */
@@ -322,6 +322,23 @@ int ecwam_hip_chunks_to_points(ecwam_hip_ctx *ctx, const void *chunked, void *po
                                int n2, int n3, void *stream);
 int ecwam_hip_points_to_chunks(ecwam_hip_ctx *ctx, const void *points, void *chunked, int nproma, int nchnk, int npts,
                                int n2, int n3, void *stream);
+
+/*
+ * One member of a FIELD_API-backed host type <-> its slot in the library's packed per-point rows: what FIELD_API's per-member
+ * GET_DEVICE_DATA_* / SYNC_DEVICE_* (host -> device) and GET_HOST_DATA_* / SYNC_HOST_* (device -> host) copies are in the reference's
+ * GPU build (drvtype_mod.fypp:116-480; the member selectors of wamodel.F90:207-226,376-385,435-470,614-642 and
+ * wamintgr_loki_gpu.F90:100-157,197-200), for a device layout that is not the host's.
+ *   chunked: DEVICE image of the host member M(NPROMA[,NM],NCHNK) (Fortran order, as copied with ecwam_hip_memcpy_h2d / _d2h),
+ *     elements of elem_bytes = 4 or 8 bytes (JWRB reals, JWRO doubles, JWIM integers move alike);
+ *   rows: device [npts][row_stride] elements of the same size; the member's NM values of point ij at rows[ij*row_stride + row_off .. + NM):
+ *     FF rows (row_stride 16: the 14 FORCING_FIELDS members + ENVIRONMENT%EMAXDPT, %DEPTH), INTF rows (16: 15 INTGT_PARAM_FIELDS members +
+ *     ENVIRONMENT%IBRMEM), WAVE2OCEAN rows (13 doubles), WVPRPT rows (5*NFRE: member j at row_off j*NFRE, NM = NFRE), MIJ (1 int32);
+ *   scatter: chunked -> rows for the npts points; gather: rows -> chunked, pad lanes of the last chunk replicating its lane 1.
+ */
+int ecwam_hip_member_scatter(ecwam_hip_ctx *ctx, const void *chunked, void *rows, int nproma, int nchnk, int npts, int nm,
+                             long long row_stride, long long row_off, int elem_bytes, void *stream);
+int ecwam_hip_member_gather(ecwam_hip_ctx *ctx, const void *rows, void *chunked, int nproma, int nchnk, int npts, int nm,
+                            long long row_stride, long long row_off, int elem_bytes, void *stream);
 
 /* Halo pack/unpack for the advection exchange (mpexchng.F90:124-138, 217-231):
  *   pack:   buf[i][:] = fl[idx[i]][:]   for i < n   (row = NANG*NFRE reals)

@@ -91,7 +91,7 @@ def _write_case(path, m, cfg, grid, nproma, nstep, obs=None, nosource=False, dom
     return nchnk
 
 
-def _read_out(path, dt, nproma, nchnk, nang, nfre, n):
+def _read_out(path, dt, nproma, nchnk, nang, nfre, n, nemo=None):
     """The harness' output file -> point-major arrays of the n owned points."""
     raw = np.fromfile(path, dtype=np.uint8)
     nsp = nproma * nang * nfre * nchnk
@@ -105,10 +105,12 @@ def _read_out(path, dt, nproma, nchnk, nang, nfre, n):
     ij = np.arange(n)
     out = dict(FL1=fl_f[ij % nproma, :, :, ij // nproma], XLLWS=xl_f[ij % nproma, :, :, ij // nproma], MIJ=mij_f[ij % nproma, ij // nproma],
                FF=ff_f[ij % nproma, ij // nproma, :], INTF=in_f[ij % nproma, ij // nproma, :], raw_fl=fl_f)
-    if off < raw.size:      # LWNEMOCOU: NEMONTAU and the 13 WAVE2OCEAN members (double), in the order of the device rows
+    if (off < raw.size) if nemo is None else nemo:      # LWNEMOCOU: NEMONTAU and the 13 WAVE2OCEAN members (double), in the order of the device rows
         out["NEMONTAU"] = int(np.frombuffer(raw, dtype=np.int32, count=1, offset=off)[0]); off += 4
         w = np.frombuffer(raw, dtype=np.float64, count=13 * nproma * nchnk, offset=off).reshape((nproma, nchnk, 13), order="F")
         out["W2N"] = w[ij % nproma, ij // nproma, :]
+        off += 8 * 13 * nproma * nchnk
+    out["_rest"] = raw[off:]
     return out
 
 
@@ -225,4 +227,84 @@ def test_fortran_two_processes_on_one_gpu_match_single_domain(tmp_path, prec, lf
     assert all(o["NEMONTAU"] == nstep for o in outs)
     got, want = cat("W2N"), w2n.cpu().numpy()
     assert np.array_equal(got, want) and np.abs(want[:, 7]).max() > 0        # NEMOTAUX accumulated over the two steps
+    m.ctx.close()
+
+
+@pytest.mark.parametrize("prec,nemo", [("sp", True), ("dp", True), ("sp", False)])
+def test_fortran_seam_sequence_replays_the_reference_call_lines(tmp_path, prec, nemo):
+    """The complete FIELD_API call sequence of the reference's GPU build around the seam (ecwam_amd/fortran/seam_sequence.F90: the lines of
+    wamodel.F90:207-226,376-385,435-470,614-642,651-671 and wamintgr_loki_gpu.F90:100-157,197-200 as they stand, WAMINTGR_HIP in the place
+    of WAMINTGR_LOKI_GPU) on the host types of yowdrvtype_hip.F90: initial copies on queues 1-3, per-step copies back on queues 4 (FL1,
+    FF_NOW), 5 (WVENVI) and 6 (WAM2NEMO), an output step, a restart step, two NEMO coupling steps (UPDNEMOSTRESS averages and resets the
+    accumulated stresses on the host, SYNC_DEVICE_RDWR sends them back on queue 3), new winds through FF_NEXT, the final
+    GET_HOST_DATA_RDWR / DELETE_DEVICE_DATA.  Every host array it ends with, the spectra it read at the output step and the stresses it
+    handed to 'NEMO' equal the Python host driving the same C ABI bit for bit; the harness itself stops if a call copies something the
+    other side did not change (device -> host only for what the device wrote)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ecwam_amd import build, grid as G
+    from ecwam_amd.wamintgr import Wamintgr
+
+    exe = build.fortran_exe(prec, "seam_sequence")
+    if not os.path.exists(exe):
+        build.build_fortran()
+    cfg = Config(nang=12, nfre=36, nfre_red=25, idelt=900, idelpro=900, lwnemocou=nemo)
+    g = G.build_grid(16, mask="continents")
+    m = Wamintgr(cfg, g, prec)
+    m.init_synthetic(seed=33)
+    nproma, nstep, n = 24, 4, g.nsea
+    case, out = str(tmp_path / "case.bin"), str(tmp_path / "out.bin")
+    nchnk = _write_case(case, m, cfg, g, nproma, nstep)
+    r = subprocess.run([exe, case, out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "seam_sequence: ok" in r.stdout, r.stdout + r.stderr
+    ffn0 = m.ff.clone()
+    w2n = torch.zeros((n, 13), dtype=torch.float64, device=m.dev) if nemo else None
+    acc = [7, 8, 11, 12, 9, 10]      # NEMOTAUX, NEMOTAUY, NEMOWSWAVE, NEMOPHIF, NEMOTAUICX, NEMOTAUICY in the device rows
+    avgs, fl_out, ufric_out = [], None, None
+    for k in range(1, nstep + 1):
+        m.ff_next = None
+        if k == 3:      # new winds in FF_NEXT, handed over by NEWWIND inside this step
+            ffn = ffn0.clone()
+            ffn[:, 3] = ffn[:, 3] * 1.1
+            ffn[:, 1] = ffn[:, 1] + 0.3
+            ffn[:, 2] = ffn[:, 2] * 0.5
+            m.ff_next = ffn
+        m.propag()
+        m.newwind()
+        m.implsch(wam2nemo=w2n)
+        if k == 2:
+            fl_out, ufric_out = m.fl1[:n].cpu().numpy().copy(), m.ff[:, 7].cpu().numpy().copy()
+        if nemo and k % 2 == 0:      # UPDNEMOSTRESS: average over the two steps, reset
+            avgs.append((w2n[:, acc] * 0.5).cpu().numpy())
+            w2n[:, acc] = 0.0
+    torch.cuda.synchronize()
+    dt = m.npdt
+    o = _read_out(out, dt, nproma, nchnk, cfg.nang, cfg.nfre, n, nemo=nemo)
+    assert np.array_equal(o["FL1"], m.fl1.cpu().numpy()[:n])
+    assert np.array_equal(o["XLLWS"], m.xllws.cpu().numpy())
+    assert np.array_equal(o["MIJ"], m.mij.cpu().numpy())
+    assert np.array_equal(o["FF"], m.ff.cpu().numpy()[:, :14])
+    assert np.array_equal(o["INTF"], m.intf.cpu().numpy()[:, :15])
+    rest = o["_rest"]
+    ij = np.arange(n)
+    off = 0
+    if nemo:
+        assert o["NEMONTAU"] == nstep and np.array_equal(o["W2N"], w2n.cpu().numpy())
+    ncoup = int(np.frombuffer(rest, dtype=np.int32, count=1, offset=off)[0]); off += 4
+    assert ncoup == (2 if nemo else 0)
+    if ncoup:
+        sa = np.frombuffer(rest, dtype=np.float64, count=nproma * nchnk * 6 * ncoup, offset=off).reshape((nproma, nchnk, 6, ncoup), order="F")
+        off += 8 * nproma * nchnk * 6 * ncoup
+        for c in range(ncoup):
+            assert np.array_equal(sa[ij % nproma, ij // nproma, :, c], avgs[c]) and np.abs(avgs[c][:, 0]).max() > 0
+    nsp = nproma * cfg.nang * cfg.nfre * nchnk
+    isz = np.dtype(dt).itemsize
+    fl_f = np.frombuffer(rest, dtype=dt, count=nsp, offset=off).reshape((nproma, cfg.nang, cfg.nfre, nchnk), order="F"); off += nsp * isz
+    uf_f = np.frombuffer(rest, dtype=dt, count=nproma * nchnk, offset=off).reshape((nproma, nchnk), order="F"); off += nproma * nchnk * isz
+    assert np.array_equal(fl_f[ij % nproma, :, :, ij // nproma], fl_out)        # what the host read at its output step (queue 4)
+    assert np.array_equal(uf_f[ij % nproma, ij // nproma], ufric_out)
+    nh2d, nd2h, bh2d, bd2h = (int(x) for x in np.frombuffer(rest, dtype=np.int64, count=4, offset=off))
+    # FL1 travels up once (+ the five FREQUENCY members: 5/12 of its size here, + the per-point fields) and comes down once per step;
+    # XLLWS once (the test's own request at the end)
+    assert nsp * isz <= bh2d < 2 * nsp * isz and (nstep + 1) * nsp * isz <= bd2h < (nstep + 2) * nsp * isz, (nh2d, nd2h, bh2d, bd2h)
     m.ctx.close()

@@ -65,8 +65,8 @@ class Oracle:
         rc = self.lib.ora_init(C.byref(oc))
         if rc:
             raise RuntimeError(f"ora_init failed rc={rc}")
-        if getattr(cfg, "lciwa1", False):   # SDICE1's tabulated block: the product's data file (cigetdeac.F90:85-552)
-            raw = np.ascontiguousarray(np.loadtxt(os.path.join(_HERE, "..", "ecwam_amd", "data", "cideac_kohout_meylan.txt")), dtype=np.float64)
+        if getattr(cfg, "lciwa1", False):   # SDICE1's tabulated block (cigetdeac.F90:85-552): the oracle's own copy of the data table
+            raw = np.ascontiguousarray(np.loadtxt(os.path.join(_HERE, "data", "cideac_kohout_meylan.txt")), dtype=np.float64)
             assert raw.shape == (36, 11)
             self.lib.ora_set_cideac(raw.ctypes.data_as(C.c_void_p))
         self.cfg = cfg

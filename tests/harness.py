@@ -33,8 +33,13 @@ def make_point_case(n: int, cfg: Config, prec: str, seed: int = 12345, spectra: 
 
 
 def oracle_implsch(case: dict, oracle, want_dbg=False) -> dict:
-    pr = case["props"]
-    return oracle.implsch(case["FL1"], pr["WAVNUM"], pr["CGROUP"], pr["CINV"], pr["XK2CG"], pr["STOKFAC"], case["ENV"], case["FF"],
+    """The oracle on ITS OWN wave-property tables: DEPTHPRPT / AKI / EMAXDPT restated in oracle/ora_tables.c from the same depths, not the
+    product's numpy tables (ecwam_amd/synthetic.py) that the device side is fed with -- the two agree to a few units in the last place
+    (tests/test_known_answers.py::test_depth_props_of_the_product_and_of_the_oracle_agree), and neither side checks itself with the other's."""
+    depth = np.ascontiguousarray(case["ENV"][:, 1])
+    pr = oracle.depthprpt(depth)
+    env = np.stack([pr["EMAXDPT"], depth], 1).astype(case["ENV"].dtype)
+    return oracle.implsch(case["FL1"], pr["WAVNUM"], pr["CGROUP"], pr["CINV"], pr["XK2CG"], pr["STOKFAC"], env, case["FF"],
                           case["INTF"], want_dbg=want_dbg, w2n=case.get("W2N"), ibrmem=case.get("IBRMEM"))
 
 

@@ -135,3 +135,44 @@ def test_drag_law_without_wave_stress():
     o.lib.ora_taut_z0(C.c_double(15.0), C.c_double(0.0), C.c_double(0.0), C.c_double(0.0), C.c_double(0.0), C.c_double(1.0), _p(out0))
     o.lib.ora_taut_z0(C.c_double(15.0), C.c_double(0.0), C.c_double(0.6 * out0[0] ** 2), C.c_double(0.0), C.c_double(0.0), C.c_double(1.0), _p(out1))
     assert out1[0] > out0[0] and out1[1] > out0[1]
+
+
+# ---- the checks of tests/known_answers.py (written once, run here on the oracle and in test_gpu_known_answers.py on the device) ----------
+import known_answers as KA  # noqa: E402
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+def test_oracle_wind_input_growth_rate_and_momentum_balance(prec):
+    run = KA.OracleRun(prec)
+    KA.check_momentum_balance(run, prec, KA.check_wind_input_growth_rate(run, prec))
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+def test_oracle_tail_and_stokes_drift(prec):
+    KA.check_tail_and_stokes_drift(KA.OracleRun(prec), prec)
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+def test_oracle_ctu_single_bin(prec):
+    KA.check_ctu_single_bin(KA.OracleRun(prec), prec)
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+def test_depth_props_of_the_product_and_of_the_oracle_agree(prec):
+    """The two restatements of DEPTHPRPT / AKI (numpy in ecwam_amd/synthetic.py, scalar C in oracle/ora_tables.c) agree to a few units in
+    the last place over the whole depth range -- including which Newton iteration AKI stops at (its convergence test has a tolerance of
+    1e-4: one iteration more or less would show as 1e-5).  The parity harness feeds each side ITS OWN tables (harness.oracle_implsch)."""
+    dt = H.np_dtype(prec)
+    cfg = Config(nang=12, nfre=36, nfre_red=25)
+    t = Tables(cfg, dt)
+    o = _oracle(cfg, prec)
+    rng = np.random.default_rng(11)
+    depth = np.concatenate([10 ** rng.uniform(0.0, 3.0, 4000), [998.999, 1.0, 2.5, 7.0, 50.0, 49.999]])
+    a, b = syn.depth_props(depth, t, dt), o.depthprpt(depth)
+    eps = np.finfo(dt).eps
+    for k in ("WAVNUM", "CINV", "CGROUP", "XK2CG", "OMOSNH2KD", "STOKFAC", "EMAXDPT"):
+        x, y = a[k].astype(float), b[k].astype(float)
+        ok = np.isfinite(y)
+        err = np.abs(x - y)[ok] / np.maximum(np.abs(y[ok]), 1e-300)
+        # OMOSNH2KD = omega / sinh(2 k d): an error e of the argument appears as 2 k d e in the result (2 k d up to 20 before the deep-water branch)
+        assert np.array_equal(np.isfinite(x), ok) and err.max() <= (64 if k == "OMOSNH2KD" else 8) * eps, (k, float(err.max() / eps))

@@ -11,7 +11,9 @@ import re
 import numpy as np
 
 SRC = "/root/reference/src/ecwam/cigetdeac.F90"
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ecwam_amd", "data", "cideac_kohout_meylan.txt")
+HERE = os.path.dirname(os.path.abspath(__file__))
+# the product's copy and the oracle's own (the checker reads nothing of the product)
+OUTS = [os.path.join(HERE, "..", "ecwam_amd", "data", "cideac_kohout_meylan.txt"), os.path.join(HERE, "..", "oracle", "data", "cideac_kohout_meylan.txt")]
 
 t = np.full((36, 16), np.nan)
 for line in open(SRC):
@@ -21,9 +23,11 @@ for line in open(SRC):
 blk = t[:, 5:]
 assert not np.isnan(blk).any(), "table block incomplete"
 assert t[0, 0] == -2.0
-with open(OUT, "w") as f:
-    f.write("# ln(attenuation coefficient per floe), rows: ice thickness 0.2 + 0.1*i m (i = 0..35), columns: wave period 6..16 s\n")
-    f.write("# data of Kohout & Meylan (2008) as tabulated in ecWAM 1.5.13 cigetdeac.F90:85-552 (extracted by tools/make_cideac_data.py)\n")
-    for r in blk:
-        f.write(" ".join(repr(float(x)) for x in r) + "\n")
-print("wrote", OUT, blk.shape)
+for OUT in OUTS:
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    with open(OUT, "w") as f:
+        f.write("# ln(attenuation coefficient per floe), rows: ice thickness 0.2 + 0.1*i m (i = 0..35), columns: wave period 6..16 s\n")
+        f.write("# data of Kohout & Meylan (2008) as tabulated in ecWAM 1.5.13 cigetdeac.F90:85-552 (extracted by tools/make_cideac_data.py)\n")
+        for r in blk:
+            f.write(" ".join(repr(float(x)) for x in r) + "\n")
+    print("wrote", OUT, blk.shape)

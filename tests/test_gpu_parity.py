@@ -1113,3 +1113,37 @@ def test_sweep_cut_at_the_cutoff_frequency_is_exact(api, prec, nang, nred, flags
     for k in ("FL1", "XLLWS", "MIJ", "FF"):
         assert np.array_equal(a[k], b[k]), k
     assert np.array_equal(a["INTF"][:, 2:], b["INTF"][:, 2:])      # WSEMEAN / WSFMEAN (slots 0, 1) are what LWFLUX adds
+
+
+# the seven configurations the reference registers as tests (tests/CMakeLists.txt:11-46) with the namelist its run script writes for
+# them (share/ecwam/scripts/ecwam_run_model.sh:85-92,211-272: ISNONLIN = 0, LBIWBK, LLCAPCHNK, LMASKICE, LWAMRSETCI, LWVFLX_SNL, the
+# LCIWA* of the yml; LICERUN = T with the operational forcings' sea-ice field, F with ERA5's): 12 directions, 25 of 36 frequencies
+_REGISTERED = {
+    "aqua_era5_O48": dict(idelt=1200, idelpro=1200, licerun=False),
+    "aqua_oper_an_fc_O48": dict(idelt=900, idelpro=900),
+    "etopo1_era5_O48": dict(idelt=1200, idelpro=1200, licerun=False),
+    "etopo1_oper_an_fc_O48": dict(idelt=900, idelpro=900),
+    "etopo1_oper_an_fc_O48_iphys_0": dict(idelt=900, idelpro=900, iphys=0),
+    "etopo1_oper_an_fc_O48_cy49r1": dict(idelt=900, idelpro=900, llgcbz0=True, llnormagam=True),
+    "etopo1_oper_an_fc_O48_cy50r1": dict(idelt=900, idelpro=900, llgcbz0=True, llnormagam=True, lciwa3=True, lciscal=True),
+}
+
+
+@pytest.mark.parametrize("prec", ["sp", "dp"])
+@pytest.mark.parametrize("name", sorted(_REGISTERED))
+def test_registered_configurations_run_on_the_fast_kernel(api, name, prec):
+    """Every configuration the reference registers as a test runs on ONE kernel generation, k_implsch4 (implsch_v4.h), in both
+    precisions, within the parity gates; k_implsch2 stays behind as the generic fallback for what no registered configuration selects
+    (LCIWA2, LWNEMOCOUWRS / STRN, ICODE 1 / 2, ISNONLIN 2, other direction counts)."""
+    flags = _REGISTERED[name]
+    cfg = Config(nang=12, nfre=36, nfre_red=25, **flags)
+    ice = bool(flags.get("lciwa3"))
+    n = 640
+    case = _ice_case(cfg, prec, n=n) if ice else H.make_point_case(n, cfg, prec, spectra="mixed", seed=71)
+    ref = H.oracle_implsch(case, _oracle(cfg, prec))
+    ctx = api.HipContext(case["tables"])
+    got = H.gpu_implsch(case, ctx)
+    gen = ctx.implsch_generation_used()
+    ctx.close()
+    assert gen == 4, (name, prec, gen)
+    _assert_implsch_stats(H.compare_implsch(ref, got, case["tables"]), n, prec)

@@ -116,7 +116,7 @@ FLANG = shutil.which("amdflang") or "/opt/rocm/lib/llvm/bin/flang"
 FSRC = os.path.join(HERE, "fortran")
 # the Fortran host layer: C interfaces + device state + transfer workers, the generated host types (tools/gen_yowdrvtype.py), the set-up
 # layer, the driver; then the harness programs (one executable each)
-FFILES = ["ecwam_hip_capi.F90", "yowdrvtype_hip.F90", "ecwam_hip_mod.F90", "wamintgr_hip.F90", "harness_case.F90"]
+FFILES = ["ecwam_hip_capi.F90", "yowdrvtype_hip.F90", "ecwam_hip_mod.F90", "ecwam_hip_restart.F90", "wamintgr_hip.F90", "harness_case.F90"]
 FPROGS = {"smoke_wamintgr_hip": "smoke_wamintgr_hip.F90", "seam_sequence": "seam_sequence.F90"}
 
 

@@ -22,6 +22,7 @@ PROGRAM SEAM_SEQUENCE
   USE FIELD_ASYNC_MODULE, ONLY : WAIT_FOR_ASYNC_QUEUE
   USE ECWAM_HIP_CAPI, ONLY : HIPST, ECWAM_HIP_CHECK, ECWAM_HIP_SYNC
   USE ECWAM_HIP_MOD, ONLY : ECWAM_HIP_FINALIZE
+  USE ECWAM_HIP_RESTART, ONLY : ECWAM_HIP_WRITEFL, ECWAM_HIP_READFL
   USE ECWAM_HIP_DRV
   USE HARNESS_CASE
   IMPLICIT NONE
@@ -51,7 +52,10 @@ PROGRAM SEAM_SEQUENCE
   INTEGER(C_LONG_LONG) :: C0(4), C1(4)
   REAL(KIND=JWRB), ALLOCATABLE :: FL1_OUT(:,:,:,:), UFRIC_OUT(:,:)
   REAL(KIND=JWRO), ALLOCATABLE :: STRESS_AVG(:,:,:,:)
-  INTEGER :: NCOUP, IU, NUP_EXPECTED
+  INTEGER :: NCOUP, IU, NUP_EXPECTED, IJ
+  CHARACTER(LEN=512) :: FRESTART
+  TYPE(TYPE_4D) :: CHK_4D
+  INTEGER(KIND=JWIM), ALLOCATABLE :: IJ2NEWIJ(:)
 
   CALL CASE_READ_AND_SETUP()
   LWNEMOCOU = (P%LWNEMOCOU /= 0); LWCOU = (P%LWCOU /= 0)
@@ -209,6 +213,25 @@ CALL FF_NEXT%GET_DEVICE_DATA_RDONLY(AIRD=.TRUE., WDWAVE=.TRUE., CICOVER=.TRUE., 
               & CHRNCK=.TRUE., CITHICK=.TRUE., USTRA=.TRUE., VSTRA=.TRUE.)
               CALL WVENVI%GET_HOST_DATA_RDONLY(DEPTH=.TRUE., DELLAM1=.TRUE., COSPHM1=.TRUE., UCUR=.TRUE., VCUR=.TRUE., &
               &                                EMAXDPT=.TRUE., IOBND=.TRUE., IODP=.TRUE.)
+      ! SAVSPEC -> WRITEFL (writefl.F90:110-118): the restart spectra as one unformatted record, then a second record in the re-labelled
+      ! order of a 2-D decomposition (here: the points reversed); both read back and compared (third command argument = the file)
+      CALL GET_COMMAND_ARGUMENT(3, FRESTART)
+      IF (LEN_TRIM(FRESTART) > 0) THEN
+        CALL COUNTERS(C0)
+        CALL ECWAM_HIP_WRITEFL(VARS_4D, TRIM(FRESTART), .TRUE.)
+        ALLOCATE(IJ2NEWIJ(NPTS))
+        IJ2NEWIJ = [(NPTS + 1 - IJ, IJ = 1, NPTS)]
+        CALL ECWAM_HIP_WRITEFL(VARS_4D, TRIM(FRESTART), .FALSE., IJ2NEWIJ)
+        CALL COUNTERS(C1)
+        IF (C1(2) /= C0(2)) CALL BAD('ECWAM_HIP_WRITEFL copied spectra the host already had', C0, C1)
+        CALL CHK_4D%ALLOC(UBOUNDS=[NPROMA, NANG, NFRE, NCHNK])
+        CALL ECWAM_HIP_READFL(CHK_4D, TRIM(FRESTART))
+        IF (ANY(CHK_4D%FL1 /= VARS_4D%FL1)) ERROR STOP 'seam_sequence: the restart record read back differs from the spectra written'
+        CHK_4D%FL1 = 0.0_JWRB
+        CALL ECWAM_HIP_READFL(CHK_4D, TRIM(FRESTART), IJ2NEWIJ, IREC=2)
+        IF (ANY(CHK_4D%FL1 /= VARS_4D%FL1)) ERROR STOP 'seam_sequence: the re-labelled restart record read back differs'
+        CALL CHK_4D%DEALLOC()
+      ENDIF
     ENDIF
 
     ! ---- wamodel.F90:607-642: WAM-NEMO coupling without the atmospheric model --------------------------------------------------------------

@@ -255,7 +255,8 @@ def test_fortran_seam_sequence_replays_the_reference_call_lines(tmp_path, prec, 
     nproma, nstep, n = 24, 4, g.nsea
     case, out = str(tmp_path / "case.bin"), str(tmp_path / "out.bin")
     nchnk = _write_case(case, m, cfg, g, nproma, nstep)
-    r = subprocess.run([exe, case, out], capture_output=True, text=True, timeout=300)
+    rst = str(tmp_path / "BLS_restart")
+    r = subprocess.run([exe, case, out, rst], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "seam_sequence: ok" in r.stdout, r.stdout + r.stderr
     ffn0 = m.ff.clone()
     w2n = torch.zeros((n, 13), dtype=torch.float64, device=m.dev) if nemo else None
@@ -303,6 +304,12 @@ def test_fortran_seam_sequence_replays_the_reference_call_lines(tmp_path, prec, 
     uf_f = np.frombuffer(rest, dtype=dt, count=nproma * nchnk, offset=off).reshape((nproma, nchnk), order="F"); off += nproma * nchnk * isz
     assert np.array_equal(fl_f[ij % nproma, :, :, ij // nproma], fl_out)        # what the host read at its output step (queue 4)
     assert np.array_equal(uf_f[ij % nproma, ij // nproma], ufric_out)
+    # the restart file ECWAM_HIP_WRITEFL wrote at the last step (writefl.F90:110-118: one unformatted record (((FL(IJ,K,M),IJ),K),M);
+    # a second one in the re-labelled order of a 2-D decomposition, here the points reversed), read with the Python host's reader
+    from ecwam_amd import restart
+    want = m.fl1.cpu().numpy()[:n]
+    assert np.array_equal(restart.read_fl(rst, n, cfg.nang, cfg.nfre, dt, record=0), want)
+    assert np.array_equal(restart.read_fl(rst, n, cfg.nang, cfg.nfre, dt, record=1), want[::-1])
     nh2d, nd2h, bh2d, bd2h = (int(x) for x in np.frombuffer(rest, dtype=np.int64, count=4, offset=off))
     # FL1 travels up once (+ the five FREQUENCY members: 5/12 of its size here, + the per-point fields) and comes down once per step;
     # XLLWS once (the test's own request at the end)

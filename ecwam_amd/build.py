@@ -12,13 +12,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libecwam_hip.so")
-SOURCES = ["capi.hip", "propag.hip", "implsch.hip", "implsch4.hip", "implsch4x.hip", "outbs.hip"]
+SOURCES = ["capi.hip", "propag.hip", "implsch.hip", "implsch4.hip", "implsch4x.hip", "implsch4r.hip", "outbs.hip"]
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # IMPLSCH is VALU-issue bound: single-precision divide/sqrt by the hardware reciprocal / square root plus one
 # refinement (<= 2.5 ulp) instead of the correctly rounded sequences; double precision is unaffected.
 FAST_DIV = ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
-IMPLSCH_SOURCES = ("implsch.hip", "implsch4.hip", "implsch4x.hip")
+IMPLSCH_SOURCES = ("implsch.hip", "implsch4.hip", "implsch4x.hip", "implsch4r.hip")
 # Build variants of the IMPLSCH translation units (the single-precision error attribution):
 #   ""         the product build: hardware reciprocal / square root / exp2 / log2 in single precision, FMA contraction on
 #   "exactdiv" every `/` and SQRT the source spells out is correctly rounded (the scalar chains per sea point: TAUT_Z0, STRESSO, FKMEAN,

@@ -84,6 +84,7 @@ template <typename T> void launch_proenv_unpack(int, int, const void*, const voi
 template <typename T> int launch_implsch(const void*, int, int, void*, const void*, void*, void*, int*, void*, double*, void*, int, int, int, hipStream_t);
 template <typename T> int launch_implsch4(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, int, int, int, int, int, int, hipStream_t);
 template <typename T> int launch_implsch4x(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, int, int, int, int, int, int, hipStream_t);
+template <typename T> int launch_implsch4r(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, int, int, int, int, int, int, hipStream_t);
 int implsch4_fin_row();
 
 // Does the fourth kernel generation cover these tables?  It needs the pull-form DIA structure with K1W = K -+ r1, K11W = K1W -+ 1,
@@ -667,19 +668,25 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   const bool rare = c->p.lciwa1 || c->p.lciwa2 || c->p.lciwa3 || c->p.lciscal || c->p.lwnemocou || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin ||
                     c->p.iphys == 0 || c->p.icode != 3 || !c->p.lwvflx_snl;
   if (c->p.llgcbz0 || rare) variant |= 32;
-  // fourth kernel generation (implsch_v4.h): flag sets A and B (LLGCBZ0, LLNORMAGAM), with or without the sea-ice damping rates that
-  // depend on the frequency only (LCIWA1, LCIWA3, LCISCAL), without the other optional branches, single and double precision.  The
-  // sheltered growth needs TAUWSHELTER /= 0, the normalised one TAUWSHELTER = 0 (setwavphys.F90:150-190).
+  // fourth kernel generation (implsch_v4.h).  The common builds: flag sets A and B (LLGCBZ0, LLNORMAGAM), with or without the sea-ice
+  // damping rates that depend on the frequency only (LCIWA1, LCIWA3, LCISCAL), and on flag set A IPHYS 0 or ISNONLIN 1 -- what the
+  // reference's registered configurations select.  Everything else the kernel covers runs its RARE builds (implsch4r.hip, sp only: LCIWA2, the
+  // NEMO ice stress and strain, ISNONLIN 2, ICODE 1 / 2, LWVFLX_SNL = F, ISNONLIN 1 beside flag set B or IPHYS 0).  The sheltered growth
+  // needs TAUWSHELTER /= 0, the normalised one TAUWSHELTER = 0 (setwavphys.F90:150-190).  k_implsch2 stays the generic fallback: other
+  // direction counts than 36 / 24 / 12, IPHYS = 0 together with LLGCBZ0 / LLNORMAGAM, the RARE configurations in double precision.
   const int ext = (c->p.llnormagam || c->p.llgcbz0) ? 1 : 0;
   const bool rare4 = c->p.lciwa2 || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin > 1 || c->p.icode != 3 || !c->p.lwvflx_snl;
   // the alternate physics the registered configurations select, on flag set A only: 1 = IPHYS 0 (sinput_jan + sdissip_jan; its
-  // TAUWSHELTER is 0), 2 = ISNONLIN 1 (TRANSF per interaction frequency); both at once: k_implsch2
+  // TAUWSHELTER is 0), 2 = ISNONLIN 1 (TRANSF per interaction frequency)
   const int alt = (c->p.iphys == 0 ? 1 : 0) | (c->p.isnonlin == 1 ? 2 : 0);
-  const bool alt_ok = alt == 0 || (!ext && alt != 3);
-  const bool shelter_ok = alt == 1 ? true : (c->p.llnormagam ? c->v4_shelter == 0 : c->v4_shelter != 0);
-  if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !rare4 && alt_ok && !dbg && shelter_ok) {
+  const bool common_ok = !rare4 && (alt == 0 || (!ext && alt != 3));
+  const bool shelter_ok = (c->p.iphys == 0) ? true : (c->p.llnormagam ? c->v4_shelter == 0 : c->v4_shelter != 0);
+  if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !dbg && shelter_ok && !(c->p.iphys == 0 && ext)) {
     if (int rc2 = ecwam_hip_implsch_reserve(c, kijl)) return rc2;   // no-op once the buffer covers kijl
-    if (alt)
+    if (!common_ok)
+      DISPATCH(rc = launch_implsch4r<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, c->p.iphys == 0 ? 1 : 0, s),
+               rc = launch_implsch4r<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, c->p.iphys == 0 ? 1 : 0, s));
+    else if (alt)
       DISPATCH(rc = launch_implsch4x<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, alt, s),
                rc = launch_implsch4x<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, alt, s));
     else

@@ -1,0 +1,33 @@
+// Launcher of the RARE builds of k_implsch4 (implsch_v4.h): what no registered test configuration of the reference selects -- ISNONLIN = 2
+// (TRANSF_SNL + PEAK_ANG), LCIWA2 (sdice2.F90), the NEMO ice stress and strain LWNEMOCOUWRS / LWNEMOCOUSTRN (wnfluxes.F90:178-196,
+// cimsstrn.F90), friction-velocity forcing ICODE = 1, 2 (airsea.F90:100-117), LWVFLX_SNL = F, and ISNONLIN = 1 beside LLGCBZ0 / LLNORMAGAM or
+// IPHYS = 0 -- decided at run time inside two builds per direction count: flag sets A and B with IPHYS = 1 (EXT + ENHMC), and IPHYS = 0 on
+// flag set A (JAN + ENHMC).  A translation unit of its own: the builds compile beside those of implsch4.hip / implsch4x.hip.
+#include "implsch_v4_launch.h"
+
+// jan: 1 = IPHYS 0.  Returns 0 when launched, -1 when no instantiation covers the configuration (k_implsch2 runs it).
+// Single precision only.  The double precision RARE builds (370 - 440 registers, 170 - 320 KB of code each) compile, but the kernel ends in
+// HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION or in wrong numbers on the first launch, also with every rare switch off at run time; the same
+// source with an early-exit branch at each phase boundary (the diagnostics build) runs correctly, so does the build with the carried SDICE
+// rates removed, while scheduling barriers, SGPR spills to memory instead of to lanes and a recomputed instead of a carried rate change
+// nothing (profiles/r04_rare_dp_note.txt): not understood, so double precision keeps k_implsch2 for these configurations.
+template <typename T>
+int launch_implsch4r(const void* tab, int kijs, int kijl, void* fl1, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws,
+                     void* fin, double* w2n, void* gfast, int gk, int NANG, int NFRE, int r1, int r2, int nh, int jan, hipStream_t s) {
+  if constexpr (sizeof(T) != 4) return -1;
+  else {
+    if (kijl - kijs <= 0) return 0;
+    if (NFRE != V4_NFRE) return -1;
+#define V4_ARGS tab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, fin, w2n, gfast, gk, s
+    if (NANG == 36 && r1 == 1 && r2 == 3 && nh == 8)
+      return jan ? launch4<T, 36, 3, 1, 3, 8, false, true, true, true>(V4_ARGS) : launch4<T, 36, 3, 1, 3, 8, true, false, true, true>(V4_ARGS);
+    if (NANG == 24 && r1 == 0 && r2 == 2 && nh == 5)
+      return jan ? launch4<T, 24, 5, 0, 2, 5, false, true, true, true>(V4_ARGS) : launch4<T, 24, 5, 0, 2, 5, true, false, true, true>(V4_ARGS);
+    if (NANG == 12 && r1 == 0 && r2 == 1 && nh == 3)
+      return jan ? launch4<T, 12, 10, 0, 1, 3, false, true, true, true>(V4_ARGS) : launch4<T, 12, 10, 0, 1, 3, true, false, true, true>(V4_ARGS);
+#undef V4_ARGS
+    return -1;
+  }
+}
+template int launch_implsch4r<float>(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, int, int, int, int, int, int, hipStream_t);
+template int launch_implsch4r<double>(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, int, int, int, int, int, int, hipStream_t);

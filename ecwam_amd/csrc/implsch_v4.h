@@ -45,7 +45,8 @@ using V2 = T __attribute__((ext_vector_type(2)));
 
 // the row of scalars per sea point that k_implsch4_pre hands to k_implsch4 and k_implsch4 to k_implsch4_fin
 enum { FIN_AIRD = 0, FIN_UFRIC, FIN_Z0M, FIN_MIJ, FIN_XS, FIN_YS, FIN_F1DCOS3, FIN_F1DCOS2, FIN_F1DSIN2, FIN_F1D, FIN_RNFAC, FIN_PHIWA,
-       FIN_SINWD, FIN_COSWD, FIN_WSWAVE, FIN_CICOVER, FIN_PHILF, FIN_XSTRESS, FIN_YSTRESS, FIN_Z0B, FIN_CHRNCK, FIN_COSDIFF, FIN_EMEAN, FIN_F1MEAN, V4_NFIN = 24 };
+       FIN_SINWD, FIN_COSWD, FIN_WSWAVE, FIN_CICOVER, FIN_PHILF, FIN_XSTRESS, FIN_YSTRESS, FIN_Z0B, FIN_CHRNCK, FIN_COSDIFF, FIN_EMEAN, FIN_F1MEAN,
+       FIN_TAUICX, FIN_TAUICY, FIN_STRNMS, FIN_SPARE, V4_NFIN = 28 };   // (the last four: the RARE build's ice stress and strain)
 
 __device__ __forceinline__ float v4_bp(int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); }
 __device__ __forceinline__ double v4_bp(int addr, double v) {
@@ -136,6 +137,20 @@ __device__ __forceinline__ T v4_allsum1(T v, const V4Rot<T>& r) {
     if (G == 12) v = v + v4_bp(r.a1, v);
     v = v + (v4_bp(r.a3, v) + v4_bp(r.a4, v));
     return v;
+  }
+}
+
+// maximum over the lanes of a point (the RARE build's PEAK_ANG)
+template <int G, typename T>
+__device__ __forceinline__ T v4_allmax1(T v, const V4Rot<T>& r) {
+  if constexpr (G == 18) {
+    v = m_max(v, v4_bp(r.a0, v));      // lanes 0, 1 of a row take their point's extras in, the others themselves
+    v = v4_rowmax<T>(v);
+    return v4_bp(r.a1, v);
+  } else {
+    v = m_max(v, v4_bp(r.a0, v));
+    if (G == 12) v = m_max(v, v4_bp(r.a1, v));
+    return m_max(v, m_max(v4_bp(r.a3, v), v4_bp(r.a4, v)));
   }
 }
 
@@ -678,6 +693,34 @@ __device__ void v4_sinput_jan(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, 
   WSYNC();
 }
 
+// Attenuation rates of the sea ice per frequency (without CGROUP and the ice cover): SDICE1's scattering ALP = EXP(CIDEAC(period, thickness))
+// DINV ZALPFACB, CIDEAC bilinear (sdice1.F90:135-168), and SDICE3's viscous friction (sdice3.F90:117-137).  One definition for the factor
+// table of the point and for the RARE build's SLICE.
+template <typename T>
+__device__ __forceinline__ T v4_sdice1_alp(const DevTab<T>& tb, int m, T CITHICKv, T DINV) {
+  const int NICT = tb.NICT, NICH = tb.NICH;
+  const T TW = T(1) / tb.FR[m];
+  int IT = (int)m_floor((TW - tb.TICMIN) / tb.DTIC + T(1));
+  IT = IT < 1 ? 1 : (IT > NICT ? NICT : IT);
+  const int IT1 = IT + 1 > NICT ? NICT : IT + 1;
+  const T WT1 = m_max(m_min(T(1), (TW - (tb.TICMIN + T(IT - 1) * tb.DTIC)) / tb.DTIC), T(0));
+  const T WT = T(1) - WT1;
+  int IH = (int)m_floor((CITHICKv - tb.HICMIN) / tb.DHIC + T(1));
+  IH = IH < 1 ? 1 : (IH > NICH ? NICH : IH);
+  const int IH1 = IH + 1 > NICH ? NICH : IH + 1;
+  const T WH1 = m_max(m_min(T(1), (CITHICKv - (tb.HICMIN + T(IH - 1) * tb.DHIC)) / tb.DHIC), T(0));
+  const T WH = T(1) - WH1;
+  const T* cd = tb.CIDEAC;
+  const T CI = WT * (WH * cd[(IH - 1) * NICT + IT - 1] + WH1 * cd[(IH1 - 1) * NICT + IT - 1]) +
+               WT1 * (WH * cd[(IH - 1) * NICT + IT1 - 1] + WH1 * cd[(IH1 - 1) * NICT + IT1 - 1]);
+  return m_exp(CI) * DINV * tb.ZALPFACB;
+}
+template <typename T>
+__device__ __forceinline__ T v4_sdice3_alp(const DevTab<T>& tb, int m, T CITHICKv, T ALPFAC) {
+  const T CDICE = T(0.1274) * m_pow(tb.ZPI / m_sqrt(tb.G), T(4.5));
+  return (T(2) * CDICE * m_pow(CITHICKv, T(1.25)) * m_pow(tb.FR[m], T(4.5))) * ALPFAC;
+}
+
 // One wavefront advances PP sea points.  Lanes beyond PP G shadow other lanes and the points of a short last wave shadow its
 // last point: shadows run the same instructions on the same data, so their LDS and global stores repeat their original's values
 // at the same addresses -- no store is predicated.
@@ -685,8 +728,12 @@ __device__ void v4_sinput_jan(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, 
 // and LLNORMAGAM (normalised growth rate) -- the cy49r1 / cy50r1 physics; the flag-set-A build has none of that code.
 // JAN: IPHYS = 0 (sinput_jan.F90 + sdissip_jan.F90: the dissipation is a rate per (point, frequency) in the saturation slot of the
 // factor table; no saturation filter, no sheltering recurrence).  ENHMC: ISNONLIN = 1 (the DIA scaled per interaction frequency by
-// TRANSF(k(MC), DEPTH), snonlin.F90:138-150).  Both without EXT.
-template <typename T, int NANG, int PP, int R1, int R2, int NH, bool EXT, bool JAN = false, bool ENHMC = false>
+// TRANSF(k(MC), DEPTH), snonlin.F90:138-150).
+// RARE: the build for what no registered configuration selects, decided at run time inside it: ISNONLIN = 2 (TRANSF_SNL with the spectral
+// widths of PEAK_ANG, snonlin.F90:152-165; ENHMC builds only), LCIWA2 (sdice2.F90: the attenuation depends on the bin's own energy), the
+// ice radiative stress LWNEMOCOUWRS (wnfluxes.F90:178-196) and strain LWNEMOCOUSTRN (cimsstrn.F90), friction-velocity forcing ICODE = 1, 2
+// (airsea.F90:100-117) and LWVFLX_SNL = F (implsch.F90:280-288) -- uniform branches, which the common builds do not pay for.
+template <typename T, int NANG, int PP, int R1, int R2, int NH, bool EXT, bool JAN = false, bool ENHMC = false, bool RARE = false>
 // single precision: two waves per SIMD (LDS: 8 waves per CU), at most 256 VGPRs; double precision: the LDS holds one wave per SIMD
 // (40 KB per wave) and the kernel may use the whole register file (340 registers: no scratch)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(V4_WPE_MIN(T), 2)))
@@ -700,7 +747,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   constexpr int VEC = 16 / (int)sizeof(T);   // elements per 16-byte global access
   constexpr int NC = NFRE / VEC;             // 16-byte chunks per direction
   static_assert(PP * G <= 64 && NFRE % G == 0 && NFRE % VEC == 0 && R2 + 2 <= 2 * NSH + 1 && PP * NFRE >= RS, "layout");
-  static_assert(!(EXT && (JAN || ENHMC)), "IPHYS = 0 and ISNONLIN = 1 are built without LLGCBZ0 / LLNORMAGAM");
+  static_assert(!(EXT && JAN), "IPHYS = 0 is built without LLGCBZ0 / LLNORMAGAM (v4_sinput_jan has no normalised growth rate)");
+  static_assert(RARE || !(EXT && ENHMC), "ISNONLIN = 1 beside LLGCBZ0 / LLNORMAGAM: the RARE build");
   typedef T VT __attribute__((ext_vector_type(VEC)));
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const DevTab<T>& tb = *tp;
@@ -808,7 +856,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   const T CICOVERi = ffa[(size_t)ij * ECWAM_HIP_NFF + 2], CITHICKi = ffa[(size_t)ij * ECWAM_HIP_NFF + 13];
   if (lane < PP) {
     T* q = sSC + lane * NSC;
-    q[C_AIRD] = p_aird; q[C_WDWAVE] = p_wdwave; q[C_WSWAVE] = p_wswave; q[C_WSTAR] = p_wstar;
+    // friction-velocity forcing (ICODE = 1, 2): the 10 m wind is the log-profile wind k_implsch4_pre derived (airsea.F90:107-115)
+    q[C_AIRD] = p_aird; q[C_WDWAVE] = p_wdwave; q[C_WSWAVE] = (RARE && tb.ICODE != 3) ? frp[FIN_WSWAVE] : p_wswave; q[C_WSTAR] = p_wstar;
     q[C_TAUW] = p_tauw; q[C_TAUWDIR] = p_tauwdir;
     q[C_RAORW] = m_max(p_aird, T(1)) * tb.ROWATERM1; q[C_EMAXDPT] = p_emaxdpt; q[C_DEPTH] = p_depth;
     q[C_SINWD] = p_sinwd; q[C_COSWD] = p_coswd; q[C_RNFAC] = p_rnfac;
@@ -816,14 +865,20 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     q[C_UFRIC] = p_ufric; q[C_Z0M] = p_z0m; q[C_Z0B] = p_z0b; q[C_CHRNCK] = p_chrnck;
     q[C_SPARE] = p_ci;   // CICOVER
   }
+  // RARE (ice radiative stress): FLDICE(M) = -ALP(M) CGROUP(M) of the last of SDICE1 / SDICE3 that is active, without the ice cover factor
+  // (SLICE of sdice1.F90:177 / sdice3.F90:143), for the lane's frequencies M = q G + j + 1; handed out row by row with one lane exchange.
+  // (A vector value, not an array: an array read through a chain of selects ends as an indexed access to scratch memory.)
+  typedef T FLIV __attribute__((ext_vector_type(RARE ? NS : 1)));
+  FLIV rFLI = T(0);
   // ---- per-frequency factors of the point: lane j fills M = j+1, j+1+G, ...
   {
+    T CITHICKv = T(0), DINV = T(0), ALPFAC = tb.ZALPFACX;      // ice thickness, inverse floe diameter, broken-ice factor of the point
     // sea-ice attenuation (implsch.F90:312-339): SDICE1 (scattering, sdice1.F90:104-181) and SDICE3 (viscous friction, sdice3.F90:110-160)
     // are, like SBOTTOM, a damping rate per (point, frequency): FLD += c, SL += c F.  The three rates share one slot of the table (the
     // reference adds them one after the other: the sums differ in rounding only).  SDICE2 depends on F itself and the NEMO coupling
-    // needs SLICE on its own: k_implsch2.
+    // needs SLICE on its own: the RARE build.
     const bool ice1 = tb.LICERUN && tb.LCIWA1, ice3 = tb.LICERUN && tb.LCIWA3;
-    T CICOVERv = T(0), CITHICKv = T(0), DINV = T(0), ALPFAC = tb.ZALPFACX;
+    T CICOVERv = T(0);
     if (ice1 || ice3) {
       CICOVERv = CICOVERi;
       CITHICKv = CITHICKi;
@@ -859,28 +914,15 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       if (ice1 || ice3) {
         const T CGROUP = w_cg[qq];
         T dmp = T(0);
-        if (ice1 && CITHICKv > T(0)) {   // CIDEAC(period, thickness), bilinear (sdice1.F90:135-163)
-          const int NICT = tb.NICT, NICH = tb.NICH;
-          const T TW = T(1) / tb.FR[m];
-          int IT = (int)m_floor((TW - tb.TICMIN) / tb.DTIC + T(1));
-          IT = IT < 1 ? 1 : (IT > NICT ? NICT : IT);
-          const int IT1 = IT + 1 > NICT ? NICT : IT + 1;
-          const T WT1 = m_max(m_min(T(1), (TW - (tb.TICMIN + T(IT - 1) * tb.DTIC)) / tb.DTIC), T(0));
-          const T WT = T(1) - WT1;
-          int IH = (int)m_floor((CITHICKv - tb.HICMIN) / tb.DHIC + T(1));
-          IH = IH < 1 ? 1 : (IH > NICH ? NICH : IH);
-          const int IH1 = IH + 1 > NICH ? NICH : IH + 1;
-          const T WH1 = m_max(m_min(T(1), (CITHICKv - (tb.HICMIN + T(IH - 1) * tb.DHIC)) / tb.DHIC), T(0));
-          const T WH = T(1) - WH1;
-          const T* cd = tb.CIDEAC;
-          const T CI = WT * (WH * cd[(IH - 1) * NICT + IT - 1] + WH1 * cd[(IH1 - 1) * NICT + IT - 1]) +
-                       WT1 * (WH * cd[(IH - 1) * NICT + IT1 - 1] + WH1 * cd[(IH1 - 1) * NICT + IT1 - 1]);
-          dmp = CICOVERv * (-(m_exp(CI) * DINV * tb.ZALPFACB) * CGROUP);
+        if (ice1 && CITHICKv > T(0)) {
+          const T d1 = -v4_sdice1_alp(tb, m, CITHICKv, DINV) * CGROUP;
+          dmp = CICOVERv * d1;
+          if constexpr (RARE) rFLI[qq] = d1;
         }
         if (ice3) {
-          const T CDICE = T(0.1274) * m_pow(tb.ZPI / m_sqrt(tb.G), T(4.5));
-          const T ALP = (T(2) * CDICE * m_pow(CITHICKv, T(1.25)) * m_pow(tb.FR[m], T(4.5))) * ALPFAC;
+          const T ALP = v4_sdice3_alp(tb, m, CITHICKv, ALPFAC);
           dmp = dmp + (-CICOVERv * ALP * CGROUP);
+          if constexpr (RARE) rFLI[qq] = -ALP * CGROUP;
         }
         sbo = dmp + sbo;
       }
@@ -1045,10 +1087,10 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     } else ALPHAP = ATAIL;
     if (j == 0) c[C_HALP] = T(0.5) * m_min(ALPHAP, tb.ALPHAPMAX);
     WSYNC();
-    taut_z0_gc(0);
+    if (!(RARE && tb.ICODE != 3)) taut_z0_gc(0);     // (friction-velocity forcing: Z0WAVE in k_implsch4_pre took the place of the first TAUT_Z0)
   }
   T UFRIC = c[C_UFRIC], Z0M = c[C_Z0M];
-  const T RNFAC = c[C_RNFAC];
+  T RNFAC = c[C_RNFAC];
 
   auto femws_finish = [&](V2<T> wse, V2<T> wslast, T& FM, T& EMW) {
     const V2<T> s = v4_allsum<G, T>(wse, L.rot);
@@ -1131,6 +1173,16 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   // ---- stage 2: STRESSO scalars, second TAUT_Z0, WSIGSTAR, swell set-up, SDIWBK
   v4_stresso<T, PP, EXT>(tb, sSC, lane, false);
   WSYNC();
+  if constexpr (RARE) {
+    if (tb.ICODE != 3 && norma && tb.LLCAPCHNK) {   // second SINFLX call: RNFAC from the log-profile wind (sinflx.F90:116-120)
+      if (lane < PP) {
+        T* q = sSC + lane * NSC;
+        q[C_RNFAC] = T(1) + tb.DTHRN_A * (T(1) + m_tanh(q[C_WSWAVE] - tb.DTHRN_U));
+      }
+      WSYNC();
+      RNFAC = c[C_RNFAC];
+    }
+  }
   if (gcb) taut_z0_gc(1);   // (with WSIGSTAR)
   if (lane < PP) {
     T* q = sSC + lane * NSC;
@@ -1173,6 +1225,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   //   rides along, one exchange per stage.  The coefficient record of the next interaction and the parked wind-input row come
   //   from global memory as vector loads one interaction (eight rows) ahead.
   V2<T> a_t = z2, a_x = z2;
+  V2<T> a_ice = z2;      // RARE: integrand of the ice radiative stress
   {
     T ENHFR = m_max(T(0.75) * DEPTH * AKMEAN, T(0.5));
     ENHFR = T(1) + (T(5.5) / ENHFR) * (T(1) - T(0.833) * ENHFR) * m_exp(-T(1.25) * ENHFR);
@@ -1182,7 +1235,75 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     constexpr int NQE = ENHMC ? (V4_NFRE + 4 + G - 1) / G : 1;
     T rENH[NQE];
     int enh_lane0 = 0, enh_ext0 = 0;   // byte addresses of the point's lanes for pair 0 and for pair 16 (36 directions: the extras)
+    if constexpr (ENHMC || RARE) {
+      if constexpr (G == 18) { enh_lane0 = 4 * (16 * p); enh_ext0 = 4 * (48 + 2 * p - 16); }
+      else { enh_lane0 = 4 * (p * G); enh_ext0 = enh_lane0; }
+    }
     if constexpr (ENHMC) {
+      // RARE: ISNONLIN = 2 -- the spectral widths of PEAK_ANG (peak_ang.F90:76-174) on the spectrum before any row is updated
+      T XNU = T(0), SIG_TH = T(0);
+      if constexpr (RARE) {
+        if (tb.ISNONLIN == 2) {
+          const T ZEPS = T(10) * (sizeof(T) == 4 ? T(1.1920928955078125e-07) : T(2.220446049250313e-16));   // 10 EPSILON
+          const int NSHF = 1 + (int)(m_log(T(1.5)) / m_log(tb.FRATIO));
+          const T* spt = sStg + SPOFF + p * NFRE;      // row totals over the directions of the point (the staging rows are idle here)
+          for (int m = 0; m < NFRE; m++) {
+            const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
+            v4_row_total_to_lds<G, T>(f.x + f.y, L.rot, gsp, m);
+          }
+          WSYNC();
+          V2<T> s01 = z2;
+          T s2 = T(0);
+#pragma unroll
+          for (int q = 0; q < NS; q++) {
+            const int m = q * G + j;
+            const T t2 = spt[m], fr = tb.FR[m], dfm = tb.DFIM[m];
+            s01 = s01 + V2<T>{dfm, tb.DFIMFR[m]} * t2;
+            s2 = s2 + (dfm * (fr * fr)) * t2;
+          }
+          s01 = v4_allsum<G, T>(s01, L.rot);
+          s2 = v4_allsum1<G, T>(s2, L.rot);
+          const T tl = spt[NFRE - 1];
+          const T S0 = (ZEPS + s01.x) + (tb.WETAIL * frl * tb.DELTH) * tl;
+          const T S1 = s01.y + (tb.WP1TAIL * tb.DELTH * (frl * frl)) * tl;
+          const T S2 = s2 + (T(0.5) * tb.DELTH * (frl * frl * frl)) * tl;   // WP2TAIL = 0.5, yowfred.F90:54
+          XNU = (S0 > ZEPS) ? m_sqrt(m_max(ZEPS, S2 * S0 / (S1 * S1) - T(1))) : ZEPS;
+          // first maximum of F over M = 2 .. NFRE-1 in the reference's (M outer, K inner) order: the smallest M that attains it
+          T vmax = T(0);
+          int mm = 2;
+          for (int m = 1; m < NFRE - 1; m++) {
+            const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
+            const T v = m_max(f.x, f.y);
+            if (v > vmax) { vmax = v; mm = m + 1; }
+          }
+          const T gmax = v4_allmax1<G, T>(vmax, L.rot);
+          const T cand = (gmax > T(0) && vmax == gmax) ? -T(mm) : -T(1.0e9);
+          const T mneg = v4_allmax1<G, T>(cand, L.rot);
+          const int MMAX = gmax > T(0) ? (int)(-mneg) : 2;      // per point
+          const int MS = MMAX - NSHF > 1 ? MMAX - NSHF : 1, ME = MMAX + NSHF < NFRE ? MMAX + NSHF : NFRE;
+          T SUM_S = T(0), SUM_C = ZEPS, SUM1 = ZEPS, SUM2 = T(0);
+          const V2<T> thk = {tb.TH[2 * j], tb.TH[2 * j + 1]};
+          for (int d = -NSHF; d <= NSHF; d++) {      // M = MMAX + d on every lane of a point, the rows outside MS .. ME contribute nothing
+            const int M = MMAX + d;
+            const bool in = (M >= MS && M <= ME);
+            const int Mc = M < 1 ? 1 : (M > NFRE ? NFRE : M);
+            V2<T> f = *reinterpret_cast<const V2<T>*>(tF + (Mc - 1) * RS);
+            if (!in) f = z2;
+            const V2<T> fs = f * L.sinth, fc = f * L.costh;
+            const V2<T> a = v4_allsum<G, T>(V2<T>{fs.x + fs.y, fc.x + fc.y}, L.rot);
+            SUM_S = SUM_S + a.x;
+            SUM_C = SUM_C + a.y;
+            const T THMEAN = m_atan2(SUM_S, SUM_C);
+            const T dfim = tb.DFIM[Mc - 1];
+            const V2<T> w = f * dfim;
+            const V2<T> b = v4_allsum<G, T>(V2<T>{w.x + w.y, m_cos(thk.x - THMEAN) * w.x + m_cos(thk.y - THMEAN) * w.y}, L.rot);
+            SUM1 = SUM1 + b.x;
+            SUM2 = SUM2 + b.y;
+          }
+          SIG_TH = (SUM1 > ZEPS) ? m_sqrt(T(2) * (T(1) - SUM2 / SUM1)) : T(0);
+          WSYNC();
+        }
+      }
 #pragma unroll
       for (int q = 0; q < NQE; q++) {
         const int mc = q * G + j;   // MC - 1
@@ -1195,10 +1316,28 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
           XK = tb.GM1 * (w * w);
         }
         rENH[q] = m_max(m_min(T(10), transf_d(tb, XK, DEPTH)), T(0.1));
+        if constexpr (RARE) {      // ISNONLIN decided at run time: 0 = the depth scaling from AKMEAN for every MC, 2 = TRANSF_SNL
+          if (tb.ISNONLIN == 0) rENH[q] = ENHFR;
+          if (tb.ISNONLIN == 2) rENH[q] = transf_snl_d(tb, XK, DEPTH, XNU, SIG_TH);
+        }
       }
-      if constexpr (G == 18) { enh_lane0 = 4 * (16 * p); enh_ext0 = 4 * (48 + 2 * p - 16); }
-      else { enh_lane0 = 4 * (p * G); enh_ext0 = enh_lane0; }
     }
+    // a value the lanes of a point hold per frequency (lane j: rows q G + j) handed to all of them for row m: one lane exchange
+    auto row_value = [&](const FLIV r, int m) -> T {
+      if constexpr (!RARE) return T(0);
+      else {
+        const int q = m / G, jl = m - q * G;
+        T v = r[0];
+#pragma unroll
+        for (int i = 1; i < NS; i++) v = (q == i) ? r[i] : v;
+        const int base = (G == 18 && jl >= 16) ? enh_ext0 : enh_lane0;
+        return v4_bp(base + 4 * jl, v);
+      }
+    };
+    const bool ice2 = RARE && tb.LICERUN && tb.LCIWA2, wrs = RARE && tb.LWNEMOCOUWRS && tb.LCFLX;
+    const bool ice13 = RARE && tb.LICERUN && (tb.LCIWA1 || tb.LCIWA3), ice3on = RARE && tb.LICERUN && tb.LCIWA3;
+    const T EPSMIN1000 = tb.EPSMIN * T(1000);
+
     auto enh_of = [&](int MC) -> T {   // MC wave-uniform
       if constexpr (!ENHMC) return ENHFR;
       else {
@@ -1277,11 +1416,33 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         const V2<T> den = {m_max(T(1) - DELT5 * fld.x, T(1)), m_max(T(1) - DELT5 * fld.y, T(1))};
         ss = V2<T>{f_div(sl.x, den.x), f_div(sl.y, den.y)} * FSNL;   // FSNL = 1 / 0: LCFLX and LWVFLX_SNL
       }
+      if constexpr (RARE) {
+        if (tb.LCFLX && !tb.LWVFLX_SNL) ss = fldw * f;      // SL after SDISSIP, before SNONLIN, unmodulated (implsch.F90:280-288)
+      }
       {
         const T sd = (m < NRED) ? SDSL : T(0);                        // SDIWBK where the point is shallow (SDSL = 0 elsewhere: exact)
         sl = sl - sd * f; fld = fld - sd;
       }
       sl = BETA * sl; fld = BETA * fld;                     // LCISCAL (implsch.F90:316-321); BETA = 1 without it: exact
+      if constexpr (RARE) {
+        if (ice2 || wrs) {
+          V2<T> fli = z2;      // FLDICE of the last active SDICEn (each overwrites SLICE, sdice.F90:94-110)
+          if (ice13) { const T v = row_value(rFLI, m); fli = V2<T>{v, v}; }
+          if (ice2) {          // sdice2.F90:97-121: the attenuation grows with the wave height of the bin itself
+            const T wn = u_wn, cgm = wp[NFRE + m];      // CGROUP(M) of the point: the factor table does not hold it
+            const T dfm = tb.SINROW[m][1];
+            const V2<T> EWH = {T(4) * m_sqrt(m_max(tb.EPSMIN, f.x * dfm)), T(4) * m_sqrt(m_max(tb.EPSMIN, f.y * dfm))};
+            const V2<T> FL2 = -(((tb.CDICWA * (wn * wn)) * tb.ZALPFACB) * cgm) * EWH;
+            sl = sl + CICOVER * (f * FL2); fld = fld + CICOVER * FL2;
+            if (!ice3on) fli = FL2;
+          }
+          if (wrs) {           // SLICE = F FLDICE / GTEMP1 into the ice radiative stress integrand (wnfluxes.F90:178-196)
+            const V2<T> num = f * fli;
+            const V2<T> slice = {f_div(num.x, m_max(T(1) - DELT5 * fli.x, T(1))), f_div(num.y, m_max(T(1) - DELT5 * fli.y, T(1)))};
+            a_ice = a_ice + (u_cinv * rhowg) * V2<T>{m_min(slice.x, -EPSMIN1000), m_min(slice.y, -EPSMIN1000)};
+          }
+        }
+      }
       sl = sl + u_sbo * f; fld = fld + u_sbo;               // SBOTTOM (zero at M > NFRE_RED) + SDICE1 + SDICE3: the table slot
       const T lim = USFM * (cofr * DELT);
       V2<T> fn;
@@ -1307,7 +1468,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     V4SYNC();
     // Rows above the cut-off MIJ need no source terms: IMPHFTAIL replaces them by the tail of row MIJ (imphftail.F90:77-88), their flux
     // weights RHOWGDFTH are zero (frcutindex.F90:100-107), and the only other reader of the updated rows before the tail goes in --
-    // FEMEANWS of implsch.F90:427 -- feeds nothing but the LWFLUX block (:435-445).  Without LWFLUX the sweep therefore ends with the
+    // FEMEANWS of implsch.F90:427 -- feeds nothing but the LWFLUX block (:435-445).  Without LWFLUX (and LWNEMOCOUWRS) the sweep therefore ends with the
     // highest cut-off of the wave's points: interaction MC adds to the rows MC-4 .. MC+3, so the last one needed is MIJ + 4, and the last
     // row updated is row MIJ.  (Exact: the same bits in every output.  On sea states whose cut-off lies in the middle of the frequency
     // range that is a third of the interactions; under sea ice and in light winds MIJ = NFRE and nothing is skipped.)
@@ -1317,7 +1478,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       const int mq = __builtin_amdgcn_readlane(MIJ, G == 18 ? 16 * q : q * G);
       mijmax = mq > mijmax ? mq : mijmax;
     }
-    const bool whole = tb.LWFLUX != 0;
+    const bool whole = tb.LWFLUX != 0 || wrs;      // (the ice radiative stress integrates SLICE over every row, wnfluxes.F90:178-196)
     const int UPD_LIM = whole ? NFRE : mijmax;                                      // rows m < UPD_LIM (0-based) are updated
     const int DIA_LIM = whole ? MLST : (mijmax + 4 < MLST ? mijmax + 4 : MLST);     // interactions MC <= DIA_LIM contribute to them
     const int MC_END = whole ? MLST : (mijmax + 5 < MLST ? mijmax + 5 : MLST);      // row MIJ is updated at the top of interaction MIJ + 5
@@ -1504,6 +1665,14 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     YSTRESS = v4_allsum1<G, T>(sy.x + sy.y, L.rot);
     PHILF = r0.x; XSTRESS = r0.y;
   }
+  T TAUICX = T(0), TAUICY = T(0);
+  if constexpr (RARE) {
+    if (tb.LCFLX && tb.LWNEMOCOUWRS) {   // wnfluxes.F90:178-196, 267-271: the stress on the ice, sign flipped
+      const V2<T> ix = a_ice * L.sinth, iy = a_ice * L.costh;
+      const V2<T> r1 = v4_allsum<G, T>(V2<T>{ix.x + ix.y, iy.x + iy.y}, L.rot);
+      TAUICX = -(tb.ZALPWRS * r1.x); TAUICY = -(tb.ZALPWRS * r1.y);
+    }
+  }
 
   // ---- second FEMEANWS, IMPHFTAIL, SETICE, STOKESDRIFT (implsch.F90:422-462).  The second FKMEAN (implsch.F90:422) has no reader: its
   //      five means are locals of IMPLSCH that nothing uses after it (WNFLUXES ran before it on the means of the old spectrum, MIJ is
@@ -1563,6 +1732,29 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     USTOKES = m_min(m_max(USTOKES, T(-1.5)), T(1.5));
     VSTOKES = m_min(m_max(VSTOKES, T(-1.5)), T(1.5));
   }
+  T STRNMS = T(0);
+  if constexpr (RARE) {
+    if (tb.LWNEMOCOUSTRN) {   // cimsstrn.F90:86-118 with aki_ice.F90:60-112 on the new spectrum: lane j takes the frequencies q G + j + 1
+      WSYNC();
+      const T* spt = sStg + SPOFF + p * NFRE;      // row totals over the directions (the staging rows are idle again)
+      for (int m = 0; m < NFRE; m++) {
+        const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
+        v4_row_total_to_lds<G, T>(f.x + f.y, L.rot, gsp, m);
+      }
+      WSYNC();
+      T term = T(0);
+#pragma unroll
+      for (int q = 0; q < NS; q++) {
+        const int m = q * G + j;
+        const T wn = L.fac4[m * 4 + Q4_WAVNUM];
+        const T XKI = aki_ice_d(tb.G, wn, DEPTH, tb.ROWATER, CITHICKi);
+        const T E = T(0.5) * CITHICKi * (XKI * XKI * XKI) / wn;
+        const T sume = spt[m];
+        if (sume > tb.FLMIN / tb.DELTH) term += (E * E) * sume * tb.DFIM[m];
+      }
+      STRNMS = v4_allsum1<G, T>(term, L.rot);
+    }
+  }
   WSYNC();
   V4_PHASE_EXIT(209);
   // ---- store FL1 (16-byte chunks gathered from VEC rows of the tile), XLLWS(K,M) from the bit masks, per-point scalars
@@ -1608,6 +1800,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   if (j == 0) {
     T* fo = ffa + (size_t)ij * ECWAM_HIP_NFF;
     fo[7] = UFRIC; fo[10] = Z0M; fo[11] = Z0B; fo[12] = CHRNCK;   // TAUW, TAUWDIR: k_implsch4_fin
+    if (RARE && tb.ICODE != 3) fo[3] = WSWAVE;                    // friction-velocity forcing: the 10 m wind is an output (airsea.F90:107-115)
     T* io = intfa + (size_t)ij * ECWAM_HIP_NINTF;
     io[2] = USTOKES; io[3] = VSTOKES;
     T* fr = fin + (size_t)ij * V4_NFIN;
@@ -1617,6 +1810,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     fr[FIN_SINWD] = sinwd; fr[FIN_COSWD] = coswd; fr[FIN_WSWAVE] = WSWAVE; fr[FIN_CICOVER] = CICOVER;
     fr[FIN_PHILF] = PHILF; fr[FIN_XSTRESS] = XSTRESS; fr[FIN_YSTRESS] = YSTRESS;
     fr[FIN_EMEAN] = c[C_EMEAN]; fr[FIN_F1MEAN] = c[C_F1MEAN];   // of the spectrum before the update (implsch.F90:396-414)
+    fr[FIN_TAUICX] = TAUICX; fr[FIN_TAUICY] = TAUICY; fr[FIN_STRNMS] = STRNMS;
+    if (RARE && tb.LWNEMOCOUSTRN) io[4] = STRNMS;
     if (tb.LWFLUX) {
       io[0] = (EMEANWS < tb.WSEMEAN_MIN) ? tb.WSEMEAN_MIN : EMEANWS;
       io[1] = (EMEANWS < tb.WSEMEAN_MIN) ? T(2) * tb.FR[NFRE - 1] : FMEANWS;
@@ -1627,7 +1822,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
 
 // The scalar start of the time step, one sea point per lane (sinflx.F90:105-122): direction of the wind, RNFAC, the first TAUT_Z0
 // (taut_z0.F90:288-340; with LLGCBZ0 only its COSDIFF -- the gravity-capillary iteration needs the spectrum and stays in k_implsch4).
-template <typename T, bool EXT>
+template <typename T, bool EXT, bool RARE = false>
 __global__ void __launch_bounds__(64) k_implsch4_pre(const DevTab<T>* __restrict__ tp, int kijs, int kijl, const T* __restrict__ ffa,
                                                      T* __restrict__ fin) {
   const DevTab<T>& tb = *tp;
@@ -1642,7 +1837,16 @@ __global__ void __launch_bounds__(64) k_implsch4_pre(const DevTab<T>* __restrict
   fr[FIN_RNFAC] = RNFAC;
   T UFRIC = ff[7], Z0M = ff[10], Z0B = ff[11], CHRNCK = ff[12];
   if (EXT && tb.LLGCBZ0) fr[FIN_COSDIFF] = m_cos(WDWAVE - ff[9]);
-  else taut_z0_a(tb, 0, WSWAVE, WDWAVE, ff[8], ff[9], UFRIC, Z0M, Z0B, CHRNCK);
+  if (RARE && tb.ICODE != 3) {
+    // friction-velocity forcing (airsea.F90:100-117): Z0WAVE (z0wave.F90:73-92), then the 10 m wind from the log profile
+    const T ALPHAOG = (tb.LLCAPCHNK ? chnkmin(tb, WSWAVE) : tb.ALPHA) * tb.GM1;
+    const T UST2 = UFRIC * UFRIC, UST3 = UST2 * UFRIC;
+    const T ARG = m_max(UST2 - ff[8], tb.EPS1);
+    Z0M = ALPHAOG * UST3 / m_sqrt(ARG);
+    Z0B = ALPHAOG * UST2;
+    CHRNCK = tb.G * Z0M / UST2;
+    fr[FIN_WSWAVE] = m_max((T(1) / tb.XKAPPA) * UFRIC * (m_log(tb.XNLEV) - m_log(Z0M)), tb.WSPMIN);
+  } else if (!(EXT && tb.LLGCBZ0)) taut_z0_a(tb, 0, WSWAVE, WDWAVE, ff[8], ff[9], UFRIC, Z0M, Z0B, CHRNCK);
   fr[FIN_UFRIC] = UFRIC; fr[FIN_Z0M] = Z0M; fr[FIN_Z0B] = Z0B; fr[FIN_CHRNCK] = CHRNCK;
 }
 
@@ -1708,7 +1912,7 @@ __global__ void __launch_bounds__(64) k_implsch4_fin(const DevTab<T>* __restrict
     PHIOCD = PHIEPS * XN;
     const T PHIAW = OOVAL * PHIWA / XN + (T(1) - OOVAL) * T(3.75);
     T* io = intfa + (size_t)ij * ECWAM_HIP_NINTF;
-    io[5] = TAUXD; io[6] = TAUYD; io[7] = TAUOCXD; io[8] = TAUOCYD; io[9] = TAUOC; io[10] = T(0); io[11] = T(0);
+    io[5] = TAUXD; io[6] = TAUYD; io[7] = TAUOCXD; io[8] = TAUOCYD; io[9] = TAUOC; io[10] = fr[FIN_TAUICX]; io[11] = fr[FIN_TAUICY];
     io[12] = PHIOCD; io[13] = PHIEPS; io[14] = PHIAW;
     if (tb.LWNEMOCOU && w2n) {  // wnfluxes.F90:304-328 (LNUPD = T; no ice stress without LWNEMOCOUWRS: that configuration runs k_implsch2)
       double* q = w2n + (size_t)ij * 13;
@@ -1718,6 +1922,7 @@ __global__ void __launch_bounds__(64) k_implsch4_fin(const DevTab<T>* __restrict
       if (tb.LWNEMOTAUOC) { q[7] += (double)TAUOCXD; q[8] += (double)TAUOCYD; }
       else { q[7] += (double)TAUXD; q[8] += (double)TAUYD; }
       q[11] += (double)WSWAVE; q[12] += (double)PHIOCD;
+      q[9] += (double)fr[FIN_TAUICX]; q[10] += (double)fr[FIN_TAUICY];      // (zero without LWNEMOCOUWRS)
     }
   }
   // stokestrn.F90:75-88 (LWNEMOCOUSTRN = F): the Stokes drift k_implsch4 left in INTFLDS
@@ -1726,5 +1931,6 @@ __global__ void __launch_bounds__(64) k_implsch4_fin(const DevTab<T>* __restrict
     double* q = w2n + (size_t)ij * 13;
     q[0] = tb.LWNEMOCOUSTK ? (double)io[2] : 0.0;
     q[1] = tb.LWNEMOCOUSTK ? (double)io[3] : 0.0;
+    if (tb.LWNEMOCOUSTRN) q[2] = (double)fr[FIN_STRNMS];      // cimsstrn.F90 (the RARE build of the main kernel)
   }
 }

@@ -59,6 +59,16 @@ def _oracle(cfg, prec):
     return Oracle(cfg, prec)
 
 
+def _generation(cfg, prec):
+    """The kernel generation ecwam_hip_implsch runs for a configuration the fast kernel covers (capi.hip): the common builds in both
+    precisions; the RARE builds (csrc/implsch4r.hip) in single precision only, double precision keeps k_implsch2 for those."""
+    rare = (cfg.lciwa2 or cfg.lwnemocouwrs or cfg.lwnemocoustrn or cfg.isnonlin > 1 or cfg.icode != 3 or not cfg.lwvflx_snl)
+    ext = cfg.llgcbz0 or cfg.llnormagam
+    alt = (1 if cfg.iphys == 0 else 0) | (2 if cfg.isnonlin == 1 else 0)
+    common = not rare and (alt == 0 or (not ext and alt != 3))
+    return 4 if (common or prec == "sp") else 2
+
+
 def test_wavefront_primitives(api):
     """usum/usum2/usum4/umax/umax2 (DPP + v_permlane*_swap), v_readlane, ds_bpermute and the lane rotations against
     serial sums, in both precisions, on the device itself."""
@@ -156,6 +166,7 @@ def test_implsch_parity_sea_ice_attenuation(api, prec, flags):
     ref = H.oracle_implsch(case, _oracle(cfg, prec))
     ctx = api.HipContext(case["tables"])
     got = H.gpu_implsch(case, ctx)
+    assert ctx.implsch_generation_used() == _generation(cfg, prec)      # (LCIWA2: the RARE build of the fast kernel, sp)
     st = H.compare_implsch(ref, got, case["tables"])
     ctx.close()
     assert np.isfinite(got["FL1"]).all() and np.isfinite(got["INTF"]).all()
@@ -181,7 +192,7 @@ def test_implsch_sea_ice_damping_on_the_fast_kernel(api, prec, nang, nred, flags
     ref = H.oracle_implsch(case, _oracle(cfg, prec))
     ctx = api.HipContext(case["tables"])
     got = H.gpu_implsch(case, ctx)
-    assert ctx.implsch_generation_used() == 4
+    assert ctx.implsch_generation_used() == _generation(cfg, prec)
     ctx.set_implsch_generation(2)
     old = H.gpu_implsch(case, ctx)
     assert ctx.implsch_generation_used() == 2
@@ -217,7 +228,7 @@ def test_implsch_parity_sdice1_and_ice_breakup(api, prec, flags):
     ref = H.oracle_implsch(case, _oracle(cfg, prec))
     ctx = api.HipContext(case["tables"])
     got = H.gpu_implsch(case, ctx)
-    assert ctx.implsch_generation_used() == 4      # both option sets are damping rates per (point, frequency): the fast kernel
+    assert ctx.implsch_generation_used() == _generation(cfg, prec)      # both option sets are damping rates per (point, frequency): the fast kernel
     st = H.compare_implsch(ref, got, case["tables"])
     ctx.close()
     assert np.isfinite(got["FL1"]).all() and np.isfinite(got["INTF"]).all()
@@ -247,6 +258,7 @@ def test_ice_radiative_stress_and_strain(api, prec, flags):
     ref = H.oracle_implsch(case, _oracle(cfg, prec))
     ctx = api.HipContext(case["tables"])
     got = H.gpu_implsch(case, ctx)
+    assert ctx.implsch_generation_used() == _generation(cfg, prec)
     ctx.close()
     tol = 1e-10 if prec == "dp" else 2e-4
     real_stress = any(flags.get(k) for k in ("lciwa1", "lciwa2", "lciwa3"))
@@ -321,7 +333,7 @@ def test_implsch_parity_isnonlin_1_2(api, prec, isnonlin):
     ref = H.oracle_implsch(case, o)
     ctx = api.HipContext(case["tables"])
     got = H.gpu_implsch(case, ctx)
-    assert ctx.implsch_generation_used() == (4 if isnonlin == 1 else 2)      # ISNONLIN = 1 is a build of the fast kernel
+    assert ctx.implsch_generation_used() == _generation(cfg, prec)      # ISNONLIN = 1 is a build of the fast kernel, ISNONLIN = 2 runs its RARE build (sp)
     st = H.compare_implsch(ref, got, case["tables"])
     ctx.close()
     if prec == "dp":
@@ -357,16 +369,14 @@ def test_alternate_physics_on_the_fast_kernel(api, prec, nang, nred, flags):
     ref = H.oracle_implsch(case, _oracle(cfg, prec))
     ctx = api.HipContext(case["tables"])
     got = H.gpu_implsch(case, ctx)
-    both = "iphys" in flags and "isnonlin" in flags
-    assert ctx.implsch_generation_used() == (2 if both else 4)
+    assert ctx.implsch_generation_used() == _generation(cfg, prec)      # (both at once: the RARE build of the IPHYS = 0 kernel, sp)
     st = H.compare_implsch(ref, got, case["tables"])
     _assert_implsch_stats(st, n, prec)
-    if not both:
-        ctx.set_implsch_generation(2)
-        got2 = H.gpu_implsch(case, ctx)
-        assert ctx.implsch_generation_used() == 2
-        st2 = H.compare_implsch(got2, got, case["tables"])
-        assert st2["mij_flips"] == 0 and st2["xllws_bins_diff"] == 0 and st2["fl1_max_rel_peak_all"] < (1e-12 if prec == "dp" else 2e-5), st2
+    ctx.set_implsch_generation(2)
+    got2 = H.gpu_implsch(case, ctx)
+    assert ctx.implsch_generation_used() == 2
+    st2 = H.compare_implsch(got2, got, case["tables"])
+    assert st2["mij_flips"] == 0 and st2["xllws_bins_diff"] == 0 and st2["fl1_max_rel_peak_all"] < (1e-12 if prec == "dp" else 2e-5), st2
     ctx.close()
 
 
@@ -416,6 +426,7 @@ def test_implsch_fluxes_without_the_nonlinear_transfer(api, prec):
     ref = H.oracle_implsch(case, _oracle(cfg, prec))
     ctx = api.HipContext(case["tables"])
     got = H.gpu_implsch(case, ctx)
+    assert ctx.implsch_generation_used() == _generation(cfg, prec)
     st = H.compare_implsch(ref, got, case["tables"])
     ctx.close()
     if prec == "dp":
@@ -637,6 +648,7 @@ def test_implsch_parity_friction_velocity_forcing(api, prec, flags):
     ref = H.oracle_implsch(case, _oracle(cfg, prec))
     ctx = api.HipContext(case["tables"])
     got = H.gpu_implsch(case, ctx)
+    assert ctx.implsch_generation_used() == _generation(cfg, prec)
     st = H.compare_implsch(ref, got, case["tables"])
     tol = 1e-11 if prec == "dp" else 2e-5
     assert np.max(np.abs(got["FF"][:, 3].astype(float) - ref["FF"][:, 3].astype(float)) / ref["FF"][:, 3]) < tol    # WSWAVE written back
@@ -1102,7 +1114,7 @@ def test_sweep_cut_at_the_cutoff_frequency_is_exact(api, prec, nang, nred, flags
         case["FF"] = syn.forcing(case["params"], slice(0, n), case["tables"], H.np_dtype(prec))
         ctx = api.HipContext(case["tables"])
         got = H.gpu_implsch(case, ctx)
-        assert ctx.implsch_generation_used() == 4
+        assert ctx.implsch_generation_used() == _generation(cfg, prec)
         ctx.close()
         res[lw] = got
         if not lw:
@@ -1147,3 +1159,37 @@ def test_registered_configurations_run_on_the_fast_kernel(api, name, prec):
     ctx.close()
     assert gen == 4, (name, prec, gen)
     _assert_implsch_stats(H.compare_implsch(ref, got, case["tables"]), n, prec)
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+@pytest.mark.parametrize("nang,nred", [(36, 36), (12, 25)])
+@pytest.mark.parametrize("flags", [dict(lciwa1=True, lciwa2=True, lmaskice=False, lwnemocou=True, lwnemocouwrs=True, lwnemocoustrn=True, zalpwrs=0.8, isnonlin=2),
+                                   dict(llgcbz0=True, llnormagam=True, isnonlin=1, icode=1, lwvflx_snl=False),
+                                   dict(iphys=0, isnonlin=2, lciwa2=True, lmaskice=False)])
+def test_rare_builds_of_the_fast_kernel(api, prec, nang, nred, flags):
+    """What no registered configuration selects, in combinations, at the direction counts the single-flag tests above do not visit:
+    the RARE builds of k_implsch4 (csrc/implsch4r.hip) against the oracle and against k_implsch2."""
+    cfg = Config(nang=nang, nfre=36, nfre_red=nred, **flags)
+    case = _ice_case(cfg, prec, n=600, seed=41)
+    n = case["n"]
+    if flags.get("lwnemocou"):
+        case["W2N"] = np.random.default_rng(2).uniform(-1.0, 1.0, (n, 13))
+    ref = H.oracle_implsch(case, _oracle(cfg, prec))
+    ctx = api.HipContext(case["tables"])
+    got = H.gpu_implsch(case, ctx)
+    assert ctx.implsch_generation_used() == _generation(cfg, prec)
+    ctx.set_implsch_generation(2)
+    old = H.gpu_implsch(case, ctx)
+    assert ctx.implsch_generation_used() == 2
+    ctx.close()
+    _assert_implsch_stats(H.compare_implsch(ref, got, case["tables"]), n, prec)
+    st2 = H.compare_implsch(old, got, case["tables"])
+    assert st2["mij_flips"] == 0 and st2["xllws_bins_diff"] == 0 and st2["fl1_max_rel_peak_all"] < (1e-12 if prec == "dp" else 2e-5), st2
+    tol = 1e-10 if prec == "dp" else 2e-4
+    if flags.get("lwnemocou"):
+        for col in (4, 10, 11):      # STRNMS, TAUICX, TAUICY
+            r, g = ref["INTF"][:, col].astype(float), got["INTF"][:, col].astype(float)
+            assert np.abs(g - r).max() < tol * max(np.abs(r).max(), 1e-300), col
+        assert np.abs(got["W2N"] - ref["W2N"]).max() < tol * np.abs(ref["W2N"]).max()
+    if flags.get("icode", 3) != 3:
+        assert np.max(np.abs(got["FF"][:, 3].astype(float) - ref["FF"][:, 3].astype(float)) / ref["FF"][:, 3]) < (1e-11 if prec == "dp" else 2e-5)

@@ -360,7 +360,7 @@ def main() -> None:
         prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
         default_wl = world == 1 and ng == 320 and a.prec == "sp" and a.nang == 36 and a.nfre == 36 and a.weights == "otf" and not a.irefra
         traffic = None
-        tf = os.path.join(prof, "r03_hbm_traffic_pmc.json")
+        tf = os.path.join(prof, "r04_hbm_traffic_pmc.json")
         if default_wl and os.path.exists(tf):
             with open(tf) as fh:
                 pm = json.load(fh).get(dom, {})
@@ -373,12 +373,12 @@ def main() -> None:
         # itself say 4.2 cycles of VALU activity per instruction (its mix is two thirds packed fp32 at 4.4 cycles): the VALU of a SIMD is
         # busy 74 % of the time, which is the headroom that is left -- valu_busy_fraction_pmc is the figure to read.
         valu = None
-        pf = os.path.join(prof, "r03_implsch_pmc.json")
+        pf = os.path.join(prof, "r04_implsch_pmc.json")
         if default_wl and os.path.exists(pf):
             with open(pf) as fh:
                 pm = json.load(fh)
             ceil_pts = 256 * 4 * 2.4e9 / (2.6 * pm["SQ_INSTS_VALU"])
-            valu = {"kernel": "implsch", "source": "committed_pmc", "file": "profiles/r03_implsch_pmc.json",
+            valu = {"kernel": "implsch", "source": "committed_pmc", "file": "profiles/r04_implsch_pmc.json",
                     "valu_busy_fraction_pmc": pm["valu_busy_fraction"], "valu_insts_per_point": pm["SQ_INSTS_VALU"],
                     "cycles_per_valu_inst_assumed": 2.6, "issue_ceiling_points_per_s": ceil_pts,
                     "achieved_points_per_s": m.n / (t_impl * 1e-3), "frac_of_issue_ceiling": m.n / (t_impl * 1e-3) / ceil_pts}
@@ -412,7 +412,7 @@ def main() -> None:
                                        for i, r_ in enumerate(per_rank)] if per_rank else None),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "committed_pmc: profiles/r03_hbm_traffic_pmc.json (rocprofv3 --pmc passes of this command on another run; not measured live)" if traffic is not None else None},
+                         "traffic_source": "committed_pmc: profiles/r04_hbm_traffic_pmc.json (rocprofv3 --pmc passes of this command on another run; not measured live)" if traffic is not None else None},
             "kernels": kern,
             "valu": valu,
             "finite": finite,

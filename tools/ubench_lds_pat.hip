@@ -6,6 +6,7 @@
 #include <vector>
 #include <string>
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 #define N_INNER 64
 #define N_OUTER 1000
 template <int KIND>
@@ -15,8 +16,8 @@ __global__ void __launch_bounds__(256) k(float* out, int n_outer, long long* clk
   for (int i = t; i < 4 * 1024; i += 256) lds[i] = (float)i;
   __syncthreads();
   const int addr = wv * 4096 + tab[lane];
-  float a[8]; f2 p[8];
-  for (int i = 0; i < 8; i++) { a[i] = (float)i; p[i] = f2{a[i], 1.f}; }
+  float a[8]; f2 p[8]; f4 r4[8];
+  for (int i = 0; i < 8; i++) { a[i] = (float)i; p[i] = f2{a[i], 1.f}; r4[i] = f4{a[i], 1.f, 2.f, 3.f}; }
   long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int o = 0; o < n_outer; o++) {
 #pragma unroll
@@ -26,12 +27,17 @@ __global__ void __launch_bounds__(256) k(float* out, int n_outer, long long* clk
       if (KIND == 1) asm volatile("ds_read_b64 %0, %1" : "=v"(p[s]) : "v"(addr));
       if (KIND == 2) asm volatile("ds_write_b64 %0, %1" : : "v"(addr), "v"(p[s]));
       if (KIND == 3) asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(a[s]));
+      if (KIND == 4) asm volatile("ds_read2_b64 %0, %1 offset0:0 offset1:54" : "=v"(r4[s]) : "v"(addr));     // two rows (row stride 108 words)
+      if (KIND == 5) asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:108" : "=v"(p[s]) : "v"(addr));
+      if (KIND == 6) asm volatile("ds_write2_b64 %0, %1, %2 offset0:0 offset1:54" : : "v"(addr), "v"(p[s]), "v"(p[(s + 1) & 7]));
+      if (KIND == 7) asm volatile("ds_write_b128 %0, %1" : : "v"(addr), "v"(r4[s]));
+      if (KIND == 8) asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:1" : "=v"(p[s]) : "v"(addr));
     }
     asm volatile("s_waitcnt lgkmcnt(0)");
   }
   long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   float s = 0.f;
-  for (int i = 0; i < 8; i++) s += a[i] + p[i].x + p[i].y;
+  for (int i = 0; i < 8; i++) s += a[i] + p[i].x + p[i].y + r4[i].x + r4[i].w;
   out[blockIdx.x * 256 + t] = s + lds[t];
   if (t == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
@@ -95,6 +101,20 @@ int main() {
       }
       printf("\n");
     }
+  }
+
+  {
+    const int bb[3] = {0, 36, 72};
+    printf("two rows per instruction, kernel map (second row 108 words further):\n");
+    for (int sh : {-4, -2, 0, 2, 4}) { char nm[160]; snprintf(nm, sizeof nm, "  ds_read2_b64 even rotation %+d of two rows", sh); pr(nm, run<4>(v4tab(bb, sh, 0))); }
+    for (int sh : {-3, -1, 1, 3}) { char nm[160]; snprintf(nm, sizeof nm, "  ds_read2_b32 first halves of odd rotation %+d of two rows", sh); pr(nm, run<5>(v4tab(bb, sh, 0))); }
+    for (int sh : {-3, -1, 1, 3}) { char nm[160]; snprintf(nm, sizeof nm, "  ds_read2_b32 both halves (adjacent words) of odd rotation %+d", sh); pr(nm, run<8>(v4tab(bb, sh, 0))); }
+    pr("  ds_write2_b64 own pair into two rows", run<6>(v4tab(bb, 0, 0)));
+    for (int l = 0; l < 64; l++) t[l] = 16 * l;
+    pr("  ds_write_b128 stride 16 B", run<7>(t));
+    for (int l = 0; l < 64; l++) t[l] = 8 * l;
+    pr("  ds_write2_b64 stride 8 B into two rows", run<6>(t));
+    pr("  ds_read2_b64 stride 8 B of two rows", run<4>(t));
   }
   const int b0[3] = {0, 36, 72}, b1[3] = {0, 37, 74}, b2[3] = {0, 36, 73}, b3[3] = {0, 38, 76}, b4[3] = {0, 37, 72}, b5[3] = {0, 40, 80}, b6[3] = {0, 41, 82};
   struct { const char* n; const int* b; } lay[] = {{"bases 0,36,72 (now)", b0}, {"bases 0,37,74", b1}, {"bases 0,36,73", b2}, {"bases 0,38,76", b3}, {"bases 0,37,72", b4}, {"bases 0,40,80", b5}, {"bases 0,41,82", b6}};

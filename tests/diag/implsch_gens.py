@@ -1,6 +1,6 @@
 """IMPLSCH kernel generations side by side (diagnostics, not a test): time per launch and parity statistics against the oracle.
 python tests/diag/implsch_gens.py [npoints] [prec,...] [nang,...] [A|B|N|G|J|E: flag set A, B (LLGCBZ0 + LLNORMAGAM), LLNORMAGAM only, LLGCBZ0 only, IPHYS = 0, ISNONLIN = 1;
-the RARE builds: R2 = ISNONLIN 2, RI = LCIWA1 + LCIWA2, RU = ICODE 1, RB = flag set B + ISNONLIN 1, RJ = IPHYS 0 + ISNONLIN 1]"""
+the RARE builds: R2 = ISNONLIN 2, RI = LCIWA1 + LCIWA2, RU = ICODE 1, RW = LWVFLX_SNL = F, RB = flag set B + ISNONLIN 1, RJ = IPHYS 0 + ISNONLIN 1]"""
 import json
 import os
 import sys
@@ -23,7 +23,7 @@ NRED = {36: 36, 24: 29, 12: 25}
 FLAGS = {"A": {}, "B": dict(llgcbz0=True, llnormagam=True), "N": dict(llnormagam=True), "G": dict(llgcbz0=True), "J": dict(iphys=0),
          "E": dict(isnonlin=1), "R2": dict(isnonlin=2),
          "RI": dict(lciwa1=True, lciwa2=True, lmaskice=False),
-         "RU": dict(icode=1), "RB": dict(llgcbz0=True, llnormagam=True, isnonlin=1), "RJ": dict(iphys=0, isnonlin=1)}[sys.argv[4] if len(sys.argv) > 4 else "A"]
+         "RU": dict(icode=1), "RW": dict(lwvflx_snl=False), "RB": dict(llgcbz0=True, llnormagam=True, isnonlin=1), "RJ": dict(iphys=0, isnonlin=1)}[sys.argv[4] if len(sys.argv) > 4 else "A"]
 for nang in nangs:
     for prec in precs:
         cfg = Config(nang=nang, nfre=36, nfre_red=NRED[nang], idelt=450, idelpro=450, **FLAGS)

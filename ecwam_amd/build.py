@@ -12,13 +12,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libecwam_hip.so")
-SOURCES = ["capi.hip", "propag.hip", "implsch.hip", "implsch4.hip", "implsch4x.hip", "implsch4r.hip", "outbs.hip"]
+SOURCES = ["capi.hip", "propag.hip", "implsch.hip", "implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip", "outbs.hip"]
+# objects that are a second compilation of another source: object name -> (source, extra flags; a later -O overrides the earlier one).
+# implsch4rd = the double precision RARE builds of k_implsch4 at -O2 (their -O3 builds fault on the device: implsch4r.hip)
+DERIVED = {"implsch4r.hip": ("implsch4r.hip", ["-DV4R_PREC=1"]), "implsch4rd.hip": ("implsch4r.hip", ["-DV4R_PREC=2", "-O2"])}
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # IMPLSCH is VALU-issue bound: single-precision divide/sqrt by the hardware reciprocal / square root plus one
 # refinement (<= 2.5 ulp) instead of the correctly rounded sequences; double precision is unaffected.
 FAST_DIV = ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
-IMPLSCH_SOURCES = ("implsch.hip", "implsch4.hip", "implsch4x.hip", "implsch4r.hip")
+IMPLSCH_SOURCES = ("implsch.hip", "implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip")
 # Build variants of the IMPLSCH translation units (the single-precision error attribution):
 #   ""         the product build: hardware reciprocal / square root / exp2 / log2 in single precision, FMA contraction on
 #   "exactdiv" every `/` and SQRT the source spells out is correctly rounded (the scalar chains per sea point: TAUT_Z0, STRESSO, FKMEAN,
@@ -35,7 +38,16 @@ IMPLSCH_SOURCES = ("implsch.hip", "implsch4.hip", "implsch4x.hip", "implsch4r.hi
 VARIANTS = {"": FAST_DIV, "exactdiv": ["-DECWAM_HIP_STRICT=0"], "strict1": ["-DECWAM_HIP_STRICT=1"], "strict2": FAST_DIV + ["-DECWAM_HIP_STRICT=2"],
             "site4": ["-DECWAM_HIP_STRICT=4"], "site8": ["-DECWAM_HIP_STRICT=8"], "site32": ["-DECWAM_HIP_STRICT=32"],
             "strict3": ["-DECWAM_HIP_STRICT=3"], "strict7": ["-DECWAM_HIP_STRICT=3", "-ffp-contract=off"],
-            "noieee": FAST_DIV + ["-mno-amdgpu-ieee", "-fno-honor-nans"]}
+            "noieee": FAST_DIV + ["-mno-amdgpu-ieee", "-fno-honor-nans"],
+            # round 5, the double precision RARE builds of k_implsch4 (profiles/r05_rare_dp_rootcause.txt): the object implsch4rd (product:
+            # -O2) at -O3 (faults), -O1, -O3 with index assertions, and -O3 as the two-kernel split (-DV4R_DP=2)
+            "rdp": FAST_DIV + ["-O3"], "rdpO1": FAST_DIV + ["-O1"], "rdpchk": FAST_DIV + ["-O3", "-DV4_CHECK=1"],
+            "rdps": FAST_DIV + ["-O3", "-DV4R_DP=2"],
+            # every build of k_implsch4 as the two-kernel split (PART 1: through the second SINFLX call | PART 2: sweep, fluxes, tail, stores)
+            "split": FAST_DIV + ["-DV4_SPLIT_ALL=1", "-DV4R_DP=2"]}
+# variants that rebuild only some of the IMPLSCH translation units (the other objects are the product's)
+VARIANT_SOURCES = {"rdp": ("implsch4rd.hip",), "rdpO1": ("implsch4rd.hip",), "rdpchk": ("implsch4rd.hip",), "rdps": ("implsch4rd.hip",),
+                   "split": ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip")}
 
 INCLUDE = os.path.join(HERE, "..", "include", "ecwam_hip.h")
 
@@ -76,11 +88,12 @@ def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
     lib = lib_path(variant)
     objs, procs, stamps = [], [], {}
     for src in SOURCES:
-        special = bool(variant) and src in IMPLSCH_SOURCES
+        special = bool(variant) and src in VARIANT_SOURCES.get(variant, IMPLSCH_SOURCES)
         obj = os.path.join(LIBDIR, src.replace(".hip", f".{variant}.o" if special else ".o"))
-        flags = FLAGS + ((VARIANTS[variant] if special else FAST_DIV) if src in IMPLSCH_SOURCES else [])
+        real_src, extra = DERIVED.get(src, (src, []))
+        flags = FLAGS + extra + ((VARIANTS[variant] if special else FAST_DIV) if src in IMPLSCH_SOURCES else [])
         objs.append(obj)
-        st = _stamp(src, flags)
+        st = _stamp(real_src, flags)
         old = ""
         if os.path.exists(obj) and os.path.exists(obj + ".stamp"):
             with open(obj + ".stamp") as fh:
@@ -88,7 +101,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
         if not force and old == st:
             continue
         stamps[obj] = st
-        cmd = [HIPCC, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC, *flags, "-c", os.path.join(CSRC, real_src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

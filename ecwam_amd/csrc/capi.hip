@@ -34,6 +34,8 @@ struct ecwam_hip_ctx {
   int implsch_last = 0; // generation the last ecwam_hip_implsch call launched (2 / 4)
   void* fin = nullptr;  // rows of scalars k_implsch4 hands to its finishing kernel, indexed by the point number; grown on demand
   size_t fin_bytes = 0;
+  void* wi = nullptr;   // rows [ij][M][K] for the wind-input coefficient between the two kernels of the split k_implsch4 (only allocated
+  size_t wi_bytes = 0;  // where the split runs: the double precision RARE builds, the "split" build variant of the library)
   // advection halo exchange (MPEXCHNG): peers, the owned rows each of them needs (concatenated in peer order) and where their rows
   // land; RCCL communicator + a stream of its own so that the exchange runs beside the interior stencil
   int rank = 0, nranks = 1;
@@ -82,10 +84,12 @@ template <typename T> void launch_pack(const void*, const int*, int, int, void*,
 template <typename T> void launch_proenv_pack(int, int, const void*, const void*, const void*, const void*, const void*, void*, hipStream_t);
 template <typename T> void launch_proenv_unpack(int, int, const void*, const void*, void*, void*, void*, void*, void*, void*, hipStream_t);
 template <typename T> int launch_implsch(const void*, int, int, void*, const void*, void*, void*, int*, void*, double*, void*, int, int, int, hipStream_t);
-template <typename T> int launch_implsch4(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, int, int, int, int, int, int, hipStream_t);
-template <typename T> int launch_implsch4x(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, int, int, int, int, int, int, hipStream_t);
-template <typename T> int launch_implsch4r(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, int, int, int, int, int, int, hipStream_t);
+template <typename T> int launch_implsch4(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, void*, int, int, int, int, int, int, hipStream_t);
+template <typename T> int launch_implsch4x(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, void*, int, int, int, int, int, int, hipStream_t);
+template <typename T> int launch_implsch4r(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, void*, int, int, int, int, int, int, hipStream_t);
 int implsch4_fin_row();
+int implsch4_split_all();
+int implsch4r_dp_split();
 
 // Does the fourth kernel generation cover these tables?  It needs the pull-form DIA structure with K1W = K -+ r1, K11W = K1W -+ 1,
 // K2W = K +- r2, K21W = K2W +- 1 (kh = 1 / 2) and saturation weights that depend on the tap only (init_sdiss_ardh.F90:88-94: they
@@ -435,6 +439,7 @@ int ecwam_hip_destroy(ecwam_hip_ctx* c) {
   if (c->dtab) (void)hipFree(c->dtab);
   if (c->norm_scratch) (void)hipFree(c->norm_scratch);
   if (c->fin) (void)hipFree(c->fin);
+  if (c->wi) (void)hipFree(c->wi);
   halo_release(c);
   delete c;
   return 0;
@@ -684,14 +689,14 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !dbg && shelter_ok && !(c->p.iphys == 0 && ext)) {
     if (int rc2 = ecwam_hip_implsch_reserve(c, kijl)) return rc2;   // no-op once the buffer covers kijl
     if (!common_ok)
-      DISPATCH(rc = launch_implsch4r<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, c->p.iphys == 0 ? 1 : 0, s),
-               rc = launch_implsch4r<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, c->p.iphys == 0 ? 1 : 0, s));
+      DISPATCH(rc = launch_implsch4r<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->wi, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, c->p.iphys == 0 ? 1 : 0, s),
+               rc = launch_implsch4r<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->wi, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, c->p.iphys == 0 ? 1 : 0, s));
     else if (alt)
-      DISPATCH(rc = launch_implsch4x<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, alt, s),
-               rc = launch_implsch4x<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, alt, s));
+      DISPATCH(rc = launch_implsch4x<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->wi, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, alt, s),
+               rc = launch_implsch4x<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->wi, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, alt, s));
     else
-      DISPATCH(rc = launch_implsch4<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s),
-               rc = launch_implsch4<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s));
+      DISPATCH(rc = launch_implsch4<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->wi, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s),
+               rc = launch_implsch4<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->wi, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s));
     if (rc == 0) { HIPCHK(hipGetLastError()); c->implsch_last = 4; return 0; }
   }
   c->implsch_last = 2;
@@ -721,6 +726,15 @@ int ecwam_hip_implsch_reserve(ecwam_hip_ctx* c, int npts) {
     HIPCHK(hipMalloc(&c->fin, need));
     HIPCHK(hipMemset(c->fin, 0, need));
     c->fin_bytes = need;
+  }
+  // the split kernel pair parks the wind-input coefficient of every bin between its two halves
+  const bool split = implsch4_split_all() || (c->real_bytes == 8 && implsch4r_dp_split());
+  const size_t need_wi = split ? (size_t)(npts > 0 ? npts : 0) * c->NANG * c->NFRE * c->real_bytes : 0;
+  if (need_wi > c->wi_bytes) {
+    if (c->wi) HIPCHK(hipFree(c->wi));
+    c->wi = nullptr; c->wi_bytes = 0;
+    HIPCHK(hipMalloc(&c->wi, need_wi));
+    c->wi_bytes = need_wi;
   }
   return 0;
 }

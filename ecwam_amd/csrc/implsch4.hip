@@ -7,11 +7,11 @@
 // returns 0 when launched, -1 when no instantiation covers (NANG, r1, r2, nh): the caller falls back to k_implsch2
 template <typename T>
 int launch_implsch4(const void* tab, int kijs, int kijl, void* fl1, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws,
-                    void* fin, double* w2n, void* gfast, int gk, int NANG, int NFRE, int r1, int r2, int nh, int ext, hipStream_t s) {
+                    void* fin, double* w2n, void* gfast, int gk, void* wi, int NANG, int NFRE, int r1, int r2, int nh, int ext, hipStream_t s) {
   if (kijl - kijs <= 0) return 0;
   if (NFRE != V4_NFRE) return -1;
   constexpr bool SP = sizeof(T) == 4;
-#define V4_ARGS tab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, fin, w2n, gfast, gk, s
+#define V4_ARGS tab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, fin, w2n, gfast, gk, wi, s
   if (NANG == 36 && r1 == 1 && r2 == 3 && nh == 8)
     return ext ? launch4<T, 36, SP ? 3 : V4_DP36_PP, 1, 3, 8, true>(V4_ARGS) : launch4<T, 36, SP ? 3 : V4_DP36_PP, 1, 3, 8, false>(V4_ARGS);
   if (NANG == 24 && r1 == 0 && r2 == 2 && nh == 5)
@@ -23,5 +23,7 @@ int launch_implsch4(const void* tab, int kijs, int kijl, void* fl1, const void* 
 }
 // elements of the working precision per sea point the caller provides in fin (indexed by the absolute point number, like FL1)
 int implsch4_fin_row() { return V4_NFIN; }
-template int launch_implsch4<float>(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, int, int, int, int, int, int, hipStream_t);
-template int launch_implsch4<double>(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, int, int, int, int, int, int, hipStream_t);
+// 1 when every build of the library runs as the two-kernel split (build variant "split"): the context then owns wind-input rows
+int implsch4_split_all() { return V4_SPLIT_ALL != 0 ? 1 : 0; }
+template int launch_implsch4<float>(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, void*, int, int, int, int, int, int, hipStream_t);
+template int launch_implsch4<double>(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, void*, int, int, int, int, int, int, hipStream_t);

@@ -11,23 +11,43 @@
 // source with an early-exit branch at each phase boundary (the diagnostics build) runs correctly, so does the build with the carried SDICE
 // rates removed, while scheduling barriers, SGPR spills to memory instead of to lanes and a recomputed instead of a carried rate change
 // nothing (profiles/r04_rare_dp_note.txt): not understood, so double precision keeps k_implsch2 for these configurations.
+// V4R_PREC selects the precision this object instantiates: 1 = single (implsch4r.o), 2 = double (implsch4rd.o, compiled at -O2: at -O3 the
+// double precision builds end in a memory access fault or in wrong numbers on their first launch, with every rare switch off at run time,
+// while -O2, -O1 and -O3 with index assertions on every table and row access run clean -- profiles/r05_rare_dp_rootcause.txt).
+// V4R_DP = 2: the double precision builds as the two-kernel split (launch4 SPLIT).
+#ifndef V4R_PREC
+#define V4R_PREC 3
+#endif
+#ifndef V4R_DP
+#define V4R_DP 1
+#endif
 template <typename T>
 int launch_implsch4r(const void* tab, int kijs, int kijl, void* fl1, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws,
-                     void* fin, double* w2n, void* gfast, int gk, int NANG, int NFRE, int r1, int r2, int nh, int jan, hipStream_t s) {
-  if constexpr (sizeof(T) != 4) return -1;
+                     void* fin, double* w2n, void* gfast, int gk, void* wi, int NANG, int NFRE, int r1, int r2, int nh, int jan, hipStream_t s) {
+  constexpr bool SP = sizeof(T) == 4;
+  if constexpr (!SP && !V4R_DP) return -1;
   else {
     if (kijl - kijs <= 0) return 0;
     if (NFRE != V4_NFRE) return -1;
-#define V4_ARGS tab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, fin, w2n, gfast, gk, s
+#define V4_ARGS tab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, fin, w2n, gfast, gk, wi, s
+    // double precision: the two-kernel split (V4R_DP = 2); single precision: one kernel unless the whole library is built as the split
+    constexpr bool SPL = (!SP && V4R_DP == 2) || V4_SPLIT_ALL != 0;
     if (NANG == 36 && r1 == 1 && r2 == 3 && nh == 8)
-      return jan ? launch4<T, 36, 3, 1, 3, 8, false, true, true, true>(V4_ARGS) : launch4<T, 36, 3, 1, 3, 8, true, false, true, true>(V4_ARGS);
+      return jan ? launch4<T, 36, 3, 1, 3, 8, false, true, true, true, SPL>(V4_ARGS) : launch4<T, 36, 3, 1, 3, 8, true, false, true, true, SPL>(V4_ARGS);
     if (NANG == 24 && r1 == 0 && r2 == 2 && nh == 5)
-      return jan ? launch4<T, 24, 5, 0, 2, 5, false, true, true, true>(V4_ARGS) : launch4<T, 24, 5, 0, 2, 5, true, false, true, true>(V4_ARGS);
+      return jan ? launch4<T, 24, SP ? 5 : 4, 0, 2, 5, false, true, true, true, SPL>(V4_ARGS) : launch4<T, 24, SP ? 5 : 4, 0, 2, 5, true, false, true, true, SPL>(V4_ARGS);
     if (NANG == 12 && r1 == 0 && r2 == 1 && nh == 3)
-      return jan ? launch4<T, 12, 10, 0, 1, 3, false, true, true, true>(V4_ARGS) : launch4<T, 12, 10, 0, 1, 3, true, false, true, true>(V4_ARGS);
+      return jan ? launch4<T, 12, SP ? 10 : 5, 0, 1, 3, false, true, true, true, SPL>(V4_ARGS) : launch4<T, 12, SP ? 10 : 5, 0, 1, 3, true, false, true, true, SPL>(V4_ARGS);
 #undef V4_ARGS
     return -1;
   }
 }
-template int launch_implsch4r<float>(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, int, int, int, int, int, int, hipStream_t);
-template int launch_implsch4r<double>(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, int, int, int, int, int, int, hipStream_t);
+#define V4R_SIG(T) template int launch_implsch4r<T>(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, void*, int, int, int, int, int, int, hipStream_t)
+#if V4R_PREC & 1
+V4R_SIG(float);
+#endif
+#if V4R_PREC & 2
+V4R_SIG(double);
+// 1 when the double precision builds of this unit need the context's wind-input rows (the two-kernel split)
+int implsch4r_dp_split() { return V4R_DP == 2 ? 1 : 0; }
+#endif

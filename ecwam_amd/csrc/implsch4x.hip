@@ -7,11 +7,11 @@
 // variant: 1 = IPHYS 0, 2 = ISNONLIN 1.  Returns 0 when launched, -1 when no instantiation covers the configuration (k_implsch2 runs it).
 template <typename T>
 int launch_implsch4x(const void* tab, int kijs, int kijl, void* fl1, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws,
-                     void* fin, double* w2n, void* gfast, int gk, int NANG, int NFRE, int r1, int r2, int nh, int variant, hipStream_t s) {
+                     void* fin, double* w2n, void* gfast, int gk, void* wi, int NANG, int NFRE, int r1, int r2, int nh, int variant, hipStream_t s) {
   if (kijl - kijs <= 0) return 0;
   if (NFRE != V4_NFRE || (variant != 1 && variant != 2)) return -1;
   constexpr bool SP = sizeof(T) == 4;
-#define V4_ARGS tab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, fin, w2n, gfast, gk, s
+#define V4_ARGS tab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, fin, w2n, gfast, gk, wi, s
   if (NANG == 36 && r1 == 1 && r2 == 3 && nh == 8)
     return variant == 1 ? launch4<T, 36, SP ? 3 : V4_DP36_PP, 1, 3, 8, false, true, false>(V4_ARGS)
                         : launch4<T, 36, SP ? 3 : V4_DP36_PP, 1, 3, 8, false, false, true>(V4_ARGS);
@@ -22,5 +22,5 @@ int launch_implsch4x(const void* tab, int kijs, int kijl, void* fl1, const void*
 #undef V4_ARGS
   return -1;
 }
-template int launch_implsch4x<float>(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, int, int, int, int, int, int, hipStream_t);
-template int launch_implsch4x<double>(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, int, int, int, int, int, int, hipStream_t);
+template int launch_implsch4x<float>(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, void*, int, int, int, int, int, int, hipStream_t);
+template int launch_implsch4x<double>(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, void*, int, int, int, int, int, int, hipStream_t);

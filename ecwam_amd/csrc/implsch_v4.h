@@ -34,6 +34,13 @@
 #else
 #define V4_PHASE_EXIT(k) do { } while (0)
 #endif
+// index checks of the debugging build (-DV4_CHECK=1, build variant "rdpchk"): device-side assert = message + trap
+#if defined(V4_CHECK) && V4_CHECK
+#include <cassert>
+#define V4_CHK(c) assert(c)
+#else
+#define V4_CHK(c) do { } while (0)
+#endif
 #define V4_NSTG 4
 #define V4_NFAC 6   // words per (point, frequency) of the factor table: [M][4] BSC, SBO, CINV, WAVNUM + the planes SQ and ZCN
 
@@ -46,7 +53,10 @@ using V2 = T __attribute__((ext_vector_type(2)));
 // the row of scalars per sea point that k_implsch4_pre hands to k_implsch4 and k_implsch4 to k_implsch4_fin
 enum { FIN_AIRD = 0, FIN_UFRIC, FIN_Z0M, FIN_MIJ, FIN_XS, FIN_YS, FIN_F1DCOS3, FIN_F1DCOS2, FIN_F1DSIN2, FIN_F1D, FIN_RNFAC, FIN_PHIWA,
        FIN_SINWD, FIN_COSWD, FIN_WSWAVE, FIN_CICOVER, FIN_PHILF, FIN_XSTRESS, FIN_YSTRESS, FIN_Z0B, FIN_CHRNCK, FIN_COSDIFF, FIN_EMEAN, FIN_F1MEAN,
-       FIN_TAUICX, FIN_TAUICY, FIN_STRNMS, FIN_SPARE, V4_NFIN = 28 };   // (the last four: the RARE build's ice stress and strain)
+       FIN_TAUICX, FIN_TAUICY, FIN_STRNMS, FIN_SPARE,                   // (these four: the RARE build's ice stress and strain)
+       // the two-kernel split (PART = 1 -> PART = 2): means of the spectrum before the update, the windsea mean frequency of the second
+       // SINFLX call, SDIWBK's rate and the scale of SDEPTHLIM (the second kernel re-applies it to the spectrum it loads)
+       FIN_FMEAN, FIN_FMEANWS, FIN_AKMEAN, FIN_XKMEAN, FIN_SDS, FIN_SC, V4_NFIN = 36 };
 
 __device__ __forceinline__ float v4_bp(int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); }
 __device__ __forceinline__ double v4_bp(int addr, double v) {
@@ -387,6 +397,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
       cw_n = *reinterpret_cast<const V2<T>*>(L.fac4 + mn * 4 + Q4_CINV);
       zcn_n = L.zcn[mn];
     }
+    V4_CHK(m >= 0 && m < NFRE);
     const T* row = tb.SINROW[m];   // one scalar load: ZPIFR, DFIM, C5, T1, RHOWG_DFIM, DFIMOFR of the row
     const T SIGm = row[0], DFIMm = row[1];
     const T CONSTF = ROGOROAIR * cinv_m * DFIMm;
@@ -733,12 +744,20 @@ __device__ __forceinline__ T v4_sdice3_alp(const DevTab<T>& tb, int m, T CITHICK
 // widths of PEAK_ANG, snonlin.F90:152-165; ENHMC builds only), LCIWA2 (sdice2.F90: the attenuation depends on the bin's own energy), the
 // ice radiative stress LWNEMOCOUWRS (wnfluxes.F90:178-196) and strain LWNEMOCOUSTRN (cimsstrn.F90), friction-velocity forcing ICODE = 1, 2
 // (airsea.F90:100-117) and LWVFLX_SNL = F (implsch.F90:280-288) -- uniform branches, which the common builds do not pay for.
-template <typename T, int NANG, int PP, int R1, int R2, int NH, bool EXT, bool JAN = false, bool ENHMC = false, bool RARE = false>
+// PART: 0 = the whole time step in one kernel (the product path of every build but the double precision RARE ones); 1 / 2 = the two-kernel
+// split of round 5: PART 1 runs the prologue, SDEPTHLIM / FKMEAN, both SINFLX calls and the scalar chain between
+// them, writes XLLWS, parks the wind-input coefficient in the rows of wi[ij][M][K] (context-owned) and hands its scalars over in fin;
+// PART 2 loads the spectrum again, re-applies SDEPTHLIM's scale and tail (the same operations: the same bits) and runs the sweep, the
+// fluxes, the tail and the stores.  Same source, same results bit for bit; two smaller functions for the compiler.
+template <typename T, int NANG, int PP, int R1, int R2, int NH, bool EXT, bool JAN = false, bool ENHMC = false, bool RARE = false, int PART = 0>
 // single precision: two waves per SIMD (LDS: 8 waves per CU), at most 256 VGPRs; double precision: the LDS holds one wave per SIMD
 // (40 KB per wave) and the kernel may use the whole register file (340 registers: no scratch)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(V4_WPE_MIN(T), 2)))
 k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__ fl1, const T* __restrict__ wvprpt, T* __restrict__ ffa,
-           T* __restrict__ intfa, int* __restrict__ mij_out, T* __restrict__ xllws, T* __restrict__ fin, T* __restrict__ gfast, int gk) {
+           T* __restrict__ intfa, int* __restrict__ mij_out, T* __restrict__ xllws, T* __restrict__ fin, T* __restrict__ gfast, int gk,
+           T* __restrict__ wi) {
+  // scalar slots of the point's LDS row that are free in PART 2 (STRESSO's temporaries) carry the hand-over values
+  enum { C2_FMEAN = C_XSN, C2_FMEANWS = C_YSN, C2_AKMEAN = C_UST, C2_XKMEAN = C_SINU, C2_SC = C_COSU };
   // gfast (optional): compact rows gfast[ij][K][gk] that also receive the first gk frequencies of the new spectrum -- what the next
   // advection step's fast-wave sub-steps start from (ecwam_hip_set_fastwave_copy): written from the tile, no second pass over FL1
   constexpr int G = NANG / 2, NFRE = V4_NFRE, N = NANG * NFRE, RS = PP * NANG, NS = NFRE / G;
@@ -839,12 +858,18 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   //      (every lane, of point lane mod PP) so that they are in flight with the tile's; the same for the factor tables below
   const int pl = lane < PP ? lane : lane % PP;
   const int pid = ij0 + (pl < n ? pl : n - 1);
+  V4_CHK(n >= 1 && n <= PP && p >= 0 && p < PP && j >= 0 && j < G && ij >= kijs && ij < kijl && pid >= kijs && pid < kijl);
   const T* ffp = ffa + (size_t)pid * ECWAM_HIP_NFF;
   const T* frp = fin + (size_t)pid * V4_NFIN;
   const T p_aird = ffp[0], p_wdwave = ffp[1], p_ci = ffp[2], p_wswave = ffp[3], p_wstar = ffp[4], p_tauw = ffp[8], p_tauwdir = ffp[9];
   const T p_emaxdpt = ffp[14], p_depth = ffp[15];
   const T p_sinwd = frp[FIN_SINWD], p_coswd = frp[FIN_COSWD], p_rnfac = frp[FIN_RNFAC], p_cosdiff = frp[FIN_COSDIFF];
   const T p_ufric = frp[FIN_UFRIC], p_z0m = frp[FIN_Z0M], p_z0b = frp[FIN_Z0B], p_chrnck = frp[FIN_CHRNCK];
+  T h_o[PART == 2 ? 9 : 1];   // PART 2: what PART 1 handed over (loaded with the rest, unconditionally)
+  if constexpr (PART == 2) {
+    h_o[0] = frp[FIN_MIJ]; h_o[1] = frp[FIN_SDS]; h_o[2] = frp[FIN_EMEAN]; h_o[3] = frp[FIN_F1MEAN]; h_o[4] = frp[FIN_FMEAN];
+    h_o[5] = frp[FIN_FMEANWS]; h_o[6] = frp[FIN_AKMEAN]; h_o[7] = frp[FIN_XKMEAN]; h_o[8] = frp[FIN_SC];
+  }
   const T* wp = wvprpt + (size_t)ij * ECWAM_HIP_NWPR * NFRE;
   T w_wn[NS], w_cg[NS], w_ci[NS], w_xk[NS];   // WAVNUM, CGROUP, CINV, XK2CG of the lane's frequencies m = s G + j
 #pragma unroll
@@ -864,6 +889,10 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     if (EXT && tb.LLGCBZ0) q[C_TWCOS] = p_cosdiff;
     q[C_UFRIC] = p_ufric; q[C_Z0M] = p_z0m; q[C_Z0B] = p_z0b; q[C_CHRNCK] = p_chrnck;
     q[C_SPARE] = p_ci;   // CICOVER
+    if constexpr (PART == 2) {
+      q[C_MIJ] = h_o[0]; q[C_SDS] = h_o[1]; q[C_EMEAN] = h_o[2]; q[C_F1MEAN] = h_o[3];
+      q[C2_FMEAN] = h_o[4]; q[C2_FMEANWS] = h_o[5]; q[C2_AKMEAN] = h_o[6]; q[C2_XKMEAN] = h_o[7]; q[C2_SC] = h_o[8];
+    }
   }
   // RARE (ice radiative stress): FLDICE(M) = -ALP(M) CGROUP(M) of the last of SDICE1 / SDICE3 that is active, without the ice cover factor
   // (SLICE of sdice1.F90:177 / sdice3.F90:143), for the lane's frequencies M = q G + j + 1; handed out row by row with one lane exchange.
@@ -976,7 +1005,19 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   // ---- SDEPTHLIM (sdepthlim.F90:64-78, semean.F90:82-120), FKMEAN, the tail of sinflx.F90:124-128 and the orbital integrals of the
   //      swell damping (sinput_ard.F90:213-222) in two passes over the tile
   T EMEAN, FMEAN, F1MEAN, AKMEAN, XKMEAN;
-  {
+  T SCL = T(1);   // SDEPTHLIM's scale of the point (handed to PART 2)
+  if constexpr (PART == 2) {
+    // the spectrum as PART 1 left it in its tile: scaled, floored, the last row raised to the noise floor (the same operations)
+    EMEAN = c[C_EMEAN]; F1MEAN = c[C_F1MEAN]; FMEAN = c[C2_FMEAN]; AKMEAN = c[C2_AKMEAN]; XKMEAN = c[C2_XKMEAN];
+    const T sc = c[C2_SC];
+    const T flo = tb.LBIWBK ? tb.EPSMIN : -std::numeric_limits<T>::infinity();
+    for (int m = 0; m < NFRE; m++) {
+      V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS) * sc;
+      f.x = m_max(f.x, flo); f.y = m_max(f.y, flo);
+      if (m == NFRE - 1) { f.x = m_max(f.x, FLM.x); f.y = m_max(f.y, FLM.y); }
+      *reinterpret_cast<V2<T>*>(tFw + m * RS) = f;
+    }
+  } else {
     T sc = T(1);
     if (tb.LBIWBK) {
       V2<T> s = z2;
@@ -992,6 +1033,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       const T EM = tb.EPSMIN + s.x + DELT25 * s.y;
       sc = m_min(EMAXDPT / EM, T(1));
     }
+    SCL = sc;
     V2<T> s0 = z2, s1 = z2, s2 = z2, so = z2;
     // branch-free rows: without LBIWBK the scale is 1 and the floor -infinity (both exact), the row is stored back unchanged; the
     // last row (raised to the noise floor for the orbital integrals only) is peeled off
@@ -1060,7 +1102,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       WSYNC();
     }
   };
-  if (gcb) {
+  if (PART != 2 && gcb) {
     // HALPHAP (halphap.F90:68-112, meansqs_lf.F90:80-100, femean.F90:84-121): Phillips parameter of the wind-sea half plane
     const V2<T> wd = {__builtin_signbit(coswdif.x) ? T(0) : T(1), __builtin_signbit(coswdif.y) ? T(0) : T(1)};
     V2<T> sa = z2, sb = z2;   // (XMSS, EM), (FM, last row of MAX(F WD, EPSMIN))
@@ -1126,6 +1168,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   T* gsp = (G == 18 && lane >= 48) ? sStg + 3 * RS + lane : sStg + SPOFF + p * NFRE;
   // stress sums below the cut-off and the F(:,MIJ) integrals of TAU_PHI_HF (stresso.F90:148-173, tau_phi_hf.F90:170-196)
   auto post_stress = [&](int MIJ, V2<T> apl, bool phiwa) {
+    V4_CHK(MIJ >= 1 && MIJ <= NFRE);
     const T zpm = tb.ZPIFR[MIJ - 1], f5m = tb.FR5[MIJ - 1];   // for STRESSO: in flight behind the sums below
     V2<T> s = z2;
     T sp = T(0);
@@ -1158,15 +1201,19 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   };
 
   // ---- first SINFLX call (sinflx.F90:105-183): MIJ and the wave stress only
-  unsigned long long xm0, xm1;
+  unsigned long long xm0 = 0ull, xm1 = 0ull;
   V2<T> wse, wslast, apl;
   T FMEANWS, EMW;
+  int MIJ;
+  T SDS;
+  T* gx = (PART == 0 ? xllws : wi) + (size_t)ij * N + 2 * j;   // this lane's pair in row 0 of the block that holds the wind-input coefficient
+  if constexpr (PART != 2) {
   if (norma) v4_sinput_n<T, NANG, PP, 1, false>(tb, L, wp + 3 * NFRE, UFRIC, Z0M, RAORW, RNFAC, T(0), T(0), T(0), T(0), coswdif, sinwdif2, nullptr, nullptr,
                                                xm0, xm1, wse, wslast, apl, rX, rY, sXY);
   else if constexpr (JAN) v4_sinput_jan<T, NANG, PP, 1, false>(tb, L, UFRIC, Z0M, RAORW, T(0), coswdif, nullptr, nullptr, xm0, xm1, wse, wslast, apl, rX, rY, sXY);
   else v4_sinput<T, NANG, PP, 1, false>(tb, L, UFRIC, Z0M, RAORW, T(0), T(0), T(0), T(0), sinwd, coswd, nullptr, nullptr, xm0, xm1, wse, wslast, apl, rX, rY, sXY);
   femws_finish(wse, wslast, FMEANWS, EMW);
-  int MIJ = frcutindex4(FMEANWS, UFRIC);
+  MIJ = frcutindex4(FMEANWS, UFRIC);
   post_stress(MIJ, apl, false);
   WSYNC();
   V4_PHASE_EXIT(203);
@@ -1197,10 +1244,10 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   }
   WSYNC();
   UFRIC = c[C_UFRIC]; Z0M = c[C_Z0M];
-  const T SDS = c[C_SDS];
+  SDS = c[C_SDS];
   V4_PHASE_EXIT(204);
-  // ---- second SINFLX call: wind-input coefficient (parked in the point's XLLWS block, [M][K]), XLLWS, MIJ, wave stress, PHIWA
-  T* gx = xllws + (size_t)ij * N + 2 * j;   // this lane's pair in row 0 of the block
+  // ---- second SINFLX call: wind-input coefficient (parked in the point's XLLWS block, [M][K]; PART 1: in the rows of wi), XLLWS, MIJ,
+  //      wave stress, PHIWA
   if (norma) v4_sinput_n<T, NANG, PP, 2, true>(tb, L, wp + 3 * NFRE, UFRIC, Z0M, RAORW, RNFAC, c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], coswdif,
                                               sinwdif2, gx, gsp, xm0, xm1, wse, wslast, apl, rX, rY, sXY);
   else if constexpr (JAN) v4_sinput_jan<T, NANG, PP, 2, true>(tb, L, UFRIC, Z0M, RAORW, c[C_SIGN], coswdif, gx, gsp, xm0, xm1, wse, wslast, apl, rX, rY, sXY);
@@ -1210,7 +1257,51 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   MIJ = frcutindex4(FMEANWS, UFRIC);
   post_stress(MIJ, apl, true);
   WSYNC();
+  } else {   // PART 2: what PART 1 handed over
+    FMEANWS = c[C2_FMEANWS]; EMW = T(0);
+    MIJ = (int)c[C_MIJ];
+    MIJ = MIJ < 1 ? 1 : (MIJ > NFRE ? NFRE : MIJ);      // a table index: whatever the row holds, stay inside 1 .. NFRE
+    SDS = c[C_SDS];
+    if (tb.LWFLUX) {   // the XLLWS masks for FEMEANWS of the new spectrum: PART 1 wrote them to the point's XLLWS block
+      const T* x0 = xllws + (size_t)ij * N + (size_t)(2 * j) * NFRE;
+      for (int m = 0; m < NFRE; m++) {
+        if (x0[m] != T(0)) xm0 |= (1ull << m);
+        if (x0[NFRE + m] != T(0)) xm1 |= (1ull << m);
+      }
+    }
+  }
   V4_PHASE_EXIT(205);
+  // XLLWS(K,M) from the bit masks: rows K = 2j and 2j+1 of the point's block are contiguous
+  auto store_xllws = [&]() {
+    T* x0 = xllws + (size_t)ij * N + (size_t)(2 * j) * NFRE;
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+      const unsigned long long xm = h ? xm1 : xm0;
+#pragma unroll
+      for (int m = 0; m < NFRE; m += VEC) {
+        VT val;
+#pragma unroll
+        for (int i = 0; i < VEC; i++) val[i] = ((xm >> (m + i)) & 1ull) ? T(1) : T(0);
+        *reinterpret_cast<VT*>(x0 + h * NFRE + m) = val;
+      }
+    }
+  };
+  if constexpr (PART == 1) {
+    // ---- end of the first kernel: XLLWS, the scalars of the point for the second kernel and for k_implsch4_fin
+    store_xllws();
+    if (j == 0) {
+      T* fr = fin + (size_t)ij * V4_NFIN;
+      fr[FIN_AIRD] = AIRD; fr[FIN_UFRIC] = UFRIC; fr[FIN_Z0M] = Z0M; fr[FIN_MIJ] = c[C_MIJ];
+      fr[FIN_XS] = c[C_XS]; fr[FIN_YS] = c[C_YS]; fr[FIN_F1DCOS3] = c[C_F1DCOS3]; fr[FIN_F1DCOS2] = c[C_F1DCOS2];
+      fr[FIN_F1DSIN2] = c[C_F1DSIN2]; fr[FIN_F1D] = c[C_F1D]; fr[FIN_RNFAC] = c[C_RNFAC]; fr[FIN_PHIWA] = c[C_PHIWA];
+      fr[FIN_SINWD] = sinwd; fr[FIN_COSWD] = coswd; fr[FIN_WSWAVE] = WSWAVE; fr[FIN_CICOVER] = CICOVER;
+      fr[FIN_Z0B] = c[C_Z0B]; fr[FIN_CHRNCK] = c[C_CHRNCK];
+      fr[FIN_EMEAN] = c[C_EMEAN]; fr[FIN_F1MEAN] = c[C_F1MEAN];
+      fr[FIN_FMEAN] = FMEAN; fr[FIN_FMEANWS] = FMEANWS; fr[FIN_AKMEAN] = AKMEAN; fr[FIN_XKMEAN] = XKMEAN; fr[FIN_SDS] = SDS; fr[FIN_SC] = SCL;
+      mij_out[ij] = MIJ;
+    }
+    return;
+  }
   // ---- STRESSO of the second call (TAUW, TAUWDIR, PHIWA) and the scalar half of WNFLUXES: nothing below needs them, and on this
   //      kernel's waves they are a long dependent chain on PP lanes.  k_implsch4_fin runs them afterwards, one point per lane.
   V4_PHASE_EXIT(206);
@@ -1327,6 +1418,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       if constexpr (!RARE) return T(0);
       else {
         const int q = m / G, jl = m - q * G;
+        V4_CHK(m >= 0 && m < NFRE && q < NS);
         T v = r[0];
 #pragma unroll
         for (int i = 1; i < NS; i++) v = (q == i) ? r[i] : v;
@@ -1342,6 +1434,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       if constexpr (!ENHMC) return ENHFR;
       else {
         const int q = (MC - 1) / G, jl = (MC - 1) - q * G;
+        V4_CHK(MC >= 1 && q < NQE);
         T v = rENH[0];
 #pragma unroll
         for (int i = 1; i < NQE; i++) v = (q == i) ? rENH[i] : v;
@@ -1462,6 +1555,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       a_t = a_t + rh * ss;
       a_x = a_x + (u_cinv * rh) * ss;
       // the slot of the wind-input ring is free: row m+4 (beyond the last row the last one again, never used: no branch)
+      V4_CHK(m >= 0 && m < NFRE && ij >= kijs && ij < kijl);
       wslot = *reinterpret_cast<const V2<T>*>(gx + (size_t)hi35(m + 4) * NANG);
     };
     if constexpr (!JAN) *reinterpret_cast<V2<T>*>(st4 + L.own) = fR[5];   // row MC-4 of the first interaction
@@ -1493,6 +1587,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         const V2<T> fIC = fR[jj & 7], fIP = fR[(jj + 2) & 7], fIM = fR[(jj + 4) & 7], fIM1 = fR[(jj + 5) & 7];
         T el[4 * NSH + 2];                // row MC-4: element e = F(2j - 2 NSH + e)
         const int IM = lo0(MC - 5), IM1 = hi35(lo0(MC - 4));
+        V4_CHK(MC >= 1 && MC <= 40 && IM >= 0 && IM < NFRE && IM1 >= 0 && IM1 < NFRE);
         T bscn = T(0);
         if constexpr (!JAN) {
 #pragma unroll
@@ -1700,6 +1795,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   }
   V4_PHASE_EXIT(208);
   {  // imphftail.F90: TEMP2(M) / TEMP1 = (XK2CG WAVNUM)(MIJ) / (XK2CG WAVNUM)(M)
+    V4_CHK(MIJ >= 1 && MIJ <= NFRE);
     const T B1 = L.fac4[(MIJ - 1) * 4 + Q4_BSC];
     const V2<T> tf = *reinterpret_cast<const V2<T>*>(tF + (MIJ - 1) * RS);
     for (int m = MIJ; m < NFRE; m++) {
@@ -1782,20 +1878,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     }
   }
   V4_PHASE_EXIT(210);
-  {   // every wind-input row parked in this block has been read by now
-    T* x0 = xllws + (size_t)ij * N + (size_t)(2 * j) * NFRE;   // rows K = 2j and 2j+1 are contiguous
-#pragma unroll 1
-    for (int h = 0; h < 2; h++) {
-      const unsigned long long xm = h ? xm1 : xm0;
-#pragma unroll
-      for (int m = 0; m < NFRE; m += VEC) {
-        VT val;
-#pragma unroll
-        for (int i = 0; i < VEC; i++) val[i] = ((xm >> (m + i)) & 1ull) ? T(1) : T(0);
-        *reinterpret_cast<VT*>(x0 + h * NFRE + m) = val;
-      }
-    }
-  }
+  if constexpr (PART == 0) store_xllws();   // every wind-input row parked in this block has been read by now
   V4_PHASE_EXIT(211);
   if (j == 0) {
     T* fo = ffa + (size_t)ij * ECWAM_HIP_NFF;
@@ -1804,12 +1887,14 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     T* io = intfa + (size_t)ij * ECWAM_HIP_NINTF;
     io[2] = USTOKES; io[3] = VSTOKES;
     T* fr = fin + (size_t)ij * V4_NFIN;
-    fr[FIN_AIRD] = AIRD; fr[FIN_UFRIC] = UFRIC; fr[FIN_Z0M] = Z0M; fr[FIN_MIJ] = c[C_MIJ];
-    fr[FIN_XS] = c[C_XS]; fr[FIN_YS] = c[C_YS]; fr[FIN_F1DCOS3] = c[C_F1DCOS3]; fr[FIN_F1DCOS2] = c[C_F1DCOS2];
-    fr[FIN_F1DSIN2] = c[C_F1DSIN2]; fr[FIN_F1D] = c[C_F1D]; fr[FIN_RNFAC] = c[C_RNFAC]; fr[FIN_PHIWA] = c[C_PHIWA];
-    fr[FIN_SINWD] = sinwd; fr[FIN_COSWD] = coswd; fr[FIN_WSWAVE] = WSWAVE; fr[FIN_CICOVER] = CICOVER;
+    if constexpr (PART == 0) {   // (PART 2: the first kernel wrote these)
+      fr[FIN_AIRD] = AIRD; fr[FIN_UFRIC] = UFRIC; fr[FIN_Z0M] = Z0M; fr[FIN_MIJ] = c[C_MIJ];
+      fr[FIN_XS] = c[C_XS]; fr[FIN_YS] = c[C_YS]; fr[FIN_F1DCOS3] = c[C_F1DCOS3]; fr[FIN_F1DCOS2] = c[C_F1DCOS2];
+      fr[FIN_F1DSIN2] = c[C_F1DSIN2]; fr[FIN_F1D] = c[C_F1D]; fr[FIN_RNFAC] = c[C_RNFAC]; fr[FIN_PHIWA] = c[C_PHIWA];
+      fr[FIN_SINWD] = sinwd; fr[FIN_COSWD] = coswd; fr[FIN_WSWAVE] = WSWAVE; fr[FIN_CICOVER] = CICOVER;
+      fr[FIN_EMEAN] = c[C_EMEAN]; fr[FIN_F1MEAN] = c[C_F1MEAN];   // of the spectrum before the update (implsch.F90:396-414)
+    }
     fr[FIN_PHILF] = PHILF; fr[FIN_XSTRESS] = XSTRESS; fr[FIN_YSTRESS] = YSTRESS;
-    fr[FIN_EMEAN] = c[C_EMEAN]; fr[FIN_F1MEAN] = c[C_F1MEAN];   // of the spectrum before the update (implsch.F90:396-414)
     fr[FIN_TAUICX] = TAUICX; fr[FIN_TAUICY] = TAUICY; fr[FIN_STRNMS] = STRNMS;
     if (RARE && tb.LWNEMOCOUSTRN) io[4] = STRNMS;
     if (tb.LWFLUX) {

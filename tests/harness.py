@@ -94,6 +94,7 @@ def compare_implsch(ref: dict, got: dict, tables) -> dict:
     mij_same = ref["MIJ"] == got["MIJ"]
     xl_same_pt = (ref["XLLWS"] == got["XLLWS"]).all(axis=(1, 2))
     st["n"] = n
+    st["idelt"] = int(getattr(getattr(tables, "cfg", None), "idelt", 0) or 0)   # the gates of the single-precision tests depend on it
     st["mij_flips"] = int((~mij_same).sum())
     st["xllws_bins_diff"] = int((ref["XLLWS"] != got["XLLWS"]).sum())
     st["xllws_pts_diff"] = int((~xl_same_pt).sum())

@@ -33,6 +33,18 @@ def api():
     return _api
 
 
+def _log_stats(st, prec):
+    """ECWAM_TEST_STATS_LOG=<file>: one JSON line per gated comparison (test id, precision, IDELT, the error statistics): what the
+    gates below are set from (tools/gate_report.py)."""
+    import json
+    import os
+
+    path = os.environ.get("ECWAM_TEST_STATS_LOG")
+    if path:
+        with open(path, "a") as fh:
+            fh.write(json.dumps(dict(test=os.environ.get("PYTEST_CURRENT_TEST", ""), prec=prec, **st)) + "\n")
+
+
 def _assert_implsch_stats(st, n, prec, flip_budget=0.005):
     """Gates of every IMPLSCH parity test.  dp: 1e-10 (observed 1e-15..1e-13).  sp: thresholds 2..10x the largest observed error
     over all test configurations (spectra 1.4e-5 of the peak at IDELT = 900 s, 8e-7 at 450 s; swh 4e-7, forcing 8e-6, fluxes 1.3e-4),
@@ -41,6 +53,7 @@ def _assert_implsch_stats(st, n, prec, flip_budget=0.005):
     1e-5 of their own value stay below 1 % of the bins that carry energy (above 1e-6 of the point's peak; observed 0.73 % with the
     sea-ice attenuation, whose exponentials amplify the rounding of the input factors, 0.1 % otherwise) and below 5 % of all bins
     (observed 2.2 % with sea ice: noise-floor bins, 1e-10 of the peak)."""
+    _log_stats(st, prec)
     if prec == "dp":
         assert st["mij_flips"] == 0 and st["xllws_bins_diff"] == 0, st
         assert st["fl1_max_rel_peak_all"] < 1e-10 and st["swh_max_rel"] < 1e-12, st
@@ -60,13 +73,9 @@ def _oracle(cfg, prec):
 
 
 def _generation(cfg, prec):
-    """The kernel generation ecwam_hip_implsch runs for a configuration the fast kernel covers (capi.hip): the common builds in both
-    precisions; the RARE builds (csrc/implsch4r.hip) in single precision only, double precision keeps k_implsch2 for those."""
-    rare = (cfg.lciwa2 or cfg.lwnemocouwrs or cfg.lwnemocoustrn or cfg.isnonlin > 1 or cfg.icode != 3 or not cfg.lwvflx_snl)
-    ext = cfg.llgcbz0 or cfg.llnormagam
-    alt = (1 if cfg.iphys == 0 else 0) | (2 if cfg.isnonlin == 1 else 0)
-    common = not rare and (alt == 0 or (not ext and alt != 3))
-    return 4 if (common or prec == "sp") else 2
+    """The kernel generation ecwam_hip_implsch runs for a configuration the fast kernel covers (capi.hip): generation 4 in both precisions --
+    the common builds, and since round 5 the RARE builds (csrc/implsch4r.hip) in double precision too (compiled at -O2)."""
+    return 4
 
 
 def test_wavefront_primitives(api):
@@ -1193,3 +1202,41 @@ def test_rare_builds_of_the_fast_kernel(api, prec, nang, nred, flags):
         assert np.abs(got["W2N"] - ref["W2N"]).max() < tol * np.abs(ref["W2N"]).max()
     if flags.get("icode", 3) != 3:
         assert np.max(np.abs(got["FF"][:, 3].astype(float) - ref["FF"][:, 3].astype(float)) / ref["FF"][:, 3]) < (1e-11 if prec == "dp" else 2e-5)
+
+
+@pytest.mark.parametrize("prec", ["sp", "dp"])
+@pytest.mark.parametrize("seed", [3, 17, 101])
+@pytest.mark.parametrize("nang,flags", [(36, dict(lwvflx_snl=False)),
+                                        (36, dict(lciwa1=True, lciwa2=True, lmaskice=False, lwnemocou=True, lwnemocouwrs=True, lwnemocoustrn=True, isnonlin=2)),
+                                        (24, dict(llgcbz0=True, llnormagam=True, isnonlin=1, icode=1)),
+                                        (12, dict(iphys=0, isnonlin=2, lciwa2=True, lmaskice=False))],
+                         ids=["snl_off_36", "ice_nemo_snl2_36", "b_enh_icode1_24", "jan_snl2_ice2_12"])
+def test_rare_builds_many_points_against_k_implsch2(api, nang, flags, seed, prec):
+    """The single-precision RARE builds of k_implsch4 sit at the 256-register cap with a few bytes of scratch, and the same source in double
+    precision faults when compiled at -O3 (it ships at -O2): beside the 600-point oracle tests, 40 000 (dp: 16 000)
+    points per seed against k_implsch2 on the device -- every output finite; double precision: MIJ and XLLWS identical, spectra within
+    1e-12 of the point's peak; single precision: at most one point in 10 000 with a flipped XLLWS bin or cut-off index (a growth test
+    within one ulp of its threshold, summed in another order), the other points within 2e-5 of the peak, forcing outputs within 5e-5."""
+    nred = {36: 36, 24: 29, 12: 25}[nang]
+    cfg = Config(nang=nang, nfre=36, nfre_red=nred, **flags)
+    n = 40001 if prec == "sp" else 16001   # ragged in every layout
+    case = _ice_case(cfg, prec, n=n, seed=seed)
+    if flags.get("lwnemocou"):
+        case["W2N"] = np.random.default_rng(seed).uniform(-1.0, 1.0, (n, 13))
+    ctx = api.HipContext(case["tables"])
+    new = H.gpu_implsch(case, ctx)
+    assert ctx.implsch_generation_used() == 4
+    ctx.set_implsch_generation(2)
+    old = H.gpu_implsch(case, ctx)
+    assert ctx.implsch_generation_used() == 2
+    ctx.close()
+    for k in ("FL1", "FF", "INTF", "XLLWS"):
+        assert np.isfinite(new[k]).all(), k
+    st = H.compare_implsch(old, new, case["tables"])
+    _log_stats(st, prec + "-v2")
+    if prec == "dp":
+        assert st["mij_flips"] == 0 and st["xllws_bins_diff"] == 0, st
+        assert st["fl1_max_rel_peak_all"] < 1e-12 and st["ff_max_rel_all"] < 1e-11 and st["swh_max_rel"] < 1e-13, st
+    else:
+        assert st["mij_flips"] <= n * 1e-4 and st["xllws_pts_diff"] <= n * 1e-4, st
+        assert st["fl1_max_rel_peak_clean"] < 2e-5 and st["ff_max_rel_clean"] < 5e-5 and st["swh_max_rel"] < 2e-6, st

@@ -4,7 +4,7 @@
 prec=$1; shift
 for i in 1 2 3 4; do
   for v in "$@"; do
-    lib=$GRAFT_REPO_ROOT/ecwam_amd/lib/libecwam_hip${v:+_$v}.so
+    lib=${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}/ecwam_amd/lib/libecwam_hip${v:+_$v}.so
     echo -n "${v:-product}: "; ECWAM_HIP_LIB=$lib python3 tools/prof_implsch.py $prec 421080 2>&1 | grep "implsch ms" | awk '{print $3}' | sort -n | head -1
   done
 done

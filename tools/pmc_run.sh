@@ -1,6 +1,6 @@
 #!/bin/bash
 # diagnostics: arbitrary PMC sets on the IMPLSCH profiling driver.  usage: PMC="A B C" [N=32768] [PREC=sp] [GEN=0|2|4] bash tools/pmc_run.sh
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}" || exit 2; mkdir -p gpurun_out
 N=${N:-32768}; PREC=${PREC:-sp}; TAG=${TAG:-x}; GEN=${GEN:-0}
 rm -rf gpurun_out/pmc_$TAG
 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d gpurun_out/pmc_$TAG -- python3 tools/prof_implsch.py $PREC $N $GEN > /dev/null 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the bench kernels (MI355X_MICROARCH.md "HBM traffic"): FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes
 # (3 + 2 TCC counters do not fit one pass), per-launch averages in bytes; FETCH_SIZE doubled for the 16 B/lane streams (gfx950).
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}" || exit 2; mkdir -p gpurun_out
 rm -rf gpurun_out/traf_*
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
   d=gpurun_out/traf_$(echo $c | cut -c1-5)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 measurement set on one MI355X (writes gpurun_out/r02/*; the summaries are copied to profiles/ by hand):
 #   bench line, rocprofv3 kernel stats of the same command, HBM traffic PMC passes, IMPLSCH SQ counter sets, FETCH_SIZE calibration
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}" || exit 2; mkdir -p gpurun_out
 O=gpurun_out/r02; mkdir -p $O
 python3 bench.py --steps 20 --warmup 3 > $O/bench_O320_sp.json 2> $O/bench_O320_sp.err || echo "bench failed"
 echo "bench done"; tail -c 600 $O/bench_O320_sp.json

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 measurement set, part 2 (one MI355X): the other BASELINE shapes through bench.py and the IMPLSCH generations side by side.
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r02; mkdir -p $O
+cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}" || exit 2; mkdir -p gpurun_out; O=gpurun_out/r02; mkdir -p $O
 for cfg in "640 sp" "1280 sp" "640 dp" "1280 dp"; do
   set -- $cfg
   timeout -k 10 280 python3 bench.py --grid $1 --prec $2 --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_O$1_$2.json 2> $O/bench_O$1_$2.err || echo "bench $cfg failed"

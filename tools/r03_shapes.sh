@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 measurement set, part 2 (one MI355X): the other BASELINE shapes through bench.py, advection work orders at O1280, the IMPLSCH
 # kernel generations side by side (flag sets A and B, IPHYS = 0, ISNONLIN = 1).
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r03; mkdir -p $O
+cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}" || exit 2; mkdir -p gpurun_out; O=gpurun_out/r03; mkdir -p $O
 run() { tag=$1; shift; timeout -k 10 280 python3 bench.py "$@" --no-cpu-baseline > $O/bench_$tag.json 2> $O/bench_$tag.err || echo "bench $tag failed";
   python3 -c "import json,sys; d=json.load(open('$O/bench_$tag.json')); print('$tag', round(d['value']/1e6,2), 'M pt-steps/s', round(d['ms_per_step'],2), 'ms', {k:round(v['ms'],2) for k,v in d['kernels'].items()})"; }
 run O640_sp --grid 640 --steps 5 --warmup 1

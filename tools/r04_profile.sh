@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 measurement set on ONE MI355X (writes gpurun_out/r04/*; the summaries are copied to profiles/ by hand):
 #   the bench line (5 windows, median), rocprofv3 kernel stats of the same command, the HBM traffic PMC passes, the SQ counter sets of IMPLSCH.
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}" || exit 2; mkdir -p gpurun_out
 O=gpurun_out/r04; mkdir -p $O
 python3 bench.py --steps 20 --warmup 3 > $O/bench_O320_sp.json 2> $O/bench_O320_sp.err || { echo "bench failed"; tail -5 $O/bench_O320_sp.err; exit 1; }
 echo "bench done"; tail -c 600 $O/bench_O320_sp.json; echo

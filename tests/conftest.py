@@ -8,6 +8,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the oracle's OpenMP loops: the GPU box reports 256 logical CPUs and gives a job 16 of them; libgomp reads the variable when it loads
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, len(os.sched_getaffinity(0))))))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

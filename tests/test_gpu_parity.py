@@ -45,14 +45,19 @@ def _log_stats(st, prec):
             fh.write(json.dumps(dict(test=os.environ.get("PYTEST_CURRENT_TEST", ""), prec=prec, **st)) + "\n")
 
 
+# Single-precision gates by source-term time step (st["idelt"]).  The error of the new spectrum grows with DELT (the increment DELT SL / (1 - DELT
+# XIMP FLD) carries the rounding of SL): observed maxima over every gated comparison of the suite, round 5 (tools/gate_report.py on the
+# statistics log of the GPU run, gpurun_out/r05s1/stats.jsonl): IDELT 900 / 1200 s: bins 1.49e-5 of the peak, swh 1.71e-6, forcing 8.2e-6,
+# fluxes 8.8e-4; IDELT <= 450 s (the benchmark's step): bins 8.4e-7, swh 4e-7.  Gates: about twice the observed maximum, and at the
+# benchmark's step the north star's 1e-6 on the wave height and 2e-6 of the peak per bin.
+_SP_GATES = {"long": dict(bins=3e-5, swh=2e-6, ff=2e-5, intf=1e-3), "short": dict(bins=2e-6, swh=1e-6, ff=2e-5, intf=1e-3)}
+
+
 def _assert_implsch_stats(st, n, prec, flip_budget=0.005):
-    """Gates of every IMPLSCH parity test.  dp: 1e-10 (observed 1e-15..1e-13).  sp: thresholds 2..10x the largest observed error
-    over all test configurations (spectra 1.4e-5 of the peak at IDELT = 900 s, 8e-7 at 450 s; swh 4e-7, forcing 8e-6, fluxes 1.3e-4),
-    per-point swh within 2e-6 (observed 1.05e-6 at the worst of 1 536 points; the reference's own tolerance, 1e-6, is on the global
-    average / minimum / maximum of swh, tests/etopo1_oper_an_fc_O48.yml relative_tolerance), and SURVEY H4: bins off by more than
-    1e-5 of their own value stay below 1 % of the bins that carry energy (above 1e-6 of the point's peak; observed 0.73 % with the
-    sea-ice attenuation, whose exponentials amplify the rounding of the input factors, 0.1 % otherwise) and below 5 % of all bins
-    (observed 2.2 % with sea ice: noise-floor bins, 1e-10 of the peak)."""
+    """Gates of every IMPLSCH parity test.  dp: 1e-10 (observed 1e-15..1e-13).  sp: _SP_GATES by the case's IDELT; SURVEY H4: bins off
+    by more than 1e-5 of their own value stay below 1 % of the bins that carry energy (above 1e-6 of the point's peak; observed 0.67 % with the
+    sea-ice attenuation, whose exponentials amplify the rounding of the input factors, 0.2 % otherwise) and below 5 % of all bins
+    (observed 2.1 % with sea ice: noise-floor bins, 1e-10 of the peak); discrete decisions (MIJ, XLLWS) may flip at flip_budget of the points."""
     _log_stats(st, prec)
     if prec == "dp":
         assert st["mij_flips"] == 0 and st["xllws_bins_diff"] == 0, st
@@ -60,9 +65,10 @@ def _assert_implsch_stats(st, n, prec, flip_budget=0.005):
         assert st["ff_max_rel_all"] < 1e-10 and st["intf_max_rel_all"] < 1e-8, st
         assert st["fl1_frac_bins_gt_1e-5"] == 0.0 and st["fl1_max_rel_bin_clean"] < 1e-9, st
     else:
+        g = _SP_GATES["short" if 0 < st.get("idelt", 900) <= 450 else "long"]
         assert st["mij_flips"] <= n * flip_budget and st["xllws_pts_diff"] <= n * flip_budget, st
-        assert st["fl1_max_rel_peak_clean"] < 3e-5 and st["swh_max_rel"] < 2e-6, st
-        assert st["ff_max_rel_clean"] < 5e-5 and st["intf_max_rel_clean"] < 1e-3, st
+        assert st["fl1_max_rel_peak_clean"] < g["bins"] and st["swh_max_rel"] < g["swh"], st
+        assert st["ff_max_rel_clean"] < g["ff"] and st["intf_max_rel_clean"] < g["intf"], st
         assert st["fl1_frac_sig_bins_gt_1e-5"] < 1e-2 and st["fl1_frac_bins_gt_1e-5"] < 5e-2, st
 
 
@@ -93,6 +99,24 @@ def test_wavefront_primitives(api):
 @pytest.mark.parametrize("llnormagam", [False, True])
 def test_implsch_parity(api, nang, nred, prec, llnormagam):
     _implsch_parity(api, nang, nred, prec, llnormagam)
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+@pytest.mark.parametrize("flags", [dict(), dict(llgcbz0=True, llnormagam=True)], ids=["A", "B"])
+def test_implsch_parity_at_the_benchmark_time_step(api, prec, flags):
+    """The configuration bench.py measures (36 x 36, IDELT = 450 s; flag sets A and B) under the gates of that time step: single precision
+    bins within 2e-6 of the point's peak, wave height within 1e-6 (_SP_GATES["short"]), 4 099 mixed-sea points."""
+    cfg = Config(nang=36, nfre=36, nfre_red=36, idelt=450, idelpro=450, **flags)
+    n = 4099
+    case = H.make_point_case(n, cfg, prec, spectra="mixed", seed=31)
+    ref = H.oracle_implsch(case, _oracle(cfg, prec))
+    ctx = api.HipContext(case["tables"])
+    got = H.gpu_implsch(case, ctx)
+    assert ctx.implsch_generation_used() == 4
+    ctx.close()
+    st = H.compare_implsch(ref, got, case["tables"])
+    assert st["idelt"] == 450
+    _assert_implsch_stats(st, n, prec)
 
 
 @pytest.mark.parametrize("nang,nred,prec,gen", [(36, 36, "sp", 2), (36, 36, "dp", 2), (24, 29, "sp", 2), (12, 25, "dp", 2), (24, 25, "sp", 2)])
@@ -1239,4 +1263,5 @@ def test_rare_builds_many_points_against_k_implsch2(api, nang, flags, seed, prec
         assert st["fl1_max_rel_peak_all"] < 1e-12 and st["ff_max_rel_all"] < 1e-11 and st["swh_max_rel"] < 1e-13, st
     else:
         assert st["mij_flips"] <= n * 1e-4 and st["xllws_pts_diff"] <= n * 1e-4, st
-        assert st["fl1_max_rel_peak_clean"] < 2e-5 and st["ff_max_rel_clean"] < 5e-5 and st["swh_max_rel"] < 2e-6, st
+        # (two single-precision kernels, each within 1.6e-5 of the oracle at this time step: observed 2.1e-5 between them)
+        assert st["fl1_max_rel_peak_clean"] < 4e-5 and st["ff_max_rel_clean"] < 5e-5 and st["swh_max_rel"] < 2e-6, st

@@ -686,7 +686,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   const int alt = (c->p.iphys == 0 ? 1 : 0) | (c->p.isnonlin == 1 ? 2 : 0);
   const bool common_ok = !rare4 && (alt == 0 || (!ext && alt != 3));
   const bool shelter_ok = (c->p.iphys == 0) ? true : (c->p.llnormagam ? c->v4_shelter == 0 : c->v4_shelter != 0);
-  if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !dbg && shelter_ok && !(c->p.iphys == 0 && ext)) {
+  if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !dbg && shelter_ok) {
     if (int rc2 = ecwam_hip_implsch_reserve(c, kijl)) return rc2;   // no-op once the buffer covers kijl
     if (!common_ok)
       DISPATCH(rc = launch_implsch4r<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->wi, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, c->p.iphys == 0 ? 1 : 0, s),

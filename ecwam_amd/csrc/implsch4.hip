@@ -1,7 +1,7 @@
 // Launcher of the fourth IMPLSCH kernel generation (implsch_v4.h): PP sea points per wavefront on adjacent direction pairs, every
 // rotation in K through LDS rows.  implsch.F90:10-468 on flag set A (LLGCBZ0 = F, LLNORMAGAM = F) and, in the EXT build of the
 // kernel, flag set B (either or both of them T: cy49r1 / cy50r1); sea-ice damping LCIWA1 / LCIWA3 / LCISCAL (no LCIWA2), the NEMO coupling outputs of LWNEMOCOU (without ice stress, strain, break-up), IPHYS = 1, ISNONLIN = 0,
-// ICODE = 3, NFRE = 36, NANG = 36 / 24 / 12, single and double precision.  Everything else runs k_implsch2 (implsch.hip).
+// ICODE = 3, NFRE = 36, NANG = 48 / 36 / 24 / 12, single and double precision.
 #include "implsch_v4_launch.h"
 
 // returns 0 when launched, -1 when no instantiation covers (NANG, r1, r2, nh): the caller falls back to k_implsch2
@@ -12,6 +12,8 @@ int launch_implsch4(const void* tab, int kijs, int kijl, void* fl1, const void* 
   if (NFRE != V4_NFRE) return -1;
   constexpr bool SP = sizeof(T) == 4;
 #define V4_ARGS tab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, fin, w2n, gfast, gk, wi, s
+  if (NANG == 48 && r1 == 1 && r2 == 4 && nh == 11)      // two points per wavefront, 24 lanes each
+    return ext ? launch4<T, 48, 2, 1, 4, 11, true>(V4_ARGS) : launch4<T, 48, 2, 1, 4, 11, false>(V4_ARGS);
   if (NANG == 36 && r1 == 1 && r2 == 3 && nh == 8)
     return ext ? launch4<T, 36, SP ? 3 : V4_DP36_PP, 1, 3, 8, true>(V4_ARGS) : launch4<T, 36, SP ? 3 : V4_DP36_PP, 1, 3, 8, false>(V4_ARGS);
   if (NANG == 24 && r1 == 0 && r2 == 2 && nh == 5)

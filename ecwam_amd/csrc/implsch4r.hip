@@ -32,12 +32,15 @@ int launch_implsch4r(const void* tab, int kijs, int kijl, void* fl1, const void*
 #define V4_ARGS tab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, fin, w2n, gfast, gk, wi, s
     // double precision: the two-kernel split (V4R_DP = 2); single precision: one kernel unless the whole library is built as the split
     constexpr bool SPL = (!SP && V4R_DP == 2) || V4_SPLIT_ALL != 0;
+    // (the IPHYS = 0 build carries LLGCBZ0 / LLNORMAGAM too: EXT and JAN)
+    if (NANG == 48 && r1 == 1 && r2 == 4 && nh == 11)
+      return jan ? launch4<T, 48, 2, 1, 4, 11, true, true, true, true, SPL>(V4_ARGS) : launch4<T, 48, 2, 1, 4, 11, true, false, true, true, SPL>(V4_ARGS);
     if (NANG == 36 && r1 == 1 && r2 == 3 && nh == 8)
-      return jan ? launch4<T, 36, 3, 1, 3, 8, false, true, true, true, SPL>(V4_ARGS) : launch4<T, 36, 3, 1, 3, 8, true, false, true, true, SPL>(V4_ARGS);
+      return jan ? launch4<T, 36, 3, 1, 3, 8, true, true, true, true, SPL>(V4_ARGS) : launch4<T, 36, 3, 1, 3, 8, true, false, true, true, SPL>(V4_ARGS);
     if (NANG == 24 && r1 == 0 && r2 == 2 && nh == 5)
-      return jan ? launch4<T, 24, SP ? 5 : 4, 0, 2, 5, false, true, true, true, SPL>(V4_ARGS) : launch4<T, 24, SP ? 5 : 4, 0, 2, 5, true, false, true, true, SPL>(V4_ARGS);
+      return jan ? launch4<T, 24, SP ? 5 : 4, 0, 2, 5, true, true, true, true, SPL>(V4_ARGS) : launch4<T, 24, SP ? 5 : 4, 0, 2, 5, true, false, true, true, SPL>(V4_ARGS);
     if (NANG == 12 && r1 == 0 && r2 == 1 && nh == 3)
-      return jan ? launch4<T, 12, SP ? 10 : 5, 0, 1, 3, false, true, true, true, SPL>(V4_ARGS) : launch4<T, 12, SP ? 10 : 5, 0, 1, 3, true, false, true, true, SPL>(V4_ARGS);
+      return jan ? launch4<T, 12, SP ? 10 : 5, 0, 1, 3, true, true, true, true, SPL>(V4_ARGS) : launch4<T, 12, SP ? 10 : 5, 0, 1, 3, true, false, true, true, SPL>(V4_ARGS);
 #undef V4_ARGS
     return -1;
   }

@@ -12,6 +12,8 @@ int launch_implsch4x(const void* tab, int kijs, int kijl, void* fl1, const void*
   if (NFRE != V4_NFRE || (variant != 1 && variant != 2)) return -1;
   constexpr bool SP = sizeof(T) == 4;
 #define V4_ARGS tab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, fin, w2n, gfast, gk, wi, s
+  if (NANG == 48 && r1 == 1 && r2 == 4 && nh == 11)
+    return variant == 1 ? launch4<T, 48, 2, 1, 4, 11, false, true, false>(V4_ARGS) : launch4<T, 48, 2, 1, 4, 11, false, false, true>(V4_ARGS);
   if (NANG == 36 && r1 == 1 && r2 == 3 && nh == 8)
     return variant == 1 ? launch4<T, 36, SP ? 3 : V4_DP36_PP, 1, 3, 8, false, true, false>(V4_ARGS)
                         : launch4<T, 36, SP ? 3 : V4_DP36_PP, 1, 3, 8, false, false, true>(V4_ARGS);

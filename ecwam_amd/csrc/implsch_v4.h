@@ -42,6 +42,10 @@
 #define V4_CHK(c) do { } while (0)
 #endif
 #define V4_NSTG 4
+// frequencies per lane: lane j of a point owns M = q G + j + 1, q = 0 .. NS - 1 (36 directions: 2, 24: 3, 12: 6; 48 directions: 2 with the
+// second one only on the lanes j < NFRE - G = 12 -- the other lanes repeat frequency NFRE: the same stores, a weight of zero in the sums)
+#define V4_NS(nang) ((V4_NFRE + (nang) / 2 - 1) / ((nang) / 2))
+#define V4_PLN(pp, nang) ((pp) * ((nang) > V4_NFRE ? (nang) : V4_NFRE))
 #define V4_NFAC 6   // words per (point, frequency) of the factor table: [M][4] BSC, SBO, CINV, WAVNUM + the planes SQ and ZCN
 
 #define V4SYNC() WSYNC()
@@ -77,7 +81,7 @@ __device__ __forceinline__ V2<T> v4_same(V2<T> v, int addr) {
 //   (one ds_bpermute: a0 = the extra of lanes 0, 1, the lane itself elsewhere, fold = 1 / 0), rotates inside the row (v_*_dpp
 //   row_ror 8, 4, 2, 1: no LDS) and hands the total to the extras and the shadows (one ds_bpermute: a1 = lane 0 of the row for
 //   them, the lane itself in rows 0..2).  ds_bpermute costs 6 cycles of the CU's LDS pipe: 2 per quantity instead of 5.
-//   G = 12 / 6: rotations by 6, 3, then 1 and 2 / by 3, then 1 and 2 (byte addresses of the source lanes).
+//   G = 24 / 12 / 6: rotations by 12, 6, 3, then 1 and 2 / by 6, 3, then 1 and 2 / by 3, then 1 and 2 (byte addresses of the source lanes).
 template <typename T>
 struct V4Rot { int a0, a1, a2, a3, a4; T fold; };
 template <int CTRL>
@@ -127,7 +131,8 @@ __device__ __forceinline__ V2<T> v4_allsum(V2<T> v, const V4Rot<T>& r) {
     return v4_same<T>(v, r.a1);
   } else {
     v = v + v4_same<T>(v, r.a0);
-    if (G == 12) v = v + v4_same<T>(v, r.a1);
+    if (G >= 12) v = v + v4_same<T>(v, r.a1);
+    if (G == 24) v = v + v4_same<T>(v, r.a2);
     v = v + (v4_same<T>(v, r.a3) + v4_same<T>(v, r.a4));
     return v;
   }
@@ -144,7 +149,8 @@ __device__ __forceinline__ T v4_allsum1(T v, const V4Rot<T>& r) {
     return v4_bp(r.a1, v);
   } else {
     v = v + v4_bp(r.a0, v);
-    if (G == 12) v = v + v4_bp(r.a1, v);
+    if (G >= 12) v = v + v4_bp(r.a1, v);
+    if (G == 24) v = v + v4_bp(r.a2, v);
     v = v + (v4_bp(r.a3, v) + v4_bp(r.a4, v));
     return v;
   }
@@ -159,7 +165,8 @@ __device__ __forceinline__ T v4_allmax1(T v, const V4Rot<T>& r) {
     return v4_bp(r.a1, v);
   } else {
     v = m_max(v, v4_bp(r.a0, v));
-    if (G == 12) v = m_max(v, v4_bp(r.a1, v));
+    if (G >= 12) v = m_max(v, v4_bp(r.a1, v));
+    if (G == 24) v = m_max(v, v4_bp(r.a2, v));
     return m_max(v, m_max(v4_bp(r.a3, v), v4_bp(r.a4, v)));
   }
 }
@@ -364,8 +371,8 @@ __device__ void taut_z0_b_rows(const DevTab<T>& tb, int l16, int IUSFG, T HALP, 
 template <typename T, int NANG, int PP, int NGST, bool LLSNEG>
 __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UFRIC, T Z0M, T RAORW, T SIG_N, T TEMP2, T PTURB, T AIRD_PVISC,
                           T sinwd, T coswd, T* __restrict__ gfl, T* __restrict__ gsp, unsigned long long& xm0, unsigned long long& xm1, V2<T>& wse,
-                          V2<T>& wslast, V2<T>& apl, T (&rX)[V4_NFRE / (NANG / 2)], T (&rY)[V4_NFRE / (NANG / 2)], T* __restrict__ sXY) {
-  constexpr int G = NANG / 2, NFRE = V4_NFRE, RS = PP * NANG, NS = NFRE / G;
+                          V2<T>& wslast, V2<T>& apl, T (&rX)[V4_NS(NANG)], T (&rY)[V4_NS(NANG)], T* __restrict__ sXY) {
+  constexpr int G = NANG / 2, NFRE = V4_NFRE, RS = PP * NANG, NS = V4_NS(NANG);
   const T CONST1 = tb.BETAMAXOXKAPPA2, ABS_TAUWSHELTER = m_abs(tb.TAUWSHELTER);
   const T FU = m_abs(tb.SWELLF3), FUD = tb.SWELLF2, ROGOROAIR = tb.G / RAORW;
   const T AVG = T(1) / T(NGST);
@@ -504,8 +511,8 @@ template <typename T, int NANG, int PP, int NGST, bool LLSNEG>
 __device__ void v4_sinput_n(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, const T* __restrict__ xk2cg, T UFRIC, T Z0M, T RAORW, T RNFAC,
                             T SIG_N, T TEMP2, T PTURB, T AIRD_PVISC, V2<T> coswdif, V2<T> sinwdif2, T* __restrict__ gfl, T* __restrict__ gsp,
                             unsigned long long& xm0, unsigned long long& xm1, V2<T>& wse, V2<T>& wslast, V2<T>& apl,
-                            T (&rX)[V4_NFRE / (NANG / 2)], T (&rY)[V4_NFRE / (NANG / 2)], T* __restrict__ sXY) {
-  constexpr int G = NANG / 2, NFRE = V4_NFRE, RS = PP * NANG, NS = NFRE / G;
+                            T (&rX)[V4_NS(NANG)], T (&rY)[V4_NS(NANG)], T* __restrict__ sXY) {
+  constexpr int G = NANG / 2, NFRE = V4_NFRE, RS = PP * NANG, NS = V4_NS(NANG);
   const T CONST1 = tb.BETAMAXOXKAPPA2;
   const T CSTRNFAC = (tb.DELTH / (tb.XKAPPA * tb.ZPI)) * RNFAC / RAORW;
   const T FU = m_abs(tb.SWELLF3), FUD = tb.SWELLF2;
@@ -612,22 +619,32 @@ __device__ void v4_sinput_n(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, co
   WSYNC();
 }
 
-// SINPUT_JAN (sinput_jan.F90:171-396, IPHYS = 0; LLNORMAGAM = F): Janssen's wind input with gustiness and the swell damping of IDAMPING.
+// SINPUT_JAN (sinput_jan.F90:171-396, IPHYS = 0): Janssen's wind input with gustiness and the swell damping of IDAMPING.
 // No sheltering: the rows do not depend on each other (the row integrals of the stress are still reduced row by row, but nothing
-// waits for them).  Same outputs as v4_sinput.  coswdif: COS(TH - WDWAVE) of the lane's pair.
-template <typename T, int NANG, int PP, int NGST, bool LLSNEG>
+// waits for them).  Same outputs as v4_sinput.  coswdif: COS(TH - WDWAVE) of the lane's pair.  NRM (the builds that carry LLNORMAGAM,
+// decided at run time by norma): the growth rate of a row and gust state renormalised by GAMNORMA = (1 + ZNZ SUMFSIN2) / (1 + ZNZ SUMF)
+// (sinput_jan.F90:329-357; one all-reduce per row and gust state); xng: plane [M] of CONSTN RNFAC / RAORW XK2CG(M), filled here.
+template <typename T, int NANG, int PP, int NGST, bool LLSNEG, bool NRM = false>
 __device__ void v4_sinput_jan(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UFRIC, T Z0M, T RAORW, T SIG_N, V2<T> coswdif,
                               T* __restrict__ gfl, T* __restrict__ gsp, unsigned long long& xm0, unsigned long long& xm1, V2<T>& wse,
-                              V2<T>& wslast, V2<T>& apl, T (&rX)[V4_NFRE / (NANG / 2)], T (&rY)[V4_NFRE / (NANG / 2)], T* __restrict__ sXY) {
-  constexpr int G = NANG / 2, NFRE = V4_NFRE, RS = PP * NANG, NS = NFRE / G;
+                              V2<T>& wslast, V2<T>& apl, T (&rX)[V4_NS(NANG)], T (&rY)[V4_NS(NANG)], T* __restrict__ sXY,
+                              bool norma = false, V2<T> sinwdif2 = V2<T>{T(0), T(0)}, const T* __restrict__ xk2cg = nullptr, T RNFAC = T(1)) {
+  constexpr int G = NANG / 2, NFRE = V4_NFRE, RS = PP * NANG, NS = V4_NS(NANG);
   const T CONST1 = tb.BETAMAXOXKAPPA2;
   const T CONST3 = T(tb.IDAMPING) * (T(2) * tb.XKAPPA / CONST1);
   const T XKAPPAD = T(1) / tb.XKAPPA;
-  for (int m = L.j; m < NFRE; m += G) L.zcn[m] = m_log(L.fac4[m * 4 + Q4_WAVNUM] * Z0M);
+  T* xng = L.sq;
+  for (int m = L.j; m < NFRE; m += G) {
+    L.zcn[m] = m_log(L.fac4[m * 4 + Q4_WAVNUM] * Z0M);
+    if constexpr (NRM) {
+      if (norma) xng[m] = ((tb.DELTH / (tb.XKAPPA * tb.ZPI)) * RNFAC / RAORW) * xk2cg[m];
+    }
+  }
   WSYNC();
   // gust states (sinput_jan.F90:200-246): US = UFRIC (1 -+ SIG_N), weights 1/2 each
   const T WS = T(1) / T(NGST);
   const V2<T> vUS = (NGST == 1) ? V2<T>{UFRIC, UFRIC} : V2<T>{UFRIC * (T(1) - SIG_N), UFRIC * (T(1) + SIG_N)};
+  const V2<T> vUSM1 = {T(1) / m_max(vUS.x, tb.EPSUS), T(1) / m_max(vUS.y, tb.EPSUS)};
   const bool c0 = coswdif.x > T(0.01), c1 = coswdif.y > T(0.01);
   const V2<T> xkoc = {tb.XKAPPA * f_rcp(coswdif.x), tb.XKAPPA * f_rcp(coswdif.y)};
   xm0 = 0ull; xm1 = 0ull;
@@ -659,8 +676,16 @@ __device__ void v4_sinput_jan(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, 
         const V2<T> Z2X = ZL * ZL * (coswdif * UCN);
         const V2<T> ex = {f_exp(Z0), f_exp(Z1)};
         const V2<T> g = ex * Z2X * Z2X * CNSN;
-        ufac1.x += n0 ? WS * g.x : T(0);
-        ufac1.y += n1 ? WS * g.y : T(0);
+        V2<T> g0 = {n0 ? g.x : T(0), n1 ? g.y : T(0)};      // GAM0 of the gust state
+        if constexpr (NRM) {
+          if (norma) {
+            const V2<T> a = g0 * f, as2 = a * sinwdif2;
+            const V2<T> sm = v4_allsum<G, T>(V2<T>{a.x + a.y, as2.x + as2.y}, L.rot);   // SUMF, SUMFSIN2
+            const T ZNZ = xng[m] * (ig ? vUSM1.y : vUSM1.x);
+            g0 = g0 * ((T(1) + ZNZ * sm.y) / (T(1) + ZNZ * sm.x));
+          }
+        }
+        ufac1 = ufac1 + WS * g0;
         xl0 = xl0 || n0;
         xl1 = xl1 || n1;
       }
@@ -760,13 +785,18 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   enum { C2_FMEAN = C_XSN, C2_FMEANWS = C_YSN, C2_AKMEAN = C_UST, C2_XKMEAN = C_SINU, C2_SC = C_COSU };
   // gfast (optional): compact rows gfast[ij][K][gk] that also receive the first gk frequencies of the new spectrum -- what the next
   // advection step's fast-wave sub-steps start from (ecwam_hip_set_fastwave_copy): written from the tile, no second pass over FL1
-  constexpr int G = NANG / 2, NFRE = V4_NFRE, N = NANG * NFRE, RS = PP * NANG, NS = NFRE / G;
+  constexpr int G = NANG / 2, NFRE = V4_NFRE, N = NANG * NFRE, RS = PP * NANG, NS = V4_NS(NANG);
   constexpr int NSH = (NH + 1) / 2;          // even shifts -2 NSH .. 2 NSH cover the taps -NH .. NH+1 and the DIA rotations
   constexpr int NTAP = 2 * NH + 1;
   constexpr int VEC = 16 / (int)sizeof(T);   // elements per 16-byte global access
   constexpr int NC = NFRE / VEC;             // 16-byte chunks per direction
-  static_assert(PP * G <= 64 && NFRE % G == 0 && NFRE % VEC == 0 && R2 + 2 <= 2 * NSH + 1 && PP * NFRE >= RS, "layout");
-  static_assert(!(EXT && JAN), "IPHYS = 0 is built without LLGCBZ0 / LLNORMAGAM (v4_sinput_jan has no normalised growth rate)");
+  static_assert(PP * G <= 64 && NFRE % VEC == 0 && R2 + 2 <= 2 * NSH + 1, "layout");
+  constexpr int PLN = V4_PLN(PP, NANG);      // elements of a plane [PP][NFRE] that doubles as a staging row [PP][NANG]
+  constexpr bool EVEN = (NFRE % G == 0);     // every lane owns NS frequencies (not at 48 directions)
+  // frequency q of the lane, and whether the lane really owns it (48 directions: q = 1 exists on the lanes j < 12 only; the others repeat
+  // frequency NFRE -- table fills then store the same values twice, sums take a weight of zero)
+  auto mq = [&](int q, int jj) -> int { const int m = q * G + jj; return (EVEN || m < NFRE) ? m : NFRE - 1; };
+  auto okq = [&](int q, int jj) -> bool { return EVEN || q * G + jj < NFRE; };
   static_assert(RARE || !(EXT && ENHMC), "ISNONLIN = 1 beside LLGCBZ0 / LLNORMAGAM: the RARE build");
   typedef T VT __attribute__((ext_vector_type(VEC)));
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -774,8 +804,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   T* sT = reinterpret_cast<T*>(smem_raw);          // [NFRE + V4_NSTG][PP][NANG]
   T* sStg = sT + NFRE * RS;                        // staging rows 0..3
   T* sFac4 = sT + (NFRE + V4_NSTG) * RS;           // [PP][NFRE][4]
-  T* sPl = sFac4 + PP * NFRE * 4;                  // [2][PP][NFRE]: SQRT(WAVNUM), LOG(WAVNUM Z0M); staging rows 4, 5 during the sweep
-  T* sSC = sPl + 2 * PP * NFRE;                    // [PP][NSC]
+  T* sPl = sFac4 + PP * NFRE * 4;                  // [2][PLN]: SQRT(WAVNUM), LOG(WAVNUM Z0M) as [PP][NFRE]; staging rows 4, 5 during the sweep
+  T* sSC = sPl + 2 * PLN;                          // [PP][NSC]
   V4Ctx<T, NANG, PP> L;
   L.lane = threadIdx.x & 63;
   const int lane = L.lane;
@@ -803,7 +833,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   const int n = kijl - ij0 < PP ? kijl - ij0 : PP;   // points of this wave; a short last wave replicates its last point
   const int ij = ij0 + (p < n ? p : n - 1);
   L.tile = sT; L.own = p * NANG + 2 * j;
-  L.fac4 = sFac4 + p * NFRE * 4; L.sq = sPl + p * NFRE; L.zcn = sPl + (PP + p) * NFRE; L.c = sSC + p * NSC;
+  L.fac4 = sFac4 + p * NFRE * 4; L.sq = sPl + p * NFRE; L.zcn = sPl + PLN + p * NFRE; L.c = sSC + p * NSC;
   int sh[2 * NSH + 1];
 #pragma unroll
   for (int i = 0; i <= 2 * NSH; i++) {
@@ -820,6 +850,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   } else {
     const int base = p * G;
 #define V4_ROT(r) (4 * (base + ((j + (r)) >= G ? j + (r) - G : j + (r))))
+    if (G == 24) { L.rot.a0 = V4_ROT(12); L.rot.a1 = V4_ROT(6); L.rot.a2 = V4_ROT(3); }
     if (G == 12) { L.rot.a0 = V4_ROT(6); L.rot.a1 = V4_ROT(3); L.rot.a2 = 0; }
     if (G == 6) { L.rot.a0 = V4_ROT(3); L.rot.a1 = 0; L.rot.a2 = 0; }
     L.rot.a3 = V4_ROT(1); L.rot.a4 = V4_ROT(2);
@@ -874,7 +905,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   T w_wn[NS], w_cg[NS], w_ci[NS], w_xk[NS];   // WAVNUM, CGROUP, CINV, XK2CG of the lane's frequencies m = s G + j
 #pragma unroll
   for (int q = 0; q < NS; q++) {
-    const int m = q * G + j;
+    const int m = mq(q, j);
     w_wn[q] = wp[m]; w_cg[q] = wp[NFRE + m]; w_ci[q] = wp[2 * NFRE + m]; w_xk[q] = wp[3 * NFRE + m];
   }
   const T DEPTHv = ffa[(size_t)ij * ECWAM_HIP_NFF + 15];
@@ -934,7 +965,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     }
 #pragma unroll
     for (int qq = 0; qq < NS; qq++) {
-      const int m = qq * G + j;
+      const int m = mq(qq, j);
       T* f = L.fac4 + m * 4;
       const T WAVNUM = w_wn[qq], XK2CG = w_xk[qq];
       f[Q4_WAVNUM] = WAVNUM; f[Q4_CINV] = w_ci[qq]; f[Q4_BSC] = WAVNUM * (T(1) / tb.ZPI) * XK2CG; L.sq[m] = m_sqrt(WAVNUM);
@@ -1068,7 +1099,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     const T CVIS = tb.RNU * tb.CDISVIS;
 #pragma unroll
     for (int q = 0; q < NS; q++) {
-      const int m = q * G + j;
+      const int m = mq(q, j);
       const T wn = L.fac4[m * 4 + Q4_WAVNUM];
       const T X = wn / XKMEAN;
       L.fac4[m * 4 + Q4_BSC] = SDSJ * X * ((T(1) - tb.DELTA_SDIS) + tb.DELTA_SDIS * X) + CVIS * (wn * wn);
@@ -1175,8 +1206,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     const T* spt = sStg + SPOFF + p * NFRE;
 #pragma unroll
     for (int q = 0; q < NS; q++) {
-      const int m = q * G + j;
-      const T w = rrh(m, MIJ);
+      const int m = mq(q, j);
+      const T w = okq(q, j) ? rrh(m, MIJ) : T(0);
       const T wx = w * L.fac4[m * 4 + Q4_CINV];
       if constexpr (G == 18) s = s + wx * *reinterpret_cast<const V2<T>*>(sXY + 2 * m);
       else s = s + V2<T>{wx * rX[q], wx * rY[q]};
@@ -1208,9 +1239,10 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   T SDS;
   T* gx = (PART == 0 ? xllws : wi) + (size_t)ij * N + 2 * j;   // this lane's pair in row 0 of the block that holds the wind-input coefficient
   if constexpr (PART != 2) {
-  if (norma) v4_sinput_n<T, NANG, PP, 1, false>(tb, L, wp + 3 * NFRE, UFRIC, Z0M, RAORW, RNFAC, T(0), T(0), T(0), T(0), coswdif, sinwdif2, nullptr, nullptr,
-                                               xm0, xm1, wse, wslast, apl, rX, rY, sXY);
-  else if constexpr (JAN) v4_sinput_jan<T, NANG, PP, 1, false>(tb, L, UFRIC, Z0M, RAORW, T(0), coswdif, nullptr, nullptr, xm0, xm1, wse, wslast, apl, rX, rY, sXY);
+  if constexpr (JAN) v4_sinput_jan<T, NANG, PP, 1, false, EXT>(tb, L, UFRIC, Z0M, RAORW, T(0), coswdif, nullptr, nullptr, xm0, xm1, wse, wslast, apl, rX, rY, sXY,
+                                                                 norma, sinwdif2, wp + 3 * NFRE, RNFAC);
+  else if (norma) v4_sinput_n<T, NANG, PP, 1, false>(tb, L, wp + 3 * NFRE, UFRIC, Z0M, RAORW, RNFAC, T(0), T(0), T(0), T(0), coswdif, sinwdif2, nullptr, nullptr,
+                                                    xm0, xm1, wse, wslast, apl, rX, rY, sXY);
   else v4_sinput<T, NANG, PP, 1, false>(tb, L, UFRIC, Z0M, RAORW, T(0), T(0), T(0), T(0), sinwd, coswd, nullptr, nullptr, xm0, xm1, wse, wslast, apl, rX, rY, sXY);
   femws_finish(wse, wslast, FMEANWS, EMW);
   MIJ = frcutindex4(FMEANWS, UFRIC);
@@ -1248,9 +1280,10 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   V4_PHASE_EXIT(204);
   // ---- second SINFLX call: wind-input coefficient (parked in the point's XLLWS block, [M][K]; PART 1: in the rows of wi), XLLWS, MIJ,
   //      wave stress, PHIWA
-  if (norma) v4_sinput_n<T, NANG, PP, 2, true>(tb, L, wp + 3 * NFRE, UFRIC, Z0M, RAORW, RNFAC, c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], coswdif,
-                                              sinwdif2, gx, gsp, xm0, xm1, wse, wslast, apl, rX, rY, sXY);
-  else if constexpr (JAN) v4_sinput_jan<T, NANG, PP, 2, true>(tb, L, UFRIC, Z0M, RAORW, c[C_SIGN], coswdif, gx, gsp, xm0, xm1, wse, wslast, apl, rX, rY, sXY);
+  if constexpr (JAN) v4_sinput_jan<T, NANG, PP, 2, true, EXT>(tb, L, UFRIC, Z0M, RAORW, c[C_SIGN], coswdif, gx, gsp, xm0, xm1, wse, wslast, apl, rX, rY, sXY,
+                                                                norma, sinwdif2, wp + 3 * NFRE, RNFAC);
+  else if (norma) v4_sinput_n<T, NANG, PP, 2, true>(tb, L, wp + 3 * NFRE, UFRIC, Z0M, RAORW, RNFAC, c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], coswdif,
+                                                   sinwdif2, gx, gsp, xm0, xm1, wse, wslast, apl, rX, rY, sXY);
   else v4_sinput<T, NANG, PP, 2, true>(tb, L, UFRIC, Z0M, RAORW, c[C_SIGN], c[C_TEMP2], c[C_PTURB], c[C_AIRDPVISC], sinwd, coswd, gx, gsp, xm0, xm1, wse,
                                        wslast, apl, rX, rY, sXY);
   femws_finish(wse, wslast, FMEANWS, EMW);
@@ -1347,8 +1380,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
           T s2 = T(0);
 #pragma unroll
           for (int q = 0; q < NS; q++) {
-            const int m = q * G + j;
-            const T t2 = spt[m], fr = tb.FR[m], dfm = tb.DFIM[m];
+            const int m = mq(q, j);
+            const T t2 = okq(q, j) ? spt[m] : T(0), fr = tb.FR[m], dfm = tb.DFIM[m];
             s01 = s01 + V2<T>{dfm, tb.DFIMFR[m]} * t2;
             s2 = s2 + (dfm * (fr * fr)) * t2;
           }
@@ -1462,7 +1495,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     T* st2 = sStg + 2 * RS;
     T* st3 = sStg + 3 * RS;
     T* st4 = sPl;
-    T* st5 = sPl + PP * NFRE;
+    T* st5 = sPl + PLN;
     V2<T> aS[8], aF[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) { aS[i] = z2; aF[i] = z2; }
@@ -1687,7 +1720,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
               P1[0] = (R1 == 0) ? DELAP : v4_at<T, NSH, R1>(sp, sh); P1s[0] = v4_at<T, NSH, R1 + 1>(sp, sh);
               if constexpr (G != 18 && !JAN) {
                 bm1 = m_max(bm1, e0);
-                if (G == 12) e1 = v4_bp(L.rot.a1, bm1);
+                if (G >= 12) e1 = v4_bp(L.rot.a1, bm1);
               }
             } else {
               A2[1] = v4_at<T, NSH, R2>(sa, sh); A2s[1] = v4_at<T, NSH, R2 + 1>(sa, sh);
@@ -1699,7 +1732,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
                 bm1 = v4_rowmax<T>(m_max(bm1, e0));
                 e3 = v4_bp(L.rot.a1, bm1);
               } else {
-                if (G == 12) bm1 = m_max(bm1, e1);
+                if (G >= 12) bm1 = m_max(bm1, e1);
+                if (G == 24) bm1 = m_max(bm1, v4_bp(L.rot.a2, bm1));      // (48 directions: one more exchange, waited for here)
                 e3 = v4_bp(L.rot.a3, bm1); e4 = v4_bp(L.rot.a4, bm1);
               }
             }
@@ -1745,7 +1779,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   T xk2r[JAN ? NS : 1];
 #pragma unroll
   for (int q = 0; q < NS; q++) {   // unconditional loads, pinned here (a conditional one is sunk into a branch behind the sums: load, wait, twice)
-    const int m = q * G + j;
+    const int m = mq(q, j);
     stkw[q] = wp[4 * NFRE + m];
     stkd[q] = tb.DFIM_SIM[m];
     if constexpr (JAN) xk2r[q] = wp[3 * NFRE + m];   // XK2CG again: the saturation scale WAVNUM XK2CG / 2 pi back into its slot for IMPHFTAIL
@@ -1776,7 +1810,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   //      they were one exposed global-memory round trip per frequency.
 #pragma unroll
   for (int q = 0; q < NS; q++) {
-    const int m = q * G + j;
+    const int m = mq(q, j);
     L.zcn[m] = (m < tb.NFRE_ODD) ? stkw[q] * stkd[q] : T(0);
     if constexpr (JAN) L.fac4[m * 4 + Q4_BSC] = L.fac4[m * 4 + Q4_WAVNUM] * (T(1) / tb.ZPI) * xk2r[q];
   }
@@ -1841,12 +1875,12 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       T term = T(0);
 #pragma unroll
       for (int q = 0; q < NS; q++) {
-        const int m = q * G + j;
+        const int m = mq(q, j);
         const T wn = L.fac4[m * 4 + Q4_WAVNUM];
         const T XKI = aki_ice_d(tb.G, wn, DEPTH, tb.ROWATER, CITHICKi);
         const T E = T(0.5) * CITHICKi * (XKI * XKI * XKI) / wn;
         const T sume = spt[m];
-        if (sume > tb.FLMIN / tb.DELTH) term += (E * E) * sume * tb.DFIM[m];
+        if (okq(q, j) && sume > tb.FLMIN / tb.DELTH) term += (E * E) * sume * tb.DFIM[m];
       }
       STRNMS = v4_allsum1<G, T>(term, L.rot);
     }

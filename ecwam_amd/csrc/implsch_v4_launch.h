@@ -11,7 +11,7 @@
 
 template <typename T, int NANG, int PP>
 static constexpr size_t v4_lds_bytes() {
-  return (size_t)((V4_NFRE + V4_NSTG) * PP * NANG + PP * V4_NFRE * V4_NFAC + PP * NSC) * sizeof(T);
+  return (size_t)((V4_NFRE + V4_NSTG) * PP * NANG + PP * V4_NFRE * 4 + 2 * V4_PLN(PP, NANG) + PP * NSC) * sizeof(T);
 }
 
 #ifndef V4_SPLIT_ALL

@@ -104,6 +104,7 @@ def compare_implsch(ref: dict, got: dict, tables) -> dict:
     e = np.abs(got["FL1"].astype(np.float64) - ref["FL1"].astype(np.float64)) / np.maximum(peak, 1e-300)
     st["fl1_max_rel_peak_clean"] = float(e[clean].max()) if clean.any() else 0.0
     st["fl1_max_rel_peak_all"] = float(e.max())
+    st["fl1_p9999_rel_peak"] = float(np.quantile(e[clean], 0.9999)) if clean.any() else 0.0      # the error of all but one bin in 10 000
     ebin = rel_err(got["FL1"], ref["FL1"], 1e-300)
     st["fl1_max_rel_bin_clean"] = float(ebin[clean].max()) if clean.any() else 0.0
     st["fl1_frac_bins_gt_1e-5"] = float((ebin > 1e-5).mean())

@@ -236,14 +236,13 @@ class HipContext:
         self._chk(self.lib.ecwam_hip_implsch_reserve(self._h, int(npts)))
 
     def implsch_generation_used(self) -> int:
-        """Kernel generation the last implsch() call launched (2 or 4)."""
+        """Kernel generation the last implsch() call launched: 4 (k_implsch4) since the one-point-per-wavefront kernel left the product."""
         return int(self.lib.ecwam_hip_implsch_generation_used(self._h))
 
-    def set_implsch_generation(self, gen: int) -> None:
-        """Cap the IMPLSCH kernel generation (2 or 4; 0 = automatic): include/ecwam_hip.h ecwam_hip_set_implsch_generation."""
-        self._chk(self.lib.ecwam_hip_set_implsch_generation(self._h, int(gen)))
+    def device_tables(self) -> int:
+        """Address of the device copy of the module tables (ecwam_hip_device_tables): diagnostics, the tests' second IMPLSCH implementation."""
+        return int(self.lib.ecwam_hip_device_tables(self._h) or 0)
 
-    # -- OUTBS subset (outblock.F90 parameters 1-3) and OUTWNORM statistics, on the device
     def outbs(self, kijs, kijl, fl1, out, zmiss: float = -999.0):
         nrow = fl1.shape[0]
         if not (0 <= kijs <= kijl <= min(nrow, out.shape[0])):

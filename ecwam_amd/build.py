@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libecwam_hip.so")
-SOURCES = ["capi.hip", "propag.hip", "implsch.hip", "implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip", "outbs.hip"]
+SOURCES = ["capi.hip", "propag.hip", "implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip", "outbs.hip"]
 # objects that are a second compilation of another source: object name -> (source, extra flags; a later -O overrides the earlier one).
 # implsch4rd = the double precision RARE builds of k_implsch4 at -O2 (their -O3 builds fault on the device: implsch4r.hip)
 DERIVED = {"implsch4r.hip": ("implsch4r.hip", ["-DV4R_PREC=1"]), "implsch4rd.hip": ("implsch4r.hip", ["-DV4R_PREC=2", "-O2"])}
@@ -21,7 +21,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # refinement (<= 2.5 ulp) instead of the correctly rounded sequences; double precision is unaffected.
 FAST_DIV = ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
-IMPLSCH_SOURCES = ("implsch.hip", "implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip")
+IMPLSCH_SOURCES = ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip")
 # Build variants of the IMPLSCH translation units (the single-precision error attribution):
 #   ""         the product build: hardware reciprocal / square root / exp2 / log2 in single precision, FMA contraction on
 #   "exactdiv" every `/` and SQRT the source spells out is correctly rounded (the scalar chains per sea point: TAUT_Z0, STRESSO, FKMEAN,

@@ -30,8 +30,7 @@ struct ecwam_hip_ctx {
   double* norm_scratch = nullptr;   // ecwam_hip_outwnorm: per-context reduction scratch (4 + 4 x 256 doubles)
   // fourth kernel generation (implsch_v4.h): DIA rotations K1 = K -+ r1, K2 = K +- r2, NSDSNTH = nh; ok = the tables have that structure
   int v4_ok = 0, v4_r1 = 0, v4_r2 = 0, v4_nh = 0, v4_shelter = 0;
-  int implsch_gen = 0;  // 0: the fastest kernel generation that covers the configuration; 2 / 4: at most that generation (tests)
-  int implsch_last = 0; // generation the last ecwam_hip_implsch call launched (2 / 4)
+  int implsch_last = 0; // generation the last ecwam_hip_implsch call launched (4; 0 before the first call)
   void* fin = nullptr;  // rows of scalars k_implsch4 hands to its finishing kernel, indexed by the point number; grown on demand
   size_t fin_bytes = 0;
   void* wi = nullptr;   // rows [ij][M][K] for the wind-input coefficient between the two kernels of the split k_implsch4 (only allocated
@@ -83,7 +82,6 @@ template <typename T> void launch_p2c(const void*, void*, int, int, int, int, in
 template <typename T> void launch_pack(const void*, const int*, int, int, void*, hipStream_t);
 template <typename T> void launch_proenv_pack(int, int, const void*, const void*, const void*, const void*, const void*, void*, hipStream_t);
 template <typename T> void launch_proenv_unpack(int, int, const void*, const void*, void*, void*, void*, void*, void*, void*, hipStream_t);
-template <typename T> int launch_implsch(const void*, int, int, void*, const void*, void*, void*, int*, void*, double*, void*, int, int, int, hipStream_t);
 template <typename T> int launch_implsch4(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, void*, int, int, int, int, int, int, hipStream_t);
 template <typename T> int launch_implsch4x(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, void*, int, int, int, int, int, int, hipStream_t);
 template <typename T> int launch_implsch4r(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, void*, int, int, int, int, int, int, hipStream_t);
@@ -430,6 +428,22 @@ int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int r
     HIPCHK_CTX(hipMemcpy(c->dtab, h.data(), sizeof(DevTab<double>), hipMemcpyHostToDevice));
   }
 #undef HIPCHK_CTX
+  // IMPLSCH runs k_implsch4 (implsch_v4.h) and nothing else since round 5: refuse here what its builds do not cover, with the reason
+  {
+    const char* why = nullptr;
+    const bool inst = (c->NANG == 48 && c->v4_r1 == 1 && c->v4_r2 == 4 && c->v4_nh == 11) || (c->NANG == 36 && c->v4_r1 == 1 && c->v4_r2 == 3 && c->v4_nh == 8) ||
+                      (c->NANG == 24 && c->v4_r1 == 0 && c->v4_r2 == 2 && c->v4_nh == 5) || (c->NANG == 12 && c->v4_r1 == 0 && c->v4_r2 == 1 && c->v4_nh == 3);
+    if (p->nfre != 36) why = "NFRE must be 36 (the frequency grid of every configuration of the reference)";
+    else if (!c->v4_ok) why = "the saturation weights / indices do not have the structure of INIT_SDISS_ARDH (COS**2 taps, symmetric, the same for every direction) or the DIA mirror images differ";
+    else if (!inst) why = "NANG must be 48, 36, 24 or 12 with the interaction rotations and the saturation half-width of INISNONLIN / INIT_SDISS_ARDH on that grid";
+    else if (p->iphys == 1 && p->llnormagam && c->v4_shelter) why = "LLNORMAGAM needs TAUWSHELTER = 0 (setwavphys.F90:150-190: the normalised growth rate replaces the sheltering)";
+    else if (p->iphys == 1 && !p->llnormagam && !c->v4_shelter) why = "IPHYS = 1 without LLNORMAGAM needs TAUWSHELTER /= 0 (setwavphys.F90:150-190)";
+    if (why) {
+      (void)hipFree(c->dtab);
+      delete c;
+      return fail(std::string("ecwam_hip_create: configuration not covered by the IMPLSCH kernel: ") + why);
+    }
+  }
   *out = c;
   return 0;
 }
@@ -668,25 +682,20 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   if (kijl > kijs && c->p.lwnemocou && !wam2nemo) return fail("ecwam_hip_implsch: LWNEMOCOU needs the WAVE2OCEAN buffer");
   if (!c->p.lwnemocou) wam2nemo = nullptr;
   hipStream_t s = (hipStream_t)stream;
-  int rc, variant = 0;
-  if (c->p.llnormagam) variant |= 16;
-  const bool rare = c->p.lciwa1 || c->p.lciwa2 || c->p.lciwa3 || c->p.lciscal || c->p.lwnemocou || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin ||
-                    c->p.iphys == 0 || c->p.icode != 3 || !c->p.lwvflx_snl;
-  if (c->p.llgcbz0 || rare) variant |= 32;
-  // fourth kernel generation (implsch_v4.h).  The common builds: flag sets A and B (LLGCBZ0, LLNORMAGAM), with or without the sea-ice
+  int rc = -1;
+  if (dbg) return fail("ecwam_hip_implsch: the per-point debug rows were an output of the retired one-point-per-wavefront kernel: pass NULL");
+  // k_implsch4 (implsch_v4.h).  The common builds: flag sets A and B (LLGCBZ0, LLNORMAGAM), with or without the sea-ice
   // damping rates that depend on the frequency only (LCIWA1, LCIWA3, LCISCAL), and on flag set A IPHYS 0 or ISNONLIN 1 -- what the
-  // reference's registered configurations select.  Everything else the kernel covers runs its RARE builds (implsch4r.hip, sp only: LCIWA2, the
-  // NEMO ice stress and strain, ISNONLIN 2, ICODE 1 / 2, LWVFLX_SNL = F, ISNONLIN 1 beside flag set B or IPHYS 0).  The sheltered growth
-  // needs TAUWSHELTER /= 0, the normalised one TAUWSHELTER = 0 (setwavphys.F90:150-190).  k_implsch2 stays the generic fallback: other
-  // direction counts than 36 / 24 / 12, IPHYS = 0 together with LLGCBZ0 / LLNORMAGAM, the RARE configurations in double precision.
+  // reference's registered configurations select.  Everything else runs its RARE builds (implsch4r.hip: LCIWA2, the NEMO ice stress and
+  // strain, ISNONLIN 2, ICODE 1 / 2, LWVFLX_SNL = F, ISNONLIN 1 beside flag set B or IPHYS 0, IPHYS 0 beside flag set B).  ecwam_hip_create
+  // has refused what no build covers.
   const int ext = (c->p.llnormagam || c->p.llgcbz0) ? 1 : 0;
   const bool rare4 = c->p.lciwa2 || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin > 1 || c->p.icode != 3 || !c->p.lwvflx_snl;
   // the alternate physics the registered configurations select, on flag set A only: 1 = IPHYS 0 (sinput_jan + sdissip_jan; its
   // TAUWSHELTER is 0), 2 = ISNONLIN 1 (TRANSF per interaction frequency)
   const int alt = (c->p.iphys == 0 ? 1 : 0) | (c->p.isnonlin == 1 ? 2 : 0);
   const bool common_ok = !rare4 && (alt == 0 || (!ext && alt != 3));
-  const bool shelter_ok = (c->p.iphys == 0) ? true : (c->p.llnormagam ? c->v4_shelter == 0 : c->v4_shelter != 0);
-  if (c->v4_ok && (c->implsch_gen == 0 || c->implsch_gen >= 4) && !dbg && shelter_ok) {
+  {
     if (int rc2 = ecwam_hip_implsch_reserve(c, kijl)) return rc2;   // no-op once the buffer covers kijl
     if (!common_ok)
       DISPATCH(rc = launch_implsch4r<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->wi, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, c->p.iphys == 0 ? 1 : 0, s),
@@ -699,13 +708,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
                rc = launch_implsch4<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->wi, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s));
     if (rc == 0) { HIPCHK(hipGetLastError()); c->implsch_last = 4; return 0; }
   }
-  c->implsch_last = 2;
-  DISPATCH(rc = launch_implsch<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s),
-           rc = launch_implsch<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, wam2nemo, dbg, c->NANG, c->NFRE, variant, s));
-  if (rc) return fail("ecwam_hip_implsch: unsupported spectral size for the LDS tiling");
-  HIPCHK(hipGetLastError());
-  if (c->fast_g) { fastwave_copy(c, fl1, kijs, kijl, s); HIPCHK(hipGetLastError()); }   // (k_implsch4 writes the compact rows from its tile)
-  return 0;
+  return fail("ecwam_hip_implsch: no build of k_implsch4 covers the configuration (ecwam_hip_create should have refused it)");
 }
 
 int ecwam_hip_set_fastwave_copy(ecwam_hip_ctx* c, void* g, int g_nfre) {
@@ -741,12 +744,9 @@ int ecwam_hip_implsch_reserve(ecwam_hip_ctx* c, int npts) {
 
 int ecwam_hip_implsch_generation_used(ecwam_hip_ctx* c) { return c ? c->implsch_last : 0; }
 
-int ecwam_hip_set_implsch_generation(ecwam_hip_ctx* c, int gen) {
-  if (!c) return fail("null context");
-  if (gen != 0 && gen != 2 && gen != 4) return fail("ecwam_hip_set_implsch_generation: 0 (automatic), 2 or 4");
-  c->implsch_gen = gen;
-  return 0;
-}
+// The device copy of the module tables (DevTab<float> or DevTab<double>, csrc/dev.h): for diagnostics and for second implementations of a
+// kernel that want to run on exactly the tables the product runs on (tests/csrc/implsch_v2.hip).
+const void* ecwam_hip_device_tables(ecwam_hip_ctx* c) { return c ? c->dtab : nullptr; }
 
 int ecwam_hip_outbs(ecwam_hip_ctx* c, int kijs, int kijl, const void* fl1, double zmiss, void* out, void* stream) {
   if (!c) return fail("null context");

@@ -1,10 +1,11 @@
-// Launcher of the fourth IMPLSCH kernel generation (implsch_v4.h): PP sea points per wavefront on adjacent direction pairs, every
-// rotation in K through LDS rows.  implsch.F90:10-468 on flag set A (LLGCBZ0 = F, LLNORMAGAM = F) and, in the EXT build of the
-// kernel, flag set B (either or both of them T: cy49r1 / cy50r1); sea-ice damping LCIWA1 / LCIWA3 / LCISCAL (no LCIWA2), the NEMO coupling outputs of LWNEMOCOU (without ice stress, strain, break-up), IPHYS = 1, ISNONLIN = 0,
-// ICODE = 3, NFRE = 36, NANG = 48 / 36 / 24 / 12, single and double precision.
+// Launcher of the common builds of k_implsch4 (implsch_v4.h: PP sea points per wavefront on adjacent direction pairs, every rotation in K
+// through LDS rows): implsch.F90:10-468 on flag set A (LLGCBZ0 = F, LLNORMAGAM = F) and, in the EXT build, flag set B (either or both of
+// them T: cy49r1 / cy50r1), with or without the sea-ice damping LCIWA1 / LCIWA3 / LCISCAL and the NEMO coupling outputs of LWNEMOCOU; IPHYS = 1,
+// ISNONLIN = 0, ICODE = 3; NFRE = 36, NANG = 48 / 36 / 24 / 12, single and double precision.  (IPHYS 0 / ISNONLIN 1: implsch4x.hip; every
+// other switch: implsch4r.hip.)
 #include "implsch_v4_launch.h"
 
-// returns 0 when launched, -1 when no instantiation covers (NANG, r1, r2, nh): the caller falls back to k_implsch2
+// returns 0 when launched, -1 when no instantiation covers (NANG, r1, r2, nh): ecwam_hip_create refuses those configurations
 template <typename T>
 int launch_implsch4(const void* tab, int kijs, int kijl, void* fl1, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws,
                     void* fin, double* w2n, void* gfast, int gk, void* wi, int NANG, int NFRE, int r1, int r2, int nh, int ext, hipStream_t s) {

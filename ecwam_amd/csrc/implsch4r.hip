@@ -5,12 +5,7 @@
 // flag set A (JAN + ENHMC).  A translation unit of its own: the builds compile beside those of implsch4.hip / implsch4x.hip.
 #include "implsch_v4_launch.h"
 
-// jan: 1 = IPHYS 0.  Returns 0 when launched, -1 when no instantiation covers the configuration (k_implsch2 runs it).
-// Single precision only.  The double precision RARE builds (370 - 440 registers, 170 - 320 KB of code each) compile, but the kernel ends in
-// HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION or in wrong numbers on the first launch, also with every rare switch off at run time; the same
-// source with an early-exit branch at each phase boundary (the diagnostics build) runs correctly, so does the build with the carried SDICE
-// rates removed, while scheduling barriers, SGPR spills to memory instead of to lanes and a recomputed instead of a carried rate change
-// nothing (profiles/r04_rare_dp_note.txt): not understood, so double precision keeps k_implsch2 for these configurations.
+// jan: 1 = IPHYS 0.  Returns 0 when launched, -1 when no instantiation covers the configuration (ecwam_hip_create refuses those).
 // V4R_PREC selects the precision this object instantiates: 1 = single (implsch4r.o), 2 = double (implsch4rd.o, compiled at -O2: at -O3 the
 // double precision builds end in a memory access fault or in wrong numbers on their first launch, with every rare switch off at run time,
 // while -O2, -O1 and -O3 with index assertions on every table and row access run clean -- profiles/r05_rare_dp_rootcause.txt).

@@ -4,7 +4,7 @@
 // those of implsch4.hip.
 #include "implsch_v4_launch.h"
 
-// variant: 1 = IPHYS 0, 2 = ISNONLIN 1.  Returns 0 when launched, -1 when no instantiation covers the configuration (k_implsch2 runs it).
+// variant: 1 = IPHYS 0, 2 = ISNONLIN 1.  Returns 0 when launched, -1 when no instantiation covers the configuration (ecwam_hip_create refuses those).
 template <typename T>
 int launch_implsch4x(const void* tab, int kijs, int kijl, void* fl1, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws,
                      void* fin, double* w2n, void* gfast, int gk, void* wi, int NANG, int NFRE, int r1, int r2, int nh, int variant, hipStream_t s) {

@@ -1,6 +1,6 @@
-// IMPLSCH, fourth kernel generation (implsch.F90:10-468 and the routines it inlines on flag set A): PP sea points per wavefront,
+// IMPLSCH (implsch.F90:10-468 and the routines it inlines), the product's one kernel generation since round 5: PP sea points per wavefront,
 // G = NANG/2 lanes per point, lane j of a point owns the ADJACENT direction pair (K = 2j, 2j+1).  Single and double precision,
-// NANG = 36 / 24 / 12 (PP = 3 / 5 / 10), NFRE = 36.
+// NANG = 48 / 36 / 24 / 12 (PP = 2 / 3 / 5 / 10 in single precision), NFRE = 36.
 //
 // What changed against the round-1 three-points-per-wavefront kernel (k_implsch3: pairs (K, K+18), ds_bpermute rotations), and why (tools/ubench_valu.hip, profiles/r02_ubench_valu.txt, MI355X):
 //   * ds_bpermute_b32 costs 6 cycles of the CU's single LDS pipe per wave instruction, ds_read_b32 / ds_read_b64 cost 2: the 53
@@ -24,7 +24,7 @@
 //   * the dependent scalar chains that need no spectrum on either side run one sea point per lane in k_implsch4_pre (first TAUT_Z0)
 //     and k_implsch4_fin (second STRESSO / TAU_PHI_HF, WNFLUXES, NEMO coupling outputs) around the main kernel.
 // The lane-per-point scalar stages between the vector stages (STRESSO of the first call, second TAUT_Z0, WSIGSTAR, swell set-up,
-// SDIWBK) are those of implsch_v2.h.
+// SDIWBK) are those of implsch_point.h.
 #pragma once
 
 #define V4_NFRE 36
@@ -233,7 +233,7 @@ enum { Q4_BSC = 0, Q4_SBO, Q4_CINV, Q4_WAVNUM };   // Q4_BSC = WAVNUM XK2CG / 2 
 // DPP row r work for one point (every argument is the value of the lane's point, the same on the lanes of a row), STRESS_GC's sum over
 // the gravity-capillary wavenumbers NS .. NWAV_GC (stress_gc.F90:80-130, at most 82 terms) runs over the lanes of the row.  The
 // iterations of a point stop by its own criterion (its lanes keep their values from then on); the wave leaves a loop when every row has.
-// taut_z0_b_w (implsch_v2.h) is the same arithmetic for one point per wave.
+// taut_z0_b_w (tests/csrc/implsch_v2.h) is the same arithmetic for one point per wave.
 template <typename T>
 __device__ T stress_gc_row(const DevTab<T>& tb, int l16, bool run, T ANG_GC, T USTAR, T Z0, T Z0MIN, T HALP, T RNFAC) {
   const T XLAMA = T(0.25), XLAMB = T(4.0);
@@ -2033,7 +2033,7 @@ __global__ void __launch_bounds__(64) k_implsch4_fin(const DevTab<T>* __restrict
     T* io = intfa + (size_t)ij * ECWAM_HIP_NINTF;
     io[5] = TAUXD; io[6] = TAUYD; io[7] = TAUOCXD; io[8] = TAUOCYD; io[9] = TAUOC; io[10] = fr[FIN_TAUICX]; io[11] = fr[FIN_TAUICY];
     io[12] = PHIOCD; io[13] = PHIEPS; io[14] = PHIAW;
-    if (tb.LWNEMOCOU && w2n) {  // wnfluxes.F90:304-328 (LNUPD = T; no ice stress without LWNEMOCOUWRS: that configuration runs k_implsch2)
+    if (tb.LWNEMOCOU && w2n) {  // wnfluxes.F90:304-328 (LNUPD = T; the ice stress of LWNEMOCOUWRS comes from the RARE build of the main kernel, zero otherwise)
       double* q = w2n + (size_t)ij * 13;
       q[3] = (double)PHIEPS; q[4] = (double)TAUOC;
       q[5] = (EM_OC != T(0)) ? 4.0 * (double)m_sqrt(EM_OC) : 0.0;

@@ -2,7 +2,7 @@
 // implsch4x.hip (IPHYS = 0, ISNONLIN = 1).
 #pragma once
 #include "implsch_common.h"
-#include "implsch_v2.h"
+#include "implsch_point.h"
 #include "implsch_v4.h"
 
 #ifndef V4_DP36_PP

@@ -175,7 +175,7 @@ SUBROUTINE WAMINTGR_HIP (CDTPRA, CDATE, CDATEWH, CDTIMP, CDTIMPNEXT,  &
       DO ISUB = 1, NINT(REAL(HIPST%IDELPRO, C_DOUBLE) / HIPST%DELPRO_LF) - 1
         CALL HIP_HALO_START(HIPST%D_G1, NANG * HIPST%LFP, S0)
         CALL ADVECT_FAST(HIPST%KIJS_INT - 1, HIPST%KIJL_INT)
-        IF (HIPST%NRANKS > 1) THEN
+        IF (HIPST%LDECOMP) THEN
           CALL HIP_HALO_FINISH(S0)
           CALL ADVECT_FAST(0_C_INT, HIPST%KIJS_INT - 1)
           CALL ADVECT_FAST(HIPST%KIJL_INT, NP)
@@ -186,7 +186,7 @@ SUBROUTINE WAMINTGR_HIP (CDTPRA, CDATE, CDATEWH, CDTIMP, CDTIMPNEXT,  &
     ENDIF
     CALL HIP_HALO_START(HIPST%D_FL1, NANG * NFRE, S0)
     CALL ADVECT_FULL(HIPST%KIJS_INT - 1, HIPST%KIJL_INT)
-    IF (HIPST%NRANKS > 1) THEN
+    IF (HIPST%LDECOMP) THEN
       CALL HIP_HALO_FINISH(S0)
       CALL ADVECT_FULL(0_C_INT, HIPST%KIJS_INT - 1)
       CALL ADVECT_FULL(HIPST%KIJL_INT, NP)
@@ -334,7 +334,7 @@ CONTAINS
     DO I = 1, NPASS
       CALL ADVECT_REFRA(PDEL(I), PMS(I), PME(I), PCP(I), PRG(I), HIPST%KIJS_INT - 1, HIPST%KIJL_INT)
     ENDDO
-    IF (HIPST%NRANKS > 1) THEN
+    IF (HIPST%LDECOMP) THEN
       CALL HIP_HALO_FINISH(S0)
       DO I = 1, NPASS
         CALL ADVECT_REFRA(PDEL(I), PMS(I), PME(I), PCP(I), PRG(I), 0_C_INT, HIPST%KIJS_INT - 1)

@@ -39,7 +39,7 @@ extern "C" {
 #define ECWAM_HIP_MAXANG 48
 /* bumped whenever ecwam_hip_params / ecwam_hip_tables or an entry point changes: 2 = refraction entry points, SDICE1 table and
  * ice break-up parameters added.  ecwam_hip_abi_version() returns the value the library was built with. */
-#define ECWAM_HIP_ABI_VERSION 4
+#define ECWAM_HIP_ABI_VERSION 5
 #define ECWAM_HIP_MAXFRE 48
 #define ECWAM_HIP_MAXMC 56     /* MLSTHG = NFRE - ISM <= 48 + 8 */
 #define ECWAM_HIP_MAXTAP 47    /* 2*NSDSNTH+1, NSDSNTH <= NANG/2-1 */
@@ -270,21 +270,20 @@ int ecwam_hip_propags2_refra(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n
  *             NEMOUSTOKES NEMOVSTOKES NEMOSTRN NPHIEPS NTAUOC NSWH NMWP NEMOTAUX NEMOTAUY NEMOTAUICX NEMOTAUICY NEMOWSWAVE
  *             NEMOPHIF; updated as wnfluxes.F90:304-328 (LNUPD = T) and stokestrn.F90:75-88 do; required when LWNEMOCOU,
  *             ignored (may be NULL) otherwise
- *   dbg: optional real[npts][32] intermediate dump (tests only), may be NULL
+ *   dbg: must be NULL (ABI 4: an intermediate dump of the retired one-point-per-wavefront kernel)
  */
 int ecwam_hip_implsch(ecwam_hip_ctx *ctx, int kijs, int kijl, void *fl1, const void *wvprpt, void *ff, void *intf, int *mij,
                       void *xllws, double *wam2nemo, void *dbg, void *stream);
 /*
- * IMPLSCH exists in two kernel generations with identical results up to rounding (csrc/implsch_v2.h: one point per wavefront, every
- * configuration; implsch_v4.h: several points per wavefront, flag sets A and B with or without the sea-ice damping LCIWA1 / LCIWA3 / LCISCAL and the
- * NEMO coupling outputs of LWNEMOCOU).  ecwam_hip_implsch launches the fastest one that
- * covers the context's configuration; gen = 2 or 4 caps the choice at that generation (parity tests that keep the generations
- * checked against each other), gen = 0 restores the automatic choice.
- */
-int ecwam_hip_set_implsch_generation(ecwam_hip_ctx *ctx, int gen);
-/* The generation the last ecwam_hip_implsch call of this context launched (2 or 4; 0 before the first call): lets a test assert that a
- * configuration runs on the kernel it is meant to run on. */
+ * IMPLSCH runs ONE kernel generation since ABI 5: k_implsch4 (csrc/implsch_v4.h: several sea points per wavefront; common builds for the
+ * configurations the reference registers as tests, RARE builds for every other switch of SURVEY.md 8a), 48 / 36 / 24 / 12 directions x 36
+ * frequencies, single and double precision.  ecwam_hip_create refuses what no build covers.  (ABI 4 carried a second, slower generation for
+ * the remainder and ecwam_hip_set_implsch_generation to choose; that kernel is now test infrastructure, tests/csrc/implsch_v2.h.)
+ * The generation the last ecwam_hip_implsch call of this context launched (4; 0 before the first call). */
 int ecwam_hip_implsch_generation_used(ecwam_hip_ctx *ctx);
+/* The device copy of the module tables the kernels read (private layout, csrc/dev.h DevTab): for diagnostics and for a second
+ * implementation of a kernel that is to run on exactly the tables the library runs on (the tests' k_implsch2).  Owned by the context. */
+const void *ecwam_hip_device_tables(ecwam_hip_ctx *ctx);
 /*
  * k_implsch4 is bracketed by two one-point-per-lane kernels (first TAUT_Z0 before, second STRESSO and WNFLUXES after it) that exchange
  * 24 scalars per sea point through a context-owned device buffer indexed by the point number.  ecwam_hip_implsch grows that buffer when

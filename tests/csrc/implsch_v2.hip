@@ -1,5 +1,7 @@
-// Launcher of the one-point-per-wavefront IMPLSCH kernel (implsch_v2.h: lane = direction, two LDS tiles, fused sweep -- every
-// configuration).  The several-points-per-wavefront kernel of flag sets A and B lives in implsch4.hip.
+// TEST INFRASTRUCTURE: launcher of the one-point-per-wavefront IMPLSCH kernel (implsch_v2.h: lane = direction, two LDS tiles, fused sweep --
+// every configuration), the second implementation the GPU tests compare k_implsch4 with.  Built by tests/v2lib.py into
+// tests/csrc/libecwam_v2.so; takes the device tables of a product context (ecwam_hip_device_tables).
+#include <hip/hip_runtime.h>
 #include "implsch_common.h"
 #include "implsch_v2.h"
 
@@ -53,3 +55,13 @@ int launch_implsch(const void* tab, int kijs, int kijl, void* fl1, const void* w
 }
 template int launch_implsch<float>(const void*, int, int, void*, const void*, void*, void*, int*, void*, double*, void*, int, int, int, hipStream_t);
 template int launch_implsch<double>(const void*, int, int, void*, const void*, void*, void*, int*, void*, double*, void*, int, int, int, hipStream_t);
+
+// variant: 16 = LLNORMAGAM, 32 = the build with the rare branches (LLGCBZ0, sea ice, NEMO coupling, IPHYS 0, ISNONLIN, ICODE 1 / 2, LWVFLX_SNL = F).
+// Returns 0 when launched, 1 when the spectral size does not fit the LDS tiling, 2 on a launch error.
+extern "C" int ecwam_v2_implsch(const void* dtab, int dp, int kijs, int kijl, void* fl1, const void* wvprpt, void* ff, void* intf, int* mij,
+                                void* xllws, double* w2n, void* dbg, int nang, int nfre, int variant, void* stream) {
+  const int rc = dp ? launch_implsch<double>(dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, w2n, dbg, nang, nfre, variant, (hipStream_t)stream)
+                    : launch_implsch<float>(dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, w2n, dbg, nang, nfre, variant, (hipStream_t)stream);
+  if (rc) return rc;
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}

@@ -7,6 +7,14 @@ import numpy as np
 from ecwam_amd import synthetic as syn
 from ecwam_amd.tables import Config, Tables
 
+try:      # the second IMPLSCH implementation (k_implsch2, test infrastructure): ctx.set_implsch_generation(2) routes implsch() to it
+    import v2lib as _v2lib
+    import torch as _torch  # noqa: F401  (only where a GPU stack exists)
+
+    _v2lib.install()
+except ImportError:      # CPU-only checks of the harness itself
+    _v2lib = None
+
 FF_OUT = [7, 8, 9, 10, 11, 12]          # UFRIC TAUW TAUWDIR Z0M Z0B CHRNCK
 INTF_OUT = [2, 3, 5, 6, 7, 8, 9, 12, 13, 14]  # USTOKES VSTOKES TAUXD TAUYD TAUOCXD TAUOCYD TAUOC PHIOCD PHIEPS PHIAW
 

@@ -230,6 +230,68 @@ def test_fortran_two_processes_on_one_gpu_match_single_domain(tmp_path, prec, lf
     m.ctx.close()
 
 
+@pytest.mark.parametrize("prec,lf", [("sp", 0), ("dp", 5)])
+def test_fortran_rccl_transport_with_a_self_peer_matches_single_domain(tmp_path, prec, lf):
+    """The RCCL path of the Fortran layer executed on the one GPU there is (mpexchng.F90:164-206 as the library's grouped ncclSend / ncclRecv):
+    ECWAM_HIP_COMM_UNIQUE_ID -> ECWAM_HIP_SET_DECOMPOSITION with the 128-byte id and NO host exchange routine -> ECWAM_HIP_SETUP
+    (ecwam_hip_halo_setup, ecwam_hip_comm_init) -> WAMINTGR_HIP steps whose HIP_HALO_START / HIP_HALO_FINISH post and await the exchange
+    around the interior advection.  One rank that is its own peer: the last rows of the grid are mirrored into halo rows and every
+    neighbour reference to them is redirected to the mirror, so each PROPAGS2 (and each fast-wave sub-step on the compact rows) reads
+    those spectra only through the exchange -- and the result must equal the plain single-domain run bit for bit.  In a child process
+    under a timeout: a transport that hangs fails the test, not the session."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import types
+
+    from ecwam_amd import build, grid as G
+    from ecwam_amd.wamintgr import Wamintgr
+
+    exe = build.fortran_exe(prec)
+    if not os.path.exists(exe):
+        build.build_fortran()
+    cfg = Config(nang=12, nfre=36, nfre_red=25, idelt=900, idelpro=900)
+    g = G.build_grid(16, mask="continents")
+    kw = dict(ifrelfmax=lf, delpro_lf=450.0 if lf else None)
+    nproma, nstep = 24, 2
+    m = Wamintgr(cfg, g, prec, **kw)
+    m.init_synthetic(seed=21)
+    n = g.nsea
+    nh = 57                                         # the mirrored rows: the last 57 sea points (more than one latitude row)
+    src = np.arange(n - nh, n)
+
+    def redirect(a):                                 # single-domain numbering (land = n) -> owned [0, n), mirrors [n, n + nh), land n + nh
+        a = np.asarray(a).astype(np.int64).copy()
+        land, mirrored = a == g.nland, (a >= n - nh) & (a < n)
+        a[mirrored] += nh
+        a[land] = n + nh
+        return a.astype(np.int32)
+
+    klon, klat, kcor = redirect(g.klon), redirect(g.klat), redirect(g.kcor)
+    reads_halo = ((klon >= n) & (klon < n + nh)).reshape(n, -1).any(1) | ((klat >= n) & (klat < n + nh)).reshape(n, -1).any(1) | \
+                 ((kcor >= n) & (kcor < n + nh)).reshape(n, -1).any(1)
+    ib = int(np.flatnonzero(reads_halo).min())
+    assert 0 < ib < n and reads_halo.sum() >= nh
+    cm1 = np.asarray(g.cosphm1_ext)
+    dom = types.SimpleNamespace(n=n, nh=nh, rank=0, nranks=1, lo=0, hi=n, send={0: src.astype(np.int32)}, recv={0: (n, nh)}, kxlt=g.kxlt,
+                                klon=klon, klat=klat, kcor=kcor, cosphm1_ext=np.concatenate([cm1[:n], cm1[src], cm1[n:n + 1]]),
+                                interior=lambda: (0, ib))
+    cg = m.cgroup_ext.cpu().numpy()
+    shim = types.SimpleNamespace(t=m.t, npdt=m.npdt, fl1=m.fl1, wvprpt=m.wvprpt, ff=m.ff, ifrelfmax=m.ifrelfmax, delpro_lf=m.delpro_lf,
+                                 cgroup_ext=torch.from_numpy(np.concatenate([cg[:n], cg[src], cg[n:n + 1]])))
+    case, out = str(tmp_path / "case.bin"), str(tmp_path / "out.bin")
+    nchnk = _write_case(case, shim, cfg, _LocalGrid(g, dom), nproma, nstep, dom=dom)
+    r = subprocess.run([exe, case, out, "run", "rccl"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout
+    for _ in range(nstep):
+        m.step()
+    torch.cuda.synchronize()
+    got = _read_out(out, m.npdt, nproma, nchnk, cfg.nang, cfg.nfre, n)
+    assert np.array_equal(got["FL1"], m.fl1.cpu().numpy()[:n])
+    assert np.array_equal(got["MIJ"], m.mij.cpu().numpy()) and np.array_equal(got["XLLWS"], m.xllws.cpu().numpy())
+    assert np.array_equal(got["FF"], m.ff.cpu().numpy()[:, :14])
+    m.ctx.close()
+
+
 @pytest.mark.parametrize("prec,nemo", [("sp", True), ("dp", True), ("sp", False)])
 def test_fortran_seam_sequence_replays_the_reference_call_lines(tmp_path, prec, nemo):
     """The complete FIELD_API call sequence of the reference's GPU build around the seam (ecwam_amd/fortran/seam_sequence.F90: the lines of

@@ -25,7 +25,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
     for name in declared:
         assert getattr(h, name) is not None
-    assert h.ecwam_hip_abi_version() == int(re.search(r"#define ECWAM_HIP_ABI_VERSION (\d+)", hdr).group(1)) == 4
+    assert h.ecwam_hip_abi_version() == int(re.search(r"#define ECWAM_HIP_ABI_VERSION (\d+)", hdr).group(1)) == 5
     # the parameter struct seen from Python has the size the C compiler gives it
     src = '#include "ecwam_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu", sizeof(ecwam_hip_params), sizeof(ecwam_hip_tables));return 0;}'
     import tempfile
@@ -98,6 +98,19 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".F90")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("test oracle", "").lower() or f in ("lib.py",), (dirpath, f)
+
+
+def test_product_never_touches_the_tests_second_implementation():
+    """k_implsch2 (tests/csrc/implsch_v2.h) left the product in round 5: nothing under ecwam_amd/ includes, builds or loads it, and the
+    product library exports no entry point that selects a kernel generation."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "ecwam_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".F90")):
+                txt = open(os.path.join(dirpath, f)).read()
+                for word in ("v2lib", "libecwam_v2", "k_implsch2<", "launch_implsch<", 'include "implsch_v2.h"', "implsch_wave_v2"):
+                    assert word not in txt, (dirpath, f, word)
+    hdr = open(os.path.join(ROOT, "include", "ecwam_hip.h")).read()
+    assert "int ecwam_hip_set_implsch_generation" not in hdr
 
 
 def test_grid_counts_and_neighbours():

@@ -152,6 +152,8 @@ def main() -> None:
     ap.add_argument("--nang", type=int, default=36)
     ap.add_argument("--nfre", type=int, default=36)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc-file", default="", help="counter summary of tools/pmc_bench.py to attach to the roofline object (HBM traffic, VALU / LDS busy "
+                    "fractions); refused when its workload or kernel is not this run's.  Default: profiles/r05_bench_O320_sp_pmc.json where it matches")
     ap.add_argument("--weights", default="otf", choices=["otf", "stored"],
                     help="CTU weights rebuilt inside PROPAGS2 (default) or streamed from the stored W array")
     ap.add_argument("--strip", type=int, default=0, help="longitude-strip width of the advection work order (0: natural order)")
@@ -353,48 +355,55 @@ def main() -> None:
             "implsch": {"ms": t_impl, "alg_bytes": b_impl * m.n, "gbs": b_impl * m.n / t_impl / 1e6},
         }
         dom = max(kern, key=lambda k: kern[k]["ms"])
-        # Figures below tagged "source: committed_pmc" are NOT measured in this run: they come from the committed rocprofv3 PMC
-        # summaries under profiles/ (tools/pmc_traffic.sh, tools/pmc_implsch_sets.sh) and are only attached to the workload they were
-        # taken on (default O320 / 36x36 / sp / on-the-fly weights, one GPU).  FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is
-        # doubled as MI355X_MICROARCH.md prescribes for gfx950 (calibrated on a 16 B/lane copy: profiles/r02_fetch_size_calibration.json).
-        prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        default_wl = world == 1 and ng == 320 and a.prec == "sp" and a.nang == 36 and a.nfre == 36 and a.weights == "otf" and not a.irefra
-        traffic = None
-        tf = os.path.join(prof, "r04_hbm_traffic_pmc.json")
-        if default_wl and os.path.exists(tf):
-            with open(tf) as fh:
-                pm = json.load(fh).get(dom, {})
-            if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
-                traffic = 1024.0 * (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"])
-        # IMPLSCH is bound by instruction issue and LDS latency at two waves per SIMD, not by HBM or MFMA (SURVEY.md 8d asks for
-        # this figure next to the HBM fraction).  Issue ceiling: 1024 SIMDs x clock / (VALU instructions per point x cycles per
-        # instruction), 2.6 cycles per wave64 VALU instruction with >= 2 waves per SIMD as measured by tools/ubench_valu.hip
-        # (profiles/r02_ubench_valu.txt; the guide's figure is 2, a wave alone issues one per 5.3 cycles).  The counters of the kernel
-        # itself say 4.2 cycles of VALU activity per instruction (its mix is two thirds packed fp32 at 4.4 cycles): the VALU of a SIMD is
-        # busy 74 % of the time, which is the headroom that is left -- valu_busy_fraction_pmc is the figure to read.
-        valu = None
-        pf = os.path.join(prof, "r04_implsch_pmc.json")
-        if default_wl and os.path.exists(pf):
-            with open(pf) as fh:
-                pm = json.load(fh)
-            ceil_pts = 256 * 4 * 2.4e9 / (2.6 * pm["SQ_INSTS_VALU"])
-            valu = {"kernel": "implsch", "source": "committed_pmc", "file": "profiles/r04_implsch_pmc.json",
-                    "valu_busy_fraction_pmc": pm["valu_busy_fraction"], "valu_insts_per_point": pm["SQ_INSTS_VALU"],
-                    "cycles_per_valu_inst_assumed": 2.6, "issue_ceiling_points_per_s": ceil_pts,
-                    "achieved_points_per_s": m.n / (t_impl * 1e-3), "frac_of_issue_ceiling": m.n / (t_impl * 1e-3) / ceil_pts}
+        # HBM traffic and the busy fractions of the vector ALU and the LDS are NOT measured in this run: they come from a counter summary
+        # tools/pmc_bench.py took with rocprofv3 --pmc on this very command (profiles/r05_bench_O320_sp_pmc.json: separate passes for the SQ
+        # sets, FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, calibrated on a copy in
+        # profiles/r02_fetch_size_calibration.json).  The summary is attached only when it describes THIS workload and THIS kernel: its workload
+        # string and dtype must equal the run's and its kernel must be the instantiation the run launches; a file given with --pmc-file that
+        # does not match is refused.
+        workload = (f"O{ng} all-ocean octahedral grid, {grid.nsea} sea points, {a.nang} dir x {a.nfre} freq "
+                    f"(NFRE_RED={cfg.nfre_red}), full WAMINTGR step = PROPAGS2 advection + NEWWIND + IMPLSCH, "
+                    f"IDELT=IDELPRO={dt} s, flag set A (IPHYS=1, ISNONLIN=0, LLGCBZ0=F, LLNORMAGAM=F)"
+                    + (f", IREFRA={a.irefra} (synthetic currents)" if a.irefra else "")
+                    + (f", {a.adv_per_source} advection steps per source step" if a.adv_per_source != 1 else "")
+                    + (f", fast waves M<={a.ifrelfmax} in two sub-steps" if a.ifrelfmax else ""))
+        dtype = "f32" if a.prec == "sp" else "f64"
+        pmc_path = a.pmc_file or os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_bench_O320_sp_pmc.json")
+        pmc, pmc_why = None, None
+        if os.path.exists(pmc_path) and world == 1:
+            with open(pmc_path) as fh:
+                cand = json.load(fh)
+            kname = (cand.get("kernels", {}).get(dom, {}) or {}).get("name") or ""
+            want_k = {"implsch": f"k_implsch4<{'float' if a.prec == 'sp' else 'double'}, {a.nang}, ", "propags2": "k_propags2"}[dom]
+            if cand.get("workload", {}).get("workload") != workload or cand.get("workload", {}).get("dtype") != dtype:
+                pmc_why = "the summary was taken on another workload: " + str(cand.get("workload", {}).get("workload"))
+            elif want_k not in kname:
+                pmc_why = f"the summary's kernel is {kname!r}, this run launches {want_k}...>"
+            else:
+                pmc = cand["kernels"][dom]
+        elif a.pmc_file:
+            pmc_why = "no such file" if not os.path.exists(pmc_path) else "counter summaries describe one GPU"
+        if a.pmc_file and pmc is None:
+            raise SystemExit(f"bench.py: --pmc-file {a.pmc_file} refused: {pmc_why}")
+        roof = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["gbs"] / HBM_PEAK_GBS,
+                "traffic": None, "valu_busy": None, "lds_busy": None, "counters": None}
+        if pmc is not None:
+            # one story: the fraction of the HBM roofline on algorithmic bytes (the contract's figure), the bytes the kernel really moved,
+            # and what its own counters say limits it -- the busy fractions of a SIMD's vector ALU and of the CU's LDS array at the resident
+            # wave count (IMPLSCH: two waves per SIMD in single precision)
+            roof.update({"traffic": pmc.get("hbm_bytes"), "valu_busy": pmc.get("valu_busy"), "lds_busy": pmc.get("lds_busy"),
+                         "limiter": "vector ALU + LDS at the resident wave count, not HBM" if dom == "implsch" else "gather latency / instruction issue",
+                         "counters": {"file": os.path.relpath(pmc_path, os.path.dirname(os.path.abspath(__file__))), "kernel": pmc.get("name"),
+                                      "not_measured_live": True, "valu_insts_per_point": pmc.get("per_point", {}).get("SQ_INSTS_VALU"),
+                                      "waitcnt_fraction": pmc.get("waitcnt_fraction"), "lds_bank_conflict_share": pmc.get("lds_bank_conflict_share")}})
         out = {
             "metric": f"grid-point spectral steps/sec (whole node) at O{ng}, {a.nang}dir x {a.nfre}freq",
             "value": grid.nsea * a.steps / el, "unit": "grid-point spectral steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "repeats": a.repeats, "window_ms": {"median": el * 1e3, "min": min(windows) * 1e3, "max": max(windows) * 1e3,
                                                 "all": [w_ * 1e3 for w_ in windows]},
-            "vs_baseline": None, "dtype": "f32" if a.prec == "sp" else "f64", "data": "synthetic",
-            "config": {"workload": f"O{ng} all-ocean octahedral grid, {grid.nsea} sea points, {a.nang} dir x {a.nfre} freq "
-                                   f"(NFRE_RED={cfg.nfre_red}), full WAMINTGR step = PROPAGS2 advection + NEWWIND + IMPLSCH, "
-                                   f"IDELT=IDELPRO={dt} s, flag set A (IPHYS=1, ISNONLIN=0, LLGCBZ0=F, LLNORMAGAM=F)"
-                                   + (f", IREFRA={a.irefra} (synthetic currents)" if a.irefra else "")
-                                   + (f", {a.adv_per_source} advection steps per source step" if a.adv_per_source != 1 else "")
-                                   + (f", fast waves M<={a.ifrelfmax} in two sub-steps" if a.ifrelfmax else ""),
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": workload,
                        "points_per_gpu": m.n, "halo_points": m.dom.nh, "parallelism": f"sea-point block x{world}",
                        "halo": halo_used if world > 1 else None, "halo_rccl_ranks": halo_ranks,
                        "strict_halo": bool(a.strict_halo) if world > 1 else None,
@@ -410,11 +419,8 @@ def main() -> None:
             # is what the overlap did not hide
             "propag_split_per_rank": ([{"rank": i, "propag_ms": r_[0], "implsch_ms": r_[1], "halo_wait_ms": r_[2], "stencil_ms": r_[0] - r_[2]}
                                        for i, r_ in enumerate(per_rank)] if per_rank else None),
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "committed_pmc: profiles/r04_hbm_traffic_pmc.json (rocprofv3 --pmc passes of this command on another run; not measured live)" if traffic is not None else None},
+            "roofline": roof,
             "kernels": kern,
-            "valu": valu,
             "finite": finite,
             "swh_norm_rank0": {"avg": swh_avg, "min": swh_min, "max": swh_max},
         }

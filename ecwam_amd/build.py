@@ -44,10 +44,12 @@ VARIANTS = {"": FAST_DIV, "exactdiv": ["-DECWAM_HIP_STRICT=0"], "strict1": ["-DE
             "rdp": FAST_DIV + ["-O3"], "rdpO1": FAST_DIV + ["-O1"], "rdpchk": FAST_DIV + ["-O3", "-DV4_CHECK=1"],
             "rdps": FAST_DIV + ["-O3", "-DV4R_DP=2"],
             # every build of k_implsch4 as the two-kernel split (PART 1: through the second SINFLX call | PART 2: sweep, fluxes, tail, stores)
-            "split": FAST_DIV + ["-DV4_SPLIT_ALL=1", "-DV4R_DP=2"]}
+            "split": FAST_DIV + ["-DV4_SPLIT_ALL=1", "-DV4R_DP=2"],
+            # the common builds at -O2 (one-line experiment of round 5: same time as -O3, profiles/r05_implsch_split_experiment.txt)
+            "o2": FAST_DIV + ["-O2"]}
 # variants that rebuild only some of the IMPLSCH translation units (the other objects are the product's)
 VARIANT_SOURCES = {"rdp": ("implsch4rd.hip",), "rdpO1": ("implsch4rd.hip",), "rdpchk": ("implsch4rd.hip",), "rdps": ("implsch4rd.hip",),
-                   "split": ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip")}
+                   "split": ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip"), "o2": ("implsch4.hip",)}
 
 INCLUDE = os.path.join(HERE, "..", "include", "ecwam_hip.h")
 

@@ -252,7 +252,22 @@ def main():
             "  SUBROUTINE ECWAM_HIP_BIND_FORCING(FF_NOW, FF_NEXT)",
             "    TYPE(FORCING_FIELDS), INTENT(IN) :: FF_NOW, FF_NEXT",
             "    IF (.NOT. ASSOCIATED(FF_NOW%HIP) .OR. .NOT. ASSOCIATED(FF_NEXT%HIP)) CALL HIP_FATAL('FORCING_FIELDS: ALLOC has not been called on this object')",
-            "    FF_NOW%HIP%ROLE = 1; FF_NEXT%HIP%ROLE = 2",
+            "    CALL REBIND(FF_NOW%HIP, 1); CALL REBIND(FF_NEXT%HIP, 2)",
+            "  CONTAINS",
+            "    ! An object that changes its role (the host swapped FF_NOW and FF_NEXT, or passes another object): the status of its members",
+            "    ! describes the rows of the OLD role.  A member whose only valid copy is on the device under the old role cannot be carried over",
+            "    ! (the rows now belong to the other object): the host has to GET_HOST_DATA_* it first.  Otherwise the host copies are the valid",
+            "    ! ones and the next device access uploads them into the rows of the new role.",
+            "    SUBROUTINE REBIND(H, IROLE)",
+            "      TYPE(HIP_FIELD_STATE), INTENT(INOUT) :: H",
+            "      INTEGER, INTENT(IN) :: IROLE",
+            "      IF (H%ROLE /= 0 .AND. H%ROLE /= IROLE) THEN",
+            "        IF (ANY(IAND(H%ST, HIP_HOST_FRESH) == 0)) CALL HIP_FATAL('FORCING_FIELDS: the object changes its role (FF_NOW <-> FF_NEXT) while ' // &",
+            "   &      'members are valid on the device only: call GET_HOST_DATA_* on it before WAMINTGR_HIP')",
+            "        H%ST(:) = HIP_HOST_FRESH",
+            "      ENDIF",
+            "      H%ROLE = IROLE",
+            "    END SUBROUTINE REBIND",
             "  END SUBROUTINE ECWAM_HIP_BIND_FORCING", ""]
     for name, (rank, mem) in TYPES.items():
         out += gen_procs(name, rank, mem)

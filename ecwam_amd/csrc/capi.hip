@@ -197,6 +197,25 @@ static int build_tab(const ecwam_hip_params* p, const ecwam_hip_tables* t, DevTa
     for (int j = 0; j < 5; j++) d->INLCOEF[i][j] = t->inlcoef[i * 5 + j] - 1;
     for (int j = 0; j < 25; j++) d->RNLCOEF[i][j] = ((const T*)t->rnlcoef)[i * 25 + j];
   }
+  {
+    // separable form of the interaction coefficients: CL11 + ACL1 = 1 and CL21 + ACL2 = 1 (nlweigt.F90:166-169), so the frequency factor of a
+    // coefficient pair is its sum and the angular weights are the ratios, taken where the factors are largest
+    double cl11 = 1.0, acl1 = 0.0, cl21 = 1.0, acl2 = 0.0, bp = 0.0, bm = 0.0;
+    for (int i = 0; i < ML; i++) {
+      const double pa = (double)d->RNLCOEF[i][5], pb = (double)d->RNLCOEF[i][6], ma = (double)d->RNLCOEF[i][17], mb = (double)d->RNLCOEF[i][18];
+      if (fabs(pa + pb) > bp) { bp = fabs(pa + pb); cl11 = pa / (pa + pb); acl1 = pb / (pa + pb); }
+      if (fabs(ma + mb) > bm) { bm = fabs(ma + mb); cl21 = ma / (ma + mb); acl2 = mb / (ma + mb); }
+    }
+    const double ang[8] = {cl11, acl1, cl21, acl2, cl11 * cl11, acl1 * acl1, cl21 * cl21, acl2 * acl2};
+    for (int j = 0; j < 8; j++) d->DIAANG[j] = (T)ang[j];
+    for (int i = 0; i < ML; i++) {
+      const T* R = d->RNLCOEF[i];
+      const double gp = (double)R[1] + R[2], gp1 = (double)R[3] + R[4], gm = (double)R[13] + R[14], gm1 = (double)R[15] + R[16];
+      const double fp = (double)R[5] + R[6], fp1 = (double)R[8] + R[7], fm = (double)R[17] + R[18], fm1 = (double)R[20] + R[19];
+      const double w[12] = {gp, gp1, gm, gm1, fp, fp1, fp * fp, fp1 * fp1, fm, fm1, fm * fm, fm1 * fm1};
+      for (int j = 0; j < 12; j++) d->DIAW[i][j] = (T)w[j];
+    }
+  }
   d->V4_ROWS = 1;
   for (int i = 0; i < ML; i++) {
     // gather set (words 0..11): FTAIL, GW1..GW8, AF11; scatter set (words 12..27): FKLAMPA .. FKLAP22, FKLAMMA .. FKLAM22

@@ -202,6 +202,25 @@ __device__ __forceinline__ V2<T> v4_at(const T* row, const int (&sh)[2 * NSH + 1
   }
 }
 
+// ca X(ra) + cb X(rb) for two ADJACENT rotations (|ra - rb| = 1) of an LDS row, X(r) = the pair (X(2j+r), X(2j+r+1)): the three elements
+// involved lie in the two ALIGNED pairs at the even shifts e and e + 2, e = 2 floor(min(ra, rb) / 2) -- two ds_read_b64 (one, where a shift is
+// zero: `own` is the lane's pair of that row, already in registers) and four plain multiply-adds on the halves.  Round 5: the DIA's angular
+// interpolation weights are the same for every interaction (inisnonlin.F90:186-241), so a gather / scatter pair of an interaction is ONE
+// such window of ONE staged row instead of an odd rotation (two 4-byte reads, two-way bank conflicts by construction) plus an even one of
+// two rows: 28 % fewer LDS instructions in the sweep, which profiles/r05_bench_O320_sp_split_pmc.json shows to be bound by the LDS
+// array (88 % busy, vector ALU 55 %).
+template <typename T, int NSH, int ra, int rb>
+__device__ __forceinline__ V2<T> v4_win(const T* row, const int (&sh)[2 * NSH + 1], V2<T> own, T ca, T cb) {
+  static_assert(ra - rb == 1 || rb - ra == 1, "adjacent rotations");
+  constexpr int lo = ra < rb ? ra : rb;
+  constexpr int e = (lo >= 0) ? (lo / 2) * 2 : -(((-lo) + 1) / 2) * 2;      // 2 floor(lo / 2)
+  static_assert(e / 2 + NSH >= 0 && e / 2 + 1 + NSH <= 2 * NSH, "shift table");
+  const V2<T> a = (e == 0) ? own : *reinterpret_cast<const V2<T>*>(row + sh[e / 2 + NSH]);
+  const V2<T> b = (e + 2 == 0) ? own : *reinterpret_cast<const V2<T>*>(row + sh[e / 2 + 1 + NSH]);
+  const T el[4] = {a.x, a.y, b.x, b.y};      // elements e .. e + 3
+  return V2<T>{ca * el[ra - e] + cb * el[rb - e], ca * el[ra - e + 1] + cb * el[rb - e + 1]};
+}
+
 template <typename T, int PP, bool RARE>
 __device__ __forceinline__ void v4_stresso(const DevTab<T>& tb, T* sSC, int lane, bool LLPHIWA) {
   if constexpr (PP <= 3) {
@@ -832,14 +851,24 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   if (ij0 >= kijl) return;
   const int n = kijl - ij0 < PP ? kijl - ij0 : PP;   // points of this wave; a short last wave replicates its last point
   const int ij = ij0 + (p < n ? p : n - 1);
-  L.tile = sT; L.own = p * NANG + 2 * j;
+  // Position of direction k of point q inside a row of PP NANG elements: q NANG + k.  (V4_ROWSPLIT = 1, build variant "rowsplit": the round-5
+  // experiment that puts the first 32 directions of the three points at 0, 32, 64 and their last four at 96, 100, 104 so that a half-wave's
+  // own pairs land on 64 different 4-byte banks -- measured: MORE conflict cycles (2 482 against 2 177 per point) and 1 % more time,
+  // profiles/r05_lds_row_layout.txt; the bank model of MI355X_MICROARCH.md does not describe what the 4-byte accesses of the odd rotations
+  // and of the transposing load / store do.)
+#ifndef V4_ROWSPLIT
+#define V4_ROWSPLIT 0
+#endif
+  constexpr bool RSPLIT = (V4_ROWSPLIT != 0) && NANG == 36 && PP == 3;
+  auto rowpos = [&](int q, int k) -> int { return RSPLIT ? (k < 32 ? 32 * q + k : 96 + 4 * q + (k - 32)) : q * NANG + k; };
+  L.tile = sT; L.own = rowpos(p, 2 * j);
   L.fac4 = sFac4 + p * NFRE * 4; L.sq = sPl + p * NFRE; L.zcn = sPl + PLN + p * NFRE; L.c = sSC + p * NSC;
   int sh[2 * NSH + 1];
 #pragma unroll
   for (int i = 0; i <= 2 * NSH; i++) {
     int k = 2 * j + 2 * (i - NSH);
     k = k < 0 ? k + NANG : (k >= NANG ? k - NANG : k);
-    sh[i] = p * NANG + k;
+    sh[i] = rowpos(p, k);
   }
   if constexpr (G == 18) {
     const bool low = lane < 48 && j < 2;
@@ -995,11 +1024,12 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     for (int it = 0; it < NITL; it++) {
       const int w = lane + 64 * it;
       if (w < NVL) {
-        T* d = sT + (r * VEC) * RS + k;
+        T* d = sT + (r * VEC) * RS + rowpos(0, k);
+        const int qo = RSPLIT ? (k < 32 ? 32 : 4) : NANG;      // distance of the next point's direction k
 #pragma unroll
         for (int q = 0; q < PP; q++)
 #pragma unroll
-          for (int i = 0; i < VEC; i++) d[i * RS + q * NANG] = val[q][it][i];
+          for (int i = 0; i < VEC; i++) d[i * RS + q * qo] = val[q][it][i];
       }
       k += 64 / NC; r += 64 % NC;
       if (r >= NC) { r -= NC; k += 1; }
@@ -1476,6 +1506,12 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       }
     };
     const T DAL1 = tb.DAL1, DAL2 = tb.DAL2;
+#ifndef V4_DIAWIN
+#define V4_DIAWIN 1
+#endif
+    constexpr bool WIN = (V4_DIAWIN != 0);      // the separable window form of the DIA gathers / scatters (v4_win)
+    const T CL11 = tb.DIAANG[0], ACL1 = tb.DIAANG[1], CL21 = tb.DIAANG[2], ACL2 = tb.DIAANG[3];
+    const T CL11Q = tb.DIAANG[4], ACL1Q = tb.DIAANG[5], CL21Q = tb.DIAANG[6], ACL2Q = tb.DIAANG[7];
     T wt[NH + 1];   // SATWEIGHTS depend on the tap only and are symmetric (checked by ecwam_hip_create): wave-uniform, taps -NH .. 0
 #pragma unroll
     for (int t = 0; t <= NH; t++) wt[t] = tb.SATWEIGHTS[t][NANG / 2];
@@ -1635,6 +1671,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         const T* cg = tb.DIACF[MC - 1];
         const T* cs = cg + 12;
         const T GW1 = cg[1], GW2 = cg[2], GW3 = cg[3], GW4 = cg[4], GW5 = cg[5], GW6 = cg[6], GW7 = cg[7], GW8 = cg[8];
+        const T* cw = tb.DIAW[MC - 1];      // the separable form (WIN): frequency factors of the gathers and of the scatter
         const T FTEMP = cg[9] * enh_of(MC <= MLST ? MC : MLST);
         const T FKLAMPA = cs[0], FKLAMPB = cs[1], FKLAMP2 = cs[2], FKLAMP1 = cs[3];
         const T FKLAPA2 = cs[4], FKLAPB2 = cs[5], FKLAP12 = cs[6], FKLAP22 = cs[7];
@@ -1660,17 +1697,29 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         //      the saturation spectrum of row MC-4 (SATWEIGHTS symmetric about the centre tap) and the first exchange of its maximum
         const V2<T> FIJ = fIC * FTAIL;
         const V2<T> fIP1 = fR[(jj + 3) & 7];
+        V2<T> SAPk[2], SAMk[2];
+        if constexpr (WIN) {
+          // W+ = GP F(:,IP) + GP1 F(:,IP1), W- = GM F(:,IM) + GM1 F(:,IM1): two staged rows; SAP = CL11 W+(K1) + ACL1 W+(K11), SAM likewise
+          const V2<T> wp = cw[0] * fIP + cw[1] * fIP1, wm = cw[2] * fIM + cw[3] * fIM1;
+          *reinterpret_cast<V2<T>*>(st0 + L.own) = wp; *reinterpret_cast<V2<T>*>(st2 + L.own) = wm;
+          V4SYNC();
+          // kh = 1: K1 = K - R1, K11 = K - R1 - 1, K2 = K + R2, K21 = K + R2 + 1; kh = 2 mirrored
+          SAPk[0] = v4_win<T, NSH, -R1, -(R1 + 1)>(st0, sh, wp, CL11, ACL1);
+          SAMk[0] = v4_win<T, NSH, R2, R2 + 1>(st2, sh, wm, CL21, ACL2);
+          SAPk[1] = v4_win<T, NSH, R1, R1 + 1>(st0, sh, wp, CL11, ACL1);
+          SAMk[1] = v4_win<T, NSH, -R2, -(R2 + 1)>(st2, sh, wm, CL21, ACL2);
+        } else {
         const V2<T> up = GW1 * fIP + GW3 * fIP1, vp = GW2 * fIP + GW4 * fIP1;
         const V2<T> um = GW5 * fIM + GW7 * fIM1, vm = GW6 * fIM + GW8 * fIM1;
         *reinterpret_cast<V2<T>*>(st0 + L.own) = up; *reinterpret_cast<V2<T>*>(st1 + L.own) = vp;
         *reinterpret_cast<V2<T>*>(st2 + L.own) = um; *reinterpret_cast<V2<T>*>(st3 + L.own) = vm;
         V4SYNC();
         // kh = 1: K1 = K - R1, K11 = K - R1 - 1, K2 = K + R2, K21 = K + R2 + 1; kh = 2 mirrored
-        V2<T> SAPk[2], SAMk[2];
         SAPk[0] = (R1 == 0 ? up : v4_at<T, NSH, -R1>(st0, sh)) + v4_at<T, NSH, -(R1 + 1)>(st1, sh);
         SAMk[0] = v4_at<T, NSH, R2>(st2, sh) + v4_at<T, NSH, R2 + 1>(st3, sh);
         SAPk[1] = (R1 == 0 ? up : v4_at<T, NSH, R1>(st0, sh)) + v4_at<T, NSH, R1 + 1>(st1, sh);
         SAMk[1] = v4_at<T, NSH, -R2>(st2, sh) + v4_at<T, NSH, -(R2 + 1)>(st3, sh);
+        }
         V2<T> bsat = z2;
         T bm1 = T(0), e0 = T(0);
         if constexpr (!JAN) {
@@ -1714,19 +1763,29 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
             *reinterpret_cast<V2<T>*>(sp + L.own) = DELAP;
             V4SYNC();
             if (kh == 0) {
+              if constexpr (WIN) {      // the angular interpolation of the scatter: one window per (quantity, leg)
+                A2[0] = v4_win<T, NSH, -R2, -(R2 + 1)>(sa, sh, AD, CL21, ACL2); A1[0] = v4_win<T, NSH, R1, R1 + 1>(sa, sh, AD, CL11, ACL1);
+                D2[0] = v4_win<T, NSH, -R2, -(R2 + 1)>(sm, sh, DELAM, CL21Q, ACL2Q); P1[0] = v4_win<T, NSH, R1, R1 + 1>(sp, sh, DELAP, CL11Q, ACL1Q);
+              } else {
               A2[0] = v4_at<T, NSH, -R2>(sa, sh); A2s[0] = v4_at<T, NSH, -(R2 + 1)>(sa, sh);
               A1[0] = (R1 == 0) ? AD : v4_at<T, NSH, R1>(sa, sh); A1s[0] = v4_at<T, NSH, R1 + 1>(sa, sh);
               D2[0] = v4_at<T, NSH, -R2>(sm, sh); D2s[0] = v4_at<T, NSH, -(R2 + 1)>(sm, sh);
               P1[0] = (R1 == 0) ? DELAP : v4_at<T, NSH, R1>(sp, sh); P1s[0] = v4_at<T, NSH, R1 + 1>(sp, sh);
+              }
               if constexpr (G != 18 && !JAN) {
                 bm1 = m_max(bm1, e0);
                 if (G >= 12) e1 = v4_bp(L.rot.a1, bm1);
               }
             } else {
+              if constexpr (WIN) {
+                A2[1] = v4_win<T, NSH, R2, R2 + 1>(sa, sh, AD, CL21, ACL2); A1[1] = v4_win<T, NSH, -R1, -(R1 + 1)>(sa, sh, AD, CL11, ACL1);
+                D2[1] = v4_win<T, NSH, R2, R2 + 1>(sm, sh, DELAM, CL21Q, ACL2Q); P1[1] = v4_win<T, NSH, -R1, -(R1 + 1)>(sp, sh, DELAP, CL11Q, ACL1Q);
+              } else {
               A2[1] = v4_at<T, NSH, R2>(sa, sh); A2s[1] = v4_at<T, NSH, R2 + 1>(sa, sh);
               A1[1] = (R1 == 0) ? AD : v4_at<T, NSH, -R1>(sa, sh); A1s[1] = v4_at<T, NSH, -(R1 + 1)>(sa, sh);
               D2[1] = v4_at<T, NSH, R2>(sm, sh); D2s[1] = v4_at<T, NSH, R2 + 1>(sm, sh);
               P1[1] = (R1 == 0) ? DELAP : v4_at<T, NSH, -R1>(sp, sh); P1s[1] = v4_at<T, NSH, -(R1 + 1)>(sp, sh);
+              }
               if constexpr (JAN) {
               } else if constexpr (G == 18) {   // extras folded in, row maximum (no LDS), back to the extras: read by the next interaction
                 bm1 = v4_rowmax<T>(m_max(bm1, e0));
@@ -1743,10 +1802,18 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
             // the two mirror images carry the same coefficients: their products are added first, then one fused multiply-add per
             // coefficient (the reference adds the terms of KH = 1 and KH = 2 one after the other: the same sum in another order)
             const V2<T> ADt = ADk[0] + ADk[1], DELADt = DELADk[0] + DELADk[1];
-            const V2<T> A2t = A2[0] + A2[1], A2st = A2s[0] + A2s[1], A1t = A1[0] + A1[1], A1st = A1s[0] + A1s[1];
-            const V2<T> D2t = D2[0] + D2[1], D2st = D2s[0] + D2s[1], P1t = P1[0] + P1[1], P1st = P1s[0] + P1s[1];
             aS[c0] -= T(2) * ADt;
             aF[c0] -= (T(2) * FTEMP) * DELADt;
+            if constexpr (WIN) {
+              // the interpolated increments of the two mirror images, one fused multiply-add per target row with the frequency factor
+              const V2<T> A2t = A2[0] + A2[1], A1t = A1[0] + A1[1], D2t = D2[0] + D2[1], P1t = P1[0] + P1[1];
+              aS[cm] += A2t * cw[9]; aF[cm] += D2t * cw[11];        // FKLAMM1, its square
+              aS[cm1] += A2t * cw[8]; aF[cm1] += D2t * cw[10];      // FKLAMM, its square
+              aS[cp] += A1t * cw[5]; aF[cp] += P1t * cw[7];         // FKLAMP1, its square
+              aS[cp1] = A1t * cw[4]; aF[cp1] = P1t * cw[6];         // FKLAMP, its square: the first contribution to the row that entered the ring
+            } else {
+            const V2<T> A2t = A2[0] + A2[1], A2st = A2s[0] + A2s[1], A1t = A1[0] + A1[1], A1st = A1s[0] + A1s[1];
+            const V2<T> D2t = D2[0] + D2[1], D2st = D2s[0] + D2s[1], P1t = P1[0] + P1[1], P1st = P1s[0] + P1s[1];
             aS[cm] += A2t * FKLAMM1; aS[cm] += A2st * FKLAMM2;
             aF[cm] += D2t * FKLAM12; aF[cm] += D2st * FKLAM22;
             aS[cm1] += A2t * FKLAMMA; aS[cm1] += A2st * FKLAMMB;
@@ -1757,6 +1824,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
             aS[cp1] = A1t * FKLAMPA; aF[cp1] = P1t * FKLAPA2;
             aS[cp1] += A1st * FKLAMPB;
             aF[cp1] += P1st * FKLAPB2;
+            }
           }
         }
         // ---- row MC-3 (the saturation row of the next interaction) -> its staging row; row MC+3 enters the ring in the slot of row MC-5
@@ -1895,13 +1963,14 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     for (int it = 0; it < NIT; it++) {
       const int w = lane + 64 * it;
       if (w < NV) {
-        const T* d = sT + (r * VEC) * RS + k;
+        const T* d = sT + (r * VEC) * RS + rowpos(0, k);
+        const int qo = RSPLIT ? (k < 32 ? 32 : 4) : NANG;
 #pragma unroll
         for (int q = 0; q < PP; q++) {
           if (q < n) {
             VT val;
 #pragma unroll
-            for (int i = 0; i < VEC; i++) val[i] = d[i * RS + q * NANG];
+            for (int i = 0; i < VEC; i++) val[i] = d[i * RS + q * qo];
             *reinterpret_cast<VT*>(fl1 + (size_t)(ij0 + q) * N + (size_t)w * VEC) = val;
             if (gfast && r * VEC < gk) *reinterpret_cast<VT*>(gfast + ((size_t)(ij0 + q) * NANG + k) * gk + r * VEC) = val;
           }

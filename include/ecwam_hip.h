@@ -286,7 +286,7 @@ int ecwam_hip_implsch_generation_used(ecwam_hip_ctx *ctx);
 const void *ecwam_hip_device_tables(ecwam_hip_ctx *ctx);
 /*
  * k_implsch4 is bracketed by two one-point-per-lane kernels (first TAUT_Z0 before, second STRESSO and WNFLUXES after it) that exchange
- * 24 scalars per sea point through a context-owned device buffer indexed by the point number.  ecwam_hip_implsch grows that buffer when
+ * 36 scalars per sea point through a context-owned device buffer indexed by the point number.  ecwam_hip_implsch grows that buffer when
  * kijl exceeds what it holds -- a device allocation and a device-wide wait inside an otherwise stream-ordered call.  A host that wants
  * none of that in its time loop (or captures the step into a hipGraph) sizes it once: npts = the largest kijl it will pass.  Calls on
  * several streams may share the buffer as long as their [kijs,kijl) do not overlap.

@@ -36,6 +36,7 @@ if r.returncode != 0 or not line:
     sys.exit("bench.py failed: " + r.stderr[-500:])
 bj = json.loads(line[-1])
 npts = bj["config"]["points_per_gpu"]
+split_build = "split" in os.path.basename(os.environ.get("ECWAM_HIP_LIB", ""))
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(set)
 names = {}
@@ -53,8 +54,12 @@ for tag, counters in SETS.items():
         k = "implsch" if "implsch" in n else ("propags2" if "propags2" in n else None)
         if not k:
             continue
-        agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         main = not ("implsch4_pre" in n or "implsch4_fin" in n)
+        if k == "implsch" and split_build:      # the two-kernel split: one entry per part, the two scalar kernels on their own
+            part = n.split(">(")[0].split(",")[-1].strip()
+            k = f"implsch_part{part}" if main else "implsch_scalar_kernels"
+            main = True
+        agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         if main:
             seen[k].add(row["Dispatch_Id"])
             names.setdefault(k, n.split("(")[0].replace("void ", ""))
@@ -75,7 +80,7 @@ for k in agg:
     if "FETCH_SIZE" in per_launch and "WRITE_SIZE" in per_launch:
         e["hbm_bytes"] = 1024.0 * (2.0 * per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"])
         e["hbm_read_bytes"], e["hbm_write_bytes"] = 2048.0 * per_launch["FETCH_SIZE"], 1024.0 * per_launch["WRITE_SIZE"]
-    if k == "implsch" and "SQ_WAVE_CYCLES" in pp:
+    if k.startswith("implsch") and k != "implsch_scalar_kernels" and "SQ_WAVE_CYCLES" in pp:
         wps = 2.0 if bj["dtype"] == "f32" else 1.0      # resident waves per SIMD of k_implsch4 (LDS: 8 / 4 waves per CU)
         e["resident_waves_per_simd"] = wps
         e["valu_busy"] = pp["SQ_ACTIVE_INST_VALU"] / (pp["SQ_WAVE_CYCLES"] / wps)

@@ -215,6 +215,8 @@ static int build_tab(const ecwam_hip_params* p, const ecwam_hip_tables* t, DevTa
       const double w[12] = {gp, gp1, gm, gm1, fp, fp1, fp * fp, fp1 * fp1, fm, fm1, fm * fm, fm1 * fm1};
       for (int j = 0; j < 12; j++) d->DIAW[i][j] = (T)w[j];
     }
+    for (int i = 0; i < ML; i++)
+      for (int j = 0; j < 4; j++) d->DIAW[i][12 + j] = (i + 1 < ML) ? d->DIAW[i + 1][j] : T(0);
   }
   d->V4_ROWS = 1;
   for (int i = 0; i < ML; i++) {

@@ -66,8 +66,9 @@ struct DevTab {
   // the same interaction coefficients in separable form (inisnonlin.F90:186-241: every GW / FKLAM* coefficient is a frequency factor times
   // one of the two angular interpolation weights CL11 | ACL1 (+ leg) or CL21 | ACL2 (- leg)): per MC the frequency factors
   // [0..3] GP, GP1, GM, GM1 (SAP = CL11 W(K1) + ACL1 W(K11), W = GP F(:,IP) + GP1 F(:,IP1); SAM likewise), [4..7] FKLAMP, FKLAMP1, their squares,
-  // [8..11] FKLAMM, FKLAMM1, their squares; DIAANG = CL11, ACL1, CL21, ACL2 and their squares
-  alignas(16) T DIAW[MAXMC][12];
+  // [8..11] FKLAMM, FKLAMM1, their squares; [12..15] GP, GP1, GM, GM1 of the NEXT interaction (the sweep stages the rows of interaction
+  // MC + 1 at the end of interaction MC); DIAANG = CL11, ACL1, CL21, ACL2 and their squares
+  alignas(16) T DIAW[MAXMC][16];
   T DIAANG[8];
   // word 31: FTAIL as the sweep applies it (1 between MFR1STFR and MFRLSTFR); words 10, 11, 28..30 of the record of interaction MC: ZPIFR of the (clamped) row MC-3 and COFRM4, FLMAX, RHOWG_DFIM, ZPIFR of row
   // MC-5, which that interaction updates -- the record is one scalar load, a lane table costs a v_readlane per value

@@ -1628,6 +1628,16 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       wslot = *reinterpret_cast<const V2<T>*>(gx + (size_t)hi35(m + 4) * NANG);
     };
     if constexpr (!JAN) *reinterpret_cast<V2<T>*>(st4 + L.own) = fR[5];   // row MC-4 of the first interaction
+    // WIN: the frequency-interpolated rows W+ / W- of an interaction are staged at the END of the interaction before it (their write -> read
+    // round trip then hides behind the next interaction's coefficient loads and row update instead of standing in its critical path);
+    // here those of the first interaction
+    V2<T> wp_c = z2, wm_c = z2;
+    if constexpr (WIN) {
+      const T* cw0 = tb.DIAW[0];
+      wp_c = cw0[0] * fR[2] + cw0[1] * fR[3];
+      wm_c = cw0[2] * fR[4] + cw0[3] * fR[5];
+      *reinterpret_cast<V2<T>*>(st0 + L.own) = wp_c; *reinterpret_cast<V2<T>*>(st2 + L.own) = wm_c;
+    }
     V4SYNC();
     // Rows above the cut-off MIJ need no source terms: IMPHFTAIL replaces them by the tail of row MIJ (imphftail.F90:77-88), their flux
     // weights RHOWGDFTH are zero (frcutindex.F90:100-107), and the only other reader of the updated rows before the tail goes in --
@@ -1667,6 +1677,9 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
           bscn = L.fac4[IM1 * 4 + Q4_BSC];
         }
         const V2<T> qf0 = *reinterpret_cast<const V2<T>*>(L.fac4 + IM * 4), qf1 = *reinterpret_cast<const V2<T>*>(L.fac4 + IM * 4 + 2);
+        // WIN: row MC+3 enters the ring now, in the slot of row MC-4 (fIM above holds it: the rows of this interaction were staged by the
+        // previous one); it is IP1 of the next interaction, whose rows are staged at the end of this one
+        if constexpr (WIN) fR[(jj + 4) & 7] = *reinterpret_cast<const V2<T>*>(tF + hi35(MC + 3) * RS);
         // ---- coefficient record of the interaction (wave-uniform)
         const T* cg = tb.DIACF[MC - 1];
         const T* cs = cg + 12;
@@ -1700,9 +1713,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         V2<T> SAPk[2], SAMk[2];
         if constexpr (WIN) {
           // W+ = GP F(:,IP) + GP1 F(:,IP1), W- = GM F(:,IM) + GM1 F(:,IM1): two staged rows; SAP = CL11 W+(K1) + ACL1 W+(K11), SAM likewise
-          const V2<T> wp = cw[0] * fIP + cw[1] * fIP1, wm = cw[2] * fIM + cw[3] * fIM1;
-          *reinterpret_cast<V2<T>*>(st0 + L.own) = wp; *reinterpret_cast<V2<T>*>(st2 + L.own) = wm;
-          V4SYNC();
+          // (staged by the previous interaction; wp_c / wm_c are the lane's own pairs of the two rows)
+          const V2<T> wp = wp_c, wm = wm_c;
           // kh = 1: K1 = K - R1, K11 = K - R1 - 1, K2 = K + R2, K21 = K + R2 + 1; kh = 2 mirrored
           SAPk[0] = v4_win<T, NSH, -R1, -(R1 + 1)>(st0, sh, wp, CL11, ACL1);
           SAMk[0] = v4_win<T, NSH, R2, R2 + 1>(st2, sh, wm, CL21, ACL2);
@@ -1829,7 +1841,13 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         }
         // ---- row MC-3 (the saturation row of the next interaction) -> its staging row; row MC+3 enters the ring in the slot of row MC-5
         if constexpr (!JAN) *reinterpret_cast<V2<T>*>(st4 + L.own) = fR[(jj + 6) & 7];
-        fR[(jj + 4) & 7] = *reinterpret_cast<const V2<T>*>(tF + hi35(MC + 3) * RS);
+        if constexpr (WIN) {      // W+ / W- of interaction MC + 1: IP = row MC+2, IP1 = MC+3 (entered the ring above), IM = MC-3, IM1 = MC-2
+          wp_c = cw[12] * fR[(jj + 3) & 7] + cw[13] * fR[(jj + 4) & 7];
+          wm_c = cw[14] * fR[(jj + 5) & 7] + cw[15] * fR[(jj + 6) & 7];
+          *reinterpret_cast<V2<T>*>(st0 + L.own) = wp_c; *reinterpret_cast<V2<T>*>(st2 + L.own) = wm_c;
+        } else {
+          fR[(jj + 4) & 7] = *reinterpret_cast<const V2<T>*>(tF + hi35(MC + 3) * RS);
+        }
         bs_p = bsat; bm_p = bm1; e3_p = e3; e4_p = e4; sig_p = cg[10];
         V4SYNC();
       }

@@ -1300,3 +1300,17 @@ def test_rare_builds_many_points_against_k_implsch2(api, nang, flags, seed, prec
         assert st["mij_flips"] <= n * 1e-4 and st["xllws_pts_diff"] <= n * 1e-4, st
         # (two single-precision kernels, each within 1.6e-5 / 1.7e-6 (swh) of the oracle at this time step: observed 2.6e-5 / 2.1e-6 between them)
         assert st["fl1_max_rel_peak_clean"] < 5e-5 and st["ff_max_rel_clean"] < 5e-5 and st["swh_max_rel"] < 4e-6, st
+
+
+@pytest.mark.parametrize("kw,why", [(dict(nang=18, nfre=36, nfre_red=30), "NANG must be"), (dict(nang=24, nfre=30, nfre_red=25), "NFRE must be 36"),
+                                    (dict(nang=16, nfre=36, nfre_red=36), "NANG must be")])
+def test_create_refuses_what_the_kernel_does_not_cover(api, kw, why):
+    """IMPLSCH has one kernel generation: a spectral grid no build of k_implsch4 covers is refused by ecwam_hip_create, with the reason, instead
+    of being routed to another kernel (through round 4 k_implsch2 took these)."""
+    t = Tables(Config(**kw), np.float32)
+    with pytest.raises(api.EcwamHipError) as e:
+        api.HipContext(t)
+    msg = str(e.value)
+    assert "not covered by the IMPLSCH kernel" in msg or "rotation structure" in msg, msg
+    if kw["nfre"] != 36:
+        assert why in msg, msg

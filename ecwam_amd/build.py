@@ -49,10 +49,12 @@ VARIANTS = {"": FAST_DIV, "exactdiv": ["-DECWAM_HIP_STRICT=0"], "strict1": ["-DE
             "o2": FAST_DIV + ["-O2"],
             # round 5 A/B partners of the common builds: the split row layout of the 36-direction tile (slower, profiles/r05_lds_row_layout.txt);
             # the DIA gathers / scatters as separate rotated reads of rounds 2 - 4 instead of the window form (profiles/r05_dia_window_ab.txt)
-            "rowsplit": FAST_DIV + ["-DV4_ROWSPLIT=1"], "diaold": FAST_DIV + ["-DV4_DIAWIN=0"]}
+            "rowsplit": FAST_DIV + ["-DV4_ROWSPLIT=1"], "diaold": FAST_DIV + ["-DV4_DIAWIN=0"],
+            # the first generation of waves staggered by half a wave lifetime (13 x s_sleep 127 = 106 k cycles) / a quarter
+            "stagger": FAST_DIV + ["-DV4_STAGGER=13"], "stagger6": FAST_DIV + ["-DV4_STAGGER=6"]}
 # variants that rebuild only some of the IMPLSCH translation units (the other objects are the product's)
 VARIANT_SOURCES = {"rdp": ("implsch4rd.hip",), "rdpO1": ("implsch4rd.hip",), "rdpchk": ("implsch4rd.hip",), "rdps": ("implsch4rd.hip",),
-                   "split": ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip"), "o2": ("implsch4.hip",), "rowsplit": ("implsch4.hip",), "diaold": ("implsch4.hip",)}
+                   "split": ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip"), "o2": ("implsch4.hip",), "rowsplit": ("implsch4.hip",), "diaold": ("implsch4.hip",), "stagger": ("implsch4.hip",), "stagger6": ("implsch4.hip",)}
 
 INCLUDE = os.path.join(HERE, "..", "include", "ecwam_hip.h")
 

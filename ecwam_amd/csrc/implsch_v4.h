@@ -849,6 +849,16 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   const int p = L.p, j = L.j;
   const int ij0 = kijs + blockIdx.x * PP;
   if (ij0 >= kijl) return;
+#if defined(V4_STAGGER) && V4_STAGGER > 0
+  // Experiment (build variant "stagger", profiles/r05_stagger_experiment.txt): the waves that fill the chip at the start of a launch all begin
+  // in the same phase; the two waves of a SIMD then compete for the vector ALU in the SINFLX half and for the LDS in the sweep half instead
+  // of complementing each other.  The waves of the first generation that sit in an odd wave slot of their SIMD wait half a wave lifetime.
+  if (blockIdx.x < 2048u) {
+    const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | ((4 - 1) << 11));      // HW_ID[3:0] = wave slot of the SIMD
+    if (hw & 1u)
+      for (int i = 0; i < V4_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   const int n = kijl - ij0 < PP ? kijl - ij0 : PP;   // points of this wave; a short last wave replicates its last point
   const int ij = ij0 + (p < n ? p : n - 1);
   // Position of direction k of point q inside a row of PP NANG elements: q NANG + k.  (V4_ROWSPLIT = 1, build variant "rowsplit": the round-5

@@ -161,3 +161,16 @@ def test_strict_halo_is_the_default_and_fails_loudly(tmp_path):
     assert "strict-halo" in r.stderr
     ok = _run([sys.executable, "bench.py", "--gpus", "2", "--no-strict-halo"] + common, env)
     assert ok["config"]["halo"].startswith("host (fallback") and ok["config"]["strict_halo"] is False
+
+
+def test_bench_refuses_a_counter_summary_of_another_workload():
+    """`bench.py --pmc-file` attaches HBM traffic and the busy fractions of a rocprofv3 counter summary to the roofline object only when the
+    summary describes the run's own workload and kernel: the committed O320 summary handed to an O48 run must be refused loudly (no JSON line)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    pmc = os.path.join(ROOT, "profiles", "r05_bench_O320_sp_pmc.json")
+    assert os.path.exists(pmc)
+    r = subprocess.run([sys.executable, "bench.py", "--grid", "48", "--steps", "1", "--warmup", "0", "--repeats", "1", "--no-cpu-baseline", "--pmc-file", pmc],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and "refused" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stderr[-400:]

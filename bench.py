@@ -152,6 +152,8 @@ def main() -> None:
     ap.add_argument("--nang", type=int, default=36)
     ap.add_argument("--nfre", type=int, default=36)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-grid", type=int, default=96, help="octahedral grid of the CPU baseline sample (default O96: a bounded sample beyond "
+                    "the cores' cache; 320 = the benchmark's own grid, 17.5 GB of packed CTU weights in single precision and a few seconds per step)")
     ap.add_argument("--pmc-file", default="", help="counter summary of tools/pmc_bench.py to attach to the roofline object (HBM traffic, VALU / LDS busy "
                     "fractions); refused when its workload or kernel is not this run's.  Default: profiles/r05_bench_O320_sp_pmc.json where it matches")
     ap.add_argument("--weights", default="otf", choices=["otf", "stored"],
@@ -425,7 +427,7 @@ def main() -> None:
             "swh_norm_rank0": {"avg": swh_avg, "min": swh_min, "max": swh_max},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.nang, a.nfre, a.prec)
+            out["cpu_baseline"] = cpu_baseline(a.nang, a.nfre, a.prec, ng=a.cpu_baseline_grid)
         print(json.dumps(out), file=result_out, flush=True)
     if dist is not None:
         dist.barrier()

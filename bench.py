@@ -152,8 +152,9 @@ def main() -> None:
     ap.add_argument("--nang", type=int, default=36)
     ap.add_argument("--nfre", type=int, default=36)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-grid", type=int, default=96, help="octahedral grid of the CPU baseline sample (default O96: a bounded sample beyond "
-                    "the cores' cache; 320 = the benchmark's own grid, 17.5 GB of packed CTU weights in single precision and a few seconds per step)")
+    ap.add_argument("--cpu-baseline-grid", type=int, default=0, help="octahedral grid of the CPU baseline sample: 320 = the benchmark's own grid (four "
+                    "steps of ~2 s on 16 threads; 17.5 GB of packed CTU weights in single precision, 35 GB for the double precision leg), 96 = a "
+                    "smaller sample beyond the cores' cache; default 0 = 320 where the host has more than 96 GB of memory available, else 96")
     ap.add_argument("--pmc-file", default="", help="counter summary of tools/pmc_bench.py to attach to the roofline object (HBM traffic, VALU / LDS busy "
                     "fractions); refused when its workload or kernel is not this run's.  Default: profiles/r05_bench_O320_sp_pmc.json where it matches")
     ap.add_argument("--weights", default="otf", choices=["otf", "stored"],
@@ -427,7 +428,17 @@ def main() -> None:
             "swh_norm_rank0": {"avg": swh_avg, "min": swh_min, "max": swh_max},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.nang, a.nfre, a.prec, ng=a.cpu_baseline_grid)
+            cng = a.cpu_baseline_grid
+            if cng <= 0:
+                try:
+                    import psutil
+                    cng = 320 if psutil.virtual_memory().available > 96e9 else 96
+                except Exception:
+                    cng = 96
+            try:
+                out["cpu_baseline"] = cpu_baseline(a.nang, a.nfre, a.prec, ng=cng)
+            except MemoryError:      # (the stored weights of the O320 sample did not fit after all)
+                out["cpu_baseline"] = cpu_baseline(a.nang, a.nfre, a.prec, ng=96)
         print(json.dumps(out), file=result_out, flush=True)
     if dist is not None:
         dist.barrier()

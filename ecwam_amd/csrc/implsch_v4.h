@@ -209,6 +209,9 @@ __device__ __forceinline__ V2<T> v4_at(const T* row, const int (&sh)[2 * NSH + 1
 // such window of ONE staged row instead of an odd rotation (two 4-byte reads, two-way bank conflicts by construction) plus an even one of
 // two rows: 28 % fewer LDS instructions in the sweep, which profiles/r05_bench_O320_sp_split_pmc.json shows to be bound by the LDS
 // array (88 % busy, vector ALU 55 %).
+#ifndef V4_WINSHUF
+#define V4_WINSHUF 1
+#endif
 template <typename T, int NSH, int ra, int rb>
 __device__ __forceinline__ V2<T> v4_win(const T* row, const int (&sh)[2 * NSH + 1], V2<T> own, T ca, T cb) {
   static_assert(ra - rb == 1 || rb - ra == 1, "adjacent rotations");
@@ -217,8 +220,32 @@ __device__ __forceinline__ V2<T> v4_win(const T* row, const int (&sh)[2 * NSH + 
   static_assert(e / 2 + NSH >= 0 && e / 2 + 1 + NSH <= 2 * NSH, "shift table");
   const V2<T> a = (e == 0) ? own : *reinterpret_cast<const V2<T>*>(row + sh[e / 2 + NSH]);
   const V2<T> b = (e + 2 == 0) ? own : *reinterpret_cast<const V2<T>*>(row + sh[e / 2 + 1 + NSH]);
+#if V4_WINSHUF
+  // the straddling pair (elements 1, 2) as ONE shuffle of the two aligned pairs (v_pk_mov_b32 in single precision) and the sum as two packed
+  // operations: spelled with scalars, the vectoriser builds the pair with two v_mov_b32
+  auto pick = [&](int i) -> V2<T> { return i == 0 ? a : (i == 2 ? b : __builtin_shufflevector(a, b, 1, 2)); };
+  return ca * pick(ra - e) + cb * pick(rb - e);
+#else
   const T el[4] = {a.x, a.y, b.x, b.y};      // elements e .. e + 3
   return V2<T>{ca * el[ra - e] + cb * el[rb - e], ca * el[ra - e + 1] + cb * el[rb - e + 1]};
+#endif
+}
+
+// the pair (X(2j+r), X(2j+r+1)) out of the aligned pairs A[i] = (X(2j + 2(i-NSH)), X(2j + 2(i-NSH) + 1)) of a row already in registers: an aligned
+// pair, or one shuffle of two neighbours
+template <typename T, int NSH, int r>
+__device__ __forceinline__ V2<T> v4_pair(const V2<T> (&A)[2 * NSH + 1]) {
+  static_assert(r >= -2 * NSH && r <= 2 * NSH, "window");
+  if constexpr ((r & 1) == 0) return A[NSH + r / 2];
+  else return __builtin_shufflevector(A[NSH + (r - 1) / 2], A[NSH + (r + 1) / 2], 1, 2);
+}
+// taps d .. NH of the symmetric saturation filter: acc += wt[NH - d] (X(-d) + X(d)) on pairs (sdissip_ard.F90:142-174)
+template <typename T, int NSH, int NH, int d>
+__device__ __forceinline__ void v4_sat_taps(const V2<T> (&A)[2 * NSH + 1], const T (&wt)[NH + 1], V2<T>& acc) {
+  if constexpr (d <= NH) {
+    acc += wt[NH - d] * (v4_pair<T, NSH, -d>(A) + v4_pair<T, NSH, d>(A));
+    v4_sat_taps<T, NSH, NH, d + 1>(A, wt, acc);
+  }
 }
 
 template <typename T, int PP, bool RARE>
@@ -1675,6 +1702,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         // ---- stage 1: row MC-4 back from its staging row (rotated reads at fixed addresses), the factors of rows MC-5 and MC-4
         const V2<T> fIC = fR[jj & 7], fIP = fR[(jj + 2) & 7], fIM = fR[(jj + 4) & 7], fIM1 = fR[(jj + 5) & 7];
         T el[4 * NSH + 2];                // row MC-4: element e = F(2j - 2 NSH + e)
+        V2<T> elp[2 * NSH + 1];           // the same as aligned pairs
         const int IM = lo0(MC - 5), IM1 = hi35(lo0(MC - 4));
         V4_CHK(MC >= 1 && MC <= 40 && IM >= 0 && IM < NFRE && IM1 >= 0 && IM1 < NFRE);
         T bscn = T(0);
@@ -1682,7 +1710,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
 #pragma unroll
           for (int i = 0; i <= 2 * NSH; i++) {
             const V2<T> v = (i == NSH) ? fIM1 : *reinterpret_cast<const V2<T>*>(st4 + sh[i]);
-            el[2 * i] = v.x; el[2 * i + 1] = v.y;
+            el[2 * i] = v.x; el[2 * i + 1] = v.y; elp[i] = v;
           }
           bscn = L.fac4[IM1 * 4 + Q4_BSC];
         }
@@ -1745,12 +1773,17 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         V2<T> bsat = z2;
         T bm1 = T(0), e0 = T(0);
         if constexpr (!JAN) {
+#if V4_WINSHUF
+          bsat = wt[NH] * elp[NSH];
+          v4_sat_taps<T, NSH, NH, 1>(elp, wt, bsat);
+#else
           bsat = V2<T>{wt[NH] * el[2 * NSH], wt[NH] * el[2 * NSH + 1]};
 #pragma unroll
           for (int d = 1; d <= NH; d++) {
             bsat.x += wt[NH - d] * (el[2 * NSH - d] + el[2 * NSH + d]);
             bsat.y += wt[NH - d] * (el[2 * NSH + 1 - d] + el[2 * NSH + 1 + d]);
           }
+#endif
           bsat = bsat * bscn;
           bm1 = m_max(bsat.x, bsat.y);
           e0 = v4_bp(L.rot.a0, bm1);

@@ -20,6 +20,10 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # IMPLSCH is VALU-issue bound: single-precision divide/sqrt by the hardware reciprocal / square root plus one
 # refinement (<= 2.5 ulp) instead of the correctly rounded sequences; double precision is unaffected.
 FAST_DIV = ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]
+# A/B partner of round 5 (build variant "plainhalves"): with the SLP vectoriser and the VectorCombine pass off, the halves of a pair that
+# straddles two aligned register pairs stay plain operations (implsch_v4.h, V4_WINSHUF = 2) instead of being re-packed at the price of one
+# v_pk_mov_b32 per pair
+NO_REPACK = ["-fno-slp-vectorize", "-mllvm", "-disable-vector-combine"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 IMPLSCH_SOURCES = ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip")
 # Build variants of the IMPLSCH translation units (the single-precision error attribution):
@@ -52,12 +56,12 @@ VARIANTS = {"": FAST_DIV, "exactdiv": ["-DECWAM_HIP_STRICT=0"], "strict1": ["-DE
             "rowsplit": FAST_DIV + ["-DV4_ROWSPLIT=1"], "diaold": FAST_DIV + ["-DV4_DIAWIN=0"],
             # the first generation of waves staggered by half a wave lifetime (13 x s_sleep 127 = 106 k cycles) / a quarter
             "stagger": FAST_DIV + ["-DV4_STAGGER=13"], "stagger6": FAST_DIV + ["-DV4_STAGGER=6"],
-            # the straddling pairs of the DIA windows and of the saturation filter left to the vectoriser (two v_mov_b32 each) instead of one
-            # shuffle (profiles/r05_pair_shuffle_ab.txt)
-            "noshuf": FAST_DIV + ["-DV4_WINSHUF=0"]}
+            # the straddling pairs of the DIA windows and of the saturation filter (profiles/r05_pair_shuffle_ab.txt): the product builds each
+            # with one shuffle; "noshuf" = left to the vectoriser (two v_mov_b32 each, rounds 2 - 4), "plainhalves" = no pair assembled
+            "noshuf": FAST_DIV + ["-DV4_WINSHUF=0"], "plainhalves": FAST_DIV + ["-DV4_WINSHUF=2"] + NO_REPACK}
 # variants that rebuild only some of the IMPLSCH translation units (the other objects are the product's)
 VARIANT_SOURCES = {"rdp": ("implsch4rd.hip",), "rdpO1": ("implsch4rd.hip",), "rdpchk": ("implsch4rd.hip",), "rdps": ("implsch4rd.hip",),
-                   "split": ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip"), "o2": ("implsch4.hip",), "rowsplit": ("implsch4.hip",), "diaold": ("implsch4.hip",), "stagger": ("implsch4.hip",), "stagger6": ("implsch4.hip",), "noshuf": ("implsch4.hip",)}
+                   "split": ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip"), "o2": ("implsch4.hip",), "rowsplit": ("implsch4.hip",), "diaold": ("implsch4.hip",), "stagger": ("implsch4.hip",), "stagger6": ("implsch4.hip",), "noshuf": ("implsch4.hip",), "plainhalves": ("implsch4.hip",)}
 
 INCLUDE = os.path.join(HERE, "..", "include", "ecwam_hip.h")
 

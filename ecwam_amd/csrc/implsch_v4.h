@@ -209,9 +209,29 @@ __device__ __forceinline__ V2<T> v4_at(const T* row, const int (&sh)[2 * NSH + 1
 // such window of ONE staged row instead of an odd rotation (two 4-byte reads, two-way bank conflicts by construction) plus an even one of
 // two rows: 28 % fewer LDS instructions in the sweep, which profiles/r05_bench_O320_sp_split_pmc.json shows to be bound by the LDS
 // array (88 % busy, vector ALU 55 %).
+// V4_WINSHUF: who assembles a STRADDLING pair (X(2j+r), X(2j+r+1)), r odd -- the high half of one aligned pair and the low half of the next
+// (the DIA windows, 12 per interaction, and the odd taps of the saturation filter).  A packed operation takes the vector pipe for four
+// cycles, a plain one for two, and the sweep is bound by those cycles (profiles/r05_pair_shuffle_ab.txt):
+//   0  scalar code, packed by the vectoriser, each straddling pair built with two v_mov_b32 (rounds 2 - 4)
+//   1  one shuffle (v_pk_mov_b32) per straddling pair, packed arithmetic: fewer instructions, the same pipe cycles
+//   2  no pair is assembled: the operation that consumes a straddling pair is done as two PLAIN operations on the halves where they lie
+//      (same cycles as the packed one, and the four of the v_pk_mov_b32 are gone); needs -fno-slp-vectorize -mllvm -disable-vector-combine,
+//      or the two passes re-pack them.  Measured: 12 % fewer pipe cycles in the sweep by the static count, 1 % of the kernel's time in
+//      single precision, and the two switches cost double precision 3 %: build variant "plainhalves", not the product
+// The product is 1.
 #ifndef V4_WINSHUF
 #define V4_WINSHUF 1
 #endif
+// plain (one value per lane) operations of V4_WINSHUF = 2: scalar code, which stays scalar only where the vectorising passes are off
+template <typename T> __device__ __forceinline__ T v4_plain_add(T a, T b) { return a + b; }
+template <typename T> __device__ __forceinline__ T v4_plain_mul(T c, T a) { return c * a; }
+template <typename T> __device__ __forceinline__ T v4_plain_fma(T c, T a, T t) {      // c a + t, fused
+  if constexpr (sizeof(T) == 4) return __builtin_fmaf(c, a, t);
+  else return __builtin_fma(c, a, t);
+}
+template <typename T> __device__ __forceinline__ V2<T> v4_fma2(T c, V2<T> a, V2<T> t) {      // c a + t on a pair, fused
+  return __builtin_elementwise_fma(V2<T>{c, c}, a, t);
+}
 template <typename T, int NSH, int ra, int rb>
 __device__ __forceinline__ V2<T> v4_win(const T* row, const int (&sh)[2 * NSH + 1], V2<T> own, T ca, T cb) {
   static_assert(ra - rb == 1 || rb - ra == 1, "adjacent rotations");
@@ -220,9 +240,18 @@ __device__ __forceinline__ V2<T> v4_win(const T* row, const int (&sh)[2 * NSH + 
   static_assert(e / 2 + NSH >= 0 && e / 2 + 1 + NSH <= 2 * NSH, "shift table");
   const V2<T> a = (e == 0) ? own : *reinterpret_cast<const V2<T>*>(row + sh[e / 2 + NSH]);
   const V2<T> b = (e + 2 == 0) ? own : *reinterpret_cast<const V2<T>*>(row + sh[e / 2 + 1 + NSH]);
-#if V4_WINSHUF
-  // the straddling pair (elements 1, 2) as ONE shuffle of the two aligned pairs (v_pk_mov_b32 in single precision) and the sum as two packed
-  // operations: spelled with scalars, the vectoriser builds the pair with two v_mov_b32
+#if V4_WINSHUF == 2
+  // ca X(ra) + cb X(rb) = fma(ca, X(ra), cb X(rb)); exactly one of the two pairs straddles (elements 1, 2 of a.x a.y b.x b.y)
+  constexpr int ia = ra - e, ib = rb - e;
+  static_assert((ia == 1) != (ib == 1), "one aligned pair, one straddling pair");
+  if constexpr (ib == 1) {
+    const V2<T> t = {v4_plain_mul(cb, a.y), v4_plain_mul(cb, b.x)};
+    return v4_fma2(ca, ia == 0 ? a : b, t);
+  } else {
+    const V2<T> t = cb * (ib == 0 ? a : b);
+    return V2<T>{v4_plain_fma(ca, a.y, t.x), v4_plain_fma(ca, b.x, t.y)};
+  }
+#elif V4_WINSHUF == 1
   auto pick = [&](int i) -> V2<T> { return i == 0 ? a : (i == 2 ? b : __builtin_shufflevector(a, b, 1, 2)); };
   return ca * pick(ra - e) + cb * pick(rb - e);
 #else
@@ -243,6 +272,14 @@ __device__ __forceinline__ V2<T> v4_pair(const V2<T> (&A)[2 * NSH + 1]) {
 template <typename T, int NSH, int NH, int d>
 __device__ __forceinline__ void v4_sat_taps(const V2<T> (&A)[2 * NSH + 1], const T (&wt)[NH + 1], V2<T>& acc) {
   if constexpr (d <= NH) {
+#if V4_WINSHUF == 2
+    if constexpr ((d & 1) != 0) {
+      // X(-d) = (A[i].y, A[i+1].x), X(d) = (A[k].y, A[k+1].x): their sum, formed half by half where the halves lie
+      constexpr int i = NSH + (-d - 1) / 2, k = NSH + (d - 1) / 2;
+      const V2<T> t = {v4_plain_add(A[i].y, A[k].y), v4_plain_add(A[i + 1].x, A[k + 1].x)};
+      acc += wt[NH - d] * t;
+    } else
+#endif
     acc += wt[NH - d] * (v4_pair<T, NSH, -d>(A) + v4_pair<T, NSH, d>(A));
     v4_sat_taps<T, NSH, NH, d + 1>(A, wt, acc);
   }
@@ -1773,7 +1810,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         V2<T> bsat = z2;
         T bm1 = T(0), e0 = T(0);
         if constexpr (!JAN) {
-#if V4_WINSHUF
+#if V4_WINSHUF != 0
           bsat = wt[NH] * elp[NSH];
           v4_sat_taps<T, NSH, NH, 1>(elp, wt, bsat);
 #else

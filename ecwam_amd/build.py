@@ -56,12 +56,12 @@ VARIANTS = {"": FAST_DIV, "exactdiv": ["-DECWAM_HIP_STRICT=0"], "strict1": ["-DE
             "rowsplit": FAST_DIV + ["-DV4_ROWSPLIT=1"], "diaold": FAST_DIV + ["-DV4_DIAWIN=0"],
             # the first generation of waves staggered by half a wave lifetime (13 x s_sleep 127 = 106 k cycles) / a quarter
             "stagger": FAST_DIV + ["-DV4_STAGGER=13"], "stagger6": FAST_DIV + ["-DV4_STAGGER=6"],
-            # the straddling pairs of the DIA windows and of the saturation filter (profiles/r05_pair_shuffle_ab.txt): the product builds each
-            # with one shuffle; "noshuf" = left to the vectoriser (two v_mov_b32 each, rounds 2 - 4), "plainhalves" = no pair assembled
-            "noshuf": FAST_DIV + ["-DV4_WINSHUF=0"], "plainhalves": FAST_DIV + ["-DV4_WINSHUF=2"] + NO_REPACK}
+            # the straddling pairs of the DIA windows and of the saturation filter (profiles/r05_pair_shuffle_ab.txt): the product leaves them
+            # to the vectoriser (two v_mov_b32 each); "shuf1" = one shuffle each, "plainhalves" = no pair assembled
+            "shuf1": FAST_DIV + ["-DV4_WINSHUF=1"], "plainhalves": FAST_DIV + ["-DV4_WINSHUF=2"] + NO_REPACK}
 # variants that rebuild only some of the IMPLSCH translation units (the other objects are the product's)
 VARIANT_SOURCES = {"rdp": ("implsch4rd.hip",), "rdpO1": ("implsch4rd.hip",), "rdpchk": ("implsch4rd.hip",), "rdps": ("implsch4rd.hip",),
-                   "split": ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip"), "o2": ("implsch4.hip",), "rowsplit": ("implsch4.hip",), "diaold": ("implsch4.hip",), "stagger": ("implsch4.hip",), "stagger6": ("implsch4.hip",), "noshuf": ("implsch4.hip",), "plainhalves": ("implsch4.hip",)}
+                   "split": ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip"), "o2": ("implsch4.hip",), "rowsplit": ("implsch4.hip",), "diaold": ("implsch4.hip",), "stagger": ("implsch4.hip",), "stagger6": ("implsch4.hip",), "shuf1": ("implsch4.hip",), "plainhalves": ("implsch4.hip",)}
 
 INCLUDE = os.path.join(HERE, "..", "include", "ecwam_hip.h")
 

@@ -218,9 +218,11 @@ __device__ __forceinline__ V2<T> v4_at(const T* row, const int (&sh)[2 * NSH + 1
 //      (same cycles as the packed one, and the four of the v_pk_mov_b32 are gone); needs -fno-slp-vectorize -mllvm -disable-vector-combine,
 //      or the two passes re-pack them.  Measured: 12 % fewer pipe cycles in the sweep by the static count, 1 % of the kernel's time in
 //      single precision, and the two switches cost double precision 3 %: build variant "plainhalves", not the product
-// The product is 1.
+// The product is 0: 1 and 2 run in the same time within 1 % and are not bit-identical to it (the packed forms contract differently); over
+// the 72 steps of test_reference_length_run_with_changing_winds the last-bit differences of 1 moved the global swh maximum -- one point's
+// value -- by 1.2e-6, past that test's 1e-6.
 #ifndef V4_WINSHUF
-#define V4_WINSHUF 1
+#define V4_WINSHUF 0
 #endif
 // plain (one value per lane) operations of V4_WINSHUF = 2: scalar code, which stays scalar only where the vectorising passes are off
 template <typename T> __device__ __forceinline__ T v4_plain_add(T a, T b) { return a + b; }

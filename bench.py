@@ -176,6 +176,9 @@ def main() -> None:
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal of the N>1 code on ONE GPU: every rank uses device 0, process group on gloo, host-staged halo")
     ap.add_argument("--dump", default="", help="write the owned spectra of every rank to <path>.<rank>.npy after the last step")
+    ap.add_argument("--host-state", action="store_true",
+                    help="DIAGNOSTIC, never the reported value: the spectra enter from and return to pinned host memory every step (what a caller "
+                         "that hands over host buffers would pay over PCIe; DESIGN.md section 6)")
     ap.add_argument("--irefra", type=int, default=0, choices=[0, 1, 2, 3],
                     help="refraction: 0 none (BASELINE configurations), 1 depth, 2 currents, 3 both (synthetic current field)")
     a = ap.parse_args()
@@ -293,6 +296,9 @@ def main() -> None:
         m.newwind()
         m.implsch()
 
+    host_fl = torch.empty((m.n, a.nang, a.nfre), dtype=m.fl1.dtype).pin_memory() if a.host_state else None
+    if host_fl is not None:
+        host_fl.copy_(m.fl1[: m.n])
     for _ in range(a.warmup):
         step_untimed()
     # a.repeats windows of a.steps steps, each bracketed by barrier + synchronize on both sides; a window's time is the MAX over ranks,
@@ -307,6 +313,9 @@ def main() -> None:
         t0 = time.perf_counter()
         for s in range(a.steps):
             e = ev[s]
+            if host_fl is not None:
+                m.fl1[: m.n].copy_(host_fl, non_blocking=True)
+                m.gfast_valid = False
             e[0].record()
             for _ in range(a.adv_per_source):
                 m.propag()        # halo exchange (N > 1) + PROPAGS2 (+ fast-wave sub-steps)
@@ -315,6 +324,8 @@ def main() -> None:
             e[2].record()
             m.implsch()
             e[3].record()
+            if host_fl is not None:
+                host_fl.copy_(m.fl1[: m.n], non_blocking=True)
         sync()
         windows.append(time.perf_counter() - t0)
         hw = sum(x.elapsed_time(y) for x, y in m.halo_events) / a.steps if m.halo_events else 0.0
@@ -369,7 +380,8 @@ def main() -> None:
                     f"IDELT=IDELPRO={dt} s, flag set A (IPHYS=1, ISNONLIN=0, LLGCBZ0=F, LLNORMAGAM=F)"
                     + (f", IREFRA={a.irefra} (synthetic currents)" if a.irefra else "")
                     + (f", {a.adv_per_source} advection steps per source step" if a.adv_per_source != 1 else "")
-                    + (f", fast waves M<={a.ifrelfmax} in two sub-steps" if a.ifrelfmax else ""))
+                    + (f", fast waves M<={a.ifrelfmax} in two sub-steps" if a.ifrelfmax else "")
+                    + (", DIAGNOSTIC: spectra copied from and to pinned host memory every step" if a.host_state else ""))
         dtype = "f32" if a.prec == "sp" else "f64"
         pmc_path = a.pmc_file or os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_bench_O320_sp_pmc.json")
         pmc, pmc_why = None, None

@@ -219,8 +219,8 @@ def test_swh_norms_after_four_steps_on_the_benchmark_grid(prec):
     IDELT = IDELPRO = 450 s, four full WAMINTGR steps of all 421 080 sea points on the device (OUTBS + OUTWNORM) against the oracle
     stepping the same state.  The oracle advects in 16 latitude bands with their halo rows (the stored CTU weights of the whole grid
     would be 17.5 GB in single precision) and integrates the source terms of all points in one call.  Tolerance: 1e-12 in double
-    precision; 1e-6 in single precision -- or the distance of the sp oracle from the dp oracle on the same sp inputs where single
-    precision itself does not carry that far, capped at 3e-6 (as in test_swh_norms_track_the_oracle_over_twelve_steps)."""
+    precision; the yml's 1e-6 in single precision (observed 1.9e-7; the sp oracle itself is 4.4e-7 from the dp oracle stepping the same sp
+    inputs -- ECWAM_NORM_TRUTH=1 steps that one as well and prints the distance: an evidence run, not part of the gate)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from ecwam_amd import grid as G
@@ -264,9 +264,9 @@ def test_swh_norms_after_four_steps_on_the_benchmark_grid(prec):
             return hs.mean(), hs.min(), hs.max()
 
     same = Track(prec)
-    truth = Track("dp") if prec == "sp" else None
-    worst = own_worst = 0.0
     import os
+    truth = Track("dp") if prec == "sp" and os.environ.get("ECWAM_NORM_TRUTH", "0") == "1" else None
+    worst = own_worst = 0.0
     nsteps = int(os.environ.get("ECWAM_NORM_STEPS", "4"))      # (a longer evidence run: profiles/r05_norms_O320_24_steps.txt)
     for it in range(1, nsteps + 1):
         m.step()
@@ -280,7 +280,7 @@ def test_swh_norms_after_four_steps_on_the_benchmark_grid(prec):
         for got, w_, t_ in zip((avg, mn, mx), want, ref):
             rd, own = abs(got - w_) / abs(w_), abs(w_ - t_) / abs(t_)
             worst, own_worst = max(worst, rd), max(own_worst, own)
-            tol = 1e-12 if prec == "dp" else min(3e-6, max(1e-6, own))
+            tol = 1e-12 if prec == "dp" else 1e-6
             assert rd <= tol, (it, got, w_, rd, own)
         if nsteps > 4:
             print(f"   step {it:3d}: device avg / min / max {avg:.6f} {mn:.6f} {mx:.6f}   worst relative difference so far {worst:.2e}", flush=True)

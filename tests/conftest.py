@@ -22,3 +22,18 @@ def oracle_built():
 
     oracle.build()
     return True
+
+
+# Evidence runs with OTHER random inputs than the ones the gates were set on: ECWAM_TEST_SEED_OFFSET=<k> adds k to the seed of every
+# synthetic sea state the tests generate (tests only: the patch lives here, ecwam_amd/synthetic.py is untouched).  Not part of the suite's
+# contract -- the gates are observed maxima with a margin, on the default seeds; profiles/r05_seed_robustness.txt records what other seeds do.
+_off = int(os.environ.get("ECWAM_TEST_SEED_OFFSET", "0") or 0)
+if _off:
+    from ecwam_amd import synthetic as _syn
+
+    _point_params = _syn.point_params
+
+    def _shifted(nglobal, seed=12345, *args, **kw):
+        return _point_params(nglobal, seed + _off, *args, **kw)
+
+    _syn.point_params = _shifted

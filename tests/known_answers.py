@@ -171,7 +171,11 @@ def check_tail_and_stokes_drift(run, prec):
     th = np.asarray(t.TH, float)
     mij = out["MIJ"]
     wd = case["FF"][:, 1].astype(float)
-    flm = float(t.FLMIN) * np.maximum(0.0, np.cos(th[None, :] - wd[:, None])) ** 2
+    cosd = np.cos(th[None, :] - wd[:, None])
+    flm = float(t.FLMIN) * np.maximum(0.0, cosd) ** 2
+    # a bin on the floor carries the rounding of TH - WDWAVE in the working precision: d(COS**2) <= 2 |COS| d(angle), d(angle) a few ulp of 2 pi
+    # (seen with other seeds, ECWAM_TEST_SEED_OFFSET: 5.8e-5 of the floor where COS = 0.004 in single precision)
+    flm_atol = float(t.FLMIN) * 2.0 * np.abs(cosd) * (2e-6 if prec == "sp" else 4e-15)
     seen = 0
     for i in range(n):
         mi = int(mij[i])
@@ -181,7 +185,7 @@ def check_tail_and_stokes_drift(run, prec):
         for m in range(mi, cfg.nfre):
             want = np.maximum(fl[i, :, mi - 1] * (fr[mi - 1] / fr[m]) ** 5, flm[i])
             rtol = (1e-5 if prec == "sp" else 1e-12) if kd[mi - 1] > 10 else 5e-4          # AKI's tolerance below k d = 10 (aki.F90:71-91)
-            assert np.allclose(fl[i, :, m], want, rtol=rtol, atol=0), (i, m)
+            assert np.all(np.abs(fl[i, :, m] - want) <= rtol * np.abs(want) + flm_atol[i]), (i, m)
             seen += 1
     assert seen > 100
     # Stokes drift of the run's own new spectrum

@@ -267,7 +267,11 @@ def test_oracle_physics_invariants():
     r = H.oracle_implsch(case, Oracle(cfg, "dp"))
     fl, mij = r["FL1"], r["MIJ"]
     assert np.isfinite(fl).all() and fl.min() >= 0
-    assert np.all(fl <= np.asarray(t.FLMAX)[None, None, :] * (1 + 1e-12) + 1e-30)
+    # the limiter's cap (implsch.F90:386-391) holds on the prognostic rows; above MIJ the diagnostic tail of row MIJ goes in afterwards
+    # (imphftail.F90:77-88) and may pass FLMAX(M) by its finite-depth factor (7.8e-5 seen with another seed, ECWAM_TEST_SEED_OFFSET)
+    prog = np.arange(36)[None, None, :] < mij[:, None, None]
+    assert np.all((fl <= np.asarray(t.FLMAX)[None, None, :] * (1 + 1e-12) + 1e-30) | ~prog)
+    assert np.all(fl <= np.asarray(t.FLMAX)[None, None, :] * (1 + 1e-3))
     ice = case["FF"][:, 2] > float(t.CITHRSH)
     assert ice.any() and np.all(fl[ice].max(axis=(1, 2)) < 1e-4)
     assert np.all((mij >= 1) & (mij <= 36))

@@ -34,15 +34,7 @@ def api():
 
 
 def _log_stats(st, prec):
-    """ECWAM_TEST_STATS_LOG=<file>: one JSON line per gated comparison (test id, precision, IDELT, the error statistics): what the
-    gates below are set from (tools/gate_report.py)."""
-    import json
-    import os
-
-    path = os.environ.get("ECWAM_TEST_STATS_LOG")
-    if path:
-        with open(path, "a") as fh:
-            fh.write(json.dumps(dict(test=os.environ.get("PYTEST_CURRENT_TEST", ""), prec=prec, **st)) + "\n")
+    """(the statistics log is written by harness.compare_implsch itself: ECWAM_TEST_STATS_LOG)"""
 
 
 # Single-precision gates by source-term time step (st["idelt"]).  The error of the new spectrum grows with DELT (the increment DELT SL / (1 - DELT

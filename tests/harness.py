@@ -112,9 +112,9 @@ def robust_max(x, frac: float = 0.002) -> float:
 # Single-precision gates of every comparison of an IMPLSCH result (dp has fixed gates at the call sites: 1e-10 and tighter, MIJ / XLLWS
 # identical).  Two tiers per quantity, by the source-term time step of the case (the error of the new spectrum grows with DELT: the
 # increment DELT SL / (1 - DELT XIMP FLD) carries the rounding of SL):
-#   gate on robust_max -- every point but 0.2 % of them: the rounding bound.  Observed over the whole GPU suite on three sets of random
-#     inputs (seed offsets 0, 1000, 2000, 3000: profiles/r05_seed_robustness.txt): IDELT 450 s (the benchmark's step): the worst bin of a
-#     point 6.8e-7 of its peak, swh 2.5e-7, forcing 8.0e-6, fluxes 7.6e-5; IDELT 900 / 1200 s: 1.04e-5, 7.7e-7, 8.0e-6, 2.6e-4
+#   gate on robust_max -- every point but 0.2 % of them: the rounding bound.  Observed over the whole GPU suite on five sets of random
+#     inputs (seed offsets 0 ... 4000: profiles/r05_seed_robustness.txt): IDELT 450 s (the benchmark's step): the worst bin of a
+#     point 7.1e-7 of its peak, swh 2.5e-7, forcing 8.0e-6, fluxes 7.6e-5; IDELT 900 / 1200 s: 1.04e-5, 7.7e-7, 8.0e-6, 2.6e-4
 #   cap on the plain maximum -- the few points where a discrete decision (limiter, clip, an iteration's exit) falls the other way; which
 #     points those are depends on the sample: observed up to 2e-4 (bins), 9.4e-5 (swh), 5.9e-3 (fluxes), and in the forcing outputs 5.6e-3
 #     except the background roughness Z0B of the gravity-capillary model, 0.11 at one point in 1 100 (IPHYS 0 + LLGCBZ0, seed offset 1000)

@@ -58,10 +58,12 @@ VARIANTS = {"": FAST_DIV, "exactdiv": ["-DECWAM_HIP_STRICT=0"], "strict1": ["-DE
             "stagger": FAST_DIV + ["-DV4_STAGGER=13"], "stagger6": FAST_DIV + ["-DV4_STAGGER=6"],
             # the straddling pairs of the DIA windows and of the saturation filter (profiles/r05_pair_shuffle_ab.txt): the product leaves them
             # to the vectoriser (two v_mov_b32 each); "shuf1" = one shuffle each, "plainhalves" = no pair assembled
-            "shuf1": FAST_DIV + ["-DV4_WINSHUF=1"], "plainhalves": FAST_DIV + ["-DV4_WINSHUF=2"] + NO_REPACK}
+            "shuf1": FAST_DIV + ["-DV4_WINSHUF=1"], "plainhalves": FAST_DIV + ["-DV4_WINSHUF=2"] + NO_REPACK,
+            # the reads of two staging rows at the same shift kept as two ds_read_b64 instead of the compiler's ds_read2_b64 (8 LDS cycles against 4)
+            "noread2": FAST_DIV + ["-DV4_NOREAD2=1"]}
 # variants that rebuild only some of the IMPLSCH translation units (the other objects are the product's)
 VARIANT_SOURCES = {"rdp": ("implsch4rd.hip",), "rdpO1": ("implsch4rd.hip",), "rdpchk": ("implsch4rd.hip",), "rdps": ("implsch4rd.hip",),
-                   "split": ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip"), "o2": ("implsch4.hip",), "rowsplit": ("implsch4.hip",), "diaold": ("implsch4.hip",), "stagger": ("implsch4.hip",), "stagger6": ("implsch4.hip",), "shuf1": ("implsch4.hip",), "plainhalves": ("implsch4.hip",)}
+                   "split": ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip"), "o2": ("implsch4.hip",), "rowsplit": ("implsch4.hip",), "diaold": ("implsch4.hip",), "stagger": ("implsch4.hip",), "stagger6": ("implsch4.hip",), "shuf1": ("implsch4.hip",), "plainhalves": ("implsch4.hip",), "noread2": ("implsch4.hip",)}
 
 INCLUDE = os.path.join(HERE, "..", "include", "ecwam_hip.h")
 

@@ -238,6 +238,13 @@ static int build_tab(const ecwam_hip_params* p, const ecwam_hip_tables* t, DevTa
     const int want[5] = {cl(MC), cl(MC + 2), cl(MC + 3), cl(MC - 4), cl(MC - 3)};
     for (int j = 0; j < 5; j++) if (d->INLCOEF[i][j] != want[j]) d->V4_ROWS = 0;
   }
+  for (int i = 0; i <= ML; i++) {
+    const int k = i < ML ? i : ML - 1;
+    static const int w7[7] = {9, 10, 11, 28, 29, 30, 31};
+    for (int j = 0; j < 7; j++) d->DIAREC[i][j] = d->DIACF[k][w7[j]];
+    d->DIAREC[i][7] = T(0);
+    for (int j = 0; j < 12; j++) d->DIAREC[i][8 + j] = d->DIAW[k][4 + j];
+  }
   for (int m = 0; m < NFRE; m++) {
     T* r = d->SINROW[m];
     r[0] = d->ZPIFR[m]; r[1] = d->DFIM[m];

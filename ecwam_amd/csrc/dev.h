@@ -70,6 +70,9 @@ struct DevTab {
   // MC + 1 at the end of interaction MC); DIAANG = CL11, ACL1, CL21, ACL2 and their squares
   alignas(16) T DIAW[MAXMC][16];
   T DIAANG[8];
+  // the words of DIACF / DIAW the window form of the sweep reads per interaction, contiguous (V4_RECPF: fetched one interaction ahead):
+  // 0..6 = DIACF 9, 10, 11, 28, 29, 30, 31; 8..19 = DIAW 4..15; row MLSTHG repeats the last interaction (the prefetch of the last one)
+  alignas(16) T DIAREC[MAXMC + 1][20];
   // word 31: FTAIL as the sweep applies it (1 between MFR1STFR and MFRLSTFR); words 10, 11, 28..30 of the record of interaction MC: ZPIFR of the (clamped) row MC-3 and COFRM4, FLMAX, RHOWG_DFIM, ZPIFR of row
   // MC-5, which that interaction updates -- the record is one scalar load, a lane table costs a v_readlane per value
   // SINPUT_ARD's per-frequency constants as one 8-word record per row: ZPIFR, DFIM, -SWELLF5 2 SQRT(2 NU_AIR SIG), -SWELLF 16 SIG**2 / G

@@ -209,6 +209,35 @@ __device__ __forceinline__ V2<T> v4_at(const T* row, const int (&sh)[2 * NSH + 1
 // such window of ONE staged row instead of an odd rotation (two 4-byte reads, two-way bank conflicts by construction) plus an even one of
 // two rows: 28 % fewer LDS instructions in the sweep, which profiles/r05_bench_O320_sp_split_pmc.json shows to be bound by the LDS
 // array (88 % busy, vector ALU 55 %).
+// V4_RECPF: the per-interaction coefficient record of the sweep (DevTab::DIAREC, 19 words) is fetched ONE INTERACTION AHEAD by three scalar
+// loads at the top of an interaction and pinned in scalar registers at its end.  Left to itself the compiler sinks each scalar load to the
+// block of its first use: eight loads in six places per interaction, each with its s_waitcnt lgkmcnt(0) one or two instructions later -- the
+// scalar-cache latency exposed six times per interaction, and the LDS reads in flight drained with it (scalar loads return out of order).
+// The 19 + 19 registers come from moving the sweep's loop-invariant uniform weights (saturation filter, angular weights) to vector registers.
+#ifndef V4_RECPF
+#define V4_RECPF 1
+#endif
+#ifndef V4_RECPF_AT
+#define V4_RECPF_AT 0      // where the sweep issues the loads of the next record: 0 at the top of the interaction, 1 in front of the row update
+#endif
+// Single precision only: in double precision the two records are 80 scalar registers, and the variant measured 3 % slower there.
+// The builds with more live registers (48 directions: twelve filter weights; the RARE builds) spill to scratch with it and stay without.
+template <bool ON, typename T>
+__device__ __forceinline__ T v4_vreg(T x) {      // a wave-uniform value moved to a vector register on purpose
+  if constexpr (ON && sizeof(T) == 4) {
+    T r;
+    asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(x));
+    return r;
+  } else return x;
+}
+template <typename T>
+__device__ __forceinline__ void v4_pin6(const T (&r)[6]) { asm volatile("" :: "s"(r[0]), "s"(r[1]), "s"(r[2]), "s"(r[3]), "s"(r[4]), "s"(r[5])); }
+template <typename T>
+__device__ __forceinline__ void v4_pin10(T (&r)[20], int o) {      // ten values held in scalar registers at this point of the program
+  // (inputs only: the values must EXIST in scalar registers here, before their uses in the next interaction -- their loads cannot sink past this
+  // point; as outputs they would be copied out of the loads' register tuples one by one)
+  asm volatile("" :: "s"(r[o]), "s"(r[o + 1]), "s"(r[o + 2]), "s"(r[o + 3]), "s"(r[o + 4]), "s"(r[o + 5]), "s"(r[o + 6]), "s"(r[o + 7]), "s"(r[o + 8]), "s"(r[o + 9]));
+}
 // V4_WINSHUF: who assembles a STRADDLING pair (X(2j+r), X(2j+r+1)), r odd -- the high half of one aligned pair and the low half of the next
 // (the DIA windows, 12 per interaction, and the odd taps of the saturation filter).  A packed operation takes the vector pipe for four
 // cycles, a plain one for two, and the sweep is bound by those cycles (profiles/r05_pair_shuffle_ab.txt):
@@ -479,18 +508,35 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
   V2<T> f_n = *reinterpret_cast<const V2<T>*>(tF);
   V2<T> cw_n = *reinterpret_cast<const V2<T>*>(L.fac4 + Q4_CINV);
   T zcn_n = L.zcn[0];
+  // V4_RECPF: the row's record of module constants one row ahead as well (its scalar load would otherwise be waited for where it is issued)
+  constexpr bool RPF = (V4_RECPF != 0) && sizeof(T) == 4;
+  T rw_n[6];
+  if constexpr (RPF) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) rw_n[i] = tb.SINROW[0][i];
+  }
 #pragma unroll 2
   for (int m = 0; m < NFRE; m++) {
     const V2<T> f = f_n, cw = cw_n;
     const T ZCN = zcn_n, cinv_m = cw.x;
+    T rw[6];
+    if constexpr (RPF) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) rw[i] = rw_n[i];
+    }
     {
       const int mn = m + 1 < NFRE ? m + 1 : m;
       f_n = *reinterpret_cast<const V2<T>*>(tF + mn * RS);
       cw_n = *reinterpret_cast<const V2<T>*>(L.fac4 + mn * 4 + Q4_CINV);
       zcn_n = L.zcn[mn];
+      if constexpr (RPF) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) rw_n[i] = tb.SINROW[mn][i];
+      }
     }
+    if constexpr (RPF) __builtin_amdgcn_sched_barrier(0);      // (left to the scheduler the loads of the next row sink to the end of this one)
     V4_CHK(m >= 0 && m < NFRE);
-    const T* row = tb.SINROW[m];   // one scalar load: ZPIFR, DFIM, C5, T1, RHOWG_DFIM, DFIMOFR of the row
+    const T* row = RPF ? rw : tb.SINROW[m];   // one scalar load: ZPIFR, DFIM, C5, T1, RHOWG_DFIM, DFIMOFR of the row
     const T SIGm = row[0], DFIMm = row[1];
     const T CONSTF = ROGOROAIR * cinv_m * DFIMm;
     const T DSTAB1 = LLSNEG ? (row[2] * AIRD_PVISC) * cw.y : T(0);
@@ -585,6 +631,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
     const V2<T> x = {xl0 ? f.x : T(0), xl1 ? f.y : T(0)};
     wse = wse + V2<T>{DFIMm, row[5]} * (x.x + x.y);
     wslast = x;
+    if constexpr (RPF) v4_pin6(rw_n);
   }
   WSYNC();
 }
@@ -1601,9 +1648,10 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     constexpr bool WIN = (V4_DIAWIN != 0);      // the separable window form of the DIA gathers / scatters (v4_win)
     const T CL11 = tb.DIAANG[0], ACL1 = tb.DIAANG[1], CL21 = tb.DIAANG[2], ACL2 = tb.DIAANG[3];
     const T CL11Q = tb.DIAANG[4], ACL1Q = tb.DIAANG[5], CL21Q = tb.DIAANG[6], ACL2Q = tb.DIAANG[7];
+    constexpr bool RECPF_ON = (V4_RECPF != 0) && sizeof(T) == 4 && NANG <= 36 && !RARE;      // (see V4_RECPF)
     T wt[NH + 1];   // SATWEIGHTS depend on the tap only and are symmetric (checked by ecwam_hip_create): wave-uniform, taps -NH .. 0
 #pragma unroll
-    for (int t = 0; t <= NH; t++) wt[t] = tb.SATWEIGHTS[t][NANG / 2];
+    for (int t = 0; t <= NH; t++) wt[t] = v4_vreg<RECPF_ON>(tb.SATWEIGHTS[t][NANG / 2]);
     const T TMP03 = T(1) / (tb.SDSBR * tb.MICHE), SSDSC4 = tb.SSDSC4;
     const T c2 = tb.SSDSC2 * tb.SSDSC6, c2m1 = tb.SSDSC2 * (T(1) - tb.SSDSC6);
     const bool turb = !JAN && tb.SSDSC5 != T(0);
@@ -1744,11 +1792,25 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     const int UPD_LIM = whole ? NFRE : mijmax;                                      // rows m < UPD_LIM (0-based) are updated
     const int DIA_LIM = whole ? MLST : (mijmax + 4 < MLST ? mijmax + 4 : MLST);     // interactions MC <= DIA_LIM contribute to them
     const int MC_END = whole ? MLST : (mijmax + 5 < MLST ? mijmax + 5 : MLST);      // row MIJ is updated at the top of interaction MIJ + 5
+    constexpr bool RECPF = WIN && RECPF_ON;
+    T ra[20], rb[20];      // RECPF: the records of two consecutive interactions, roles alternating (the loop is unrolled by eight: static)
+    if constexpr (RECPF) {
+#pragma unroll
+      for (int i = 0; i < 20; i++) ra[i] = tb.DIAREC[0][i];
+      v4_pin10(ra, 0); v4_pin10(ra, 10);
+    }
     int MCb = 0;
     for (; MCb < MC_END; MCb += 8) {
 #pragma unroll
       for (int jj = 0; jj < 8; jj++) {
         const int MC = MCb + 1 + jj;
+        T (&rc)[20] = (jj & 1) ? rb : ra;      // this interaction's record
+        T (&rn)[20] = (jj & 1) ? ra : rb;      // the next one's
+        if constexpr (RECPF && V4_RECPF_AT == 0) {      // the record of interaction MC + 1 (row MLSTHG of the table repeats the last one)
+          const T* rp = tb.DIAREC[MC < MLST ? MC : MLST];
+#pragma unroll
+          for (int i = 0; i < 20; i++) rn[i] = rp[i];
+        }
         const int c0 = (1 + jj) & 7, cm = (1 + jj + 4) & 7, cm1 = (1 + jj + 5) & 7, cp = (1 + jj + 2) & 7, cp1 = (1 + jj + 3) & 7;
         const int m = MC - 5;   // row that is complete after this interaction (updated at the top of the next one)
         // ---- stage 1: row MC-4 back from its staging row (rotated reads at fixed addresses), the factors of rows MC-5 and MC-4
@@ -1774,15 +1836,23 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         const T* cg = tb.DIACF[MC - 1];
         const T* cs = cg + 12;
         const T GW1 = cg[1], GW2 = cg[2], GW3 = cg[3], GW4 = cg[4], GW5 = cg[5], GW6 = cg[6], GW7 = cg[7], GW8 = cg[8];
-        const T* cw = tb.DIAW[MC - 1];      // the separable form (WIN): frequency factors of the gathers and of the scatter
-        const T FTEMP = cg[9] * enh_of(MC <= MLST ? MC : MLST);
+        const T* cw = RECPF ? rc + 4 : tb.DIAW[MC - 1];      // the separable form (WIN): frequency factors of the gathers and of the scatter (words 4 .. 15)
+        const T cg9 = RECPF ? rc[0] : cg[9], cg10 = RECPF ? rc[1] : cg[10], cg11 = RECPF ? rc[2] : cg[11];
+        const T cg28 = RECPF ? rc[3] : cg[28], cg29 = RECPF ? rc[4] : cg[29], cg30 = RECPF ? rc[5] : cg[30], cg31 = RECPF ? rc[6] : cg[31];
+        const T FTEMP = cg9 * enh_of(MC <= MLST ? MC : MLST);
         const T FKLAMPA = cs[0], FKLAMPB = cs[1], FKLAMP2 = cs[2], FKLAMP1 = cs[3];
         const T FKLAPA2 = cs[4], FKLAPB2 = cs[5], FKLAP12 = cs[6], FKLAP22 = cs[7];
         const T FKLAMMA = cs[8], FKLAMMB = cs[9], FKLAMM2 = cs[10], FKLAMM1 = cs[11];
         const T FKLAMA2 = cs[12], FKLAMB2 = cs[13], FKLAM12 = cs[14], FKLAM22 = cs[15];
-        const T FTAIL = cg[31];   // the tail factor RNLCOEF(1), or 1 between MFR1STFR and MFRLSTFR where the reference skips it (x 1 is exact)
+        const T FTAIL = cg31;   // the tail factor RNLCOEF(1), or 1 between MFR1STFR and MFRLSTFR where the reference skips it (x 1 is exact)
+        if constexpr (RECPF && V4_RECPF_AT == 1) {      // (the same in front of the row update, held there)
+          const T* rp = tb.DIAREC[MC < MLST ? MC : MLST];
+#pragma unroll
+          for (int i = 0; i < 20; i++) rn[i] = rp[i];
+          __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- meanwhile: the row the previous interaction completed
-        if (m - 1 >= 0 && m - 1 < UPD_LIM) update_row(m - 1, aS[(jj + 4) & 7], aF[(jj + 4) & 7], wiq[(jj + 3) & 3], cg[28], cg[29], cg[30], cg[11]);
+        if (m - 1 >= 0 && m - 1 < UPD_LIM) update_row(m - 1, aS[(jj + 4) & 7], aF[(jj + 4) & 7], wiq[(jj + 3) & 3], cg28, cg29, cg30, cg11);
         // the dissipation coefficient of row m (sdissip_ard.F90:117-314) from the saturation spectrum and the maximum the previous
         // interaction left in flight
         if constexpr (JAN) {   // SDISSIP_JAN: the rate of row m sits in the saturation slot of the factor table
@@ -1943,7 +2013,10 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         } else {
           fR[(jj + 4) & 7] = *reinterpret_cast<const V2<T>*>(tF + hi35(MC + 3) * RS);
         }
-        bs_p = bsat; bm_p = bm1; e3_p = e3; e4_p = e4; sig_p = cg[10];
+        bs_p = bsat; bm_p = bm1; e3_p = e3; e4_p = e4; sig_p = cg10;
+        if constexpr (RECPF) {      // the next record is complete by now: pinned (not re-loaded piecemeal), it becomes the current one
+          v4_pin10(rn, 0); v4_pin10(rn, 10);
+        }
         V4SYNC();
       }
     }

@@ -217,6 +217,9 @@ __device__ __forceinline__ V2<T> v4_at(const T* row, const int (&sh)[2 * NSH + 1
 #ifndef V4_RECPF
 #define V4_RECPF 1
 #endif
+#ifndef V4_RECPF_DP
+#define V4_RECPF_DP 0      // 1: the SINPUT rows' constants fetched ahead in double precision as well (experiment)
+#endif
 #ifndef V4_RECPF_AT
 #define V4_RECPF_AT 0      // where the sweep issues the loads of the next record: 0 at the top of the interaction, 1 in front of the row update
 #endif
@@ -509,7 +512,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
   V2<T> cw_n = *reinterpret_cast<const V2<T>*>(L.fac4 + Q4_CINV);
   T zcn_n = L.zcn[0];
   // V4_RECPF: the row's record of module constants one row ahead as well (its scalar load would otherwise be waited for where it is issued)
-  constexpr bool RPF = (V4_RECPF != 0) && sizeof(T) == 4;
+  constexpr bool RPF = (V4_RECPF != 0) && (sizeof(T) == 4 || V4_RECPF_DP != 0);
   T rw_n[6];
   if constexpr (RPF) {
 #pragma unroll

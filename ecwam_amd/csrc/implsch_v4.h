@@ -1030,6 +1030,9 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     L.rDFIM = tb.DFIM[mi]; L.rDFIMOFR = tb.DFIMOFR[mi]; L.rDFIMFR = tb.DFIMFR[mi]; L.rZPIFR = tb.ZPIFR[mi]; L.rRHOWG = tb.RHOWG_DFIM[mi];
     L.rCOFRM4 = tb.COFRM4[mi]; L.rFLMAX = tb.FLMAX[mi];
   }
+  // V4_RECPF: the module constants of a row from the lane-held copies of the tables above (v_readlane) instead of a scalar load per row
+  // that is waited for where it is issued (the row loops of SDEPTHLIM / FKMEAN and FEMEANWS)
+  constexpr bool RLANE = (V4_RECPF != 0) && (sizeof(T) == 4 || V4_RECPF_DP != 0);
   L.sinth = V2<T>{tb.SINTH[2 * j], tb.SINTH[2 * j + 1]};
   L.costh = V2<T>{tb.COSTH[2 * j], tb.COSTH[2 * j + 1]};
   T* c = L.c;
@@ -1223,7 +1226,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       V2<T> s = z2;
       for (int m = 0; m < NFRE; m++) {
         const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
-        s.x = s.x + tb.SINROW[m][1] * (f.x + f.y);
+        s.x = s.x + (RLANE ? lane_get(L.rDFIM, m) : tb.SINROW[m][1]) * (f.x + f.y);
       }
       {
         const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + (NFRE - 1) * RS);
@@ -1243,9 +1246,9 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       f.x = m_max(f.x, flo); f.y = m_max(f.y, flo);
       const T t = f.x + f.y;
       const T* row = tb.SINROW[m];
-      const T dfm = row[1], sqm = L.sq[m], sig = row[0];
-      s0 = s0 + V2<T>{dfm, row[5]} * t;
-      s1 = s1 + V2<T>{row[6], fs_div<32>(dfm, sqm)} * t;
+      const T dfm = RLANE ? lane_get(L.rDFIM, m) : row[1], sqm = L.sq[m], sig = RLANE ? lane_get(L.rZPIFR, m) : row[0];
+      s0 = s0 + V2<T>{dfm, RLANE ? lane_get(L.rDFIMOFR, m) : row[5]} * t;
+      s1 = s1 + V2<T>{RLANE ? lane_get(L.rDFIMFR, m) : row[6], fs_div<32>(dfm, sqm)} * t;
       s2.x = s2.x + (sqm * dfm) * t;
       if (last) {
         s2.y = t;
@@ -2079,7 +2082,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
       const T* row = tb.SINROW[m];
       const V2<T> x = {((xm0 >> m) & 1ull) ? f.x : T(0), ((xm1 >> m) & 1ull) ? f.y : T(0)};
-      we = we + V2<T>{row[1], row[5]} * (x.x + x.y);
+      we = we + V2<T>{RLANE ? lane_get(L.rDFIM, m) : row[1], RLANE ? lane_get(L.rDFIMOFR, m) : row[5]} * (x.x + x.y);
       wl = x;
     }
     femws_finish(we, wl, FMEANWS, EMEANWS);

@@ -218,7 +218,7 @@ __device__ __forceinline__ V2<T> v4_at(const T* row, const int (&sh)[2 * NSH + 1
 #define V4_RECPF 1
 #endif
 #ifndef V4_RECPF_DP
-#define V4_RECPF_DP 0      // 1: the SINPUT rows' constants fetched ahead in double precision as well (experiment)
+#define V4_RECPF_DP 0      // double precision (experiments): bit 1 the SINPUT rows' constants fetched ahead, bit 2 the lane-held tables in the unrolled row loops
 #endif
 #ifndef V4_RECPF_AT
 #define V4_RECPF_AT 0      // where the sweep issues the loads of the next record: 0 at the top of the interaction, 1 in front of the row update
@@ -512,7 +512,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
   V2<T> cw_n = *reinterpret_cast<const V2<T>*>(L.fac4 + Q4_CINV);
   T zcn_n = L.zcn[0];
   // V4_RECPF: the row's record of module constants one row ahead as well (its scalar load would otherwise be waited for where it is issued)
-  constexpr bool RPF = (V4_RECPF != 0) && (sizeof(T) == 4 || V4_RECPF_DP != 0);
+  constexpr bool RPF = (V4_RECPF != 0) && (sizeof(T) == 4 || (V4_RECPF_DP & 1) != 0);
   T rw_n[6];
   if constexpr (RPF) {
 #pragma unroll
@@ -1032,7 +1032,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   }
   // V4_RECPF: the module constants of a row from the lane-held copies of the tables above (v_readlane) instead of a scalar load per row
   // that is waited for where it is issued (the row loops of SDEPTHLIM / FKMEAN and FEMEANWS)
-  constexpr bool RLANE = (V4_RECPF != 0) && (sizeof(T) == 4 || V4_RECPF_DP != 0);
+  constexpr bool RLANE = (V4_RECPF != 0) && (sizeof(T) == 4 || (V4_RECPF_DP & 2) != 0);
   L.sinth = V2<T>{tb.SINTH[2 * j], tb.SINTH[2 * j + 1]};
   L.costh = V2<T>{tb.COSTH[2 * j], tb.COSTH[2 * j + 1]};
   T* c = L.c;

@@ -673,12 +673,27 @@ __device__ void v4_sinput_n(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, co
   const V2<T> rcos = {f_rcp(coswdif.x), f_rcp(coswdif.y)};
   T GAMNORMA[2] = {T(1), T(1)};
   const T* tF = L.tile + L.own;
+  constexpr bool RPF = (V4_RECPF != 0) && sizeof(T) == 4;      // the next row's module constants fetched ahead (see v4_sinput)
+  T rw_n[6];
+  if constexpr (RPF) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) rw_n[i] = tb.SINROW[0][i];
+  }
 #pragma unroll 2
   for (int m = 0; m < NFRE; m++) {
+    T rw[6];
+    if constexpr (RPF) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) rw[i] = rw_n[i];
+      const int mn = m + 1 < NFRE ? m + 1 : m;
+#pragma unroll
+      for (int i = 0; i < 6; i++) rw_n[i] = tb.SINROW[mn][i];
+      __builtin_amdgcn_sched_barrier(0);
+    }
     const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
     const V2<T> cw = *reinterpret_cast<const V2<T>*>(L.fac4 + m * 4 + Q4_CINV);
     const T ZCN = L.zcn[m], cinv_m = cw.x, XNGAMCONST = xng[m];
-    const T* row = tb.SINROW[m];   // one scalar load: ZPIFR, DFIM, C5, T1, RHOWG_DFIM, DFIMOFR of the row
+    const T* row = RPF ? rw : tb.SINROW[m];   // one scalar load: ZPIFR, DFIM, C5, T1, RHOWG_DFIM, DFIMOFR of the row
     const T SIGm = row[0], DFIMm = row[1];
     const T DSTAB1 = LLSNEG ? (row[2] * AIRD_PVISC) * cw.y : T(0);
     const T CNSN = (SIGm * CONST1) * RAORW;
@@ -750,6 +765,7 @@ __device__ void v4_sinput_n(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, co
     const V2<T> x = {xl0 ? f.x : T(0), xl1 ? f.y : T(0)};
     wse = wse + V2<T>{DFIMm, row[5]} * (x.x + x.y);
     wslast = x;
+    if constexpr (RPF) v4_pin6(rw_n);
   }
   WSYNC();
 }
@@ -788,12 +804,27 @@ __device__ void v4_sinput_jan(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, 
 #pragma unroll
   for (int s = 0; s < NS; s++) { rX[s] = T(0); rY[s] = T(0); }
   const T* tF = L.tile + L.own;
+  constexpr bool RPF = (V4_RECPF != 0) && sizeof(T) == 4;      // the next row's module constants fetched ahead (see v4_sinput)
+  T rw_n[6];
+  if constexpr (RPF) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) rw_n[i] = tb.SINROW[0][i];
+  }
 #pragma unroll 2
   for (int m = 0; m < NFRE; m++) {
+    T rw[6];
+    if constexpr (RPF) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) rw[i] = rw_n[i];
+      const int mn = m + 1 < NFRE ? m + 1 : m;
+#pragma unroll
+      for (int i = 0; i < 6; i++) rw_n[i] = tb.SINROW[mn][i];
+      __builtin_amdgcn_sched_barrier(0);
+    }
     const V2<T> f = *reinterpret_cast<const V2<T>*>(tF + m * RS);
     const V2<T> cw = *reinterpret_cast<const V2<T>*>(L.fac4 + m * 4 + Q4_CINV);   // CINV, WAVNUM
     const T ZCN = L.zcn[m], cinv_m = cw.x;
-    const T* row = tb.SINROW[m];   // ZPIFR, DFIM, -, -, RHOWG_DFIM, DFIMOFR of the row
+    const T* row = RPF ? rw : tb.SINROW[m];   // ZPIFR, DFIM, -, -, RHOWG_DFIM, DFIMOFR of the row
     const T SIGm = row[0], DFIMm = row[1];
     const T ZTANHKD = (SIGm * SIGm) * f_rcp(tb.G * cw.y);
     const T CNSN = (SIGm * CONST1) * ZTANHKD * RAORW;
@@ -860,6 +891,7 @@ __device__ void v4_sinput_jan(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, 
     const V2<T> x = {xl0 ? f.x : T(0), xl1 ? f.y : T(0)};
     wse = wse + V2<T>{DFIMm, row[5]} * (x.x + x.y);
     wslast = x;
+    if constexpr (RPF) v4_pin6(rw_n);
   }
   WSYNC();
 }

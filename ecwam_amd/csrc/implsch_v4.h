@@ -220,6 +220,15 @@ __device__ __forceinline__ V2<T> v4_at(const T* row, const int (&sh)[2 * NSH + 1
 #ifndef V4_RECPF_DP
 #define V4_RECPF_DP 0      // double precision (experiments): bit 1 the SINPUT rows' constants fetched ahead, bit 2 the lane-held tables in the unrolled row loops
 #endif
+// Double precision (V4_RECV): two records are 76 scalar registers, so the sweep's record is fetched differently there:
+//   2 (the product)  the record of THIS interaction by scalar loads issued together at its top and held there by a scheduling barrier: five
+//      loads in one place and 70 lgkmcnt(0) waits per eight interactions instead of seven in six places and 91; - 4 % kernel time, bit-identical
+//   1  one interaction ahead in VECTOR registers by wave-uniform vector loads (their counter is its own): the compiler parks the 40 values in
+//      accumulation registers and moves them in and out (+ 28 % vector instructions in the sweep): the same time as 0
+//   0  as the compiler places them
+#ifndef V4_RECV
+#define V4_RECV 2
+#endif
 #ifndef V4_RECPF_AT
 #define V4_RECPF_AT 0      // where the sweep issues the loads of the next record: 0 at the top of the interaction, 1 in front of the row update
 #endif
@@ -1830,22 +1839,37 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     const int UPD_LIM = whole ? NFRE : mijmax;                                      // rows m < UPD_LIM (0-based) are updated
     const int DIA_LIM = whole ? MLST : (mijmax + 4 < MLST ? mijmax + 4 : MLST);     // interactions MC <= DIA_LIM contribute to them
     const int MC_END = whole ? MLST : (mijmax + 5 < MLST ? mijmax + 5 : MLST);      // row MIJ is updated at the top of interaction MIJ + 5
-    constexpr bool RECPF = WIN && RECPF_ON;
+    constexpr bool RECV = WIN && (V4_RECV == 1) && sizeof(T) == 8 && NANG <= 36 && !RARE;      // (see V4_RECV)
+    // V4_RECV = 2 (double precision): the record of THIS interaction by scalar loads issued together at its top and held there (one
+    // register set: two are 76 scalar registers) -- one wait per interaction instead of six
+    constexpr bool RECS = WIN && (V4_RECV == 2) && sizeof(T) == 8 && NANG <= 36 && !RARE;
+    constexpr bool RECPF = WIN && (RECPF_ON || RECV || RECS);
     T ra[20], rb[20];      // RECPF: the records of two consecutive interactions, roles alternating (the loop is unrolled by eight: static)
+    int vzero = 0;         // RECV: a zero the compiler cannot see through, added to the record's address: a vector load instead of a scalar one
+    if constexpr (RECV) asm("v_mov_b32 %0, 0" : "=v"(vzero));
     if constexpr (RECPF) {
+      const T* rp0 = tb.DIAREC[0] + vzero;
+      if constexpr (!RECS) {
 #pragma unroll
-      for (int i = 0; i < 20; i++) ra[i] = tb.DIAREC[0][i];
-      v4_pin10(ra, 0); v4_pin10(ra, 10);
+        for (int i = 0; i < 20; i++) ra[i] = rp0[i];
+      }
+      if constexpr (!RECV && !RECS) { v4_pin10(ra, 0); v4_pin10(ra, 10); }
     }
     int MCb = 0;
     for (; MCb < MC_END; MCb += 8) {
 #pragma unroll
       for (int jj = 0; jj < 8; jj++) {
         const int MC = MCb + 1 + jj;
-        T (&rc)[20] = (jj & 1) ? rb : ra;      // this interaction's record
+        T (&rc)[20] = (RECS || !(jj & 1)) ? ra : rb;      // this interaction's record
         T (&rn)[20] = (jj & 1) ? ra : rb;      // the next one's
-        if constexpr (RECPF && V4_RECPF_AT == 0) {      // the record of interaction MC + 1 (row MLSTHG of the table repeats the last one)
-          const T* rp = tb.DIAREC[MC < MLST ? MC : MLST];
+        if constexpr (RECS) {
+          const T* rp = tb.DIAREC[MC - 1];
+#pragma unroll
+          for (int i = 0; i < 20; i++) ra[i] = rp[i];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (RECPF && !RECS && V4_RECPF_AT == 0) {      // the record of interaction MC + 1 (row MLSTHG of the table repeats the last one)
+          const T* rp = tb.DIAREC[MC < MLST ? MC : MLST] + vzero;
 #pragma unroll
           for (int i = 0; i < 20; i++) rn[i] = rp[i];
         }
@@ -1883,7 +1907,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         const T FKLAMMA = cs[8], FKLAMMB = cs[9], FKLAMM2 = cs[10], FKLAMM1 = cs[11];
         const T FKLAMA2 = cs[12], FKLAMB2 = cs[13], FKLAM12 = cs[14], FKLAM22 = cs[15];
         const T FTAIL = cg31;   // the tail factor RNLCOEF(1), or 1 between MFR1STFR and MFRLSTFR where the reference skips it (x 1 is exact)
-        if constexpr (RECPF && V4_RECPF_AT == 1) {      // (the same in front of the row update, held there)
+        if constexpr (RECPF && !RECS && V4_RECPF_AT == 1) {      // (the same in front of the row update, held there)
           const T* rp = tb.DIAREC[MC < MLST ? MC : MLST];
 #pragma unroll
           for (int i = 0; i < 20; i++) rn[i] = rp[i];
@@ -2052,8 +2076,12 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
           fR[(jj + 4) & 7] = *reinterpret_cast<const V2<T>*>(tF + hi35(MC + 3) * RS);
         }
         bs_p = bsat; bm_p = bm1; e3_p = e3; e4_p = e4; sig_p = cg10;
-        if constexpr (RECPF) {      // the next record is complete by now: pinned (not re-loaded piecemeal), it becomes the current one
+        if constexpr (RECPF && !RECV && !RECS) {      // the next record is complete by now: pinned (not re-loaded piecemeal), it becomes the current one
           v4_pin10(rn, 0); v4_pin10(rn, 10);
+        }
+        if constexpr (RECV) {      // (the same for vector registers: the loads stay where they are issued)
+#pragma unroll
+          for (int i = 0; i < 20; i++) asm volatile("" :: "v"(rn[i]));
         }
         V4SYNC();
       }

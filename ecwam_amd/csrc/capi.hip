@@ -701,6 +701,7 @@ int ecwam_hip_propags2_refra(ecwam_hip_ctx* c, const void* f1, void* f3, int n, 
                              copy_rest ? 1 : 0, (hipStream_t)stream);
 }
 
+static int implsch_reserve_on(ecwam_hip_ctx* c, int npts, hipStream_t s, bool sync);
 int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws,
                       double* wam2nemo, void* dbg, void* stream) {
   if (!c) return fail("null context");
@@ -724,7 +725,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   const int alt = (c->p.iphys == 0 ? 1 : 0) | (c->p.isnonlin == 1 ? 2 : 0);
   const bool common_ok = !rare4 && (alt == 0 || (!ext && alt != 3));
   {
-    if (int rc2 = ecwam_hip_implsch_reserve(c, kijl)) return rc2;   // no-op once the buffer covers kijl
+    if (int rc2 = implsch_reserve_on(c, kijl, s, false)) return rc2;   // no-op once the buffer covers kijl
     if (!common_ok)
       DISPATCH(rc = launch_implsch4r<float>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->wi, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, c->p.iphys == 0 ? 1 : 0, s),
                rc = launch_implsch4r<double>(c->dtab, kijs, kijl, fl1, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, c->fast_g, c->fast_gk, c->wi, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, c->p.iphys == 0 ? 1 : 0, s));
@@ -747,15 +748,18 @@ int ecwam_hip_set_fastwave_copy(ecwam_hip_ctx* c, void* g, int g_nfre) {
   return 0;
 }
 
-int ecwam_hip_implsch_reserve(ecwam_hip_ctx* c, int npts) {
-  if (!c) return fail("ecwam_hip_implsch_reserve: null context");
+// grows the context's per-point buffers to npts points.  `s`: the stream of the IMPLSCH call that needs them (the rows are zeroed ON that
+// stream: a hipMemset on the null stream is not ordered against a non-blocking stream -- the caller's kernels could write their rows
+// before the zeroes arrive; found by test_implsch_in_blocks_is_bit_identical in a long test process), or sync = true for the set-up call
+static int implsch_reserve_on(ecwam_hip_ctx* c, int npts, hipStream_t s, bool sync) {
   HIPCHK(hipSetDevice(c->device));
   const size_t need = (size_t)(npts > 0 ? npts : 0) * implsch4_fin_row() * c->real_bytes;
   if (need > c->fin_bytes) {   // hipFree waits for the kernels still reading the old rows
     if (c->fin) HIPCHK(hipFree(c->fin));
     c->fin = nullptr; c->fin_bytes = 0;
     HIPCHK(hipMalloc(&c->fin, need));
-    HIPCHK(hipMemset(c->fin, 0, need));
+    HIPCHK(hipMemsetAsync(c->fin, 0, need, s));
+    if (sync) HIPCHK(hipStreamSynchronize(s));
     c->fin_bytes = need;
   }
   // the split kernel pair parks the wind-input coefficient of every bin between its two halves
@@ -768,6 +772,11 @@ int ecwam_hip_implsch_reserve(ecwam_hip_ctx* c, int npts) {
     c->wi_bytes = need_wi;
   }
   return 0;
+}
+
+int ecwam_hip_implsch_reserve(ecwam_hip_ctx* c, int npts) {
+  if (!c) return fail("ecwam_hip_implsch_reserve: null context");
+  return implsch_reserve_on(c, npts, nullptr, true);
 }
 
 int ecwam_hip_implsch_generation_used(ecwam_hip_ctx* c) { return c ? c->implsch_last : 0; }

@@ -1842,7 +1842,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     constexpr bool RECV = WIN && (V4_RECV == 1) && sizeof(T) == 8 && NANG <= 36 && !RARE;      // (see V4_RECV)
     // V4_RECV = 2 (double precision): the record of THIS interaction by scalar loads issued together at its top and held there (one
     // register set: two are 76 scalar registers) -- one wait per interaction instead of six
-    constexpr bool RECS = WIN && (V4_RECV == 2) && sizeof(T) == 8 && NANG <= 36 && !RARE;
+    constexpr bool RECS = WIN && !RARE && (V4_RECV == 2) && sizeof(T) == 8;      // (sp at 48 directions: its spilled scalar registers push the vector registers past 256)
     constexpr bool RECPF = WIN && (RECPF_ON || RECV || RECS);
     T ra[20], rb[20];      // RECPF: the records of two consecutive interactions, roles alternating (the loop is unrolled by eight: static)
     int vzero = 0;         // RECV: a zero the compiler cannot see through, added to the record's address: a vector load instead of a scalar one

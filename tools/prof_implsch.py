@@ -15,7 +15,8 @@ from ecwam_amd.tables import Config  # noqa: E402
 prec = sys.argv[1] if len(sys.argv) > 1 else "sp"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 131072
 FLAGS = {"A": {}, "B": dict(llgcbz0=True, llnormagam=True)}[sys.argv[4] if len(sys.argv) > 4 else "A"]   # flag set
-cfg = Config(nang=36, nfre=36, nfre_red=36, idelt=450, idelpro=450, **FLAGS)
+NANG = int(os.environ.get("ECWAM_PROF_NANG", "36"))      # 36 (the benchmark), 24, 12 or 48 directions
+cfg = Config(nang=NANG, nfre=36, nfre_red=36, idelt=450, idelpro=450, **FLAGS)
 case = H.make_point_case(4096, cfg, prec, spectra="mixed")
 ctx = api.HipContext(case["tables"])
 if len(sys.argv) > 3:

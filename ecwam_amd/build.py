@@ -66,10 +66,12 @@ VARIANTS = {"": FAST_DIV, "exactdiv": ["-DECWAM_HIP_STRICT=0"], "strict1": ["-DE
             "norecpf": FAST_DIV + ["-DV4_RECPF=0"], "recpf1": FAST_DIV + ["-DV4_RECPF=1", "-DV4_RECPF_AT=1"],
             "recpfdp": FAST_DIV + ["-DV4_RECPF_DP=1"], "rlanedp": FAST_DIV + ["-DV4_RECPF_DP=2"],
             # double precision, the sweep's record (implsch_v4.h, V4_RECV; the product = 2): one interaction ahead in vector registers / as the compiler places the loads
-            "recv": FAST_DIV + ["-DV4_RECV=1"], "norecs": FAST_DIV + ["-DV4_RECV=0"]}
+            "recv": FAST_DIV + ["-DV4_RECV=1"], "norecs": FAST_DIV + ["-DV4_RECV=0"],
+            # the all-reduces of a SINPUT row one after the other (rounds 2 - 5a) instead of in one batch (V4_REDN)
+            "noredn": FAST_DIV + ["-DV4_REDN=0"], "redndp": FAST_DIV + ["-DV4_REDN=3"]}
 # variants that rebuild only some of the IMPLSCH translation units (the other objects are the product's)
 VARIANT_SOURCES = {"rdp": ("implsch4rd.hip",), "rdpO1": ("implsch4rd.hip",), "rdpchk": ("implsch4rd.hip",), "rdps": ("implsch4rd.hip",),
-                   "split": ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip"), "o2": ("implsch4.hip",), "rowsplit": ("implsch4.hip",), "diaold": ("implsch4.hip",), "stagger": ("implsch4.hip",), "stagger6": ("implsch4.hip",), "shuf1": ("implsch4.hip",), "plainhalves": ("implsch4.hip",), "noread2": ("implsch4.hip",), "norecpf": ("implsch4.hip",), "recpf1": ("implsch4.hip",), "recpfdp": ("implsch4.hip",), "rlanedp": ("implsch4.hip",), "recv": ("implsch4.hip",), "norecs": ("implsch4.hip",)}
+                   "split": ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip"), "o2": ("implsch4.hip",), "rowsplit": ("implsch4.hip",), "diaold": ("implsch4.hip",), "stagger": ("implsch4.hip",), "stagger6": ("implsch4.hip",), "shuf1": ("implsch4.hip",), "plainhalves": ("implsch4.hip",), "noread2": ("implsch4.hip",), "norecpf": ("implsch4.hip",), "recpf1": ("implsch4.hip",), "recpfdp": ("implsch4.hip",), "rlanedp": ("implsch4.hip",), "recv": ("implsch4.hip",), "norecs": ("implsch4.hip",), "noredn": ("implsch4.hip",), "redndp": ("implsch4.hip",)}
 
 INCLUDE = os.path.join(HERE, "..", "include", "ecwam_hip.h")
 

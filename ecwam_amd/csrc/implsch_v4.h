@@ -156,6 +156,58 @@ __device__ __forceinline__ T v4_allsum1(T v, const V4Rot<T>& r) {
   }
 }
 
+// N independent all-reduces at once (V4_REDN): the exchanges of every stage are issued together and waited for together -- N quantities
+// cost the LDS round trips of one.  The first NB come back on every lane of the point; the others (G = 18) are complete on the sixteen
+// lanes of the point's DPP row only, which is what v4_row_total_to_lds needs.  Per quantity the operations and their order are those of
+// v4_allsum / v4_allsum1 / v4_row_total_to_lds: the same bits.
+template <int G, int N, int NB, typename T>
+__device__ __forceinline__ void v4_allsum_n(T (&v)[N], const V4Rot<T>& r) {
+  T e[N];
+  if constexpr (G == 18) {
+#pragma unroll
+    for (int i = 0; i < N; i++) e[i] = v4_bp(r.a0, v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = v[i] + r.fold * e[i];
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = v[i] + v4_dpp<V4_ROW_ROR(8)>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = v[i] + v4_dpp<V4_ROW_ROR(4)>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = v[i] + v4_dpp<V4_ROW_ROR(2)>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = v[i] + v4_dpp<V4_ROW_ROR(1)>(v[i]);
+#pragma unroll
+    for (int i = 0; i < NB; i++) e[i] = v4_bp(r.a1, v[i]);
+#pragma unroll
+    for (int i = 0; i < NB; i++) v[i] = e[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; i++) e[i] = v4_bp(r.a0, v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = v[i] + e[i];
+    if constexpr (G >= 12) {
+#pragma unroll
+      for (int i = 0; i < N; i++) e[i] = v4_bp(r.a1, v[i]);
+#pragma unroll
+      for (int i = 0; i < N; i++) v[i] = v[i] + e[i];
+    }
+    if constexpr (G == 24) {
+#pragma unroll
+      for (int i = 0; i < N; i++) e[i] = v4_bp(r.a2, v[i]);
+#pragma unroll
+      for (int i = 0; i < N; i++) v[i] = v[i] + e[i];
+    }
+    T f[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) { e[i] = v4_bp(r.a3, v[i]); f[i] = v4_bp(r.a4, v[i]); }
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = v[i] + (e[i] + f[i]);
+  }
+}
+#ifndef V4_REDN
+#define V4_REDN 1
+#endif
+
 // maximum over the lanes of a point (the RARE build's PEAK_ANG)
 template <int G, typename T>
 __device__ __forceinline__ T v4_allmax1(T v, const V4Rot<T>& r) {
@@ -606,7 +658,46 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
     sp = AVG * sp;
     fl = AVG * fl;
     T xrow = T(0), yrow = T(0);
+    // V4_REDN (single precision, where the branch above is always taken): the all-reduces of the row -- the stress of each gust state and, in
+    // the second call, the row's positive input -- in one batch: two LDS round trips per row instead of five
+    constexpr bool REDN = (V4_REDN != 0) && sizeof(T) == 4;
+    if constexpr (REDN) {
+      constexpr int NR = 2 * NGST + (LLSNEG ? 1 : 0);
+      T red[NR];
+#pragma unroll
+      for (int ig = 0; ig < NGST; ig++) {
+        const V2<T> sx = SLP[ig] * L.sinth, sy = SLP[ig] * L.costh;
+        red[2 * ig] = sx.x + sx.y; red[2 * ig + 1] = sy.x + sy.y;
+      }
+      if constexpr (LLSNEG) red[2 * NGST] = sp.x + sp.y;
+      v4_allsum_n<G, NR, (G == 18 ? 2 * NGST : NR)>(red, L.rot);
+#pragma unroll
+      for (int ig = 0; ig < NGST; ig++) {
+        if (ig == 0) { vXS.x = vXS.x + CONSTF * red[0]; vYS.x = vYS.x + CONSTF * red[1]; }
+        else { vXS.y = vXS.y + CONSTF * red[2 * ig]; vYS.y = vYS.y + CONSTF * red[2 * ig + 1]; }
+        xrow += red[2 * ig];
+        yrow += red[2 * ig + 1];
+      }
+      xrow = AVG * xrow; yrow = AVG * yrow;
+      if constexpr (LLSNEG) gsp[m] = red[2 * NGST];      // (v4_row_total_to_lds: every lane of the row stores the same total)
+    } else
     if (sizeof(T) == 4 || __builtin_amdgcn_ballot_w64(xl0 || xl1) != 0ull) {
+      if constexpr ((V4_REDN & 2) != 0) {      // (double precision: the stress sums of the gust states in one batch, inside the branch)
+        T red[2 * NGST];
+#pragma unroll
+        for (int ig = 0; ig < NGST; ig++) {
+          const V2<T> sx = SLP[ig] * L.sinth, sy = SLP[ig] * L.costh;
+          red[2 * ig] = sx.x + sx.y; red[2 * ig + 1] = sy.x + sy.y;
+        }
+        v4_allsum_n<G, 2 * NGST, 2 * NGST>(red, L.rot);
+#pragma unroll
+        for (int ig = 0; ig < NGST; ig++) {
+          if (ig == 0) { vXS.x = vXS.x + CONSTF * red[0]; vYS.x = vYS.x + CONSTF * red[1]; }
+          else { vXS.y = vXS.y + CONSTF * red[2 * ig]; vYS.y = vYS.y + CONSTF * red[2 * ig + 1]; }
+          xrow += red[2 * ig];
+          yrow += red[2 * ig + 1];
+        }
+      } else {
 #pragma unroll
       for (int ig = 0; ig < NGST; ig++) {
         const V2<T> sx = SLP[ig] * L.sinth, sy = SLP[ig] * L.costh;
@@ -615,6 +706,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
         else { vXS.y = vXS.y + CONSTF * xs.x; vYS.y = vYS.y + CONSTF * xs.y; }
         xrow += xs.x;
         yrow += xs.y;
+      }
       }
       xrow = AVG * xrow; yrow = AVG * yrow;
     }
@@ -636,7 +728,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
       apl = apl + (fl * f - sp) * row[4];
       *reinterpret_cast<V2<T>*>(gfl + (size_t)m * NANG) = fl;
       // the row's positive input summed over the directions -> the point's row table (weighted below the cut-off once MIJ is known)
-      v4_row_total_to_lds<G, T>(sp.x + sp.y, L.rot, gsp, m);
+      if constexpr (!REDN) v4_row_total_to_lds<G, T>(sp.x + sp.y, L.rot, gsp, m);
     }
     if (xl0) xm0 |= (1ull << m);
     if (xl1) xm1 |= (1ull << m);

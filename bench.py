@@ -179,6 +179,10 @@ def main() -> None:
     ap.add_argument("--host-state", action="store_true",
                     help="DIAGNOSTIC, never the reported value: the spectra enter from and return to pinned host memory every step (what a caller "
                          "that hands over host buffers would pay over PCIe; DESIGN.md section 6)")
+    ap.add_argument("--fused", default="off", choices=["off", "on"],
+                    help="the 1:1 step as ONE kernel (ecwam_hip_propags2_implsch: PROPAGS2 inside IMPLSCH's tile load; bit-identical to the two "
+                         "kernels) where a build covers the configuration")
+    ap.add_argument("--fused-flags", type=int, default=0, help="diagnostics: flags of ecwam_hip_propags2_implsch (1: natural workgroup order; 2: the probe)")
     ap.add_argument("--irefra", type=int, default=0, choices=[0, 1, 2, 3],
                     help="refraction: 0 none (BASELINE configurations), 1 depth, 2 currents, 3 both (synthetic current field)")
     a = ap.parse_args()
@@ -290,7 +294,16 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
+    fused = a.fused == "on" and a.adv_per_source == 1 and m.fused_available()
+    if a.fused == "on" and a.host_state:
+        raise SystemExit("bench.py: --fused and --host-state exclude each other")
+    if a.fused == "on" and not fused:
+        raise SystemExit("bench.py: --fused on, but no one-kernel build covers this configuration")
+
     def step_untimed():
+        if fused:
+            m.step_fused(flags=a.fused_flags)
+            return
         for _ in range(a.adv_per_source):
             m.propag()
         m.newwind()
@@ -317,6 +330,12 @@ def main() -> None:
                 m.fl1[: m.n].copy_(host_fl, non_blocking=True)
                 m.gfast_valid = False
             e[0].record()
+            if fused:             # NEWWIND, then halo exchange (N > 1) + the one kernel that advects and integrates
+                e[1].record()
+                e[2].record()
+                m.step_fused(flags=a.fused_flags)
+                e[3].record()
+                continue
             for _ in range(a.adv_per_source):
                 m.propag()        # halo exchange (N > 1) + PROPAGS2 (+ fast-wave sub-steps)
             e[1].record()

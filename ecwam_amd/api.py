@@ -231,6 +231,39 @@ class HipContext:
             pw = wam2nemo.data_ptr()
         self._chk(self.lib.ecwam_hip_implsch(self._h, kijs, kijl, *a, pw, pd, _stream_ptr()))
 
+    # -- the one-kernel step: PROPAGS2 inside IMPLSCH's tile load (ecwam_hip_propags2_implsch)
+    def fused_supported(self) -> bool:
+        return bool(self.lib.ecwam_hip_propags2_implsch_supported(self._h))
+
+    def propags2_implsch(self, f1, f3, grid_dev: dict, cgroup_ext, delpro: float, kijs, kijl, wvprpt, ff, intf, mij, xllws, nd3s=1, nd3e=None,
+                         wam2nemo=None, flags: int = 0):
+        """Rows [kijs, kijl): advect from the rows of f1 (read only) and integrate the source terms; the new spectrum goes to the rows of f3.
+        Bit for bit propags2_otf(f1 -> f3) followed by implsch(f3)."""
+        nd3e = self.NR if nd3e is None else nd3e
+        g = grid_dev
+        n, nland, ngy = g["n"], g["nland"], g["ngy"]
+        nrow = f1.shape[0]
+        if not (0 <= kijs <= kijl <= n) or nland >= nrow or cgroup_ext.shape[0] != nrow or f3.shape[0] < kijl:
+            raise ValueError("PROPAGS2 + IMPLSCH: KIJS/KIJL outside the neighbour tables, or F1 / CGROUP_EXT without the land row")
+        if not (kijl <= min(wvprpt.shape[0], ff.shape[0], intf.shape[0], mij.shape[0], xllws.shape[0])):
+            raise ValueError("PROPAGS2 + IMPLSCH: KIJL outside the operands")
+        pw = None
+        if wam2nemo is not None:
+            if not (wam2nemo.is_cuda and wam2nemo.dtype == torch.float64 and wam2nemo.is_contiguous() and wam2nemo.dim() == 2
+                    and wam2nemo.shape[1] == 13 and wam2nemo.shape[0] >= kijl):
+                raise ValueError("WAM2NEMO: expected contiguous float64 cuda tensor [npts >= KIJL][13]")
+            pw = wam2nemo.data_ptr()
+        args = [self._real(f1, (nrow, self.NANG, self.NFRE), "F1"), self._real(f3, (f3.shape[0], self.NANG, self.NFRE), "F3"), n, ngy, float(delpro),
+                self._int(g["kxlt"], (n,), "KXLT"), self._real(g["zdello"], (ngy,), "ZDELLO"), float(g["xdella"]),
+                self._real(g["cosph"], (ngy,), "COSPH"), self._real(g["sinph"], (ngy,), "SINPH"),
+                self._int(g["klon"], (n, 2), "KLON"), self._int(g["klat"], (n, 2, 2), "KLAT"), self._int(g["kcor"], (n, 4, 2), "KCOR"),
+                self._real(g["wlat"], (n, 2), "WLAT"), self._real(g["wcor"], (n, 4), "WCOR"),
+                self._real(cgroup_ext, (nrow, self.NFRE), "CGROUP_EXT"), self._real(g["cosphm1_ext"], (nrow,), "COSPHM1_EXT"), kijs, kijl, nd3s, nd3e,
+                self._real(wvprpt, (wvprpt.shape[0], NWPR, self.NFRE), "WVPRPT"), self._real(ff, (ff.shape[0], NFF), "FF"),
+                self._real(intf, (intf.shape[0], NINTF), "INTF"), self._int(mij, (mij.shape[0],), "MIJ"),
+                self._real(xllws, (xllws.shape[0], self.NANG, self.NFRE), "XLLWS"), pw, int(flags), _stream_ptr()]
+        self._chk(self.lib.ecwam_hip_propags2_implsch(self._h, *args))
+
     def implsch_reserve(self, npts: int) -> None:
         """Size the per-point scalar rows of the IMPLSCH kernels once, outside the time loop: ecwam_hip_implsch_reserve."""
         self._chk(self.lib.ecwam_hip_implsch_reserve(self._h, int(npts)))

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libecwam_hip.so")
-SOURCES = ["capi.hip", "propag.hip", "implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip", "outbs.hip"]
+SOURCES = ["capi.hip", "propag.hip", "implsch4.hip", "implsch4a.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip", "outbs.hip"]
 # objects that are a second compilation of another source: object name -> (source, extra flags; a later -O overrides the earlier one).
 # implsch4rd = the double precision RARE builds of k_implsch4 at -O2 (their -O3 builds fault on the device: implsch4r.hip)
 DERIVED = {"implsch4r.hip": ("implsch4r.hip", ["-DV4R_PREC=1"]), "implsch4rd.hip": ("implsch4r.hip", ["-DV4R_PREC=2", "-O2"])}
@@ -25,7 +25,7 @@ FAST_DIV = ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]
 # v_pk_mov_b32 per pair
 NO_REPACK = ["-fno-slp-vectorize", "-mllvm", "-disable-vector-combine"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
-IMPLSCH_SOURCES = ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip")
+IMPLSCH_SOURCES = ("implsch4.hip", "implsch4a.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip")
 # Build variants of the IMPLSCH translation units (the single-precision error attribution):
 #   ""         the product build: hardware reciprocal / square root / exp2 / log2 in single precision, FMA contraction on
 #   "exactdiv" every `/` and SQRT the source spells out is correctly rounded (the scalar chains per sea point: TAUT_Z0, STRESSO, FKMEAN,
@@ -68,9 +68,11 @@ VARIANTS = {"": FAST_DIV, "exactdiv": ["-DECWAM_HIP_STRICT=0"], "strict1": ["-DE
             # double precision, the sweep's record (implsch_v4.h, V4_RECV; the product = 2): one interaction ahead in vector registers / as the compiler places the loads
             "recv": FAST_DIV + ["-DV4_RECV=1"], "norecs": FAST_DIV + ["-DV4_RECV=0"],
             # the all-reduces of a SINPUT row one after the other (rounds 2 - 5a) instead of in one batch (V4_REDN)
+            # round 6: the library with the go / no-go probe of the one-kernel step (implsch4a.hip, flags bit 1 of ecwam_hip_propags2_implsch)
+            "advprobe": FAST_DIV + ["-DV4_ADV_PROBE=1"],
             "noredn": FAST_DIV + ["-DV4_REDN=0"], "redndp": FAST_DIV + ["-DV4_REDN=3"]}
 # variants that rebuild only some of the IMPLSCH translation units (the other objects are the product's)
-VARIANT_SOURCES = {"rdp": ("implsch4rd.hip",), "rdpO1": ("implsch4rd.hip",), "rdpchk": ("implsch4rd.hip",), "rdps": ("implsch4rd.hip",),
+VARIANT_SOURCES = {"advprobe": ("implsch4a.hip",), "rdp": ("implsch4rd.hip",), "rdpO1": ("implsch4rd.hip",), "rdpchk": ("implsch4rd.hip",), "rdps": ("implsch4rd.hip",),
                    "split": ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip"), "o2": ("implsch4.hip",), "rowsplit": ("implsch4.hip",), "diaold": ("implsch4.hip",), "stagger": ("implsch4.hip",), "stagger6": ("implsch4.hip",), "shuf1": ("implsch4.hip",), "plainhalves": ("implsch4.hip",), "noread2": ("implsch4.hip",), "norecpf": ("implsch4.hip",), "recpf1": ("implsch4.hip",), "recpfdp": ("implsch4.hip",), "rlanedp": ("implsch4.hip",), "recv": ("implsch4.hip",), "norecs": ("implsch4.hip",), "noredn": ("implsch4.hip",), "redndp": ("implsch4.hip",)}
 
 INCLUDE = os.path.join(HERE, "..", "include", "ecwam_hip.h")

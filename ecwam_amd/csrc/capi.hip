@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>   // types and prototypes only: librccl is loaded with dlopen when a communicator is asked for
 
 #include "dev.h"
+#include "implsch_adv_args.h"
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) {
@@ -60,6 +61,10 @@ struct ecwam_hip_ctx {
   ecwam_hip_params p;
   void* fast_g = nullptr;     // ecwam_hip_set_fastwave_copy: compact rows [ij][K][fast_gk] IMPLSCH / NOSOURCE also leave the new fast waves in
   int fast_gk = 0;
+  // one-kernel step (ecwam_hip_propags2_implsch): per-point and per-direction scalars of the CTU weights (propag.hip::k_ctu_prep)
+  void* adv_pt = nullptr;     // [npts][12]
+  size_t adv_pt_bytes = 0;
+  void* adv_dir = nullptr;    // reals [4 NANG + 4], then ints [4 NANG]
   const void* obs = nullptr;  // LSUBGRID: device OBS[n_obs][8][NFRE] (ecwam_hip_set_obstructions), read by CTUW / PROPAGS2
   int n_obs = 0;
 };
@@ -85,6 +90,8 @@ template <typename T> void launch_proenv_unpack(int, int, const void*, const voi
 template <typename T> int launch_implsch4(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, void*, int, int, int, int, int, int, hipStream_t);
 template <typename T> int launch_implsch4x(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, void*, int, int, int, int, int, int, hipStream_t);
 template <typename T> int launch_implsch4r(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, void*, int, int, int, int, int, int, hipStream_t);
+template <typename T> void launch_ctu_prep(const void*, int, int, int, double, const int*, const void*, double, const void*, const void*, const void*, const void*, const void*, void*, void*, int*, hipStream_t);
+template <typename T> int launch_implsch4_adv(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, const Implsch4AdvArgs*, int, int, int, int, int, int, hipStream_t);
 int implsch4_fin_row();
 int implsch4_split_all();
 int implsch4r_dp_split();
@@ -482,6 +489,8 @@ int ecwam_hip_destroy(ecwam_hip_ctx* c) {
   if (c->norm_scratch) (void)hipFree(c->norm_scratch);
   if (c->fin) (void)hipFree(c->fin);
   if (c->wi) (void)hipFree(c->wi);
+  if (c->adv_pt) (void)hipFree(c->adv_pt);
+  if (c->adv_dir) (void)hipFree(c->adv_dir);
   halo_release(c);
   delete c;
   return 0;
@@ -738,6 +747,58 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
     if (rc == 0) { HIPCHK(hipGetLastError()); c->implsch_last = 4; return 0; }
   }
   return fail("ecwam_hip_implsch: no build of k_implsch4 covers the configuration (ecwam_hip_create should have refused it)");
+}
+
+// the configurations the one-kernel step covers (implsch4a.hip); everything else runs ecwam_hip_propags2_otf + ecwam_hip_implsch
+static bool fused_ok(const ecwam_hip_ctx* c) {
+  const bool rare4 = c->p.lciwa2 || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin > 1 || c->p.icode != 3 || !c->p.lwvflx_snl;
+  return !rare4 && c->p.iphys == 1 && c->p.isnonlin == 0 && c->real_bytes == 4 && c->NANG == 36 && c->NFRE == 36 && c->v4_r1 == 1 && c->v4_r2 == 3 &&
+         c->v4_nh == 8 && !c->obs && !c->fast_g;
+}
+int ecwam_hip_propags2_implsch_supported(ecwam_hip_ctx* c) { return c && fused_ok(c) ? 1 : 0; }
+
+int ecwam_hip_propags2_implsch(ecwam_hip_ctx* c, const void* f1, void* f3, int n, int ngy, double delpro, const int* kxlt, const void* zdello,
+                               double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat, const int* kcor,
+                               const void* wlat, const void* wcor, const void* cgroup_ext, const void* cosphm1_ext, int kijs, int kijl, int nd3s,
+                               int nd3e, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws, double* wam2nemo, int flags, void* stream) {
+  if (!c) return fail("null context");
+  if (!fused_ok(c)) return fail("ecwam_hip_propags2_implsch: no one-kernel build covers the configuration (ecwam_hip_propags2_implsch_supported): call ecwam_hip_propags2_otf and ecwam_hip_implsch");
+  if (kijl < kijs || kijs < 0 || kijl > n || nd3s < 1 || nd3e > c->NFRE_RED || nd3e < nd3s - 1) return fail("ecwam_hip_propags2_implsch: bad range");
+  if (kijl > kijs && (!f1 || !f3 || !kxlt || !zdello || !cosph || !sinph || !klon || !klat || !kcor || !wlat || !wcor || !cgroup_ext || !cosphm1_ext ||
+                      !wvprpt || !ff || !intf || !mij || !xllws))
+    return fail("ecwam_hip_propags2_implsch: null pointer");
+  if (f1 == f3) return fail("ecwam_hip_propags2_implsch: F1 and F3 must not alias (the neighbours of a point are read while other points are stored)");
+  if (((uintptr_t)f1 % 16) != 0 || ((uintptr_t)f3 % 16) != 0) return fail("ecwam_hip_propags2_implsch: the spectra must be 16-byte aligned");
+  if (c->p.lwnemocou && kijl > kijs && !wam2nemo) return fail("ecwam_hip_propags2_implsch: LWNEMOCOU needs the WAVE2OCEAN buffer");
+  if (!c->p.lwnemocou) wam2nemo = nullptr;
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (kijl == kijs) return 0;
+  if (int rc2 = implsch_reserve_on(c, kijl, s, false)) return rc2;
+  const size_t need = (size_t)kijl * 12 * c->real_bytes;
+  if (need > c->adv_pt_bytes) {
+    if (c->adv_pt) HIPCHK(hipFree(c->adv_pt));
+    c->adv_pt = nullptr; c->adv_pt_bytes = 0;
+    HIPCHK(hipMalloc(&c->adv_pt, need));
+    c->adv_pt_bytes = need;
+  }
+  if (!c->adv_dir) HIPCHK(hipMalloc(&c->adv_dir, (size_t)(4 * c->NANG + 4) * c->real_bytes + (size_t)4 * c->NANG * sizeof(int)));
+  int* dirI = reinterpret_cast<int*>(reinterpret_cast<char*>(c->adv_dir) + (size_t)(4 * c->NANG + 4) * c->real_bytes);
+  DISPATCH(launch_ctu_prep<float>(c->dtab, kijs, kijl, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, wlat, wcor, cosphm1_ext, c->adv_pt, c->adv_dir, dirI, s),
+           launch_ctu_prep<double>(c->dtab, kijs, kijl, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, wlat, wcor, cosphm1_ext, c->adv_pt, c->adv_dir, dirI, s));
+  Implsch4AdvArgs a;
+  a.f_in = f1; a.klon = klon; a.klat = klat; a.kcor = kcor; a.cg = cgroup_ext; a.pt = c->adv_pt; a.dirT = c->adv_dir; a.dirI = dirI;
+  a.xdella = xdella; a.delpro = delpro; a.m0 = nd3s - 1; a.m1 = nd3e;
+  a.xcd_walk = (flags & 1) ? 0 : 1;      // flags bit 0: the workgroups in their natural order (diagnostics)
+  a.mode = (flags & 2) ? 2 : 1;          // flags bit 1: the go / no-go probe (libraries built with -DV4_ADV_PROBE only)
+  const int ext = (c->p.llnormagam || c->p.llgcbz0) ? 1 : 0;
+  int rc = -1;
+  DISPATCH(rc = launch_implsch4_adv<float>(c->dtab, kijs, kijl, f3, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, &a, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s),
+           rc = launch_implsch4_adv<double>(c->dtab, kijs, kijl, f3, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, &a, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s));
+  if (rc != 0) return fail("ecwam_hip_propags2_implsch: no one-kernel build covers the configuration");
+  HIPCHK(hipGetLastError());
+  c->implsch_last = 4;
+  return 0;
 }
 
 int ecwam_hip_set_fastwave_copy(ecwam_hip_ctx* c, void* g, int g_nfre) {

@@ -26,6 +26,7 @@
 // The lane-per-point scalar stages between the vector stages (STRESSO of the first call, second TAUT_Z0, WSIGSTAR, swell set-up,
 // SDIWBK) are those of implsch_point.h.
 #pragma once
+#include "ctu.h"
 
 #define V4_NFRE 36
 // phase timing (tools/time_v4_phases.sh): a diagnostics build (-DECWAM_HIP_DIAGNOSTICS) returns early at the phase boundary DBG_SKIP
@@ -406,6 +407,156 @@ struct V4Ctx {
   T rDFIM, rDFIMOFR, rDFIMFR, rZPIFR, rRHOWG, rCOFRM4, rFLMAX;
 };
 enum { Q4_BSC = 0, Q4_SBO, Q4_CINV, Q4_WAVNUM };   // Q4_BSC = WAVNUM XK2CG / 2 pi
+
+// ---- The advecting tile load (round 6, ADV builds of k_implsch4): PROPAGS2 (propags2.F90:99-121, IREFRA = 0) of the wave's PP points from the
+//      rows of A.f_in straight into the tile [M][point][K], so that a 1:1 WAMINTGR step (wamintgr.F90:94-146: PROPAG_WAM, NEWWIND, IMPLSCH) is
+//      ONE pass over the spectra instead of two -- the advected spectrum never goes to memory.  The arithmetic is ctu.h's, the helpers
+//      k_propags2_otf applies (contraction off): the tile holds bit for bit what that kernel would have written to FL3.
+//      Work order: a "chunk" is the 16 bytes (direction k, frequencies m .. m + VEC - 1) of one point, chunk w = lane + 64 it of point q is
+//      one step; a step's eight 16-byte gathers (own, longitude, two latitude, two corner neighbours, directions k -+ 1 of the own row) are
+//      issued D steps ahead of the step that consumes them (a ring of D x 8 vectors in registers), so that the memory latency of a step
+//      hides behind the weights and stencil of the D - 1 steps before it.  Per-point scalars of the weights come from the table k_ctu_prep
+//      (propag.hip) fills -- their divisions are correctly rounded there, this translation unit is compiled with the fast ones.
+template <typename T>
+struct V4Adv {
+  const T* f_in;        // [rows][NANG][NFRE]: owned rows, halo rows, land row -- what the stencil reads (never the rows the kernel stores to)
+  const int* klon;      // [n][2]
+  const int* klat;      // [n][2][2]
+  const int* kcor;      // [n][4][2]
+  const T* cg;          // CGROUP_EXT [rows][NFRE]
+  const T* pt;          // [n][12]: ZDELLO, COSPHM1, 1 / (ZDELLO XDELLA), TAN(lat), DP(1:2), WLAT(1:2), WCOR(1:4) (k_ctu_prep)
+  const T* dirT;        // [NANG][4]: DELTH0 (SINTH(K) + SINTH(K+1)) / R, the same for K-1, SINTH, COSTH; then CMTODEG
+  const int* dirI;      // [NANG][4]: JXO(K,1) | JYO(K,1) << 1 | KCR(K,1) << 2, KPM(K,-1), KPM(K,1)
+  T xdella, delpro;
+  int m0, m1;           // advected frequencies [m0, m1); the others are carried over
+  int xcd_walk;         // XCD-aware order of the workgroups
+};
+#ifndef V4_ADV_DEPTH
+#define V4_ADV_DEPTH 3
+#endif
+template <typename T, int NANG, int PP, int MODE>
+__device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n, int lane, T* __restrict__ sT, T* __restrict__ sScr, int nscr) {
+  constexpr int NFRE = V4_NFRE, N = NANG * NFRE, RS = PP * NANG, VEC = 16 / (int)sizeof(T), NC = NFRE / VEC, NVL = N / VEC, NITL = (NVL + 63) / 64;
+  constexpr int NCH = NITL * PP, D = V4_ADV_DEPTH;
+  typedef T VT __attribute__((ext_vector_type(VEC)));
+  typedef int I4 __attribute__((ext_vector_type(4)));
+  T* sB = sScr;                                        // [PP][5][NFRE]: the direction-independent halves of the weights (ctu_base)
+  T* sPt = sB + PP * 5 * NFRE;                         // [PP][12]
+  T* sK = sPt + PP * 12;                               // [NANG][4] + CMTODEG
+  int* sI = reinterpret_cast<int*>(sK + NANG * 4 + 4); // [PP][16]: ij, KLON(1:2), KLAT(1:2,1:2), KCOR(1:4,1:2)
+  int* sD = sI + PP * 16;                              // [NANG][4]
+  V4_CHK((int)((reinterpret_cast<T*>(sD + NANG * 4) - sScr)) <= nscr);
+  for (int i = lane; i < PP * 12; i += 64) {
+    const int q = i / 12, e = i - q * 12;
+    sPt[i] = A.pt[(size_t)(ij0 + (q < n ? q : n - 1)) * 12 + e];
+  }
+  for (int i = lane; i < PP * 16; i += 64) {
+    const int q = i >> 4, e = i & 15;
+    const int ijq = ij0 + (q < n ? q : n - 1);
+    int v = ijq;
+    if (e >= 1 && e <= 2) v = A.klon[(size_t)ijq * 2 + (e - 1)];
+    if (e >= 3 && e <= 6) v = A.klat[(size_t)ijq * 4 + (e - 3)];
+    if (e >= 7 && e <= 14) v = A.kcor[(size_t)ijq * 8 + (e - 7)];
+    sI[i] = v;
+  }
+  for (int i = lane; i < NANG * 4 + 4; i += 64) sK[i] = A.dirT[i];
+  for (int i = lane; i < NANG * 4; i += 64) sD[i] = A.dirI[i];
+  WSYNC();
+  if constexpr (MODE == 1) {
+    for (int i = lane; i < PP * NFRE; i += 64) {
+      const int q = i / NFRE, m = i - q * NFRE;
+      const int* iq = sI + q * 16;
+      const T* pq = sPt + q * 12;
+      T cgl[2], cgy0[2], cgy1[2];
+#pragma unroll
+      for (int ic = 0; ic < 2; ic++) {
+        cgl[ic] = A.cg[(size_t)iq[1 + ic] * NFRE + m];
+        cgy0[ic] = A.cg[(size_t)iq[3 + 2 * ic] * NFRE + m];
+        cgy1[ic] = A.cg[(size_t)iq[4 + 2 * ic] * NFRE + m];
+      }
+      const T wl[2] = {pq[6], pq[7]}, dp[2] = {pq[4], pq[5]};
+      const CtuBase<T> b = ctu_base(A.cg[(size_t)iq[0] * NFRE + m], cgl, cgy0, cgy1, wl, dp);
+      T* o = sB + q * 5 * NFRE + m;
+      o[0] = b.h[0]; o[NFRE] = b.h[1]; o[2 * NFRE] = b.hy[0]; o[3 * NFRE] = b.hy[1]; o[4 * NFRE] = b.cg0;
+    }
+    WSYNC();
+  }
+  VT buf[D][8];
+  auto chunk_of = [&](int it, int& k, int& m) {
+    int w = lane + 64 * it;
+    if (it == NITL - 1 && NVL % 64 != 0) w = w < NVL ? w : NVL - 1;      // the lanes beyond the last chunk repeat it (the same stores)
+    k = w / NC;
+    m = (w - k * NC) * VEC;
+  };
+  auto issue = [&](int c, VT (&b)[8]) {
+    const int it = c / PP, q = c - it * PP;
+    int k, m;
+    chunk_of(it, k, m);
+    const I4 dk = *reinterpret_cast<const I4*>(sD + 4 * k);
+    const int jx0 = dk.x & 1, jy0 = (dk.x >> 1) & 1, kc = (dk.x >> 2) & 3;
+    const int* iq = sI + q * 16;
+    const T* own = A.f_in + (size_t)iq[0] * N;
+    const int el = k * NFRE + m;
+    b[0] = *reinterpret_cast<const VT*>(own + el);
+    b[1] = *reinterpret_cast<const VT*>(A.f_in + (size_t)iq[1 + jx0] * N + el);
+    b[2] = *reinterpret_cast<const VT*>(A.f_in + (size_t)iq[3 + 2 * jy0] * N + el);
+    b[3] = *reinterpret_cast<const VT*>(A.f_in + (size_t)iq[4 + 2 * jy0] * N + el);
+    b[4] = *reinterpret_cast<const VT*>(A.f_in + (size_t)iq[7 + 2 * kc] * N + el);
+    b[5] = *reinterpret_cast<const VT*>(A.f_in + (size_t)iq[8 + 2 * kc] * N + el);
+    b[6] = *reinterpret_cast<const VT*>(own + dk.y * NFRE + m);
+    b[7] = *reinterpret_cast<const VT*>(own + dk.z * NFRE + m);
+  };
+  auto finish = [&](int c, const VT (&b)[8]) {
+    const int it = c / PP, q = c - it * PP;
+    int k, m;
+    chunk_of(it, k, m);
+    T r[VEC];
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int i = 0; i < VEC; i++) r[i] = T(0.3) * b[0][i] + T(0.1) * (((b[1][i] + b[2][i]) + (b[3][i] + b[4][i])) + ((b[5][i] + b[6][i]) + b[7][i]));
+    } else {
+      const I4 dk = *reinterpret_cast<const I4*>(sD + 4 * k);
+      const int jx0 = dk.x & 1, jy0 = (dk.x >> 1) & 1, kc = (dk.x >> 2) & 3;
+      const T* pq = sPt + q * 12;
+      const T zd = pq[0], cpm1 = pq[1], ga = pq[2], tanph = pq[3], wl_jy0 = pq[6 + jy0], wc_kc = pq[8 + kc];
+      const T cmtodeg = sK[NANG * 4];
+      const T* kk = sK + 4 * k;
+      T tsp, tsm;
+      {
+#pragma clang fp contract(off)
+        tsp = tanph * kk[0];
+        tsm = tanph * kk[1];
+      }
+      const T sink = kk[2], cosk = kk[3];
+      const T* bb = sB + q * 5 * NFRE + m;
+      const VT bh0 = *reinterpret_cast<const VT*>(bb), bh1 = *reinterpret_cast<const VT*>(bb + NFRE), by0 = *reinterpret_cast<const VT*>(bb + 2 * NFRE),
+               by1 = *reinterpret_cast<const VT*>(bb + 3 * NFRE), bc0 = *reinterpret_cast<const VT*>(bb + 4 * NFRE);
+      const V2<T> dl = {A.delpro, A.delpro}, sp2 = {tsp, tsp}, sm2 = {tsm, tsm};
+#pragma unroll
+      for (int i = 0; i < VEC; i += 2) {
+#define P2(a) V2<T>{a[i], a[i + 1]}
+        const V2<T> rr = ctu_w8_stencil_pk<T>(P2(bh0), P2(bh1), P2(by0), P2(by1), P2(bc0), sink, cosk, cpm1, zd, A.xdella, ga, dl, cmtodeg, jx0, jy0,
+                                              wl_jy0, wc_kc, sp2, sm2, P2(b[0]), P2(b[1]), P2(b[2]), P2(b[3]), P2(b[4]), P2(b[5]), P2(b[6]), P2(b[7]));
+#undef P2
+        r[i] = rr.x; r[i + 1] = rr.y;
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; i++)
+        if (m + i < A.m0 || m + i >= A.m1) r[i] = b[0][i];      // outside the advected range: carried over
+    }
+    T* d = sT + m * RS + q * NANG + k;
+#pragma unroll
+    for (int i = 0; i < VEC; i++) d[i * RS] = r[i];
+  };
+#pragma unroll
+  for (int c = 0; c < NCH + D - 1; c++) {
+    if (c < NCH) issue(c, buf[c % D]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (c >= D - 1) finish(c - (D - 1), buf[(c - (D - 1)) % D]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  WSYNC();
+}
 
 // TAUT_Z0 with the gravity-capillary roughness model (taut_z0.F90:148-287, LLGCBZ0 = T) for FOUR sea points at once: the 16 lanes of
 // DPP row r work for one point (every argument is the value of the lane's point, the same on the lanes of a row), STRESS_GC's sum over
@@ -1042,13 +1193,17 @@ __device__ __forceinline__ T v4_sdice3_alp(const DevTab<T>& tb, int m, T CITHICK
 // them, writes XLLWS, parks the wind-input coefficient in the rows of wi[ij][M][K] (context-owned) and hands its scalars over in fin;
 // PART 2 loads the spectrum again, re-applies SDEPTHLIM's scale and tail (the same operations: the same bits) and runs the sweep, the
 // fluxes, the tail and the stores.  Same source, same results bit for bit; two smaller functions for the compiler.
-template <typename T, int NANG, int PP, int R1, int R2, int NH, bool EXT, bool JAN = false, bool ENHMC = false, bool RARE = false, int PART = 0>
+// ADV: 0 = the tile is loaded from FL1 (IMPLSCH on its own, behind a PROPAGS2 kernel); 1 = the tile load IS the advection (round 6:
+// v4_advect_tile above -- PROPAGS2 of the wave's points from the rows of adv.f_in straight into the tile, the new spectrum stored to the rows
+// of fl1, which must be another buffer: one kernel per WAMINTGR step); 2 = the go / no-go probe of that build (the eight gathers of the
+// stencil through the real neighbour tables, made-up weights).
+template <typename T, int NANG, int PP, int R1, int R2, int NH, bool EXT, bool JAN = false, bool ENHMC = false, bool RARE = false, int PART = 0, int ADV = 0>
 // single precision: two waves per SIMD (LDS: 8 waves per CU), at most 256 VGPRs; double precision: the LDS holds one wave per SIMD
 // (40 KB per wave) and the kernel may use the whole register file (340 registers: no scratch)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(V4_WPE_MIN(T), 2)))
 k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__ fl1, const T* __restrict__ wvprpt, T* __restrict__ ffa,
            T* __restrict__ intfa, int* __restrict__ mij_out, T* __restrict__ xllws, T* __restrict__ fin, T* __restrict__ gfast, int gk,
-           T* __restrict__ wi) {
+           T* __restrict__ wi, const V4Adv<T> adv) {
   // scalar slots of the point's LDS row that are free in PART 2 (STRESSO's temporaries) carry the hand-over values
   enum { C2_FMEAN = C_XSN, C2_FMEANWS = C_YSN, C2_AKMEAN = C_UST, C2_XKMEAN = C_SINU, C2_SC = C_COSU };
   // gfast (optional): compact rows gfast[ij][K][gk] that also receive the first gk frequencies of the new spectrum -- what the next
@@ -1096,7 +1251,10 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     }
   }
   const int p = L.p, j = L.j;
-  const int ij0 = kijs + blockIdx.x * PP;
+  // ADV: the workgroups of a launch are dealt round-robin to the 8 XCDs; XCD x takes the contiguous eighth [x gridDim.x / 8, ...) of the
+  // wave's triples so that a row fetched as somebody's neighbour is met again in the same L2 (gridDim.x is a multiple of 8)
+  const int blk = (ADV != 0 && adv.xcd_walk) ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int ij0 = kijs + blk * PP;
   if (ij0 >= kijl) return;
 #if defined(V4_STAGGER) && V4_STAGGER > 0
   // Experiment (build variant "stagger", profiles/r05_stagger_experiment.txt): the waves that fill the chip at the start of a launch all begin
@@ -1177,8 +1335,12 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   //      -- and before the loads of the point scalars and factor tables below, whose LDS stores come first: one round trip to memory
   //      for all of them instead of one after the other
   constexpr int NVL = N / VEC, NITL = (NVL + 63) / 64;   // chunks per point, iterations per point
-  VT val[PP][NITL];
-  {
+  VT val[ADV != 0 ? 1 : PP][ADV != 0 ? 1 : NITL];
+  if constexpr (ADV != 0) {
+    // the tile is the advected spectrum: staging rows, factor table and planes are free until the tables below are filled
+    static_assert(PART == 0, "the advecting tile load belongs to the one-kernel build");
+    v4_advect_tile<T, NANG, PP, ADV>(adv, ij0, n, lane, sT, sStg, (NFRE + V4_NSTG) * RS - NFRE * RS + PP * NFRE * 4 + 2 * PLN);
+  } else {
 #pragma unroll
     for (int q = 0; q < PP; q++) {
       const T* g = fl1 + (size_t)(ij0 + (q < n ? q : n - 1)) * N;
@@ -1293,7 +1455,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       f[Q4_SBO] = sbo;
     }
   }
-  {   // the tile: registers -> LDS
+  if constexpr (ADV == 0) {   // the tile: registers -> LDS
     int k = lane / NC, r = lane - k * NC;
 #pragma unroll
     for (int it = 0; it < NITL; it++) {

@@ -31,7 +31,7 @@ static int launch4(const void* tab, int kijs, int kijl, void* fl1, const void* w
   if (SPLIT && !wi) return -1;
   // the scalar start of the step (first TAUT_Z0), one point per lane, into the rows of fin
   hipLaunchKernelGGL((k_implsch4_pre<T, EXT, RARE>), dim3((n + 63) / 64), dim3(64), 0, s, (const DevTab<T>*)tab, kijs, kijl, (const T*)ff, (T*)fin);
-#define V4_KARGS (const DevTab<T>*)tab, kijs, kijl, (T*)fl1, (const T*)wvprpt, (T*)ff, (T*)intf, mij, (T*)xllws, (T*)fin, (T*)gfast, gk, (T*)wi
+#define V4_KARGS (const DevTab<T>*)tab, kijs, kijl, (T*)fl1, (const T*)wvprpt, (T*)ff, (T*)intf, mij, (T*)xllws, (T*)fin, (T*)gfast, gk, (T*)wi, V4Adv<T>{}
   if constexpr (SPLIT) {
     auto k1 = k_implsch4<T, NANG, PP, R1, R2, NH, EXT, JAN, ENHMC, RARE, 1>;
     auto k2 = k_implsch4<T, NANG, PP, R1, R2, NH, EXT, JAN, ENHMC, RARE, 2>;
@@ -48,6 +48,26 @@ static int launch4(const void* tab, int kijs, int kijl, void* fl1, const void* w
   }
 #undef V4_KARGS
   // the scalar end of the step (second STRESSO, WNFLUXES), one point per lane, from the rows the kernel above left in fin
+  hipLaunchKernelGGL((k_implsch4_fin<T, EXT>), dim3((n + 63) / 64), dim3(64), 0, s, (const DevTab<T>*)tab, kijs, kijl, (const T*)fin, (T*)ff,
+                     (T*)intf, w2n);
+  return 0;
+}
+
+// The one-kernel WAMINTGR step (ADV builds of k_implsch4: the tile load is PROPAGS2 of the wave's points from the rows of adv.f_in; fl1 = the
+// rows the new spectrum is stored to, another buffer).  The grid is a whole number of rounds of the 8 XCDs (adv.xcd_walk).
+template <typename T, int NANG, int PP, int R1, int R2, int NH, bool EXT, int ADV>
+static int launch4_adv(const void* tab, int kijs, int kijl, void* fl1, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws, void* fin,
+                       double* w2n, void* gfast, int gk, const V4Adv<T>& adv, hipStream_t s) {
+  const int n = kijl - kijs;
+  constexpr size_t shmem = v4_lds_bytes<T, NANG, PP>();
+  static_assert(shmem <= 160 * 1024, "LDS");
+  hipLaunchKernelGGL((k_implsch4_pre<T, EXT, false>), dim3((n + 63) / 64), dim3(64), 0, s, (const DevTab<T>*)tab, kijs, kijl, (const T*)ff, (T*)fin);
+  auto kfn = k_implsch4<T, NANG, PP, R1, R2, NH, EXT, false, false, false, 0, ADV>;
+  if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  int nb = (n + PP - 1) / PP;
+  if (adv.xcd_walk) nb = (nb + 7) & ~7;
+  hipLaunchKernelGGL(kfn, dim3(nb), dim3(64), shmem, s, (const DevTab<T>*)tab, kijs, kijl, (T*)fl1, (const T*)wvprpt, (T*)ff, (T*)intf, mij, (T*)xllws,
+                     (T*)fin, (T*)gfast, gk, (T*)nullptr, adv);
   hipLaunchKernelGGL((k_implsch4_fin<T, EXT>), dim3((n + 63) / 64), dim3(64), 0, s, (const DevTab<T>*)tab, kijs, kijl, (const T*)fin, (T*)ff,
                      (T*)intf, w2n);
   return 0;

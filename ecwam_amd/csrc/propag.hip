@@ -8,22 +8,7 @@
 // is re-used by its ~8 neighbours within one or two latitude rows).
 #include "dev.h"
 
-// propags2.F90:107-116 for one element, in the reference's association order; contraction off so that every kernel that
-// applies the stencil (stored weights, vectorised, on-the-fly weights) rounds identically
-template <typename T>
-__device__ __forceinline__ T ctu_stencil(T w0, T w1, T w2, T w3, T w4, T w5, T w6, T w7, T f0, T f1, T f2, T f3, T f4, T f5, T f6,
-                                         T f7) {
-#pragma clang fp contract(off)
-  T r = (T(1) - w0) * f0;
-  r = r + w1 * f1;
-  r = r + w2 * f2;
-  r = r + w3 * f3;
-  r = r + w4 * f4;
-  r = r + w5 * f5;
-  r = r + w6 * f6;
-  r = r + w7 * f7;
-  return r;
-}
+#include "ctu.h"
 
 template <typename T>
 __global__ void __launch_bounds__(256) k_propags2(const DevTab<T>* __restrict__ tab, const T* __restrict__ f1, T* __restrict__ f3,
@@ -149,154 +134,6 @@ __global__ void k_ctuwini(int n, int nland, const int* __restrict__ klat, const 
   }
 }
 
-// ctuw.F90:146-275 (space weights), :407-484 (great-circle refraction WKPMN), :536-608 (range checks, SUMWN)
-// restricted to what PROPAGS2 reads for IREFRA=0 (ISSU=ISSV=1 => DXDW=DYDW=0).
-//
-// The arithmetic lives in two helpers shared by k_ctuw (weights stored once, the reference's scheme) and k_propags2_otf
-// (weights rebuilt inside the stencil): floating-point contraction is switched off in them so that both kernels produce
-// the same bits whatever the surrounding code looks like.
-template <typename T>
-struct CtuBase {  // direction-independent part for one (point, frequency)
-  T h[2];   // 0.5*(CG(IJ)+CG(KLON(IC)))
-  T hy[2];  // 0.5*(CG(IJ)+DP(IC)*CGYP(IC))
-  T cg0;
-};
-template <typename T>
-__device__ __forceinline__ CtuBase<T> ctu_base(T cg0, const T cgl[2], const T cgy0[2], const T cgy1[2], const T wl[2], const T dp[2]) {
-#pragma clang fp contract(off)
-  CtuBase<T> b;
-  b.cg0 = cg0;
-  for (int ic = 0; ic < 2; ic++) {
-    b.h[ic] = T(0.5) * (cg0 + cgl[ic]);
-    const T cgyp = wl[ic] * cgy0[ic] + (T(1) - wl[ic]) * cgy1[ic];
-    b.hy[ic] = T(0.5) * (cg0 + dp[ic] * cgyp);
-  }
-  return b;
-}
-// w8 = SUMWN, WLONN(JXO(K,1)), WLATN(JYO(K,1),1:2), WCORN(1,1:2), WKPMN(-1), WKPMN(+1); returns the CFL / range failure flag
-template <typename T>
-__device__ __forceinline__ bool ctu_w8(const CtuBase<T>& b, T sink, T cosk, T cpm1, T zd, T xdella, T ga, T delpro, T cmtodeg,
-                                       int jx0, int jx1, int jy0, int jy1, T wl_jy0, T wc_kc, T tsp, T tsm, T* w8) {
-#pragma clang fp contract(off)
-  T adxp[2], adyp[2];
-  bool fail = false;
-  for (int ic = 0; ic < 2; ic++) {
-    const T cgx = b.h[ic] * sink * cpm1;
-    const T cgy = b.hy[ic] * cosk;
-    adxp[ic] = m_abs(-delpro * cgx * cmtodeg);
-    adyp[ic] = m_abs(-delpro * cgy * cmtodeg);
-    if (adxp[ic] > zd || adyp[ic] > xdella) fail = true;
-  }
-  const T dxx = zd - adxp[jx1];
-  const T dyy = xdella - adyp[jy1];
-  const T wgt_lat = dxx * adyp[jy0] * ga;  // WEIGHT(JYO(K,1))
-  const T wlatn1 = wl_jy0 * wgt_lat;
-  const T wlatn2 = (T(1) - wl_jy0) * wgt_lat;
-  const T wlonn = dyy * adxp[jx0] * ga;
-  const T wgt_cor = adxp[jx0] * adyp[jy0] * ga;  // WEIGHT(1)
-  const T wcorn1 = wc_kc * wgt_cor;
-  const T wcorn2 = (T(1) - wc_kc) * wgt_cor;
-  T sumwn = (zd * adyp[jy1] + xdella * adxp[jx1] - adxp[jx1] * adyp[jy1]) * ga;
-  const T dthp = tsp * b.cg0;  // TANPH*SP*CG
-  const T dthm = tsm * b.cg0;
-  const T wk0 = (dthp + m_abs(dthp)) + (m_abs(dthm) - dthm);
-  const T wkp = -dthp + m_abs(dthp);
-  const T wkm = dthm + m_abs(dthm);
-  sumwn = sumwn + wk0;
-  const T one = T(1), zero = T(0);
-  if (wlatn1 > one || wlatn1 < zero || wlatn2 > one || wlatn2 < zero || wlonn > one || wlonn < zero || wcorn1 > one ||
-      wcorn1 < zero || wcorn2 > one || wcorn2 < zero || wk0 > one || wk0 < zero || wkp > one || wkp < zero || wkm > one ||
-      wkm < zero || sumwn > one || sumwn < zero)
-    fail = true;
-  w8[0] = sumwn; w8[1] = wlonn; w8[2] = wlatn1; w8[3] = wlatn2; w8[4] = wcorn1; w8[5] = wcorn2; w8[6] = wkm; w8[7] = wkp;
-  return fail;
-}
-// ctu_w8 + ctu_stencil on TWO frequencies at a time as packed-fp32 operands (v_pk_mul_f32 / v_pk_add_f32): the same operations
-// in the same order per component, contraction off, hence the same bits as the scalar helpers -- at half the instruction issue
-// (the advection kernel spends 2/3 of its time issuing vector instructions).  No checks here: k_ctuw does them once.
-typedef float F2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ F2 v_abs2(F2 x) { F2 r = {fabsf(x.x), fabsf(x.y)}; return r; }
-__device__ __forceinline__ F2 ctu_w8_stencil_pk(F2 h0, F2 h1, F2 hy0, F2 hy1, F2 cg0, float sink, float cosk, float cpm1, float zd,
-                                                float xdella, float ga, F2 delpro, float cmtodeg, int jx0, int jy0, float wl_jy0,
-                                                float wc_kc, F2 tsp, F2 tsm, F2 f0, F2 f1, F2 f2, F2 f3, F2 f4, F2 f5, F2 f6, F2 f7) {
-#pragma clang fp contract(off)
-  const F2 adx0 = v_abs2(-delpro * (h0 * sink * cpm1) * cmtodeg), adx1 = v_abs2(-delpro * (h1 * sink * cpm1) * cmtodeg);
-  const F2 ady0 = v_abs2(-delpro * (hy0 * cosk) * cmtodeg), ady1 = v_abs2(-delpro * (hy1 * cosk) * cmtodeg);
-  const F2 adx_a = jx0 ? adx1 : adx0, adx_b = jx0 ? adx0 : adx1;   // ADXP(JXO(K,1)), ADXP(JXO(K,2))
-  const F2 ady_a = jy0 ? ady1 : ady0, ady_b = jy0 ? ady0 : ady1;
-  const F2 dxx = zd - adx_b;
-  const F2 dyy = xdella - ady_b;
-  const F2 wgt_lat = dxx * ady_a * ga;
-  const F2 wlatn1 = wl_jy0 * wgt_lat;
-  const F2 wlatn2 = (1.0f - wl_jy0) * wgt_lat;
-  const F2 wlonn = dyy * adx_a * ga;
-  const F2 wgt_cor = adx_a * ady_a * ga;
-  const F2 wcorn1 = wc_kc * wgt_cor;
-  const F2 wcorn2 = (1.0f - wc_kc) * wgt_cor;
-  F2 sumwn = (zd * ady_b + xdella * adx_b - adx_b * ady_b) * ga;
-  const F2 dthp = tsp * cg0;
-  const F2 dthm = tsm * cg0;
-  const F2 wk0 = (dthp + v_abs2(dthp)) + (v_abs2(dthm) - dthm);
-  const F2 wkp = -dthp + v_abs2(dthp);
-  const F2 wkm = dthm + v_abs2(dthm);
-  sumwn = sumwn + wk0;
-  F2 r = (1.0f - sumwn) * f0;
-  r = r + wlonn * f1;
-  r = r + wlatn1 * f2;
-  r = r + wlatn2 * f3;
-  r = r + wcorn1 * f4;
-  r = r + wcorn2 * f5;
-  r = r + wkm * f6;
-  r = r + wkp * f7;
-  return r;
-}
-// per-point scalars of the weights (ctuw.F90:146-170, 407-420)
-template <typename T>
-struct CtuPoint {
-  T zd, cpm1, ga, tanph, dp[2], wl[2], wc[4];
-};
-template <typename T>
-__device__ __forceinline__ CtuPoint<T> ctu_point(int ij, int ngy, const int* __restrict__ kxlt, const T* __restrict__ zdello, T xdella,
-                                                 const T* __restrict__ cosph, const T* __restrict__ sinph, const T* __restrict__ wlat,
-                                                 const T* __restrict__ wcor, const T* __restrict__ cosphm1) {
-#pragma clang fp contract(off)
-  CtuPoint<T> p;
-  const int ky = kxlt[ij];
-  p.zd = zdello[ky];
-  p.cpm1 = cosphm1[ij];
-  p.ga = T(1) / (p.zd * xdella);
-  p.tanph = sinph[ky] / cosph[ky];
-  for (int ic = 0; ic < 2; ic++) {
-    int kk = ky + 1 + 2 * (ic + 1) - 3;  // 1-based row of the neighbour latitude, ctuwini.F90:159-162
-    kk = kk < 1 ? 1 : (kk > ngy ? ngy : kk);
-    p.dp[ic] = cosph[kk - 1] * p.cpm1;
-    p.wl[ic] = wlat[ij * 2 + ic];
-  }
-  for (int ic = 0; ic < 4; ic++) p.wc[ic] = wcor[ij * 4 + ic];
-  return p;
-}
-// TANPH*SP and TANPH*SM factors of direction k (ctuw.F90:407-420): DELTH0*(SINTH(K)+SINTH(K+-1))/R
-template <typename T>
-__device__ __forceinline__ void ctu_dirfac(const DevTab<T>* tab, int k, T delth0, T tanph, T& tsp, T& tsm) {
-#pragma clang fp contract(off)
-  const int kp1 = tab->KPM[k][2], km1 = tab->KPM[k][0];
-  const T sp = delth0 * (tab->SINTH[k] + tab->SINTH[kp1]) / tab->R;
-  const T sm = delth0 * (tab->SINTH[k] + tab->SINTH[km1]) / tab->R;
-  tsp = tanph * sp;
-  tsm = tanph * sm;
-}
-
-// Sub-grid obstructions (LSUBGRID, ctuw.F90:703-733): after the checks, the space weights of the neighbours are scaled by the
-// transmission coefficients OBS[ij][8][NFRE] = OBSLAT(IJ,M,1:2), OBSLON(IJ,M,1:2), OBSCOR(IJ,M,1:4); SUMWN keeps its value
-// (what the obstruction blocks is lost).  o points at plane 0 of (ij, m), planes are `stride` apart.
-template <typename T>
-__device__ __forceinline__ void ctu_obstruct8(T* w8, const T* o, int stride, int jx0, int jy0, int kc) {
-#pragma clang fp contract(off)
-  const T olon = o[(2 + jx0) * stride], olat = o[jy0 * stride], ocor = o[(4 + kc) * stride];
-  w8[1] = w8[1] * olon;
-  w8[2] = w8[2] * olat; w8[3] = w8[3] * olat;
-  w8[4] = w8[4] * ocor; w8[5] = w8[5] * ocor;
-}
 
 // One thread per (ij,K,M): stores the eight weights (w != nullptr) and raises the CFL flag of the point.
 template <typename T>
@@ -533,7 +370,7 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
           const F2 sp2 = {lf0 ? (float)tsp_lf : (float)tsp, lf1 ? (float)tsp_lf : (float)tsp};
           const F2 sm2 = {lf0 ? (float)tsm_lf : (float)tsm, lf1 ? (float)tsm_lf : (float)tsm};
 #define P2(a) F2{(float)a[c], (float)a[c + 1]}
-          const F2 rr = ctu_w8_stencil_pk(P2(bh0), P2(bh1), P2(by0), P2(by1), P2(bc0), (float)sink, (float)cosk, (float)p.cpm1, (float)p.zd,
+          const F2 rr = ctu_w8_stencil_pk<float>(P2(bh0), P2(bh1), P2(by0), P2(by1), P2(bc0), (float)sink, (float)cosk, (float)p.cpm1, (float)p.zd,
                                           (float)xdella, (float)p.ga, dl, (float)CMTODEG, jx0, jy0, (float)p.wl[jy0], (float)p.wc[kc], sp2,
                                           sm2, P2(fo), P2(flon), P2(fla1), P2(fla2), P2(fco1), P2(fco2), P2(fkm), P2(fkp));
 #undef P2
@@ -1365,6 +1202,47 @@ void launch_newwind(const void* tab, int n, void* ff, const void* ffn, int icode
   if (n <= 0) return;
   hipLaunchKernelGGL(k_newwind<T>, dim3((n + 255) / 256), dim3(256), 0, s, (const DevTab<T>*)tab, n, (T*)ff, (const T*)ffn, icode_wnd);
 }
+// The scalars of the CTU weights that the advecting tile load of k_implsch4 (implsch_v4.h::v4_advect_tile) takes ready-made: per point
+// PT[ij][12] = ctu_point (ZDELLO, COSPHM1, 1 / (ZDELLO XDELLA), TAN(lat), DP(1:2), WLAT(1:2), WCOR(1:4)), per direction the factors of
+// ctu_dirfac with TANPH = 1, SINTH, COSTH, then CMTODEG, and the index words JXO(K,1) | JYO(K,1) << 1 | KCR(K,1) << 2, KPM(K,-1), KPM(K,1).
+// Computed HERE because the divisions in them are correctly rounded in this translation unit (the IMPLSCH units are built with the
+// hardware reciprocal): the one-kernel step then forms the same weights, bit for bit, as k_propags2_otf.
+template <typename T>
+__global__ void k_ctu_prep(const DevTab<T>* __restrict__ tab, int kijs, int kijl, int ngy, T delpro, const int* __restrict__ kxlt,
+                           const T* __restrict__ zdello, T xdella, const T* __restrict__ cosph, const T* __restrict__ sinph,
+                           const T* __restrict__ wlat, const T* __restrict__ wcor, const T* __restrict__ cosphm1, T* __restrict__ pt,
+                           T* __restrict__ dirT, int* __restrict__ dirI) {
+  const int NANG = tab->NANG;
+  if (blockIdx.x == 0) {
+    const T DELTH0 = T(0.25) * delpro / tab->DELTH;
+    for (int k = threadIdx.x; k < NANG; k += blockDim.x) {
+      T a, b;
+      ctu_dirfac(tab, k, DELTH0, T(1), a, b);
+      dirT[4 * k] = a; dirT[4 * k + 1] = b; dirT[4 * k + 2] = tab->SINTH[k]; dirT[4 * k + 3] = tab->COSTH[k];
+      dirI[4 * k] = tab->JXO[k][0] | (tab->JYO[k][0] << 1) | (tab->KCR[k][0] << 2);
+      dirI[4 * k + 1] = tab->KPM[k][0]; dirI[4 * k + 2] = tab->KPM[k][2]; dirI[4 * k + 3] = 0;
+    }
+    if (threadIdx.x == 0) {
+      dirT[4 * NANG] = T(360.0) / tab->CIRC;
+      dirT[4 * NANG + 1] = dirT[4 * NANG + 2] = dirT[4 * NANG + 3] = T(0);
+    }
+  }
+  for (int ij = kijs + blockIdx.x * blockDim.x + threadIdx.x; ij < kijl; ij += gridDim.x * blockDim.x) {
+    const CtuPoint<T> p = ctu_point(ij, ngy, kxlt, zdello, xdella, cosph, sinph, wlat, wcor, cosphm1);
+    T* o = pt + (size_t)ij * 12;
+    o[0] = p.zd; o[1] = p.cpm1; o[2] = p.ga; o[3] = p.tanph; o[4] = p.dp[0]; o[5] = p.dp[1]; o[6] = p.wl[0]; o[7] = p.wl[1];
+    o[8] = p.wc[0]; o[9] = p.wc[1]; o[10] = p.wc[2]; o[11] = p.wc[3];
+  }
+}
+template <typename T>
+void launch_ctu_prep(const void* tab, int kijs, int kijl, int ngy, double delpro, const int* kxlt, const void* zdello, double xdella,
+                     const void* cosph, const void* sinph, const void* wlat, const void* wcor, const void* cosphm1, void* pt, void* dirT, int* dirI,
+                     hipStream_t s) {
+  const int n = kijl - kijs;
+  hipLaunchKernelGGL(k_ctu_prep<T>, dim3(n > 0 ? grid_for(n) : 1), dim3(256), 0, s, (const DevTab<T>*)tab, kijs, kijl, ngy, (T)delpro, kxlt,
+                     (const T*)zdello, (T)xdella, (const T*)cosph, (const T*)sinph, (const T*)wlat, (const T*)wcor, (const T*)cosphm1, (T*)pt,
+                     (T*)dirT, dirI);
+}
 // NO SOURCE TERM CONTRIBUTION (wamintgr.F90:152-160): FL1 = MAX(FL1, EPSMIN), MIJ = NFRE, XLLWS = 0 on rows [kijs, kijl)
 template <typename T>
 __global__ void k_nosource(const DevTab<T>* __restrict__ tab, long long e0, long long e1, T* __restrict__ fl1, T* __restrict__ xllws, int kijs,
@@ -1431,6 +1309,7 @@ void launch_proenv_unpack(int nrows, int NFRE, const void* buf, const void* land
                                const void*, const int*, const int*, const int*, void*, void*, const void*, const void*, void*,   \
                                int*, int, const void*, hipStream_t);                                                              \
   template void launch_newwind<T>(const void*, int, void*, const void*, int, hipStream_t);                                        \
+  template void launch_ctu_prep<T>(const void*, int, int, int, double, const int*, const void*, double, const void*, const void*, const void*, const void*, const void*, void*, void*, int*, hipStream_t);\
   template void launch_nosource<T>(const void*, int, int, int, void*, void*, int*, hipStream_t);                                  \
   template void launch_propdot<T>(const void*, int, int, int, const int*, const void*, double, const void*, const int*,         \
                                   const int*, const void*, const void*, const void*, const void*, const void*, void*, hipStream_t); \

@@ -57,13 +57,13 @@ class TablePtrs(C.Structure):
 
 
 EXPORTS = ["ecwam_hip_last_error", "ecwam_hip_abi_version", "ecwam_hip_selftest", "ecwam_hip_create", "ecwam_hip_destroy", "ecwam_hip_set_obstructions", "ecwam_hip_propags2",
-           "ecwam_hip_ctuw", "ecwam_hip_propags2_otf", "ecwam_hip_propags2_otf_split", "ecwam_hip_propags2_otf_fast", "ecwam_hip_set_fastwave_copy", "ecwam_hip_copy_freq_range", "ecwam_hip_propdot", "ecwam_hip_ctuw_refra", "ecwam_hip_propags2_refra", "ecwam_hip_implsch", "ecwam_hip_implsch_generation_used", "ecwam_hip_device_tables", "ecwam_hip_implsch_reserve", "ecwam_hip_outbs", "ecwam_hip_outwnorm", "ecwam_hip_newwind", "ecwam_hip_newwind_icode", "ecwam_hip_nosource", "ecwam_hip_host_register", "ecwam_hip_host_unregister", "ecwam_hip_chunks_to_points",
+           "ecwam_hip_ctuw", "ecwam_hip_propags2_otf", "ecwam_hip_propags2_otf_split", "ecwam_hip_propags2_otf_fast", "ecwam_hip_set_fastwave_copy", "ecwam_hip_copy_freq_range", "ecwam_hip_propdot", "ecwam_hip_ctuw_refra", "ecwam_hip_propags2_refra", "ecwam_hip_implsch", "ecwam_hip_implsch_generation_used", "ecwam_hip_device_tables", "ecwam_hip_implsch_reserve", "ecwam_hip_propags2_implsch_supported", "ecwam_hip_propags2_implsch", "ecwam_hip_outbs", "ecwam_hip_outwnorm", "ecwam_hip_newwind", "ecwam_hip_newwind_icode", "ecwam_hip_nosource", "ecwam_hip_host_register", "ecwam_hip_host_unregister", "ecwam_hip_chunks_to_points",
            "ecwam_hip_points_to_chunks", "ecwam_hip_member_scatter", "ecwam_hip_member_gather", "ecwam_hip_pack_rows", "ecwam_hip_unpack_rows", "ecwam_hip_halo_setup", "ecwam_hip_halo_counts", "ecwam_hip_comm_unique_id",
            "ecwam_hip_comm_init", "ecwam_hip_comm_count", "ecwam_hip_halo_start", "ecwam_hip_halo_finish", "ecwam_hip_halo_pack_host", "ecwam_hip_halo_unpack_host", "ecwam_hip_proenvhalo_pack", "ecwam_hip_proenvhalo_unpack", "ecwam_hip_malloc", "ecwam_hip_free",
            "ecwam_hip_memcpy_h2d", "ecwam_hip_memcpy_d2h", "ecwam_hip_memset", "ecwam_hip_sync", "ecwam_hip_queue_create", "ecwam_hip_queue_destroy",
            "ecwam_hip_queue_wait_for"]
 
-ABI_VERSION = 5        # include/ecwam_hip.h ECWAM_HIP_ABI_VERSION
+ABI_VERSION = 6        # include/ecwam_hip.h ECWAM_HIP_ABI_VERSION
 _lib = None
 
 
@@ -96,6 +96,8 @@ def load() -> C.CDLL:
     lib.ecwam_hip_propags2_otf_split.argtypes = [vp, vp, vp, ci, ci, cd, cd, ci, ci, vp, ci, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
     lib.ecwam_hip_propags2_otf_fast.argtypes = [vp, vp, vp, ci, ci, cd, cd, ci, ci, vp, ci, ci, vp, ci, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
     lib.ecwam_hip_set_fastwave_copy.argtypes = [vp, vp, ci]
+    lib.ecwam_hip_propags2_implsch_supported.argtypes = [vp]
+    lib.ecwam_hip_propags2_implsch.argtypes = [vp, vp, vp, ci, ci, cd, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]
     lib.ecwam_hip_copy_freq_range.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
     lib.ecwam_hip_propdot.argtypes = [vp, ci, ci, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ecwam_hip_ctuw_refra.argtypes = [vp, ci, ci, ci, cd, ci, ci, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp]

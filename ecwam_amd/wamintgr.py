@@ -482,7 +482,45 @@ class Wamintgr:
                 self.ctx.set_fastwave_copy(None)
         self.gfast_valid = on
 
-    def step(self, advect: bool = True, source: bool = True, llsource: bool = True) -> None:
+    # ---- the 1:1 step as one kernel (round 6): PROPAGS2 inside IMPLSCH's tile load (ecwam_hip_propags2_implsch)
+    def fused_available(self) -> bool:
+        """The one-kernel step covers this model: a build exists (single precision, 36 x 36, common IMPLSCH builds) and the advection is the
+        plain one (IREFRA = 0, on-the-fly weights, no fast-wave sub-steps, natural row order, no obstructions)."""
+        return (self.ctx.fused_supported() and not self.irefra and self.weights == "otf" and self.order is None
+                and not (0 < self.ifrelfmax < self.cfg.nfre_red))
+
+    def step_fused(self, wam2nemo=None, flags: int = 0) -> None:
+        """PROPAG_WAM + NEWWIND + IMPLSCH of one step (wamintgr.F90:94-146) with the advection done by the source-term kernel's tile load.
+        NEWWIND touches the forcing only and runs first; the halo exchange is posted, the rows that read no halo row are integrated while
+        it runs, then the two ends of the band (propag_wam.F90:166, mpexchng.F90)."""
+        if not self.weights_ready:
+            nfail = self.build_weights()
+            if nfail:
+                raise api.EcwamHipError(f"CFL criterion violated at {nfail} points (ctuwdrv.F90:128-146)")
+        self.newwind()
+        c = self.cfg
+
+        def rows(k0, k1):
+            if k1 > k0:
+                self.ctx.propags2_implsch(self.fl1, self.fl3, self.gd, self.cgroup_ext, float(c.idelpro), k0, k1, self.wvprpt, self.ff, self.intf,
+                                          self.mij, self.xllws, 1, c.nfre_red, wam2nemo=wam2nemo, flags=flags)
+
+        if self.dom.nranks > 1:
+            ia, ib = self.interior
+            reqs = self.halo.start(self.fl1)
+            rows(ia, ib)
+            self._halo_finish_timed(reqs)
+            rows(0, ia)
+            rows(ib, self.n)
+        else:
+            rows(0, self.n)
+        self.fl1, self.fl3 = self.fl3, self.fl1
+        self.gfast_valid = False
+
+    def step(self, advect: bool = True, source: bool = True, llsource: bool = True, fused: bool = False) -> None:
+        if fused and advect and source and llsource and self.fused_available():
+            self.step_fused()
+            return
         if advect:
             self.propag()
         self.newwind()

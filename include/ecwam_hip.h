@@ -39,7 +39,7 @@ extern "C" {
 #define ECWAM_HIP_MAXANG 48
 /* bumped whenever ecwam_hip_params / ecwam_hip_tables or an entry point changes: 2 = refraction entry points, SDICE1 table and
  * ice break-up parameters added.  ecwam_hip_abi_version() returns the value the library was built with. */
-#define ECWAM_HIP_ABI_VERSION 5
+#define ECWAM_HIP_ABI_VERSION 6
 #define ECWAM_HIP_MAXFRE 48
 #define ECWAM_HIP_MAXMC 56     /* MLSTHG = NFRE - ISM <= 48 + 8 */
 #define ECWAM_HIP_MAXTAP 47    /* 2*NSDSNTH+1, NSDSNTH <= NANG/2-1 */
@@ -292,6 +292,26 @@ const void *ecwam_hip_device_tables(ecwam_hip_ctx *ctx);
  * several streams may share the buffer as long as their [kijs,kijl) do not overlap.
  */
 int ecwam_hip_implsch_reserve(ecwam_hip_ctx *ctx, int npts);
+
+/*
+ * One WAMINTGR step with a 1:1 ratio of advection and source-term steps as ONE pass over the spectra (wamintgr.F90:94-146: PROPAG_WAM then
+ * IMPLSCH; propag_wam.F90:124-147,247-251,373-400; propags2.F90:99-121): the kernel that integrates the source terms of rows [kijs,kijl)
+ * advects them itself while it loads them -- PROPAGS2 (IREFRA = 0, one time step for every frequency, CTU weights rebuilt on the fly from the
+ * arguments of ecwam_hip_propags2_otf) from the rows of f1 (owned + halo + land rows: read only) straight into the kernel's working tile --
+ * and stores the new spectrum to the rows of f3.  The advected spectrum never goes to memory.  Result: bit for bit what
+ * ecwam_hip_propags2_otf(f1 -> f3, copy_rest = 1) followed by ecwam_hip_implsch(f3) leaves in f3, FF, INTF, MIJ, XLLWS, WAM2NEMO.
+ * The caller runs NEWWIND (ecwam_hip_newwind) BEFORE this call (it touches the forcing only) and swaps f1 / f3 after it, as after PROPAGS2.
+ * Rows whose stencil reads halo rows are passed in a second call behind ecwam_hip_halo_finish, exactly as with ecwam_hip_propags2_otf.
+ * Covered: what ecwam_hip_propags2_implsch_supported reports (single precision, 36 directions x 36 frequencies, the common builds of
+ * IMPLSCH with IPHYS = 1 / ISNONLIN = 0, no obstructions, no fast-wave sub-steps); everything else runs the two calls.
+ * flags: 0 (bit 0: workgroups in their natural order instead of the XCD-aware one; bit 1: the go / no-go probe of diagnostics builds).
+ */
+int ecwam_hip_propags2_implsch_supported(ecwam_hip_ctx *ctx);
+int ecwam_hip_propags2_implsch(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n, int ngy, double delpro, const int *kxlt, const void *zdello,
+                               double xdella, const void *cosph, const void *sinph, const int *klon, const int *klat, const int *kcor,
+                               const void *wlat, const void *wcor, const void *cgroup_ext, const void *cosphm1_ext, int kijs, int kijl,
+                               int nd3s, int nd3e, const void *wvprpt, void *ff, void *intf, int *mij, void *xllws, double *wam2nemo, int flags,
+                               void *stream);
 
 /*
  * Integrated output parameters without a spectrum copy-back (the device-side part of OUTBS: outblock.F90:204,223-243,

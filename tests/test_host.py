@@ -25,7 +25,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
     for name in declared:
         assert getattr(h, name) is not None
-    assert h.ecwam_hip_abi_version() == int(re.search(r"#define ECWAM_HIP_ABI_VERSION (\d+)", hdr).group(1)) == 5
+    assert h.ecwam_hip_abi_version() == int(re.search(r"#define ECWAM_HIP_ABI_VERSION (\d+)", hdr).group(1)) == 6
     # the parameter struct seen from Python has the size the C compiler gives it
     src = '#include "ecwam_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu", sizeof(ecwam_hip_params), sizeof(ecwam_hip_tables));return 0;}'
     import tempfile

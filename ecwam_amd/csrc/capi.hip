@@ -752,7 +752,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
 // the configurations the one-kernel step covers (implsch4a.hip); everything else runs ecwam_hip_propags2_otf + ecwam_hip_implsch
 static bool fused_ok(const ecwam_hip_ctx* c) {
   const bool rare4 = c->p.lciwa2 || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin > 1 || c->p.icode != 3 || !c->p.lwvflx_snl;
-  return !rare4 && c->p.iphys == 1 && c->p.isnonlin == 0 && c->real_bytes == 4 && c->NANG == 36 && c->NFRE == 36 && c->v4_r1 == 1 && c->v4_r2 == 3 &&
+  return !rare4 && c->p.iphys == 1 && c->p.isnonlin == 0 && c->NANG == 36 && c->NFRE == 36 && c->v4_r1 == 1 && c->v4_r2 == 3 &&
          c->v4_nh == 8 && !c->obs && !c->fast_g;
 }
 int ecwam_hip_propags2_implsch_supported(ecwam_hip_ctx* c) { return c && fused_ok(c) ? 1 : 0; }
@@ -789,7 +789,7 @@ int ecwam_hip_propags2_implsch(ecwam_hip_ctx* c, const void* f1, void* f3, int n
   Implsch4AdvArgs a;
   a.f_in = f1; a.klon = klon; a.klat = klat; a.kcor = kcor; a.cg = cgroup_ext; a.pt = c->adv_pt; a.dirT = c->adv_dir; a.dirI = dirI;
   a.xdella = xdella; a.delpro = delpro; a.m0 = nd3s - 1; a.m1 = nd3e;
-  a.xcd_walk = (flags & 1) ? 0 : 1;      // flags bit 0: the workgroups in their natural order (diagnostics)
+  a.xcd_walk = (flags & 1) ? 1 : 0;      // flags bit 0: the workgroups in the XCD-aware order of k_propags2_otf (diagnostics: 1 % slower here)
   a.mode = (flags & 2) ? 2 : 1;          // flags bit 1: the go / no-go probe (libraries built with -DV4_ADV_PROBE only)
   const int ext = (c->p.llnormagam || c->p.llgcbz0) ? 1 : 0;
   int rc = -1;

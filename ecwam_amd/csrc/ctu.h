@@ -129,6 +129,48 @@ __device__ __forceinline__ CtuV2<T> ctu_w8_stencil_pk(CtuV2<T> h0, CtuV2<T> h1, 
   r = r + wkp * f7;
   return r;
 }
+// The same weights and stencil with every absolute value and every selection taken out of the per-element code -- for a caller that
+// prepares, per (point, frequency), |h| and |hy| already ordered by the direction's quadrant (ha = |h(JXO(K,1))|, hb = |h(JXO(K,2))|, the same
+// for hy with JYO) and, per (point, direction), the four non-negative numbers a2 = MAX(2 TSP, 0), p2 = MAX(-2 TSP, 0), b2 = MAX(-2 TSM, 0),
+// m2 = MAX(2 TSM, 0) with TSP = TANPH SP, TSM = TANPH SM (the advecting tile load of k_implsch4, implsch_v4.h).  Same bits as
+// ctu_w8_stencil_pk, because
+//   * rounding is symmetric in the sign: |fl(a b)| = fl(|a| |b|), so ABS(-DELPRO CGX CMTODEG) is the same product of magnitudes
+//     (DELPRO, CMTODEG > 0; asink = |SINTH(K)|, acosk = |COSTH(K)|, acpm1 = |COSPHM1|);
+//   * doubling is exact: with x = fl(TSP CG) and CG >= 0 (a group velocity), x + |x| is fl((2 TSP) CG) where TSP >= 0 and 0 otherwise,
+//     and -x + |x|, |y| - y, y + |y| likewise: WKPMN(0) = a2 CG + b2 CG, WKPMN(1) = p2 CG, WKPMN(-1) = m2 CG.
+template <typename T>
+__device__ __forceinline__ CtuV2<T> ctu_w8_stencil_abs(CtuV2<T> ha, CtuV2<T> hb, CtuV2<T> hya, CtuV2<T> hyb, CtuV2<T> cg0, T asink, T acosk, T acpm1,
+                                                       T zd, T xdella, T ga, T delpro, T cmtodeg, T wl, T omwl, T wc, T omwc, T a2, T b2, T p2, T m2,
+                                                       CtuV2<T> f0, CtuV2<T> f1, CtuV2<T> f2, CtuV2<T> f3, CtuV2<T> f4, CtuV2<T> f5, CtuV2<T> f6,
+                                                       CtuV2<T> f7) {
+#pragma clang fp contract(off)
+  typedef CtuV2<T> F;
+  const F adx_a = delpro * (ha * asink * acpm1) * cmtodeg, adx_b = delpro * (hb * asink * acpm1) * cmtodeg;
+  const F ady_a = delpro * (hya * acosk) * cmtodeg, ady_b = delpro * (hyb * acosk) * cmtodeg;
+  const F dxx = zd - adx_b;
+  const F dyy = xdella - ady_b;
+  const F wgt_lat = dxx * ady_a * ga;
+  const F wlatn1 = wl * wgt_lat;
+  const F wlatn2 = omwl * wgt_lat;
+  const F wlonn = dyy * adx_a * ga;
+  const F wgt_cor = adx_a * ady_a * ga;
+  const F wcorn1 = wc * wgt_cor;
+  const F wcorn2 = omwc * wgt_cor;
+  F sumwn = (zd * ady_b + xdella * adx_b - adx_b * ady_b) * ga;
+  const F wk0 = a2 * cg0 + b2 * cg0;
+  const F wkp = p2 * cg0;
+  const F wkm = m2 * cg0;
+  sumwn = sumwn + wk0;
+  F r = (T(1) - sumwn) * f0;
+  r = r + wlonn * f1;
+  r = r + wlatn1 * f2;
+  r = r + wlatn2 * f3;
+  r = r + wcorn1 * f4;
+  r = r + wcorn2 * f5;
+  r = r + wkm * f6;
+  r = r + wkp * f7;
+  return r;
+}
 // per-point scalars of the weights (ctuw.F90:146-170, 407-420)
 template <typename T>
 struct CtuPoint {

@@ -429,26 +429,35 @@ struct V4Adv {
   const int* dirI;      // [NANG][4]: JXO(K,1) | JYO(K,1) << 1 | KCR(K,1) << 2, KPM(K,-1), KPM(K,1)
   T xdella, delpro;
   int m0, m1;           // advected frequencies [m0, m1); the others are carried over
-  int xcd_walk;         // XCD-aware order of the workgroups
+  int xcd_walk;         // XCD-aware order of the workgroups (diagnostics: measured 1 % slower than the natural order, profiles/r06_fused_*.txt)
 };
 #ifndef V4_ADV_DEPTH
 #define V4_ADV_DEPTH 3
 #endif
-template <typename T, int NANG, int PP, int MODE>
-__device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n, int lane, T* __restrict__ sT, T* __restrict__ sScr, int nscr) {
-  constexpr int NFRE = V4_NFRE, N = NANG * NFRE, RS = PP * NANG, VEC = 16 / (int)sizeof(T), NC = NFRE / VEC, NVL = N / VEC, NITL = (NVL + 63) / 64;
-  constexpr int NCH = NITL * PP, D = V4_ADV_DEPTH;
+template <typename T, int NANG, int PP, int MODE, int NSCR>
+__device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n, int lane, T* __restrict__ sT, T* __restrict__ sScr) {
+  constexpr int NFRE = V4_NFRE, N = NANG * NFRE, RS = PP * NANG, VEC = 16 / (int)sizeof(T), NC = NFRE / VEC, NVL = N / VEC;
+  // steps: NFULL rounds of 64 chunks per point, point after point inside a round (the chunk's direction and frequencies are then the same
+  // for the PP steps of a round); the NREM chunks of every point that are left share NTS tail steps (36 directions, single precision:
+  // 324 chunks per point = 5 rounds + 4, the 12 left-over chunks of the three points are ONE step: 16 steps instead of 18)
+  constexpr int NFULL = NVL / 64, NREM = NVL - 64 * NFULL, NTS = (PP * NREM + 63) / 64, NCH = NFULL * PP + NTS, D = V4_ADV_DEPTH;
+  constexpr int PTW = 20;                              // words per point of sPt
   typedef T VT __attribute__((ext_vector_type(VEC)));
   typedef int I4 __attribute__((ext_vector_type(4)));
-  T* sB = sScr;                                        // [PP][5][NFRE]: the direction-independent halves of the weights (ctu_base)
-  T* sPt = sB + PP * 5 * NFRE;                         // [PP][12]
-  T* sK = sPt + PP * 12;                               // [NANG][4] + CMTODEG
+  T* sB = sScr;                                        // [PP][5][NFRE]: |h(1:2)|, |hy(1:2)|, CG of ctu_base
+  T* sPt = sB + PP * 5 * NFRE;                         // [PP][PTW]: ZDELLO, |COSPHM1|, GA, TANPH, DP(1:2), WLAT(1:2), WCOR(1:4), 1 - WLAT, 1 - WCOR
+  T* sK = sPt + PP * PTW;                              // [NANG][4]: 2 SP, 2 SM (ctu_dirfac with TANPH = 1, doubled), |SINTH|, |COSTH|; then CMTODEG
   int* sI = reinterpret_cast<int*>(sK + NANG * 4 + 4); // [PP][16]: ij, KLON(1:2), KLAT(1:2,1:2), KCOR(1:4,1:2)
   int* sD = sI + PP * 16;                              // [NANG][4]
-  V4_CHK((int)((reinterpret_cast<T*>(sD + NANG * 4) - sScr)) <= nscr);
-  for (int i = lane; i < PP * 12; i += 64) {
-    const int q = i / 12, e = i - q * 12;
-    sPt[i] = A.pt[(size_t)(ij0 + (q < n ? q : n - 1)) * 12 + e];
+  static_assert((PP * 5 * NFRE + PP * PTW + NANG * 4 + 4) * sizeof(T) + (PP * 16 + NANG * 4) * sizeof(int) <= NSCR * sizeof(T), "LDS scratch of the advecting load");
+  for (int i = lane; i < PP * PTW; i += 64) {
+    const int q = i / PTW, e = i - q * PTW;
+    const T* g = A.pt + (size_t)(ij0 + (q < n ? q : n - 1)) * 12;
+    T v = T(0);
+    if (e < 12) v = g[e];
+    else if (e < 18) v = T(1) - g[e - 6];              // 1 - WLAT(1:2), 1 - WCOR(1:4)
+    if (e == 1) v = m_abs(v);
+    sPt[i] = v;
   }
   for (int i = lane; i < PP * 16; i += 64) {
     const int q = i >> 4, e = i & 15;
@@ -459,39 +468,33 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
     if (e >= 7 && e <= 14) v = A.kcor[(size_t)ijq * 8 + (e - 7)];
     sI[i] = v;
   }
-  for (int i = lane; i < NANG * 4 + 4; i += 64) sK[i] = A.dirT[i];
+  for (int i = lane; i < NANG * 4 + 4; i += 64) {
+    const T v = A.dirT[i];
+    const int e = i & 3;
+    sK[i] = i >= NANG * 4 ? v : (e < 2 ? T(2) * v : m_abs(v));
+  }
   for (int i = lane; i < NANG * 4; i += 64) sD[i] = A.dirI[i];
   WSYNC();
-  if constexpr (MODE == 1) {
-    for (int i = lane; i < PP * NFRE; i += 64) {
-      const int q = i / NFRE, m = i - q * NFRE;
-      const int* iq = sI + q * 16;
-      const T* pq = sPt + q * 12;
-      T cgl[2], cgy0[2], cgy1[2];
-#pragma unroll
-      for (int ic = 0; ic < 2; ic++) {
-        cgl[ic] = A.cg[(size_t)iq[1 + ic] * NFRE + m];
-        cgy0[ic] = A.cg[(size_t)iq[3 + 2 * ic] * NFRE + m];
-        cgy1[ic] = A.cg[(size_t)iq[4 + 2 * ic] * NFRE + m];
-      }
-      const T wl[2] = {pq[6], pq[7]}, dp[2] = {pq[4], pq[5]};
-      const CtuBase<T> b = ctu_base(A.cg[(size_t)iq[0] * NFRE + m], cgl, cgy0, cgy1, wl, dp);
-      T* o = sB + q * 5 * NFRE + m;
-      o[0] = b.h[0]; o[NFRE] = b.h[1]; o[2 * NFRE] = b.hy[0]; o[3 * NFRE] = b.hy[1]; o[4 * NFRE] = b.cg0;
-    }
-    WSYNC();
-  }
   VT buf[D][8];
-  auto chunk_of = [&](int it, int& k, int& m) {
-    int w = lane + 64 * it;
-    if (it == NITL - 1 && NVL % 64 != 0) w = w < NVL ? w : NVL - 1;      // the lanes beyond the last chunk repeat it (the same stores)
+  // (point, direction, first frequency) of the lane's chunk in step c
+  auto chunk_of = [&](int c, int& q, int& k, int& m) {
+    int w;
+    if (c < NFULL * PP) {
+      const int it = c / PP;
+      q = c - it * PP;
+      w = lane + 64 * it;
+    } else {      // tail steps: chunk t of the PP NREM left-over ones; the lanes beyond the last one repeat it (the same stores)
+      int t = lane + 64 * (c - NFULL * PP);
+      t = t < PP * NREM ? t : PP * NREM - 1;
+      q = t / (NREM > 0 ? NREM : 1);
+      w = 64 * NFULL + (t - q * NREM);
+    }
     k = w / NC;
     m = (w - k * NC) * VEC;
   };
   auto issue = [&](int c, VT (&b)[8]) {
-    const int it = c / PP, q = c - it * PP;
-    int k, m;
-    chunk_of(it, k, m);
+    int q, k, m;
+    chunk_of(c, q, k, m);
     const I4 dk = *reinterpret_cast<const I4*>(sD + 4 * k);
     const int jx0 = dk.x & 1, jy0 = (dk.x >> 1) & 1, kc = (dk.x >> 2) & 3;
     const int* iq = sI + q * 16;
@@ -507,36 +510,35 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
     b[7] = *reinterpret_cast<const VT*>(own + dk.z * NFRE + m);
   };
   auto finish = [&](int c, const VT (&b)[8]) {
-    const int it = c / PP, q = c - it * PP;
-    int k, m;
-    chunk_of(it, k, m);
+    int q, k, m;
+    chunk_of(c, q, k, m);
     T r[VEC];
     if constexpr (MODE == 2) {
 #pragma unroll
       for (int i = 0; i < VEC; i++) r[i] = T(0.3) * b[0][i] + T(0.1) * (((b[1][i] + b[2][i]) + (b[3][i] + b[4][i])) + ((b[5][i] + b[6][i]) + b[7][i]));
     } else {
-      const I4 dk = *reinterpret_cast<const I4*>(sD + 4 * k);
-      const int jx0 = dk.x & 1, jy0 = (dk.x >> 1) & 1, kc = (dk.x >> 2) & 3;
-      const T* pq = sPt + q * 12;
-      const T zd = pq[0], cpm1 = pq[1], ga = pq[2], tanph = pq[3], wl_jy0 = pq[6 + jy0], wc_kc = pq[8 + kc];
+      const int sel = sD[4 * k];
+      const int jx0 = sel & 1, jy0 = (sel >> 1) & 1, kc = (sel >> 2) & 3;
+      const T* pq = sPt + q * PTW;
+      const T zd = pq[0], acpm1 = pq[1], ga = pq[2], tanph = pq[3], wl = pq[6 + jy0], omwl = pq[12 + jy0], wc = pq[8 + kc], omwc = pq[14 + kc];
       const T cmtodeg = sK[NANG * 4];
-      const T* kk = sK + 4 * k;
-      T tsp, tsm;
+      const VT kk = *reinterpret_cast<const VT*>(sK + 4 * k);      // (double precision: two 16-byte reads)
+      const T kk2 = sizeof(T) == 4 ? kk[2 % VEC] : sK[4 * k + 2], kk3 = sizeof(T) == 4 ? kk[3 % VEC] : sK[4 * k + 3];
+      T a2, b2, p2, m2;
       {
 #pragma clang fp contract(off)
-        tsp = tanph * kk[0];
-        tsm = tanph * kk[1];
+        const T tsp2 = tanph * kk[0], tsm2 = tanph * kk[1];
+        a2 = m_max(tsp2, T(0)); p2 = m_max(-tsp2, T(0)); b2 = m_max(-tsm2, T(0)); m2 = m_max(tsm2, T(0));
       }
-      const T sink = kk[2], cosk = kk[3];
       const T* bb = sB + q * 5 * NFRE + m;
-      const VT bh0 = *reinterpret_cast<const VT*>(bb), bh1 = *reinterpret_cast<const VT*>(bb + NFRE), by0 = *reinterpret_cast<const VT*>(bb + 2 * NFRE),
-               by1 = *reinterpret_cast<const VT*>(bb + 3 * NFRE), bc0 = *reinterpret_cast<const VT*>(bb + 4 * NFRE);
-      const V2<T> dl = {A.delpro, A.delpro}, sp2 = {tsp, tsp}, sm2 = {tsm, tsm};
+      const VT bha = *reinterpret_cast<const VT*>(bb + jx0 * NFRE), bhb = *reinterpret_cast<const VT*>(bb + (1 - jx0) * NFRE),
+               bya = *reinterpret_cast<const VT*>(bb + (2 + jy0) * NFRE), byb = *reinterpret_cast<const VT*>(bb + (3 - jy0) * NFRE),
+               bc0 = *reinterpret_cast<const VT*>(bb + 4 * NFRE);
 #pragma unroll
       for (int i = 0; i < VEC; i += 2) {
 #define P2(a) V2<T>{a[i], a[i + 1]}
-        const V2<T> rr = ctu_w8_stencil_pk<T>(P2(bh0), P2(bh1), P2(by0), P2(by1), P2(bc0), sink, cosk, cpm1, zd, A.xdella, ga, dl, cmtodeg, jx0, jy0,
-                                              wl_jy0, wc_kc, sp2, sm2, P2(b[0]), P2(b[1]), P2(b[2]), P2(b[3]), P2(b[4]), P2(b[5]), P2(b[6]), P2(b[7]));
+        const V2<T> rr = ctu_w8_stencil_abs<T>(P2(bha), P2(bhb), P2(bya), P2(byb), P2(bc0), kk2, kk3, acpm1, zd, A.xdella, ga, A.delpro, cmtodeg, wl, omwl,
+                                               wc, omwc, a2, b2, p2, m2, P2(b[0]), P2(b[1]), P2(b[2]), P2(b[3]), P2(b[4]), P2(b[5]), P2(b[6]), P2(b[7]));
 #undef P2
         r[i] = rr.x; r[i + 1] = rr.y;
       }
@@ -548,11 +550,35 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
 #pragma unroll
     for (int i = 0; i < VEC; i++) d[i * RS] = r[i];
   };
+  // the gathers of the first D - 1 steps leave before the direction-independent halves of the weights are built: their latency hides
+  // behind the seven CGROUP gathers per (point, frequency) below
 #pragma unroll
-  for (int c = 0; c < NCH + D - 1; c++) {
-    if (c < NCH) issue(c, buf[c % D]);
+  for (int c = 0; c < D - 1 && c < NCH; c++) issue(c, buf[c % D]);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (MODE == 1) {
+    for (int i = lane; i < PP * NFRE; i += 64) {
+      const int q = i / NFRE, m = i - q * NFRE;
+      const int* iq = sI + q * 16;
+      const T* pq = sPt + q * PTW;
+      T cgl[2], cgy0[2], cgy1[2];
+#pragma unroll
+      for (int ic = 0; ic < 2; ic++) {
+        cgl[ic] = A.cg[(size_t)iq[1 + ic] * NFRE + m];
+        cgy0[ic] = A.cg[(size_t)iq[3 + 2 * ic] * NFRE + m];
+        cgy1[ic] = A.cg[(size_t)iq[4 + 2 * ic] * NFRE + m];
+      }
+      const T wl[2] = {pq[6], pq[7]}, dp[2] = {pq[4], pq[5]};
+      const CtuBase<T> b = ctu_base(A.cg[(size_t)iq[0] * NFRE + m], cgl, cgy0, cgy1, wl, dp);
+      T* o = sB + q * 5 * NFRE + m;
+      o[0] = m_abs(b.h[0]); o[NFRE] = m_abs(b.h[1]); o[2 * NFRE] = m_abs(b.hy[0]); o[3 * NFRE] = m_abs(b.hy[1]); o[4 * NFRE] = b.cg0;
+    }
+    WSYNC();
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    if (c + D - 1 < NCH) issue(c + D - 1, buf[(c + D - 1) % D]);
     __builtin_amdgcn_sched_barrier(0);
-    if (c >= D - 1) finish(c - (D - 1), buf[(c - (D - 1)) % D]);
+    finish(c, buf[c % D]);
     __builtin_amdgcn_sched_barrier(0);
   }
   WSYNC();
@@ -1339,7 +1365,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   if constexpr (ADV != 0) {
     // the tile is the advected spectrum: staging rows, factor table and planes are free until the tables below are filled
     static_assert(PART == 0, "the advecting tile load belongs to the one-kernel build");
-    v4_advect_tile<T, NANG, PP, ADV>(adv, ij0, n, lane, sT, sStg, (NFRE + V4_NSTG) * RS - NFRE * RS + PP * NFRE * 4 + 2 * PLN);
+    v4_advect_tile<T, NANG, PP, ADV, V4_NSTG * RS + PP * NFRE * 4 + 2 * PLN>(adv, ij0, n, lane, sT, sStg);
   } else {
 #pragma unroll
     for (int q = 0; q < PP; q++) {

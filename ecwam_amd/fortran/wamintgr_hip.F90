@@ -27,6 +27,9 @@ MODULE ECWAM_HIP_DRV
   INTEGER(KIND=JWIM) :: HIP_NEMONTAU = 0       ! YOWCOUP:NEMONTAU  accumulation count of the WAVE2OCEAN stresses: advanced after every IMPLSCH
                                                ! call when LWNEMOCOU (wamintgr.F90:150); UPDNEMOSTRESS divides by it and resets it (updnemostress.F90:84-123)
   INTEGER(KIND=JWIM) :: HIP_ICODE_WND = 0      ! NEWWIND's ICODE_WND: ICODE_CPL when LWCOU (newwind.F90:120-124); 0 = ICODE of the set-up
+  ! the 1:1 step as ONE kernel where a build covers the configuration (ecwam_hip_propags2_implsch: PROPAGS2 inside IMPLSCH's tile load, the same
+  ! bits as the two kernels); .FALSE. keeps PROPAGS2 and IMPLSCH apart
+  LOGICAL :: HIP_LFUSED_STEP = .TRUE.
   LOGICAL :: HIP_LSYNC_EAGER = .FALSE.         ! end every source-term step with the reference's asynchronous copies (wamintgr_loki_gpu.F90:197-200:
                                                ! FL1 + FF_NOW on queue 4, WVENVI on 5, WAM2NEMO on 6): 2.2 GB per step at O320 -- off by default,
                                                ! the host's GET_HOST_DATA_* at its output steps fetch what is missing
@@ -102,7 +105,7 @@ SUBROUTINE WAMINTGR_HIP (CDTPRA, CDATE, CDATEWH, CDTIMP, CDTIMPNEXT,  &
   INTEGER :: NP, NPROMA, NFRE, NANG, ISUB
   INTEGER(C_INT) :: NPASS, PMS(2), PME(2), PCP(2), PRG(2)
   REAL(C_DOUBLE) :: PDEL(2)
-  LOGICAL :: LSOURCE_NOW
+  LOGICAL :: LSOURCE_NOW, LFUSE
 
   S0 = HIPST%QUEUE(0)     ! every kernel and copy of the step on the compute queue (a non-blocking stream)
   NP = HIPST%NPTS; NPROMA = HIPST%NPROMA; NFRE = HIPST%NFRE; NANG = HIPST%NANG
@@ -133,6 +136,7 @@ SUBROUTINE WAMINTGR_HIP (CDTPRA, CDATE, CDATEWH, CDTIMP, CDTIMPNEXT,  &
   CALL BLK2GLO%GET_DEVICE_DATA_RDONLY()
 
   !*     PROPAGATION TIME (wamintgr.F90:94-100)
+  LFUSE = .FALSE.
   IF (CDATE == CDTPRA) THEN
     IF (HIPST%IREFRA /= 0) THEN
       ! depth / current refraction: every weight rebuilt inside the stencil from the dot terms of ECWAM_HIP_SET_ENVIRONMENT
@@ -165,6 +169,13 @@ SUBROUTINE WAMINTGR_HIP (CDTPRA, CDATE, CDATEWH, CDTIMP, CDTIMPNEXT,  &
     ! PROPAG_WAM (propag_wam.F90:166,247-313): MPEXCHNG, then fast (M <= IFRELFMAX, DELPRO_LF) and slow waves in one pass, then the
     ! remaining fast-wave sub-steps on the compact buffer (exchanged again before each, as propag_wam.F90:293 does).  With more than
     ! one rank the exchange runs on the library's stream while the rows that read no halo row are advected.
+    ! When the source terms are due right after this propagation step (wamintgr.F90:110) and a one-kernel build covers the configuration, the
+    ! advection is left to IMPLSCH's tile load: only the exchange is posted here, FL1 / FL3 are swapped behind that kernel
+    LFUSE = HIP_LFUSED_STEP .AND. HIPST%IFRELFMAX <= 0 .AND. HIP_LLSOURCE .AND. (HIP_CDTPRO >= CDTIMPNEXT)
+    IF (LFUSE) LFUSE = ECWAM_HIP_PROPAGS2_IMPLSCH_SUPPORTED(HIPST%CTX) /= 0
+    IF (LFUSE) THEN
+      CALL HIP_HALO_START(HIPST%D_FL1, NANG * NFRE, S0)
+    ELSE
     IF (HIPST%IFRELFMAX > 0) THEN
       ! the fast waves do not depend on the slow ones: their sub-steps 1 .. NSTEP_LF-1 first, compact rows -> compact rows, then one full
       ! pass that takes their last state from the compact rows as the input of the last sub-step and writes complete FL3 rows and the
@@ -196,7 +207,10 @@ SUBROUTINE WAMINTGR_HIP (CDTPRA, CDATE, CDATEWH, CDTIMP, CDTIMPNEXT,  &
       HIPST%LGFAST_VALID = .TRUE.
     ENDIF
     ENDIF
-    DTMP = HIPST%D_FL1; HIPST%D_FL1 = HIPST%D_FL3; HIPST%D_FL3 = DTMP
+    ENDIF
+    IF (.NOT. LFUSE) THEN
+      DTMP = HIPST%D_FL1; HIPST%D_FL1 = HIPST%D_FL3; HIPST%D_FL3 = DTMP
+    ENDIF
     CDATE = HIP_CDTPRO
   ENDIF
 
@@ -238,10 +252,21 @@ SUBROUTINE WAMINTGR_HIP (CDTPRA, CDATE, CDATEWH, CDTIMP, CDTIMPNEXT,  &
  &    TAUICX=.TRUE., TAUICY=.TRUE.)
     CALL VARS_4D%GET_DEVICE_DATA_WRONLY(XLLWS=.TRUE.)
     CALL MIJ%GET_DEVICE_DATA_WRONLY()
+    IF (LFUSE) THEN
+      ! PROPAGS2 + IMPLSCH of the rows that read no halo row while the exchange runs, then the two ends of the band (propag_wam.F90:166)
+      CALL ADVECT_AND_INTEGRATE(HIPST%KIJS_INT - 1, HIPST%KIJL_INT)
+      IF (HIPST%LDECOMP) THEN
+        CALL HIP_HALO_FINISH(S0)
+        CALL ADVECT_AND_INTEGRATE(0_C_INT, HIPST%KIJS_INT - 1)
+        CALL ADVECT_AND_INTEGRATE(HIPST%KIJL_INT, NP)
+      ENDIF
+      DTMP = HIPST%D_FL1; HIPST%D_FL1 = HIPST%D_FL3; HIPST%D_FL3 = DTMP
+    ELSE
     CALL FAST_SINK(.TRUE.)      ! IMPLSCH leaves the fast waves of its result in the compact rows as well
     CALL ECWAM_HIP_CHECK(ECWAM_HIP_IMPLSCH(HIPST%CTX, 0_C_INT, NP, HIPST%D_FL1, HIPST%D_WVPRPT, HIPST%D_FF, HIPST%D_INTF, &
  &        HIPST%D_MIJ, HIPST%D_XLLWS, HIPST%D_W2N, C_NULL_PTR, S0), 'ECWAM_HIP_IMPLSCH')
     CALL FAST_SINK(.FALSE.)
+    ENDIF
     IF (HIP_LSYNC_EAGER) THEN      ! wamintgr_loki_gpu.F90:197-200
       CALL VARS_4D%SYNC_HOST_RDONLY(FL1=.TRUE., QUEUE=4)
       CALL FF_NOW%SYNC_HOST_RDONLY(QUEUE=4)
@@ -291,6 +316,15 @@ CONTAINS
     ELSE      ! the library keeps no pointer into a buffer this layer swaps
       CALL ECWAM_HIP_CHECK(ECWAM_HIP_SET_FASTWAVE_COPY(HIPST%CTX, C_NULL_PTR, 0_C_INT), 'ECWAM_HIP_SET_FASTWAVE_COPY')
     ENDIF
+  END SUBROUTINE
+  ! the one-kernel step on local rows [K0, K1): PROPAGS2 from the rows of FL1 inside IMPLSCH's tile load, the new spectrum to the rows of FL3
+  SUBROUTINE ADVECT_AND_INTEGRATE(K0, K1)
+    INTEGER(C_INT), INTENT(IN) :: K0, K1
+    IF (K1 <= K0) RETURN
+    CALL ECWAM_HIP_CHECK(ECWAM_HIP_PROPAGS2_IMPLSCH(HIPST%CTX, HIPST%D_FL1, HIPST%D_FL3, NP, HIPST%NGY, REAL(HIPST%IDELPRO, C_DOUBLE), &
+ &        HIPST%D_KXLT, HIPST%D_ZD, HIPST%XDELLA, HIPST%D_CP, HIPST%D_SP, HIPST%D_KLON, HIPST%D_KLAT, HIPST%D_KCOR, HIPST%D_WLAT, &
+ &        HIPST%D_WCOR, HIPST%D_CG, HIPST%D_CM1, K0, K1, 1_C_INT, HIPST%NFRE_RED, HIPST%D_WVPRPT, HIPST%D_FF, HIPST%D_INTF, HIPST%D_MIJ, &
+ &        HIPST%D_XLLWS, HIPST%D_W2N, 0_C_INT, S0), 'ECWAM_HIP_PROPAGS2_IMPLSCH')
   END SUBROUTINE
   SUBROUTINE ADVECT_FULL(K0, K1)
     INTEGER(C_INT), INTENT(IN) :: K0, K1

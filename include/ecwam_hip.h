@@ -302,9 +302,10 @@ int ecwam_hip_implsch_reserve(ecwam_hip_ctx *ctx, int npts);
  * ecwam_hip_propags2_otf(f1 -> f3, copy_rest = 1) followed by ecwam_hip_implsch(f3) leaves in f3, FF, INTF, MIJ, XLLWS, WAM2NEMO.
  * The caller runs NEWWIND (ecwam_hip_newwind) BEFORE this call (it touches the forcing only) and swaps f1 / f3 after it, as after PROPAGS2.
  * Rows whose stencil reads halo rows are passed in a second call behind ecwam_hip_halo_finish, exactly as with ecwam_hip_propags2_otf.
- * Covered: what ecwam_hip_propags2_implsch_supported reports (single precision, 36 directions x 36 frequencies, the common builds of
+ * Covered: what ecwam_hip_propags2_implsch_supported reports (36 directions x 36 frequencies in either precision, the common builds of
  * IMPLSCH with IPHYS = 1 / ISNONLIN = 0, no obstructions, no fast-wave sub-steps); everything else runs the two calls.
- * flags: 0 (bit 0: workgroups in their natural order instead of the XCD-aware one; bit 1: the go / no-go probe of diagnostics builds).
+ * flags: 0 (bit 0: workgroups in the XCD-aware order of the stencil kernel instead of the natural one; bit 1: the go / no-go probe of
+ * diagnostics builds).
  */
 int ecwam_hip_propags2_implsch_supported(ecwam_hip_ctx *ctx);
 int ecwam_hip_propags2_implsch(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n, int ngy, double delpro, const int *kxlt, const void *zdello,

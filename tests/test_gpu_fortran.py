@@ -119,6 +119,18 @@ def _read_out(path, dt, nproma, nchnk, nang, nfre, n, nemo=None):
                                                              ("sp", 0, 2, True, False), ("sp", 0, 0, False, True), ("dp", 5, 0, False, True),
                                                              ("sp", 5, 2, False, False), ("dp", 4, 3, False, False)])
 def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec, lf, irefra, subgrid, nosource):
+    _fortran_vs_python_host(tmp_path, prec, lf, irefra, subgrid, nosource)
+
+
+@pytest.mark.parametrize("prec,nosource", [("sp", False), ("dp", False), ("sp", True)])
+def test_fortran_one_kernel_step_matches_python_host_two_kernels(tmp_path, prec, nosource):
+    """36 directions: WAMINTGR_HIP takes the one-kernel step (ecwam_hip_propags2_implsch: the exchange posted at propagation time, PROPAGS2
+    inside IMPLSCH's tile load when the source terms are due), the Python host drives PROPAGS2 and IMPLSCH as two kernels -- the same bits.
+    With LLSOURCE = F the Fortran side must fall back to the separate advection."""
+    _fortran_vs_python_host(tmp_path, prec, 0, 0, False, nosource, nang=36, nfre_red=36, idelt=450)
+
+
+def _fortran_vs_python_host(tmp_path, prec, lf, irefra, subgrid, nosource, nang=12, nfre_red=25, idelt=900):
     """lf > 0 together with irefra > 0: fast-wave sub-steps with refraction (propag_wam.F90:175-212 + :247-313), the reference's call
     sequence on the full rows with one CURMASK per frequency range.
     nosource: YOWSTAT's LLSOURCE = F -- the branch of wamintgr.F90:152-160 (FL1 = MAX(FL1, EPSMIN), MIJ = NFRE, XLLWS = 0) runs on the
@@ -131,7 +143,7 @@ def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec, lf, irefra, su
     exe = build.fortran_exe(prec)
     if not os.path.exists(exe):
         build.build_fortran()
-    cfg = Config(nang=12, nfre=36, nfre_red=25, idelt=900, idelpro=900, irefra=irefra)
+    cfg = Config(nang=nang, nfre=36, nfre_red=nfre_red, idelt=idelt, idelpro=idelt, irefra=irefra)
     g = G.build_grid(16, mask="continents")
     m = Wamintgr(cfg, g, prec, ifrelfmax=lf, delpro_lf=450.0 if lf else None)    # lf: fast waves M <= lf in two sub-steps
     m.init_synthetic(seed=21)
@@ -171,8 +183,8 @@ def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec, lf, irefra, su
     m.ctx.close()
 
 
-@pytest.mark.parametrize("prec,lf,irefra", [("sp", 0, 0), ("dp", 5, 0), ("sp", 0, 2), ("dp", 4, 3)])
-def test_fortran_two_processes_on_one_gpu_match_single_domain(tmp_path, prec, lf, irefra):
+@pytest.mark.parametrize("prec,lf,irefra,nang", [("sp", 0, 0, 12), ("dp", 5, 0, 12), ("sp", 0, 2, 12), ("dp", 4, 3, 12), ("sp", 0, 0, 36)])
+def test_fortran_two_processes_on_one_gpu_match_single_domain(tmp_path, prec, lf, irefra, nang):
     """The multi-rank path of the Fortran layer, executed: two processes of the harness share the GPU, each owns one band of the sea
     points (ECWAM_HIP_SET_DECOMPOSITION with the reference's 1-based NTOPE / IJTOPE / NIJSTART-style lists -> 0-based device rows,
     halo rows and land slot behind the owned rows, interior range), the halo travels host-staged (ecwam_hip_halo_pack_host ->
@@ -180,7 +192,8 @@ def test_fortran_two_processes_on_one_gpu_match_single_domain(tmp_path, prec, lf
     compact rows.  Both bands together must equal the single-domain Python host bit for bit.  Also LWNEMOCOU: the WAVE2OCEAN sums and
     the accumulation count NEMONTAU (wamintgr.F90:150) after two source steps.  irefra > 0: refraction on two ranks -- each process hands
     ECWAM_HIP_PROENVHALO its own DEPTH / UCUR / VCUR / OMOSNH2KD, the halo rows of the environment travel through the same exchange as rows
-    of 3 NFRE + 3 reals, every PROPAGS2 call of the (sub-stepped) sequence runs behind its own exchange of the spectra."""
+    of 3 NFRE + 3 reals, every PROPAGS2 call of the (sub-stepped) sequence runs behind its own exchange of the spectra.
+    nang = 36: the Fortran ranks take the one-kernel step (interior rows behind the posted exchange, the two ends behind its arrival)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from ecwam_amd import build, decomp, grid as G
@@ -189,7 +202,8 @@ def test_fortran_two_processes_on_one_gpu_match_single_domain(tmp_path, prec, lf
     exe = build.fortran_exe(prec)
     if not os.path.exists(exe):
         build.build_fortran()
-    cfg = Config(nang=12, nfre=36, nfre_red=25, idelt=900, idelpro=900, lwnemocou=True, irefra=irefra)
+    dt_ = 900 if nang == 12 else 450
+    cfg = Config(nang=nang, nfre=36, nfre_red=25 if nang == 12 else 36, idelt=dt_, idelpro=dt_, lwnemocou=True, irefra=irefra)
     g = G.build_grid(16, mask="continents")
     kw = dict(ifrelfmax=lf, delpro_lf=450.0 if lf else None)
     nranks, nproma, nstep = 2, 24, 2

@@ -29,12 +29,12 @@ def api():
     return _api
 
 
-def _pair(cfg, g, seed, **kw):
+def _pair(cfg, g, seed, prec="sp", **kw):
     from ecwam_amd.wamintgr import Wamintgr
 
     ms = []
     for _ in range(2):
-        m = Wamintgr(cfg, g, "sp", **kw)
+        m = Wamintgr(cfg, g, prec, **kw)
         m.init_synthetic(seed=seed)
         m.ff_next = m.ff.clone()
         m.ff_next[:, 3] *= 1.03      # a new wind speed: NEWWIND hands it over before the source terms
@@ -49,16 +49,17 @@ def _same_state(a, b):
         assert torch.equal(x, y), f"{name}: {int((x != y).sum())} of {x.numel()} elements differ"
 
 
+@pytest.mark.parametrize("prec", ["sp", "dp"])
 @pytest.mark.parametrize("flags", [dict(), dict(llgcbz0=True, llnormagam=True)])
 @pytest.mark.parametrize("nfre_red,ngrid", [(36, 24), (29, 17)])
-def test_one_kernel_step_is_bit_identical_to_the_two_kernels(api, flags, nfre_red, ngrid):
+def test_one_kernel_step_is_bit_identical_to_the_two_kernels(api, flags, nfre_red, ngrid, prec):
     """Three steps on a grid with land (land slot, short last wave: the sea-point count is not a multiple of three at either size), all
     frequencies advected or the last seven carried over (NFRE_RED = 29 cuts a 16-byte vector)."""
     from ecwam_amd import grid as G
 
     cfg = Config(nang=36, nfre=36, nfre_red=nfre_red, idelt=450, idelpro=450, **flags)
     g = G.build_grid(ngrid, mask="continents")
-    two, one = _pair(cfg, g, seed=21)
+    two, one = _pair(cfg, g, seed=21, prec=prec)
     assert one.fused_available()
     assert two.build_weights() == 0 and one.build_weights() == 0
     for _ in range(3):
@@ -71,7 +72,7 @@ def test_one_kernel_step_is_bit_identical_to_the_two_kernels(api, flags, nfre_re
 
 
 def test_one_kernel_step_natural_order_and_row_blocks(api):
-    """The workgroups in their natural order (flags bit 0) and the rows passed in three unequal blocks give the same bits as one call."""
+    """The workgroups in the XCD-aware order (flags bit 0) and the rows passed in three unequal blocks give the same bits as one call."""
     from ecwam_amd import grid as G
 
     cfg = Config(nang=36, nfre=36, nfre_red=36, idelt=450, idelpro=450)

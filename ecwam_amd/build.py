@@ -70,11 +70,16 @@ VARIANTS = {"": FAST_DIV, "exactdiv": ["-DECWAM_HIP_STRICT=0"], "strict1": ["-DE
             # the all-reduces of a SINPUT row one after the other (rounds 2 - 5a) instead of in one batch (V4_REDN)
             # round 6: the library with the go / no-go probe of the one-kernel step (implsch4a.hip, flags bit 1 of ecwam_hip_propags2_implsch)
             "advprobe": FAST_DIV + ["-DV4_ADV_PROBE=1"],
+            # the on-the-fly CTU weights (k_propags2_otf and the advecting load of k_implsch4) in ctuw.F90's order of operations, contraction off:
+            # bit-identical to the stored-weight scheme (csrc/ctu.h; the product hoists the factors and fuses the multiply-adds)
+            "ctustrict": FAST_DIV,
             # ... and with 2 / 4 steps of gathers in flight instead of 3 (V4_ADV_DEPTH)
             "advd2": FAST_DIV + ["-DV4_ADV_DEPTH=2"], "advd4": FAST_DIV + ["-DV4_ADV_DEPTH=4"],
             "noredn": FAST_DIV + ["-DV4_REDN=0"], "redndp": FAST_DIV + ["-DV4_REDN=3"]}
+# flags a variant adds to EVERY source it rebuilds (not only the IMPLSCH units)
+VARIANT_ANY = {"ctustrict": ["-DECWAM_HIP_CTU_STRICT=1"]}
 # variants that rebuild only some of the IMPLSCH translation units (the other objects are the product's)
-VARIANT_SOURCES = {"advprobe": ("implsch4a.hip",), "advd2": ("implsch4a.hip",), "advd4": ("implsch4a.hip",), "rdp": ("implsch4rd.hip",), "rdpO1": ("implsch4rd.hip",), "rdpchk": ("implsch4rd.hip",), "rdps": ("implsch4rd.hip",),
+VARIANT_SOURCES = {"ctustrict": ("propag.hip", "implsch4a.hip"), "advprobe": ("implsch4a.hip",), "advd2": ("implsch4a.hip",), "advd4": ("implsch4a.hip",), "rdp": ("implsch4rd.hip",), "rdpO1": ("implsch4rd.hip",), "rdpchk": ("implsch4rd.hip",), "rdps": ("implsch4rd.hip",),
                    "split": ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip"), "o2": ("implsch4.hip",), "rowsplit": ("implsch4.hip",), "diaold": ("implsch4.hip",), "stagger": ("implsch4.hip",), "stagger6": ("implsch4.hip",), "shuf1": ("implsch4.hip",), "plainhalves": ("implsch4.hip",), "noread2": ("implsch4.hip",), "norecpf": ("implsch4.hip",), "recpf1": ("implsch4.hip",), "recpfdp": ("implsch4.hip",), "rlanedp": ("implsch4.hip",), "recv": ("implsch4.hip",), "norecs": ("implsch4.hip",), "noredn": ("implsch4.hip",), "redndp": ("implsch4.hip",)}
 
 INCLUDE = os.path.join(HERE, "..", "include", "ecwam_hip.h")
@@ -119,7 +124,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
         special = bool(variant) and src in VARIANT_SOURCES.get(variant, IMPLSCH_SOURCES)
         obj = os.path.join(LIBDIR, src.replace(".hip", f".{variant}.o" if special else ".o"))
         real_src, extra = DERIVED.get(src, (src, []))
-        flags = FLAGS + extra + ((VARIANTS[variant] if special else FAST_DIV) if src in IMPLSCH_SOURCES else [])
+        flags = FLAGS + extra + ((VARIANTS[variant] if special else FAST_DIV) if src in IMPLSCH_SOURCES else []) + (VARIANT_ANY.get(variant, []) if special else [])
         objs.append(obj)
         st = _stamp(real_src, flags)
         old = ""

@@ -4,6 +4,10 @@
 #pragma once
 #include "dev.h"
 
+#ifndef ECWAM_HIP_CTU_STRICT
+#define ECWAM_HIP_CTU_STRICT 0   // 1: the on-the-fly weights in ctuw.F90's order of operations (bit-identical to the stored-weight scheme)
+#endif
+
 // propags2.F90:107-116 for one element, in the reference's association order; contraction off so that every kernel that
 // applies the stencil (stored weights, vectorised, on-the-fly weights) rounds identically
 template <typename T>
@@ -170,6 +174,82 @@ __device__ __forceinline__ CtuV2<T> ctu_w8_stencil_abs(CtuV2<T> ha, CtuV2<T> hb,
   r = r + wkm * f6;
   r = r + wkp * f7;
   return r;
+}
+// The weights with every factor that does not depend on all three of (point, frequency, direction) hoisted out of the per-element code, and
+// the fused multiply-adds the expressions offer (round 6; the product form of the on-the-fly weights).  Per (point, frequency) the caller
+// prepares xa = |h| COSPHM1 DELPRO CMTODEG and ya = |hy| DELPRO CMTODEG for both neighbours (ctu_fast_planes), ordered by the direction's
+// quadrant; per (point, direction) ab2 = MAX(2 TSP, 0) + MAX(-2 TSM, 0), p2 = MAX(-2 TSP, 0), m2 = MAX(2 TSM, 0); per point zdg = ZDELLO GA and
+// xdg = XDELLA GA.  ABS(-DELPRO CGX CMTODEG) is then ONE product xa |SINTH(K)| (four in ctuw.F90's order), and so on: 30 packed operations
+// per pair of frequencies instead of 54.  Every weight goes through fewer roundings than in ctuw.F90's order of operations; against the
+// stored-weight scheme (k_ctuw + k_propags2, the reference's order: the bit-identity partner) the weights differ by a few units in the last
+// place (tests: <= 4 eps of the weight's scale 1).  -DECWAM_HIP_CTU_STRICT=1 builds the kernels with ctuw.F90's order instead.
+template <typename T>
+__device__ __forceinline__ void ctu_fast_planes(const CtuBase<T>& b, T acpm1, T dc, T* xa0, T* xa1, T* ya0, T* ya1) {   // dc = DELPRO CMTODEG
+#pragma clang fp contract(off)
+  *xa0 = (m_abs(b.h[0]) * acpm1) * dc; *xa1 = (m_abs(b.h[1]) * acpm1) * dc;
+  *ya0 = m_abs(b.hy[0]) * dc; *ya1 = m_abs(b.hy[1]) * dc;
+}
+template <typename T>
+__device__ __forceinline__ CtuV2<T> ctu_v2fma(CtuV2<T> a, CtuV2<T> b, CtuV2<T> c) {
+  CtuV2<T> r;
+  if constexpr (sizeof(T) == 4) r = __builtin_elementwise_fma(a, b, c);
+  else { r.x = __builtin_fma(a.x, b.x, c.x); r.y = __builtin_fma(a.y, b.y, c.y); }
+  return r;
+}
+template <typename T>
+struct CtuFastW8 {      // SUMWN, WLONN(JXO(K,1)), WLATN(JYO(K,1),1:2), WCORN(1,1:2), WKPMN(-1), WKPMN(+1) for a pair of frequencies
+  CtuV2<T> sumwn, wlon, wlat1, wlat2, wcor1, wcor2, wkm, wkp;
+};
+template <typename T>
+__device__ __forceinline__ CtuFastW8<T> ctu_fast_w8(CtuV2<T> xa, CtuV2<T> xb, CtuV2<T> ya, CtuV2<T> yb, CtuV2<T> cg0, T asink, T acosk, T zd, T xdella, T ga,
+                                                    T zdg, T xdg, T wl, T omwl, T wc, T omwc, CtuV2<T> ab2, CtuV2<T> p2, CtuV2<T> m2) {
+#pragma clang fp contract(off)      // the fused multiply-adds are the ones written out: the same bits in every translation unit
+  typedef CtuV2<T> F;
+  const F adx_a = xa * asink, adx_b = xb * asink, ady_a = ya * acosk, ady_b = yb * acosk;
+  const F dxx = zd - adx_b, dyy = xdella - ady_b;
+  const F yag = ady_a * ga, xag = adx_a * ga, xbg = adx_b * ga;
+  const F wgt_lat = dxx * yag;
+  const F wgt_cor = adx_a * yag;
+  CtuFastW8<T> w;
+  w.wlon = dyy * xag;
+  F sumwn = ab2 * cg0;                                                  // WKPMN(0)
+  sumwn = ctu_v2fma<T>(F{zdg, zdg}, ady_b, sumwn);
+  sumwn = ctu_v2fma<T>(F{xdg, xdg}, adx_b, sumwn);
+  w.sumwn = ctu_v2fma<T>(-xbg, ady_b, sumwn);
+  w.wlat1 = wl * wgt_lat; w.wlat2 = omwl * wgt_lat;
+  w.wcor1 = wc * wgt_cor; w.wcor2 = omwc * wgt_cor;
+  w.wkm = m2 * cg0; w.wkp = p2 * cg0;
+  return w;
+}
+template <typename T>
+__device__ __forceinline__ CtuV2<T> ctu_fast_apply(const CtuFastW8<T>& w, CtuV2<T> f0, CtuV2<T> f1, CtuV2<T> f2, CtuV2<T> f3, CtuV2<T> f4, CtuV2<T> f5,
+                                                   CtuV2<T> f6, CtuV2<T> f7) {
+#pragma clang fp contract(off)
+  CtuV2<T> r = ctu_v2fma<T>(-w.sumwn, f0, f0);                          // (1 - SUMWN) F
+  r = ctu_v2fma<T>(w.wlon, f1, r);
+  r = ctu_v2fma<T>(w.wlat1, f2, r);
+  r = ctu_v2fma<T>(w.wlat2, f3, r);
+  r = ctu_v2fma<T>(w.wcor1, f4, r);
+  r = ctu_v2fma<T>(w.wcor2, f5, r);
+  r = ctu_v2fma<T>(w.wkm, f6, r);
+  r = ctu_v2fma<T>(w.wkp, f7, r);
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ CtuV2<T> ctu_fast_stencil(CtuV2<T> xa, CtuV2<T> xb, CtuV2<T> ya, CtuV2<T> yb, CtuV2<T> cg0, T asink, T acosk, T zd, T xdella,
+                                                     T ga, T zdg, T xdg, T wl, T omwl, T wc, T omwc, CtuV2<T> ab2, CtuV2<T> p2, CtuV2<T> m2, CtuV2<T> f0,
+                                                     CtuV2<T> f1, CtuV2<T> f2, CtuV2<T> f3, CtuV2<T> f4, CtuV2<T> f5, CtuV2<T> f6, CtuV2<T> f7) {
+  return ctu_fast_apply<T>(ctu_fast_w8<T>(xa, xb, ya, yb, cg0, asink, acosk, zd, xdella, ga, zdg, xdg, wl, omwl, wc, omwc, ab2, p2, m2), f0, f1, f2, f3, f4,
+                           f5, f6, f7);
+}
+// the direction's four numbers of the great-circle term from TSP2 = 2 TANPH SP, TSM2 = 2 TANPH SM (see ctu_w8_stencil_abs)
+template <typename T>
+__device__ __forceinline__ void ctu_fast_dir(T tanph, T sp2, T sm2, T& ab2, T& p2, T& m2) {
+#pragma clang fp contract(off)
+  const T tsp2 = tanph * sp2, tsm2 = tanph * sm2;
+  ab2 = m_max(tsp2, T(0)) + m_max(-tsm2, T(0));
+  p2 = m_max(-tsp2, T(0));
+  m2 = m_max(tsm2, T(0));
 }
 // per-point scalars of the weights (ctuw.F90:146-170, 407-420)
 template <typename T>

@@ -456,6 +456,8 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
     T v = T(0);
     if (e < 12) v = g[e];
     else if (e < 18) v = T(1) - g[e - 6];              // 1 - WLAT(1:2), 1 - WCOR(1:4)
+    else if (e == 18) v = g[0] * g[2];                 // ZDELLO GA
+    else v = A.xdella * g[2];                          // XDELLA GA
     if (e == 1) v = m_abs(v);
     sPt[i] = v;
   }
@@ -524,16 +526,22 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
       const T cmtodeg = sK[NANG * 4];
       const VT kk = *reinterpret_cast<const VT*>(sK + 4 * k);      // (double precision: two 16-byte reads)
       const T kk2 = sizeof(T) == 4 ? kk[2 % VEC] : sK[4 * k + 2], kk3 = sizeof(T) == 4 ? kk[3 % VEC] : sK[4 * k + 3];
+#if ECWAM_HIP_CTU_STRICT
       T a2, b2, p2, m2;
       {
 #pragma clang fp contract(off)
         const T tsp2 = tanph * kk[0], tsm2 = tanph * kk[1];
         a2 = m_max(tsp2, T(0)); p2 = m_max(-tsp2, T(0)); b2 = m_max(-tsm2, T(0)); m2 = m_max(tsm2, T(0));
       }
+#else
+      T ab2, p2, m2;
+      ctu_fast_dir<T>(tanph, kk[0], kk[1], ab2, p2, m2);
+#endif
       const T* bb = sB + q * 5 * NFRE + m;
       const VT bha = *reinterpret_cast<const VT*>(bb + jx0 * NFRE), bhb = *reinterpret_cast<const VT*>(bb + (1 - jx0) * NFRE),
                bya = *reinterpret_cast<const VT*>(bb + (2 + jy0) * NFRE), byb = *reinterpret_cast<const VT*>(bb + (3 - jy0) * NFRE),
                bc0 = *reinterpret_cast<const VT*>(bb + 4 * NFRE);
+#if ECWAM_HIP_CTU_STRICT
 #pragma unroll
       for (int i = 0; i < VEC; i += 2) {
 #define P2(a) V2<T>{a[i], a[i + 1]}
@@ -542,6 +550,18 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
 #undef P2
         r[i] = rr.x; r[i + 1] = rr.y;
       }
+#else
+      const T zdg = pq[18], xdg = pq[19];
+#pragma unroll
+      for (int i = 0; i < VEC; i += 2) {
+#define P2(a) V2<T>{a[i], a[i + 1]}
+        const V2<T> rr = ctu_fast_stencil<T>(P2(bha), P2(bhb), P2(bya), P2(byb), P2(bc0), kk2, kk3, zd, A.xdella, ga, zdg, xdg, wl, omwl, wc, omwc,
+                                             V2<T>{ab2, ab2}, V2<T>{p2, p2}, V2<T>{m2, m2}, P2(b[0]), P2(b[1]), P2(b[2]), P2(b[3]), P2(b[4]), P2(b[5]),
+                                             P2(b[6]), P2(b[7]));
+#undef P2
+        r[i] = rr.x; r[i + 1] = rr.y;
+      }
+#endif
 #pragma unroll
       for (int i = 0; i < VEC; i++)
         if (m + i < A.m0 || m + i >= A.m1) r[i] = b[0][i];      // outside the advected range: carried over
@@ -570,7 +590,12 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
       const T wl[2] = {pq[6], pq[7]}, dp[2] = {pq[4], pq[5]};
       const CtuBase<T> b = ctu_base(A.cg[(size_t)iq[0] * NFRE + m], cgl, cgy0, cgy1, wl, dp);
       T* o = sB + q * 5 * NFRE + m;
+#if ECWAM_HIP_CTU_STRICT
       o[0] = m_abs(b.h[0]); o[NFRE] = m_abs(b.h[1]); o[2 * NFRE] = m_abs(b.hy[0]); o[3 * NFRE] = m_abs(b.hy[1]); o[4 * NFRE] = b.cg0;
+#else
+      ctu_fast_planes<T>(b, pq[1], A.delpro * sK[NANG * 4], o, o + NFRE, o + 2 * NFRE, o + 3 * NFRE);
+      o[4 * NFRE] = b.cg0;
+#endif
     }
     WSYNC();
   }

@@ -250,16 +250,24 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
   T* sK = sB + (size_t)OTF_TP * 5 * NFRE;                           // [NANG][4]: (SINTH+SINTH(K+1))*DELTH0/R, same for K-1; both for DELTH0_LF
   T* sT = sK + 4 * NANG;                                            // [NANG][2]: SINTH, COSTH
   int* sD = reinterpret_cast<int*>(sT + 2 * NANG);                  // [NANG][8]: JXO(K,1:2), JYO(K,1:2), KCR(K,1), KPM(K,-1), KPM(K,1)
-  T* sO = reinterpret_cast<T*>(sD + 8 * NANG);                      // OBS: [TP][8][NFRE] transmission coefficients
+  T* sQ = reinterpret_cast<T*>(sD + 8 * NANG);                      // [TP][8]: ZDELLO GA, XDELLA GA, 1 - WLAT(1:2), 1 - WCOR(1:4) (the hoisted form of the weights, ctu.h)
+  T* sO = sQ + 8 * OTF_TP;                                          // OBS: [TP][8][NFRE] transmission coefficients
   // the per-direction tables go to LDS once per block: read from the DevTab in global memory inside the stencil loop they
   // were seven more loads in front of every group of gathers, through the same L1 miss queue the gathers wait in
   for (int k = threadIdx.x; k < NANG; k += blockDim.x) {
     T a, b;
     ctu_dirfac(tab, k, DELTH0, T(1), a, b);  // TANPH applied per point below: TANPH*SP is formed as in k_ctuw
+#if ECWAM_HIP_CTU_STRICT
     sK[4 * k] = a; sK[4 * k + 1] = b;
     ctu_dirfac(tab, k, DELTH0_LF, T(1), a, b);
     sK[4 * k + 2] = a; sK[4 * k + 3] = b;
     sT[2 * k] = tab->SINTH[k]; sT[2 * k + 1] = tab->COSTH[k];
+#else      // doubled factors of the great-circle term, magnitudes of SINTH / COSTH (ctu.h: ctu_fast_dir, ctu_fast_w8)
+    sK[4 * k] = T(2) * a; sK[4 * k + 1] = T(2) * b;
+    ctu_dirfac(tab, k, DELTH0_LF, T(1), a, b);
+    sK[4 * k + 2] = T(2) * a; sK[4 * k + 3] = T(2) * b;
+    sT[2 * k] = m_abs(tab->SINTH[k]); sT[2 * k + 1] = m_abs(tab->COSTH[k]);
+#endif
     int* d = sD + 8 * k;
     d[0] = tab->JXO[k][0]; d[1] = tab->JXO[k][1]; d[2] = tab->JYO[k][0]; d[3] = tab->JYO[k][1]; d[4] = tab->KCR[k][0];
     d[5] = tab->KPM[k][0]; d[6] = tab->KPM[k][2]; d[7] = 0;
@@ -287,7 +295,11 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
       int* q = sI + t * 16;
       q[0] = ij;   // < 0: padding entry of a 2-D tile (skipped)
       if (ij >= 0) {
-        sP[t] = ctu_point(ij, ngy, kxlt, zdello, xdella, cosph, sinph, wlat, wcor, cosphm1);
+        const CtuPoint<T> cp = ctu_point(ij, ngy, kxlt, zdello, xdella, cosph, sinph, wlat, wcor, cosphm1);
+        sP[t] = cp;
+        T* e = sQ + 8 * t;
+        e[0] = cp.zd * cp.ga; e[1] = xdella * cp.ga; e[2] = T(1) - cp.wl[0]; e[3] = T(1) - cp.wl[1];
+        for (int i = 0; i < 4; i++) e[4 + i] = T(1) - cp.wc[i];
         q[1] = klon[ij * 2 + 0]; q[2] = klon[ij * 2 + 1];
         for (int i = 0; i < 4; i++) q[3 + i] = klat[ij * 4 + i];
         for (int i = 0; i < 8; i++) q[7 + i] = kcor[ij * 8 + i];
@@ -306,7 +318,12 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
         }
         const CtuBase<T> b = ctu_base(cg[(size_t)q[0] * NFRE + m], cgl, cgy0, cgy1, sP[t].wl, sP[t].dp);
         T* o = sB + (size_t)t * 5 * NFRE + m;
+#if ECWAM_HIP_CTU_STRICT
         o[0] = b.h[0]; o[NFRE] = b.h[1]; o[2 * NFRE] = b.hy[0]; o[3 * NFRE] = b.hy[1]; o[4 * NFRE] = b.cg0;
+#else      // |h| COSPHM1 DELPRO CMTODEG and |hy| DELPRO CMTODEG with the frequency's own time step
+        ctu_fast_planes<T>(b, m_abs(sP[t].cpm1), (m < mlf ? delpro_lf : delpro) * CMTODEG, o, o + NFRE, o + 2 * NFRE, o + 3 * NFRE);
+        o[4 * NFRE] = b.cg0;
+#endif
         if (OBS) {
 #pragma unroll
           for (int i = 0; i < 8; i++) sO[((size_t)t * 8 + i) * NFRE + m] = obs[((size_t)q[0] * 8 + i) * NFRE + m];
@@ -358,9 +375,10 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
       IO::ld(f1 + own_in + km * ik + m, fkm);
       IO::ld(f1 + own_in + kp * ik + m, fkp);
       const T* bb = sB + (size_t)t * 5 * NFRE + m;
+      T r[VW];
+#if ECWAM_HIP_CTU_STRICT
       T bh0[VW], bh1[VW], by0[VW], by1[VW], bc0[VW];
       IO::ld(bb, bh0); IO::ld(bb + NFRE, bh1); IO::ld(bb + 2 * NFRE, by0); IO::ld(bb + 3 * NFRE, by1); IO::ld(bb + 4 * NFRE, bc0);
-      T r[VW];
       if constexpr (sizeof(T) == 4 && (VW % 2 == 0) && !OBS) {
         // two frequencies per packed-fp32 operand
 #pragma unroll
@@ -390,6 +408,39 @@ __global__ void __launch_bounds__(256) k_propags2_otf(const DevTab<T>* __restric
                                 fco2[c], fkm[c], fkp[c]);
         r[c] = a;
       }
+#else
+      {
+        // the hoisted form (ctu.h: ctu_fast_w8): planes ordered by the direction's quadrant, two frequencies per packed operand
+        T xa[VW], xb[VW], ya[VW], yb[VW], bc0[VW];
+        IO::ld(bb + jx0 * NFRE, xa); IO::ld(bb + (1 - jx0) * NFRE, xb); IO::ld(bb + (2 + jy0) * NFRE, ya); IO::ld(bb + (3 - jy0) * NFRE, yb);
+        IO::ld(bb + 4 * NFRE, bc0);
+        const T* e = sQ + 8 * t;
+        const T zdg = e[0], xdg = e[1], omwl = e[2 + jy0], omwc = e[4 + kc], wl = p.wl[jy0], wc = p.wc[kc];
+        T ab2, p2, m2, ab2_lf, p2_lf, m2_lf;
+        ctu_fast_dir<T>(p.tanph, sK[4 * k], sK[4 * k + 1], ab2, p2, m2);
+        ctu_fast_dir<T>(p.tanph, sK[4 * k + 2], sK[4 * k + 3], ab2_lf, p2_lf, m2_lf);
+        typedef CtuV2<T> F;
+#pragma unroll
+        for (int c = 0; c < VW; c += 2) {
+          constexpr int c1 = VW > 1 ? 1 : 0;      // (scalar accesses: the pair holds the element twice)
+          const bool lf0 = (m + c) < mlf, lf1 = (m + c + c1) < mlf;
+#define P2(a) F{a[c], a[c + c1]}
+          CtuFastW8<T> w = ctu_fast_w8<T>(P2(xa), P2(xb), P2(ya), P2(yb), P2(bc0), sink, cosk, p.zd, xdella, p.ga, zdg, xdg, wl, omwl, wc, omwc,
+                                          F{lf0 ? ab2_lf : ab2, lf1 ? ab2_lf : ab2}, F{lf0 ? p2_lf : p2, lf1 ? p2_lf : p2},
+                                          F{lf0 ? m2_lf : m2, lf1 ? m2_lf : m2});
+          if (OBS) {      // ctuw.F90:703-733: the space weights of the neighbours scaled by the transmission coefficients
+            const T* o = sO + (size_t)t * 8 * NFRE + m + c;
+            const F olon = {o[(2 + jx0) * NFRE], o[(2 + jx0) * NFRE + c1]}, olat = {o[jy0 * NFRE], o[jy0 * NFRE + c1]},
+                    ocor = {o[(4 + kc) * NFRE], o[(4 + kc) * NFRE + c1]};
+            w.wlon = w.wlon * olon; w.wlat1 = w.wlat1 * olat; w.wlat2 = w.wlat2 * olat; w.wcor1 = w.wcor1 * ocor; w.wcor2 = w.wcor2 * ocor;
+          }
+          const F rr = ctu_fast_apply<T>(w, P2(fo), P2(flon), P2(fla1), P2(fla2), P2(fco1), P2(fco2), P2(fkm), P2(fkp));
+#undef P2
+          r[c] = rr.x;
+          if (VW > 1) r[c + c1] = rr.y;
+        }
+      }
+#endif
       if (partial) {  // elements outside [m0, m1): carried over from F1 (copy_rest) or left as they are in F3
         T keep[VW];
         if (copy_rest & 1) {
@@ -1107,7 +1158,7 @@ void launch_propags2_otf(const void* tab, const void* f1, void* f3, int n_geom, 
   if (n <= 0) return;
   const int ntiles = (n + OTF_TP - 1) / OTF_TP;
   const size_t shmem = OTF_TP * (sizeof(CtuPoint<T>) + 16 * sizeof(int)) +
-                       ((size_t)OTF_TP * (obs ? 13 : 5) * NFRE + 6 * NANG) * sizeof(T) + 8 * NANG * sizeof(int) + 16;
+                       ((size_t)OTF_TP * (obs ? 13 : 5) * NFRE + 6 * NANG + 8 * OTF_TP) * sizeof(T) + 8 * NANG * sizeof(int) + 16;
   int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
 #ifdef ECWAM_HIP_DIAGNOSTICS
   { const char* e_ = getenv("ECWAM_HIP_OTF_GRID"); if (e_ && atoi(e_) > 0 && atoi(e_) < grid) grid = atoi(e_); }

@@ -21,6 +21,24 @@ FF_OUT = [7, 8, 9, 10, 11, 12]          # UFRIC TAUW TAUWDIR Z0M Z0B CHRNCK
 INTF_OUT = [2, 3, 5, 6, 7, 8, 9, 12, 13, 14]  # USTOKES VSTOKES TAUXD TAUYD TAUOCXD TAUOCYD TAUOC PHIOCD PHIEPS PHIAW
 
 
+# The on-the-fly CTU weights of the product (csrc/ctu.h: hoisted factors, explicit fused multiply-adds) differ from the stored-weight scheme
+# (the reference's order of operations, k_ctuw + k_propags2) by a few units in the last place; the library built with
+# -DECWAM_HIP_CTU_STRICT=1 (build variant "ctustrict") is bit-identical to it.  ECWAM_TEST_CTU_STRICT=1 says that library is loaded
+# (tests/test_gpu_fused.py runs the bit-identity tests on it in a child process).
+CTU_STRICT = bool(int(os.environ.get("ECWAM_TEST_CTU_STRICT", "0") or 0))
+
+
+def assert_same_advection(otf, stored, eps, scale=1.0, what="on-the-fly vs stored weights"):
+    """Spectra advected with on-the-fly and with stored weights: the same bits on the strict build, within 8 eps of the spectral scale
+    on the product build (eight weights a few ulp apart, each times a spectrum value <= scale; observed <= 2 eps)."""
+    otf, stored = np.asarray(otf), np.asarray(stored)
+    if CTU_STRICT:
+        assert np.array_equal(otf, stored), what
+    else:
+        d = float(np.max(np.abs(otf.astype(np.float64) - stored.astype(np.float64))))
+        assert d < 8 * eps * scale, (what, d / (eps * scale), "eps")
+
+
 def np_dtype(prec: str):
     return np.float32 if prec == "sp" else np.float64
 

@@ -75,7 +75,12 @@ def test_advection_two_kernels_one_result_and_the_oracle_on_a_sample(model):
     f3 = torch.zeros_like(f1)
     m.ctx.propags2(f1, f3, m.gd["klon"], m.gd["klat"], m.gd["kcor"], w, 0, n, 1, cfg.nfre_red, copy_rest=True)
     torch.cuda.synchronize()
-    assert torch.equal(f3[:n], otf)
+    # the product's on-the-fly weights (hoisted factors, explicit fused multiply-adds) and the reference's order: the same spectra within
+    # rounding -- bit for bit on the strict build (tests/harness.py: CTU_STRICT)
+    if H.CTU_STRICT:
+        assert torch.equal(f3[:n], otf)
+    else:
+        assert float((f3[:n].double() - otf.double()).abs().max().item()) < 8 * np.finfo(np.float32).eps * float(f1.abs().max().item())
     assert float(otf.min().item()) >= 0.0
     # linearity of the stencil at full size
     rng = torch.Generator(device="cpu").manual_seed(5)

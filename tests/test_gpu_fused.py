@@ -175,3 +175,26 @@ def test_one_kernel_step_on_a_decomposed_grid_is_bit_identical(api):
     assert torch.equal(torch.cat([m.mij for m in parts]), ref.mij)
     for m in parts + [ref]:
         m.ctx.close()
+
+
+def test_strict_build_of_the_weights_is_bit_identical_to_the_stored_weight_scheme(api):
+    """The library built with -DECWAM_HIP_CTU_STRICT=1 (build variant "ctustrict": the on-the-fly weights in ctuw.F90's order of operations,
+    contraction off) in a child process: on-the-fly and stored weights give the same bits (tests/harness.py: CTU_STRICT), and the one-kernel
+    step still equals the two kernels."""
+    import os
+    import subprocess
+    import sys
+
+    from ecwam_amd import build
+
+    lib = build.lib_path("ctustrict")
+    if not os.path.exists(lib):
+        build.build(variant="ctustrict")
+    env = dict(os.environ, ECWAM_HIP_LIB=lib, ECWAM_TEST_CTU_STRICT="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(here, "test_gpu_parity.py"), os.path.join(here, "test_gpu_refraction.py"),
+                        os.path.join(here, "test_gpu_fused.py"), "-k",
+                        "ctuw_and_propags2_parity or subgrid_obstructions or one_kernel_step_is_bit_identical or zero_currents_reduce"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

@@ -599,8 +599,8 @@ def test_ctuw_and_propags2_parity(api, prec, mask):
     f3b = tf3b.cpu().numpy()
     assert np.all(f3b[:3] == -7.0) and np.all(f3b[g.nsea - 2:] == -7.0) and np.all(f3b[3:g.nsea - 2, :, 5:] == -7.0)
     assert np.array_equal(f3b[3:g.nsea - 2, :, :5], f3[3:g.nsea - 2, :, :5])
-    # on-the-fly weights (no W array): bit-identical to the stored-weight path, in any processing order, and the
-    # check-only form of CTUW raises the same CFL flags
+    # on-the-fly weights (no W array): the stored-weight path's spectra within rounding (bit-identical on the strict build, harness.py),
+    # the same bits in any processing order, within 16 eps of the oracle; the check-only form of CTUW raises the same CFL flags
     cg = torch.from_numpy(cg_ext).to(dev)
     tf3c = torch.full_like(tf1, -7.0)
     ctx.propags2_otf(tf1, tf3c, gd, cg, float(cfg.idelpro), 0, g.nsea)
@@ -612,8 +612,11 @@ def test_ctuw_and_propags2_parity(api, prec, mask):
     fail2 = torch.ones(g.nsea, dtype=torch.int32, device=dev) * 0
     ctx.ctuw(gd, cg, None, fail2, float(cfg.idelpro))
     torch.cuda.synchronize()
-    assert np.array_equal(tf3c.cpu().numpy(), f3) and np.array_equal(tf3d.cpu().numpy(), f3)
-    assert np.array_equal(tf3e.cpu().numpy(), f3b)
+    H.assert_same_advection(tf3c.cpu().numpy(), f3, eps)                      # f1 <= 1
+    assert torch.equal(tf3d, tf3c)                                            # any processing order: the same bits
+    H.assert_same_advection(tf3e.cpu().numpy(), f3b, eps)
+    assert torch.equal(tf3e[3:g.nsea - 2, :, :5], tf3c[3:g.nsea - 2, :, :5])   # the scalar-access variant of the kernel: the same bits
+    assert np.max(np.abs(tf3c.cpu().numpy()[: g.nsea, :, :nr].astype(float) - f3ref[: g.nsea, :, :nr].astype(float))) < 16 * eps
     assert int(fail2.sum()) == 0
     ctx.close()
 

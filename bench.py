@@ -14,6 +14,7 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import math
 import os
@@ -26,6 +27,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+VALU_PEAK_TFLOPS = {"sp": 157.3, "dp": 78.6}      # MI355X_MICROARCH.md: vector (non-matrix) peaks
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
@@ -179,9 +181,10 @@ def main() -> None:
     ap.add_argument("--host-state", action="store_true",
                     help="DIAGNOSTIC, never the reported value: the spectra enter from and return to pinned host memory every step (what a caller "
                          "that hands over host buffers would pay over PCIe; DESIGN.md section 6)")
-    ap.add_argument("--fused", default="off", choices=["off", "on"],
+    ap.add_argument("--fused", default="auto", choices=["auto", "off", "on"],
                     help="the 1:1 step as ONE kernel (ecwam_hip_propags2_implsch: PROPAGS2 inside IMPLSCH's tile load; bit-identical to the two "
-                         "kernels) where a build covers the configuration")
+                         "kernels).  auto (default): where a build covers the configuration (36 x 36, one advection step per source step, no "
+                         "refraction / fast waves); on: refuse to run otherwise; off: PROPAGS2 and IMPLSCH as two kernels (the A/B partner)")
     ap.add_argument("--fused-flags", type=int, default=0, help="diagnostics: flags of ecwam_hip_propags2_implsch (1: natural workgroup order; 2: the probe)")
     ap.add_argument("--irefra", type=int, default=0, choices=[0, 1, 2, 3],
                     help="refraction: 0 none (BASELINE configurations), 1 depth, 2 currents, 3 both (synthetic current field)")
@@ -227,7 +230,23 @@ def main() -> None:
     # with 36 directions near the poles of the all-ocean grid, ctuw.F90:637); scaled with the grid spacing beyond
     dt = 450 if ng <= 320 else max(15, int(450 * 320 / ng) // 15 * 15)
     cfg = Config(nang=a.nang, nfre=a.nfre, nfre_red=a.nfre, idelt=dt, idelpro=dt, irefra=a.irefra)
-    grid = G.build_grid(ng)
+    # N > 1: rank 0 builds the grid tables once and hands them to the other ranks through a file (all ranks of a node building the whole
+    # O1280 grid side by side cost 54 s of numpy each on the node's CPU share before the first step)
+    if world > 1:
+        import tempfile
+        gpath = os.path.join(tempfile.gettempdir(), f"ecwam_amd_grid_O{ng}_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}.npz")
+        if rank == 0:
+            grid = G.build_grid(ng)
+            G.save_grid(grid, gpath)
+        flag = torch.zeros(1, dtype=torch.int32)          # (a CPU tensor: reduced over gloo in either process group)
+        dist.all_reduce(flag)
+        if rank != 0:
+            grid = G.load_grid(gpath)
+        dist.all_reduce(flag)
+        if rank == 0:
+            os.remove(gpath)
+    else:
+        grid = G.build_grid(ng)
     # N > 1: the model starts on the host-staged transport (no RCCL involved: it cannot fail to set up), then moves to the asked one
     m = Wamintgr(cfg, grid, a.prec, device=local_rank, rank=rank, nranks=world, weights=a.weights, strip_width=a.strip,
                  ifrelfmax=a.ifrelfmax, delpro_lf=(dt / 2.0 if a.ifrelfmax else None), halo_transport="host" if world > 1 else "torch")
@@ -294,7 +313,7 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    fused = a.fused == "on" and a.adv_per_source == 1 and m.fused_available()
+    fused = a.fused != "off" and a.adv_per_source == 1 and not a.host_state and a.weights == "otf" and m.fused_available()
     if a.fused == "on" and a.host_state:
         raise SystemExit("bench.py: --fused and --host-state exclude each other")
     if a.fused == "on" and not fused:
@@ -382,11 +401,23 @@ def main() -> None:
             b_prop = w * 10 * NR + 56                    # 8 weights + F1 + F3, 14 int32 neighbour ids
         else:
             b_prop = w * (2 * NR + a.nfre + 13) + 60     # F1 + F3 + own CGROUP row + point geometry, 15 int32 ids
-        kern = {
-            "propags2": {"ms": t_prop, "alg_bytes": b_prop * m.n * a.adv_per_source,
-                         "gbs": b_prop * m.n * a.adv_per_source / t_prop / 1e6},
-            "implsch": {"ms": t_impl, "alg_bytes": b_impl * m.n, "gbs": b_impl * m.n / t_impl / 1e6},
-        }
+        # vector flops per point-step (IMPLSCH 0.47 Mflop at 36 x 36; the advection: 61 per spectral bin = 8 multiply-adds of the
+        # stencil + the rebuild of the eight weights in their hoisted form, csrc/ctu.h) against the 157.3 TFLOP/s fp32 vector peak (78.6 fp64)
+        fl_impl = 0.47e6 * (a.nang * a.nfre) / 1296.0
+        fl_prop = 61.0 * NR
+        if fused:
+            # ONE kernel per step: F1 read, F3 written, XLLWS written, the five per-frequency properties, the own CGROUP row and point geometry
+            # of the weights, ~68 scalars, 15 int32 neighbour ids -- the advected spectrum never goes to memory (2 N w bytes less than the
+            # two kernels together)
+            b_step = w * (3 * N + 6 * a.nfre + 68) + 60
+            kern = {"implsch_adv": {"ms": t_impl, "alg_bytes": b_step * m.n, "gbs": b_step * m.n / t_impl / 1e6, "flop": (fl_impl + fl_prop) * m.n,
+                                    "what": "k_implsch4<..., ADV = 1>: PROPAGS2 inside IMPLSCH's tile load (+ k_ctu_prep, k_implsch4_pre / _fin)"}}
+        else:
+            kern = {
+                "propags2": {"ms": t_prop, "alg_bytes": b_prop * m.n * a.adv_per_source,
+                             "gbs": b_prop * m.n * a.adv_per_source / t_prop / 1e6, "flop": fl_prop * m.n * a.adv_per_source},
+                "implsch": {"ms": t_impl, "alg_bytes": b_impl * m.n, "gbs": b_impl * m.n / t_impl / 1e6, "flop": fl_impl * m.n},
+            }
         dom = max(kern, key=lambda k: kern[k]["ms"])
         # HBM traffic and the busy fractions of the vector ALU and the LDS are NOT measured in this run: they come from a counter summary
         # tools/pmc_bench.py took with rocprofv3 --pmc on this very command (profiles/r05_bench_O320_sp_pmc.json: separate passes for the SQ
@@ -395,41 +426,63 @@ def main() -> None:
         # string and dtype must equal the run's and its kernel must be the instantiation the run launches; a file given with --pmc-file that
         # does not match is refused.
         workload = (f"O{ng} all-ocean octahedral grid, {grid.nsea} sea points, {a.nang} dir x {a.nfre} freq "
-                    f"(NFRE_RED={cfg.nfre_red}), full WAMINTGR step = PROPAGS2 advection + NEWWIND + IMPLSCH, "
+                    f"(NFRE_RED={cfg.nfre_red}), full WAMINTGR step = PROPAGS2 advection + NEWWIND + IMPLSCH"
+                    + (" as one kernel (PROPAGS2 inside IMPLSCH's tile load)" if fused else "") + ", "
                     f"IDELT=IDELPRO={dt} s, flag set A (IPHYS=1, ISNONLIN=0, LLGCBZ0=F, LLNORMAGAM=F)"
                     + (f", IREFRA={a.irefra} (synthetic currents)" if a.irefra else "")
                     + (f", {a.adv_per_source} advection steps per source step" if a.adv_per_source != 1 else "")
                     + (f", fast waves M<={a.ifrelfmax} in two sub-steps" if a.ifrelfmax else "")
                     + (", DIAGNOSTIC: spectra copied from and to pinned host memory every step" if a.host_state else ""))
         dtype = "f32" if a.prec == "sp" else "f64"
-        pmc_path = a.pmc_file or os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_bench_O320_sp_pmc.json")
+        here = os.path.dirname(os.path.abspath(__file__))
+        pmc_path = a.pmc_file or os.path.join(here, "profiles", f"r06_bench_O{ng}_{a.prec}_pmc.json")
         pmc, pmc_why = None, None
+        from ecwam_amd import lib as L
+        lib_file = L.LIBPATH      # (ECWAM_HIP_LIB, or the product library)
+        lib_sha = hashlib.sha256(open(lib_file, "rb").read()).hexdigest()
         if os.path.exists(pmc_path) and world == 1:
             with open(pmc_path) as fh:
                 cand = json.load(fh)
-            kname = (cand.get("kernels", {}).get(dom, {}) or {}).get("name") or ""
-            want_k = {"implsch": f"k_implsch4<{'float' if a.prec == 'sp' else 'double'}, {a.nang}, ", "propags2": "k_propags2"}[dom]
+            ck = "implsch" if dom.startswith("implsch") else dom
+            kname = (cand.get("kernels", {}).get(ck, {}) or {}).get("name") or ""
+            tn = "float" if a.prec == "sp" else "double"
+            want_k = {"implsch": f"k_implsch4<{tn}, {a.nang}, ", "propags2": "k_propags2"}[ck]
+            adv_ok = (kname.rstrip(">").split(",")[-1].strip() == ("1" if fused else "0")) if ck == "implsch" else True
             if cand.get("workload", {}).get("workload") != workload or cand.get("workload", {}).get("dtype") != dtype:
                 pmc_why = "the summary was taken on another workload: " + str(cand.get("workload", {}).get("workload"))
-            elif want_k not in kname:
-                pmc_why = f"the summary's kernel is {kname!r}, this run launches {want_k}...>"
+            elif want_k not in kname or not adv_ok:
+                pmc_why = f"the summary's kernel is {kname!r}, this run launches {want_k}...>" + (" with the advecting tile load" if fused else "")
+            elif cand.get("library", {}).get("sha256") != lib_sha:
+                pmc_why = (f"the summary was taken on another build of the library (sha256 {str(cand.get('library', {}).get('sha256'))[:16]}..., "
+                           f"this run loaded {lib_sha[:16]}...)")
             else:
-                pmc = cand["kernels"][dom]
+                pmc = cand["kernels"][ck]
         elif a.pmc_file:
             pmc_why = "no such file" if not os.path.exists(pmc_path) else "counter summaries describe one GPU"
+        elif world == 1:
+            pmc_why = "no counter summary for this workload under profiles/"
         if a.pmc_file and pmc is None:
             raise SystemExit(f"bench.py: --pmc-file {a.pmc_file} refused: {pmc_why}")
+        vec_peak = VALU_PEAK_TFLOPS[a.prec]
         roof = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["gbs"] / HBM_PEAK_GBS,
-                "traffic": None, "valu_busy": None, "lds_busy": None, "counters": None}
+                "traffic": None,
+                # the roof that binds this kernel (above the fp32 ridge): its vector flops against the vector peak
+                "valu_frac": kern[dom]["flop"] / (kern[dom]["ms"] * 1e-3) / (vec_peak * 1e12), "valu_peak_tflops": vec_peak,
+                "valu_busy": None, "lds_busy": None, "counters": None, "counters_why_null": pmc_why, "library_sha256": lib_sha}
         if pmc is not None:
             # one story: the fraction of the HBM roofline on algorithmic bytes (the contract's figure), the bytes the kernel really moved,
             # and what its own counters say limits it -- the busy fractions of a SIMD's vector ALU and of the CU's LDS array at the resident
-            # wave count (IMPLSCH: two waves per SIMD in single precision)
-            roof.update({"traffic": pmc.get("hbm_bytes"), "valu_busy": pmc.get("valu_busy"), "lds_busy": pmc.get("lds_busy"),
-                         "limiter": "vector ALU + LDS at the resident wave count, not HBM" if dom == "implsch" else "gather latency / instruction issue",
-                         "counters": {"file": os.path.relpath(pmc_path, os.path.dirname(os.path.abspath(__file__))), "kernel": pmc.get("name"),
+            # wave count (IMPLSCH: two waves per SIMD in single precision).  `bound` follows the counters: "hbm" only for a kernel that moves
+            # its bytes at more than half the peak, else the busiest unit
+            vb, lb = pmc.get("valu_busy"), pmc.get("lds_busy")
+            hbm_frac_real = (pmc.get("hbm_bytes") or 0.0) / (kern[dom]["ms"] * 1e-3) / (HBM_PEAK_GBS * 1e9)
+            bound = "hbm" if hbm_frac_real > 0.5 else ("valu+lds" if (vb or 0) > 0.5 and (lb or 0) > 0.4 else ("valu" if (vb or 0) > 0.5 else "latency"))
+            roof.update({"bound": bound, "traffic": pmc.get("hbm_bytes"), "valu_busy": vb, "lds_busy": lb, "hbm_frac_of_moved_bytes": hbm_frac_real,
+                         "limiter": "vector ALU + LDS at the resident wave count, not HBM" if dom.startswith("implsch") else "gather latency / instruction issue",
+                         "counters": {"file": os.path.relpath(pmc_path, here), "kernel": pmc.get("name"), "library_sha256": lib_sha,
                                       "not_measured_live": True, "valu_insts_per_point": pmc.get("per_point", {}).get("SQ_INSTS_VALU"),
                                       "waitcnt_fraction": pmc.get("waitcnt_fraction"), "lds_bank_conflict_share": pmc.get("lds_bank_conflict_share")}})
+            roof.pop("counters_why_null")
         out = {
             "metric": f"grid-point spectral steps/sec (whole node) at O{ng}, {a.nang}dir x {a.nfre}freq",
             "value": grid.nsea * a.steps / el, "unit": "grid-point spectral steps/s", "n_gpus": world, "steps": a.steps,

@@ -14,16 +14,13 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libecwam_hip.so")
 SOURCES = ["capi.hip", "propag.hip", "implsch4.hip", "implsch4a.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip", "outbs.hip"]
 # objects that are a second compilation of another source: object name -> (source, extra flags; a later -O overrides the earlier one).
-# implsch4rd = the double precision RARE builds of k_implsch4 at -O2 (their -O3 builds fault on the device: implsch4r.hip)
-DERIVED = {"implsch4r.hip": ("implsch4r.hip", ["-DV4R_PREC=1"]), "implsch4rd.hip": ("implsch4r.hip", ["-DV4R_PREC=2", "-O2"])}
+# implsch4rd = the double precision RARE builds of k_implsch4 as the two-kernel split (V4R_DP = 2) at -O3: as ONE function they fault on the device
+# at -O3 (implsch4r.hip; round 5 shipped that function at -O2) -- the split passes at every optimisation level and is bit-identical
+DERIVED = {"implsch4r.hip": ("implsch4r.hip", ["-DV4R_PREC=1"]), "implsch4rd.hip": ("implsch4r.hip", ["-DV4R_PREC=2", "-DV4R_DP=2"])}
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # IMPLSCH is VALU-issue bound: single-precision divide/sqrt by the hardware reciprocal / square root plus one
 # refinement (<= 2.5 ulp) instead of the correctly rounded sequences; double precision is unaffected.
 FAST_DIV = ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]
-# A/B partner of round 5 (build variant "plainhalves"): with the SLP vectoriser and the VectorCombine pass off, the halves of a pair that
-# straddles two aligned register pairs stay plain operations (implsch_v4.h, V4_WINSHUF = 2) instead of being re-packed at the price of one
-# v_pk_mov_b32 per pair
-NO_REPACK = ["-fno-slp-vectorize", "-mllvm", "-disable-vector-combine"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 IMPLSCH_SOURCES = ("implsch4.hip", "implsch4a.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip")
 # Build variants of the IMPLSCH translation units (the single-precision error attribution):
@@ -43,44 +40,30 @@ VARIANTS = {"": FAST_DIV, "exactdiv": ["-DECWAM_HIP_STRICT=0"], "strict1": ["-DE
             "site4": ["-DECWAM_HIP_STRICT=4"], "site8": ["-DECWAM_HIP_STRICT=8"], "site32": ["-DECWAM_HIP_STRICT=32"],
             "strict3": ["-DECWAM_HIP_STRICT=3"], "strict7": ["-DECWAM_HIP_STRICT=3", "-ffp-contract=off"],
             "noieee": FAST_DIV + ["-mno-amdgpu-ieee", "-fno-honor-nans"],
-            # round 5, the double precision RARE builds of k_implsch4 (profiles/r05_rare_dp_rootcause.txt): the object implsch4rd (product:
-            # -O2) at -O3 (faults), -O1, -O3 with index assertions, and -O3 as the two-kernel split (-DV4R_DP=2)
-            "rdp": FAST_DIV + ["-O3"], "rdpO1": FAST_DIV + ["-O1"], "rdpchk": FAST_DIV + ["-O3", "-DV4_CHECK=1"],
-            "rdps": FAST_DIV + ["-O3", "-DV4R_DP=2"],
+            # the double precision RARE builds of k_implsch4 (profiles/r05_rare_dp_rootcause.txt, r06_rare_dp_note.txt): the object implsch4rd
+            # (product: the two-kernel split at -O3, V4R_DP = 2) as the one kernel at -O3 (faults), at -O3 with index assertions, at -O2
+            "rdp": FAST_DIV + ["-O3", "-DV4R_DP=1"], "rdpchk": FAST_DIV + ["-O3", "-DV4R_DP=1", "-DV4_CHECK=1"], "rdpO2": FAST_DIV + ["-O2", "-DV4R_DP=1"],
             # every build of k_implsch4 as the two-kernel split (PART 1: through the second SINFLX call | PART 2: sweep, fluxes, tail, stores)
             "split": FAST_DIV + ["-DV4_SPLIT_ALL=1", "-DV4R_DP=2"],
-            # the common builds at -O2 (one-line experiment of round 5: same time as -O3, profiles/r05_implsch_split_experiment.txt)
-            "o2": FAST_DIV + ["-O2"],
-            # round 5 A/B partners of the common builds: the split row layout of the 36-direction tile (slower, profiles/r05_lds_row_layout.txt);
-            # the DIA gathers / scatters as separate rotated reads of rounds 2 - 4 instead of the window form (profiles/r05_dia_window_ab.txt)
-            "rowsplit": FAST_DIV + ["-DV4_ROWSPLIT=1"], "diaold": FAST_DIV + ["-DV4_DIAWIN=0"],
-            # the first generation of waves staggered by half a wave lifetime (13 x s_sleep 127 = 106 k cycles) / a quarter
-            "stagger": FAST_DIV + ["-DV4_STAGGER=13"], "stagger6": FAST_DIV + ["-DV4_STAGGER=6"],
-            # the straddling pairs of the DIA windows and of the saturation filter (profiles/r05_pair_shuffle_ab.txt): the product leaves them
-            # to the vectoriser (two v_mov_b32 each); "shuf1" = one shuffle each, "plainhalves" = no pair assembled
-            "shuf1": FAST_DIV + ["-DV4_WINSHUF=1"], "plainhalves": FAST_DIV + ["-DV4_WINSHUF=2"] + NO_REPACK,
-            # the reads of two staging rows at the same shift kept as two ds_read_b64 instead of the compiler's ds_read2_b64 (8 LDS cycles against 4)
-            "noread2": FAST_DIV + ["-DV4_NOREAD2=1"],
-            # the per-interaction / per-row coefficient records fetched ahead (implsch_v4.h, V4_RECPF: the product in single precision): off, and
-            # with the sweep's loads in front of the row update instead of at the top of the interaction
-            "norecpf": FAST_DIV + ["-DV4_RECPF=0"], "recpf1": FAST_DIV + ["-DV4_RECPF=1", "-DV4_RECPF_AT=1"],
-            "recpfdp": FAST_DIV + ["-DV4_RECPF_DP=1"], "rlanedp": FAST_DIV + ["-DV4_RECPF_DP=2"],
-            # double precision, the sweep's record (implsch_v4.h, V4_RECV; the product = 2): one interaction ahead in vector registers / as the compiler places the loads
-            "recv": FAST_DIV + ["-DV4_RECV=1"], "norecs": FAST_DIV + ["-DV4_RECV=0"],
-            # the all-reduces of a SINPUT row one after the other (rounds 2 - 5a) instead of in one batch (V4_REDN)
+            # A/B partners of the mechanisms of round 5 that are in the product (profiles/r05_scalar_prefetch.txt): the per-interaction / per-row
+            # coefficient records fetched ahead (V4_RECPF, single precision) off; the double precision sweep's record as the compiler places its
+            # loads (V4_RECV = 0); the all-reduces of a SINPUT row one after the other instead of in one batch (V4_REDN = 0)
+            "norecpf": FAST_DIV + ["-DV4_RECPF=0"], "norecs": FAST_DIV + ["-DV4_RECV=0"], "noredn": FAST_DIV + ["-DV4_REDN=0"],
             # round 6: the library with the go / no-go probe of the one-kernel step (implsch4a.hip, flags bit 1 of ecwam_hip_propags2_implsch)
             "advprobe": FAST_DIV + ["-DV4_ADV_PROBE=1"],
             # the on-the-fly CTU weights (k_propags2_otf and the advecting load of k_implsch4) in ctuw.F90's order of operations, contraction off:
             # bit-identical to the stored-weight scheme (csrc/ctu.h; the product hoists the factors and fuses the multiply-adds)
             "ctustrict": FAST_DIV,
-            # ... and with 2 / 4 steps of gathers in flight instead of 3 (V4_ADV_DEPTH)
-            "advd2": FAST_DIV + ["-DV4_ADV_DEPTH=2"], "advd4": FAST_DIV + ["-DV4_ADV_DEPTH=4"],
-            "noredn": FAST_DIV + ["-DV4_REDN=0"], "redndp": FAST_DIV + ["-DV4_REDN=3"]}
+            # the advecting load with 2 / 4 steps of gathers in flight instead of 3 (V4_ADV_DEPTH), and at a raised wave priority (s_setprio):
+            # all within the noise of the product (profiles/r06_fused_step_experiments.txt)
+            "advd2": FAST_DIV + ["-DV4_ADV_DEPTH=2"], "advd4": FAST_DIV + ["-DV4_ADV_DEPTH=4"], "advprio": FAST_DIV + ["-DV4_ADV_PRIO=2"]}
 # flags a variant adds to EVERY source it rebuilds (not only the IMPLSCH units)
 VARIANT_ANY = {"ctustrict": ["-DECWAM_HIP_CTU_STRICT=1"]}
-# variants that rebuild only some of the IMPLSCH translation units (the other objects are the product's)
-VARIANT_SOURCES = {"ctustrict": ("propag.hip", "implsch4a.hip"), "advprobe": ("implsch4a.hip",), "advd2": ("implsch4a.hip",), "advd4": ("implsch4a.hip",), "rdp": ("implsch4rd.hip",), "rdpO1": ("implsch4rd.hip",), "rdpchk": ("implsch4rd.hip",), "rdps": ("implsch4rd.hip",),
-                   "split": ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip"), "o2": ("implsch4.hip",), "rowsplit": ("implsch4.hip",), "diaold": ("implsch4.hip",), "stagger": ("implsch4.hip",), "stagger6": ("implsch4.hip",), "shuf1": ("implsch4.hip",), "plainhalves": ("implsch4.hip",), "noread2": ("implsch4.hip",), "norecpf": ("implsch4.hip",), "recpf1": ("implsch4.hip",), "recpfdp": ("implsch4.hip",), "rlanedp": ("implsch4.hip",), "recv": ("implsch4.hip",), "norecs": ("implsch4.hip",), "noredn": ("implsch4.hip",), "redndp": ("implsch4.hip",)}
+# variants that rebuild only some of the translation units (the other objects are the product's)
+VARIANT_SOURCES = {"ctustrict": ("propag.hip", "implsch4a.hip"), "advprobe": ("implsch4a.hip",), "advd2": ("implsch4a.hip",), "advd4": ("implsch4a.hip",),
+                   "advprio": ("implsch4a.hip",), "rdp": ("implsch4rd.hip",), "rdpchk": ("implsch4rd.hip",), "rdpO2": ("implsch4rd.hip",),
+                   "split": ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip"), "norecpf": ("implsch4.hip",), "norecs": ("implsch4.hip",),
+                   "noredn": ("implsch4.hip",)}
 
 INCLUDE = os.path.join(HERE, "..", "include", "ecwam_hip.h")
 

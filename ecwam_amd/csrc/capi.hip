@@ -62,6 +62,7 @@ struct ecwam_hip_ctx {
   void* fast_g = nullptr;     // ecwam_hip_set_fastwave_copy: compact rows [ij][K][fast_gk] IMPLSCH / NOSOURCE also leave the new fast waves in
   int fast_gk = 0;
   // one-kernel step (ecwam_hip_propags2_implsch): per-point and per-direction scalars of the CTU weights (propag.hip::k_ctu_prep)
+  std::string implsch_why;    // non-empty: no build of k_implsch4 covers the configuration (ecwam_hip_implsch refuses with this text)
   void* adv_pt = nullptr;     // [npts][12]
   size_t adv_pt_bytes = 0;
   void* adv_dir = nullptr;    // reals [4 NANG + 4], then ints [4 NANG]
@@ -200,6 +201,7 @@ static int build_tab(const ecwam_hip_params* p, const ecwam_hip_tables* t, DevTa
     if (t->ikm[i] != MC - 4 || t->ikm1[i] != MC - 3) d->DIA_PULL = 0;
   }
   if (ML != NFRE + 4 || p->kfrh != 8 || p->mfrstlw != -3) d->DIA_PULL = 0;
+  bool sep_ok = true;      // RNLCOEF factors as frequency factor x angular weight (checked below)
   for (int i = 0; i < ML; i++) {
     for (int j = 0; j < 5; j++) d->INLCOEF[i][j] = t->inlcoef[i * 5 + j] - 1;
     for (int j = 0; j < 25; j++) d->RNLCOEF[i][j] = ((const T*)t->rnlcoef)[i * 25 + j];
@@ -224,8 +226,25 @@ static int build_tab(const ecwam_hip_params* p, const ecwam_hip_tables* t, DevTa
     }
     for (int i = 0; i < ML; i++)
       for (int j = 0; j < 4; j++) d->DIAW[i][12 + j] = (i + 1 < ML) ? d->DIAW[i + 1][j] : T(0);
+    // The kernel never reads RNLCOEF(2:25): it forms the coefficients as frequency factor x angular weight (inisnonlin.F90:186-241).  Tables
+    // that do not factor that way (not from INISNONLIN, or modified) would silently give another Snl: rebuild every word and compare;
+    // V4_ROWS = 0 makes ecwam_hip_create refuse the tables with the reason.
+    const double tol = (sizeof(T) == 4 ? 1.2e-7 : 2.3e-16) * 64.0;
+    for (int i = 0; i < ML && sep_ok; i++) {
+      const T* R = d->RNLCOEF[i];
+      const T* W = d->DIAW[i];
+      const double gp = W[0], gp1 = W[1], gm = W[2], gm1 = W[3], fp = W[4], fp1 = W[5], fm = W[8], fm1 = W[9];
+      const double want[24] = {gp * cl11, gp * acl1, gp1 * cl11, gp1 * acl1, fp * cl11, fp * acl1, fp1 * acl1, fp1 * cl11,
+                               (fp * cl11) * (fp * cl11), (fp * acl1) * (fp * acl1), (fp1 * cl11) * (fp1 * cl11), (fp1 * acl1) * (fp1 * acl1),
+                               gm * cl21, gm * acl2, gm1 * cl21, gm1 * acl2, fm * cl21, fm * acl2, fm1 * acl2, fm1 * cl21,
+                               (fm * cl21) * (fm * cl21), (fm * acl2) * (fm * acl2), (fm1 * cl21) * (fm1 * cl21), (fm1 * acl2) * (fm1 * acl2)};
+      for (int j = 0; j < 24; j++) {
+        const double scale = fabs(want[j]) > fabs((double)R[1 + j]) ? fabs(want[j]) : fabs((double)R[1 + j]);
+        if (fabs(want[j] - (double)R[1 + j]) > tol * scale) sep_ok = false;
+      }
+    }
   }
-  d->V4_ROWS = 1;
+  d->V4_ROWS = sep_ok ? 1 : 0;
   for (int i = 0; i < ML; i++) {
     // gather set (words 0..11): FTAIL, GW1..GW8, AF11; scatter set (words 12..27): FKLAMPA .. FKLAP22, FKLAMMA .. FKLAM22
     for (int j = 0; j < 32; j++) d->DIACF[i][j] = T(0);
@@ -473,11 +492,9 @@ int ecwam_hip_create(const ecwam_hip_params* p, const ecwam_hip_tables* t, int r
     else if (!inst) why = "NANG must be 48, 36, 24 or 12 with the interaction rotations and the saturation half-width of INISNONLIN / INIT_SDISS_ARDH on that grid";
     else if (p->iphys == 1 && p->llnormagam && c->v4_shelter) why = "LLNORMAGAM needs TAUWSHELTER = 0 (setwavphys.F90:150-190: the normalised growth rate replaces the sheltering)";
     else if (p->iphys == 1 && !p->llnormagam && !c->v4_shelter) why = "IPHYS = 1 without LLNORMAGAM needs TAUWSHELTER /= 0 (setwavphys.F90:150-190)";
-    if (why) {
-      (void)hipFree(c->dtab);
-      delete c;
-      return fail(std::string("ecwam_hip_create: configuration not covered by the IMPLSCH kernel: ") + why);
-    }
+    // (the context is created all the same: advection, OUTBS, halo exchange and restart do not depend on IMPLSCH's builds, and the reference
+    // accepts any NANG -- ecwam_hip_implsch / ecwam_hip_propags2_implsch then refuse with this reason)
+    if (why) c->implsch_why = std::string("configuration not covered by the IMPLSCH kernel: ") + why;
   }
   *out = c;
   return 0;
@@ -721,6 +738,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   if (!c->p.lwnemocou) wam2nemo = nullptr;
   hipStream_t s = (hipStream_t)stream;
   int rc = -1;
+  if (!c->implsch_why.empty()) return fail("ecwam_hip_implsch: " + c->implsch_why);
   if (dbg) return fail("ecwam_hip_implsch: the per-point debug rows were an output of the retired one-point-per-wavefront kernel: pass NULL");
   // k_implsch4 (implsch_v4.h).  The common builds: flag sets A and B (LLGCBZ0, LLNORMAGAM), with or without the sea-ice
   // damping rates that depend on the frequency only (LCIWA1, LCIWA3, LCISCAL), and on flag set A IPHYS 0 or ISNONLIN 1 -- what the
@@ -751,6 +769,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
 
 // the configurations the one-kernel step covers (implsch4a.hip); everything else runs ecwam_hip_propags2_otf + ecwam_hip_implsch
 static bool fused_ok(const ecwam_hip_ctx* c) {
+  if (!c->implsch_why.empty()) return false;
   const bool rare4 = c->p.lciwa2 || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin > 1 || c->p.icode != 3 || !c->p.lwvflx_snl;
   return !rare4 && c->p.iphys == 1 && c->p.isnonlin == 0 && c->NANG == 36 && c->NFRE == 36 && c->v4_r1 == 1 && c->v4_r2 == 3 &&
          c->v4_nh == 8 && !c->obs && !c->fast_g;
@@ -789,7 +808,9 @@ int ecwam_hip_propags2_implsch(ecwam_hip_ctx* c, const void* f1, void* f3, int n
   Implsch4AdvArgs a;
   a.f_in = f1; a.klon = klon; a.klat = klat; a.kcor = kcor; a.cg = cgroup_ext; a.pt = c->adv_pt; a.dirT = c->adv_dir; a.dirI = dirI;
   a.xdella = xdella; a.delpro = delpro; a.m0 = nd3s - 1; a.m1 = nd3e;
-  a.xcd_walk = (flags & 1) ? 1 : 0;      // flags bit 0: the workgroups in the XCD-aware order of k_propags2_otf (diagnostics: 1 % slower here)
+  // flags bit 0: the workgroups in the XCD-aware order of k_propags2_otf (diagnostics: 1 % slower here); bits 8..19: G > 1 = groups of G
+  // consecutive waves per XCD (diagnostics)
+  a.xcd_walk = (flags & 1) ? 1 : (((flags >> 8) & 0xFFF) > 1 ? ((flags >> 8) & 0xFFF) : 0);
   a.mode = (flags & 2) ? 2 : 1;          // flags bit 1: the go / no-go probe (libraries built with -DV4_ADV_PROBE only)
   const int ext = (c->p.llnormagam || c->p.llgcbz0) ? 1 : 0;
   int rc = -1;
@@ -820,7 +841,10 @@ static int implsch_reserve_on(ecwam_hip_ctx* c, int npts, hipStream_t s, bool sy
     c->fin = nullptr; c->fin_bytes = 0;
     HIPCHK(hipMalloc(&c->fin, need));
     HIPCHK(hipMemsetAsync(c->fin, 0, need, s));
-    if (sync) HIPCHK(hipStreamSynchronize(s));
+    // growth is a stall anyway (hipFree / hipMalloc): wait for the zeroes, so that a call on ANOTHER stream issued right after this one
+    // (which needs no growth itself) cannot have its rows overwritten by a memset still pending here
+    HIPCHK(hipStreamSynchronize(s));
+    (void)sync;
     c->fin_bytes = need;
   }
   // the split kernel pair parks the wind-input coefficient of every bin between its two halves

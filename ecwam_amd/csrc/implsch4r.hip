@@ -6,10 +6,13 @@
 #include "implsch_v4_launch.h"
 
 // jan: 1 = IPHYS 0.  Returns 0 when launched, -1 when no instantiation covers the configuration (ecwam_hip_create refuses those).
-// V4R_PREC selects the precision this object instantiates: 1 = single (implsch4r.o), 2 = double (implsch4rd.o, compiled at -O2: at -O3 the
-// double precision builds end in a memory access fault or in wrong numbers on their first launch, with every rare switch off at run time,
-// while -O2, -O1 and -O3 with index assertions on every table and row access run clean -- profiles/r05_rare_dp_rootcause.txt).
-// V4R_DP = 2: the double precision builds as the two-kernel split (launch4 SPLIT).
+// V4R_PREC selects the precision this object instantiates: 1 = single (implsch4r.o), 2 = double (implsch4rd.o).
+// V4R_DP = 2 (the product's implsch4rd.o since round 6): the double precision builds as the two-kernel split (launch4 SPLIT; + 12 % time, the
+// context owns wind-input rows for them).  As ONE function (V4R_DP = 1) the double precision builds end in a memory access fault or in wrong
+// numbers at -O3 on their first launch, with every rare switch off at run time, while -O2, -O1, -O3 with index assertions on every table and
+// row access and -O3 as the split run clean and bit-identical (profiles/r05_rare_dp_rootcause.txt: code generation of one 280 KB function
+// with > 256 VGPRs + AGPR copies + > 100 SGPR spills + a call; no small reproducer).  Round 5 shipped the one function at -O2; the split does
+// not depend on the optimisation level, so the next compiler cannot bring the fault back.
 #ifndef V4R_PREC
 #define V4R_PREC 3
 #endif

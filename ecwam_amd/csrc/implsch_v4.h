@@ -270,20 +270,12 @@ __device__ __forceinline__ V2<T> v4_at(const T* row, const int (&sh)[2 * NSH + 1
 #ifndef V4_RECPF
 #define V4_RECPF 1
 #endif
-#ifndef V4_RECPF_DP
-#define V4_RECPF_DP 0      // double precision (experiments): bit 1 the SINPUT rows' constants fetched ahead, bit 2 the lane-held tables in the unrolled row loops
-#endif
-// Double precision (V4_RECV): two records are 76 scalar registers, so the sweep's record is fetched differently there:
-//   2 (the product)  the record of THIS interaction by scalar loads issued together at its top and held there by a scheduling barrier: five
-//      loads in one place and 70 lgkmcnt(0) waits per eight interactions instead of seven in six places and 91; - 4 % kernel time, bit-identical
-//   1  one interaction ahead in VECTOR registers by wave-uniform vector loads (their counter is its own): the compiler parks the 40 values in
-//      accumulation registers and moves them in and out (+ 28 % vector instructions in the sweep): the same time as 0
-//   0  as the compiler places them
+// Double precision (V4_RECV = 2): two records are 76 scalar registers, so the record of THIS interaction is fetched by scalar loads issued
+// together at its top and held there by a scheduling barrier: five loads in one place and 70 lgkmcnt(0) waits per eight interactions instead
+// of seven in six places and 91; - 4 % kernel time, bit-identical (0: as the compiler places them; the record one interaction ahead in vector
+// registers was measured in round 5: + 28 % vector instructions, the same time -- profiles/r05_scalar_prefetch.txt).
 #ifndef V4_RECV
 #define V4_RECV 2
-#endif
-#ifndef V4_RECPF_AT
-#define V4_RECPF_AT 0      // where the sweep issues the loads of the next record: 0 at the top of the interaction, 1 in front of the row update
 #endif
 // Single precision only: in double precision the two records are 80 scalar registers, and the variant measured 3 % slower there.
 // The builds with more live registers (48 directions: twelve filter weights; the RARE builds) spill to scratch with it and stay without.
@@ -303,31 +295,10 @@ __device__ __forceinline__ void v4_pin10(T (&r)[20], int o) {      // ten values
   // point; as outputs they would be copied out of the loads' register tuples one by one)
   asm volatile("" :: "s"(r[o]), "s"(r[o + 1]), "s"(r[o + 2]), "s"(r[o + 3]), "s"(r[o + 4]), "s"(r[o + 5]), "s"(r[o + 6]), "s"(r[o + 7]), "s"(r[o + 8]), "s"(r[o + 9]));
 }
-// V4_WINSHUF: who assembles a STRADDLING pair (X(2j+r), X(2j+r+1)), r odd -- the high half of one aligned pair and the low half of the next
-// (the DIA windows, 12 per interaction, and the odd taps of the saturation filter).  A packed operation takes the vector pipe for four
-// cycles, a plain one for two, and the sweep is bound by those cycles (profiles/r05_pair_shuffle_ab.txt):
-//   0  scalar code, packed by the vectoriser, each straddling pair built with two v_mov_b32 (rounds 2 - 4)
-//   1  one shuffle (v_pk_mov_b32) per straddling pair, packed arithmetic: fewer instructions, the same pipe cycles
-//   2  no pair is assembled: the operation that consumes a straddling pair is done as two PLAIN operations on the halves where they lie
-//      (same cycles as the packed one, and the four of the v_pk_mov_b32 are gone); needs -fno-slp-vectorize -mllvm -disable-vector-combine,
-//      or the two passes re-pack them.  Measured: 12 % fewer pipe cycles in the sweep by the static count, 1 % of the kernel's time in
-//      single precision, and the two switches cost double precision 3 %: build variant "plainhalves", not the product
-// The product is 0: 1 and 2 run in the same time within 1 % and are not bit-identical to it (the packed forms contract differently); over
-// the 72 steps of test_reference_length_run_with_changing_winds the last-bit differences of 1 moved the global swh maximum -- one point's
-// value -- by 1.2e-6, past that test's 1e-6.
-#ifndef V4_WINSHUF
-#define V4_WINSHUF 0
-#endif
-// plain (one value per lane) operations of V4_WINSHUF = 2: scalar code, which stays scalar only where the vectorising passes are off
-template <typename T> __device__ __forceinline__ T v4_plain_add(T a, T b) { return a + b; }
-template <typename T> __device__ __forceinline__ T v4_plain_mul(T c, T a) { return c * a; }
-template <typename T> __device__ __forceinline__ T v4_plain_fma(T c, T a, T t) {      // c a + t, fused
-  if constexpr (sizeof(T) == 4) return __builtin_fmaf(c, a, t);
-  else return __builtin_fma(c, a, t);
-}
-template <typename T> __device__ __forceinline__ V2<T> v4_fma2(T c, V2<T> a, V2<T> t) {      // c a + t on a pair, fused
-  return __builtin_elementwise_fma(V2<T>{c, c}, a, t);
-}
+// A STRADDLING pair (X(2j+r), X(2j+r+1)), r odd -- the high half of one aligned pair and the low half of the next (the DIA windows, 12 per
+// interaction, and the odd taps of the saturation filter) -- is left to the vectoriser (two v_mov_b32 each).  One shuffle per pair, or no pair
+// assembled at all (the consuming operation as two plain operations on the halves), were measured in round 5: the same time within 1 %, not
+// bit-identical (profiles/r05_pair_shuffle_ab.txt).
 template <typename T, int NSH, int ra, int rb>
 __device__ __forceinline__ V2<T> v4_win(const T* row, const int (&sh)[2 * NSH + 1], V2<T> own, T ca, T cb) {
   static_assert(ra - rb == 1 || rb - ra == 1, "adjacent rotations");
@@ -336,24 +307,8 @@ __device__ __forceinline__ V2<T> v4_win(const T* row, const int (&sh)[2 * NSH + 
   static_assert(e / 2 + NSH >= 0 && e / 2 + 1 + NSH <= 2 * NSH, "shift table");
   const V2<T> a = (e == 0) ? own : *reinterpret_cast<const V2<T>*>(row + sh[e / 2 + NSH]);
   const V2<T> b = (e + 2 == 0) ? own : *reinterpret_cast<const V2<T>*>(row + sh[e / 2 + 1 + NSH]);
-#if V4_WINSHUF == 2
-  // ca X(ra) + cb X(rb) = fma(ca, X(ra), cb X(rb)); exactly one of the two pairs straddles (elements 1, 2 of a.x a.y b.x b.y)
-  constexpr int ia = ra - e, ib = rb - e;
-  static_assert((ia == 1) != (ib == 1), "one aligned pair, one straddling pair");
-  if constexpr (ib == 1) {
-    const V2<T> t = {v4_plain_mul(cb, a.y), v4_plain_mul(cb, b.x)};
-    return v4_fma2(ca, ia == 0 ? a : b, t);
-  } else {
-    const V2<T> t = cb * (ib == 0 ? a : b);
-    return V2<T>{v4_plain_fma(ca, a.y, t.x), v4_plain_fma(ca, b.x, t.y)};
-  }
-#elif V4_WINSHUF == 1
-  auto pick = [&](int i) -> V2<T> { return i == 0 ? a : (i == 2 ? b : __builtin_shufflevector(a, b, 1, 2)); };
-  return ca * pick(ra - e) + cb * pick(rb - e);
-#else
   const T el[4] = {a.x, a.y, b.x, b.y};      // elements e .. e + 3
   return V2<T>{ca * el[ra - e] + cb * el[rb - e], ca * el[ra - e + 1] + cb * el[rb - e + 1]};
-#endif
 }
 
 // the pair (X(2j+r), X(2j+r+1)) out of the aligned pairs A[i] = (X(2j + 2(i-NSH)), X(2j + 2(i-NSH) + 1)) of a row already in registers: an aligned
@@ -368,14 +323,6 @@ __device__ __forceinline__ V2<T> v4_pair(const V2<T> (&A)[2 * NSH + 1]) {
 template <typename T, int NSH, int NH, int d>
 __device__ __forceinline__ void v4_sat_taps(const V2<T> (&A)[2 * NSH + 1], const T (&wt)[NH + 1], V2<T>& acc) {
   if constexpr (d <= NH) {
-#if V4_WINSHUF == 2
-    if constexpr ((d & 1) != 0) {
-      // X(-d) = (A[i].y, A[i+1].x), X(d) = (A[k].y, A[k+1].x): their sum, formed half by half where the halves lie
-      constexpr int i = NSH + (-d - 1) / 2, k = NSH + (d - 1) / 2;
-      const V2<T> t = {v4_plain_add(A[i].y, A[k].y), v4_plain_add(A[i + 1].x, A[k + 1].x)};
-      acc += wt[NH - d] * t;
-    } else
-#endif
     acc += wt[NH - d] * (v4_pair<T, NSH, -d>(A) + v4_pair<T, NSH, d>(A));
     v4_sat_taps<T, NSH, NH, d + 1>(A, wt, acc);
   }
@@ -477,6 +424,9 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
   }
   for (int i = lane; i < NANG * 4; i += 64) sD[i] = A.dirI[i];
   WSYNC();
+#if defined(V4_ADV_PRIO)
+  __builtin_amdgcn_s_setprio(V4_ADV_PRIO);      // experiment: the wave that has gathers to issue goes first on its SIMD
+#endif
   VT buf[D][8];
   // (point, direction, first frequency) of the lane's chunk in step c
   auto chunk_of = [&](int c, int& q, int& k, int& m) {
@@ -606,6 +556,9 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
     finish(c, buf[c % D]);
     __builtin_amdgcn_sched_barrier(0);
   }
+#if defined(V4_ADV_PRIO)
+  __builtin_amdgcn_s_setprio(0);
+#endif
   WSYNC();
 }
 
@@ -775,7 +728,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
   V2<T> cw_n = *reinterpret_cast<const V2<T>*>(L.fac4 + Q4_CINV);
   T zcn_n = L.zcn[0];
   // V4_RECPF: the row's record of module constants one row ahead as well (its scalar load would otherwise be waited for where it is issued)
-  constexpr bool RPF = (V4_RECPF != 0) && (sizeof(T) == 4 || (V4_RECPF_DP & 1) != 0);
+  constexpr bool RPF = (V4_RECPF != 0) && sizeof(T) == 4;
   T rw_n[6];
   if constexpr (RPF) {
 #pragma unroll
@@ -884,22 +837,7 @@ __device__ void v4_sinput(const DevTab<T>& tb, const V4Ctx<T, NANG, PP>& L, T UF
       if constexpr (LLSNEG) gsp[m] = red[2 * NGST];      // (v4_row_total_to_lds: every lane of the row stores the same total)
     } else
     if (sizeof(T) == 4 || __builtin_amdgcn_ballot_w64(xl0 || xl1) != 0ull) {
-      if constexpr ((V4_REDN & 2) != 0) {      // (double precision: the stress sums of the gust states in one batch, inside the branch)
-        T red[2 * NGST];
-#pragma unroll
-        for (int ig = 0; ig < NGST; ig++) {
-          const V2<T> sx = SLP[ig] * L.sinth, sy = SLP[ig] * L.costh;
-          red[2 * ig] = sx.x + sx.y; red[2 * ig + 1] = sy.x + sy.y;
-        }
-        v4_allsum_n<G, 2 * NGST, 2 * NGST>(red, L.rot);
-#pragma unroll
-        for (int ig = 0; ig < NGST; ig++) {
-          if (ig == 0) { vXS.x = vXS.x + CONSTF * red[0]; vYS.x = vYS.x + CONSTF * red[1]; }
-          else { vXS.y = vXS.y + CONSTF * red[2 * ig]; vYS.y = vYS.y + CONSTF * red[2 * ig + 1]; }
-          xrow += red[2 * ig];
-          yrow += red[2 * ig + 1];
-        }
-      } else {
+      {
 #pragma unroll
       for (int ig = 0; ig < NGST; ig++) {
         const V2<T> sx = SLP[ig] * L.sinth, sy = SLP[ig] * L.costh;
@@ -1304,31 +1242,22 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   const int p = L.p, j = L.j;
   // ADV: the workgroups of a launch are dealt round-robin to the 8 XCDs; XCD x takes the contiguous eighth [x gridDim.x / 8, ...) of the
   // wave's triples so that a row fetched as somebody's neighbour is met again in the same L2 (gridDim.x is a multiple of 8)
-  const int blk = (ADV != 0 && adv.xcd_walk) ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  // (xcd_walk = G > 1: groups of G consecutive waves per XCD, the groups of the 8 XCDs interleaved -- the chip still moves through the grid as
+  // one front; gridDim.x is then a multiple of 8 G)
+  int blk = (int)blockIdx.x;
+  if (ADV != 0 && adv.xcd_walk == 1) blk = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  else if (ADV != 0 && adv.xcd_walk > 1) {
+    const int G_ = adv.xcd_walk, x_ = (int)(blockIdx.x & 7u), j_ = (int)(blockIdx.x >> 3);
+    blk = (j_ / G_) * (8 * G_) + x_ * G_ + (j_ % G_);
+  }
   const int ij0 = kijs + blk * PP;
   if (ij0 >= kijl) return;
-#if defined(V4_STAGGER) && V4_STAGGER > 0
-  // Experiment (build variant "stagger", profiles/r05_stagger_experiment.txt): the waves that fill the chip at the start of a launch all begin
-  // in the same phase; the two waves of a SIMD then compete for the vector ALU in the SINFLX half and for the LDS in the sweep half instead
-  // of complementing each other.  The waves of the first generation that sit in an odd wave slot of their SIMD wait half a wave lifetime.
-  if (blockIdx.x < 2048u) {
-    const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | ((4 - 1) << 11));      // HW_ID[3:0] = wave slot of the SIMD
-    if (hw & 1u)
-      for (int i = 0; i < V4_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
-  }
-#endif
   const int n = kijl - ij0 < PP ? kijl - ij0 : PP;   // points of this wave; a short last wave replicates its last point
   const int ij = ij0 + (p < n ? p : n - 1);
-  // Position of direction k of point q inside a row of PP NANG elements: q NANG + k.  (V4_ROWSPLIT = 1, build variant "rowsplit": the round-5
-  // experiment that puts the first 32 directions of the three points at 0, 32, 64 and their last four at 96, 100, 104 so that a half-wave's
-  // own pairs land on 64 different 4-byte banks -- measured: MORE conflict cycles (2 482 against 2 177 per point) and 1 % more time,
-  // profiles/r05_lds_row_layout.txt; the bank model of MI355X_MICROARCH.md does not describe what the 4-byte accesses of the odd rotations
-  // and of the transposing load / store do.)
-#ifndef V4_ROWSPLIT
-#define V4_ROWSPLIT 0
-#endif
-  constexpr bool RSPLIT = (V4_ROWSPLIT != 0) && NANG == 36 && PP == 3;
-  auto rowpos = [&](int q, int k) -> int { return RSPLIT ? (k < 32 ? 32 * q + k : 96 + 4 * q + (k - 32)) : q * NANG + k; };
+  // Position of direction k of point q inside a row of PP NANG elements: q NANG + k.  (A split layout -- the first 32 directions of the three
+  // points at 0, 32, 64, their last four at 96, 100, 104, so that a half-wave's own pairs land on 64 different banks -- measured MORE
+  // conflict cycles and 1 % more time in round 5: profiles/r05_lds_row_layout.txt.)
+  auto rowpos = [&](int q, int k) -> int { return q * NANG + k; };
   L.tile = sT; L.own = rowpos(p, 2 * j);
   L.fac4 = sFac4 + p * NFRE * 4; L.sq = sPl + p * NFRE; L.zcn = sPl + PLN + p * NFRE; L.c = sSC + p * NSC;
   int sh[2 * NSH + 1];
@@ -1338,19 +1267,6 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     k = k < 0 ? k + NANG : (k >= NANG ? k - NANG : k);
     sh[i] = rowpos(p, k);
   }
-  // V4_NOREAD2: a second copy of the shift table, one element further and opaque to the compiler, for the reads of the DELAM / DELAP staging
-  // rows: with the same address register as the reads of the AD row at the same shift the compiler merges each such pair into one
-  // ds_read2_b64 -- 8 LDS cycles against 2 + 2 for two ds_read_b64 (MI355X_MICROARCH.md, LDS table)
-#ifndef V4_NOREAD2
-#define V4_NOREAD2 0
-#endif
-  int shb[2 * NSH + 1];
-#pragma unroll
-  for (int i = 0; i <= 2 * NSH; i++) {
-    shb[i] = sh[i] + (V4_NOREAD2 ? 2 : 0);
-    if constexpr (V4_NOREAD2 != 0) asm("" : "+v"(shb[i]));
-  }
-  constexpr int SHB = V4_NOREAD2 ? 2 : 0;      // rows read through shb are addressed SHB elements lower
   if constexpr (G == 18) {
     const bool low = lane < 48 && j < 2;
     L.rot.a0 = 4 * (low ? 48 + 2 * p + j : lane);
@@ -1374,7 +1290,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
   }
   // V4_RECPF: the module constants of a row from the lane-held copies of the tables above (v_readlane) instead of a scalar load per row
   // that is waited for where it is issued (the row loops of SDEPTHLIM / FKMEAN and FEMEANWS)
-  constexpr bool RLANE = (V4_RECPF != 0) && (sizeof(T) == 4 || (V4_RECPF_DP & 2) != 0);
+  constexpr bool RLANE = (V4_RECPF != 0) && sizeof(T) == 4;
   L.sinth = V2<T>{tb.SINTH[2 * j], tb.SINTH[2 * j + 1]};
   L.costh = V2<T>{tb.COSTH[2 * j], tb.COSTH[2 * j + 1]};
   T* c = L.c;
@@ -1513,7 +1429,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       const int w = lane + 64 * it;
       if (w < NVL) {
         T* d = sT + (r * VEC) * RS + rowpos(0, k);
-        const int qo = RSPLIT ? (k < 32 ? 32 : 4) : NANG;      // distance of the next point's direction k
+        const int qo = NANG;      // distance of the next point's direction k
 #pragma unroll
         for (int q = 0; q < PP; q++)
 #pragma unroll
@@ -1994,10 +1910,6 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       }
     };
     const T DAL1 = tb.DAL1, DAL2 = tb.DAL2;
-#ifndef V4_DIAWIN
-#define V4_DIAWIN 1
-#endif
-    constexpr bool WIN = (V4_DIAWIN != 0);      // the separable window form of the DIA gathers / scatters (v4_win)
     const T CL11 = tb.DIAANG[0], ACL1 = tb.DIAANG[1], CL21 = tb.DIAANG[2], ACL2 = tb.DIAANG[3];
     const T CL11Q = tb.DIAANG[4], ACL1Q = tb.DIAANG[5], CL21Q = tb.DIAANG[6], ACL2Q = tb.DIAANG[7];
     constexpr bool RECPF_ON = (V4_RECPF != 0) && sizeof(T) == 4 && NANG <= 36 && !RARE;      // (see V4_RECPF)
@@ -2121,7 +2033,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     // round trip then hides behind the next interaction's coefficient loads and row update instead of standing in its critical path);
     // here those of the first interaction
     V2<T> wp_c = z2, wm_c = z2;
-    if constexpr (WIN) {
+    {
       const T* cw0 = tb.DIAW[0];
       wp_c = cw0[0] * fR[2] + cw0[1] * fR[3];
       wm_c = cw0[2] * fR[4] + cw0[3] * fR[5];
@@ -2144,21 +2056,18 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
     const int UPD_LIM = whole ? NFRE : mijmax;                                      // rows m < UPD_LIM (0-based) are updated
     const int DIA_LIM = whole ? MLST : (mijmax + 4 < MLST ? mijmax + 4 : MLST);     // interactions MC <= DIA_LIM contribute to them
     const int MC_END = whole ? MLST : (mijmax + 5 < MLST ? mijmax + 5 : MLST);      // row MIJ is updated at the top of interaction MIJ + 5
-    constexpr bool RECV = WIN && (V4_RECV == 1) && sizeof(T) == 8 && NANG <= 36 && !RARE;      // (see V4_RECV)
     // V4_RECV = 2 (double precision): the record of THIS interaction by scalar loads issued together at its top and held there (one
     // register set: two are 76 scalar registers) -- one wait per interaction instead of six
-    constexpr bool RECS = WIN && !RARE && (V4_RECV == 2) && sizeof(T) == 8;      // (sp at 48 directions: its spilled scalar registers push the vector registers past 256)
-    constexpr bool RECPF = WIN && (RECPF_ON || RECV || RECS);
+    constexpr bool RECS = !RARE && (V4_RECV == 2) && sizeof(T) == 8;      // (sp at 48 directions: its spilled scalar registers push the vector registers past 256)
+    constexpr bool RECPF = (RECPF_ON || RECS);
     T ra[20], rb[20];      // RECPF: the records of two consecutive interactions, roles alternating (the loop is unrolled by eight: static)
-    int vzero = 0;         // RECV: a zero the compiler cannot see through, added to the record's address: a vector load instead of a scalar one
-    if constexpr (RECV) asm("v_mov_b32 %0, 0" : "=v"(vzero));
     if constexpr (RECPF) {
-      const T* rp0 = tb.DIAREC[0] + vzero;
+      const T* rp0 = tb.DIAREC[0];
       if constexpr (!RECS) {
 #pragma unroll
         for (int i = 0; i < 20; i++) ra[i] = rp0[i];
       }
-      if constexpr (!RECV && !RECS) { v4_pin10(ra, 0); v4_pin10(ra, 10); }
+      if constexpr (!RECS) { v4_pin10(ra, 0); v4_pin10(ra, 10); }
     }
     int MCb = 0;
     for (; MCb < MC_END; MCb += 8) {
@@ -2173,8 +2082,8 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
           for (int i = 0; i < 20; i++) ra[i] = rp[i];
           __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (RECPF && !RECS && V4_RECPF_AT == 0) {      // the record of interaction MC + 1 (row MLSTHG of the table repeats the last one)
-          const T* rp = tb.DIAREC[MC < MLST ? MC : MLST] + vzero;
+        if constexpr (RECPF && !RECS) {      // the record of interaction MC + 1 (row MLSTHG of the table repeats the last one)
+          const T* rp = tb.DIAREC[MC < MLST ? MC : MLST];
 #pragma unroll
           for (int i = 0; i < 20; i++) rn[i] = rp[i];
         }
@@ -2198,7 +2107,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         const V2<T> qf0 = *reinterpret_cast<const V2<T>*>(L.fac4 + IM * 4), qf1 = *reinterpret_cast<const V2<T>*>(L.fac4 + IM * 4 + 2);
         // WIN: row MC+3 enters the ring now, in the slot of row MC-4 (fIM above holds it: the rows of this interaction were staged by the
         // previous one); it is IP1 of the next interaction, whose rows are staged at the end of this one
-        if constexpr (WIN) fR[(jj + 4) & 7] = *reinterpret_cast<const V2<T>*>(tF + hi35(MC + 3) * RS);
+        fR[(jj + 4) & 7] = *reinterpret_cast<const V2<T>*>(tF + hi35(MC + 3) * RS);
         // ---- coefficient record of the interaction (wave-uniform)
         const T* cg = tb.DIACF[MC - 1];
         const T* cs = cg + 12;
@@ -2212,12 +2121,6 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         const T FKLAMMA = cs[8], FKLAMMB = cs[9], FKLAMM2 = cs[10], FKLAMM1 = cs[11];
         const T FKLAMA2 = cs[12], FKLAMB2 = cs[13], FKLAM12 = cs[14], FKLAM22 = cs[15];
         const T FTAIL = cg31;   // the tail factor RNLCOEF(1), or 1 between MFR1STFR and MFRLSTFR where the reference skips it (x 1 is exact)
-        if constexpr (RECPF && !RECS && V4_RECPF_AT == 1) {      // (the same in front of the row update, held there)
-          const T* rp = tb.DIAREC[MC < MLST ? MC : MLST];
-#pragma unroll
-          for (int i = 0; i < 20; i++) rn[i] = rp[i];
-          __builtin_amdgcn_sched_barrier(0);
-        }
         // ---- meanwhile: the row the previous interaction completed
         if (m - 1 >= 0 && m - 1 < UPD_LIM) update_row(m - 1, aS[(jj + 4) & 7], aF[(jj + 4) & 7], wiq[(jj + 3) & 3], cg28, cg29, cg30, cg11);
         // the dissipation coefficient of row m (sdissip_ard.F90:117-314) from the saturation spectrum and the maximum the previous
@@ -2238,7 +2141,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
         const V2<T> FIJ = fIC * FTAIL;
         const V2<T> fIP1 = fR[(jj + 3) & 7];
         V2<T> SAPk[2], SAMk[2];
-        if constexpr (WIN) {
+        {
           // W+ = GP F(:,IP) + GP1 F(:,IP1), W- = GM F(:,IM) + GM1 F(:,IM1): two staged rows; SAP = CL11 W+(K1) + ACL1 W+(K11), SAM likewise
           // (staged by the previous interaction; wp_c / wm_c are the lane's own pairs of the two rows)
           const V2<T> wp = wp_c, wm = wm_c;
@@ -2247,32 +2150,16 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
           SAMk[0] = v4_win<T, NSH, R2, R2 + 1>(st2, sh, wm, CL21, ACL2);
           SAPk[1] = v4_win<T, NSH, R1, R1 + 1>(st0, sh, wp, CL11, ACL1);
           SAMk[1] = v4_win<T, NSH, -R2, -(R2 + 1)>(st2, sh, wm, CL21, ACL2);
-        } else {
-        const V2<T> up = GW1 * fIP + GW3 * fIP1, vp = GW2 * fIP + GW4 * fIP1;
-        const V2<T> um = GW5 * fIM + GW7 * fIM1, vm = GW6 * fIM + GW8 * fIM1;
-        *reinterpret_cast<V2<T>*>(st0 + L.own) = up; *reinterpret_cast<V2<T>*>(st1 + L.own) = vp;
-        *reinterpret_cast<V2<T>*>(st2 + L.own) = um; *reinterpret_cast<V2<T>*>(st3 + L.own) = vm;
-        V4SYNC();
-        // kh = 1: K1 = K - R1, K11 = K - R1 - 1, K2 = K + R2, K21 = K + R2 + 1; kh = 2 mirrored
-        SAPk[0] = (R1 == 0 ? up : v4_at<T, NSH, -R1>(st0, sh)) + v4_at<T, NSH, -(R1 + 1)>(st1, sh);
-        SAMk[0] = v4_at<T, NSH, R2>(st2, sh) + v4_at<T, NSH, R2 + 1>(st3, sh);
-        SAPk[1] = (R1 == 0 ? up : v4_at<T, NSH, R1>(st0, sh)) + v4_at<T, NSH, R1 + 1>(st1, sh);
-        SAMk[1] = v4_at<T, NSH, -R2>(st2, sh) + v4_at<T, NSH, -(R2 + 1)>(st3, sh);
         }
         V2<T> bsat = z2;
         T bm1 = T(0), e0 = T(0);
         if constexpr (!JAN) {
-#if V4_WINSHUF != 0
-          bsat = wt[NH] * elp[NSH];
-          v4_sat_taps<T, NSH, NH, 1>(elp, wt, bsat);
-#else
           bsat = V2<T>{wt[NH] * el[2 * NSH], wt[NH] * el[2 * NSH + 1]};
 #pragma unroll
           for (int d = 1; d <= NH; d++) {
             bsat.x += wt[NH - d] * (el[2 * NSH - d] + el[2 * NSH + d]);
             bsat.y += wt[NH - d] * (el[2 * NSH + 1 - d] + el[2 * NSH + 1 + d]);
           }
-#endif
           bsat = bsat * bscn;
           bm1 = m_max(bsat.x, bsat.y);
           e0 = v4_bp(L.rot.a0, bm1);
@@ -2307,28 +2194,18 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
             *reinterpret_cast<V2<T>*>(sp + L.own) = DELAP;
             V4SYNC();
             if (kh == 0) {
-              if constexpr (WIN) {      // the angular interpolation of the scatter: one window per (quantity, leg)
+              {      // the angular interpolation of the scatter: one window per (quantity, leg)
                 A2[0] = v4_win<T, NSH, -R2, -(R2 + 1)>(sa, sh, AD, CL21, ACL2); A1[0] = v4_win<T, NSH, R1, R1 + 1>(sa, sh, AD, CL11, ACL1);
-                D2[0] = v4_win<T, NSH, -R2, -(R2 + 1)>(sm - SHB, shb, DELAM, CL21Q, ACL2Q); P1[0] = v4_win<T, NSH, R1, R1 + 1>(sp - SHB, shb, DELAP, CL11Q, ACL1Q);
-              } else {
-              A2[0] = v4_at<T, NSH, -R2>(sa, sh); A2s[0] = v4_at<T, NSH, -(R2 + 1)>(sa, sh);
-              A1[0] = (R1 == 0) ? AD : v4_at<T, NSH, R1>(sa, sh); A1s[0] = v4_at<T, NSH, R1 + 1>(sa, sh);
-              D2[0] = v4_at<T, NSH, -R2>(sm, sh); D2s[0] = v4_at<T, NSH, -(R2 + 1)>(sm, sh);
-              P1[0] = (R1 == 0) ? DELAP : v4_at<T, NSH, R1>(sp, sh); P1s[0] = v4_at<T, NSH, R1 + 1>(sp, sh);
+                D2[0] = v4_win<T, NSH, -R2, -(R2 + 1)>(sm, sh, DELAM, CL21Q, ACL2Q); P1[0] = v4_win<T, NSH, R1, R1 + 1>(sp, sh, DELAP, CL11Q, ACL1Q);
               }
               if constexpr (G != 18 && !JAN) {
                 bm1 = m_max(bm1, e0);
                 if (G >= 12) e1 = v4_bp(L.rot.a1, bm1);
               }
             } else {
-              if constexpr (WIN) {
+              {
                 A2[1] = v4_win<T, NSH, R2, R2 + 1>(sa, sh, AD, CL21, ACL2); A1[1] = v4_win<T, NSH, -R1, -(R1 + 1)>(sa, sh, AD, CL11, ACL1);
-                D2[1] = v4_win<T, NSH, R2, R2 + 1>(sm - SHB, shb, DELAM, CL21Q, ACL2Q); P1[1] = v4_win<T, NSH, -R1, -(R1 + 1)>(sp - SHB, shb, DELAP, CL11Q, ACL1Q);
-              } else {
-              A2[1] = v4_at<T, NSH, R2>(sa, sh); A2s[1] = v4_at<T, NSH, R2 + 1>(sa, sh);
-              A1[1] = (R1 == 0) ? AD : v4_at<T, NSH, -R1>(sa, sh); A1s[1] = v4_at<T, NSH, -(R1 + 1)>(sa, sh);
-              D2[1] = v4_at<T, NSH, R2>(sm, sh); D2s[1] = v4_at<T, NSH, R2 + 1>(sm, sh);
-              P1[1] = (R1 == 0) ? DELAP : v4_at<T, NSH, -R1>(sp, sh); P1s[1] = v4_at<T, NSH, -(R1 + 1)>(sp, sh);
+                D2[1] = v4_win<T, NSH, R2, R2 + 1>(sm, sh, DELAM, CL21Q, ACL2Q); P1[1] = v4_win<T, NSH, -R1, -(R1 + 1)>(sp, sh, DELAP, CL11Q, ACL1Q);
               }
               if constexpr (JAN) {
               } else if constexpr (G == 18) {   // extras folded in, row maximum (no LDS), back to the extras: read by the next interaction
@@ -2348,45 +2225,26 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
             const V2<T> ADt = ADk[0] + ADk[1], DELADt = DELADk[0] + DELADk[1];
             aS[c0] -= T(2) * ADt;
             aF[c0] -= (T(2) * FTEMP) * DELADt;
-            if constexpr (WIN) {
+            {
               // the interpolated increments of the two mirror images, one fused multiply-add per target row with the frequency factor
               const V2<T> A2t = A2[0] + A2[1], A1t = A1[0] + A1[1], D2t = D2[0] + D2[1], P1t = P1[0] + P1[1];
               aS[cm] += A2t * cw[9]; aF[cm] += D2t * cw[11];        // FKLAMM1, its square
               aS[cm1] += A2t * cw[8]; aF[cm1] += D2t * cw[10];      // FKLAMM, its square
               aS[cp] += A1t * cw[5]; aF[cp] += P1t * cw[7];         // FKLAMP1, its square
               aS[cp1] = A1t * cw[4]; aF[cp1] = P1t * cw[6];         // FKLAMP, its square: the first contribution to the row that entered the ring
-            } else {
-            const V2<T> A2t = A2[0] + A2[1], A2st = A2s[0] + A2s[1], A1t = A1[0] + A1[1], A1st = A1s[0] + A1s[1];
-            const V2<T> D2t = D2[0] + D2[1], D2st = D2s[0] + D2s[1], P1t = P1[0] + P1[1], P1st = P1s[0] + P1s[1];
-            aS[cm] += A2t * FKLAMM1; aS[cm] += A2st * FKLAMM2;
-            aF[cm] += D2t * FKLAM12; aF[cm] += D2st * FKLAM22;
-            aS[cm1] += A2t * FKLAMMA; aS[cm1] += A2st * FKLAMMB;
-            aF[cm1] += D2t * FKLAMA2; aF[cm1] += D2st * FKLAMB2;
-            aS[cp] += A1t * FKLAMP1; aS[cp] += A1st * FKLAMP2;
-            aF[cp] += P1t * FKLAP12; aF[cp] += P1st * FKLAP22;
-            // first contribution to the row that entered the ring (0 + x = x: no zeroing of the slot)
-            aS[cp1] = A1t * FKLAMPA; aF[cp1] = P1t * FKLAPA2;
-            aS[cp1] += A1st * FKLAMPB;
-            aF[cp1] += P1st * FKLAPB2;
             }
           }
         }
         // ---- row MC-3 (the saturation row of the next interaction) -> its staging row; row MC+3 enters the ring in the slot of row MC-5
         if constexpr (!JAN) *reinterpret_cast<V2<T>*>(st4 + L.own) = fR[(jj + 6) & 7];
-        if constexpr (WIN) {      // W+ / W- of interaction MC + 1: IP = row MC+2, IP1 = MC+3 (entered the ring above), IM = MC-3, IM1 = MC-2
+        {      // W+ / W- of interaction MC + 1: IP = row MC+2, IP1 = MC+3 (entered the ring above), IM = MC-3, IM1 = MC-2
           wp_c = cw[12] * fR[(jj + 3) & 7] + cw[13] * fR[(jj + 4) & 7];
           wm_c = cw[14] * fR[(jj + 5) & 7] + cw[15] * fR[(jj + 6) & 7];
           *reinterpret_cast<V2<T>*>(st0 + L.own) = wp_c; *reinterpret_cast<V2<T>*>(st2 + L.own) = wm_c;
-        } else {
-          fR[(jj + 4) & 7] = *reinterpret_cast<const V2<T>*>(tF + hi35(MC + 3) * RS);
         }
         bs_p = bsat; bm_p = bm1; e3_p = e3; e4_p = e4; sig_p = cg10;
-        if constexpr (RECPF && !RECV && !RECS) {      // the next record is complete by now: pinned (not re-loaded piecemeal), it becomes the current one
+        if constexpr (RECPF && !RECS) {      // the next record is complete by now: pinned (not re-loaded piecemeal), it becomes the current one
           v4_pin10(rn, 0); v4_pin10(rn, 10);
-        }
-        if constexpr (RECV) {      // (the same for vector registers: the loads stay where they are issued)
-#pragma unroll
-          for (int i = 0; i < 20; i++) asm volatile("" :: "v"(rn[i]));
         }
         V4SYNC();
       }
@@ -2521,7 +2379,7 @@ k_implsch4(const DevTab<T>* __restrict__ tp, int kijs, int kijl, T* __restrict__
       const int w = lane + 64 * it;
       if (w < NV) {
         const T* d = sT + (r * VEC) * RS + rowpos(0, k);
-        const int qo = RSPLIT ? (k < 32 ? 32 : 4) : NANG;
+        const int qo = NANG;
 #pragma unroll
         for (int q = 0; q < PP; q++) {
           if (q < n) {

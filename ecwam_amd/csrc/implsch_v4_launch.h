@@ -65,7 +65,8 @@ static int launch4_adv(const void* tab, int kijs, int kijl, void* fl1, const voi
   auto kfn = k_implsch4<T, NANG, PP, R1, R2, NH, EXT, false, false, false, 0, ADV>;
   if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   int nb = (n + PP - 1) / PP;
-  if (adv.xcd_walk) nb = (nb + 7) & ~7;
+  if (adv.xcd_walk == 1) nb = (nb + 7) & ~7;
+  else if (adv.xcd_walk > 1) nb = (nb + 8 * adv.xcd_walk - 1) / (8 * adv.xcd_walk) * (8 * adv.xcd_walk);
   hipLaunchKernelGGL(kfn, dim3(nb), dim3(64), shmem, s, (const DevTab<T>*)tab, kijs, kijl, (T*)fl1, (const T*)wvprpt, (T*)ff, (T*)intf, mij, (T*)xllws,
                      (T*)fin, (T*)gfast, gk, (T*)nullptr, adv);
   hipLaunchKernelGGL((k_implsch4_fin<T, EXT>), dim3((n + 63) / 64), dim3(64), 0, s, (const DevTab<T>*)tab, kijs, kijl, (const T*)fin, (T*)ff,

@@ -98,8 +98,14 @@ def local_domain(grid, rank: int, nranks: int) -> LocalDomain:
         idx = np.flatnonzero(owner == p)
         assert np.all(np.diff(idx) == 1)
         recv[int(p)] = (n + int(idx[0]), int(idx.size))
+    # only a band within one latitude row of this one can read its rows (KLAT / KCOR reach the adjacent latitude rows, KLON stays in the
+    # row): the others are skipped -- at 8 ranks on O1280 that is two bands' neighbour tables scanned per rank instead of seven
+    kx = np.asarray(grid.kxlt)
+    my_rows = (int(kx[lo]), int(kx[hi - 1])) if n else (0, -1)
     for p in range(nranks):
-        if p == rank:
+        if p == rank or not n or bounds[p + 1] <= bounds[p]:
+            continue
+        if int(kx[bounds[p]]) > my_rows[1] + 1 or int(kx[bounds[p + 1] - 1]) < my_rows[0] - 1:
             continue
         ph = _halo_global(grid, int(bounds[p]), int(bounds[p + 1]))
         mine = ph[(ph >= lo) & (ph < hi)]

@@ -185,3 +185,25 @@ def build_grid(n: int, mask: str = "aqua", seed: int = 20230101, land_fraction: 
 def nsea_aqua(n: int) -> int:
     """Sea-point count of the all-ocean O<n> grid (4N(N+9)-40)."""
     return 4 * n * (n + 9) - 40
+
+
+# ---- the tables on disk: an N-rank run builds the grid ONCE (rank 0) and hands it to the other ranks through a file instead of N ranks
+#      building the whole grid side by side on a node's CPU share (54 s per rank at O1280; bench.py).  Plain .npy members in one .npz.
+_ARRAYS = ("nlonrgg", "zdello", "cosph", "sinph", "ixlg", "kxlt", "klon", "klat", "kcor", "wlat", "wcor", "row_start")
+
+
+def save_grid(g: Grid, path: str) -> None:
+    """Write the tables to `path` (atomically: a reader never sees half a file)."""
+    import os
+
+    tmp = f"{path}.{os.getpid()}.tmp.npz"
+    np.savez(tmp, name=np.array(g.name), scalars=np.array([g.ngy, g.nsea], dtype=np.int64), reals=np.array([g.xdella, g.amosop]),
+             **{k: getattr(g, k) for k in _ARRAYS})
+    os.replace(tmp, path)
+
+
+def load_grid(path: str) -> Grid:
+    with np.load(path) as z:
+        ngy, nsea = (int(x) for x in z["scalars"])
+        xdella, amosop = (float(x) for x in z["reals"])
+        return Grid(name=str(z["name"]), ngy=ngy, nsea=nsea, xdella=xdella, amosop=amosop, **{k: z[k] for k in _ARRAYS})

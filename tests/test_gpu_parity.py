@@ -1283,13 +1283,27 @@ def test_rare_builds_many_points_against_k_implsch2(api, nang, flags, seed, prec
 
 @pytest.mark.parametrize("kw,why", [(dict(nang=18, nfre=36, nfre_red=30), "NANG must be"), (dict(nang=24, nfre=30, nfre_red=25), "NFRE must be 36"),
                                     (dict(nang=16, nfre=36, nfre_red=36), "NANG must be")])
-def test_create_refuses_what_the_kernel_does_not_cover(api, kw, why):
-    """IMPLSCH has one kernel generation: a spectral grid no build of k_implsch4 covers is refused by ecwam_hip_create, with the reason, instead
-    of being routed to another kernel (through round 4 k_implsch2 took these)."""
+def test_implsch_refuses_what_the_kernel_does_not_cover(api, kw, why):
+    """IMPLSCH has one kernel generation: on a spectral grid no build of k_implsch4 covers, ecwam_hip_implsch refuses with the reason instead of
+    routing to another kernel (through round 4 k_implsch2 took these).  The context itself is created (round 6: the reference accepts any
+    NANG, and advection / OUTBS / halo exchange do not depend on IMPLSCH's builds) unless the interaction tables lack INISNONLIN's structure."""
     t = Tables(Config(**kw), np.float32)
+    try:
+        ctx = api.HipContext(t)
+    except api.EcwamHipError as e:
+        assert "rotation structure" in str(e), str(e)
+        return
+    assert not ctx.fused_supported()
+    n, K, M = 4, kw["nang"], kw["nfre"]
+    z = dict(dtype=torch.float32, device=ctx.device)
     with pytest.raises(api.EcwamHipError) as e:
-        api.HipContext(t)
+        ctx.implsch(0, n, torch.zeros((n, K, M), **z), torch.zeros((n, api.NWPR, M), **z), torch.zeros((n, api.NFF), **z), torch.zeros((n, api.NINTF), **z),
+                    torch.zeros(n, dtype=torch.int32, device=ctx.device), torch.zeros((n, K, M), **z))
     msg = str(e.value)
-    assert "not covered by the IMPLSCH kernel" in msg or "rotation structure" in msg, msg
-    if kw["nfre"] != 36:
-        assert why in msg, msg
+    assert "not covered by the IMPLSCH kernel" in msg, msg
+    assert why in msg, msg
+    out = torch.zeros((n, 5), **z)
+    ctx.outbs(0, n, torch.ones((n, K, M), **z), out)      # the rest of the library serves the context
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out[:, 0]).all()) and float(out[:, 0].min()) > 0
+    ctx.close()

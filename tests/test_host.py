@@ -379,7 +379,45 @@ sys.exit(0 if int(t) == 1 else 3)
 '''
 
 
-@pytest.mark.parametrize("world", [2, 3])
+def test_eight_rank_decomposition_and_grid_file():
+    """What a SCALE run at N = 8 executes before its first step, on the CPU: the grid tables through the file rank 0 writes for the other
+    ranks (grid.save_grid / load_grid: identical tables), the eight bands (mpdecomp.F90:58-100: equal counts, contiguous), every halo row
+    owned by exactly the peer that lists it in its send table in the same order (mpexchng.F90:141-206), and the send tables -- built from
+    the bands within one latitude row only -- equal to the ones a scan of all bands gives."""
+    import tempfile
+
+    from ecwam_amd import decomp, grid as G
+
+    g0 = G.build_grid(96)
+    path = os.path.join(tempfile.mkdtemp(), "grid.npz")
+    G.save_grid(g0, path)
+    g = G.load_grid(path)
+    for k in G._ARRAYS:
+        assert np.array_equal(getattr(g0, k), getattr(g, k)), k
+    assert (g0.name, g0.ngy, g0.nsea, g0.xdella, g0.amosop) == (g.name, g.ngy, g.nsea, g.xdella, g.amosop)
+    nr = 8
+    doms = [decomp.local_domain(g, r, nr) for r in range(nr)]
+    bounds = decomp.split_points(g.nsea, nr)
+    assert sum(d.n for d in doms) == g.nsea and all(d.lo == bounds[d.rank] and d.hi == bounds[d.rank + 1] for d in doms)
+    for d in doms:
+        assert sorted(d.recv) == sorted(p for p in range(nr) if p != d.rank and d.rank in doms[p].send)
+        covered = 0
+        for peer, (dst0, cnt) in d.recv.items():
+            assert np.array_equal(d.halo_global[dst0 - d.n: dst0 - d.n + cnt], doms[peer].send[d.rank] + doms[peer].lo), (d.rank, peer)
+            covered += cnt
+        assert covered == d.nh
+        # the brute-force send table: what EVERY other band's stencil reads of this band
+        for p in range(nr):
+            if p == d.rank:
+                continue
+            ph = decomp._halo_global(g, int(bounds[p]), int(bounds[p + 1]))
+            mine = ph[(ph >= d.lo) & (ph < d.hi)] - d.lo
+            assert (mine.size == 0 and p not in d.send) or np.array_equal(mine, d.send[p]), (d.rank, p)
+        a, b = d.interior()
+        assert 0 <= a <= b <= d.n and (b - a) > 0.8 * d.n      # most of a band is advected behind the exchange
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_halo_exchange_gloo(tmp_path, world):
     """N>1 path on CPU: `world` processes, gloo backend, the same HaloExchange object the GPU path uses, through the
     start / finish pair Wamintgr.propag overlaps with the interior, for full rows and for compact fast-wave rows."""

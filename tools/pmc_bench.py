@@ -65,7 +65,18 @@ for tag, counters in SETS.items():
             names.setdefault(k, n.split("(")[0].replace("void ", ""))
     for k in seen:
         launches[(k, tag)] = len(seen[k])
+import hashlib
+sys.path.insert(0, ROOT)
+from ecwam_amd import lib as _L
+# what ties the summary to the code object that ran: bench.py attaches it only to runs of the same library file
+lib_id = {"file": os.path.relpath(_L.LIBPATH, ROOT), "sha256": hashlib.sha256(open(_L.LIBPATH, "rb").read()).hexdigest(),
+          "bench_py_sha256": hashlib.sha256(open(os.path.join(ROOT, "bench.py"), "rb").read()).hexdigest()}
+try:
+    lib_id["git_head"] = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip() or None      # (no .git on a GPU box)
+except OSError:
+    lib_id["git_head"] = None
 out = {"workload": {"metric": bj["metric"], "dtype": bj["dtype"], "workload": bj["config"]["workload"], "points": npts, "bench_args": bench_args},
+       "library": lib_id,
        "command": " ".join(cmd), "counter_sets": SETS, "kernels": {}}
 for k in agg:
     per_launch = {}

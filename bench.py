@@ -313,7 +313,8 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    fused = a.fused != "off" and a.adv_per_source == 1 and not a.host_state and a.weights == "otf" and m.fused_available()
+    # (several advection steps per source step: the LAST one is the tile load of the source-term kernel, the others run PROPAGS2)
+    fused = a.fused != "off" and not a.host_state and a.weights == "otf" and m.fused_available()
     if a.fused == "on" and a.host_state:
         raise SystemExit("bench.py: --fused and --host-state exclude each other")
     if a.fused == "on" and not fused:
@@ -321,6 +322,8 @@ def main() -> None:
 
     def step_untimed():
         if fused:
+            for _ in range(a.adv_per_source - 1):
+                m.propag()
             m.step_fused(flags=a.fused_flags)
             return
         for _ in range(a.adv_per_source):
@@ -349,7 +352,9 @@ def main() -> None:
                 m.fl1[: m.n].copy_(host_fl, non_blocking=True)
                 m.gfast_valid = False
             e[0].record()
-            if fused:             # NEWWIND, then halo exchange (N > 1) + the one kernel that advects and integrates
+            if fused:             # (the advection steps but the last,) NEWWIND, then halo exchange (N > 1) + the one kernel that advects and integrates
+                for _ in range(a.adv_per_source - 1):
+                    m.propag()
                 e[1].record()
                 e[2].record()
                 m.step_fused(flags=a.fused_flags)
@@ -411,7 +416,11 @@ def main() -> None:
             # two kernels together)
             b_step = w * (3 * N + 6 * a.nfre + 68) + 60
             kern = {"implsch_adv": {"ms": t_impl, "alg_bytes": b_step * m.n, "gbs": b_step * m.n / t_impl / 1e6, "flop": (fl_impl + fl_prop) * m.n,
-                                    "what": "k_implsch4<..., ADV = 1>: PROPAGS2 inside IMPLSCH's tile load (+ k_ctu_prep, k_implsch4_pre / _fin)"}}
+                                    "what": "k_implsch4<..., ADV = 1 | 3>: PROPAGS2 inside IMPLSCH's tile load (+ k_ctu_prep, k_implsch4_pre / _fin"
+                                            + (", + the fast waves' sub-steps on compact rows" if a.ifrelfmax else "") + ")"}}
+            if a.adv_per_source > 1:      # the advection steps before the last one: PROPAGS2 on its own
+                kern["propags2"] = {"ms": t_prop, "alg_bytes": b_prop * m.n * (a.adv_per_source - 1),
+                                    "gbs": b_prop * m.n * (a.adv_per_source - 1) / t_prop / 1e6, "flop": fl_prop * m.n * (a.adv_per_source - 1)}
         else:
             kern = {
                 "propags2": {"ms": t_prop, "alg_bytes": b_prop * m.n * a.adv_per_source,

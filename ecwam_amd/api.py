@@ -236,9 +236,10 @@ class HipContext:
         return bool(self.lib.ecwam_hip_propags2_implsch_supported(self._h))
 
     def propags2_implsch(self, f1, f3, grid_dev: dict, cgroup_ext, delpro: float, kijs, kijl, wvprpt, ff, intf, mij, xllws, nd3s=1, nd3e=None,
-                         wam2nemo=None, flags: int = 0):
+                         wam2nemo=None, flags: int = 0, ifrelfmax: int = 0, delpro_lf: float | None = None, gin=None):
         """Rows [kijs, kijl): advect from the rows of f1 (read only) and integrate the source terms; the new spectrum goes to the rows of f3.
-        Bit for bit propags2_otf(f1 -> f3) followed by implsch(f3)."""
+        Bit for bit propags2_otf(f1 -> f3) followed by implsch(f3).  ifrelfmax > 0 with gin: frequencies 1..ifrelfmax advance with delpro_lf
+        from the compact rows gin [nrow][NANG][w] (the last fast-wave sub-step), the others with delpro from f1."""
         nd3e = self.NR if nd3e is None else nd3e
         g = grid_dev
         n, nland, ngy = g["n"], g["nland"], g["ngy"]
@@ -261,7 +262,10 @@ class HipContext:
                 self._real(cgroup_ext, (nrow, self.NFRE), "CGROUP_EXT"), self._real(g["cosphm1_ext"], (nrow,), "COSPHM1_EXT"), kijs, kijl, nd3s, nd3e,
                 self._real(wvprpt, (wvprpt.shape[0], NWPR, self.NFRE), "WVPRPT"), self._real(ff, (ff.shape[0], NFF), "FF"),
                 self._real(intf, (intf.shape[0], NINTF), "INTF"), self._int(mij, (mij.shape[0],), "MIJ"),
-                self._real(xllws, (xllws.shape[0], self.NANG, self.NFRE), "XLLWS"), pw, int(flags), _stream_ptr()]
+                self._real(xllws, (xllws.shape[0], self.NANG, self.NFRE), "XLLWS"), pw,
+                float(delpro if delpro_lf is None else delpro_lf), int(ifrelfmax),
+                None if gin is None else self._real(gin, (gin.shape[0], self.NANG, gin.shape[2]), "GIN"), 0 if gin is None else int(gin.shape[2]),
+                int(flags), _stream_ptr()]
         self._chk(self.lib.ecwam_hip_propags2_implsch(self._h, *args))
 
     def implsch_reserve(self, npts: int) -> None:

@@ -91,7 +91,7 @@ template <typename T> void launch_proenv_unpack(int, int, const void*, const voi
 template <typename T> int launch_implsch4(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, void*, int, int, int, int, int, int, hipStream_t);
 template <typename T> int launch_implsch4x(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, void*, int, int, int, int, int, int, hipStream_t);
 template <typename T> int launch_implsch4r(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, void*, int, int, int, int, int, int, hipStream_t);
-template <typename T> void launch_ctu_prep(const void*, int, int, int, double, const int*, const void*, double, const void*, const void*, const void*, const void*, const void*, void*, void*, int*, hipStream_t);
+template <typename T> void launch_ctu_prep(const void*, int, int, int, double, double, const int*, const void*, double, const void*, const void*, const void*, const void*, const void*, void*, void*, int*, hipStream_t);
 template <typename T> int launch_implsch4_adv(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, const Implsch4AdvArgs*, int, int, int, int, int, int, hipStream_t);
 int implsch4_fin_row();
 int implsch4_split_all();
@@ -772,14 +772,15 @@ static bool fused_ok(const ecwam_hip_ctx* c) {
   if (!c->implsch_why.empty()) return false;
   const bool rare4 = c->p.lciwa2 || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin > 1 || c->p.icode != 3 || !c->p.lwvflx_snl;
   return !rare4 && c->p.iphys == 1 && c->p.isnonlin == 0 && c->NANG == 36 && c->NFRE == 36 && c->v4_r1 == 1 && c->v4_r2 == 3 &&
-         c->v4_nh == 8 && !c->obs && !c->fast_g;
+         c->v4_nh == 8 && !c->obs;
 }
 int ecwam_hip_propags2_implsch_supported(ecwam_hip_ctx* c) { return c && fused_ok(c) ? 1 : 0; }
 
 int ecwam_hip_propags2_implsch(ecwam_hip_ctx* c, const void* f1, void* f3, int n, int ngy, double delpro, const int* kxlt, const void* zdello,
                                double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat, const int* kcor,
                                const void* wlat, const void* wcor, const void* cgroup_ext, const void* cosphm1_ext, int kijs, int kijl, int nd3s,
-                               int nd3e, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws, double* wam2nemo, int flags, void* stream) {
+                               int nd3e, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws, double* wam2nemo, double delpro_lf,
+                               int ifrelfmax, const void* gin, int gin_nfre, int flags, void* stream) {
   if (!c) return fail("null context");
   if (!fused_ok(c)) return fail("ecwam_hip_propags2_implsch: no one-kernel build covers the configuration (ecwam_hip_propags2_implsch_supported): call ecwam_hip_propags2_otf and ecwam_hip_implsch");
   if (kijl < kijs || kijs < 0 || kijl > n || nd3s < 1 || nd3e > c->NFRE_RED || nd3e < nd3s - 1) return fail("ecwam_hip_propags2_implsch: bad range");
@@ -788,6 +789,12 @@ int ecwam_hip_propags2_implsch(ecwam_hip_ctx* c, const void* f1, void* f3, int n
     return fail("ecwam_hip_propags2_implsch: null pointer");
   if (f1 == f3) return fail("ecwam_hip_propags2_implsch: F1 and F3 must not alias (the neighbours of a point are read while other points are stored)");
   if (((uintptr_t)f1 % 16) != 0 || ((uintptr_t)f3 % 16) != 0) return fail("ecwam_hip_propags2_implsch: the spectra must be 16-byte aligned");
+  // fast waves (propag_wam.F90:247-313): frequencies 1..ifrelfmax advance with delpro_lf and are read from the compact rows their sub-steps left
+  if (ifrelfmax < 0 || ifrelfmax > c->NFRE_RED || (ifrelfmax > 0) != (gin != nullptr))
+    return fail("ecwam_hip_propags2_implsch: fast waves (ifrelfmax > 0) come with their compact input rows (gin), and only then");
+  if (gin && (nd3s != 1 || gin_nfre < ifrelfmax || gin_nfre > c->NFRE || gin_nfre % (16 / c->real_bytes) != 0 || ((uintptr_t)gin % 16) != 0 || gin == c->fast_g ||
+              !(delpro_lf > 0.0)))
+    return fail("ecwam_hip_propags2_implsch: the compact fast-wave rows must be 16-byte aligned, hold the fast waves in a multiple of 16 bytes per direction, and differ from the rows of ecwam_hip_set_fastwave_copy");
   if (c->p.lwnemocou && kijl > kijs && !wam2nemo) return fail("ecwam_hip_propags2_implsch: LWNEMOCOU needs the WAVE2OCEAN buffer");
   if (!c->p.lwnemocou) wam2nemo = nullptr;
   HIPCHK(hipSetDevice(c->device));
@@ -801,13 +808,17 @@ int ecwam_hip_propags2_implsch(ecwam_hip_ctx* c, const void* f1, void* f3, int n
     HIPCHK(hipMalloc(&c->adv_pt, need));
     c->adv_pt_bytes = need;
   }
-  if (!c->adv_dir) HIPCHK(hipMalloc(&c->adv_dir, (size_t)(4 * c->NANG + 4) * c->real_bytes + (size_t)4 * c->NANG * sizeof(int)));
-  int* dirI = reinterpret_cast<int*>(reinterpret_cast<char*>(c->adv_dir) + (size_t)(4 * c->NANG + 4) * c->real_bytes);
-  DISPATCH(launch_ctu_prep<float>(c->dtab, kijs, kijl, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, wlat, wcor, cosphm1_ext, c->adv_pt, c->adv_dir, dirI, s),
-           launch_ctu_prep<double>(c->dtab, kijs, kijl, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, wlat, wcor, cosphm1_ext, c->adv_pt, c->adv_dir, dirI, s));
+  const size_t dir_reals = (size_t)(6 * c->NANG + 4);      // [NANG][4], CMTODEG (+ 3 pad), [NANG][2] for the fast waves' time step
+  if (!c->adv_dir) HIPCHK(hipMalloc(&c->adv_dir, dir_reals * c->real_bytes + (size_t)4 * c->NANG * sizeof(int)));
+  int* dirI = reinterpret_cast<int*>(reinterpret_cast<char*>(c->adv_dir) + dir_reals * c->real_bytes);
+  const double dlf = gin ? delpro_lf : 0.0;
+  DISPATCH(launch_ctu_prep<float>(c->dtab, kijs, kijl, ngy, delpro, dlf, kxlt, zdello, xdella, cosph, sinph, wlat, wcor, cosphm1_ext, c->adv_pt, c->adv_dir, dirI, s),
+           launch_ctu_prep<double>(c->dtab, kijs, kijl, ngy, delpro, dlf, kxlt, zdello, xdella, cosph, sinph, wlat, wcor, cosphm1_ext, c->adv_pt, c->adv_dir, dirI, s));
   Implsch4AdvArgs a;
   a.f_in = f1; a.klon = klon; a.klat = klat; a.kcor = kcor; a.cg = cgroup_ext; a.pt = c->adv_pt; a.dirT = c->adv_dir; a.dirI = dirI;
   a.xdella = xdella; a.delpro = delpro; a.m0 = nd3s - 1; a.m1 = nd3e;
+  a.gin = gin; a.delpro_lf = dlf; a.gin_k = gin ? gin_nfre : 0; a.mlf = gin ? ifrelfmax : 0;
+  a.gfast = c->fast_g; a.gfast_k = c->fast_g ? c->fast_gk : 0;      // ecwam_hip_set_fastwave_copy, as for ecwam_hip_implsch
   // flags bit 0: the workgroups in the XCD-aware order of k_propags2_otf (diagnostics: 1 % slower here); bits 8..19: G > 1 = groups of G
   // consecutive waves per XCD (diagnostics)
   a.xcd_walk = (flags & 1) ? 1 : (((flags >> 8) & 0xFFF) > 1 ? ((flags >> 8) & 0xFFF) : 0);

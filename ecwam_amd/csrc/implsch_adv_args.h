@@ -9,6 +9,11 @@ struct Implsch4AdvArgs {
   const void* dirT;                     // per-direction factors (k_ctu_prep)
   const int* dirI;
   double xdella, delpro;
+  const void* gin;                      // fast waves after their sub-steps: compact rows [rows][NANG][gin_k] (or NULL)
+  double delpro_lf;
+  int gin_k, mlf;                       // frequencies [0, mlf) advance with delpro_lf
+  void* gfast;                          // compact rows that also receive the first gfast_k frequencies of the new spectrum (or NULL)
+  int gfast_k;
   int m0, m1;                           // advected frequencies [m0, m1)
   int xcd_walk;
   int mode;                             // 1 = the product; 2 = the go / no-go probe (made-up weights; builds with -DV4_ADV_PROBE only)

@@ -375,6 +375,12 @@ struct V4Adv {
   const T* dirT;        // [NANG][4]: DELTH0 (SINTH(K) + SINTH(K+1)) / R, the same for K-1, SINTH, COSTH; then CMTODEG
   const int* dirI;      // [NANG][4]: JXO(K,1) | JYO(K,1) << 1 | KCR(K,1) << 2, KPM(K,-1), KPM(K,1)
   T xdella, delpro;
+  // ADV = 3 (the native O1280 mode, propag_wam.F90:247-313): frequencies [0, mlf) -- the fast waves -- advance with delpro_lf, and the first
+  // gin_k frequencies of every direction (own and neighbours) are READ from the compact rows gin[rows][NANG][gin_k], the fast waves after
+  // their sub-steps; dirT then carries the factors of ctu_dirfac for delpro_lf behind CMTODEG ([NANG][2])
+  const T* gin;
+  T delpro_lf;
+  int gin_k, mlf;
   int m0, m1;           // advected frequencies [m0, m1); the others are carried over
   int xcd_walk;         // XCD-aware order of the workgroups (diagnostics: measured 1 % slower than the natural order, profiles/r06_fused_*.txt)
 };
@@ -394,9 +400,11 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
   T* sB = sScr;                                        // [PP][5][NFRE]: |h(1:2)|, |hy(1:2)|, CG of ctu_base
   T* sPt = sB + PP * 5 * NFRE;                         // [PP][PTW]: ZDELLO, |COSPHM1|, GA, TANPH, DP(1:2), WLAT(1:2), WCOR(1:4), 1 - WLAT, 1 - WCOR
   T* sK = sPt + PP * PTW;                              // [NANG][4]: 2 SP, 2 SM (ctu_dirfac with TANPH = 1, doubled), |SINTH|, |COSTH|; then CMTODEG
-  int* sI = reinterpret_cast<int*>(sK + NANG * 4 + 4); // [PP][16]: ij, KLON(1:2), KLAT(1:2,1:2), KCOR(1:4,1:2)
+  constexpr bool LF = (MODE == 3);                     // fast waves with their own time step, read from compact rows
+  constexpr int NKW = NANG * 4 + 4 + (LF ? NANG * 2 : 0);      // (LF: then [NANG][2]: 2 SP, 2 SM for DELPRO_LF)
+  int* sI = reinterpret_cast<int*>(sK + NKW);          // [PP][16]: ij, KLON(1:2), KLAT(1:2,1:2), KCOR(1:4,1:2)
   int* sD = sI + PP * 16;                              // [NANG][4]
-  static_assert((PP * 5 * NFRE + PP * PTW + NANG * 4 + 4) * sizeof(T) + (PP * 16 + NANG * 4) * sizeof(int) <= NSCR * sizeof(T), "LDS scratch of the advecting load");
+  static_assert((PP * 5 * NFRE + PP * PTW + NKW) * sizeof(T) + (PP * 16 + NANG * 4) * sizeof(int) <= NSCR * sizeof(T), "LDS scratch of the advecting load");
   for (int i = lane; i < PP * PTW; i += 64) {
     const int q = i / PTW, e = i - q * PTW;
     const T* g = A.pt + (size_t)(ij0 + (q < n ? q : n - 1)) * 12;
@@ -417,10 +425,10 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
     if (e >= 7 && e <= 14) v = A.kcor[(size_t)ijq * 8 + (e - 7)];
     sI[i] = v;
   }
-  for (int i = lane; i < NANG * 4 + 4; i += 64) {
+  for (int i = lane; i < NKW; i += 64) {
     const T v = A.dirT[i];
     const int e = i & 3;
-    sK[i] = i >= NANG * 4 ? v : (e < 2 ? T(2) * v : m_abs(v));
+    sK[i] = i >= NANG * 4 + 4 ? T(2) * v : (i >= NANG * 4 ? v : (e < 2 ? T(2) * v : m_abs(v)));
   }
   for (int i = lane; i < NANG * 4; i += 64) sD[i] = A.dirI[i];
   WSYNC();
@@ -450,16 +458,21 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
     const I4 dk = *reinterpret_cast<const I4*>(sD + 4 * k);
     const int jx0 = dk.x & 1, jy0 = (dk.x >> 1) & 1, kc = (dk.x >> 2) & 3;
     const int* iq = sI + q * 16;
-    const T* own = A.f_in + (size_t)iq[0] * N;
-    const int el = k * NFRE + m;
+    // (LF: this chunk's operands, own and neighbours, live in the compact rows when its frequencies are among their gin_k)
+    const bool fromg = LF && m < A.gin_k;
+    const T* src = fromg ? A.gin : A.f_in;
+    const int rk = fromg ? A.gin_k : NFRE;               // frequencies per direction of the source rows
+    const size_t rn = (size_t)NANG * rk;
+    const T* own = src + (size_t)iq[0] * rn;
+    const int el = k * rk + m;
     b[0] = *reinterpret_cast<const VT*>(own + el);
-    b[1] = *reinterpret_cast<const VT*>(A.f_in + (size_t)iq[1 + jx0] * N + el);
-    b[2] = *reinterpret_cast<const VT*>(A.f_in + (size_t)iq[3 + 2 * jy0] * N + el);
-    b[3] = *reinterpret_cast<const VT*>(A.f_in + (size_t)iq[4 + 2 * jy0] * N + el);
-    b[4] = *reinterpret_cast<const VT*>(A.f_in + (size_t)iq[7 + 2 * kc] * N + el);
-    b[5] = *reinterpret_cast<const VT*>(A.f_in + (size_t)iq[8 + 2 * kc] * N + el);
-    b[6] = *reinterpret_cast<const VT*>(own + dk.y * NFRE + m);
-    b[7] = *reinterpret_cast<const VT*>(own + dk.z * NFRE + m);
+    b[1] = *reinterpret_cast<const VT*>(src + (size_t)iq[1 + jx0] * rn + el);
+    b[2] = *reinterpret_cast<const VT*>(src + (size_t)iq[3 + 2 * jy0] * rn + el);
+    b[3] = *reinterpret_cast<const VT*>(src + (size_t)iq[4 + 2 * jy0] * rn + el);
+    b[4] = *reinterpret_cast<const VT*>(src + (size_t)iq[7 + 2 * kc] * rn + el);
+    b[5] = *reinterpret_cast<const VT*>(src + (size_t)iq[8 + 2 * kc] * rn + el);
+    b[6] = *reinterpret_cast<const VT*>(own + dk.y * rk + m);
+    b[7] = *reinterpret_cast<const VT*>(own + dk.z * rk + m);
   };
   auto finish = [&](int c, const VT (&b)[8]) {
     int q, k, m;
@@ -486,6 +499,8 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
 #else
       T ab2, p2, m2;
       ctu_fast_dir<T>(tanph, kk[0], kk[1], ab2, p2, m2);
+      T ab2_lf = ab2, p2_lf = p2, m2_lf = m2;
+      if constexpr (LF) ctu_fast_dir<T>(tanph, sK[NANG * 4 + 4 + 2 * k], sK[NANG * 4 + 4 + 2 * k + 1], ab2_lf, p2_lf, m2_lf);
 #endif
       const T* bb = sB + q * 5 * NFRE + m;
       const VT bha = *reinterpret_cast<const VT*>(bb + jx0 * NFRE), bhb = *reinterpret_cast<const VT*>(bb + (1 - jx0) * NFRE),
@@ -505,8 +520,10 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
 #pragma unroll
       for (int i = 0; i < VEC; i += 2) {
 #define P2(a) V2<T>{a[i], a[i + 1]}
+        const bool lf0 = LF && (m + i) < A.mlf, lf1 = LF && (m + i + 1) < A.mlf;
         const V2<T> rr = ctu_fast_stencil<T>(P2(bha), P2(bhb), P2(bya), P2(byb), P2(bc0), kk2, kk3, zd, A.xdella, ga, zdg, xdg, wl, omwl, wc, omwc,
-                                             V2<T>{ab2, ab2}, V2<T>{p2, p2}, V2<T>{m2, m2}, P2(b[0]), P2(b[1]), P2(b[2]), P2(b[3]), P2(b[4]), P2(b[5]),
+                                             V2<T>{lf0 ? ab2_lf : ab2, lf1 ? ab2_lf : ab2}, V2<T>{lf0 ? p2_lf : p2, lf1 ? p2_lf : p2},
+                                             V2<T>{lf0 ? m2_lf : m2, lf1 ? m2_lf : m2}, P2(b[0]), P2(b[1]), P2(b[2]), P2(b[3]), P2(b[4]), P2(b[5]),
                                              P2(b[6]), P2(b[7]));
 #undef P2
         r[i] = rr.x; r[i + 1] = rr.y;
@@ -525,7 +542,7 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
 #pragma unroll
   for (int c = 0; c < D - 1 && c < NCH; c++) issue(c, buf[c % D]);
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (MODE == 1) {
+  if constexpr (MODE == 1 || MODE == 3) {
     for (int i = lane; i < PP * NFRE; i += 64) {
       const int q = i / NFRE, m = i - q * NFRE;
       const int* iq = sI + q * 16;
@@ -543,7 +560,7 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
 #if ECWAM_HIP_CTU_STRICT
       o[0] = m_abs(b.h[0]); o[NFRE] = m_abs(b.h[1]); o[2 * NFRE] = m_abs(b.hy[0]); o[3 * NFRE] = m_abs(b.hy[1]); o[4 * NFRE] = b.cg0;
 #else
-      ctu_fast_planes<T>(b, pq[1], A.delpro * sK[NANG * 4], o, o + NFRE, o + 2 * NFRE, o + 3 * NFRE);
+      ctu_fast_planes<T>(b, pq[1], ((LF && m < A.mlf) ? A.delpro_lf : A.delpro) * sK[NANG * 4], o, o + NFRE, o + 2 * NFRE, o + 3 * NFRE);
       o[4 * NFRE] = b.cg0;
 #endif
     }
@@ -1184,7 +1201,8 @@ __device__ __forceinline__ T v4_sdice3_alp(const DevTab<T>& tb, int m, T CITHICK
 // fluxes, the tail and the stores.  Same source, same results bit for bit; two smaller functions for the compiler.
 // ADV: 0 = the tile is loaded from FL1 (IMPLSCH on its own, behind a PROPAGS2 kernel); 1 = the tile load IS the advection (round 6:
 // v4_advect_tile above -- PROPAGS2 of the wave's points from the rows of adv.f_in straight into the tile, the new spectrum stored to the rows
-// of fl1, which must be another buffer: one kernel per WAMINTGR step); 2 = the go / no-go probe of that build (the eight gathers of the
+// of fl1, which must be another buffer: one kernel per WAMINTGR step); 3 = the same for the native O1280 mode: the fast waves with their own
+// time step, read from the compact rows their sub-steps left (V4Adv::gin); 2 = the go / no-go probe of ADV = 1 (the eight gathers of the
 // stencil through the real neighbour tables, made-up weights).
 template <typename T, int NANG, int PP, int R1, int R2, int NH, bool EXT, bool JAN = false, bool ENHMC = false, bool RARE = false, int PART = 0, int ADV = 0>
 // single precision: two waves per SIMD (LDS: 8 waves per CU), at most 256 VGPRs; double precision: the LDS holds one wave per SIMD

@@ -1258,8 +1258,9 @@ void launch_newwind(const void* tab, int n, void* ff, const void* ffn, int icode
 // ctu_dirfac with TANPH = 1, SINTH, COSTH, then CMTODEG, and the index words JXO(K,1) | JYO(K,1) << 1 | KCR(K,1) << 2, KPM(K,-1), KPM(K,1).
 // Computed HERE because the divisions in them are correctly rounded in this translation unit (the IMPLSCH units are built with the
 // hardware reciprocal): the one-kernel step then forms the same weights, bit for bit, as k_propags2_otf.
+// (delpro_lf > 0: the factors of ctu_dirfac for the fast waves' time step follow CMTODEG as [NANG][2].)
 template <typename T>
-__global__ void k_ctu_prep(const DevTab<T>* __restrict__ tab, int kijs, int kijl, int ngy, T delpro, const int* __restrict__ kxlt,
+__global__ void k_ctu_prep(const DevTab<T>* __restrict__ tab, int kijs, int kijl, int ngy, T delpro, T delpro_lf, const int* __restrict__ kxlt,
                            const T* __restrict__ zdello, T xdella, const T* __restrict__ cosph, const T* __restrict__ sinph,
                            const T* __restrict__ wlat, const T* __restrict__ wcor, const T* __restrict__ cosphm1, T* __restrict__ pt,
                            T* __restrict__ dirT, int* __restrict__ dirI) {
@@ -1272,6 +1273,10 @@ __global__ void k_ctu_prep(const DevTab<T>* __restrict__ tab, int kijs, int kijl
       dirT[4 * k] = a; dirT[4 * k + 1] = b; dirT[4 * k + 2] = tab->SINTH[k]; dirT[4 * k + 3] = tab->COSTH[k];
       dirI[4 * k] = tab->JXO[k][0] | (tab->JYO[k][0] << 1) | (tab->KCR[k][0] << 2);
       dirI[4 * k + 1] = tab->KPM[k][0]; dirI[4 * k + 2] = tab->KPM[k][2]; dirI[4 * k + 3] = 0;
+      if (delpro_lf > T(0)) {
+        ctu_dirfac(tab, k, T(0.25) * delpro_lf / tab->DELTH, T(1), a, b);
+        dirT[4 * NANG + 4 + 2 * k] = a; dirT[4 * NANG + 4 + 2 * k + 1] = b;
+      }
     }
     if (threadIdx.x == 0) {
       dirT[4 * NANG] = T(360.0) / tab->CIRC;
@@ -1286,11 +1291,11 @@ __global__ void k_ctu_prep(const DevTab<T>* __restrict__ tab, int kijs, int kijl
   }
 }
 template <typename T>
-void launch_ctu_prep(const void* tab, int kijs, int kijl, int ngy, double delpro, const int* kxlt, const void* zdello, double xdella,
+void launch_ctu_prep(const void* tab, int kijs, int kijl, int ngy, double delpro, double delpro_lf, const int* kxlt, const void* zdello, double xdella,
                      const void* cosph, const void* sinph, const void* wlat, const void* wcor, const void* cosphm1, void* pt, void* dirT, int* dirI,
                      hipStream_t s) {
   const int n = kijl - kijs;
-  hipLaunchKernelGGL(k_ctu_prep<T>, dim3(n > 0 ? grid_for(n) : 1), dim3(256), 0, s, (const DevTab<T>*)tab, kijs, kijl, ngy, (T)delpro, kxlt,
+  hipLaunchKernelGGL(k_ctu_prep<T>, dim3(n > 0 ? grid_for(n) : 1), dim3(256), 0, s, (const DevTab<T>*)tab, kijs, kijl, ngy, (T)delpro, (T)delpro_lf, kxlt,
                      (const T*)zdello, (T)xdella, (const T*)cosph, (const T*)sinph, (const T*)wlat, (const T*)wcor, (const T*)cosphm1, (T*)pt,
                      (T*)dirT, dirI);
 }
@@ -1360,7 +1365,7 @@ void launch_proenv_unpack(int nrows, int NFRE, const void* buf, const void* land
                                const void*, const int*, const int*, const int*, void*, void*, const void*, const void*, void*,   \
                                int*, int, const void*, hipStream_t);                                                              \
   template void launch_newwind<T>(const void*, int, void*, const void*, int, hipStream_t);                                        \
-  template void launch_ctu_prep<T>(const void*, int, int, int, double, const int*, const void*, double, const void*, const void*, const void*, const void*, const void*, void*, void*, int*, hipStream_t);\
+  template void launch_ctu_prep<T>(const void*, int, int, int, double, double, const int*, const void*, double, const void*, const void*, const void*, const void*, const void*, void*, void*, int*, hipStream_t);\
   template void launch_nosource<T>(const void*, int, int, int, void*, void*, int*, hipStream_t);                                  \
   template void launch_propdot<T>(const void*, int, int, int, const int*, const void*, double, const void*, const int*,         \
                                   const int*, const void*, const void*, const void*, const void*, const void*, void*, hipStream_t); \

@@ -171,11 +171,9 @@ SUBROUTINE WAMINTGR_HIP (CDTPRA, CDATE, CDATEWH, CDTIMP, CDTIMPNEXT,  &
     ! one rank the exchange runs on the library's stream while the rows that read no halo row are advected.
     ! When the source terms are due right after this propagation step (wamintgr.F90:110) and a one-kernel build covers the configuration, the
     ! advection is left to IMPLSCH's tile load: only the exchange is posted here, FL1 / FL3 are swapped behind that kernel
-    LFUSE = HIP_LFUSED_STEP .AND. HIPST%IFRELFMAX <= 0 .AND. HIP_LLSOURCE .AND. (HIP_CDTPRO >= CDTIMPNEXT)
+    LFUSE = HIP_LFUSED_STEP .AND. HIP_LLSOURCE .AND. (HIP_CDTPRO >= CDTIMPNEXT)
+    IF (LFUSE .AND. HIPST%IFRELFMAX > 0) LFUSE = C_ASSOCIATED(HIPST%D_G1)
     IF (LFUSE) LFUSE = ECWAM_HIP_PROPAGS2_IMPLSCH_SUPPORTED(HIPST%CTX) /= 0
-    IF (LFUSE) THEN
-      CALL HIP_HALO_START(HIPST%D_FL1, NANG * NFRE, S0)
-    ELSE
     IF (HIPST%IFRELFMAX > 0) THEN
       ! the fast waves do not depend on the slow ones: their sub-steps 1 .. NSTEP_LF-1 first, compact rows -> compact rows, then one full
       ! pass that takes their last state from the compact rows as the input of the last sub-step and writes complete FL3 rows and the
@@ -196,6 +194,7 @@ SUBROUTINE WAMINTGR_HIP (CDTPRA, CDATE, CDATEWH, CDTIMP, CDTIMPNEXT,  &
       CALL HIP_HALO_START(HIPST%D_G1, NANG * HIPST%LFP, S0)     ! the short rows first: the second exchange queues behind the first
     ENDIF
     CALL HIP_HALO_START(HIPST%D_FL1, NANG * NFRE, S0)
+    IF (.NOT. LFUSE) THEN      ! (LFUSE: the full pass is the tile load of the source-term kernel below; the exchanges are posted)
     CALL ADVECT_FULL(HIPST%KIJS_INT - 1, HIPST%KIJL_INT)
     IF (HIPST%LDECOMP) THEN
       CALL HIP_HALO_FINISH(S0)
@@ -261,6 +260,10 @@ SUBROUTINE WAMINTGR_HIP (CDTPRA, CDATE, CDATEWH, CDTIMP, CDTIMPNEXT,  &
         CALL ADVECT_AND_INTEGRATE(HIPST%KIJL_INT, NP)
       ENDIF
       DTMP = HIPST%D_FL1; HIPST%D_FL1 = HIPST%D_FL3; HIPST%D_FL3 = DTMP
+      IF (HIPST%IFRELFMAX > 0) THEN      ! D_G2 received the new fast waves: it is what the next advection step starts from
+        DTMP = HIPST%D_G1; HIPST%D_G1 = HIPST%D_G2; HIPST%D_G2 = DTMP
+        HIPST%LGFAST_VALID = .TRUE.
+      ENDIF
     ELSE
     CALL FAST_SINK(.TRUE.)      ! IMPLSCH leaves the fast waves of its result in the compact rows as well
     CALL ECWAM_HIP_CHECK(ECWAM_HIP_IMPLSCH(HIPST%CTX, 0_C_INT, NP, HIPST%D_FL1, HIPST%D_WVPRPT, HIPST%D_FF, HIPST%D_INTF, &
@@ -321,10 +324,20 @@ CONTAINS
   SUBROUTINE ADVECT_AND_INTEGRATE(K0, K1)
     INTEGER(C_INT), INTENT(IN) :: K0, K1
     IF (K1 <= K0) RETURN
+    IF (HIPST%IFRELFMAX > 0) THEN
+      ! the fast waves' last sub-step reads the compact rows D_G1 (after their sub-steps 1 .. NSTEP_LF-1); the new fast waves go to D_G2
+      CALL ECWAM_HIP_CHECK(ECWAM_HIP_SET_FASTWAVE_COPY(HIPST%CTX, HIPST%D_G2, HIPST%LFP), 'ECWAM_HIP_SET_FASTWAVE_COPY')
+      CALL ECWAM_HIP_CHECK(ECWAM_HIP_PROPAGS2_IMPLSCH(HIPST%CTX, HIPST%D_FL1, HIPST%D_FL3, NP, HIPST%NGY, REAL(HIPST%IDELPRO, C_DOUBLE), &
+ &          HIPST%D_KXLT, HIPST%D_ZD, HIPST%XDELLA, HIPST%D_CP, HIPST%D_SP, HIPST%D_KLON, HIPST%D_KLAT, HIPST%D_KCOR, HIPST%D_WLAT, &
+ &          HIPST%D_WCOR, HIPST%D_CG, HIPST%D_CM1, K0, K1, 1_C_INT, HIPST%NFRE_RED, HIPST%D_WVPRPT, HIPST%D_FF, HIPST%D_INTF, HIPST%D_MIJ, &
+ &          HIPST%D_XLLWS, HIPST%D_W2N, HIPST%DELPRO_LF, HIPST%IFRELFMAX, HIPST%D_G1, HIPST%LFP, 0_C_INT, S0), 'ECWAM_HIP_PROPAGS2_IMPLSCH')
+      CALL ECWAM_HIP_CHECK(ECWAM_HIP_SET_FASTWAVE_COPY(HIPST%CTX, C_NULL_PTR, 0_C_INT), 'ECWAM_HIP_SET_FASTWAVE_COPY')
+      RETURN
+    ENDIF
     CALL ECWAM_HIP_CHECK(ECWAM_HIP_PROPAGS2_IMPLSCH(HIPST%CTX, HIPST%D_FL1, HIPST%D_FL3, NP, HIPST%NGY, REAL(HIPST%IDELPRO, C_DOUBLE), &
  &        HIPST%D_KXLT, HIPST%D_ZD, HIPST%XDELLA, HIPST%D_CP, HIPST%D_SP, HIPST%D_KLON, HIPST%D_KLAT, HIPST%D_KCOR, HIPST%D_WLAT, &
  &        HIPST%D_WCOR, HIPST%D_CG, HIPST%D_CM1, K0, K1, 1_C_INT, HIPST%NFRE_RED, HIPST%D_WVPRPT, HIPST%D_FF, HIPST%D_INTF, HIPST%D_MIJ, &
- &        HIPST%D_XLLWS, HIPST%D_W2N, 0_C_INT, S0), 'ECWAM_HIP_PROPAGS2_IMPLSCH')
+ &        HIPST%D_XLLWS, HIPST%D_W2N, 0.0_C_DOUBLE, 0_C_INT, C_NULL_PTR, 0_C_INT, 0_C_INT, S0), 'ECWAM_HIP_PROPAGS2_IMPLSCH')
   END SUBROUTINE
   SUBROUTINE ADVECT_FULL(K0, K1)
     INTEGER(C_INT), INTENT(IN) :: K0, K1

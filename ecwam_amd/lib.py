@@ -97,7 +97,8 @@ def load() -> C.CDLL:
     lib.ecwam_hip_propags2_otf_fast.argtypes = [vp, vp, vp, ci, ci, cd, cd, ci, ci, vp, ci, ci, vp, ci, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
     lib.ecwam_hip_set_fastwave_copy.argtypes = [vp, vp, ci]
     lib.ecwam_hip_propags2_implsch_supported.argtypes = [vp]
-    lib.ecwam_hip_propags2_implsch.argtypes = [vp, vp, vp, ci, ci, cd, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]
+    lib.ecwam_hip_propags2_implsch.argtypes = [vp, vp, vp, ci, ci, cd, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp,
+                                               cd, ci, vp, ci, ci, vp]
     lib.ecwam_hip_copy_freq_range.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
     lib.ecwam_hip_propdot.argtypes = [vp, ci, ci, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ecwam_hip_ctuw_refra.argtypes = [vp, ci, ci, ci, cd, ci, ci, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp]

@@ -484,10 +484,12 @@ class Wamintgr:
 
     # ---- the 1:1 step as one kernel (round 6): PROPAGS2 inside IMPLSCH's tile load (ecwam_hip_propags2_implsch)
     def fused_available(self) -> bool:
-        """The one-kernel step covers this model: a build exists (single precision, 36 x 36, common IMPLSCH builds) and the advection is the
-        plain one (IREFRA = 0, on-the-fly weights, no fast-wave sub-steps, natural row order, no obstructions)."""
+        """The one-kernel step covers this model: a build exists (36 x 36, common IMPLSCH builds) and the advection is IREFRA = 0 with
+        on-the-fly weights in the natural row order, without obstructions; fast-wave sub-steps run on compact rows (the last one inside the
+        kernel)."""
+        lf = 0 < self.ifrelfmax < self.cfg.nfre_red
         return (self.ctx.fused_supported() and not self.irefra and self.weights == "otf" and self.order is None
-                and not (0 < self.ifrelfmax < self.cfg.nfre_red))
+                and (not lf or (self.g1 is not None and self.fast_mode == "compact")))
 
     def step_fused(self, wam2nemo=None, flags: int = 0) -> None:
         """PROPAG_WAM + NEWWIND + IMPLSCH of one step (wamintgr.F90:94-146) with the advection done by the source-term kernel's tile load.
@@ -499,23 +501,54 @@ class Wamintgr:
                 raise api.EcwamHipError(f"CFL criterion violated at {nfail} points (ctuwdrv.F90:128-146)")
         self.newwind()
         c = self.cfg
+        lf = 0 < self.ifrelfmax < c.nfre_red
+        multi = self.dom.nranks > 1
+        ia, ib = self.interior if multi else (0, self.n)
+        ga = gb = None
+        kw = {}
+        if lf:
+            # the fast waves' sub-steps 1 .. NSTEP_LF-1 on compact rows (propag_wam.F90:285-313, as _propag_fast_compact); their last sub-step
+            # and the slow waves' step are the tile load of the source-term kernel, which also leaves the new fast waves in compact rows
+            lfm, dlf = self.ifrelfmax, float(self.delpro_lf)
+            nstep_lf = int(round(float(c.idelpro) / dlf))
+            lfp = int(self.g1.shape[2])
+            if not self.gfast_valid:
+                self.ctx.copy_freq_range(self.fl1, self.g1, self.n, 1, lfp)
+            ga, gb = self.g1, self.g2
+            for _ in range(nstep_lf - 1):
+                reqs = self.halo.start(ga) if multi else []
+                self.ctx.propags2_otf(ga, gb, self.gd, self.cgroup_ext, dlf, ia, ib, 1, lfm, copy_rest=True)
+                if multi:
+                    self._halo_finish_timed(reqs)
+                    for k0, k1 in ((0, ia), (ib, self.n)):
+                        if k1 > k0:
+                            self.ctx.propags2_otf(ga, gb, self.gd, self.cgroup_ext, dlf, k0, k1, 1, lfm, copy_rest=True)
+                ga, gb = gb, ga
+            kw = dict(ifrelfmax=lfm, delpro_lf=dlf, gin=ga)
+            self.ctx.set_fastwave_copy(gb)
 
         def rows(k0, k1):
             if k1 > k0:
                 self.ctx.propags2_implsch(self.fl1, self.fl3, self.gd, self.cgroup_ext, float(c.idelpro), k0, k1, self.wvprpt, self.ff, self.intf,
-                                          self.mij, self.xllws, 1, c.nfre_red, wam2nemo=wam2nemo, flags=flags)
+                                          self.mij, self.xllws, 1, c.nfre_red, wam2nemo=wam2nemo, flags=flags, **kw)
 
-        if self.dom.nranks > 1:
-            ia, ib = self.interior
-            reqs = self.halo.start(self.fl1)
-            rows(ia, ib)
-            self._halo_finish_timed(reqs)
-            rows(0, ia)
-            rows(ib, self.n)
-        else:
-            rows(0, self.n)
+        try:
+            if multi:
+                reqs = ([self.halo.start(ga)] if lf else []) + [self.halo.start(self.fl1)]      # the short rows first
+                rows(ia, ib)
+                for r in reqs:
+                    self._halo_finish_timed(r)
+                rows(0, ia)
+                rows(ib, self.n)
+            else:
+                rows(0, self.n)
+        finally:
+            if lf:
+                self.ctx.set_fastwave_copy(None)
         self.fl1, self.fl3 = self.fl3, self.fl1
-        self.gfast_valid = False
+        if lf:
+            self.g1, self.g2 = gb, ga
+        self.gfast_valid = lf
 
     def step(self, advect: bool = True, source: bool = True, llsource: bool = True, fused: bool = False) -> None:
         if fused and advect and source and llsource and self.fused_available():

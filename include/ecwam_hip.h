@@ -302,8 +302,13 @@ int ecwam_hip_implsch_reserve(ecwam_hip_ctx *ctx, int npts);
  * ecwam_hip_propags2_otf(f1 -> f3, copy_rest = 1) followed by ecwam_hip_implsch(f3) leaves in f3, FF, INTF, MIJ, XLLWS, WAM2NEMO.
  * The caller runs NEWWIND (ecwam_hip_newwind) BEFORE this call (it touches the forcing only) and swaps f1 / f3 after it, as after PROPAGS2.
  * Rows whose stencil reads halo rows are passed in a second call behind ecwam_hip_halo_finish, exactly as with ecwam_hip_propags2_otf.
+ * Fast waves (the native O1280 cycle, propag_wam.F90:247-313): ifrelfmax > 0 with gin = the compact rows [rows][NANG][gin_nfre] that hold the
+ * fast waves after their sub-steps 1 .. NSTEP_LF - 1 (ecwam_hip_propags2_otf_fast, compact -> compact): the call is then the LAST sub-step
+ * of the fast waves (time step delpro_lf, read from gin) together with the slow waves' step (delpro, read from f1) -- what
+ * ecwam_hip_propags2_otf_fast(f1 -> f3, gin) does -- and the source terms; with ecwam_hip_set_fastwave_copy the new fast waves also go to
+ * the compact rows the next advection step starts from.  Else ifrelfmax = 0, gin = NULL.
  * Covered: what ecwam_hip_propags2_implsch_supported reports (36 directions x 36 frequencies in either precision, the common builds of
- * IMPLSCH with IPHYS = 1 / ISNONLIN = 0, no obstructions, no fast-wave sub-steps); everything else runs the two calls.
+ * IMPLSCH with IPHYS = 1 / ISNONLIN = 0, no obstructions, no refraction); everything else runs the two calls.
  * flags: 0 (bit 0: workgroups in the XCD-aware order of the stencil kernel instead of the natural one; bit 1: the go / no-go probe of
  * diagnostics builds).
  */
@@ -311,8 +316,8 @@ int ecwam_hip_propags2_implsch_supported(ecwam_hip_ctx *ctx);
 int ecwam_hip_propags2_implsch(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n, int ngy, double delpro, const int *kxlt, const void *zdello,
                                double xdella, const void *cosph, const void *sinph, const int *klon, const int *klat, const int *kcor,
                                const void *wlat, const void *wcor, const void *cgroup_ext, const void *cosphm1_ext, int kijs, int kijl,
-                               int nd3s, int nd3e, const void *wvprpt, void *ff, void *intf, int *mij, void *xllws, double *wam2nemo, int flags,
-                               void *stream);
+                               int nd3s, int nd3e, const void *wvprpt, void *ff, void *intf, int *mij, void *xllws, double *wam2nemo,
+                               double delpro_lf, int ifrelfmax, const void *gin, int gin_nfre, int flags, void *stream);
 
 /*
  * Integrated output parameters without a spectrum copy-back (the device-side part of OUTBS: outblock.F90:204,223-243,

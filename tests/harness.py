@@ -123,38 +123,55 @@ def robust_max(x, frac: float = 0.002) -> float:
     x = np.sort(np.asarray(x, dtype=np.float64).ravel())
     if x.size == 0:
         return 0.0
-    k = max(1, int(np.ceil(frac * x.size)))
+    # 0.2 % of the points, at least one -- but none of a small sample (under 500 points 0.2 % is less than a point: its plain maximum meets
+    # the tight gate, or the test names its outlier)
+    k = int(np.ceil(frac * x.size)) if x.size >= 500 else 0
     return float(x[max(0, x.size - 1 - k)])
 
 
 # Single-precision gates of every comparison of an IMPLSCH result (dp has fixed gates at the call sites: 1e-10 and tighter, MIJ / XLLWS
-# identical).  Two tiers per quantity, by the source-term time step of the case (the error of the new spectrum grows with DELT: the
+# identical).  Three tiers per quantity, by the source-term time step of the case (the error of the new spectrum grows with DELT: the
 # increment DELT SL / (1 - DELT XIMP FLD) carries the rounding of SL):
-#   gate on robust_max -- every point but 0.2 % of them: the rounding bound.  Observed over the whole GPU suite on five sets of random
-#     inputs (seed offsets 0 ... 4000: profiles/r05_seed_robustness.txt): IDELT 450 s (the benchmark's step): the worst bin of a
-#     point 7.1e-7 of its peak, swh 2.5e-7, forcing 8.0e-6, fluxes 7.6e-5; IDELT 900 / 1200 s: 1.04e-5, 7.7e-7, 8.0e-6, 2.6e-4
-#   cap on the plain maximum -- the few points where a discrete decision (limiter, clip, an iteration's exit) falls the other way; which
-#     points those are depends on the sample: observed up to 2e-4 (bins), 9.4e-5 (swh), 5.9e-3 (fluxes), and in the forcing outputs 5.6e-3
-#     except the background roughness Z0B of the gravity-capillary model, 0.11 at one point in 1 100 (IPHYS 0 + LLGCBZ0, seed offset 1000)
-# "v2": k_implsch4 against the tests' second device implementation (tests/csrc), both in single precision.
+#   SP_GATES on robust_max -- every point but 0.2 % of them (every point of a sample under 500 points): the rounding bound.  Observed over the
+#     whole GPU suite on seven sets of random inputs (seed offsets 0 ... 4000 in round 5, profiles/r05_seed_robustness.txt; 0 and 1000 again on
+#     the round-6 kernels, profiles/r06_gates.txt): IDELT 450 s (the benchmark's step): the worst bin of a point 7.1e-7 of its peak, swh
+#     2.5e-7, forcing 1.8e-5 after two full steps (8.0e-6 after one), fluxes 7.6e-5; IDELT 900 / 1200 s: 1.04e-5, 7.7e-7, 8.0e-6, 2.6e-4
+#   SP_CAPS_CLEAN on the plain maximum over the points whose discrete outputs (MIJ, the XLLWS mask) equal the oracle's: the bins only (a
+#     limiter or an iteration's exit that falls the other way inside TAUT_Z0 / the flux integrals is not visible in those two outputs, so the
+#     forcing and flux maxima of "clean" points are those of all points): observed 9.6e-6 at 450 s, 4.0e-5 at 900 s
+#   SP_CAPS on the plain maximum over ALL points -- the few points where a discrete decision falls the other way; which points those are depends
+#     on the sample.  At most 10 x the observed maxima: 450 s: 4.6e-5 (bins), 2.8e-5 (swh), 3.5e-3 (forcing), 9.8e-3 (fluxes); 900 / 1200 s:
+#     2.1e-4, 9.4e-5, 5.6e-3, 5.9e-3.  ONE named exception: the roughness outputs (Z0M, Z0B, CHRNCK) of the gravity-capillary model under
+#     IPHYS 0 (test_implsch_parity_iphys_0[gcbz0_*]), 0.11 at one point in 1 100 on seed offset 1000 -- they alone then get Z0B_CAP_GCBZ0_JAN
+# "v2": k_implsch4 against the tests' second device implementation (tests/csrc), both in single precision (observed maxima on seed offsets 0
+#     and 1000: bins 7.7e-4, swh 4.4e-4, forcing 1.0e-3, fluxes 5.0e-3 at one point in 40 001 whose limiter falls the other way; 2.6e-5 over
+#     the points with equal MIJ / XLLWS).
 SP_GATES = {"short": dict(bins=2e-6, swh=1e-6, ff=2e-5, intf=2e-4), "long": dict(bins=3e-5, swh=2e-6, ff=2e-5, intf=1e-3),
             "v2": dict(bins=2e-5, swh=1e-6, ff=2e-5, intf=5e-4)}
-SP_CAPS = {"short": dict(bins=1e-4, swh=1e-4, ff=2e-2, intf=2e-2), "long": dict(bins=2e-3, swh=1e-3, ff=3e-1, intf=1e-1),
-           "v2": dict(bins=5e-3, swh=1e-3, ff=3e-1, intf=1e-1)}
+SP_CAPS = {"short": dict(bins=1e-4, swh=1e-4, ff=2e-2, intf=2e-2), "long": dict(bins=2e-3, swh=9e-4, ff=5e-2, intf=5e-2),
+           "v2": dict(bins=5e-3, swh=1e-3, ff=1e-2, intf=5e-2)}
+SP_CAPS_CLEAN = {"short": dict(bins=5e-5), "long": dict(bins=4e-4), "v2": dict(bins=3e-4)}
+Z0B_CAP_GCBZ0_JAN = 3e-1
 _ROB = dict(bins="fl1_rob_rel_peak", swh="swh_rob_rel", ff="ff_rob_rel", intf="intf_rob_rel")
-_MAX = dict(bins="fl1_max_rel_peak_all", swh="swh_max_rel", ff="ff_max_rel_all", intf="intf_max_rel_all")
+_MAX = dict(bins="fl1_max_rel_peak_all", swh="swh_max_rel", ff="ff_max_rel_all_but_z0", intf="intf_max_rel_all")
+_CLEAN = dict(bins="fl1_max_rel_peak_clean")
 
 
 def assert_sp_gates(st: dict, n: int, flip_budget: float = 0.005, what=("bins", "swh", "ff", "intf"), kind: str | None = None) -> None:
     """The single-precision gates above on the statistics of compare_implsch; discrete decisions (MIJ, XLLWS) may flip at flip_budget of
     the points (at least one)."""
     kind = kind or ("short" if 0 < st.get("idelt", 900) <= 450 else "long")
-    g, c = SP_GATES[kind], SP_CAPS[kind]
+    g, c, cc = SP_GATES[kind], SP_CAPS[kind], SP_CAPS_CLEAN[kind]
     budget = max(1, int(n * flip_budget))
     assert st["mij_flips"] <= budget and st["xllws_pts_diff"] <= budget, st
     for q in what:
         assert st[_ROB[q]] < g[q], (q, "all but 0.2 % of the points", st[_ROB[q]], g[q], st)
-        assert st[_MAX[q]] < c[q], (q, "every point", st[_MAX[q]], c[q], st)
+        assert st.get(_MAX[q], st.get("ff_max_rel_all", 0.0)) < c[q], (q, "every point", st.get(_MAX[q]), c[q], st)
+        if q in cc:
+            assert st[_CLEAN[q]] < cc[q], (q, "every point whose MIJ and XLLWS equal the oracle's", st[_CLEAN[q]], cc[q], st)
+        if q == "ff":      # the roughness outputs (Z0M, Z0B, CHRNCK) on their own: the forcing cap, or the named exception's
+            zcap = Z0B_CAP_GCBZ0_JAN if st.get("z0b_exception") else c[q]
+            assert st.get("ff_z0_max_rel", 0.0) < zcap, ("Z0M / Z0B / CHRNCK", st.get("ff_z0_max_rel"), zcap, st)
 
 
 def compare_implsch(ref: dict, got: dict, tables) -> dict:
@@ -165,6 +182,8 @@ def compare_implsch(ref: dict, got: dict, tables) -> dict:
     xl_same_pt = (ref["XLLWS"] == got["XLLWS"]).all(axis=(1, 2))
     st["n"] = n
     st["idelt"] = int(getattr(getattr(tables, "cfg", None), "idelt", 0) or 0)   # the gates of the single-precision tests depend on it
+    _cfg = getattr(tables, "cfg", None)
+    st["z0b_exception"] = bool(_cfg is not None and int(getattr(_cfg, "iphys", 1)) == 0 and bool(getattr(_cfg, "llgcbz0", False)))
     st["mij_flips"] = int((~mij_same).sum())
     st["xllws_bins_diff"] = int((ref["XLLWS"] != got["XLLWS"]).sum())
     st["xllws_pts_diff"] = int((~xl_same_pt).sum())
@@ -182,6 +201,11 @@ def compare_implsch(ref: dict, got: dict, tables) -> dict:
     # where EPSMIN / FLMIN-sized values differ by 1e-5 of themselves and 1e-15 of the peak
     sig = np.abs(ref["FL1"].astype(np.float64)) > 1e-6 * peak
     st["fl1_frac_sig_bins_gt_1e-5"] = float((ebin[sig] > 1e-5).mean()) if sig.any() else 0.0
+    # the north star's "1e-6 rel" read per bin: relative error of every bin above 1e-3 of its point's peak (the bins that make the wave height)
+    sig3 = np.abs(ref["FL1"].astype(np.float64)) > 1e-3 * peak
+    st["fl1_sigbin_rel_max"] = float(ebin[sig3].max()) if sig3.any() else 0.0
+    st["fl1_sigbin_rel_rob"] = robust_max(np.where(sig3, ebin, 0.0).max(axis=(1, 2)))
+    st["fl1_sigbin_rel_p999"] = float(np.quantile(ebin[sig3], 0.999)) if sig3.any() else 0.0
     dfim = np.asarray(tables.DFIM, dtype=np.float64)
     hs_r = 4 * np.sqrt((ref["FL1"].astype(np.float64).sum(1) * dfim).sum(1))
     hs_g = 4 * np.sqrt((got["FL1"].astype(np.float64).sum(1) * dfim).sum(1))
@@ -197,6 +221,11 @@ def compare_implsch(ref: dict, got: dict, tables) -> dict:
     st["ff_max_rel_all"] = float(err.max())
     st["ff_rob_rel"] = robust_max(err.max(1))
     st["ff_worst_col"] = int(FF_OUT[int(np.argmax(err.max(0)))])
+    # the roughness outputs Z0M, Z0B, CHRNCK on their own: the forcing outputs with a known outlier (gravity-capillary model under IPHYS 0)
+    iz = [FF_OUT.index(10), FF_OUT.index(11), FF_OUT.index(12)]
+    st["ff_max_rel_all_but_z0"] = float(np.delete(err, iz, axis=1).max())
+    st["ff_z0_max_rel"] = float(err[:, iz].max())
+    st["ff_col_max_rel"] = [float(x) for x in err.max(0)]      # UFRIC TAUW TAUWDIR Z0M Z0B CHRNCK
     # flux outputs: errors relative to the physical scale of each group (they are differences of nearly cancelling
     # integrals): Stokes drift and stresses as vectors, energy fluxes against |PHIEPS|+|PHIAW| (x XN for PHIOCD)
     ri, gi = ref["INTF"].astype(np.float64), got["INTF"].astype(np.float64)

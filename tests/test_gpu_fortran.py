@@ -122,12 +122,13 @@ def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec, lf, irefra, su
     _fortran_vs_python_host(tmp_path, prec, lf, irefra, subgrid, nosource)
 
 
-@pytest.mark.parametrize("prec,nosource", [("sp", False), ("dp", False), ("sp", True)])
-def test_fortran_one_kernel_step_matches_python_host_two_kernels(tmp_path, prec, nosource):
+@pytest.mark.parametrize("prec,nosource,lf", [("sp", False, 0), ("dp", False, 0), ("sp", True, 0), ("sp", False, 5), ("dp", False, 4)])
+def test_fortran_one_kernel_step_matches_python_host_two_kernels(tmp_path, prec, nosource, lf):
     """36 directions: WAMINTGR_HIP takes the one-kernel step (ecwam_hip_propags2_implsch: the exchange posted at propagation time, PROPAGS2
     inside IMPLSCH's tile load when the source terms are due), the Python host drives PROPAGS2 and IMPLSCH as two kernels -- the same bits.
-    With LLSOURCE = F the Fortran side must fall back to the separate advection."""
-    _fortran_vs_python_host(tmp_path, prec, 0, 0, False, nosource, nang=36, nfre_red=36, idelt=450)
+    With LLSOURCE = F the Fortran side must fall back to the separate advection.  lf > 0: fast-wave sub-steps on compact rows, the last one
+    inside the kernel."""
+    _fortran_vs_python_host(tmp_path, prec, lf, 0, False, nosource, nang=36, nfre_red=36, idelt=450)
 
 
 def _fortran_vs_python_host(tmp_path, prec, lf, irefra, subgrid, nosource, nang=12, nfre_red=25, idelt=900):
@@ -145,7 +146,7 @@ def _fortran_vs_python_host(tmp_path, prec, lf, irefra, subgrid, nosource, nang=
         build.build_fortran()
     cfg = Config(nang=nang, nfre=36, nfre_red=nfre_red, idelt=idelt, idelpro=idelt, irefra=irefra)
     g = G.build_grid(16, mask="continents")
-    m = Wamintgr(cfg, g, prec, ifrelfmax=lf, delpro_lf=450.0 if lf else None)    # lf: fast waves M <= lf in two sub-steps
+    m = Wamintgr(cfg, g, prec, ifrelfmax=lf, delpro_lf=idelt / 2.0 if lf else None)    # lf: fast waves M <= lf in two sub-steps
     m.init_synthetic(seed=21)
     m.llcflcuroff = irefra != 3     # refraction: ECWAM_HIP_SET_ENVIRONMENT on the Fortran side, with and without LLCFLCUROFF
     assert m.nrows == g.nsea + 1

@@ -71,6 +71,35 @@ def test_one_kernel_step_is_bit_identical_to_the_two_kernels(api, flags, nfre_re
     two.ctx.close(); one.ctx.close()
 
 
+@pytest.mark.parametrize("prec", ["sp", "dp"])
+@pytest.mark.parametrize("nfre_red,lfm", [(36, 5), (29, 4)])
+def test_one_kernel_step_with_fast_wave_sub_steps_is_bit_identical(api, prec, nfre_red, lfm):
+    """The native O1280 structure (propag_wam.F90:247-313): fast waves M <= IFRELFMAX in two sub-steps of half the time step on compact rows.
+    The one-kernel step runs the first sub-step as PROPAGS2 compact -> compact and takes the last one -- together with the slow waves' step --
+    into the tile load (ADV = 3: compact input rows, per-frequency time step), and leaves the new fast waves in the compact rows the next
+    step starts from; three steps, so that the compact rows are handed from step to step.  IFRELFMAX = 5 cuts a 16-byte vector."""
+    from ecwam_amd import grid as G
+
+    cfg = Config(nang=36, nfre=36, nfre_red=nfre_red, idelt=450, idelpro=450)
+    g = G.build_grid(20, mask="continents")
+    two, one = _pair(cfg, g, seed=33, prec=prec, ifrelfmax=lfm, delpro_lf=225.0)
+    assert one.fused_available()
+    assert two.build_weights() == 0 and one.build_weights() == 0
+    for _ in range(3):
+        two.step()
+        one.step(fused=True)
+        torch.cuda.synchronize()
+        _same_state(two, one)
+        assert one.gfast_valid and torch.equal(one.g1[: one.n], two.g1[: two.n])
+    # two advection steps per source step (the O1280 cycle): PROPAG_WAM, then the one-kernel step
+    for m, fused in ((two, False), (one, True)):
+        m.propag()
+        m.step(fused=fused)
+    torch.cuda.synchronize()
+    _same_state(two, one)
+    two.ctx.close(); one.ctx.close()
+
+
 def test_one_kernel_step_natural_order_and_row_blocks(api):
     """The workgroups in the XCD-aware order (flags bit 0) and the rows passed in three unequal blocks give the same bits as one call."""
     from ecwam_amd import grid as G

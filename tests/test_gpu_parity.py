@@ -113,8 +113,9 @@ def test_implsch_parity_at_the_benchmark_time_step(api, prec, flags, seed):
           f"{st['fl1_max_rel_peak_all']:.2e}; bins above 1e-3 of the peak relative to THEMSELVES: 99.9 % of them {st['fl1_sigbin_rel_p999']:.2e}, all but 0.2 % "
           f"of the points {st['fl1_sigbin_rel_rob']:.2e}, every bin {st['fl1_sigbin_rel_max']:.2e}; swh {st['swh_rob_rel']:.2e} / {st['swh_max_rel']:.2e}")
     _assert_implsch_stats(st, n, prec)
-    if prec == "sp":      # per bin, relative to the bin: a bin at 1e-3 of the peak costs three digits of the peak-relative bound
-        assert st["fl1_sigbin_rel_p999"] < 1e-3 and st["fl1_sigbin_rel_rob"] < 1e-2, st
+    if prec == "sp":      # per bin, relative to the bin itself (a bin at 1e-3 of the peak costs three digits of the peak-relative bound): observed
+        # on both seeds and flag sets 99.9 % of the bins 4.2e-6, all but 0.2 % of the points 1.3e-5, every bin 2.3e-5
+        assert st["fl1_sigbin_rel_p999"] < 2e-5 and st["fl1_sigbin_rel_rob"] < 1e-4 and st["fl1_sigbin_rel_max"] < 1e-3, st
     else:
         assert st["fl1_sigbin_rel_max"] < 1e-9, st
 

@@ -251,6 +251,63 @@ __device__ __forceinline__ void ctu_fast_dir(T tanph, T sp2, T sm2, T& ab2, T& p
   p2 = m_max(-tsp2, T(0));
   m2 = m_max(tsm2, T(0));
 }
+// The weights with refraction (IREFRA = 1, 2, 3; ctuw.F90:146-275, 403-527) for the lanes whose advection velocity keeps the sign of the group
+// velocity (no upwind switch: the downwind weights are zero), in the hoisted form of ctu_fast_w8.  xa .. yb as there; su, sva, svb: the current's
+// contribution to ADXP / ADYP with the sign of the group velocity component, (U COSPHM1) DELPRO CMTODEG SIGN(SINTH) and
+// (V (1 + DP(IC)) / 2) DELPRO CMTODEG SIGN(COSTH) for the two neighbours in the direction's order (zero without currents); dthp, dthm: the
+// complete theta-dot sums, fdp, fdm: those of the frequency shift (zero without currents).  neg: a component came out negative -- the
+// current turns the advection velocity round: the caller takes the general path for this lane.
+template <typename T>
+struct CtuFastGenW {
+  CtuV2<T> sumwn, wlon, wlat1, wlat2, wcor1, wcor2, wkm, wkp, wmm, wmp;
+};
+template <typename T>
+__device__ __forceinline__ CtuV2<T> ctu_v2max0(CtuV2<T> a) { return CtuV2<T>{m_max(a.x, T(0)), m_max(a.y, T(0))}; }
+template <typename T>
+__device__ __forceinline__ CtuFastGenW<T> ctu_fast_wgen(CtuV2<T> xa, CtuV2<T> xb, CtuV2<T> ya, CtuV2<T> yb, T asink, T acosk, T su, T sva, T svb, T zd,
+                                                        T xdella, T ga, T zdg, T xdg, T wl, T omwl, T wc, T omwc, CtuV2<T> dthp, CtuV2<T> dthm,
+                                                        CtuV2<T> fdp, CtuV2<T> fdm, T fratio, T rfratio, bool& neg) {
+#pragma clang fp contract(off)
+  typedef CtuV2<T> F;
+  const F adx_a = ctu_v2fma<T>(xa, F{asink, asink}, F{su, su}), adx_b = ctu_v2fma<T>(xb, F{asink, asink}, F{su, su});
+  const F ady_a = ctu_v2fma<T>(ya, F{acosk, acosk}, F{sva, sva}), ady_b = ctu_v2fma<T>(yb, F{acosk, acosk}, F{svb, svb});
+  const F lo = {m_min(m_min(adx_a.x, adx_b.x), m_min(ady_a.x, ady_b.x)), m_min(m_min(adx_a.y, adx_b.y), m_min(ady_a.y, ady_b.y))};
+  neg = lo.x < T(0) || lo.y < T(0);
+  const F dxx = zd - adx_b, dyy = xdella - ady_b;
+  const F yag = ady_a * ga, xag = adx_a * ga, xbg = adx_b * ga;
+  const F wgt_lat = dxx * yag;
+  const F wgt_cor = adx_a * yag;
+  CtuFastGenW<T> w;
+  w.wlon = dyy * xag;
+  // WKPMN(0) + WMPMN(0): (x + |x|) + (|y| - y) = 2 MAX(x, 0) + 2 MAX(-y, 0)
+  const F two = {T(2), T(2)};
+  F sumwn = two * (ctu_v2max0<T>(dthp) + ctu_v2max0<T>(-dthm)) + two * (ctu_v2max0<T>(fdp) + ctu_v2max0<T>(-fdm));
+  sumwn = ctu_v2fma<T>(F{zdg, zdg}, ady_b, sumwn);
+  sumwn = ctu_v2fma<T>(F{xdg, xdg}, adx_b, sumwn);
+  w.sumwn = ctu_v2fma<T>(-xbg, ady_b, sumwn);
+  w.wlat1 = wl * wgt_lat; w.wlat2 = omwl * wgt_lat;
+  w.wcor1 = wc * wgt_cor; w.wcor2 = omwc * wgt_cor;
+  w.wkm = two * ctu_v2max0<T>(dthm); w.wkp = two * ctu_v2max0<T>(-dthp);
+  w.wmm = (two * ctu_v2max0<T>(fdm)) * fratio; w.wmp = (two * ctu_v2max0<T>(-fdp)) * rfratio;
+  return w;
+}
+// propags2.F90:127-192 for such a lane: own, the five upwind space neighbours, the direction and frequency neighbours of the own spectrum
+template <typename T>
+__device__ __forceinline__ CtuV2<T> ctu_fast_apply_gen(const CtuFastGenW<T>& w, CtuV2<T> f0, CtuV2<T> flon, CtuV2<T> fla1, CtuV2<T> fla2, CtuV2<T> fco1,
+                                                       CtuV2<T> fco2, CtuV2<T> fkm, CtuV2<T> fkp, CtuV2<T> fmm, CtuV2<T> fmp) {
+#pragma clang fp contract(off)
+  CtuV2<T> r = ctu_v2fma<T>(-w.sumwn, f0, f0);
+  r = ctu_v2fma<T>(w.wlon, flon, r);
+  r = ctu_v2fma<T>(w.wlat1, fla1, r);
+  r = ctu_v2fma<T>(w.wcor1, fco1, r);
+  r = ctu_v2fma<T>(w.wlat2, fla2, r);
+  r = ctu_v2fma<T>(w.wcor2, fco2, r);
+  r = ctu_v2fma<T>(w.wkm, fkm, r);
+  r = ctu_v2fma<T>(w.wmm, fmm, r);
+  r = ctu_v2fma<T>(w.wkp, fkp, r);
+  r = ctu_v2fma<T>(w.wmp, fmp, r);
+  return r;
+}
 // per-point scalars of the weights (ctuw.F90:146-170, 407-420)
 template <typename T>
 struct CtuPoint {

@@ -689,7 +689,12 @@ __device__ __forceinline__ bool ctu_wgen(const CtuBase<T>& b, T sink, T cosk, co
 // only when its weight is zero at every point: adding a zero product changes nothing).
 // theta-dot (ctuw.F90:424-452, 471-493) and sigma-dot (ctuw.F90:506-520) sums are formed per thread from the REFR row.
 #define GEN_TP 16
-template <typename T, int VW, bool CHECK, bool OBS>
+// MODE (the stencil without obstructions, product build of the weights): 0 = every lane in one kernel; 1 = the hoisted form ONLY -- a lane whose
+// advection velocity turns against the group velocity writes nothing and raises its point's flag in `flips` (no general weights: half the
+// registers, twice the resident waves, 16-byte accesses); 2 = the whole kernel again on the tiles that hold a flagged point (the lanes without
+// an upwind switch repeat the arithmetic of mode 1: the same bits).  Launched as 1 then 2: with currents below the group velocities
+// everywhere the second launch reads one flag per point and ends.
+template <typename T, int VW, bool CHECK, bool OBS, int MODE = 0>
 __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restrict__ tab, int IREFRA, const T* __restrict__ f1,
                                                       T* __restrict__ f3, int ngy, T delpro, const int* __restrict__ kxlt,
                                                       const T* __restrict__ zdello, T xdella, const T* __restrict__ cosph,
@@ -699,8 +704,9 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
                                                       const T* __restrict__ cg, const T* __restrict__ om, const T* __restrict__ wn,
                                                       const T* __restrict__ cosphm1, const T* __restrict__ refr,
                                                       int* __restrict__ cflfail, int slot, int kijs, int kijl, int m0, int m1,
-                                                      int copy_rest, int ntiles, const T* __restrict__ obs) {
+                                                      int copy_rest, int ntiles, const T* __restrict__ obs, int* __restrict__ flips) {
   extern __shared__ __align__(16) unsigned char gen_smem[];
+  static_assert(MODE == 0 || (!CHECK && !OBS), "modes 1 / 2 belong to the plain stencil");
   const int NANG = tab->NANG, NFRE = tab->NFRE, NR = tab->NFRE_RED;
   const int N = NANG * NFRE, RW = REFR_W(NANG), NV = N / VW, FV = NFRE / VW;
   const T CMTODEG = T(360.0) / tab->CIRC;
@@ -720,7 +726,9 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
   T* sDF = sK + 2 * NANG;                                           // [2][NFRE]: DELFR0/FR(M), DELFR0/FR(MAX(1,M-1))
   T* sT = sDF + 2 * NFRE;                                           // [NANG][2]: SINTH, COSTH
   int* sD = reinterpret_cast<int*>(sT + 2 * NANG);                  // [NANG][12]: JXO(K,1:2), JYO(K,1:2), KPM(K,-1), KPM(K,1), -, -, KCR(K,1:4)
-  T* sO = reinterpret_cast<T*>(sD + 12 * NANG);                     // OBS: [TP][8][NFRE] transmission coefficients (LSUBGRID)
+  T* sQ = reinterpret_cast<T*>(sD + 12 * NANG);                     // [TP][12]: ZDELLO GA, XDELLA GA, 1 - WLAT(1:2), 1 - WCOR(1:4), the current's U / V terms of ADXP / ADYP(1:2)
+  T* sBF = sQ + 12 * GEN_TP;                                        // [TP][4][NFRE]: the hoisted planes of the weights (ctu_fast_planes)
+  T* sO = sBF + (size_t)GEN_TP * 4 * NFRE;                          // OBS: [TP][8][NFRE] transmission coefficients (LSUBGRID)
   for (int k = threadIdx.x; k < NANG; k += blockDim.x) {            // per-direction tables: LDS instead of global loads in the stencil loop
     T a, b;
     ctu_dirfac(tab, k, DELTH0, T(1), a, b);
@@ -739,10 +747,26 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int p0 = kijs + tile * GEN_TP;
     const int np = min(GEN_TP, kijl - p0);
+    if constexpr (MODE == 2) {      // only the tiles with a flagged point
+      if (!__syncthreads_or(((int)threadIdx.x < np) ? flips[p0 + threadIdx.x] : 0)) continue;
+    }
     __syncthreads();
     if (threadIdx.x < np) {
       const int t = threadIdx.x, ij = p0 + t;
-      sP[t] = ctu_point(ij, ngy, kxlt, zdello, xdella, cosph, sinph, wlat, wcor, cosphm1);
+      const CtuPoint<T> cp = ctu_point(ij, ngy, kxlt, zdello, xdella, cosph, sinph, wlat, wcor, cosphm1);
+      sP[t] = cp;
+      {
+#pragma clang fp contract(off)
+        T* e = sQ + 12 * t;
+        const T dc = delpro * CMTODEG;
+        const T* rr = refr + (size_t)ij * RW;
+        e[0] = cp.zd * cp.ga; e[1] = xdella * cp.ga; e[2] = T(1) - cp.wl[0]; e[3] = T(1) - cp.wl[1];
+        for (int i = 0; i < 4; i++) e[4 + i] = T(1) - cp.wc[i];
+        e[8] = cur ? (rr[REFR_U(NANG)] * cp.cpm1) * dc : T(0);
+        e[9] = cur ? (rr[REFR_V(NANG)] * T(0.5) * (T(1) + cp.dp[0])) * dc : T(0);
+        e[10] = cur ? (rr[REFR_V(NANG)] * T(0.5) * (T(1) + cp.dp[1])) * dc : T(0);
+        e[11] = T(0);
+      }
       int* q = sI + t * 16;
       q[0] = ij;
       q[1] = klon[ij * 2 + 0]; q[2] = klon[ij * 2 + 1];
@@ -765,6 +789,10 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
       o[0] = b.h[0]; o[NFRE] = b.h[1]; o[2 * NFRE] = b.hy[0]; o[3 * NFRE] = b.hy[1]; o[4 * NFRE] = b.cg0;
       o[5 * NFRE] = om[(size_t)q[0] * NFRE + m];
       o[6 * NFRE] = wn[(size_t)q[0] * NFRE + m];
+      {
+        T* of = sBF + (size_t)t * 4 * NFRE + m;
+        ctu_fast_planes<T>(b, m_abs(sP[t].cpm1), delpro * CMTODEG, of, of + NFRE, of + 2 * NFRE, of + 3 * NFRE);
+      }
       if (OBS) {
 #pragma unroll
         for (int i = 0; i < 8; i++) sO[((size_t)t * 8 + i) * NFRE + m] = obs[((size_t)q[0] * 8 + i) * NFRE + m];
@@ -833,28 +861,102 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
             if (m + c >= NR) sd[c + 1] = sd[NR - m];
         }
       }
+      T dthp_[VW], dthm_[VW], fdp_[VW], fdm_[VW];
+#pragma unroll
+      for (int c = 0; c < VW; c++) {
+#pragma clang fp contract(off)
+        fdp_[c] = fdm_[c] = T(0);
+        if (IREFRA == 0) {
+          dthp_[c] = drgp * bc0[c] + drcp;
+          dthm_[c] = drgm * bc0[c] + drcm;
+        } else {
+          dthp_[c] = drgp * bc0[c] + bom[c] * drdp + drcp;
+          dthm_[c] = drgm * bc0[c] + bom[c] * drdm + drcm;
+        }
+        if (cur) {
+          const int mc = m + c;
+          fdp_[c] = mask * (sd[c + 1] + (mc + 1 < NR ? sd[c + 2] : sd[c + 1])) * sDF[mc];
+          fdm_[c] = mask * (sd[c + 1] + sd[c]) * sDF[NFRE + mc];
+        }
+      }
+#if !ECWAM_HIP_CTU_STRICT
+      if constexpr (!CHECK && !OBS) {
+        // The lanes whose advection velocity keeps the sign of the group velocity (all of them unless the current exceeds it somewhere): the
+        // upwind weights in the hoisted form (ctu.h: ctu_fast_wgen), two frequencies per packed operand.  Decided per LANE from the lane's own
+        // numbers, so that a point's arithmetic does not depend on which points share its wavefront (decompositions stay bit-identical).
+        typedef CtuV2<T> F;
+        const T* bf = sBF + (size_t)t * 4 * NFRE + m;
+        T xa[VW], xb[VW], ya[VW], yb[VW];
+        IO::ld(bf + jx0 * NFRE, xa); IO::ld(bf + (1 - jx0) * NFRE, xb); IO::ld(bf + (2 + jy0) * NFRE, ya); IO::ld(bf + (3 - jy0) * NFRE, yb);
+        const T* e = sQ + 12 * t;
+        const T su = sink < T(0) ? -e[8] : e[8];
+        const T sva = cosk < T(0) ? -e[9 + jy0] : e[9 + jy0], svb = cosk < T(0) ? -e[10 - jy0] : e[10 - jy0];
+        const T rfr = T(1) / FRATIO;
+        CtuFastGenW<T> fw[(VW + 1) / 2];
+        bool neg = false;
+        constexpr int c1 = VW > 1 ? 1 : 0;
+#pragma unroll
+        for (int c = 0; c < VW; c += 2) {
+#define P2(a) F{a[c], a[c + c1]}
+          bool n_;
+          fw[c / 2] = ctu_fast_wgen<T>(P2(xa), P2(xb), P2(ya), P2(yb), m_abs(sink), m_abs(cosk), su, sva, svb, p.zd, xdella, p.ga, e[0], e[1], p.wl[jy0],
+                                       e[2 + jy0], p.wc[kc[0]], e[4 + kc[0]], P2(dthp_), P2(dthm_), P2(fdp_), P2(fdm_), FRATIO, rfr, n_);
+          neg |= n_;
+        }
+        if (!neg) {
+          const T* fo = f1 + own;
+          T fown[VW], flon[VW], fla1[VW], fla2[VW], fco1[VW], fco2[VW], fkm[VW], fkp[VW], fmm[VW], fmp[VW], r[VW];
+          IO::ld(fo + el, fown);
+          IO::ld(f1 + (size_t)q[1 + jx0] * N + el, flon);
+          IO::ld(f1 + (size_t)q[3 + 2 * jy0] * N + el, fla1);
+          IO::ld(f1 + (size_t)q[4 + 2 * jy0] * N + el, fla2);
+          IO::ld(f1 + (size_t)q[7 + 2 * kc[0]] * N + el, fco1);
+          IO::ld(f1 + (size_t)q[8 + 2 * kc[0]] * N + el, fco2);
+          IO::ld(fo + km * NFRE + m, fkm);
+          IO::ld(fo + kp * NFRE + m, fkp);
+          if (cur) {      // the frequency neighbours of the own spectrum, MPM clamps of ctuwupdt.F90:96-100
+            const T flo = fo[k * NFRE + (m > 0 ? m - 1 : 0)];
+            const int mh = m + VW < NR ? m + VW : NR - 1;
+            const T fhi = fo[k * NFRE + mh];
+#pragma unroll
+            for (int c = 0; c < VW; c++) {
+              fmm[c] = (c == 0) ? flo : fown[c - 1];
+              fmp[c] = (c == VW - 1) ? fhi : fown[c + 1];
+              if (m + c + 1 > NR - 1) fmp[c] = fown[c];
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < VW; c++) fmm[c] = fmp[c] = T(0);
+          }
+#pragma unroll
+          for (int c = 0; c < VW; c += 2) {
+            const F rr2 = ctu_fast_apply_gen<T>(fw[c / 2], P2(fown), P2(flon), P2(fla1), P2(fla2), P2(fco1), P2(fco2), P2(fkm), P2(fkp), P2(fmm), P2(fmp));
+#undef P2
+            r[c] = rr2.x;
+            if (VW > 1) r[c + c1] = rr2.y;
+          }
+          if (m + VW > m1) {
+#pragma unroll
+            for (int c = 0; c < VW; c++)
+              if (m + c >= m1) r[c] = (copy_rest & 1) ? fown[c] : f3[own + el + c];
+          }
+          IO::st_stream(f3 + own + el, r);
+          continue;
+        }
+        if constexpr (MODE == 1) {      // an upwind switch in this lane: the point goes to the second launch
+          flips[q[0]] = 1;
+          continue;
+        }
+      }
+#endif
+      if constexpr (MODE == 1) continue;
       CtuGenW<T> w[VW];
       bool fail = false, flipped = false;
 #pragma unroll
       for (int c = 0; c < VW; c++) {
         CtuBase<T> b;
         b.h[0] = bh0[c]; b.h[1] = bh1[c]; b.hy[0] = by0[c]; b.hy[1] = by1[c]; b.cg0 = bc0[c];
-        T dthp, dthm, fdp = T(0), fdm = T(0);
-        {
-#pragma clang fp contract(off)
-          if (IREFRA == 0) {
-            dthp = drgp * b.cg0 + drcp;
-            dthm = drgm * b.cg0 + drcm;
-          } else {
-            dthp = drgp * b.cg0 + bom[c] * drdp + drcp;
-            dthm = drgm * b.cg0 + bom[c] * drdm + drcm;
-          }
-          if (cur) {
-            const int mc = m + c;
-            fdp = mask * (sd[c + 1] + (mc + 1 < NR ? sd[c + 2] : sd[c + 1])) * sDF[mc];
-            fdm = mask * (sd[c + 1] + sd[c]) * sDF[NFRE + mc];
-          }
-        }
+        const T dthp = dthp_[c], dthm = dthm_[c], fdp = fdp_[c], fdm = fdm_[c];
         {
           bool fl_;
           const bool f_ = ctu_wgen<T, CHECK>(b, sink, cosk, p, xdella, delpro, CMTODEG, jx0, jx1, jy0, jy1, kc, cur, u, v, dthp, dthm, fdp, fdm, FRATIO, w[c], fl_);
@@ -1213,20 +1315,20 @@ void launch_propags2_gen(const void* tab, int irefra, const void* f1, void* f3, 
                          const void* zdello, double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat,
                          const int* kcor, const void* wlat, const void* wcor, const void* cg, const void* om, const void* wn,
                          const void* cosphm1, const void* refr, int* cflfail, int slot, int kijs, int kijl, int m0, int m1,
-                         int copy_rest, int dims, const void* obs, hipStream_t s) {
+                         int copy_rest, int dims, const void* obs, int* flips, hipStream_t s) {
   const int NANG = dims >> 16, NFRE = (dims >> 8) & 0xFF, NR = dims & 0xFF;
   const int n = kijl - kijs;
   if (n <= 0) return;
   const int ntiles = (n + GEN_TP - 1) / GEN_TP;
   const size_t shmem = GEN_TP * (sizeof(CtuPoint<T>) + 16 * sizeof(int)) +
-                       ((size_t)GEN_TP * (obs && f1 ? 15 : 7) * NFRE + (size_t)GEN_TP * REFR_W(NANG) + 4 * NANG + 2 * NFRE) * sizeof(T) + 12 * NANG * sizeof(int) + 16;
+                       ((size_t)GEN_TP * (obs && f1 ? 19 : 11) * NFRE + (size_t)GEN_TP * (REFR_W(NANG) + 12) + 4 * NANG + 2 * NFRE) * sizeof(T) + 12 * NANG * sizeof(int) + 16;
   const int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
   constexpr int W = VecOf<T>::W;
   const bool aligned = ((uintptr_t)f1 % 16 == 0) && ((uintptr_t)f3 % 16 == 0);
 #define GEN_ARGS                                                                                                               \
   (const DevTab<T>*)tab, irefra, (const T*)f1, (T*)f3, ngy, (T)delpro, kxlt, (const T*)zdello, (T)xdella, (const T*)cosph,       \
       (const T*)sinph, klon, klat, kcor, (const T*)wlat, (const T*)wcor, (const T*)cg, (const T*)om, (const T*)wn,             \
-      (const T*)cosphm1, (const T*)refr, cflfail, slot, kijs, kijl, m0, m1, copy_rest, ntiles, (const T*)obs
+      (const T*)cosphm1, (const T*)refr, cflfail, slot, kijs, kijl, m0, m1, copy_rest, ntiles, (const T*)obs, flips
   // 8 bytes per lane is the fastest width here (measured at O320 sp: 7.9 ms, against 9.2 ms at 16 bytes and 9.0 ms scalar):
   // the VW sets of 21 weights a thread keeps live cost more occupancy than the wider accesses save
   int vw = 2;
@@ -1240,7 +1342,18 @@ void launch_propags2_gen(const void* tab, int irefra, const void* f1, void* f3, 
   else if (obs) {
     if (v2) { allow_lds(k_propags2_gen<T, 2, false, true>, shmem); hipLaunchKernelGGL((k_propags2_gen<T, 2, false, true>), dim3(grid), dim3(256), shmem, s, GEN_ARGS); }
     else { allow_lds(k_propags2_gen<T, 1, false, true>, shmem); hipLaunchKernelGGL((k_propags2_gen<T, 1, false, true>), dim3(grid), dim3(256), shmem, s, GEN_ARGS); }
-  } else if (v4)
+  }
+#if !ECWAM_HIP_CTU_STRICT
+  else if (flips && aligned && NFRE % W == 0 && NR % W == 0 && m0 % W == 0 && m1 % W == 0) {
+    // two launches: the hoisted form on every lane (16-byte accesses), then the whole kernel on the tiles with an upwind switch
+    (void)hipMemsetAsync(flips + kijs, 0, sizeof(int) * (size_t)n, s);
+    allow_lds(k_propags2_gen<T, W, false, false, 1>, shmem);
+    hipLaunchKernelGGL((k_propags2_gen<T, W, false, false, 1>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
+    allow_lds(k_propags2_gen<T, 2, false, false, 2>, shmem);
+    hipLaunchKernelGGL((k_propags2_gen<T, 2, false, false, 2>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
+  }
+#endif
+  else if (v4)
     { allow_lds(k_propags2_gen<T, W, false, false>, shmem); hipLaunchKernelGGL((k_propags2_gen<T, W, false, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS); }
   else if (v2)
     { allow_lds(k_propags2_gen<T, 2, false, false>, shmem); hipLaunchKernelGGL((k_propags2_gen<T, 2, false, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS); }
@@ -1374,7 +1487,7 @@ void launch_proenv_unpack(int nrows, int NFRE, const void* buf, const void* land
   template void launch_propags2_gen<T>(const void*, int, const void*, void*, int, double, const int*, const void*, double,        \
                                        const void*, const void*, const int*, const int*, const int*, const void*, const void*,   \
                                        const void*, const void*, const void*, const void*, const void*, int*, int, int, int, int, \
-                                       int, int, int, const void*, hipStream_t);                                                                    \
+                                       int, int, int, const void*, int*, hipStream_t);                                                              \
   template void launch_propags2_otf<T>(const void*, const void*, void*, int, int, double, const int*, const void*, double,        \
                                        const void*, const void*, const int*, const int*, const int*, const void*, const void*,   \
                                        const void*, const void*, const int*, int, int, int, int, int, int, const void*, int, double,   \

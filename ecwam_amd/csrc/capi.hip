@@ -62,8 +62,6 @@ struct ecwam_hip_ctx {
   void* fast_g = nullptr;     // ecwam_hip_set_fastwave_copy: compact rows [ij][K][fast_gk] IMPLSCH / NOSOURCE also leave the new fast waves in
   int fast_gk = 0;
   // one-kernel step (ecwam_hip_propags2_implsch): per-point and per-direction scalars of the CTU weights (propag.hip::k_ctu_prep)
-  int* gen_flips = nullptr;   // refraction stencil: one flag per point whose lanes need the general weights (upwind switch); grown on demand
-  size_t gen_flips_bytes = 0;
   std::string implsch_why;    // non-empty: no build of k_implsch4 covers the configuration (ecwam_hip_implsch refuses with this text)
   void* adv_pt = nullptr;     // [npts][12]
   size_t adv_pt_bytes = 0;
@@ -78,7 +76,7 @@ template <typename T> void launch_ctuw(const void*, int, int, int, double, int, 
 template <typename T> void launch_ctuwini_only(int, int, const int*, const int*, void*, void*, hipStream_t);
 template <typename T> void launch_propdot(const void*, int, int, int, const int*, const void*, double, const void*, const int*, const int*, const void*, const void*, const void*, const void*, const void*, void*, hipStream_t);
 template <typename T> void launch_curmask(int, int, int, const int*, void*, hipStream_t);
-template <typename T> void launch_propags2_gen(const void*, int, const void*, void*, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const void*, const void*, const void*, int*, int, int, int, int, int, int, int, const void*, int*, hipStream_t);
+template <typename T> void launch_propags2_gen(const void*, int, const void*, void*, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const void*, const void*, const void*, int*, int, int, int, int, int, int, int, const void*, hipStream_t);
 template <typename T> void launch_propags2_otf(const void*, const void*, void*, int, int, double, const int*, const void*, double, const void*, const void*, const int*, const int*, const int*, const void*, const void*, const void*, const void*, const int*, int, int, int, int, int, int, const void*, int, double, int, void*, int, const void*, int, int, hipStream_t);
 template <typename T> void launch_copy_freq_range(const void*, void*, int, int, int, int, int, int, hipStream_t);
 template <typename T> int launch_outbs(const void*, int, int, const void*, double, void*, int, int, hipStream_t);
@@ -510,7 +508,6 @@ int ecwam_hip_destroy(ecwam_hip_ctx* c) {
   if (c->wi) (void)hipFree(c->wi);
   if (c->adv_pt) (void)hipFree(c->adv_pt);
   if (c->adv_dir) (void)hipFree(c->adv_dir);
-  if (c->gen_flips) (void)hipFree(c->gen_flips);
   halo_release(c);
   delete c;
   return 0;
@@ -658,20 +655,8 @@ static int propags2_gen_launch(ecwam_hip_ctx* c, const char* who, const void* f1
                       !wavnum_ext || !cosphm1_ext || !refr))
     return fail((std::string(who) + ": null pointer").c_str());
   const int N = (c->NANG << 16) | (c->NFRE << 8) | c->NFRE_RED;
-  // the stencil (f1 given) runs as two launches that hand the points with an upwind switch over in one flag per point (propag.hip: MODE 1 / 2)
-  int* flips = nullptr;
-  if (f1 && !c->obs && kijl > kijs) {
-    const size_t need = sizeof(int) * (size_t)kijl;
-    if (need > c->gen_flips_bytes) {
-      if (c->gen_flips) HIPCHK(hipFree(c->gen_flips));
-      c->gen_flips = nullptr; c->gen_flips_bytes = 0;
-      HIPCHK(hipMalloc(&c->gen_flips, need));
-      c->gen_flips_bytes = need;
-    }
-    flips = c->gen_flips;
-  }
-  DISPATCH(launch_propags2_gen<float>(c->dtab, c->p.irefra, f1, f3, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, omosnh2kd_ext, wavnum_ext, cosphm1_ext, refr, cflfail, slot, kijs, kijl, m0, m1, copy_rest, N, c->obs, flips, s),
-           launch_propags2_gen<double>(c->dtab, c->p.irefra, f1, f3, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, omosnh2kd_ext, wavnum_ext, cosphm1_ext, refr, cflfail, slot, kijs, kijl, m0, m1, copy_rest, N, c->obs, flips, s));
+  DISPATCH(launch_propags2_gen<float>(c->dtab, c->p.irefra, f1, f3, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, omosnh2kd_ext, wavnum_ext, cosphm1_ext, refr, cflfail, slot, kijs, kijl, m0, m1, copy_rest, N, c->obs, s),
+           launch_propags2_gen<double>(c->dtab, c->p.irefra, f1, f3, ngy, delpro, kxlt, zdello, xdella, cosph, sinph, klon, klat, kcor, wlat, wcor, cgroup_ext, omosnh2kd_ext, wavnum_ext, cosphm1_ext, refr, cflfail, slot, kijs, kijl, m0, m1, copy_rest, N, c->obs, s));
   HIPCHK(hipGetLastError());
   return 0;
 }

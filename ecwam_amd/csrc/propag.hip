@@ -689,12 +689,7 @@ __device__ __forceinline__ bool ctu_wgen(const CtuBase<T>& b, T sink, T cosk, co
 // only when its weight is zero at every point: adding a zero product changes nothing).
 // theta-dot (ctuw.F90:424-452, 471-493) and sigma-dot (ctuw.F90:506-520) sums are formed per thread from the REFR row.
 #define GEN_TP 16
-// MODE (the stencil without obstructions, product build of the weights): 0 = every lane in one kernel; 1 = the hoisted form ONLY -- a lane whose
-// advection velocity turns against the group velocity writes nothing and raises its point's flag in `flips` (no general weights: half the
-// registers, twice the resident waves, 16-byte accesses); 2 = the whole kernel again on the tiles that hold a flagged point (the lanes without
-// an upwind switch repeat the arithmetic of mode 1: the same bits).  Launched as 1 then 2: with currents below the group velocities
-// everywhere the second launch reads one flag per point and ends.
-template <typename T, int VW, bool CHECK, bool OBS, int MODE = 0>
+template <typename T, int VW, bool CHECK, bool OBS>
 __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restrict__ tab, int IREFRA, const T* __restrict__ f1,
                                                       T* __restrict__ f3, int ngy, T delpro, const int* __restrict__ kxlt,
                                                       const T* __restrict__ zdello, T xdella, const T* __restrict__ cosph,
@@ -704,9 +699,8 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
                                                       const T* __restrict__ cg, const T* __restrict__ om, const T* __restrict__ wn,
                                                       const T* __restrict__ cosphm1, const T* __restrict__ refr,
                                                       int* __restrict__ cflfail, int slot, int kijs, int kijl, int m0, int m1,
-                                                      int copy_rest, int ntiles, const T* __restrict__ obs, int* __restrict__ flips) {
+                                                      int copy_rest, int ntiles, const T* __restrict__ obs) {
   extern __shared__ __align__(16) unsigned char gen_smem[];
-  static_assert(MODE == 0 || (!CHECK && !OBS), "modes 1 / 2 belong to the plain stencil");
   const int NANG = tab->NANG, NFRE = tab->NFRE, NR = tab->NFRE_RED;
   const int N = NANG * NFRE, RW = REFR_W(NANG), NV = N / VW, FV = NFRE / VW;
   const T CMTODEG = T(360.0) / tab->CIRC;
@@ -747,9 +741,6 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int p0 = kijs + tile * GEN_TP;
     const int np = min(GEN_TP, kijl - p0);
-    if constexpr (MODE == 2) {      // only the tiles with a flagged point
-      if (!__syncthreads_or(((int)threadIdx.x < np) ? flips[p0 + threadIdx.x] : 0)) continue;
-    }
     __syncthreads();
     if (threadIdx.x < np) {
       const int t = threadIdx.x, ij = p0 + t;
@@ -943,13 +934,8 @@ __global__ void __launch_bounds__(256) k_propags2_gen(const DevTab<T>* __restric
           IO::st_stream(f3 + own + el, r);
           continue;
         }
-        if constexpr (MODE == 1) {      // an upwind switch in this lane: the point goes to the second launch
-          flips[q[0]] = 1;
-          continue;
-        }
       }
 #endif
-      if constexpr (MODE == 1) continue;
       CtuGenW<T> w[VW];
       bool fail = false, flipped = false;
 #pragma unroll
@@ -1315,7 +1301,7 @@ void launch_propags2_gen(const void* tab, int irefra, const void* f1, void* f3, 
                          const void* zdello, double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat,
                          const int* kcor, const void* wlat, const void* wcor, const void* cg, const void* om, const void* wn,
                          const void* cosphm1, const void* refr, int* cflfail, int slot, int kijs, int kijl, int m0, int m1,
-                         int copy_rest, int dims, const void* obs, int* flips, hipStream_t s) {
+                         int copy_rest, int dims, const void* obs, hipStream_t s) {
   const int NANG = dims >> 16, NFRE = (dims >> 8) & 0xFF, NR = dims & 0xFF;
   const int n = kijl - kijs;
   if (n <= 0) return;
@@ -1328,7 +1314,7 @@ void launch_propags2_gen(const void* tab, int irefra, const void* f1, void* f3, 
 #define GEN_ARGS                                                                                                               \
   (const DevTab<T>*)tab, irefra, (const T*)f1, (T*)f3, ngy, (T)delpro, kxlt, (const T*)zdello, (T)xdella, (const T*)cosph,       \
       (const T*)sinph, klon, klat, kcor, (const T*)wlat, (const T*)wcor, (const T*)cg, (const T*)om, (const T*)wn,             \
-      (const T*)cosphm1, (const T*)refr, cflfail, slot, kijs, kijl, m0, m1, copy_rest, ntiles, (const T*)obs, flips
+      (const T*)cosphm1, (const T*)refr, cflfail, slot, kijs, kijl, m0, m1, copy_rest, ntiles, (const T*)obs
   // 8 bytes per lane is the fastest width here (measured at O320 sp: 7.9 ms, against 9.2 ms at 16 bytes and 9.0 ms scalar):
   // the VW sets of 21 weights a thread keeps live cost more occupancy than the wider accesses save
   int vw = 2;
@@ -1342,18 +1328,7 @@ void launch_propags2_gen(const void* tab, int irefra, const void* f1, void* f3, 
   else if (obs) {
     if (v2) { allow_lds(k_propags2_gen<T, 2, false, true>, shmem); hipLaunchKernelGGL((k_propags2_gen<T, 2, false, true>), dim3(grid), dim3(256), shmem, s, GEN_ARGS); }
     else { allow_lds(k_propags2_gen<T, 1, false, true>, shmem); hipLaunchKernelGGL((k_propags2_gen<T, 1, false, true>), dim3(grid), dim3(256), shmem, s, GEN_ARGS); }
-  }
-#if !ECWAM_HIP_CTU_STRICT
-  else if (flips && aligned && NFRE % W == 0 && NR % W == 0 && m0 % W == 0 && m1 % W == 0) {
-    // two launches: the hoisted form on every lane (16-byte accesses), then the whole kernel on the tiles with an upwind switch
-    (void)hipMemsetAsync(flips + kijs, 0, sizeof(int) * (size_t)n, s);
-    allow_lds(k_propags2_gen<T, W, false, false, 1>, shmem);
-    hipLaunchKernelGGL((k_propags2_gen<T, W, false, false, 1>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
-    allow_lds(k_propags2_gen<T, 2, false, false, 2>, shmem);
-    hipLaunchKernelGGL((k_propags2_gen<T, 2, false, false, 2>), dim3(grid), dim3(256), shmem, s, GEN_ARGS);
-  }
-#endif
-  else if (v4)
+  } else if (v4)
     { allow_lds(k_propags2_gen<T, W, false, false>, shmem); hipLaunchKernelGGL((k_propags2_gen<T, W, false, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS); }
   else if (v2)
     { allow_lds(k_propags2_gen<T, 2, false, false>, shmem); hipLaunchKernelGGL((k_propags2_gen<T, 2, false, false>), dim3(grid), dim3(256), shmem, s, GEN_ARGS); }
@@ -1487,7 +1462,7 @@ void launch_proenv_unpack(int nrows, int NFRE, const void* buf, const void* land
   template void launch_propags2_gen<T>(const void*, int, const void*, void*, int, double, const int*, const void*, double,        \
                                        const void*, const void*, const int*, const int*, const int*, const void*, const void*,   \
                                        const void*, const void*, const void*, const void*, const void*, int*, int, int, int, int, \
-                                       int, int, int, const void*, int*, hipStream_t);                                                              \
+                                       int, int, int, const void*, hipStream_t);                                                                    \
   template void launch_propags2_otf<T>(const void*, const void*, void*, int, int, double, const int*, const void*, double,        \
                                        const void*, const void*, const int*, const int*, const int*, const void*, const void*,   \
                                        const void*, const void*, const int*, int, int, int, int, int, int, const void*, int, double,   \

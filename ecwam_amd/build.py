@@ -117,7 +117,9 @@ def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
         if not force and old == st:
             continue
         stamps[obj] = st
-        cmd = [HIPCC, *flags, "-c", os.path.join(CSRC, real_src), "-o", obj]
+        # -cuid: clang derives a compilation-unit id from the source file's PATH by default, which goes into the code object's symbol
+        # names -- the library's bytes (and the sha256 bench.py ties the counter summaries to) would depend on where the tree lives
+        cmd = [HIPCC, *flags, f"-cuid=ecwam_{os.path.basename(obj).replace('.', '_')}", "-c", os.path.join(CSRC, real_src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

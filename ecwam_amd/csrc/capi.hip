@@ -727,6 +727,13 @@ int ecwam_hip_propags2_refra(ecwam_hip_ctx* c, const void* f1, void* f3, int n, 
                              copy_rest ? 1 : 0, (hipStream_t)stream);
 }
 
+// the configurations that run the RARE builds of k_implsch4 (ecwam_hip_implsch below makes the same choice)
+static bool runs_rare_builds(const ecwam_hip_ctx* c) {
+  const int ext = (c->p.llnormagam || c->p.llgcbz0) ? 1 : 0;
+  const bool rare4 = c->p.lciwa2 || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin > 1 || c->p.icode != 3 || !c->p.lwvflx_snl;
+  const int alt = (c->p.iphys == 0 ? 1 : 0) | (c->p.isnonlin == 1 ? 2 : 0);
+  return !(!rare4 && (alt == 0 || (!ext && alt != 3)));
+}
 static int implsch_reserve_on(ecwam_hip_ctx* c, int npts, hipStream_t s, bool sync);
 int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws,
                       double* wam2nemo, void* dbg, void* stream) {
@@ -750,7 +757,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
   // the alternate physics the registered configurations select, on flag set A only: 1 = IPHYS 0 (sinput_jan + sdissip_jan; its
   // TAUWSHELTER is 0), 2 = ISNONLIN 1 (TRANSF per interaction frequency)
   const int alt = (c->p.iphys == 0 ? 1 : 0) | (c->p.isnonlin == 1 ? 2 : 0);
-  const bool common_ok = !rare4 && (alt == 0 || (!ext && alt != 3));
+  const bool common_ok = !rare4 && (alt == 0 || (!ext && alt != 3));      // (= !runs_rare_builds(c))
   {
     if (int rc2 = implsch_reserve_on(c, kijl, s, false)) return rc2;   // no-op once the buffer covers kijl
     if (!common_ok)
@@ -858,8 +865,10 @@ static int implsch_reserve_on(ecwam_hip_ctx* c, int npts, hipStream_t s, bool sy
     (void)sync;
     c->fin_bytes = need;
   }
-  // the split kernel pair parks the wind-input coefficient of every bin between its two halves
-  const bool split = implsch4_split_all() || (c->real_bytes == 8 && implsch4r_dp_split());
+  // the split kernel pair parks the wind-input coefficient of every bin between its two halves: the whole library built as the split (build
+  // variant), or a double precision context whose configuration runs the RARE builds (implsch4r.hip: their dp form is the split) -- NOT
+  // every double precision context: the rows are a fourth spectrum-sized array (68 GB at O1280)
+  const bool split = implsch4_split_all() || (c->real_bytes == 8 && implsch4r_dp_split() && runs_rare_builds(c));
   const size_t need_wi = split ? (size_t)(npts > 0 ? npts : 0) * c->NANG * c->NFRE * c->real_bytes : 0;
   if (need_wi > c->wi_bytes) {
     if (c->wi) HIPCHK(hipFree(c->wi));

@@ -50,7 +50,7 @@ def _same_state(a, b):
 
 
 @pytest.mark.parametrize("prec", ["sp", "dp"])
-@pytest.mark.parametrize("flags", [dict(), dict(llgcbz0=True, llnormagam=True)])
+@pytest.mark.parametrize("flags", [dict(), dict(llgcbz0=True, llnormagam=True), dict(lciwa3=True, lciscal=True, lciwa1=True)])
 @pytest.mark.parametrize("nfre_red,ngrid", [(36, 24), (29, 17)])
 def test_one_kernel_step_is_bit_identical_to_the_two_kernels(api, flags, nfre_red, ngrid, prec):
     """Three steps on a grid with land (land slot, short last wave: the sea-point count is not a multiple of three at either size), all
@@ -60,6 +60,15 @@ def test_one_kernel_step_is_bit_identical_to_the_two_kernels(api, flags, nfre_re
     cfg = Config(nang=36, nfre=36, nfre_red=nfre_red, idelt=450, idelpro=450, **flags)
     g = G.build_grid(ngrid, mask="continents")
     two, one = _pair(cfg, g, seed=21, prec=prec)
+    if flags.get("lciwa3"):      # sea-ice attenuation (common builds: the rates depend on the frequency only): partial ice cover on a third of the points
+        rng = np.random.default_rng(8)
+        for m in (two, one):
+            ice = torch.from_numpy(np.where(rng.uniform(size=m.n) < 0.33, rng.uniform(0.05, 0.95, m.n), 0.0)).to(m.dev, m.dtype)
+            thick = torch.from_numpy(rng.uniform(0.1, 3.0, m.n)).to(m.dev, m.dtype)
+            for ff in (m.ff, m.ff_next):
+                ff[:, 2] = ice
+                ff[:, 13] = thick
+            rng = np.random.default_rng(8)
     assert one.fused_available()
     assert two.build_weights() == 0 and one.build_weights() == 0
     for _ in range(3):

@@ -1006,10 +1006,11 @@ def test_implsch_kernel_generations_agree(api):
         _assert_two_implementations(H.compare_implsch(a, b, case["tables"]), n, "sp")
 
 
-def test_two_steps_replay_from_a_hip_graph(api):
-    """The time loop makes no allocation and no host synchronisation (ecwam_hip_implsch_reserve at set-up): two WAMINTGR steps -- the
-    ping-pong spectra are back in place after an even number -- are captured into a hipGraph and replayed; bit-identical to the
-    same steps launched one by one."""
+@pytest.mark.parametrize("fused", [False, True], ids=["two_kernels", "one_kernel"])
+def test_two_steps_replay_from_a_hip_graph(api, fused):
+    """The time loop makes no allocation and no host synchronisation (ecwam_hip_implsch_reserve at set-up; the tables of the one-kernel step
+    are sized by its first call): two WAMINTGR steps -- the ping-pong spectra are back in place after an even number -- are captured into a
+    hipGraph and replayed; bit-identical to the same steps launched one by one."""
     from ecwam_amd import grid as G
     from ecwam_amd.wamintgr import Wamintgr
 
@@ -1021,16 +1022,16 @@ def test_two_steps_replay_from_a_hip_graph(api):
         w.init_synthetic()
         assert w.build_weights() == 0
     for _ in range(6):
-        a.step()
+        a.step(fused=fused)
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
-        b.step()
-        b.step()                               # outside the capture: whatever a first call sets up
+        b.step(fused=fused)
+        b.step(fused=fused)                    # outside the capture: whatever a first call sets up
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, stream=s):    # captured, not run
-        b.step()
-        b.step()
+        b.step(fused=fused)
+        b.step(fused=fused)
     graph.replay()
     graph.replay()
     torch.cuda.synchronize()

@@ -186,6 +186,9 @@ def main() -> None:
                          "kernels).  auto (default): where a build covers the configuration (36 x 36, one advection step per source step, no "
                          "refraction / fast waves); on: refuse to run otherwise; off: PROPAGS2 and IMPLSCH as two kernels (the A/B partner)")
     ap.add_argument("--fused-flags", type=int, default=0, help="diagnostics: flags of ecwam_hip_propags2_implsch (1: natural workgroup order; 2: the probe)")
+    ap.add_argument("--subgrid", action="store_true",
+                    help="LSUBGRID (the reference's default on real bathymetry, mpuserin.F90:704): synthetic sub-grid obstruction coefficients scale the "
+                         "space weights of the advection (ctuw.F90:703-733); not part of the BASELINE configurations (all-ocean grids)")
     ap.add_argument("--irefra", type=int, default=0, choices=[0, 1, 2, 3],
                     help="refraction: 0 none (BASELINE configurations), 1 depth, 2 currents, 3 both (synthetic current field)")
     a = ap.parse_args()
@@ -252,6 +255,9 @@ def main() -> None:
                  ifrelfmax=a.ifrelfmax, delpro_lf=(dt / 2.0 if a.ifrelfmax else None), halo_transport="host" if world > 1 else "torch")
     m.init_synthetic(env_on_device=bool(a.irefra) and world > 1)      # refraction on N > 1 ranks: PROENVHALO on the device, halo rows through the transport
     m.ff_next = m.ff.clone()      # NEWWIND hands the (unchanged synthetic) forcing over every step: k_newwind is part of the step
+    if a.subgrid:
+        from ecwam_amd import synthetic as syn
+        m.set_obstructions(syn.obstructions(grid, a.nfre, seed=5))
     nfail = m.build_weights()
     if dist is not None:      # every rank leaves together (the reference aborts the whole run, ctuwdrv.F90:124-146): nobody waits in a collective
         tot = torch.tensor([nfail], dtype=torch.int64)
@@ -439,6 +445,7 @@ def main() -> None:
                     + (" as one kernel (PROPAGS2 inside IMPLSCH's tile load)" if fused else "") + ", "
                     f"IDELT=IDELPRO={dt} s, flag set A (IPHYS=1, ISNONLIN=0, LLGCBZ0=F, LLNORMAGAM=F)"
                     + (f", IREFRA={a.irefra} (synthetic currents)" if a.irefra else "")
+                    + (", LSUBGRID (synthetic obstruction coefficients)" if a.subgrid else "")
                     + (f", {a.adv_per_source} advection steps per source step" if a.adv_per_source != 1 else "")
                     + (f", fast waves M<={a.ifrelfmax} in two sub-steps" if a.ifrelfmax else "")
                     + (", DIAGNOSTIC: spectra copied from and to pinned host memory every step" if a.host_state else ""))

@@ -779,7 +779,7 @@ static bool fused_ok(const ecwam_hip_ctx* c) {
   if (!c->implsch_why.empty()) return false;
   const bool rare4 = c->p.lciwa2 || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin > 1 || c->p.icode != 3 || !c->p.lwvflx_snl;
   return !rare4 && c->p.iphys == 1 && c->p.isnonlin == 0 && c->NANG == 36 && c->NFRE == 36 && c->v4_r1 == 1 && c->v4_r2 == 3 &&
-         c->v4_nh == 8 && !c->obs;
+         c->v4_nh == 8;
 }
 int ecwam_hip_propags2_implsch_supported(ecwam_hip_ctx* c) { return c && fused_ok(c) ? 1 : 0; }
 
@@ -803,6 +803,7 @@ int ecwam_hip_propags2_implsch(ecwam_hip_ctx* c, const void* f1, void* f3, int n
               !(delpro_lf > 0.0)))
     return fail("ecwam_hip_propags2_implsch: the compact fast-wave rows must be 16-byte aligned, hold the fast waves in a multiple of 16 bytes per direction, and differ from the rows of ecwam_hip_set_fastwave_copy");
   if (c->p.lwnemocou && kijl > kijs && !wam2nemo) return fail("ecwam_hip_propags2_implsch: LWNEMOCOU needs the WAVE2OCEAN buffer");
+  if (c->obs && kijl > c->n_obs) return fail("ecwam_hip_propags2_implsch: more points than the obstruction table holds");
   if (!c->p.lwnemocou) wam2nemo = nullptr;
   HIPCHK(hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)stream;
@@ -825,6 +826,7 @@ int ecwam_hip_propags2_implsch(ecwam_hip_ctx* c, const void* f1, void* f3, int n
   a.f_in = f1; a.klon = klon; a.klat = klat; a.kcor = kcor; a.cg = cgroup_ext; a.pt = c->adv_pt; a.dirT = c->adv_dir; a.dirI = dirI;
   a.xdella = xdella; a.delpro = delpro; a.m0 = nd3s - 1; a.m1 = nd3e;
   a.gin = gin; a.delpro_lf = dlf; a.gin_k = gin ? gin_nfre : 0; a.mlf = gin ? ifrelfmax : 0;
+  a.obs = c->obs;      // ecwam_hip_set_obstructions (LSUBGRID)
   a.gfast = c->fast_g; a.gfast_k = c->fast_g ? c->fast_gk : 0;      // ecwam_hip_set_fastwave_copy, as for ecwam_hip_implsch
   // flags bit 0: the workgroups in the XCD-aware order of k_propags2_otf (diagnostics: 1 % slower here); bits 8..19: G > 1 = groups of G
   // consecutive waves per XCD (diagnostics)
@@ -834,7 +836,7 @@ int ecwam_hip_propags2_implsch(ecwam_hip_ctx* c, const void* f1, void* f3, int n
   int rc = -1;
   DISPATCH(rc = launch_implsch4_adv<float>(c->dtab, kijs, kijl, f3, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, &a, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s),
            rc = launch_implsch4_adv<double>(c->dtab, kijs, kijl, f3, wvprpt, ff, intf, mij, xllws, c->fin, wam2nemo, &a, c->NANG, c->NFRE, c->v4_r1, c->v4_r2, c->v4_nh, ext, s));
-  if (rc != 0) return fail("ecwam_hip_propags2_implsch: no one-kernel build covers the configuration");
+  if (rc != 0) return fail("ecwam_hip_propags2_implsch: no one-kernel build covers the configuration (the strict build of the weights has neither the fast-wave nor the obstruction form)");
   HIPCHK(hipGetLastError());
   c->implsch_last = 4;
   return 0;

@@ -12,6 +12,7 @@ struct Implsch4AdvArgs {
   const void* gin;                      // fast waves after their sub-steps: compact rows [rows][NANG][gin_k] (or NULL)
   double delpro_lf;
   int gin_k, mlf;                       // frequencies [0, mlf) advance with delpro_lf
+  const void* obs;                      // LSUBGRID: OBS[n][8][NFRE] (or NULL)
   void* gfast;                          // compact rows that also receive the first gfast_k frequencies of the new spectrum (or NULL)
   int gfast_k;
   int m0, m1;                           // advected frequencies [m0, m1)

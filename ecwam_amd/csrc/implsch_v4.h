@@ -381,6 +381,9 @@ struct V4Adv {
   const T* gin;
   T delpro_lf;
   int gin_k, mlf;
+  // ADV & 4 (LSUBGRID, the reference's default on real bathymetry): OBS[n][8][NFRE], the transmission coefficients OBSLAT(1:2), OBSLON(1:2),
+  // OBSCOR(1:4) that scale the space weights of the neighbours (ctuw.F90:703-733)
+  const T* obs;
   int m0, m1;           // advected frequencies [m0, m1); the others are carried over
   int xcd_walk;         // XCD-aware order of the workgroups (diagnostics: measured 1 % slower than the natural order, profiles/r06_fused_*.txt)
 };
@@ -400,7 +403,10 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
   T* sB = sScr;                                        // [PP][5][NFRE]: |h(1:2)|, |hy(1:2)|, CG of ctu_base
   T* sPt = sB + PP * 5 * NFRE;                         // [PP][PTW]: ZDELLO, |COSPHM1|, GA, TANPH, DP(1:2), WLAT(1:2), WCOR(1:4), 1 - WLAT, 1 - WCOR
   T* sK = sPt + PP * PTW;                              // [NANG][4]: 2 SP, 2 SM (ctu_dirfac with TANPH = 1, doubled), |SINTH|, |COSTH|; then CMTODEG
-  constexpr bool LF = (MODE == 3);                     // fast waves with their own time step, read from compact rows
+  constexpr bool LF = (MODE & 3) == 3;                 // fast waves with their own time step, read from compact rows
+  constexpr bool OBS = (MODE & 4) != 0;                // sub-grid obstructions: three more 16-byte loads per step (the coefficients of the step's neighbours)
+  constexpr int NB = OBS ? 11 : 8;
+  static_assert(MODE == 2 || (MODE & 1), "modes: 1 plain, 3 fast waves, + 4 obstructions; 2 the probe");
   constexpr int NKW = NANG * 4 + 4 + (LF ? NANG * 2 : 0);      // (LF: then [NANG][2]: 2 SP, 2 SM for DELPRO_LF)
   int* sI = reinterpret_cast<int*>(sK + NKW);          // [PP][16]: ij, KLON(1:2), KLAT(1:2,1:2), KCOR(1:4,1:2)
   int* sD = sI + PP * 16;                              // [NANG][4]
@@ -435,7 +441,7 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
 #if defined(V4_ADV_PRIO)
   __builtin_amdgcn_s_setprio(V4_ADV_PRIO);      // experiment: the wave that has gathers to issue goes first on its SIMD
 #endif
-  VT buf[D][8];
+  VT buf[D][NB];
   // (point, direction, first frequency) of the lane's chunk in step c
   auto chunk_of = [&](int c, int& q, int& k, int& m) {
     int w;
@@ -452,7 +458,7 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
     k = w / NC;
     m = (w - k * NC) * VEC;
   };
-  auto issue = [&](int c, VT (&b)[8]) {
+  auto issue = [&](int c, VT (&b)[NB]) {
     int q, k, m;
     chunk_of(c, q, k, m);
     const I4 dk = *reinterpret_cast<const I4*>(sD + 4 * k);
@@ -473,8 +479,14 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
     b[5] = *reinterpret_cast<const VT*>(src + (size_t)iq[8 + 2 * kc] * rn + el);
     b[6] = *reinterpret_cast<const VT*>(own + dk.y * rk + m);
     b[7] = *reinterpret_cast<const VT*>(own + dk.z * rk + m);
+    if constexpr (OBS) {
+      const T* o = A.obs + (size_t)iq[0] * 8 * NFRE + m;
+      b[8] = *reinterpret_cast<const VT*>(o + (2 + jx0) * NFRE);      // OBSLON(JXO(K,1))
+      b[9] = *reinterpret_cast<const VT*>(o + jy0 * NFRE);            // OBSLAT(JYO(K,1))
+      b[10] = *reinterpret_cast<const VT*>(o + (4 + kc) * NFRE);      // OBSCOR(KCR(K,1))
+    }
   };
-  auto finish = [&](int c, const VT (&b)[8]) {
+  auto finish = [&](int c, const VT (&b)[NB]) {
     int q, k, m;
     chunk_of(c, q, k, m);
     T r[VEC];
@@ -507,6 +519,7 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
                bya = *reinterpret_cast<const VT*>(bb + (2 + jy0) * NFRE), byb = *reinterpret_cast<const VT*>(bb + (3 - jy0) * NFRE),
                bc0 = *reinterpret_cast<const VT*>(bb + 4 * NFRE);
 #if ECWAM_HIP_CTU_STRICT
+      static_assert(!LF && !OBS, "the strict build of the weights has the plain form only");
 #pragma unroll
       for (int i = 0; i < VEC; i += 2) {
 #define P2(a) V2<T>{a[i], a[i + 1]}
@@ -521,10 +534,13 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
       for (int i = 0; i < VEC; i += 2) {
 #define P2(a) V2<T>{a[i], a[i + 1]}
         const bool lf0 = LF && (m + i) < A.mlf, lf1 = LF && (m + i + 1) < A.mlf;
-        const V2<T> rr = ctu_fast_stencil<T>(P2(bha), P2(bhb), P2(bya), P2(byb), P2(bc0), kk2, kk3, zd, A.xdella, ga, zdg, xdg, wl, omwl, wc, omwc,
-                                             V2<T>{lf0 ? ab2_lf : ab2, lf1 ? ab2_lf : ab2}, V2<T>{lf0 ? p2_lf : p2, lf1 ? p2_lf : p2},
-                                             V2<T>{lf0 ? m2_lf : m2, lf1 ? m2_lf : m2}, P2(b[0]), P2(b[1]), P2(b[2]), P2(b[3]), P2(b[4]), P2(b[5]),
-                                             P2(b[6]), P2(b[7]));
+        CtuFastW8<T> w = ctu_fast_w8<T>(P2(bha), P2(bhb), P2(bya), P2(byb), P2(bc0), kk2, kk3, zd, A.xdella, ga, zdg, xdg, wl, omwl, wc, omwc,
+                                        V2<T>{lf0 ? ab2_lf : ab2, lf1 ? ab2_lf : ab2}, V2<T>{lf0 ? p2_lf : p2, lf1 ? p2_lf : p2},
+                                        V2<T>{lf0 ? m2_lf : m2, lf1 ? m2_lf : m2});
+        if constexpr (OBS) {      // as k_propags2_otf: after the weights, before the stencil
+          w.wlon = w.wlon * P2(b[8]); w.wlat1 = w.wlat1 * P2(b[9]); w.wlat2 = w.wlat2 * P2(b[9]); w.wcor1 = w.wcor1 * P2(b[10]); w.wcor2 = w.wcor2 * P2(b[10]);
+        }
+        const V2<T> rr = ctu_fast_apply<T>(w, P2(b[0]), P2(b[1]), P2(b[2]), P2(b[3]), P2(b[4]), P2(b[5]), P2(b[6]), P2(b[7]));
 #undef P2
         r[i] = rr.x; r[i + 1] = rr.y;
       }
@@ -542,7 +558,7 @@ __device__ __forceinline__ void v4_advect_tile(const V4Adv<T>& A, int ij0, int n
 #pragma unroll
   for (int c = 0; c < D - 1 && c < NCH; c++) issue(c, buf[c % D]);
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (MODE == 1 || MODE == 3) {
+  if constexpr ((MODE & 1) != 0) {
     for (int i = lane; i < PP * NFRE; i += 64) {
       const int q = i / NFRE, m = i - q * NFRE;
       const int* iq = sI + q * 16;
@@ -1202,8 +1218,8 @@ __device__ __forceinline__ T v4_sdice3_alp(const DevTab<T>& tb, int m, T CITHICK
 // ADV: 0 = the tile is loaded from FL1 (IMPLSCH on its own, behind a PROPAGS2 kernel); 1 = the tile load IS the advection (round 6:
 // v4_advect_tile above -- PROPAGS2 of the wave's points from the rows of adv.f_in straight into the tile, the new spectrum stored to the rows
 // of fl1, which must be another buffer: one kernel per WAMINTGR step); 3 = the same for the native O1280 mode: the fast waves with their own
-// time step, read from the compact rows their sub-steps left (V4Adv::gin); 2 = the go / no-go probe of ADV = 1 (the eight gathers of the
-// stencil through the real neighbour tables, made-up weights).
+// time step, read from the compact rows their sub-steps left (V4Adv::gin); + 4 (5, 7) = with the sub-grid obstructions of LSUBGRID (V4Adv::obs);
+// 2 = the go / no-go probe of ADV = 1 (the eight gathers of the stencil through the real neighbour tables, made-up weights).
 template <typename T, int NANG, int PP, int R1, int R2, int NH, bool EXT, bool JAN = false, bool ENHMC = false, bool RARE = false, int PART = 0, int ADV = 0>
 // single precision: two waves per SIMD (LDS: 8 waves per CU), at most 256 VGPRs; double precision: the LDS holds one wave per SIMD
 // (40 KB per wave) and the kernel may use the whole register file (340 registers: no scratch)

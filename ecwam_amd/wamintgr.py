@@ -485,8 +485,8 @@ class Wamintgr:
     # ---- the 1:1 step as one kernel (round 6): PROPAGS2 inside IMPLSCH's tile load (ecwam_hip_propags2_implsch)
     def fused_available(self) -> bool:
         """The one-kernel step covers this model: a build exists (36 x 36, common IMPLSCH builds) and the advection is IREFRA = 0 with
-        on-the-fly weights in the natural row order, without obstructions; fast-wave sub-steps run on compact rows (the last one inside the
-        kernel)."""
+        on-the-fly weights in the natural row order, with or without sub-grid obstructions; fast-wave sub-steps run on compact rows (the
+        last one inside the kernel)."""
         lf = 0 < self.ifrelfmax < self.cfg.nfre_red
         return (self.ctx.fused_supported() and not self.irefra and self.weights == "otf" and self.order is None
                 and (not lf or (self.g1 is not None and self.fast_mode == "compact")))

@@ -308,7 +308,8 @@ int ecwam_hip_implsch_reserve(ecwam_hip_ctx *ctx, int npts);
  * ecwam_hip_propags2_otf_fast(f1 -> f3, gin) does -- and the source terms; with ecwam_hip_set_fastwave_copy the new fast waves also go to
  * the compact rows the next advection step starts from.  Else ifrelfmax = 0, gin = NULL.
  * Covered: what ecwam_hip_propags2_implsch_supported reports (36 directions x 36 frequencies in either precision, the common builds of
- * IMPLSCH with IPHYS = 1 / ISNONLIN = 0, no obstructions, no refraction); everything else runs the two calls.
+ * IMPLSCH with IPHYS = 1 / ISNONLIN = 0, no refraction; with or without the obstructions of ecwam_hip_set_obstructions); everything else runs
+ * the two calls.
  * flags: 0 (bit 0: workgroups in the XCD-aware order of the stencil kernel instead of the natural one; bit 1: the go / no-go probe of
  * diagnostics builds).
  */

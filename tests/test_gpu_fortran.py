@@ -122,13 +122,14 @@ def test_fortran_wamintgr_hip_matches_python_host(tmp_path, prec, lf, irefra, su
     _fortran_vs_python_host(tmp_path, prec, lf, irefra, subgrid, nosource)
 
 
-@pytest.mark.parametrize("prec,nosource,lf", [("sp", False, 0), ("dp", False, 0), ("sp", True, 0), ("sp", False, 5), ("dp", False, 4)])
-def test_fortran_one_kernel_step_matches_python_host_two_kernels(tmp_path, prec, nosource, lf):
+@pytest.mark.parametrize("prec,nosource,lf,subgrid", [("sp", False, 0, False), ("dp", False, 0, False), ("sp", True, 0, False), ("sp", False, 5, False),
+                                                      ("dp", False, 4, False), ("sp", False, 0, True), ("dp", False, 5, True)])
+def test_fortran_one_kernel_step_matches_python_host_two_kernels(tmp_path, prec, nosource, lf, subgrid):
     """36 directions: WAMINTGR_HIP takes the one-kernel step (ecwam_hip_propags2_implsch: the exchange posted at propagation time, PROPAGS2
     inside IMPLSCH's tile load when the source terms are due), the Python host drives PROPAGS2 and IMPLSCH as two kernels -- the same bits.
     With LLSOURCE = F the Fortran side must fall back to the separate advection.  lf > 0: fast-wave sub-steps on compact rows, the last one
     inside the kernel."""
-    _fortran_vs_python_host(tmp_path, prec, lf, 0, False, nosource, nang=36, nfre_red=36, idelt=450)
+    _fortran_vs_python_host(tmp_path, prec, lf, 0, subgrid, nosource, nang=36, nfre_red=36, idelt=450)      # subgrid: LSUBGRID (ECWAM_HIP_SET_SUBGRID)
 
 
 def _fortran_vs_python_host(tmp_path, prec, lf, irefra, subgrid, nosource, nang=12, nfre_red=25, idelt=900):

@@ -109,6 +109,36 @@ def test_one_kernel_step_with_fast_wave_sub_steps_is_bit_identical(api, prec, nf
     two.ctx.close(); one.ctx.close()
 
 
+@pytest.mark.parametrize("prec,lfm", [("sp", 0), ("dp", 0), ("sp", 5), ("dp", 4)])
+def test_one_kernel_step_with_sub_grid_obstructions_is_bit_identical(api, prec, lfm):
+    """LSUBGRID (the reference's default on real bathymetry, mpuserin.F90:704): the transmission coefficients OBSLAT / OBSLON / OBSCOR scale the
+    space weights of the neighbours (ctuw.F90:703-733).  The tile load fetches the three coefficient vectors of a step's neighbours with its
+    gathers (ADV = 5; with fast-wave sub-steps ADV = 7) and applies them as k_propags2_otf does: three steps, the same bits; and the table
+    acts (the result differs from the run without it)."""
+    from ecwam_amd import grid as G, synthetic as syn
+
+    cfg = Config(nang=36, nfre=36, nfre_red=36, idelt=450, idelpro=450)
+    g = G.build_grid(20, mask="continents")
+    kw = dict(ifrelfmax=lfm, delpro_lf=225.0) if lfm else {}
+    two, one = _pair(cfg, g, seed=17, prec=prec, **kw)
+    plain, _ = _pair(cfg, g, seed=17, prec=prec, **kw)
+    _.ctx.close()
+    obs = syn.obstructions(g, cfg.nfre, seed=5)
+    for m in (two, one):
+        m.set_obstructions(obs)
+        assert m.build_weights() == 0
+    assert plain.build_weights() == 0 and one.fused_available()
+    for _i in range(3):
+        two.step()
+        one.step(fused=True)
+        plain.step(fused=True)
+        torch.cuda.synchronize()
+        _same_state(two, one)
+    assert not torch.equal(one.fl1[: one.n], plain.fl1[: plain.n])
+    for m in (two, one, plain):
+        m.ctx.close()
+
+
 def test_one_kernel_step_natural_order_and_row_blocks(api):
     """The workgroups in the XCD-aware order (flags bit 0) and the rows passed in three unequal blocks give the same bits as one call."""
     from ecwam_amd import grid as G

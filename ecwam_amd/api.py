@@ -71,6 +71,10 @@ class HipContext:
         return t.data_ptr()
 
     # -- LSUBGRID: OBS[n][8][NFRE] = OBSLAT(:,M,1:2), OBSLON(:,M,1:2), OBSCOR(:,M,1:4); the tensor is kept alive here
+    @property
+    def has_obstructions(self) -> bool:
+        return getattr(self, "_obs", None) is not None
+
     def set_obstructions(self, obs) -> None:
         if obs is None:
             self._obs = None
@@ -232,8 +236,11 @@ class HipContext:
         self._chk(self.lib.ecwam_hip_implsch(self._h, kijs, kijl, *a, pw, pd, _stream_ptr()))
 
     # -- the one-kernel step: PROPAGS2 inside IMPLSCH's tile load (ecwam_hip_propags2_implsch)
-    def fused_supported(self) -> bool:
-        return bool(self.lib.ecwam_hip_propags2_implsch_supported(self._h))
+    def fused_supported(self, fast_waves: bool = False, obstructions: bool = False) -> bool:
+        """The one-kernel step covers the context (and, if asked, its forms with fast-wave sub-steps / sub-grid obstructions)."""
+        mask = int(self.lib.ecwam_hip_propags2_implsch_supported(self._h))
+        need = 1 | (2 if fast_waves else 0) | (4 if obstructions else 0)
+        return (mask & need) == need
 
     def propags2_implsch(self, f1, f3, grid_dev: dict, cgroup_ext, delpro: float, kijs, kijl, wvprpt, ff, intf, mij, xllws, nd3s=1, nd3e=None,
                          wam2nemo=None, flags: int = 0, ifrelfmax: int = 0, delpro_lf: float | None = None, gin=None):

@@ -56,11 +56,14 @@ VARIANTS = {"": FAST_DIV, "exactdiv": ["-DECWAM_HIP_STRICT=0"], "strict1": ["-DE
             "ctustrict": FAST_DIV,
             # the advecting load with 2 / 4 steps of gathers in flight instead of 3 (V4_ADV_DEPTH), and at a raised wave priority (s_setprio):
             # all within the noise of the product (profiles/r06_fused_step_experiments.txt)
+            # the one-kernel builds at -O1 (with every double precision direction count enabled in implsch4a.hip this was the proof that their -O3
+            # failures are code generation: profiles/r06_fused_step_experiments.txt)
+            "advO1": FAST_DIV + ["-O1"],
             "advd2": FAST_DIV + ["-DV4_ADV_DEPTH=2"], "advd4": FAST_DIV + ["-DV4_ADV_DEPTH=4"], "advprio": FAST_DIV + ["-DV4_ADV_PRIO=2"]}
 # flags a variant adds to EVERY source it rebuilds (not only the IMPLSCH units)
 VARIANT_ANY = {"ctustrict": ["-DECWAM_HIP_CTU_STRICT=1"]}
 # variants that rebuild only some of the translation units (the other objects are the product's)
-VARIANT_SOURCES = {"ctustrict": ("propag.hip", "implsch4a.hip"), "advprobe": ("implsch4a.hip",), "advd2": ("implsch4a.hip",), "advd4": ("implsch4a.hip",),
+VARIANT_SOURCES = {"ctustrict": ("propag.hip", "implsch4a.hip"), "advprobe": ("implsch4a.hip",), "advO1": ("implsch4a.hip",), "advd2": ("implsch4a.hip",), "advd4": ("implsch4a.hip",),
                    "advprio": ("implsch4a.hip",), "rdp": ("implsch4rd.hip",), "rdpchk": ("implsch4rd.hip",), "rdpO2": ("implsch4rd.hip",),
                    "split": ("implsch4.hip", "implsch4x.hip", "implsch4r.hip", "implsch4rd.hip"), "norecpf": ("implsch4.hip",), "norecs": ("implsch4.hip",),
                    "noredn": ("implsch4.hip",)}

@@ -93,6 +93,7 @@ template <typename T> int launch_implsch4x(const void*, int, int, void*, const v
 template <typename T> int launch_implsch4r(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, void*, int, void*, int, int, int, int, int, int, hipStream_t);
 template <typename T> void launch_ctu_prep(const void*, int, int, int, double, double, const int*, const void*, double, const void*, const void*, const void*, const void*, const void*, void*, void*, int*, hipStream_t);
 template <typename T> int launch_implsch4_adv(const void*, int, int, void*, const void*, void*, void*, int*, void*, void*, double*, const Implsch4AdvArgs*, int, int, int, int, int, int, hipStream_t);
+int implsch4_adv_forms(int, int);
 int implsch4_fin_row();
 int implsch4_split_all();
 int implsch4r_dp_split();
@@ -778,10 +779,11 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
 static bool fused_ok(const ecwam_hip_ctx* c) {
   if (!c->implsch_why.empty()) return false;
   const bool rare4 = c->p.lciwa2 || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin > 1 || c->p.icode != 3 || !c->p.lwvflx_snl;
-  return !rare4 && c->p.iphys == 1 && c->p.isnonlin == 0 && c->NANG == 36 && c->NFRE == 36 && c->v4_r1 == 1 && c->v4_r2 == 3 &&
-         c->v4_nh == 8;
+  return !rare4 && c->p.iphys == 1 && c->p.isnonlin == 0 && c->NFRE == 36;      // (the direction count: one of k_implsch4's, checked at create)
 }
-int ecwam_hip_propags2_implsch_supported(ecwam_hip_ctx* c) { return c && fused_ok(c) ? 1 : 0; }
+// bit 0: the one-kernel step covers the context; bit 1: also with fast-wave sub-steps (gin); bit 2: also with the obstructions of
+// ecwam_hip_set_obstructions -- a caller takes the one-kernel step when the bits of what it needs are set
+int ecwam_hip_propags2_implsch_supported(ecwam_hip_ctx* c) { return c && fused_ok(c) ? implsch4_adv_forms(c->NANG, c->real_bytes) : 0; }
 
 int ecwam_hip_propags2_implsch(ecwam_hip_ctx* c, const void* f1, void* f3, int n, int ngy, double delpro, const int* kxlt, const void* zdello,
                                double xdella, const void* cosph, const void* sinph, const int* klon, const int* klat, const int* kcor,
@@ -789,7 +791,7 @@ int ecwam_hip_propags2_implsch(ecwam_hip_ctx* c, const void* f1, void* f3, int n
                                int nd3e, const void* wvprpt, void* ff, void* intf, int* mij, void* xllws, double* wam2nemo, double delpro_lf,
                                int ifrelfmax, const void* gin, int gin_nfre, int flags, void* stream) {
   if (!c) return fail("null context");
-  if (!fused_ok(c)) return fail("ecwam_hip_propags2_implsch: no one-kernel build covers the configuration (ecwam_hip_propags2_implsch_supported): call ecwam_hip_propags2_otf and ecwam_hip_implsch");
+  if (!fused_ok(c) || !implsch4_adv_forms(c->NANG, c->real_bytes)) return fail("ecwam_hip_propags2_implsch: no one-kernel build covers the configuration (ecwam_hip_propags2_implsch_supported): call ecwam_hip_propags2_otf and ecwam_hip_implsch");
   if (kijl < kijs || kijs < 0 || kijl > n || nd3s < 1 || nd3e > c->NFRE_RED || nd3e < nd3s - 1) return fail("ecwam_hip_propags2_implsch: bad range");
   if (kijl > kijs && (!f1 || !f3 || !kxlt || !zdello || !cosph || !sinph || !klon || !klat || !kcor || !wlat || !wcor || !cgroup_ext || !cosphm1_ext ||
                       !wvprpt || !ff || !intf || !mij || !xllws))

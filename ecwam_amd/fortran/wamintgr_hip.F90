@@ -106,6 +106,7 @@ SUBROUTINE WAMINTGR_HIP (CDTPRA, CDATE, CDATEWH, CDTIMP, CDTIMPNEXT,  &
   INTEGER(C_INT) :: NPASS, PMS(2), PME(2), PCP(2), PRG(2)
   REAL(C_DOUBLE) :: PDEL(2)
   LOGICAL :: LSOURCE_NOW, LFUSE
+  INTEGER(C_INT) :: IFORMS, INEED
 
   S0 = HIPST%QUEUE(0)     ! every kernel and copy of the step on the compute queue (a non-blocking stream)
   NP = HIPST%NPTS; NPROMA = HIPST%NPROMA; NFRE = HIPST%NFRE; NANG = HIPST%NANG
@@ -173,7 +174,13 @@ SUBROUTINE WAMINTGR_HIP (CDTPRA, CDATE, CDATEWH, CDTIMP, CDTIMPNEXT,  &
     ! advection is left to IMPLSCH's tile load: only the exchange is posted here, FL1 / FL3 are swapped behind that kernel
     LFUSE = HIP_LFUSED_STEP .AND. HIP_LLSOURCE .AND. (HIP_CDTPRO >= CDTIMPNEXT)
     IF (LFUSE .AND. HIPST%IFRELFMAX > 0) LFUSE = C_ASSOCIATED(HIPST%D_G1)
-    IF (LFUSE) LFUSE = ECWAM_HIP_PROPAGS2_IMPLSCH_SUPPORTED(HIPST%CTX) /= 0
+    IF (LFUSE) THEN      ! the forms this configuration needs: bit 0 the plain step, bit 1 fast waves, bit 2 obstructions (LSUBGRID)
+      IFORMS = ECWAM_HIP_PROPAGS2_IMPLSCH_SUPPORTED(HIPST%CTX)
+      INEED = 1
+      IF (HIPST%IFRELFMAX > 0) INEED = INEED + 2
+      IF (C_ASSOCIATED(HIPST%D_OBS)) INEED = INEED + 4
+      LFUSE = IAND(IFORMS, INEED) == INEED
+    ENDIF
     IF (HIPST%IFRELFMAX > 0) THEN
       ! the fast waves do not depend on the slow ones: their sub-steps 1 .. NSTEP_LF-1 first, compact rows -> compact rows, then one full
       ! pass that takes their last state from the compact rows as the input of the last sub-step and writes complete FL3 rows and the

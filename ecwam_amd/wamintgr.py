@@ -488,8 +488,8 @@ class Wamintgr:
         on-the-fly weights in the natural row order, with or without sub-grid obstructions; fast-wave sub-steps run on compact rows (the
         last one inside the kernel)."""
         lf = 0 < self.ifrelfmax < self.cfg.nfre_red
-        return (self.ctx.fused_supported() and not self.irefra and self.weights == "otf" and self.order is None
-                and (not lf or (self.g1 is not None and self.fast_mode == "compact")))
+        return (self.ctx.fused_supported(fast_waves=lf, obstructions=self.ctx.has_obstructions) and not self.irefra and self.weights == "otf"
+                and self.order is None and (not lf or (self.g1 is not None and self.fast_mode == "compact")))
 
     def step_fused(self, wam2nemo=None, flags: int = 0) -> None:
         """PROPAG_WAM + NEWWIND + IMPLSCH of one step (wamintgr.F90:94-146) with the advection done by the source-term kernel's tile load.

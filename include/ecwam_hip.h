@@ -307,12 +307,13 @@ int ecwam_hip_implsch_reserve(ecwam_hip_ctx *ctx, int npts);
  * of the fast waves (time step delpro_lf, read from gin) together with the slow waves' step (delpro, read from f1) -- what
  * ecwam_hip_propags2_otf_fast(f1 -> f3, gin) does -- and the source terms; with ecwam_hip_set_fastwave_copy the new fast waves also go to
  * the compact rows the next advection step starts from.  Else ifrelfmax = 0, gin = NULL.
- * Covered: what ecwam_hip_propags2_implsch_supported reports (36 directions x 36 frequencies in either precision, the common builds of
+ * Covered: what ecwam_hip_propags2_implsch_supported reports (48 / 36 / 24 / 12 directions x 36 frequencies in single, 36 x 36 in double precision, the common builds of
  * IMPLSCH with IPHYS = 1 / ISNONLIN = 0, no refraction; with or without the obstructions of ecwam_hip_set_obstructions); everything else runs
  * the two calls.
  * flags: 0 (bit 0: workgroups in the XCD-aware order of the stencil kernel instead of the natural one; bit 1: the go / no-go probe of
  * diagnostics builds).
  */
+/* 0: no one-kernel build covers the context; else a mask: bit 0 the plain step, bit 1 also with fast waves (gin), bit 2 also with obstructions */
 int ecwam_hip_propags2_implsch_supported(ecwam_hip_ctx *ctx);
 int ecwam_hip_propags2_implsch(ecwam_hip_ctx *ctx, const void *f1, void *f3, int n, int ngy, double delpro, const int *kxlt, const void *zdello,
                                double xdella, const void *cosph, const void *sinph, const int *klon, const int *klat, const int *kcor,

@@ -139,6 +139,39 @@ def test_one_kernel_step_with_sub_grid_obstructions_is_bit_identical(api, prec, 
         m.ctx.close()
 
 
+@pytest.mark.parametrize("prec", ["sp", "dp"])
+@pytest.mark.parametrize("nang,nfre_red,lfm,subgrid", [(24, 29, 0, False), (24, 29, 5, True), (12, 25, 0, False), (12, 25, 4, True), (48, 36, 0, False),
+                                                       (48, 36, 0, True)])
+def test_one_kernel_step_at_the_other_direction_counts(api, prec, nang, nfre_red, lfm, subgrid):
+    """The spectral grids of the reference's registered configurations (24 x 29 and 12 x 25 of NFRE = 36: tests/CMakeLists.txt:11-46,
+    etopo1_oper_an_fc_O320.yml:2-3) and 48 directions: 5 / 10 / 2 points per wavefront, other round and tail counts of the advecting load
+    (24 directions: 3 rounds + 24 left-over chunks per point = two tail steps; 12: 1 round + 44 = seven), with fast-wave sub-steps and
+    obstructions where a build holds them (48 directions: no fast-wave form).  Three steps, bit-identical to the two kernels."""
+    from ecwam_amd import grid as G, synthetic as syn
+
+    cfg = Config(nang=nang, nfre=36, nfre_red=nfre_red, idelt=450, idelpro=450)
+    g = G.build_grid(17, mask="continents")
+    kw = dict(ifrelfmax=lfm, delpro_lf=225.0) if lfm else {}
+    two, one = _pair(cfg, g, seed=29, prec=prec, **kw)
+    if prec == "dp":
+        # double precision has one-kernel builds at 36 directions only (implsch4a.hip: the others were miscompiled at -O3 and are not
+        # shipped): the model must say so and step(fused=True) must fall back to the two kernels -- still the same bits
+        assert not one.fused_available()
+    if subgrid:
+        obs = syn.obstructions(g, cfg.nfre, seed=5)
+        obs[:, :, nfre_red:] = 1.0
+        for m in (two, one):
+            m.set_obstructions(obs)
+    assert two.build_weights() == 0 and one.build_weights() == 0 and (prec == "dp" or one.fused_available())
+    for _i in range(3):
+        two.step()
+        one.step(fused=True)
+        torch.cuda.synchronize()
+        _same_state(two, one)
+    assert float(one.fl1[: one.n].abs().max()) > 0 and bool(torch.isfinite(one.fl1).all())
+    two.ctx.close(); one.ctx.close()
+
+
 def test_one_kernel_step_natural_order_and_row_blocks(api):
     """The workgroups in the XCD-aware order (flags bit 0) and the rows passed in three unequal blocks give the same bits as one call."""
     from ecwam_amd import grid as G

@@ -1,3 +1,8 @@
+"""Diagnostics (not a test): one step of the one-kernel path against the two kernels on a small grid with land, for a list of
+(directions, NFRE_RED, precision, IFRELFMAX, LSUBGRID) cases; prints how many bins / points differ and where (per direction, per frequency).
+What showed that the double precision one-kernel builds at 12 / 24 directions are miscompiled at -O3 (profiles/r06_fused_step_experiments.txt):
+with every direction count enabled in implsch4a.hip, run it on the product library and on ECWAM_HIP_LIB=<...>/libecwam_hip_advO1.so.
+python tools/dbg_fused.py"""
 import sys, numpy as np, torch
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 from ecwam_amd import grid as G

@@ -728,6 +728,21 @@ int ecwam_hip_propags2_refra(ecwam_hip_ctx* c, const void* f1, void* f3, int n, 
                              copy_rest ? 1 : 0, (hipStream_t)stream);
 }
 
+// The tables the one-kernel step takes its CTU scalars from (k_ctu_prep fills them every call): sized with the fin rows, so that a host that
+// called ecwam_hip_implsch_reserve has no allocation in its time loop on this path either.  Contexts without a one-kernel build hold none.
+static bool fused_ok(const ecwam_hip_ctx* c);
+static int adv_reserve(ecwam_hip_ctx* c, int npts) {
+  if (!fused_ok(c) || !implsch4_adv_forms(c->NANG, c->real_bytes)) return 0;
+  const size_t need = (size_t)(npts > 0 ? npts : 0) * 12 * c->real_bytes;
+  if (need > c->adv_pt_bytes) {   // hipFree waits for the kernels still reading the old table
+    if (c->adv_pt) HIPCHK(hipFree(c->adv_pt));
+    c->adv_pt = nullptr; c->adv_pt_bytes = 0;
+    HIPCHK(hipMalloc(&c->adv_pt, need));
+    c->adv_pt_bytes = need;
+  }
+  if (!c->adv_dir) HIPCHK(hipMalloc(&c->adv_dir, (size_t)(6 * c->NANG + 4) * c->real_bytes + (size_t)4 * c->NANG * sizeof(int)));
+  return 0;
+}
 // the configurations that run the RARE builds of k_implsch4 (ecwam_hip_implsch below makes the same choice)
 static bool runs_rare_builds(const ecwam_hip_ctx* c) {
   const int ext = (c->p.llnormagam || c->p.llgcbz0) ? 1 : 0;
@@ -776,7 +791,7 @@ int ecwam_hip_implsch(ecwam_hip_ctx* c, int kijs, int kijl, void* fl1, const voi
 }
 
 // the configurations the one-kernel step covers (implsch4a.hip); everything else runs ecwam_hip_propags2_otf + ecwam_hip_implsch
-static bool fused_ok(const ecwam_hip_ctx* c) {
+static bool fused_ok(const ecwam_hip_ctx* c) {      // (declared above adv_reserve)
   if (!c->implsch_why.empty()) return false;
   const bool rare4 = c->p.lciwa2 || c->p.lwnemocouwrs || c->p.lwnemocoustrn || c->p.isnonlin > 1 || c->p.icode != 3 || !c->p.lwvflx_snl;
   return !rare4 && c->p.iphys == 1 && c->p.isnonlin == 0 && c->NFRE == 36;      // (the direction count: one of k_implsch4's, checked at create)
@@ -810,16 +825,8 @@ int ecwam_hip_propags2_implsch(ecwam_hip_ctx* c, const void* f1, void* f3, int n
   HIPCHK(hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)stream;
   if (kijl == kijs) return 0;
-  if (int rc2 = implsch_reserve_on(c, kijl, s, false)) return rc2;
-  const size_t need = (size_t)kijl * 12 * c->real_bytes;
-  if (need > c->adv_pt_bytes) {
-    if (c->adv_pt) HIPCHK(hipFree(c->adv_pt));
-    c->adv_pt = nullptr; c->adv_pt_bytes = 0;
-    HIPCHK(hipMalloc(&c->adv_pt, need));
-    c->adv_pt_bytes = need;
-  }
+  if (int rc2 = implsch_reserve_on(c, kijl, s, false)) return rc2;      // (also the tables of the weights: adv_reserve)
   const size_t dir_reals = (size_t)(6 * c->NANG + 4);      // [NANG][4], CMTODEG (+ 3 pad), [NANG][2] for the fast waves' time step
-  if (!c->adv_dir) HIPCHK(hipMalloc(&c->adv_dir, dir_reals * c->real_bytes + (size_t)4 * c->NANG * sizeof(int)));
   int* dirI = reinterpret_cast<int*>(reinterpret_cast<char*>(c->adv_dir) + dir_reals * c->real_bytes);
   const double dlf = gin ? delpro_lf : 0.0;
   DISPATCH(launch_ctu_prep<float>(c->dtab, kijs, kijl, ngy, delpro, dlf, kxlt, zdello, xdella, cosph, sinph, wlat, wcor, cosphm1_ext, c->adv_pt, c->adv_dir, dirI, s),
@@ -880,7 +887,7 @@ static int implsch_reserve_on(ecwam_hip_ctx* c, int npts, hipStream_t s, bool sy
     HIPCHK(hipMalloc(&c->wi, need_wi));
     c->wi_bytes = need_wi;
   }
-  return 0;
+  return adv_reserve(c, npts);
 }
 
 int ecwam_hip_implsch_reserve(ecwam_hip_ctx* c, int npts) {

@@ -289,7 +289,8 @@ const void *ecwam_hip_device_tables(ecwam_hip_ctx *ctx);
  * 36 scalars per sea point through a context-owned device buffer indexed by the point number.  ecwam_hip_implsch grows that buffer when
  * kijl exceeds what it holds -- a device allocation and a device-wide wait inside an otherwise stream-ordered call.  A host that wants
  * none of that in its time loop (or captures the step into a hipGraph) sizes it once: npts = the largest kijl it will pass.  Calls on
- * several streams may share the buffer as long as their [kijs,kijl) do not overlap.
+ * several streams may share the buffer as long as their [kijs,kijl) do not overlap.  The same call sizes the tables of the one-kernel step
+ * (ecwam_hip_propags2_implsch: 12 reals per point) where the context has such a build.
  */
 int ecwam_hip_implsch_reserve(ecwam_hip_ctx *ctx, int npts);
 

@@ -237,7 +237,8 @@ def main() -> None:
     # O1280 grid side by side cost 54 s of numpy each on the node's CPU share before the first step)
     if world > 1:
         import tempfile
-        gpath = os.path.join(tempfile.gettempdir(), f"ecwam_amd_grid_O{ng}_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}.npz")
+        # (named by the rendezvous port: the ranks of one run share it whatever started them, two runs on a node cannot)
+        gpath = os.path.join(tempfile.gettempdir(), f"ecwam_amd_grid_O{ng}_w{world}_{os.environ.get('MASTER_PORT', '0')}.npz")
         if rank == 0:
             grid = G.build_grid(ng)
             G.save_grid(grid, gpath)
